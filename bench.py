@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Headline benchmark: ModeT volume-pairs/sec on synthetic 160x192x160 fp32 pairs (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|fwd]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one volume pair per rank:
+  train (default, BASELINE metric "fwd+bwd"): ModeT.forward + NCC + Grad3d('l2') + backward +
+        (RCCL all-reduce of the flat 4.12 MB gradient when N>1) + Adam-amsgrad step   [cfg 3 / cfg 4]
+  fwd : ModeT.forward incl. the final warp, no grad                                    [cfg 2]
+Inputs are resident in HBM before the timed region.  One JSON line on stdout (rank 0).
+
+roofline: the dominant kernel group (largest share of step time, found in an untimed profiled step) is
+timed live with HIP events on the launch stream during the K timed steps; achieved = its algorithmic
+FLOPs (or bytes) / its summed duration.  cpu_baseline: the CPU oracle (oracle/modet_torch.py, ATen-CPU,
+same op sequence as the reference's PyTorch-CPU path) on this host's cores, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(shape, workload, budget_s=40.0):
+    """oracle timed on the host cores on a bounded sample of the same workload"""
+    from oracle import modet_torch as orc
+    from smilecode_amd import synth
+    heads = (8, 4, 2, 1, 1)
+    cores = torch.get_num_threads()
+
+    def run(shp):
+        p = {n: torch.from_numpy(v).requires_grad_(workload == "train") for n, v in synth.make_weights(24).items()}
+        mov, fix = (torch.from_numpy(a) for a in synth.make_pair(shp, 24))
+        t0 = time.perf_counter()
+        if workload == "train":
+            loss = orc.train_loss(p, mov, fix, heads, 6, 1.0)[0]
+            torch.autograd.grad(loss, list(p.values()))
+        else:
+            with torch.no_grad():
+                orc.modet_forward(p, mov, fix, heads, 6, 1.0)
+        return time.perf_counter() - t0
+
+    half = tuple(s // 2 for s in shape)
+    run((32, 48, 32))                       # warm ATen / thread pool
+    t_half = run(half)
+    if 8.0 * t_half * 1.2 <= budget_s:
+        t_full = run(shape)
+        return {"value": 1.0 / t_full, "unit": "volume-pairs/sec", "cores": cores, "kind": "port",
+                "sample": "1 pair %dx%dx%d %s, oracle/modet_torch.py (ATen-CPU fp32), %.2f s" % (*shape, workload, t_full)}
+    return {"value": 1.0 / (8.0 * t_half), "unit": "volume-pairs/sec", "cores": cores, "kind": "port",
+            "sample": "1 pair %dx%dx%d %s (1/8 of the voxels, %.2f s) scaled x8, oracle/modet_torch.py (ATen-CPU fp32)"
+                      % (*half, workload, t_half)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["train", "fwd"], default="train")
+    ap.add_argument("--shape", default="160,192,160")
+    ap.add_argument("--batch", type=int, default=1, help="volume pairs per rank per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default="", help="write the per-op breakdown of one profiled step to this JSON file")
+    args = ap.parse_args()
+    shape = tuple(int(s) for s in args.shape.split(","))
+
+    from smilecode_amd import models, ops, synth
+    from smilecode_amd.engine import Trainer
+    from smilecode_amd.parallel import init_from_env
+
+    rank, local, world = init_from_env()
+    if world != args.gpus:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).to(dev)
+    models.load_numpy_weights(model, synth.make_weights(24))
+    trainer = Trainer(model)
+    mov, fix = synth.make_pair(shape, 24 + 2 * args.batch * rank, args.batch)      # per-rank pairs, weak scaling
+    mov, fix = torch.from_numpy(mov).to(dev), torch.from_numpy(fix).to(dev)
+
+    def step():
+        if args.workload == "train":
+            trainer.train_step(mov, fix, epoch=0)
+        else:
+            trainer.infer(mov, fix)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warmup (untimed); the last warmup step is profiled per op to find the dominant kernel group
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    torch.cuda.synchronize()
+    tm = ops.KernelTimer()
+    ops.set_kernel_timer(tm)
+    step()
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(None)
+    breakdown = tm.summary()
+    dominant = max(breakdown, key=lambda k: breakdown[k]["ms"]) if breakdown else None
+    if rank == 0:
+        tot = sum(v["ms"] for v in breakdown.values())
+        log(f"[bench] per-op breakdown of one {args.workload} step (HIP events, sum {tot:.3f} ms):")
+        for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]):
+            log(f"   {k:26s} calls {v['calls']:3d}  {v['ms']:8.3f} ms  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:9.2f} TFLOP/s"
+                f"  {v['bytes'] / v['ms'] / 1e6 if v['ms'] else 0:9.1f} GB/s(alg)")
+        if args.breakdown:
+            with open(args.breakdown, "w") as f:
+                json.dump(breakdown, f, indent=1, sort_keys=True)
+
+    # timed region: exactly K steps, only the dominant group carries events
+    tsel = ops.KernelTimer(select={dominant} if dominant else set())
+    barrier()
+    ops.set_kernel_timer(tsel)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        pairs = args.steps * args.batch * world
+        roof = None
+        if dominant:
+            d = tsel.summary()[dominant]
+            sec = d["ms"] * 1e-3
+            if dominant.startswith("conv"):
+                ach = d["flops"] / sec / 1e12
+                roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None}
+            else:
+                ach = d["bytes"] / sec / 1e9
+                roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": ach / PEAK_HBM_GBS, "traffic": None}
+            roof.update({"kernel": dominant, "launches": d["calls"], "avg_launch_ms": d["ms"] / d["calls"],
+                         "share_of_step": d["ms"] / (dt * 1e3)})
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc runs
+            if os.path.exists(pmc):
+                try:
+                    roof["traffic"] = json.load(open(pmc)).get(dominant)
+                except Exception:
+                    pass
+        out = {
+            "metric": "volume-pairs/sec (160x192x160) fwd+bwd" if args.workload == "train" else "volume-pairs/sec (160x192x160) fwd+warp",
+            "value": pairs / dt, "unit": "volume-pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("ModeT LPBA %dx%dx%d fp32, batch=%d/GPU, %s" % (
+                *shape, args.batch, "full train step NCC+Grad3d fwd+bwd+Adam-amsgrad" + (" + RCCL grad all-reduce" if world > 1 else "")
+                if args.workload == "train" else "forward+warp")),
+                "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(shape, args.workload)
+            except Exception as e:                                     # the GPU number must still be reported
+                out["cpu_baseline"] = {"value": None, "unit": "volume-pairs/sec", "cores": torch.get_num_threads(),
+                                       "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/* libmodet_hip.so -- C ABI of the MI355X-native ModeT hot path (gfx950, hand-written HIP).
+ *
+ * Drop-in boundary for ZAX130/SmileCode's ModeT operator layer.  The reference binds ONE
+ * native module, `modet` (ModeT-cu/modet/modet.cpp:34-37: modet_fw / modet_bw), from Python
+ * (ModeT-cu/functional.py:3,10,18) and gets every other op of ModeT.forward
+ * (ModeT/models.py:377-412) from ATen.  This library exports that operator (modet_qk_*) with
+ * the reference's exact tensor contract, plus the fused/native forms of every other op on
+ * the path; `smilecode_amd/` binds it with ctypes (INTEGRATION.md shows the reference-side stub).
+ *
+ * Conventions
+ *  - plain C, no torch types: raw DEVICE pointers, sizes, an explicit hipStream_t (as void*).
+ *  - fp32 everywhere.  Activations are channels-last "(B,D,H,W,C)" unless a comment says
+ *    otherwise; (D,H,W) are the reference's (H,W,T) = the three spatial axes in memory order.
+ *  - caller allocates every output and workspace; the library never allocates, frees or retains
+ *    device memory, keeps no global/thread-local mutable state, and is re-entrant (the autograd
+ *    engine calls the backward entry points from another thread).
+ *  - all launches are asynchronous on `stream`; nothing synchronises.
+ *  - return value: 0 = ok, <0 = argument error (enum below), >0 = hipError_t from the launch.
+ *  - `ws`/`ws_bytes`: scratch from the matching *_ws_bytes(); contents undefined afterwards.
+ *  - 64-bit safe offsets throughout (the reference's PackedTensorAccessor32 limit,
+ *    modet_kernel.cu:19-22, does not apply).
+ */
+#ifndef MODET_HIP_H
+#define MODET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* modet_stream_t; /* hipStream_t */
+
+enum {
+  MODET_OK = 0,
+  MODET_ERR_NULL = -1,        /* required pointer is NULL (reference: CHECK_CUDA, utils.h:7)          */
+  MODET_ERR_DIM = -2,         /* non-positive / inconsistent dims (reference: CHECK_3DFEATMAP, utils.h:10) */
+  MODET_ERR_UNSUPPORTED = -3, /* configuration not built (reference: CHECK_KERNELSIZE, utils.h:11-14)  */
+  MODET_ERR_WORKSPACE = -4    /* ws_bytes smaller than *_ws_bytes() says                               */
+};
+
+int modet_hip_version(void);
+const char* modet_hip_strerror(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Neighbourhood attention, reference operator contract  (replaces modet_fw / modet_bw,
+ * ModeT-cu/modet/modet.cpp:4-31 -> modet_kernel.cu:17-381).
+ *   q    (B,heads,D,H,W,hd)        already multiplied by scale (ModeT-cu/models.py:304)
+ *   kpad (B,heads,D+2,H+2,W+2,hd)  zero padded by the caller (models.py:309-310)
+ *   rpb  (heads,3,3,3) or NULL (= zeros, modet.cpp:13)
+ *   attn (B,heads,D,H,W,27)        token t = 9*ki+3*kj+kk (modet_kernel.cu:44-52,:80)
+ * Backward: d_q like q, d_kpad like kpad (pad ring included, as the reference returns it),
+ * d_rpb (heads,27) or NULL when the bias is disabled (modet_kernel.cu:343-345).
+ * d_rpb is reduced in two deterministic stages (the reference uses fastAtomicAdd, :315). */
+int modet_qk_fwd(const float* q, const float* kpad, const float* rpb, float* attn,
+                 int B, int heads, int D, int H, int W, int hd, modet_stream_t stream);
+size_t modet_qk_bwd_ws_bytes(int B, int heads, int D, int H, int W);
+int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad,
+                 float* d_q, float* d_kpad, float* d_rpb, void* ws, size_t ws_bytes,
+                 int B, int heads, int D, int H, int W, int hd, modet_stream_t stream);
+
+/* Fused ModeTransformer.forward (ModeT/models.py:308-334 == ModeT-cu/models.py:300-316):
+ *   logits = scale*q.k(n+off) + rpb, softmax over the 27 modes, out = sum_t p[t]*off(t).
+ *   q,k (B,D,H,W,heads*hd) channels-last, unpadded, unscaled; rpb (heads,27);
+ *   out (B,D,H,W,heads*3), channel = head*3+axis (models.py:332).  hd must be 6 (train.py:49).
+ * Never materialises the (..,27) attention tensor.  Backward recomputes the softmax. */
+int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out,
+                 int B, int D, int H, int W, int heads, int hd, float scale, modet_stream_t stream);
+size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads);
+int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* d_out,
+                 float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes,
+                 int B, int D, int H, int W, int heads, int hd, float scale, modet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3x3x3 convolution, stride 1, zero pad 1 (nn.Conv3d call sites ModeT/models.py:127,:144,:254)
+ * as an fp32 MFMA implicit GEMM.  x (B,D,H,W,Cin), y (B,D,H,W,Cout) channels-last;
+ * w in the reference's parameter layout (Cout,Cin,3,3,3); bias (Cout) or NULL.
+ * act: 0 = none, 1 = LeakyReLU(0.1) fused (ConvBlock, models.py:119-133). */
+size_t modet_conv3d_ws_bytes(int Cin, int Cout);
+int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                     int B, int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream);
+/* d_x = conv(d_y, flipped/transposed w) */
+int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes,
+                          int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+/* d_w (Cout,Cin,3,3,3), d_bias (Cout) or NULL; deterministic two-stage reduction */
+size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes,
+                            int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+
+/* InstanceNorm3d(affine=False, eps, biased variance) + LeakyReLU(0.1) (ConvInsBlock, models.py:135-151).
+ * x,y (B,V,C) channels-last with V = D*H*W; mean,rstd (B*C) are outputs of fwd / inputs of bwd. */
+size_t modet_instnorm_ws_bytes(int B, int64_t V, int C);
+int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes,
+                             int B, int64_t V, int C, float eps, modet_stream_t stream);
+int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
+                             void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream);
+/* d_x = d_y * (y > 0 ? 1 : 0.1): backward of the LeakyReLU fused into modet_conv3d_fwd(act=1) */
+int modet_lrelu_bwd(const float* d_y, const float* y, float* d_x, int64_t n, modet_stream_t stream);
+/* AvgPool3d(2) (models.py:201,:207,:213,:219); D,H,W are the INPUT dims (even). */
+int modet_avgpool2_fwd(const float* x, float* y, int B, int D, int H, int W, int C, modet_stream_t stream);
+int modet_avgpool2_bwd(const float* d_y, float* d_x, int B, int D, int H, int W, int C, modet_stream_t stream);
+
+/* ProjectionLayer: Linear(Cin->dim) + LayerNorm(dim, eps) (models.py:230-241).
+ * x (N,Cin) channels-last voxels, Wt = proj.weight (dim,Cin), y (N,dim). */
+int modet_proj_ln_fwd(const float* x, const float* Wt, const float* bias, const float* gamma, const float* beta,
+                      float* y, int64_t N, int Cin, int dim, float eps, modet_stream_t stream);
+size_t modet_proj_ln_bwd_ws_bytes(int64_t N, int Cin, int dim);
+int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const float* gamma, const float* d_y,
+                      float* d_x, float* d_Wt, float* d_bias, float* d_gamma, float* d_beta,
+                      void* ws, size_t ws_bytes, int64_t N, int Cin, int dim, float eps, modet_stream_t stream);
+
+/* SpatialTransformer (models.py:25-67; utils.py:30-83 for mode 1):
+ *   out[b,p,c] = sample(src[b,:,c], p + flow[b,p,:]), zero padding, voxel coordinates
+ *   (the reference's normalise -> grid_sample(align_corners=True) round trip is the identity).
+ * src,out (B,D,H,W,C); flow (B,D,H,W,3) channels-last, component a = displacement along axis a.
+ * mode 0 = trilinear, 1 = nearest (round half to even, as ATen's nearbyint).
+ * add_flow=1 (needs C==3): out = warp(src,flow) + flow, the composition of models.py:392,:398,:403,:408. */
+int modet_warp_fwd(const float* src, const float* flow, float* out, int B, int D, int H, int W, int C,
+                   int mode, int add_flow, modet_stream_t stream);
+/* d_src (zeroed here, then scatter-added) and/or d_flow; either may be NULL.  Trilinear only. */
+int modet_warp_bwd(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow,
+                   int B, int D, int H, int W, int C, int add_flow, modet_stream_t stream);
+
+/* nn.Upsample(2,'trilinear',align_corners=True) of scale*x (models.py:354,:257-261); d,h,w = INPUT dims.
+ * x (B,d,h,w,C) -> y (B,2d,2h,2w,C).  Backward is the exact transpose in gather form (no atomics). */
+int modet_upsample2_fwd(const float* x, float* y, int B, int d, int h, int w, int C, float scale, modet_stream_t stream);
+int modet_upsample2_bwd(const float* d_y, float* d_x, int B, int d, int h, int w, int C, float scale, modet_stream_t stream);
+
+/* layout changes at the module boundary: (B,C,V) <-> (B,V,C) */
+int modet_ncdhw_to_cl(const float* x, float* y, int B, int C, int64_t V, modet_stream_t stream);
+int modet_cl_to_ncdhw(const float* x, float* y, int B, int C, int64_t V, modet_stream_t stream);
+
+/* CWM tail (models.py:263-275): out[n,a] = 2 * sum_h softmax_h(logits[n,:])[h] * x[n,3h+a].
+ * x (N,heads*3) = upsampled sub-flows, logits (N,heads) = output of the last CWM conv, out (N,3). */
+int modet_cwm_tail_fwd(const float* x, const float* logits, float* out, int64_t N, int heads, modet_stream_t stream);
+int modet_cwm_tail_bwd(const float* x, const float* logits, const float* d_out, float* d_x, float* d_logits,
+                       int64_t N, int heads, modet_stream_t stream);
+
+/* NCC_vxm(win=9) (losses.py:34-94): loss[0] = -mean(cc); d_J (same shape as J) = d loss / d J or NULL.
+ * I = y_true, J = y_pred, (B,D,H,W) single channel.  Separable zero-padded box sums. */
+size_t modet_ncc_ws_bytes(int B, int D, int H, int W);
+int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes,
+                      int B, int D, int H, int W, modet_stream_t stream);
+/* Grad3d('l2') (losses.py:6-31) on a planar flow (B,3,D,H,W): loss[0], d_flow (NULL to skip). */
+size_t modet_grad3d_ws_bytes(int B, int D, int H, int W);
+int modet_grad3d_fwd_bwd(const float* flow, float* loss, float* d_flow, void* ws, size_t ws_bytes,
+                         int B, int D, int H, int W, modet_stream_t stream);
+/* y = x * s[0] with s a DEVICE scalar (chains an upstream scalar gradient without a host sync) */
+int modet_scale_by_dev_scalar(const float* x, const float* s, float* y, int64_t n, modet_stream_t stream);
+
+/* torch.optim.Adam(amsgrad=True, weight_decay=0) over one flat buffer (train.py:101,:131-133).
+ * g is multiplied by grad_scale first (1/world_size after the all-reduce).  step counts from 1. */
+int modet_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n,
+                            float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                            modet_stream_t stream);
+
+/* Evaluation tail (utils.py:74-106, infer.py:86-92): nearest-neighbour warp of the moving label map by
+ * `flow` (B=1,(D,H,W,3) channels-last) and the per-label voxel counts Dice needs.
+ * counts (3*(nlabels+1) int64, zeroed here): [0]=n(pred==l), [1]=n(true==l), [2]=n(both==l).
+ * warped (D*H*W int16) may be NULL. */
+int modet_label_warp_counts(const int16_t* lab_moving, const float* flow, const int16_t* lab_fixed,
+                            int16_t* warped, int64_t* counts, int D, int H, int W, int nlabels,
+                            modet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODET_HIP_H */

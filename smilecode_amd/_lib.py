@@ -1,0 +1,94 @@
+"""ctypes binding of libmodet_hip.so (the C ABI declared in include/modet_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails this module
+raises.  ``load()`` is cheap after the first call.  ctypes drops the GIL for the duration
+of each call (CDLL), the library itself is stateless/re-entrant.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmodet_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "modet_hip.h")
+
+P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/modet_hip.h one to one
+SIGNATURES = {
+    "modet_hip_version": (I, []),
+    "modet_hip_strerror": (C.c_char_p, [I]),
+    "modet_qk_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "modet_qk_bwd_ws_bytes": (SZ, [I, I, I, I, I]),
+    "modet_qk_bwd": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
+    "modet_na_fwd": (I, [P, P, P, P, I, I, I, I, I, I, F, P]),
+    "modet_na_bwd_ws_bytes": (SZ, [I, I, I, I, I]),
+    "modet_na_bwd": (I, [P, P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, F, P]),
+    "modet_conv3d_ws_bytes": (SZ, [I, I]),
+    "modet_conv3d_fwd": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P]),
+    "modet_conv3d_bwd_data": (I, [P, P, P, P, SZ, I, I, I, I, I, I, P]),
+    "modet_conv3d_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I, I]),
+    "modet_conv3d_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
+    "modet_instnorm_ws_bytes": (SZ, [I, I64, I]),
+    "modet_instnorm_lrelu_fwd": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
+    "modet_instnorm_lrelu_bwd": (I, [P, P, P, P, P, P, SZ, I, I64, I, P]),
+    "modet_lrelu_bwd": (I, [P, P, P, I64, P]),
+    "modet_avgpool2_fwd": (I, [P, P, I, I, I, I, I, P]),
+    "modet_avgpool2_bwd": (I, [P, P, I, I, I, I, I, P]),
+    "modet_proj_ln_fwd": (I, [P, P, P, P, P, P, I64, I, I, F, P]),
+    "modet_proj_ln_bwd_ws_bytes": (SZ, [I64, I, I]),
+    "modet_proj_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
+    "modet_warp_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
+    "modet_warp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "modet_upsample2_fwd": (I, [P, P, I, I, I, I, I, F, P]),
+    "modet_upsample2_bwd": (I, [P, P, I, I, I, I, I, F, P]),
+    "modet_ncdhw_to_cl": (I, [P, P, I, I, I64, P]),
+    "modet_cl_to_ncdhw": (I, [P, P, I, I, I64, P]),
+    "modet_cwm_tail_fwd": (I, [P, P, P, I64, I, P]),
+    "modet_cwm_tail_bwd": (I, [P, P, P, P, P, I64, I, P]),
+    "modet_ncc_ws_bytes": (SZ, [I, I, I, I]),
+    "modet_ncc_fwd_bwd": (I, [P, P, P, P, P, SZ, I, I, I, I, P]),
+    "modet_grad3d_ws_bytes": (SZ, [I, I, I, I]),
+    "modet_grad3d_fwd_bwd": (I, [P, P, P, P, SZ, I, I, I, I, P]),
+    "modet_scale_by_dev_scalar": (I, [P, P, P, I64, P]),
+    "modet_adam_amsgrad_step": (I, [P, P, P, P, P, I64, F, F, F, F, I, F, P]),
+    "modet_label_warp_counts": (I, [P, P, P, P, P, I, I, I, I, P]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Every function name include/modet_hip.h declares (used by the export test)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(modet_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load():
+    """dlopen the library and attach signatures; raises if it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m smilecode_amd.build` "
+            "(the ModeT hot path has no CPU / eager fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def strerror(code: int) -> str:
+    return load().modet_hip_strerror(int(code)).decode()
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed: [{code}] {strerror(code)}")

@@ -1,0 +1,21 @@
+// version / error strings of libmodet_hip.so
+#include "common.h"
+
+extern "C" {
+
+int modet_hip_version(void) { return 100; /* 0.1.0 */ }
+
+const char* modet_hip_strerror(int code) {
+  switch (code) {
+    case MODET_OK: return "ok";
+    case MODET_ERR_NULL: return "required pointer is NULL";
+    case MODET_ERR_DIM: return "invalid or inconsistent dimensions";
+    case MODET_ERR_UNSUPPORTED: return "configuration not supported by this build";
+    case MODET_ERR_WORKSPACE: return "workspace too small (see *_ws_bytes)";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "unknown modet_hip error";
+}
+
+}  // extern "C"

@@ -1,0 +1,411 @@
+// 3x3x3 / stride 1 / zero-pad 1 convolution as an fp32 MFMA implicit GEMM on gfx950 (exact f32:
+// v_mfma_f32_16x16x4_f32 is bitwise an fmaf chain), channels-last activations.
+//   reference call sites: nn.Conv3d in ConvBlock / ConvInsBlock / CWM, ModeT/models.py:127,:144,:254
+//   (arithmetic itself lives in ATen/MIOpen there).
+//
+// forward / dgrad:  D[voxel(16 along W)][cout(16)] += A[voxel][cin(4)] * B[cin(4)][cout]   per tap
+//   A from an LDS input tile [cin][halo'd voxels] (channel stride = 16 mod 32 dwords -> conflict-free ds_read_b32
+//   across the k-groups), B from an LDS weight tile [tap][cin][cout]; a wave owns R rows x NT cout tiles and
+//   re-uses each B fragment R times.  dgrad is the same kernel on flipped + transposed weights.
+// wgrad:  D[cin(16)][cout(16)] += A[cin][voxel(4)] * B[voxel(4)][cout]   per tap, K runs over the voxels;
+//   Cin<=8 packs two taps into the 16 M rows.  Workgroups walk tiles persistently, partial d_w goes to a
+//   workspace and is summed in fixed order in fp64 (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NTHR = 256;
+constexpr int TX = 16, HX = TX + 2;
+
+__host__ __device__ constexpr int pad16mod32(int n) { return ((n - 16 + 31) / 32) * 32 + 16; }
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// mode 0 (forward): wpk[tap][c][n] = w[n][c][tap]           w: (Cout=n, Cin=c, 27)
+// mode 1 (dgrad)  : wpk[tap][c][n] = w[c][n][26 - tap]      w: (Co=c, Ci=n, 27) -> conv over d_y channels c
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int CinP,
+                                    int CoutP, int mode) {
+  const int total = 27 * CinP * CoutP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i % CoutP, t = i / CoutP;
+    const int c = t % CinP, tap = t / CinP;
+    float v = 0.f;
+    if (c < Cin && n < Cout) v = mode == 0 ? w[((int64_t)n * Cin + c) * 27 + tap] : w[((int64_t)c * Cout + n) * 27 + 26 - tap];
+    wpk[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+template <int TZ, int TY, int WM, int WN, int NT, int CK>
+__global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int D,
+                                                           int H, int W, int Cin, int Cout, int CinP, int CoutP, int act,
+                                                           int tiles_x, int tiles_y, int tiles_z) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int ROWS = TZ * TY, R = ROWS / WM, NCB = WN * NT * 16;
+  constexpr int HZ = TZ + 2, HY = TY + 2, HVOX = HZ * HY * HX;
+  constexpr int CS = pad16mod32(HVOX);
+  constexpr int NCBS = (NCB % 32 == 16) ? NCB : NCB + 16;
+  __shared__ __attribute__((aligned(16))) float xs[CK * CS];
+  __shared__ __attribute__((aligned(16))) float wsm[27 * CK * NCBS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 15, lk = lane >> 4;
+  int t = blockIdx.x;
+  const int x0 = (t % tiles_x) * TX; t /= tiles_x;
+  const int y0 = (t % tiles_y) * TY; t /= tiles_y;
+  const int z0 = (t % tiles_z) * TZ;
+  const int b = t / tiles_z;
+  const int cb0 = blockIdx.y * NCB;
+  const int64_t xbase = (int64_t)b * D * H * W;
+  const bool vec4 = (Cin & 3) == 0;
+
+  f32x4 acc[R][NT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int rowbase[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int rr = wm * R + r;
+    rowbase[r] = ((rr / TY) * HY + (rr % TY)) * HX + li + lk * CS;
+  }
+
+  for (int c0 = 0; c0 < CinP; c0 += CK) {
+    __syncthreads();
+    if (vec4) {
+      constexpr int Q = CK / 4;
+      for (int idx = tid; idx < HVOX * Q; idx += NTHR) {
+        const int hv = idx / Q, c4 = idx - hv * Q;
+        const int hx = hv % HX, t2 = hv / HX;
+        const int hy = t2 % HY, hz = t2 / HY;
+        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+        const int c = c0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
+          v = *reinterpret_cast<const float4*>(x + (xbase + ((int64_t)z * H + yy) * W + xx) * Cin + c);
+        xs[(c4 * 4 + 0) * CS + hv] = v.x;
+        xs[(c4 * 4 + 1) * CS + hv] = v.y;
+        xs[(c4 * 4 + 2) * CS + hv] = v.z;
+        xs[(c4 * 4 + 3) * CS + hv] = v.w;
+      }
+    } else {
+      for (int idx = tid; idx < HVOX * CK; idx += NTHR) {
+        const int hv = idx / CK, cc = idx - hv * CK;
+        const int hx = hv % HX, t2 = hv / HX;
+        const int hy = t2 % HY, hz = t2 / HY;
+        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+        const int c = c0 + cc;
+        float v = 0.f;
+        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
+          v = x[(xbase + ((int64_t)z * H + yy) * W + xx) * Cin + c];
+        xs[cc * CS + hv] = v;
+      }
+    }
+    {
+      constexpr int Q = NCB / 4;
+      for (int idx = tid; idx < 27 * CK * Q; idx += NTHR) {
+        const int n4 = idx % Q, row = idx / Q;
+        const int tap = row / CK, cc = row - tap * CK;
+        const float4 v = *reinterpret_cast<const float4*>(wpk + ((int64_t)(tap * CinP + c0 + cc)) * CoutP + cb0 + n4 * 4);
+        *reinterpret_cast<float4*>(wsm + row * NCBS + n4 * 4) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int tap = (dz * 3 + dy) * 3 + dx;
+          const int toff = (dz * HY + dy) * HX + dx;
+#pragma unroll
+          for (int kg = 0; kg < CK / 4; ++kg) {
+            float bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = wsm[(tap * CK + kg * 4 + lk) * NCBS + (wn * NT + n) * 16 + li];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const float a = xs[rowbase[r] + toff + kg * 4 * CS];
+#pragma unroll
+              for (int n = 0; n < NT; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[n], acc[r][n], 0, 0, 0);
+            }
+          }
+        }
+  }
+
+  // epilogue: lane holds cout = li, voxels x = lk*4 + j
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int rr = wm * R + r;
+    const int z = z0 + rr / TY, yy = y0 + rr % TY;
+    if (z >= D || yy >= H) continue;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = cb0 + (wn * NT + n) * 16 + li;
+      if (co >= Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xx = x0 + lk * 4 + j;
+        if (xx < W) {
+          float v = acc[r][n][j] + bv;
+          if (act) v = lrelu(v);
+          y[(xbase + ((int64_t)z * H + yy) * W + xx) * Cout + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+constexpr int WG_TZ = 2, WG_TY = 8, WG_ROWS = WG_TZ * WG_TY;
+constexpr int WG_HY = WG_TY + 2, WG_HVOX = (WG_TZ + 2) * WG_HY * HX;
+
+template <int CIT>   // 16: one tap per MFMA; 8: two taps per MFMA (rows 0-7 tap 2g, rows 8-15 tap 2g+1)
+__global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ part, int D, int H, int W, int Cin,
+                                                            int Cout, int tiles_x, int tiles_y, int tiles_z,
+                                                            int ntiles, int n_ci_tiles) {
+  constexpr int TP = 16 / CIT, NG = (27 + TP - 1) / TP, GPW = (NG + 3) / 4;
+  __shared__ __attribute__((aligned(16))) float xs[WG_HVOX * CIT];
+  __shared__ __attribute__((aligned(16))) float dys[WG_ROWS * TX * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ci_tile = blockIdx.y % n_ci_tiles, co_tile = blockIdx.y / n_ci_tiles;
+  const int ci0 = ci_tile * CIT, co0 = co_tile * 16;
+
+  f32x4 acc[GPW];
+  int aoff[GPW];
+  bool aval[GPW];
+#pragma unroll
+  for (int g = 0; g < GPW; ++g) {
+    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int grp = wave * GPW + g;
+    const int tap = grp * TP + (TP == 2 ? (li >> 3) : 0);
+    aval[g] = (grp < NG) && (tap < 27);
+    const int tt = tap < 27 ? tap : 0;
+    const int dz = tt / 9, dyy = (tt / 3) % 3, dx = tt % 3;
+    aoff[g] = ((dz * WG_HY + dyy) * HX + dx + lk) * CIT + (li % CIT);
+  }
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int x0 = (t % tiles_x) * TX; t /= tiles_x;
+    const int y0 = (t % tiles_y) * WG_TY; t /= tiles_y;
+    const int z0 = (t % tiles_z) * WG_TZ;
+    const int b = t / tiles_z;
+    const int64_t vb = (int64_t)b * D * H * W;
+    __syncthreads();
+    for (int idx = tid; idx < WG_HVOX * CIT; idx += NTHR) {
+      const int hv = idx / CIT, cc = idx - hv * CIT;
+      const int hx = hv % HX, t2 = hv / HX;
+      const int hy = t2 % WG_HY, hz = t2 / WG_HY;
+      const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+      const int c = ci0 + cc;
+      float v = 0.f;
+      if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
+        v = x[(vb + ((int64_t)z * H + yy) * W + xx) * Cin + c];
+      xs[idx] = v;
+    }
+    for (int idx = tid; idx < WG_ROWS * TX * 16; idx += NTHR) {
+      const int vox = idx >> 4, cc = idx & 15;
+      const int row = vox / TX, xx = x0 + vox % TX;
+      const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY;
+      const int co = co0 + cc;
+      float v = 0.f;
+      if (z < D && yy < H && xx < W && co < Cout) v = dy[(vb + ((int64_t)z * H + yy) * W + xx) * Cout + co];
+      dys[idx] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int row = 0; row < WG_ROWS; ++row) {
+      const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float bf = dys[(row * TX + s * 4 + lk) * 16 + li];
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+          float a = xs[rb + s * 4 * CIT + aoff[g]];
+          if (!aval[g]) a = 0.f;
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf, acc[g], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial[(bx*gridDim.y + by)*NG + grp][i = M row][col = cout]
+#pragma unroll
+  for (int g = 0; g < GPW; ++g) {
+    const int grp = wave * GPW + g;
+    if (grp >= NG) continue;
+    float* p = part + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NG + grp) * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[(lk * 4 + j) * 16 + li] = acc[g][j];
+  }
+}
+
+// d_w[co][ci][tap] = sum over workgroups bx, fp64, fixed order
+__global__ void wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cin, int Cout,
+                                      int gx, int gy, int n_ci_tiles, int cit) {
+  const int total = Cout * Cin * 27;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int tap = i % 27, ci = (i / 27) % Cin, co = i / (27 * Cin);
+  const int tp = 16 / cit, ng = (27 + tp - 1) / tp;
+  const int grp = tap / tp, mrow = (tap % tp) * cit + (ci % cit);
+  const int by = (co / 16) * n_ci_tiles + ci / cit;
+  double s = 0.0;
+  for (int bx = 0; bx < gx; ++bx) s += (double)part[(((int64_t)bx * gy + by) * ng + grp) * 256 + mrow * 16 + (co % 16)];
+  dw[i] = (float)s;
+}
+
+// d_bias[c] = sum_n dy[n][c]: per-workgroup partials over a chunk of voxels, then fixed-order fp64
+constexpr int DB_CHUNK = 4096;
+__global__ __launch_bounds__(NTHR) void dbias_partial_kernel(const float* __restrict__ dy, float* __restrict__ part,
+                                                             int64_t N, int C) {
+  __shared__ float red[NTHR];
+  const int VPB = NTHR / C;
+  const int c = threadIdx.x % C, vl = threadIdx.x / C;
+  float s = 0.f;
+  const int64_t n0 = (int64_t)blockIdx.x * DB_CHUNK;
+  const int64_t n1 = n0 + DB_CHUNK < N ? n0 + DB_CHUNK : N;
+  if (vl < VPB)
+    for (int64_t n = n0 + vl; n < n1; n += VPB) s += dy[n * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float r = 0.f;
+    for (int j = 0; j < VPB; ++j) r += red[j * C + threadIdx.x];
+    part[(int64_t)blockIdx.x * C + threadIdx.x] = r;
+  }
+}
+__global__ void dbias_finalize_kernel(const float* __restrict__ part, float* __restrict__ db, int nchunk, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < nchunk; ++i) s += (double)part[(int64_t)i * C + c];
+  db[c] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct FwdPlan {
+  int cfg;       // 0:A 1:B 2:C 3:D
+  int ncb, ck, tz, ty;
+};
+inline FwdPlan plan_fwd(int64_t BV, int Cout) {
+  if (Cout <= 16) return {0, 16, 8, 4, 8};
+  if (Cout <= 32 && BV >= 200000) return {1, 32, 4, 4, 8};
+  if (Cout <= 64) return {2, 64, 4, 2, 4};
+  return {3, 64, 4, 1, 4};
+}
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+inline size_t fwd_ws_elems(int Cin, int Cout) {
+  // generous: any plan pads Cin to <= 8 and Cout to <= 64 granules
+  return (size_t)27 * round_up(Cin, 8) * round_up(Cout, 64);
+}
+
+int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
+                int Cin, int Cout, int act, int pack_mode, hipStream_t s) {
+  const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cout);
+  const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
+  const int total = 27 * CinP * CoutP;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
+                     wpk, Cin, Cout, CinP, CoutP, pack_mode);
+  const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
+  dim3 grid((unsigned)((int64_t)tiles_x * tiles_y * tiles_z * B), CoutP / p.ncb);
+#define CONV_LAUNCH(...) hipLaunchKernelGGL((conv3d_mfma_kernel<__VA_ARGS__>), grid, dim3(NTHR), 0, s, x, (const float*)wpk, \
+                                            bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z)
+  switch (p.cfg) {
+    case 0: CONV_LAUNCH(4, 8, 4, 1, 1, 8); break;
+    case 1: CONV_LAUNCH(4, 8, 4, 1, 2, 4); break;
+    case 2: CONV_LAUNCH(2, 4, 2, 2, 2, 4); break;
+    default: CONV_LAUNCH(1, 4, 1, 4, 1, 4); break;
+  }
+#undef CONV_LAUNCH
+  return modet_launch_status();
+}
+
+struct WgPlan { int cit, n_ci, n_co, gx, gy, ng, ntiles, tiles_x, tiles_y, tiles_z; };
+inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
+  WgPlan p;
+  p.cit = Cin <= 8 ? 8 : 16;
+  p.n_ci = cdiv(Cin, p.cit);
+  p.n_co = cdiv(Cout, 16);
+  p.gy = p.n_ci * p.n_co;
+  p.tiles_x = cdiv(W, TX); p.tiles_y = cdiv(H, WG_TY); p.tiles_z = cdiv(D, WG_TZ);
+  p.ntiles = B * p.tiles_x * p.tiles_y * p.tiles_z;
+  int gx = 1024 / p.gy;
+  if (gx < 1) gx = 1;
+  if (gx > p.ntiles) gx = p.ntiles;
+  p.gx = gx;
+  p.ng = p.cit == 8 ? 14 : 27;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t modet_conv3d_ws_bytes(int Cin, int Cout) {
+  const int m = Cin > Cout ? Cin : Cout;       // bwd_data swaps the roles
+  return fwd_ws_elems(m, m) * sizeof(float);
+}
+
+int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
+                     int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
+  return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
+}
+
+int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,
+                          int W, int Cin, int Cout, modet_stream_t stream) {
+  MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(w); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  if (ws_bytes < fwd_ws_elems(Cout, Cin) * sizeof(float)) return MODET_ERR_WORKSPACE;
+  // a convolution of d_y (Cout channels) producing Cin channels
+  return conv_launch(d_y, w, nullptr, d_x, (float*)ws, B, D, H, W, Cout, Cin, 0, 1, (hipStream_t)stream);
+}
+
+size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
+  const int64_t N = (int64_t)B * D * H * W;
+  return ((size_t)p.gx * p.gy * p.ng * 256 + (size_t)cdiv64(N, DB_CHUNK) * Cout) * sizeof(float);
+}
+
+int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes,
+                            int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  if (Cout > NTHR) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_conv3d_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
+  float* part = (float*)ws;
+  dim3 grid(p.gx, p.gy);
+  if (p.cit == 8)
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<8>, grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, p.tiles_x,
+                       p.tiles_y, p.tiles_z, p.ntiles, p.n_ci);
+  else
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<16>, grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, p.tiles_x,
+                       p.tiles_y, p.tiles_z, p.ntiles, p.n_ci);
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(cdiv(Cout * Cin * 27, 256)), dim3(256), 0, s, (const float*)part, d_w,
+                     Cin, Cout, p.gx, p.gy, p.n_ci, p.cit);
+  if (d_bias) {
+    const int64_t N = (int64_t)B * D * H * W;
+    const int nchunk = (int)cdiv64(N, DB_CHUNK);
+    float* bpart = part + (size_t)p.gx * p.gy * p.ng * 256;
+    hipLaunchKernelGGL(dbias_partial_kernel, dim3(nchunk), dim3(NTHR), 0, s, d_y, bpart, N, Cout);
+    hipLaunchKernelGGL(dbias_finalize_kernel, dim3(cdiv(Cout, 64)), dim3(64), 0, s, (const float*)bpart, d_bias, nchunk,
+                       Cout);
+  }
+  return modet_launch_status();
+}
+
+}  // extern "C"

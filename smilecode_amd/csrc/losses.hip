@@ -1,0 +1,221 @@
+// NCC_vxm(win=9) and Grad3d('l2') forward + gradient (reference ModeT/losses.py:34-94, :6-31).
+//
+// The reference evaluates five dense 9x9x9 all-ones conv3d (729 taps each, ~36 GFLOP at 160x192x160); the box
+// filter is separable, so here each is three 9-tap passes (W, H, D) over channels-last-free (B,D,H,W) volumes:
+// HBM-bound streams.  The backward uses that the zero-padded box sum S is self-adjoint:
+//   d(-mean cc)/dJ = g * ( S(cB) + 2 J S(cD) + I S(cE) ),  g = -1/N,
+//   cE = d cc/d IJ_sum, cD = d cc/d J2_sum, cB = d cc/d J_sum  (pointwise in the five sums).
+// Scalar losses are reduced in two deterministic stages (workgroup partials -> fixed-order fp64 sum).
+#include "common.h"
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int WIN = 9, PAD = 4;
+constexpr float WINSZ = 729.f;
+
+struct Dims { int B, D, H, W; };
+
+__device__ __forceinline__ void decode(int64_t i, const Dims d, int& z, int& y, int& x) {
+  x = (int)(i % d.W);
+  const int64_t t = i / d.W;
+  y = (int)(t % d.H);
+  z = (int)((t / d.H) % d.D);
+}
+
+// pass along W fused with the five products: T[k][p] = sum_{|dx|<=4} {I, J, I*I, J*J, I*J}[p+dx]
+__global__ __launch_bounds__(BLK) void ncc_pass_w_kernel(const float* __restrict__ I, const float* __restrict__ J,
+                                                         float* __restrict__ T, Dims d, int64_t N) {
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
+    const int x = (int)(i % d.W);
+    float a = 0.f, b = 0.f, c = 0.f, e = 0.f, f = 0.f;
+#pragma unroll
+    for (int k = -PAD; k <= PAD; ++k) {
+      const int xx = x + k;
+      if (xx >= 0 && xx < d.W) {
+        const float iv = I[i + k], jv = J[i + k];
+        a += iv; b += jv; c = fmaf(iv, iv, c); e = fmaf(jv, jv, e); f = fmaf(iv, jv, f);
+      }
+    }
+    T[i] = a; T[N + i] = b; T[2 * N + i] = c; T[3 * N + i] = e; T[4 * N + i] = f;
+  }
+}
+
+// generic 9-tap pass along axis (0 = D, 1 = H, 2 = W) over `nvol` stacked volumes
+__global__ __launch_bounds__(BLK) void box_pass_kernel(const float* __restrict__ in, float* __restrict__ out, Dims d,
+                                                       int64_t N, int nvol, int axis) {
+  const int64_t stride = axis == 0 ? (int64_t)d.H * d.W : (axis == 1 ? d.W : 1);
+  const int len = axis == 0 ? d.D : (axis == 1 ? d.H : d.W);
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
+    int z, y, x;
+    decode(i, d, z, y, x);
+    const int pos = axis == 0 ? z : (axis == 1 ? y : x);
+    for (int v = 0; v < nvol; ++v) {
+      const float* p = in + (int64_t)v * N + i;
+      float s = 0.f;
+#pragma unroll
+      for (int k = -PAD; k <= PAD; ++k)
+        if (pos + k >= 0 && pos + k < len) s += p[(int64_t)k * stride];
+      out[(int64_t)v * N + i] = s;
+    }
+  }
+}
+
+// last forward pass (along D) fused with cc and the three backward coefficients; arithmetic in the
+// reference's own (expanded) order, losses.py:85-91
+__global__ __launch_bounds__(BLK) void ncc_pass_d_fwd_kernel(const float* __restrict__ T, float* __restrict__ coef,
+                                                             float* __restrict__ part, Dims d, int64_t N) {
+  __shared__ float red[BLK / 64];
+  const int64_t stride = (int64_t)d.H * d.W;
+  float lsum = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
+    int z, y, x;
+    decode(i, d, z, y, x);
+    float s[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+      const float* p = T + (int64_t)v * N + i;
+      float a = 0.f;
+#pragma unroll
+      for (int k = -PAD; k <= PAD; ++k)
+        if (z + k >= 0 && z + k < d.D) a += p[(int64_t)k * stride];
+      s[v] = a;
+    }
+    const float I_sum = s[0], J_sum = s[1], I2_sum = s[2], J2_sum = s[3], IJ_sum = s[4];
+    const float u_I = I_sum / WINSZ, u_J = J_sum / WINSZ;
+    const float cross = IJ_sum - u_J * I_sum - u_I * J_sum + u_I * u_J * WINSZ;
+    const float I_var = I2_sum - 2.f * u_I * I_sum + u_I * u_I * WINSZ;
+    const float J_var = J2_sum - 2.f * u_J * J_sum + u_J * u_J * WINSZ;
+    const float den = I_var * J_var + 1e-5f;
+    const float cc = cross * cross / den;
+    lsum += cc;
+    if (coef) {
+      const float cE = 2.f * cross / den;
+      const float cD = -cc * I_var / den;
+      const float cB = -(cE * I_sum + 2.f * cD * J_sum) / WINSZ;
+      coef[i] = cB; coef[N + i] = cD; coef[2 * N + i] = cE;
+    }
+  }
+  const float r = block_sum(lsum, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+// last backward pass (along D) fused with the final combine
+__global__ __launch_bounds__(BLK) void ncc_pass_d_bwd_kernel(const float* __restrict__ T, const float* __restrict__ I,
+                                                             const float* __restrict__ J, float* __restrict__ dJ,
+                                                             Dims d, int64_t N, float g) {
+  const int64_t stride = (int64_t)d.H * d.W;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
+    int z, y, x;
+    decode(i, d, z, y, x);
+    float s[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const float* p = T + (int64_t)v * N + i;
+      float a = 0.f;
+#pragma unroll
+      for (int k = -PAD; k <= PAD; ++k)
+        if (z + k >= 0 && z + k < d.D) a += p[(int64_t)k * stride];
+      s[v] = a;
+    }
+    dJ[i] = g * (s[0] + 2.f * J[i] * s[1] + I[i] * s[2]);
+  }
+}
+
+// loss[0] = scale * sum(part[0..n))  (fp64, fixed order); optionally adds into loss (accumulate != 0)
+__global__ void scalar_finalize_kernel(const float* __restrict__ part, int n, double scale, float* __restrict__ loss) {
+  __shared__ double sm[BLK];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += BLK) s += (double)part[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = 0.0;
+    for (int i = 0; i < BLK; ++i) r += sm[i];
+    loss[0] = (float)(r * scale);
+  }
+}
+
+// Grad3d('l2'): flow (B,3,D,H,W) planar.  loss = (mean dH^2 + mean dD^2 + mean dW^2)/3 (losses.py:17-27).
+__global__ __launch_bounds__(BLK) void grad3d_kernel(const float* __restrict__ f, float* __restrict__ df,
+                                                     float* __restrict__ part, Dims d, int64_t N, float inD, float inH,
+                                                     float inW) {
+  __shared__ float red[BLK / 64];
+  const int64_t sD = (int64_t)d.H * d.W, sH = d.W;
+  float lsum = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
+    int z, y, x;
+    decode(i, d, z, y, x);
+    const float v = f[i];
+    float g = 0.f;
+    if (z + 1 < d.D) { const float t = f[i + sD] - v; lsum = fmaf(t * t, inD, lsum); g -= t * inD; }
+    if (z > 0)       { const float t = v - f[i - sD]; g += t * inD; }
+    if (y + 1 < d.H) { const float t = f[i + sH] - v; lsum = fmaf(t * t, inH, lsum); g -= t * inH; }
+    if (y > 0)       { const float t = v - f[i - sH]; g += t * inH; }
+    if (x + 1 < d.W) { const float t = f[i + 1] - v;  lsum = fmaf(t * t, inW, lsum); g -= t * inW; }
+    if (x > 0)       { const float t = v - f[i - 1];  g += t * inW; }
+    if (df) df[i] = g * (2.f / 3.f);
+  }
+  const float r = block_sum(lsum, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+inline int red_grid(int64_t N) {
+  int g = flat_grid(N, BLK);
+  return g > 2048 ? 2048 : g;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t modet_ncc_ws_bytes(int B, int D, int H, int W) {
+  const int64_t N = (int64_t)B * D * H * W;
+  return ((size_t)10 * N + 2048) * sizeof(float);
+}
+
+int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B, int D,
+                      int H, int W, modet_stream_t stream) {
+  MODET_CHECK_PTR(I); MODET_CHECK_PTR(J); MODET_CHECK_PTR(loss); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0);
+  if (ws_bytes < modet_ncc_ws_bytes(B, D, H, W)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const Dims d{B, D, H, W};
+  const int64_t N = (int64_t)B * D * H * W;
+  float* T1 = (float*)ws;
+  float* T2 = T1 + 5 * N;
+  float* part = T2 + 5 * N;
+  const int grid = flat_grid(N, BLK), rg = red_grid(N);
+  hipLaunchKernelGGL(ncc_pass_w_kernel, dim3(grid), dim3(BLK), 0, s, I, J, T1, d, N);
+  hipLaunchKernelGGL(box_pass_kernel, dim3(grid), dim3(BLK), 0, s, (const float*)T1, T2, d, N, 5, 1);
+  hipLaunchKernelGGL(ncc_pass_d_fwd_kernel, dim3(rg), dim3(BLK), 0, s, (const float*)T2, d_J ? T1 : nullptr, part, d, N);
+  hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(BLK), 0, s, (const float*)part, rg, -1.0 / (double)N, loss);
+  if (d_J) {
+    hipLaunchKernelGGL(box_pass_kernel, dim3(grid), dim3(BLK), 0, s, (const float*)T1, T2, d, N, 3, 2);
+    hipLaunchKernelGGL(box_pass_kernel, dim3(grid), dim3(BLK), 0, s, (const float*)T2, T1, d, N, 3, 1);
+    hipLaunchKernelGGL(ncc_pass_d_bwd_kernel, dim3(grid), dim3(BLK), 0, s, (const float*)T1, I, J, d_J, d, N,
+                       -1.f / (float)N);
+  }
+  return modet_launch_status();
+}
+
+size_t modet_grad3d_ws_bytes(int, int, int, int) { return 2048 * sizeof(float); }
+
+int modet_grad3d_fwd_bwd(const float* flow, float* loss, float* d_flow, void* ws, size_t ws_bytes, int B, int D, int H,
+                         int W, modet_stream_t stream) {
+  MODET_CHECK_PTR(flow); MODET_CHECK_PTR(loss); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1);
+  if (ws_bytes < modet_grad3d_ws_bytes(B, D, H, W)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const Dims d{B * 3, D, H, W};
+  const int64_t N = (int64_t)B * 3 * D * H * W;
+  const float inD = (float)(1.0 / ((double)B * 3 * (D - 1) * H * W));
+  const float inH = (float)(1.0 / ((double)B * 3 * D * (H - 1) * W));
+  const float inW = (float)(1.0 / ((double)B * 3 * D * H * (W - 1)));
+  const int rg = red_grid(N);
+  hipLaunchKernelGGL(grad3d_kernel, dim3(rg), dim3(BLK), 0, s, flow, d_flow, (float*)ws, d, N, inD, inH, inW);
+  hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(BLK), 0, s, (const float*)ws, rg, 1.0 / 3.0, loss);
+  return modet_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,465 @@
+// Neighbourhood (3x3x3) attention of the motion-decomposition head, gfx950.
+//
+//  * modet_na_fwd / modet_na_bwd : fused ModeTransformer.forward (reference ModeT/models.py:308-334,
+//    ModeT-cu/models.py:300-316): logits -> softmax over the 27 modes -> expected offset, one thread per
+//    (voxel, head) owning all 27 logits in registers; the K tile (+1-voxel halo) is staged in LDS once
+//    per workgroup and read 27x from there.  The (..,27) attention tensor is never written to HBM.
+//  * modet_qk_fwd / modet_qk_bwd : the reference CUDA operator's exact tensor contract
+//    (ModeT-cu/modet/modet_kernel.cu:17-381), for callers shaped like ModeT-cu/functional.py.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 6;          // head_dim (train.py:49); the fused kernels are specialised for it
+constexpr int TZ = 4, TY = 4, TX = 16;           // voxel tile of one workgroup (256 threads)
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+constexpr int HVOX = HZ * HY * HX;               // 648 halo'd voxels
+constexpr int NTHREADS = TZ * TY * TX;
+
+struct TileGeom {
+  int tiles_x, tiles_y, tiles_z;
+};
+
+__device__ __forceinline__ void tile_origin(int tile, const TileGeom g, int& z0, int& y0, int& x0) {
+  const int tx = tile % g.tiles_x;
+  const int t2 = tile / g.tiles_x;
+  x0 = tx * TX;
+  y0 = (t2 % g.tiles_y) * TY;
+  z0 = (t2 / g.tiles_y) * TZ;
+}
+
+// stage k[b, z0-1.., y0-1.., x0-1.., head*6 + 0..5] into LDS, zeros outside the volume
+__device__ __forceinline__ void stage_k_tile(float* __restrict__ kt, const float* __restrict__ k, int64_t bbase,
+                                             int z0, int y0, int x0, int D, int H, int W, int C, int hoff) {
+  for (int idx = threadIdx.x; idx < HVOX * 3; idx += NTHREADS) {
+    const int v = idx / 3, part = idx - v * 3;
+    const int hx = v % HX, t = v / HX;
+    const int hy = t % HY, hz = t / HY;
+    const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+    float2 val = make_float2(0.f, 0.f);
+    if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
+      const int64_t off = (bbase + ((int64_t)z * H + y) * W + x) * C + hoff + part * 2;
+      val = *reinterpret_cast<const float2*>(k + off);
+    }
+    *reinterpret_cast<float2*>(kt + v * HD + part * 2) = val;
+  }
+}
+
+__device__ __forceinline__ void load6(const float* __restrict__ p, float (&r)[HD]) {
+  const float2 a = *reinterpret_cast<const float2*>(p);
+  const float2 b = *reinterpret_cast<const float2*>(p + 2);
+  const float2 c = *reinterpret_cast<const float2*>(p + 4);
+  r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y; r[4] = c.x; r[5] = c.y;
+}
+
+// 27 logits of one voxel from the LDS tile; lt = linear halo index of the voxel's (-1,-1,-1) neighbour
+__device__ __forceinline__ void logits27(const float* __restrict__ kt, int lt, const float (&qs)[HD],
+                                         const float* __restrict__ rpb_h, float (&lg)[27]) {
+#pragma unroll
+  for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+    for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int t = ki * 9 + kj * 3 + kk;
+        float kv[HD];
+        load6(kt + (lt + (ki * HY + kj) * HX + kk) * HD, kv);
+        float s = rpb_h[t];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) s = fmaf(qs[c], kv[c], s);
+        lg[t] = s;
+      }
+}
+
+__device__ __forceinline__ float softmax27(float (&lg)[27]) {   // lg -> exp(lg - max); returns 1/sum
+  float m = lg[0];
+#pragma unroll
+  for (int t = 1; t < 27; ++t) m = fmaxf(m, lg[t]);
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    lg[t] = __expf(lg[t] - m);
+    s += lg[t];
+  }
+  return 1.f / s;
+}
+
+// ------------------------------------------------------------------------------------------ fused forward
+__global__ __launch_bounds__(NTHREADS) void na_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ rpb, float* __restrict__ out,
+                                                          int D, int H, int W, int heads, float scale, TileGeom g) {
+  __shared__ __attribute__((aligned(16))) float kt[HVOX * HD];
+  __shared__ float rp[27];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int C = heads * HD;
+  const int64_t V = (int64_t)D * H * W;
+  int z0, y0, x0;
+  tile_origin(blockIdx.x, g, z0, y0, x0);
+  if (threadIdx.x < 27) rp[threadIdx.x] = rpb[h * 27 + threadIdx.x];
+  stage_k_tile(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
+  __syncthreads();
+
+  const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
+  const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+  if (z >= D || y >= H || x >= W) return;
+  const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+  float qs[HD];
+  load6(q + n * C + h * HD, qs);
+#pragma unroll
+  for (int c = 0; c < HD; ++c) qs[c] *= scale;
+  float p[27];
+  logits27(kt, (tz * HY + ty) * HX + tx, qs, rp, p);
+  const float inv = softmax27(p);
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+  for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+    for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const float pv = p[ki * 9 + kj * 3 + kk];
+        o0 += pv * (float)(ki - 1);
+        o1 += pv * (float)(kj - 1);
+        o2 += pv * (float)(kk - 1);
+      }
+  float* o = out + n * (heads * 3) + h * 3;
+  o[0] = o0 * inv; o[1] = o1 * inv; o[2] = o2 * inv;
+}
+
+// ------------------------------------------------------------------------------------------ fused backward
+// d_q by gather from the LDS K tile; d_k by LDS accumulation (ds_add_f32) of dlogit*q into a halo'd tile that
+// is flushed with global float atomics (d_k pre-zeroed); d_rpb partial per workgroup -> workspace.
+__global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ rpb, const float* __restrict__ dout,
+                                                          float* __restrict__ dq, float* __restrict__ dk,
+                                                          float* __restrict__ drpb_part, int D, int H, int W,
+                                                          int heads, float scale, TileGeom g) {
+  __shared__ __attribute__((aligned(16))) float kt[HVOX * HD];
+  __shared__ __attribute__((aligned(16))) float dkt[HVOX * HD];
+  __shared__ float red[27 * (NTHREADS / 64)];
+  __shared__ float rp[27];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int C = heads * HD;
+  const int64_t V = (int64_t)D * H * W;
+  int z0, y0, x0;
+  tile_origin(blockIdx.x, g, z0, y0, x0);
+  if (threadIdx.x < 27) rp[threadIdx.x] = rpb[h * 27 + threadIdx.x];
+  for (int i = threadIdx.x; i < HVOX * HD; i += NTHREADS) dkt[i] = 0.f;
+  stage_k_tile(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
+  __syncthreads();
+
+  const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
+  const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+  const bool live = (z < D && y < H && x < W);
+  float dl[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) dl[t] = 0.f;
+  if (live) {
+    const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+    float qs[HD];
+    load6(q + n * C + h * HD, qs);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) qs[c] *= scale;
+    const int lt = (tz * HY + ty) * HX + tx;
+    logits27(kt, lt, qs, rp, dl);
+    const float inv = softmax27(dl);
+    const float* go = dout + n * (heads * 3) + h * 3;
+    const float g0 = go[0], g1 = go[1], g2 = go[2];
+    float s = 0.f;
+#pragma unroll
+    for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+      for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          const int t = ki * 9 + kj * 3 + kk;
+          dl[t] *= inv;                                                   // p[t]
+          s += dl[t] * ((float)(ki - 1) * g0 + (float)(kj - 1) * g1 + (float)(kk - 1) * g2);
+        }
+    float dqa[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dqa[c] = 0.f;
+#pragma unroll
+    for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+      for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          const int t = ki * 9 + kj * 3 + kk;
+          const float gt = (float)(ki - 1) * g0 + (float)(kj - 1) * g1 + (float)(kk - 1) * g2;
+          const float d = dl[t] * (gt - s);                               // d loss / d logit[t]
+          dl[t] = d;
+          const int lo = (lt + (ki * HY + kj) * HX + kk) * HD;
+          float kv[HD];
+          load6(kt + lo, kv);
+#pragma unroll
+          for (int c = 0; c < HD; ++c) {
+            dqa[c] = fmaf(d, kv[c], dqa[c]);
+            atomicAdd(&dkt[lo + c], d * qs[c]);                           // qs carries the scale
+          }
+        }
+    float* dqp = dq + n * C + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dqp[c] = dqa[c] * scale;
+  }
+  // d_rpb partial of this workgroup: wave shuffle-reduce, then across waves through LDS
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    const float r = wave_sum(dl[t]);
+    if (lane == 0) red[wv * 27 + t] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    float r = 0.f;
+    for (int w = 0; w < NTHREADS / 64; ++w) r += red[w * 27 + threadIdx.x];
+    const int64_t blk = ((int64_t)b * gridDim.y + h) * gridDim.x + blockIdx.x;
+    drpb_part[blk * 27 + threadIdx.x] = r;
+  }
+  // flush the d_k tile
+  for (int idx = threadIdx.x; idx < HVOX * HD; idx += NTHREADS) {
+    const int v = idx / HD, c = idx - v * HD;
+    const int hx = v % HX, t = v / HX;
+    const int hy = t % HY, hz = t / HY;
+    const int zz = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+    if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const float val = dkt[idx];
+      if (val != 0.f)
+        atomicAdd(dk + ((int64_t)b * V + ((int64_t)zz * H + yy) * W + xx) * C + h * HD + c, val);
+    }
+  }
+}
+
+// partial (B, heads, nblk, 27) -> out (heads,27): fixed-order sum in double (deterministic)
+__global__ void drpb_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int heads,
+                                     int64_t nblk) {
+  const int h = blockIdx.x, t = threadIdx.x & 31, sl = threadIdx.x >> 5;   // 8 slices x 32 (27 used)
+  __shared__ double acc[8][32];
+  double s = 0.0;
+  if (t < 27)
+    for (int b = 0; b < B; ++b)
+      for (int64_t i = sl; i < nblk; i += 8) s += (double)part[(((int64_t)b * heads + h) * nblk + i) * 27 + t];
+  acc[sl][t] = s;
+  __syncthreads();
+  if (sl == 0 && t < 27) {
+    double r = 0.0;
+    for (int i = 0; i < 8; ++i) r += acc[i][t];
+    out[h * 27 + t] = (float)r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ reference contract
+// one thread per (b,h,voxel); 256 consecutive voxels per workgroup so the (voxel,27) slab it produces is one
+// contiguous 27 KB range of attn, written/read through LDS in fully coalesced rows.
+constexpr int QK_BLOCK = 256;
+
+template <typename T>
+__device__ __forceinline__ void qk_decode(int64_t v, int H, int W, T& z, T& y, T& x) {
+  x = (T)(v % W);
+  const int64_t t = v / W;
+  y = (T)(t % H);
+  z = (T)(t / H);
+}
+
+__global__ __launch_bounds__(QK_BLOCK) void qk_fwd_kernel(const float* __restrict__ q, const float* __restrict__ kpad,
+                                                          const float* __restrict__ rpb, float* __restrict__ attn,
+                                                          int heads, int D, int H, int W, int hd) {
+  __shared__ float slab[QK_BLOCK * 27];
+  const int64_t V = (int64_t)D * H * W;
+  const int bh = blockIdx.y, h = bh % heads;
+  const int64_t v0 = (int64_t)blockIdx.x * QK_BLOCK, v = v0 + threadIdx.x;
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t Vp = (int64_t)(D + 2) * Hp * Wp;
+  if (v < V) {
+    int z, y, x;
+    qk_decode(v, H, W, z, y, x);
+    const float* qp = q + ((int64_t)bh * V + v) * hd;
+    for (int ki = 0; ki < 3; ++ki)
+      for (int kj = 0; kj < 3; ++kj)
+        for (int kk = 0; kk < 3; ++kk) {
+          const float* kp = kpad + ((int64_t)bh * Vp + ((int64_t)(z + ki) * Hp + (y + kj)) * Wp + (x + kk)) * hd;
+          float s = 0.f;
+          for (int c = 0; c < hd; ++c) s = fmaf(qp[c], kp[c], s);
+          const int t = ki * 9 + kj * 3 + kk;
+          slab[threadIdx.x * 27 + t] = s + (rpb ? rpb[h * 27 + t] : 0.f);
+        }
+  }
+  __syncthreads();
+  const int64_t nvalid = (V - v0 < QK_BLOCK ? V - v0 : QK_BLOCK) * 27;
+  float* dst = attn + ((int64_t)bh * V + v0) * 27;
+  for (int64_t i = threadIdx.x; i < nvalid; i += QK_BLOCK) dst[i] = slab[i];
+}
+
+__global__ __launch_bounds__(QK_BLOCK) void qk_dq_kernel(const float* __restrict__ dattn, const float* __restrict__ kpad,
+                                                         float* __restrict__ dq, int D, int H, int W, int hd) {
+  __shared__ float slab[QK_BLOCK * 27];
+  const int64_t V = (int64_t)D * H * W;
+  const int bh = blockIdx.y;
+  const int64_t v0 = (int64_t)blockIdx.x * QK_BLOCK, v = v0 + threadIdx.x;
+  const int64_t nvalid = (V - v0 < QK_BLOCK ? V - v0 : QK_BLOCK) * 27;
+  const float* src = dattn + ((int64_t)bh * V + v0) * 27;
+  for (int64_t i = threadIdx.x; i < nvalid; i += QK_BLOCK) slab[i] = src[i];
+  __syncthreads();
+  if (v >= V) return;
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t Vp = (int64_t)(D + 2) * Hp * Wp;
+  int z, y, x;
+  qk_decode(v, H, W, z, y, x);
+  float* dqp = dq + ((int64_t)bh * V + v) * hd;
+  for (int c = 0; c < hd; ++c) {
+    float s = 0.f;
+    for (int ki = 0; ki < 3; ++ki)
+      for (int kj = 0; kj < 3; ++kj)
+        for (int kk = 0; kk < 3; ++kk)
+          s = fmaf(slab[threadIdx.x * 27 + ki * 9 + kj * 3 + kk],
+                   kpad[((int64_t)bh * Vp + ((int64_t)(z + ki) * Hp + (y + kj)) * Wp + (x + kk)) * hd + c], s);
+    dqp[c] = s;
+  }
+}
+
+// gather over the PADDED key volume (pad ring included, as modetdk_bw_kernel :209-267 returns it)
+__global__ __launch_bounds__(QK_BLOCK) void qk_dk_kernel(const float* __restrict__ dattn, const float* __restrict__ q,
+                                                         float* __restrict__ dkpad, int D, int H, int W, int hd) {
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t Vp = (int64_t)(D + 2) * Hp * Wp, V = (int64_t)D * H * W;
+  const int bh = blockIdx.y;
+  const int64_t pv = (int64_t)blockIdx.x * QK_BLOCK + threadIdx.x;
+  if (pv >= Vp) return;
+  int pz, py, px;
+  qk_decode(pv, Hp, Wp, pz, py, px);
+  float* dkp = dkpad + ((int64_t)bh * Vp + pv) * hd;
+  for (int c = 0; c < hd; ++c) {
+    float s = 0.f;
+    for (int ki = 0; ki < 3; ++ki) {
+      const int z = pz - ki;
+      if (z < 0 || z >= D) continue;
+      for (int kj = 0; kj < 3; ++kj) {
+        const int y = py - kj;
+        if (y < 0 || y >= H) continue;
+        for (int kk = 0; kk < 3; ++kk) {
+          const int x = px - kk;
+          if (x < 0 || x >= W) continue;
+          const int64_t n = (int64_t)bh * V + ((int64_t)z * H + y) * W + x;
+          s = fmaf(q[n * hd + c], dattn[n * 27 + ki * 9 + kj * 3 + kk], s);
+        }
+      }
+    }
+    dkp[c] = s;
+  }
+}
+
+// d_rpb partials: workgroup (chunk, b*heads+h) sums its 256*QK_RPB_ITERS voxels for all 27 tokens
+constexpr int QK_RPB_ITERS = 16;
+__global__ __launch_bounds__(QK_BLOCK) void qk_drpb_partial_kernel(const float* __restrict__ dattn,
+                                                                   float* __restrict__ part, int64_t V) {
+  __shared__ float red[27 * (QK_BLOCK / 64)];
+  const int bh = blockIdx.y;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  const int64_t base = (int64_t)blockIdx.x * QK_BLOCK * QK_RPB_ITERS;
+  for (int it = 0; it < QK_RPB_ITERS; ++it) {
+    const int64_t v = base + (int64_t)it * QK_BLOCK + threadIdx.x;
+    if (v < V) {
+      const float* p = dattn + ((int64_t)bh * V + v) * 27;
+#pragma unroll
+      for (int t = 0; t < 27; ++t) acc[t] += p[t];
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    const float r = wave_sum(acc[t]);
+    if (lane == 0) red[wv * 27 + t] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    float r = 0.f;
+    for (int w = 0; w < QK_BLOCK / 64; ++w) r += red[w * 27 + threadIdx.x];
+    part[((int64_t)bh * gridDim.x + blockIdx.x) * 27 + threadIdx.x] = r;
+  }
+}
+
+inline TileGeom geom(int D, int H, int W) { return TileGeom{cdiv(W, TX), cdiv(H, TY), cdiv(D, TZ)}; }
+
+}  // namespace
+
+extern "C" {
+
+int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, int B, int D, int H, int W,
+                 int heads, int hd, float scale, modet_stream_t stream) {
+  MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(out);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
+  if (hd != HD) return MODET_ERR_UNSUPPORTED;
+  const TileGeom g = geom(D, H, W);
+  dim3 grid(g.tiles_x * g.tiles_y * g.tiles_z, heads, B);
+  hipLaunchKernelGGL(na_fwd_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, q, k, rpb, out, D, H, W, heads,
+                     scale, g);
+  return modet_launch_status();
+}
+
+size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads) {
+  const TileGeom g = geom(D, H, W);
+  return (size_t)B * heads * g.tiles_x * g.tiles_y * g.tiles_z * 27 * sizeof(float);
+}
+
+int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* d_out, float* d_q, float* d_k,
+                 float* d_rpb, void* ws, size_t ws_bytes, int B, int D, int H, int W, int heads, int hd, float scale,
+                 modet_stream_t stream) {
+  MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(d_out);
+  MODET_CHECK_PTR(d_q); MODET_CHECK_PTR(d_k); MODET_CHECK_PTR(d_rpb); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
+  if (hd != HD) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_na_bwd_ws_bytes(B, D, H, W, heads)) return MODET_ERR_WORKSPACE;
+  const TileGeom g = geom(D, H, W);
+  const int64_t nblk = (int64_t)g.tiles_x * g.tiles_y * g.tiles_z;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_k, 0, (size_t)B * D * H * W * heads * HD * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid((unsigned)nblk, heads, B);
+  hipLaunchKernelGGL(na_bwd_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, d_out, d_q, d_k, (float*)ws, D, H, W,
+                     heads, scale, g);
+  hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads), dim3(256), 0, s, (const float*)ws, d_rpb, B, heads, nblk);
+  return modet_launch_status();
+}
+
+int modet_qk_fwd(const float* q, const float* kpad, const float* rpb, float* attn, int B, int heads, int D, int H,
+                 int W, int hd, modet_stream_t stream) {
+  MODET_CHECK_PTR(q); MODET_CHECK_PTR(kpad); MODET_CHECK_PTR(attn);
+  MODET_CHECK_DIM(B > 0 && heads > 0 && hd > 0);
+  MODET_CHECK_DIM(D >= 3 && H >= 3 && W >= 3);   // CHECK_3DFEATMAP, utils.h:10
+  const int64_t V = (int64_t)D * H * W;
+  dim3 grid((unsigned)cdiv64(V, QK_BLOCK), B * heads);
+  hipLaunchKernelGGL(qk_fwd_kernel, grid, dim3(QK_BLOCK), 0, (hipStream_t)stream, q, kpad, rpb, attn, heads, D, H, W,
+                     hd);
+  return modet_launch_status();
+}
+
+size_t modet_qk_bwd_ws_bytes(int B, int heads, int D, int H, int W) {
+  const int64_t V = (int64_t)D * H * W;
+  return (size_t)B * heads * cdiv64(V, (int64_t)QK_BLOCK * QK_RPB_ITERS) * 27 * sizeof(float);
+}
+
+int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad, float* d_q, float* d_kpad, float* d_rpb,
+                 void* ws, size_t ws_bytes, int B, int heads, int D, int H, int W, int hd, modet_stream_t stream) {
+  MODET_CHECK_PTR(d_attn); MODET_CHECK_PTR(q); MODET_CHECK_PTR(kpad); MODET_CHECK_PTR(d_q); MODET_CHECK_PTR(d_kpad);
+  MODET_CHECK_DIM(B > 0 && heads > 0 && hd > 0);
+  MODET_CHECK_DIM(D >= 3 && H >= 3 && W >= 3);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t V = (int64_t)D * H * W, Vp = (int64_t)(D + 2) * (H + 2) * (W + 2);
+  if (d_rpb) {
+    MODET_CHECK_PTR(ws);
+    if (ws_bytes < modet_qk_bwd_ws_bytes(B, heads, D, H, W)) return MODET_ERR_WORKSPACE;
+    const int64_t nchunk = cdiv64(V, (int64_t)QK_BLOCK * QK_RPB_ITERS);
+    hipLaunchKernelGGL(qk_drpb_partial_kernel, dim3((unsigned)nchunk, B * heads), dim3(QK_BLOCK), 0, s, d_attn,
+                       (float*)ws, V);
+    hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads), dim3(256), 0, s, (const float*)ws, d_rpb, B, heads, nchunk);
+  }
+  hipLaunchKernelGGL(qk_dq_kernel, dim3((unsigned)cdiv64(V, QK_BLOCK), B * heads), dim3(QK_BLOCK), 0, s, d_attn, kpad,
+                     d_q, D, H, W, hd);
+  hipLaunchKernelGGL(qk_dk_kernel, dim3((unsigned)cdiv64(Vp, QK_BLOCK), B * heads), dim3(QK_BLOCK), 0, s, d_attn, q,
+                     d_kpad, D, H, W, hd);
+  return modet_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// InstanceNorm3d + LeakyReLU (ConvInsBlock, reference ModeT/models.py:135-151), AvgPool3d(2) (:201-219),
+// LeakyReLU backward, flat Adam-amsgrad (ModeT/train.py:101), device-scalar scaling.  Channels-last streams.
+//
+// InstanceNorm statistics are reduced in two deterministic stages: per-workgroup fp32 partial sums over a
+// chunk of voxels -> workspace, then one fixed-order fp64 sum per (b,c).  No atomics, so ranks stay bit-consistent.
+#include "common.h"
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int CHUNK = 4096;           // voxels per partial-sum workgroup
+
+// MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat), g = dy * lrelu'(xhat)
+template <int MODE>
+__global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ part, int64_t V, int C) {
+  __shared__ float red[BLK * 8];
+  const int G = C >> 2;                        // float4 groups per voxel
+  const int VPB = BLK / G;                     // voxels per pass
+  const int b = blockIdx.y;
+  const int g = threadIdx.x % G, vl = threadIdx.x / G;
+  const bool active = vl < VPB;
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
+  if (MODE == 1 && active) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { mu[c] = mean[b * C + g * 4 + c]; rs[c] = rstd[b * C + g * 4 + c]; }
+  }
+  const int64_t v0 = (int64_t)blockIdx.x * CHUNK;
+  const int64_t v1 = v0 + CHUNK < V ? v0 + CHUNK : V;
+  if (active) {
+    for (int64_t v = v0 + vl; v < v1; v += VPB) {
+      const int64_t off = ((int64_t)b * V + v) * C + g * 4;
+      const float4 xv = *reinterpret_cast<const float4*>(x + off);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      if (MODE == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[c] += xs[c]; q[c] = fmaf(xs[c], xs[c], q[c]); }
+      } else {
+        const float4 gv = *reinterpret_cast<const float4*>(dy + off);
+        const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float xh = (xs[c] - mu[c]) * rs[c];
+          const float gg = gs[c] * (xh > 0.f ? 1.f : LRELU_SLOPE);
+          a[c] += gg; q[c] = fmaf(gg, xh, q[c]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { red[threadIdx.x * 8 + c] = a[c]; red[threadIdx.x * 8 + 4 + c] = q[c]; }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < VPB; ++j) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s[c] += red[(j * G + threadIdx.x) * 8 + c];
+    }
+    float* p = part + (((int64_t)b * gridDim.x + blockIdx.x) * C + threadIdx.x * 4) * 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { p[c * 2] = s[c]; p[c * 2 + 1] = s[4 + c]; }
+  }
+}
+
+// MODE 0: -> mean, rstd.   MODE 1: -> (sum g)/V, (sum g*xhat)/V in out0/out1.
+template <int MODE>
+__global__ void in_finalize_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
+                                   int64_t V, int C, int nchunk, float eps) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nchunk; ++i) {
+      const float* p = part + (((int64_t)b * nchunk + i) * C + c) * 2;
+      s += (double)p[0]; q += (double)p[1];
+    }
+    if (MODE == 0) {
+      const double m = s / (double)V;
+      double var = q / (double)V - m * m;
+      if (var < 0.0) var = 0.0;
+      out0[b * C + c] = (float)m;
+      out1[b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      out0[b * C + c] = (float)(s / (double)V);
+      out1[b * C + c] = (float)(q / (double)V);
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLK) void in_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       int64_t V, int C, int64_t total4) {
+  const int G = C >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
+    const int g = (int)(i % G);
+    const int64_t b = (i / G) / V;
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 m = *reinterpret_cast<const float4*>(mean + b * C + g * 4);
+    const float4 r = *reinterpret_cast<const float4*>(rstd + b * C + g * 4);
+    float4 o;
+    o.x = lrelu((xv.x - m.x) * r.x); o.y = lrelu((xv.y - m.y) * r.y);
+    o.z = lrelu((xv.z - m.z) * r.z); o.w = lrelu((xv.w - m.w) * r.w);
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat))
+__global__ __launch_bounds__(BLK) void in_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ s1, const float* __restrict__ s2,
+                                                           float* __restrict__ dx, int64_t V, int C, int64_t total4) {
+  const int G = C >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
+    const int g = (int)(i % G);
+    const int64_t b = (i / G) / V;
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 gv = reinterpret_cast<const float4*>(dy)[i];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int bc = (int)b * C + g * 4 + c;
+      const float r = rstd[bc];
+      const float xh = (xs[c] - mean[bc]) * r;
+      const float gg = gs[c] * (xh > 0.f ? 1.f : LRELU_SLOPE);
+      o[c] = r * (gg - s1[bc] - xh * s2[bc]);
+    }
+    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ __launch_bounds__(BLK) void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        float* __restrict__ dx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK)
+    dx[i] = dy[i] * (y[i] > 0.f ? 1.f : LRELU_SLOPE);
+}
+
+__global__ __launch_bounds__(BLK) void scale_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                    float* __restrict__ y, int64_t n) {
+  const float f = s[0];
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) y[i] = x[i] * f;
+}
+
+// ---- AvgPool3d(2): (B,D,H,W,C) -> (B,D/2,H/2,W/2,C), float4 channel groups
+__global__ __launch_bounds__(BLK) void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int D,
+                                                           int H, int W, int C, int64_t total4) {
+  const int G = C >> 2, d = D / 2, h = H / 2, w = W / 2;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
+    const int g = (int)(i % G);
+    int64_t t = i / G;
+    const int xo = (int)(t % w); t /= w;
+    const int yo = (int)(t % h); t /= h;
+    const int zo = (int)(t % d);
+    const int64_t b = t / d;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int64_t off = (((b * D + 2 * zo + dz) * H + 2 * yo + dy) * W + 2 * xo + dx) * C + g * 4;
+          const float4 v = *reinterpret_cast<const float4*>(x + off);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    s.x *= 0.125f; s.y *= 0.125f; s.z *= 0.125f; s.w *= 0.125f;
+    reinterpret_cast<float4*>(y)[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(BLK) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int D,
+                                                           int H, int W, int C, int64_t total4) {
+  const int G = C >> 2, h = H / 2, w = W / 2, d = D / 2;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
+    const int g = (int)(i % G);
+    int64_t t = i / G;
+    const int xi = (int)(t % W); t /= W;
+    const int yi = (int)(t % H); t /= H;
+    const int zi = (int)(t % D);
+    const int64_t b = t / D;
+    const int64_t off = (((b * d + zi / 2) * h + yi / 2) * w + xi / 2) * C + g * 4;
+    float4 v = *reinterpret_cast<const float4*>(dy + off);
+    v.x *= 0.125f; v.y *= 0.125f; v.z *= 0.125f; v.w *= 0.125f;
+    reinterpret_cast<float4*>(dx)[i] = v;
+  }
+}
+
+// ---- Adam(amsgrad=True): single-tensor update of torch.optim.Adam (bias corrections from `step`)
+__global__ __launch_bounds__(BLK) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ vmax, int64_t n, float step_size, float beta1,
+                                                   float beta2, float eps, float inv_sqrt_bc2, float grad_scale) {
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
+    const float gi = g[i] * grad_scale;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;      // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    const float vm = fmaxf(vmax[i], vi);
+    m[i] = mi; v[i] = vi; vmax[i] = vm;
+    const float denom = sqrtf(vm) * inv_sqrt_bc2 + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t modet_instnorm_ws_bytes(int B, int64_t V, int C) {
+  const int64_t nchunk = cdiv64(V, CHUNK);
+  return ((size_t)B * nchunk * C * 2 + (size_t)B * C * 2) * sizeof(float);
+}
+
+int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes, int B,
+                             int64_t V, int C, float eps, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(y); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
+  if (C % 4 != 0 || C > 4 * BLK) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_instnorm_ws_bytes(B, V, C)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = (int)cdiv64(V, CHUNK);
+  float* part = (float*)ws;
+  hipLaunchKernelGGL(in_partial_kernel<0>, dim3(nchunk, B), dim3(BLK), 0, s, x, nullptr, nullptr, nullptr, part, V, C);
+  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3(B), dim3(128), 0, s, part, mean, rstd, V, C, nchunk, eps);
+  const int64_t total4 = (int64_t)B * V * (C / 4);
+  hipLaunchKernelGGL(in_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total4);
+  return modet_launch_status();
+}
+
+int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
+                             void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream) {
+  MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x);
+  MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
+  if (C % 4 != 0 || C > 4 * BLK) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_instnorm_ws_bytes(B, V, C)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = (int)cdiv64(V, CHUNK);
+  float* part = (float*)ws;
+  float* s1 = part + (size_t)B * nchunk * C * 2;
+  float* s2 = s1 + (size_t)B * C;
+  hipLaunchKernelGGL(in_partial_kernel<1>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C);
+  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(B), dim3(128), 0, s, part, s1, s2, V, C, nchunk, 0.f);
+  const int64_t total4 = (int64_t)B * V * (C / 4);
+  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2,
+                     d_x, V, C, total4);
+  return modet_launch_status();
+}
+
+int modet_lrelu_bwd(const float* d_y, const float* y, float* d_x, int64_t n, modet_stream_t stream) {
+  MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(y); MODET_CHECK_PTR(d_x);
+  MODET_CHECK_DIM(n > 0);
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(flat_grid(n, BLK)), dim3(BLK), 0, (hipStream_t)stream, d_y, y, d_x, n);
+  return modet_launch_status();
+}
+
+int modet_scale_by_dev_scalar(const float* x, const float* s, float* y, int64_t n, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(s); MODET_CHECK_PTR(y);
+  MODET_CHECK_DIM(n > 0);
+  hipLaunchKernelGGL(scale_kernel, dim3(flat_grid(n, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, s, y, n);
+  return modet_launch_status();
+}
+
+int modet_avgpool2_fwd(const float* x, float* y, int B, int D, int H, int W, int C, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(y);
+  MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1 && C > 0);
+  MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
+  if (C % 4 != 0) return MODET_ERR_UNSUPPORTED;
+  const int64_t total4 = (int64_t)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, y, D, H,
+                     W, C, total4);
+  return modet_launch_status();
+}
+
+int modet_avgpool2_bwd(const float* d_y, float* d_x, int B, int D, int H, int W, int C, modet_stream_t stream) {
+  MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_x);
+  MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1 && C > 0);
+  MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
+  if (C % 4 != 0) return MODET_ERR_UNSUPPORTED;
+  const int64_t total4 = (int64_t)B * D * H * W * (C / 4);
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, (hipStream_t)stream, d_y, d_x, D,
+                     H, W, C, total4);
+  return modet_launch_status();
+}
+
+int modet_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr,
+                            float beta1, float beta2, float eps, int step, float grad_scale, modet_stream_t stream) {
+  MODET_CHECK_PTR(p); MODET_CHECK_PTR(g); MODET_CHECK_PTR(m); MODET_CHECK_PTR(v); MODET_CHECK_PTR(vmax);
+  MODET_CHECK_DIM(n > 0 && step >= 1);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n, BLK)), dim3(BLK), 0, (hipStream_t)stream, p, g, m, v, vmax, n,
+                     step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
+  return modet_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,524 @@
+// SpatialTransformer warp / flow composition, trilinear x2 upsample, layout changes, CWM tail and the
+// label-warp + Dice-count evaluation tail.  All HBM-bound gathers/streams: channels-last so one 8-corner
+// address computation serves every channel of a voxel, float4 per lane where C allows it.
+//   reference: ModeT/models.py:25-67 (SpatialTransformer), :354/:257-261 (Upsample), :263-275 (CWM),
+//              ModeT/utils.py:30-106 (nearest label warp, dice_val_VOI).
+#include "common.h"
+
+namespace {
+
+constexpr int BLK = 256;
+
+template <int CPT> struct Vec;
+template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<3> { using T = float3; };   // loaded element-wise (12 B, no alignment guarantee)
+template <> struct Vec<1> { using T = float; };
+
+template <int CPT> __device__ __forceinline__ void ldv(const float* p, float (&r)[CPT]) {
+  if constexpr (CPT == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) r[i] = p[i];
+  }
+}
+template <int CPT> __device__ __forceinline__ void stv(float* p, const float (&r)[CPT]) {
+  if constexpr (CPT == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) p[i] = r[i];
+  }
+}
+
+struct Tri {            // trilinear footprint of one sample point
+  int z0, y0, x0;
+  float fz, fy, fx;
+};
+__device__ __forceinline__ Tri tri_setup(float z, float y, float x) {
+  Tri t;
+  const float zf = floorf(z), yf = floorf(y), xf = floorf(x);
+  t.fz = z - zf; t.fy = y - yf; t.fx = x - xf;
+  // clamp before the int conversion so wild flows cannot overflow; anything outside [-2, dim] is invalid anyway
+  t.z0 = (int)fminf(fmaxf(zf, -2.f), 1.0e9f);
+  t.y0 = (int)fminf(fmaxf(yf, -2.f), 1.0e9f);
+  t.x0 = (int)fminf(fmaxf(xf, -2.f), 1.0e9f);
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------ warp fwd
+template <int CPT>
+__global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                       float* __restrict__ out, int D, int H, int W, int C, int G,
+                                                       int64_t total, int mode, int add_flow) {
+  const int64_t V = (int64_t)D * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+    const int g = (int)(idx % G);
+    const int64_t n = idx / G;                 // b*V + voxel
+    const int64_t b = n / V, v = n - b * V;
+    const int xi = (int)(v % W);
+    const int64_t t2 = v / W;
+    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
+    const float* fp = flow + n * 3;
+    const float f0 = fp[0], f1 = fp[1], f2 = fp[2];
+    const float z = (float)zi + f0, y = (float)yi + f1, x = (float)xi + f2;
+    const float* sb = src + b * V * C + g * CPT;
+    float acc[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
+    if (mode == 1) {
+      const float zr = rintf(z), yr = rintf(y), xr = rintf(x);     // round half to even = nearbyint
+      if (zr >= 0.f && zr < (float)D && yr >= 0.f && yr < (float)H && xr >= 0.f && xr < (float)W)
+        ldv<CPT>(sb + (((int64_t)zr * H + (int64_t)yr) * W + (int64_t)xr) * C, acc);
+    } else {
+      const Tri t = tri_setup(z, y, x);
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz) {
+        const int zz = t.z0 + dz;
+        const float wz = dz ? t.fz : 1.f - t.fz;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int yy = t.y0 + dy;
+          const float wy = dy ? t.fy : 1.f - t.fy;
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int xx = t.x0 + dx;
+            const float wx = dx ? t.fx : 1.f - t.fx;
+            if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+              float s[CPT];
+              ldv<CPT>(sb + (((int64_t)zz * H + yy) * W + xx) * C, s);
+              const float wgt = wz * wy * wx;
+#pragma unroll
+              for (int c = 0; c < CPT; ++c) acc[c] = fmaf(wgt, s[c], acc[c]);
+            }
+          }
+        }
+      }
+    }
+    if (add_flow) {                            // C == 3, CPT == 3, G == 1
+      if constexpr (CPT == 3) { acc[0] += f0; acc[1] += f1; acc[2] += f2; }
+    }
+    stv<CPT>(out + n * C + g * CPT, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ warp bwd
+// d_src: scatter-add of the 8 corner weights (float atomics, as ATen's grid_sampler_3d_backward does);
+// d_flow: per-voxel gather; the partial sums of the G channel groups of a voxel sit in adjacent lanes and are
+// combined with xor-shuffles (G is a power of two <= 64).
+template <int CPT>
+__global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                       const float* __restrict__ dout, float* __restrict__ dsrc,
+                                                       float* __restrict__ dflow, int D, int H, int W, int C, int G,
+                                                       int64_t total, int add_flow) {
+  const int64_t V = (int64_t)D * H * W;
+  const int64_t total_pad = cdiv64(total, BLK) * BLK;       // keep whole waves alive for the shuffles
+  for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total_pad; idx += (int64_t)gridDim.x * BLK) {
+    const bool live = idx < total;
+    const int64_t id = live ? idx : total - 1;
+    const int g = (int)(id % G);
+    const int64_t n = id / G;
+    const int64_t b = n / V, v = n - b * V;
+    const int xi = (int)(v % W);
+    const int64_t t2 = v / W;
+    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
+    const float* fp = flow + n * 3;
+    const Tri t = tri_setup((float)zi + fp[0], (float)yi + fp[1], (float)xi + fp[2]);
+    float go[CPT];
+    ldv<CPT>(dout + n * C + g * CPT, go);
+    if (!live) {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) go[c] = 0.f;
+    }
+    const float* sb = src + b * V * C + g * CPT;
+    float* db = dsrc ? dsrc + b * V * C + g * CPT : nullptr;
+    float gz = 0.f, gy = 0.f, gx = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz) {
+      const int zz = t.z0 + dz;
+      const float wz = dz ? t.fz : 1.f - t.fz;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int yy = t.y0 + dy;
+        const float wy = dy ? t.fy : 1.f - t.fy;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int xx = t.x0 + dx;
+          const float wx = dx ? t.fx : 1.f - t.fx;
+          if (live && zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const int64_t off = (((int64_t)zz * H + yy) * W + xx) * C;
+            if (db) {
+              const float wgt = wz * wy * wx;
+#pragma unroll
+              for (int c = 0; c < CPT; ++c) atomicAdd(db + off + c, wgt * go[c]);
+            }
+            if (dflow) {
+              float s[CPT];
+              ldv<CPT>(sb + off, s);
+              float dot = 0.f;
+#pragma unroll
+              for (int c = 0; c < CPT; ++c) dot = fmaf(s[c], go[c], dot);
+              gz += (dz ? 1.f : -1.f) * wy * wx * dot;
+              gy += (dy ? 1.f : -1.f) * wz * wx * dot;
+              gx += (dx ? 1.f : -1.f) * wz * wy * dot;
+            }
+          }
+        }
+      }
+    }
+    if (dflow) {
+      for (int o = 1; o < G; o <<= 1) {
+        gz += __shfl_xor(gz, o, 64);
+        gy += __shfl_xor(gy, o, 64);
+        gx += __shfl_xor(gx, o, 64);
+      }
+      if (live && g == 0) {
+        if (add_flow) {
+          if constexpr (CPT == 3) { gz += go[0]; gy += go[1]; gx += go[2]; }
+        }
+        float* dfp = dflow + n * 3;
+        dfp[0] = gz; dfp[1] = gy; dfp[2] = gx;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ upsample x2
+struct Lin { int i0, i1; float l0, l1; };
+// ATen compute_source_index_and_lambda, align_corners=True (UpSample.h): src = ratio*dst
+__device__ __forceinline__ Lin lin_src(int o, float ratio, int n_in) {
+  Lin r;
+  const float real = ratio * (float)o;
+  r.i0 = min((int)real, n_in - 1);
+  r.l1 = fminf(fmaxf(real - (float)r.i0, 0.f), 1.f);
+  r.i1 = r.i0 + (r.i0 < n_in - 1 ? 1 : 0);
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+__host__ __device__ __forceinline__ float up_ratio(int n_in) {
+  return n_in > 1 ? (float)(n_in - 1) / (float)(2 * n_in - 1) : 0.f;
+}
+
+template <int CPT>
+__global__ __launch_bounds__(BLK) void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int d,
+                                                            int h, int w, int C, int G, int64_t total, float scale) {
+  const int D = 2 * d, H = 2 * h, W = 2 * w;
+  const float rz = up_ratio(d), ry = up_ratio(h), rx = up_ratio(w);
+  const int64_t Vo = (int64_t)D * H * W, Vi = (int64_t)d * h * w;
+  for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+    const int g = (int)(idx % G);
+    const int64_t n = idx / G;
+    const int64_t b = n / Vo, v = n - b * Vo;
+    const int xo = (int)(v % W);
+    const int64_t t2 = v / W;
+    const int yo = (int)(t2 % H), zo = (int)(t2 / H);
+    const Lin lz = lin_src(zo, rz, d), ly = lin_src(yo, ry, h), lx = lin_src(xo, rx, w);
+    const float* xb = x + b * Vi * C + g * CPT;
+    float acc[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int zz = a ? lz.i1 : lz.i0, yy = bb ? ly.i1 : ly.i0, xx = cc ? lx.i1 : lx.i0;
+          const float wgt = (a ? lz.l1 : lz.l0) * (bb ? ly.l1 : ly.l0) * (cc ? lx.l1 : lx.l0);
+          float s[CPT];
+          ldv<CPT>(xb + (((int64_t)zz * h + yy) * w + xx) * C, s);
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) acc[c] = fmaf(wgt, s[c], acc[c]);
+        }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[c] *= scale;
+    stv<CPT>(y + n * C + g * CPT, acc);
+  }
+}
+
+// weight with which output index o reads input index i (exact transpose of lin_src)
+__device__ __forceinline__ float lin_wt(int o, int i, float ratio, int n_in) {
+  const Lin l = lin_src(o, ratio, n_in);
+  return (l.i0 == i ? l.l0 : 0.f) + (l.i1 == i ? l.l1 : 0.f);
+}
+__device__ __forceinline__ void lin_range(int i, float ratio, int n_in, int& lo, int& hi) {
+  const int n_out = 2 * n_in;
+  if (ratio <= 0.f) { lo = 0; hi = n_out - 1; return; }
+  lo = max(0, (int)floorf((float)(i - 1) / ratio) - 1);
+  hi = min(n_out - 1, (int)ceilf((float)(i + 1) / ratio) + 1);
+}
+
+template <int CPT>
+__global__ __launch_bounds__(BLK) void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int d,
+                                                            int h, int w, int C, int G, int64_t total, float scale) {
+  const int H = 2 * h, W = 2 * w;
+  const float rz = up_ratio(d), ry = up_ratio(h), rx = up_ratio(w);
+  const int64_t Vo = (int64_t)8 * d * h * w, Vi = (int64_t)d * h * w;
+  for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+    const int g = (int)(idx % G);
+    const int64_t n = idx / G;
+    const int64_t b = n / Vi, v = n - b * Vi;
+    const int xi = (int)(v % w);
+    const int64_t t2 = v / w;
+    const int yi = (int)(t2 % h), zi = (int)(t2 / h);
+    int zlo, zhi, ylo, yhi, xlo, xhi;
+    lin_range(zi, rz, d, zlo, zhi);
+    lin_range(yi, ry, h, ylo, yhi);
+    lin_range(xi, rx, w, xlo, xhi);
+    const float* gb = dy + b * Vo * C + g * CPT;
+    float acc[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
+    for (int zo = zlo; zo <= zhi; ++zo) {
+      const float wz = lin_wt(zo, zi, rz, d);
+      if (wz == 0.f) continue;
+      for (int yo = ylo; yo <= yhi; ++yo) {
+        const float wy = lin_wt(yo, yi, ry, h);
+        if (wy == 0.f) continue;
+        for (int xo = xlo; xo <= xhi; ++xo) {
+          const float wx = lin_wt(xo, xi, rx, w);
+          if (wx == 0.f) continue;
+          float s[CPT];
+          ldv<CPT>(gb + (((int64_t)zo * H + yo) * W + xo) * C, s);
+          const float wgt = wz * wy * wx;
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) acc[c] = fmaf(wgt, s[c], acc[c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[c] *= scale;
+    stv<CPT>(dx + n * C + g * CPT, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ layout
+// (B,C,V) -> (B,V,C): threads walk the output; reads are C strided streams, each coalesced across lanes
+__global__ __launch_bounds__(BLK) void ncdhw_to_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                          int64_t V, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+    const int64_t b = idx / V, v = idx - b * V;
+    for (int c = 0; c < C; ++c) y[idx * C + c] = x[(b * C + c) * V + v];
+  }
+}
+__global__ __launch_bounds__(BLK) void cl_to_ncdhw_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                          int64_t V, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+    const int64_t b = idx / V, v = idx - b * V;
+    for (int c = 0; c < C; ++c) y[(b * C + c) * V + v] = x[idx * C + c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ CWM tail
+template <int HEADS>
+__global__ __launch_bounds__(BLK) void cwm_tail_fwd_kernel(const float* __restrict__ x, const float* __restrict__ lg,
+                                                           float* __restrict__ out, int64_t N) {
+  for (int64_t n = (int64_t)blockIdx.x * BLK + threadIdx.x; n < N; n += (int64_t)gridDim.x * BLK) {
+    float l[HEADS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < HEADS; ++i) { l[i] = lg[n * HEADS + i]; m = fmaxf(m, l[i]); }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < HEADS; ++i) { l[i] = __expf(l[i] - m); s += l[i]; }
+    const float inv = 2.f / s;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < HEADS; ++i) {
+      const float* xp = x + n * (HEADS * 3) + i * 3;
+      o0 = fmaf(l[i], xp[0], o0); o1 = fmaf(l[i], xp[1], o1); o2 = fmaf(l[i], xp[2], o2);
+    }
+    out[n * 3 + 0] = o0 * inv; out[n * 3 + 1] = o1 * inv; out[n * 3 + 2] = o2 * inv;
+  }
+}
+
+template <int HEADS>
+__global__ __launch_bounds__(BLK) void cwm_tail_bwd_kernel(const float* __restrict__ x, const float* __restrict__ lg,
+                                                           const float* __restrict__ dout, float* __restrict__ dx,
+                                                           float* __restrict__ dlg, int64_t N) {
+  for (int64_t n = (int64_t)blockIdx.x * BLK + threadIdx.x; n < N; n += (int64_t)gridDim.x * BLK) {
+    float p[HEADS], gdot[HEADS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < HEADS; ++i) { p[i] = lg[n * HEADS + i]; m = fmaxf(m, p[i]); }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < HEADS; ++i) { p[i] = __expf(p[i] - m); s += p[i]; }
+    const float inv = 1.f / s;
+    const float g0 = 2.f * dout[n * 3 + 0], g1 = 2.f * dout[n * 3 + 1], g2 = 2.f * dout[n * 3 + 2];
+    float mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < HEADS; ++i) {
+      p[i] *= inv;
+      const float* xp = x + n * (HEADS * 3) + i * 3;
+      gdot[i] = g0 * xp[0] + g1 * xp[1] + g2 * xp[2];       // d out / d weight_i
+      mean = fmaf(p[i], gdot[i], mean);
+      float* dxp = dx + n * (HEADS * 3) + i * 3;
+      dxp[0] = p[i] * g0; dxp[1] = p[i] * g1; dxp[2] = p[i] * g2;
+    }
+#pragma unroll
+    for (int i = 0; i < HEADS; ++i) dlg[n * HEADS + i] = p[i] * (gdot[i] - mean);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ eval tail
+constexpr int MAXLAB = 256;
+__global__ __launch_bounds__(BLK) void label_warp_counts_kernel(const int16_t* __restrict__ lm,
+                                                                const float* __restrict__ flow,
+                                                                const int16_t* __restrict__ lf,
+                                                                int16_t* __restrict__ warped,
+                                                                unsigned long long* __restrict__ counts, int D, int H,
+                                                                int W, int nlab1) {
+  __shared__ unsigned int hist[3 * MAXLAB];
+  for (int i = threadIdx.x; i < 3 * nlab1; i += BLK) hist[i] = 0u;
+  __syncthreads();
+  const int64_t V = (int64_t)D * H * W;
+  for (int64_t v = (int64_t)blockIdx.x * BLK + threadIdx.x; v < V; v += (int64_t)gridDim.x * BLK) {
+    const int xi = (int)(v % W);
+    const int64_t t2 = v / W;
+    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
+    const float zr = rintf((float)zi + flow[v * 3 + 0]);
+    const float yr = rintf((float)yi + flow[v * 3 + 1]);
+    const float xr = rintf((float)xi + flow[v * 3 + 2]);
+    int lab = 0;
+    if (zr >= 0.f && zr < (float)D && yr >= 0.f && yr < (float)H && xr >= 0.f && xr < (float)W)
+      lab = lm[((int64_t)zr * H + (int64_t)yr) * W + (int64_t)xr];
+    if (warped) warped[v] = (int16_t)lab;
+    const int tl = lf[v];
+    if (lab >= 0 && lab < nlab1) atomicAdd(&hist[lab], 1u);
+    if (tl >= 0 && tl < nlab1) atomicAdd(&hist[nlab1 + tl], 1u);
+    if (lab == tl && lab >= 0 && lab < nlab1) atomicAdd(&hist[2 * nlab1 + lab], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * nlab1; i += BLK)
+    if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline int pick_cpt(int C) { return (C % 4 == 0) ? 4 : (C % 3 == 0 ? 3 : 1); }
+
+}  // namespace
+
+#define DISPATCH_CPT(cpt, KERNEL, grid, stream, ...)                                                       \
+  do {                                                                                                     \
+    if ((cpt) == 4) hipLaunchKernelGGL(KERNEL<4>, dim3(grid), dim3(BLK), 0, stream, __VA_ARGS__);          \
+    else if ((cpt) == 3) hipLaunchKernelGGL(KERNEL<3>, dim3(grid), dim3(BLK), 0, stream, __VA_ARGS__);     \
+    else hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(BLK), 0, stream, __VA_ARGS__);                     \
+  } while (0)
+
+extern "C" {
+
+int modet_warp_fwd(const float* src, const float* flow, float* out, int B, int D, int H, int W, int C, int mode,
+                   int add_flow, modet_stream_t stream) {
+  MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(out);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
+  if (mode != 0 && mode != 1) return MODET_ERR_UNSUPPORTED;
+  if (add_flow && (C != 3 || mode != 0)) return MODET_ERR_DIM;
+  const int cpt = pick_cpt(C), G = C / cpt;
+  const int64_t total = (int64_t)B * D * H * W * G;
+  DISPATCH_CPT(cpt, warp_fwd_kernel, flat_grid(total, BLK), (hipStream_t)stream, src, flow, out, D, H, W, C, G, total,
+               mode, add_flow);
+  return modet_launch_status();
+}
+
+int modet_warp_bwd(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow, int B, int D,
+                   int H, int W, int C, int add_flow, modet_stream_t stream) {
+  MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(d_out);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
+  if (add_flow && C != 3) return MODET_ERR_DIM;
+  if (!d_src && !d_flow) return MODET_OK;
+  const int cpt = pick_cpt(C), G = C / cpt;
+  if (!pow2(G) || G > 64) return MODET_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (d_src) {
+    hipError_t e = hipMemsetAsync(d_src, 0, (size_t)B * D * H * W * C * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int64_t total = (int64_t)B * D * H * W * G;
+  DISPATCH_CPT(cpt, warp_bwd_kernel, flat_grid(total, BLK), s, src, flow, d_out, d_src, d_flow, D, H, W, C, G, total,
+               add_flow);
+  return modet_launch_status();
+}
+
+int modet_upsample2_fwd(const float* x, float* y, int B, int d, int h, int w, int C, float scale,
+                        modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(y);
+  MODET_CHECK_DIM(B > 0 && d > 0 && h > 0 && w > 0 && C > 0);
+  const int cpt = pick_cpt(C), G = C / cpt;
+  const int64_t total = (int64_t)B * 8 * d * h * w * G;
+  DISPATCH_CPT(cpt, upsample2_fwd_kernel, flat_grid(total, BLK), (hipStream_t)stream, x, y, d, h, w, C, G, total,
+               scale);
+  return modet_launch_status();
+}
+
+int modet_upsample2_bwd(const float* d_y, float* d_x, int B, int d, int h, int w, int C, float scale,
+                        modet_stream_t stream) {
+  MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_x);
+  MODET_CHECK_DIM(B > 0 && d > 0 && h > 0 && w > 0 && C > 0);
+  const int cpt = pick_cpt(C), G = C / cpt;
+  const int64_t total = (int64_t)B * d * h * w * G;
+  DISPATCH_CPT(cpt, upsample2_bwd_kernel, flat_grid(total, BLK), (hipStream_t)stream, d_y, d_x, d, h, w, C, G, total,
+               scale);
+  return modet_launch_status();
+}
+
+int modet_ncdhw_to_cl(const float* x, float* y, int B, int C, int64_t V, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(y);
+  MODET_CHECK_DIM(B > 0 && C > 0 && V > 0);
+  const int64_t total = (int64_t)B * V;
+  hipLaunchKernelGGL(ncdhw_to_cl_kernel, dim3(flat_grid(total, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, y, C, V,
+                     total);
+  return modet_launch_status();
+}
+
+int modet_cl_to_ncdhw(const float* x, float* y, int B, int C, int64_t V, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(y);
+  MODET_CHECK_DIM(B > 0 && C > 0 && V > 0);
+  const int64_t total = (int64_t)B * V;
+  hipLaunchKernelGGL(cl_to_ncdhw_kernel, dim3(flat_grid(total, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, y, C, V,
+                     total);
+  return modet_launch_status();
+}
+
+#define DISPATCH_HEADS(KERNEL, ...)                                                                               \
+  switch (heads) {                                                                                                \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(flat_grid(N, BLK)), dim3(BLK), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(flat_grid(N, BLK)), dim3(BLK), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(flat_grid(N, BLK)), dim3(BLK), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(flat_grid(N, BLK)), dim3(BLK), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    default: return MODET_ERR_UNSUPPORTED;                                                                        \
+  }
+
+int modet_cwm_tail_fwd(const float* x, const float* logits, float* out, int64_t N, int heads, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(logits); MODET_CHECK_PTR(out);
+  MODET_CHECK_DIM(N > 0 && heads > 0);
+  DISPATCH_HEADS(cwm_tail_fwd_kernel, x, logits, out, N);
+  return modet_launch_status();
+}
+
+int modet_cwm_tail_bwd(const float* x, const float* logits, const float* d_out, float* d_x, float* d_logits,
+                       int64_t N, int heads, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(logits); MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(d_logits);
+  MODET_CHECK_DIM(N > 0 && heads > 0);
+  DISPATCH_HEADS(cwm_tail_bwd_kernel, x, logits, d_out, d_x, d_logits, N);
+  return modet_launch_status();
+}
+
+int modet_label_warp_counts(const int16_t* lab_moving, const float* flow, const int16_t* lab_fixed, int16_t* warped,
+                            int64_t* counts, int D, int H, int W, int nlabels, modet_stream_t stream) {
+  MODET_CHECK_PTR(lab_moving); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(lab_fixed); MODET_CHECK_PTR(counts);
+  MODET_CHECK_DIM(D > 0 && H > 0 && W > 0 && nlabels > 0);
+  if (nlabels + 1 > MAXLAB) return MODET_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)3 * (nlabels + 1) * sizeof(int64_t), s);
+  if (e != hipSuccess) return (int)e;
+  const int64_t V = (int64_t)D * H * W;
+  int grid = flat_grid(V, BLK);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(label_warp_counts_kernel, dim3(grid), dim3(BLK), 0, s, lab_moving, flow, lab_fixed, warped,
+                     (unsigned long long*)counts, D, H, W, nlabels + 1);
+  return modet_launch_status();
+}
+
+}  // extern "C"

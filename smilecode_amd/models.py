@@ -1,0 +1,287 @@
+"""Drop-in ``ModeT`` / ``ModeT_cu`` modules for the MI355X-native hot path.
+
+Same constructor signature, attribute names, ``forward(moving, fixed) -> (y_moved, flow)``
+contract and state_dict keys as the reference (ModeT/models.py:338-412, ModeT-cu/models.py:
+319-393), so train.py / infer.py / existing checkpoints work unchanged.  What differs is
+underneath: every op is a hand-written HIP kernel behind libmodet_hip.so (smilecode_amd.ops),
+activations are channels-last, moving+fixed go through the shared encoder as one batch, the
+neighbourhood attention is a single fused kernel, and the SpatialTransformer computes its
+identity grid in-kernel instead of keeping a 59 MB buffer per level.
+
+state_dict compatibility:
+  * parameters: identical names/shapes (``encoder.conv0.0.main.weight`` ... ``cwm5.conv.2.bias``);
+  * ``mdtN.grid`` (3,3,3,3) [ModeT] / ``mdtN.v`` (27,3) [ModeT_cu]: kept as buffers, either flavour loads;
+  * ``transformer.N.grid``: accepted and dropped on load; not emitted on save unless
+    ``legacy_grid_buffers=True`` (then regenerated so the reference can load our checkpoints strictly).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class SpatialTransformer(nn.Module):
+    """N-D spatial transformer (reference ModeT/models.py:25-67), NCDHW in / NCDHW out.
+
+    ``forward(src, flow)``: src (B,C,D,H,W), flow (B,3,D,H,W) in voxels.  mode 'bilinear' | 'nearest'."""
+
+    def __init__(self, size, mode="bilinear", legacy_grid_buffers=False):
+        super().__init__()
+        self.size = tuple(int(s) for s in size)
+        self.mode = mode
+        self.legacy_grid_buffers = legacy_grid_buffers
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "grid", None)          # reference checkpoints carry it (models.py:47)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self.legacy_grid_buffers:
+            vec = [torch.arange(0, s) for s in self.size]
+            grid = torch.stack(torch.meshgrid(vec, indexing="ij")).unsqueeze(0).float()
+            destination[prefix + "grid"] = grid
+
+    def forward(self, src, flow):
+        out = ops.warp(ops.to_channels_last(src.contiguous()), ops.to_channels_last(flow.contiguous()),
+                       0 if self.mode == "bilinear" else 1, False)
+        return ops.to_ncdhw(out)
+
+    def forward_cl(self, src_cl, flow_cl, add_flow=False):
+        return ops.warp(src_cl, flow_cl, 0 if self.mode == "bilinear" else 1, add_flow)
+
+
+class _Conv3dParams(nn.Module):
+    """parameter holder with nn.Conv3d's names, shapes and default init (weight (Cout,Cin,3,3,3), bias)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3, 3))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(cin * 27)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class ConvBlock(nn.Module):
+    """conv + LeakyReLU(0.1) (reference models.py:119-133); channels-last in/out."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.main = _Conv3dParams(in_channels, out_channels)
+
+    def forward(self, x):
+        return ops.conv3d(x, self.main.weight, self.main.bias, True)
+
+
+class ConvInsBlock(nn.Module):
+    """conv + InstanceNorm3d + LeakyReLU(0.1) (reference models.py:135-151); channels-last in/out."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.main = _Conv3dParams(in_channels, out_channels)
+
+    def forward(self, x):
+        return ops.instnorm_lrelu(ops.conv3d(x, self.main.weight, self.main.bias, False))
+
+
+class _AvgPool(nn.Module):
+    def forward(self, x):
+        return ops.avgpool2(x)
+
+
+class Encoder(nn.Module):
+    """five-level conv pyramid (reference models.py:181-228); channels-last in/out."""
+
+    def __init__(self, in_channel=1, first_out_channel=4):
+        super().__init__()
+        c = first_out_channel
+        self.conv0 = nn.Sequential(ConvBlock(in_channel, c), ConvInsBlock(c, 2 * c), ConvInsBlock(2 * c, 2 * c))
+        self.conv1 = nn.Sequential(_AvgPool(), ConvInsBlock(2 * c, 4 * c), ConvInsBlock(4 * c, 4 * c))
+        self.conv2 = nn.Sequential(_AvgPool(), ConvInsBlock(4 * c, 8 * c), ConvInsBlock(8 * c, 8 * c))
+        self.conv3 = nn.Sequential(_AvgPool(), ConvInsBlock(8 * c, 16 * c), ConvInsBlock(16 * c, 16 * c))
+        self.conv4 = nn.Sequential(_AvgPool(), ConvInsBlock(16 * c, 32 * c), ConvInsBlock(32 * c, 32 * c))
+
+    def forward(self, x):
+        out0 = self.conv0(x)
+        out1 = self.conv1(out0)
+        out2 = self.conv2(out1)
+        out3 = self.conv3(out2)
+        out4 = self.conv4(out3)
+        return out0, out1, out2, out3, out4
+
+
+class _LinearParams(nn.Module):
+    def __init__(self, cin, dim):
+        super().__init__()
+        # reference init: weight ~ N(0, 1e-5), bias 0 (models.py:235-236)
+        self.weight = nn.Parameter(torch.randn(dim, cin) * 1e-5)
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _LayerNormParams(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class ProjectionLayer(nn.Module):
+    """Linear + LayerNorm (reference models.py:230-241); channels-last (B,D,H,W,C) -> (B,D,H,W,dim)."""
+
+    def __init__(self, in_channels, dim=6):
+        super().__init__()
+        self.norm = _LayerNormParams(dim)
+        self.proj = _LinearParams(in_channels, dim)
+
+    def forward(self, feat):
+        return ops.proj_ln(feat, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, 1e-5)
+
+
+class CWM(nn.Module):
+    """competitive weighting module (reference models.py:243-275); channels-last."""
+
+    def __init__(self, in_channels, channels):
+        super().__init__()
+        self.num_fields = in_channels // 3
+        # index 3 of the reference Sequential is nn.Softmax (no parameters)
+        self.conv = nn.Sequential(ConvInsBlock(in_channels, channels), ConvInsBlock(channels, channels),
+                                  _Conv3dParams(channels, self.num_fields))
+
+    def forward(self, x):
+        x = ops.upsample2(x, 1.0)
+        h = self.conv[1](self.conv[0](x))
+        logits = ops.conv3d(h, self.conv[2].weight, self.conv[2].bias, False)
+        return ops.cwm_tail(x, logits)
+
+
+class ModeTransformer(nn.Module):
+    """3x3x3 neighbourhood attention whose values are the 27 offsets (reference models.py:278-334)."""
+
+    def __init__(self, dim, num_heads, kernel_size=3, qk_scale=None, use_rpb=True, buffer_flavour="grid"):
+        super().__init__()
+        if kernel_size != 3:
+            raise RuntimeError("ModeTransformer does not support kernel size %d" % kernel_size)
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = qk_scale or self.head_dim ** -0.5
+        self.kernel_size = kernel_size
+        self.use_rpb = use_rpb
+        if use_rpb:
+            self.rpb = nn.Parameter(torch.zeros(num_heads, 3, 3, 3))
+        r = torch.arange(-1, 2)
+        grid = torch.stack(torch.meshgrid(r, r, r, indexing="ij"), -1).float()
+        self.buffer_flavour = buffer_flavour
+        if buffer_flavour == "grid":
+            self.register_buffer("grid", grid)                       # ModeT/models.py:293-296
+        else:
+            self.register_buffer("v", grid.reshape(27, 3))           # ModeT-cu/models.py:294-298
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        have, other = ("grid", "v") if self.buffer_flavour == "grid" else ("v", "grid")
+        if prefix + other in state_dict and prefix + have not in state_dict:
+            t = state_dict.pop(prefix + other)
+            state_dict[prefix + have] = t.reshape(3, 3, 3, 3) if have == "grid" else t.reshape(27, 3)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, q, k):
+        if self.use_rpb:
+            rpb = self.rpb
+        else:
+            rpb = torch.zeros(self.num_heads, 3, 3, 3, dtype=q.dtype, device=q.device)
+        return ops.neighbourhood_attention(q, k, rpb, self.num_heads, self.scale)
+
+
+class ModeT(nn.Module):
+    """reference ModeT/models.py:338-412 (scale=None -> head_dim**-0.5)."""
+
+    _flavour = "grid"
+
+    def __init__(self, inshape=(160, 192, 160), in_channel=1, channels=4, head_dim=6, num_heads=[8, 4, 2, 1, 1],
+                 scale=None, legacy_grid_buffers=False):
+        super().__init__()
+        for s in inshape:
+            if s % 16 != 0:
+                raise RuntimeError("ModeT: every input dimension must be a multiple of 16 (four 2x poolings)")
+        self.channels = channels
+        self.step = 7
+        self.inshape = tuple(inshape)
+        c = channels
+        fl = self._flavour
+        self.encoder = Encoder(in_channel=in_channel, first_out_channel=c)
+        self.projblock1 = ProjectionLayer(2 * c, dim=head_dim * num_heads[4])
+        self.mdt1 = ModeTransformer(head_dim * num_heads[4], num_heads[4], qk_scale=scale, buffer_flavour=fl)
+        self.projblock2 = ProjectionLayer(4 * c, dim=head_dim * num_heads[3])
+        self.mdt2 = ModeTransformer(head_dim * num_heads[3], num_heads[3], qk_scale=scale, buffer_flavour=fl)
+        self.projblock3 = ProjectionLayer(8 * c, dim=head_dim * num_heads[2])
+        self.mdt3 = ModeTransformer(head_dim * num_heads[2], num_heads[2], qk_scale=scale, buffer_flavour=fl)
+        self.cwm3 = CWM(3 * num_heads[2], 3 * num_heads[2] * 2)
+        self.projblock4 = ProjectionLayer(16 * c, dim=head_dim * num_heads[1])
+        self.mdt4 = ModeTransformer(head_dim * num_heads[1], num_heads[1], qk_scale=scale, buffer_flavour=fl)
+        self.cwm4 = CWM(3 * num_heads[1], 3 * num_heads[1] * 2)
+        self.projblock5 = ProjectionLayer(32 * c, dim=head_dim * num_heads[0])
+        self.mdt5 = ModeTransformer(head_dim * num_heads[0], num_heads[0], qk_scale=scale, buffer_flavour=fl)
+        self.cwm5 = CWM(3 * num_heads[0], 3 * num_heads[0] * 2)
+        self.transformer = nn.ModuleList(
+            [SpatialTransformer([s // 2 ** i for s in inshape], legacy_grid_buffers=legacy_grid_buffers)
+             for i in range(4)])
+
+    def forward(self, moving, fixed):
+        if moving.shape != fixed.shape or moving.dim() != 5:
+            raise RuntimeError("ModeT.forward expects two (B,C,D,H,W) volumes of the same shape")
+        B = moving.shape[0]
+        mov_cl = ops.to_channels_last(moving.contiguous())
+        fix_cl = ops.to_channels_last(fixed.contiguous())
+        # shared encoder on both images as one batch (InstanceNorm is per sample, so this is exact)
+        feats = self.encoder(torch.cat([mov_cl, fix_cl], 0))
+        M = [f[:B] for f in feats]
+        Fx = [f[B:] for f in feats]
+        ST = self.transformer
+
+        q5, k5 = self.projblock5(Fx[4]), self.projblock5(M[4])
+        flow = self.cwm5(self.mdt5(q5, k5))
+
+        M4 = ST[3].forward_cl(M[3], flow)
+        q4, k4 = self.projblock4(Fx[3]), self.projblock4(M4)
+        w = self.cwm4(self.mdt4(q4, k4))
+        flow = ST[2].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
+
+        M3 = ST[2].forward_cl(M[2], flow)
+        q3, k3 = self.projblock3(Fx[2]), self.projblock3(M3)
+        w = self.cwm3(self.mdt3(q3, k3))
+        flow = ST[1].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
+
+        M2 = ST[1].forward_cl(M[1], flow)
+        q2, k2 = self.projblock2(Fx[1]), self.projblock2(M2)
+        w = self.mdt2(q2, k2)
+        flow = ops.upsample2(ST[1].forward_cl(flow, w, add_flow=True), 2.0)
+
+        M1 = ST[0].forward_cl(M[0], flow)
+        q1, k1 = self.projblock1(Fx[0]), self.projblock1(M1)
+        w = self.mdt1(q1, k1)
+        flow = ST[0].forward_cl(flow, w, add_flow=True)
+
+        y_moved = ST[0].forward_cl(mov_cl, flow)
+        return ops.to_ncdhw(y_moved), ops.to_ncdhw(flow)
+
+
+class ModeT_cu(ModeT):
+    """reference ModeT-cu/models.py:319-393: same network, ``scale=1`` default, ``mdtN.v`` buffers."""
+
+    _flavour = "v"
+
+    def __init__(self, inshape=(160, 192, 160), in_channel=1, channels=4, head_dim=6, num_heads=[8, 4, 2, 1, 1],
+                 scale=1, legacy_grid_buffers=False):
+        super().__init__(inshape, in_channel, channels, head_dim, num_heads, scale, legacy_grid_buffers)
+
+
+def load_numpy_weights(model: nn.Module, weights) -> None:
+    """copy a name -> ndarray dict (smilecode_amd.synth.make_weights) into the model's parameters"""
+    params = dict(model.named_parameters())
+    with torch.no_grad():
+        for name, arr in weights.items():
+            params[name].copy_(torch.from_numpy(arr).to(params[name].device))

@@ -1,0 +1,558 @@
+"""Torch-facing operators of the ModeT hot path: thin autograd wrappers over libmodet_hip.so.
+
+PyTorch is plumbing here (device memory from the caching allocator, the current HIP
+stream, autograd's tape); every arithmetic kernel is hand-written HIP behind the C ABI of
+include/modet_hip.h.  Activations are channels-last ``(B, D, H, W, C)`` fp32, contiguous.
+There is no eager / CPU fallback: a missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+LRELU_SLOPE = 0.1
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("smilecode_amd: tensor must live on the GPU (the HIP path has no CPU fallback)")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"smilecode_amd: expected float32, got {t.dtype}")
+        if not t.is_contiguous():
+            raise RuntimeError("smilecode_amd: tensor must be contiguous")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes, like):
+    return torch.empty((int(nbytes) + 3) // 4 + 1, dtype=torch.float32, device=like.device)
+
+
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's live roofline leg).
+    ``select`` = None times every tagged launch, or a set of tags to time only those."""
+
+    def __init__(self, select=None):
+        self.select = select
+        self.records = []          # (tag, flops, bytes, start_event, end_event)
+
+    def summary(self):
+        """tag -> dict(calls, ms, flops, bytes); synchronises the events it reads"""
+        out = {}
+        for tag, fl, by, e0, e1 in self.records:
+            e1.synchronize()
+            d = out.setdefault(tag, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+_TIMER = None
+
+
+def set_kernel_timer(timer):
+    """install / remove (None) the KernelTimer consulted by every launch below"""
+    global _TIMER
+    _TIMER = timer
+
+
+class _Guard:
+    """make x's device current for the launch (autograd worker threads, multi-GPU hosts); when a
+    KernelTimer is installed, bracket the launch with HIP events on the current stream."""
+
+    def __init__(self, t, tag=None, flops=0.0, nbytes=0.0):
+        self.idx = t.device.index
+        self.prev = None
+        self.tag, self.flops, self.nbytes = tag, flops, nbytes
+        self.e0 = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+        tm = _TIMER
+        if tm is not None and self.tag is not None and (tm.select is None or self.tag in tm.select):
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _TIMER.records.append((self.tag, self.flops, self.nbytes, self.e0, e1))
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+# ------------------------------------------------------------------------------------------------ raw calls
+def conv3d_forward(x, w, b, act):
+    _chk(x, w, b)
+    B, D, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, Cin, 3, 3, 3):
+        raise RuntimeError(f"conv3d: weight {tuple(w.shape)} does not match input channels {Cin}")
+    y = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=x.device)
+    L = _L()
+    nb = L.modet_conv3d_ws_bytes(Cin, Cout)
+    ws = _ws(nb, x)
+    n = float(B) * D * H * W
+    with _Guard(x, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+        _lib.check(L.modet_conv3d_fwd(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, B, D, H, W, Cin, Cout, int(act),
+                                      _stream()), "modet_conv3d_fwd")
+    return y
+
+
+def conv3d_backward_data(dy, w, Cin):
+    _chk(dy, w)
+    B, D, H, W, Cout = dy.shape
+    dx = torch.empty((B, D, H, W, Cin), dtype=torch.float32, device=dy.device)
+    L = _L()
+    nb = L.modet_conv3d_ws_bytes(Cin, Cout)
+    ws = _ws(nb, dy)
+    n = float(B) * D * H * W
+    with _Guard(dy, f"conv_dgrad[{Cout}->{Cin}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+        _lib.check(L.modet_conv3d_bwd_data(_p(dy), _p(w), _p(dx), _p(ws), nb, B, D, H, W, Cin, Cout, _stream()),
+                   "modet_conv3d_bwd_data")
+    return dx
+
+
+def conv3d_backward_weight(x, dy, want_bias):
+    _chk(x, dy)
+    B, D, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    L = _L()
+    nb = L.modet_conv3d_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)
+    ws = _ws(nb, x)
+    n = float(B) * D * H * W
+    with _Guard(x, f"conv_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+        _lib.check(L.modet_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
+                                             _stream()), "modet_conv3d_bwd_weight")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------------------ autograd ops
+class _Conv3d(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        y = conv3d_forward(x, w, b, act)
+        ctx.act = bool(act)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.act:
+            g = torch.empty_like(dy)
+            with _Guard(dy, "lrelu_bwd", dy.numel(), 12.0 * dy.numel()):
+                _lib.check(_L().modet_lrelu_bwd(_p(dy), _p(y), _p(g), dy.numel(), _stream()), "modet_lrelu_bwd")
+            dy = g
+        dx = conv3d_backward_data(dy, w, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias)
+        return dx, dw, db, None
+
+
+def conv3d(x, w, b=None, act=False):
+    """3x3x3 conv, zero pad 1 (+ fused LeakyReLU(0.1) if act).  reference: nn.Conv3d, models.py:127,:144,:254"""
+    return _Conv3d.apply(x, w, b, act)
+
+
+class _InstNormLReLU(Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        _chk(x)
+        B, C = x.shape[0], x.shape[-1]
+        V = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        L = _L()
+        nb = L.modet_instnorm_ws_bytes(B, V, C)
+        ws = _ws(nb, x)
+        with _Guard(x, "instnorm_lrelu_fwd", 8.0 * x.numel(), 8.0 * x.numel()):
+            _lib.check(L.modet_instnorm_lrelu_fwd(_p(x), _p(y), _p(mean), _p(rstd), _p(ws), nb, B, V, C, eps,
+                                                  _stream()), "modet_instnorm_lrelu_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        V = x.numel() // (B * C)
+        dx = torch.empty_like(x)
+        L = _L()
+        nb = L.modet_instnorm_ws_bytes(B, V, C)
+        ws = _ws(nb, x)
+        with _Guard(x, "instnorm_lrelu_bwd", 14.0 * x.numel(), 12.0 * x.numel()):
+            _lib.check(L.modet_instnorm_lrelu_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C,
+                                                  _stream()), "modet_instnorm_lrelu_bwd")
+        return dx, None
+
+
+def instnorm_lrelu(x, eps=1e-5):
+    """InstanceNorm3d(affine=False) + LeakyReLU(0.1), channels-last.  reference: models.py:144-150"""
+    return _InstNormLReLU.apply(x, eps)
+
+
+class _AvgPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        B, D, H, W, C = x.shape
+        y = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+        with _Guard(x, "avgpool2_fwd", x.numel(), 4.5 * x.numel()):
+            _lib.check(_L().modet_avgpool2_fwd(_p(x), _p(y), B, D, H, W, C, _stream()), "modet_avgpool2_fwd")
+        ctx.shape = (B, D, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, D, H, W, C = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        with _Guard(dy, "avgpool2_bwd", dx.numel(), 4.5 * dx.numel()):
+            _lib.check(_L().modet_avgpool2_bwd(_p(dy), _p(dx), B, D, H, W, C, _stream()), "modet_avgpool2_bwd")
+        return dx
+
+
+def avgpool2(x):
+    """nn.AvgPool3d(2), channels-last.  reference: models.py:201,:207,:213,:219"""
+    return _AvgPool2.apply(x)
+
+
+class _ProjLN(Function):
+    @staticmethod
+    def forward(ctx, x, Wt, b, gamma, beta, eps):
+        _chk(x, Wt, b, gamma, beta)
+        Cin = x.shape[-1]
+        dim = Wt.shape[0]
+        N = x.numel() // Cin
+        y = torch.empty(x.shape[:-1] + (dim,), dtype=torch.float32, device=x.device)
+        with _Guard(x, f"proj_ln_fwd[{Cin}->{dim}]", N * (2.0 * Cin * dim + 8.0 * dim), 4.0 * N * (Cin + dim)):
+            _lib.check(_L().modet_proj_ln_fwd(_p(x), _p(Wt), _p(b), _p(gamma), _p(beta), _p(y), N, Cin, dim, eps,
+                                              _stream()), "modet_proj_ln_fwd")
+        ctx.save_for_backward(x, Wt, b, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wt, b, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cin = x.shape[-1]
+        dim = Wt.shape[0]
+        N = x.numel() // Cin
+        dx = torch.empty_like(x)
+        dW, db, dg, dbeta = torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma), torch.empty_like(gamma)
+        L = _L()
+        nb = L.modet_proj_ln_bwd_ws_bytes(N, Cin, dim)
+        ws = _ws(nb, x)
+        with _Guard(x, f"proj_ln_bwd[{Cin}->{dim}]", N * (6.0 * Cin * dim + 20.0 * dim), 4.0 * N * (2 * Cin + dim)):
+            _lib.check(L.modet_proj_ln_bwd(_p(x), _p(Wt), _p(b), _p(gamma), _p(dy), _p(dx), _p(dW), _p(db), _p(dg),
+                                           _p(dbeta), _p(ws), nb, N, Cin, dim, ctx.eps, _stream()), "modet_proj_ln_bwd")
+        return dx, dW, db, dg, dbeta, None
+
+
+def proj_ln(x, Wt, b, gamma, beta, eps=1e-5):
+    """Linear + LayerNorm on channels-last voxels.  reference: ProjectionLayer, models.py:230-241"""
+    return _ProjLN.apply(x, Wt, b, gamma, beta, eps)
+
+
+class _NA(Function):
+    @staticmethod
+    def forward(ctx, q, k, rpb, heads, scale):
+        _chk(q, k, rpb)
+        B, D, H, W, C = q.shape
+        if k.shape != q.shape:
+            raise RuntimeError("neighbourhood attention: q and k shapes differ")
+        hd = C // heads
+        out = torch.empty((B, D, H, W, heads * 3), dtype=torch.float32, device=q.device)
+        nvh = float(B) * D * H * W * heads      # 60 B and ~620 flop per voxel-head
+        with _Guard(q, f"na_fwd[h{heads}]", 620.0 * nvh, 60.0 * nvh):
+            _lib.check(_L().modet_na_fwd(_p(q), _p(k), _p(rpb), _p(out), B, D, H, W, heads, hd, float(scale),
+                                         _stream()), "modet_na_fwd")
+        ctx.save_for_backward(q, k, rpb)
+        ctx.heads, ctx.scale = heads, float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, rpb = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, D, H, W, C = q.shape
+        heads = ctx.heads
+        dq, dk, drpb = torch.empty_like(q), torch.empty_like(k), torch.empty_like(rpb)
+        L = _L()
+        nb = L.modet_na_bwd_ws_bytes(B, D, H, W, heads)
+        ws = _ws(nb, q)
+        nvh = float(B) * D * H * W * heads      # reads q,k,d_out (15 floats), writes d_q,d_k (12)
+        with _Guard(q, f"na_bwd[h{heads}]", 1600.0 * nvh, 108.0 * nvh):
+            _lib.check(L.modet_na_bwd(_p(q), _p(k), _p(rpb), _p(dout), _p(dq), _p(dk), _p(drpb), _p(ws), nb, B, D, H,
+                                      W, heads, C // heads, ctx.scale, _stream()), "modet_na_bwd")
+        return dq, dk, drpb, None, None
+
+
+def neighbourhood_attention(q, k, rpb, heads, scale):
+    """Fused ModeTransformer.forward: (B,D,H,W,heads*6) x2 -> (B,D,H,W,heads*3).  reference: models.py:308-334"""
+    return _NA.apply(q, k, rpb.contiguous(), heads, scale)
+
+
+class _Warp(Function):
+    @staticmethod
+    def forward(ctx, src, flow, mode, add_flow):
+        _chk(src, flow)
+        B, D, H, W, C = src.shape
+        if tuple(flow.shape) != (B, D, H, W, 3):
+            raise RuntimeError(f"warp: flow {tuple(flow.shape)} does not match src {tuple(src.shape)}")
+        out = torch.empty_like(src)
+        n = float(B) * D * H * W                # 4*(2C+3) B per voxel
+        with _Guard(src, f"warp_fwd[C{C}]", n * (24.0 * C + 30.0), 4.0 * n * (2 * C + 3)):
+            _lib.check(_L().modet_warp_fwd(_p(src), _p(flow), _p(out), B, D, H, W, C, mode, int(add_flow), _stream()),
+                       "modet_warp_fwd")
+        ctx.save_for_backward(src, flow)
+        ctx.mode, ctx.add_flow = mode, int(add_flow)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        src, flow = ctx.saved_tensors
+        if ctx.mode != 0:
+            raise RuntimeError("warp: nearest mode is not differentiable")
+        dout = dout.contiguous()
+        B, D, H, W, C = src.shape
+        dsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
+        dflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
+        n = float(B) * D * H * W
+        with _Guard(src, f"warp_bwd[C{C}]", n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6)):
+            _lib.check(_L().modet_warp_bwd(_p(src), _p(flow), _p(dout), _p(dsrc), _p(dflow), B, D, H, W, C,
+                                           ctx.add_flow, _stream()), "modet_warp_bwd")
+        return dsrc, dflow, None, None
+
+
+def warp(src, flow, mode=0, add_flow=False):
+    """SpatialTransformer on channels-last tensors; add_flow -> warp(src,flow)+flow.  reference: models.py:25-67"""
+    return _Warp.apply(src, flow, mode, add_flow)
+
+
+class _Upsample2(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        _chk(x)
+        B, d, h, w, C = x.shape
+        y = torch.empty((B, 2 * d, 2 * h, 2 * w, C), dtype=torch.float32, device=x.device)
+        with _Guard(x, f"upsample2_fwd[C{C}]", 16.0 * y.numel(), 4.0 * (x.numel() + y.numel())):
+            _lib.check(_L().modet_upsample2_fwd(_p(x), _p(y), B, d, h, w, C, float(scale), _stream()),
+                       "modet_upsample2_fwd")
+        ctx.shape, ctx.scale = (B, d, h, w, C), float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, d, h, w, C = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        with _Guard(dy, f"upsample2_bwd[C{C}]", 16.0 * dy.numel(), 4.0 * (dx.numel() + dy.numel())):
+            _lib.check(_L().modet_upsample2_bwd(_p(dy), _p(dx), B, d, h, w, C, ctx.scale, _stream()),
+                       "modet_upsample2_bwd")
+        return dx, None
+
+
+def upsample2(x, scale=1.0):
+    """scale * Upsample(x2, trilinear, align_corners=True), channels-last.  reference: models.py:354,:257-261"""
+    return _Upsample2.apply(x, scale)
+
+
+class _CwmTail(Function):
+    @staticmethod
+    def forward(ctx, x, logits):
+        _chk(x, logits)
+        heads = logits.shape[-1]
+        N = logits.numel() // heads
+        out = torch.empty(logits.shape[:-1] + (3,), dtype=torch.float32, device=x.device)
+        with _Guard(x, "cwm_tail_fwd", 12.0 * x.numel(), 4.0 * (x.numel() + logits.numel() + out.numel())):
+            _lib.check(_L().modet_cwm_tail_fwd(_p(x), _p(logits), _p(out), N, heads, _stream()), "modet_cwm_tail_fwd")
+        ctx.save_for_backward(x, logits)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, logits = ctx.saved_tensors
+        dout = dout.contiguous()
+        heads = logits.shape[-1]
+        N = logits.numel() // heads
+        dx, dl = torch.empty_like(x), torch.empty_like(logits)
+        with _Guard(x, "cwm_tail_bwd", 20.0 * x.numel(), 8.0 * (x.numel() + logits.numel()) + 4.0 * dout.numel()):
+            _lib.check(_L().modet_cwm_tail_bwd(_p(x), _p(logits), _p(dout), _p(dx), _p(dl), N, heads, _stream()),
+                       "modet_cwm_tail_bwd")
+        return dx, dl
+
+
+def cwm_tail(x, logits):
+    """2 * sum_h softmax_h(logits) * x[..., 3h:3h+3].  reference: CWM.forward, models.py:263-275"""
+    return _CwmTail.apply(x, logits)
+
+
+class _ToCL(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        B, C = x.shape[0], x.shape[1]
+        V = x.numel() // (B * C)
+        if C == 1:
+            return x.reshape((B,) + tuple(x.shape[2:]) + (1,))
+        y = torch.empty((B,) + tuple(x.shape[2:]) + (C,), dtype=torch.float32, device=x.device)
+        with _Guard(x, "layout", 0.0, 8.0 * x.numel()):
+            _lib.check(_L().modet_ncdhw_to_cl(_p(x), _p(y), B, C, V, _stream()), "modet_ncdhw_to_cl")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _ToNCDHW.apply(dy.contiguous())
+
+
+class _ToNCDHW(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        B, C = x.shape[0], x.shape[-1]
+        V = x.numel() // (B * C)
+        if C == 1:
+            return x.reshape((B, 1) + tuple(x.shape[1:-1]))
+        y = torch.empty((B, C) + tuple(x.shape[1:-1]), dtype=torch.float32, device=x.device)
+        with _Guard(x, "layout", 0.0, 8.0 * x.numel()):
+            _lib.check(_L().modet_cl_to_ncdhw(_p(x), _p(y), B, C, V, _stream()), "modet_cl_to_ncdhw")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _ToCL.apply(dy.contiguous())
+
+
+def to_channels_last(x):
+    """(B,C,D,H,W) -> (B,D,H,W,C) (a free view when C == 1)"""
+    return _ToCL.apply(x)
+
+
+def to_ncdhw(x):
+    """(B,D,H,W,C) -> (B,C,D,H,W)"""
+    return _ToNCDHW.apply(x)
+
+
+def _scale_by(x, s):
+    y = torch.empty_like(x)
+    with _Guard(x, "scale", x.numel(), 8.0 * x.numel()):
+        _lib.check(_L().modet_scale_by_dev_scalar(_p(x), _p(s), _p(y), x.numel(), _stream()),
+                   "modet_scale_by_dev_scalar")
+    return y
+
+
+class _NCC(Function):
+    @staticmethod
+    def forward(ctx, y_true, y_pred):
+        _chk(y_true, y_pred)
+        if y_true.shape != y_pred.shape or y_true.dim() != 5 or y_true.shape[1] != 1:
+            raise RuntimeError("NCC: expects two (B,1,D,H,W) volumes")
+        B, _, D, H, W = y_true.shape
+        loss = torch.empty(1, dtype=torch.float32, device=y_true.device)
+        need = ctx.needs_input_grad[1]
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("NCC: gradient w.r.t. y_true is not implemented (the fixed image is an input)")
+        dJ = torch.empty_like(y_pred) if need else None
+        L = _L()
+        nb = L.modet_ncc_ws_bytes(B, D, H, W)
+        ws = _ws(nb, y_true)
+        nv = float(y_true.numel())               # reads I,J once, writes d_J once
+        with _Guard(y_true, "ncc_fwd_bwd", 400.0 * nv, 12.0 * nv):
+            _lib.check(L.modet_ncc_fwd_bwd(_p(y_true), _p(y_pred), _p(loss), _p(dJ), _p(ws), nb, B, D, H, W, _stream()),
+                       "modet_ncc_fwd_bwd")
+        ctx.save_for_backward(dJ)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dJ,) = ctx.saved_tensors
+        return None, _scale_by(dJ, g.contiguous().reshape(1))
+
+
+def ncc_loss(y_true, y_pred):
+    """NCC_vxm(win=9): -mean(cc).  reference: losses.py:34-94"""
+    return _NCC.apply(y_true, y_pred)
+
+
+class _Grad3d(Function):
+    @staticmethod
+    def forward(ctx, flow):
+        _chk(flow)
+        if flow.dim() != 5 or flow.shape[1] != 3:
+            raise RuntimeError("Grad3d: expects a (B,3,D,H,W) flow")
+        B, _, D, H, W = flow.shape
+        loss = torch.empty(1, dtype=torch.float32, device=flow.device)
+        df = torch.empty_like(flow) if ctx.needs_input_grad[0] else None
+        L = _L()
+        nb = L.modet_grad3d_ws_bytes(B, D, H, W)
+        ws = _ws(nb, flow)
+        with _Guard(flow, "grad3d_fwd_bwd", 20.0 * flow.numel(), 8.0 * flow.numel()):
+            _lib.check(L.modet_grad3d_fwd_bwd(_p(flow), _p(loss), _p(df), _p(ws), nb, B, D, H, W, _stream()),
+                       "modet_grad3d_fwd_bwd")
+        ctx.save_for_backward(df)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (df,) = ctx.saved_tensors
+        return _scale_by(df, g.contiguous().reshape(1))
+
+
+def grad3d_loss(flow):
+    """Grad3d(penalty='l2') on a planar (B,3,D,H,W) flow.  reference: losses.py:6-31"""
+    return _Grad3d.apply(flow)
+
+
+# ------------------------------------------------------------------------------------------------ non-autograd
+def adam_amsgrad_step_(p, g, m, v, vmax, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """in-place Adam(amsgrad=True) over flat buffers.  reference: train.py:101,:131-133"""
+    _chk(p, g, m, v, vmax)
+    with _Guard(p, "adam_amsgrad", 12.0 * p.numel(), 28.0 * p.numel()):
+        _lib.check(_L().modet_adam_amsgrad_step(_p(p), _p(g), _p(m), _p(v), _p(vmax), p.numel(), float(lr), beta1,
+                                                beta2, eps, int(step), float(grad_scale), _stream()),
+                   "modet_adam_amsgrad_step")
+
+
+def label_warp_counts(lab_moving, flow_cl, lab_fixed, nlabels=54, want_warped=True):
+    """nearest label warp + Dice voxel counts on the GPU.  lab_* (D,H,W) int16, flow_cl (1,D,H,W,3).
+    reference: utils.py:74-106, infer.py:86-92.  Returns (warped int16 or None, counts int64 (3, nlabels+1))."""
+    if lab_moving.dtype != torch.int16 or lab_fixed.dtype != torch.int16:
+        raise RuntimeError("label_warp_counts: labels must be int16")
+    _chk(flow_cl)
+    D, H, W = lab_moving.shape[-3:]
+    lm, lf = lab_moving.contiguous(), lab_fixed.contiguous()
+    warped = torch.empty((D, H, W), dtype=torch.int16, device=lm.device) if want_warped else None
+    counts = torch.empty((3, nlabels + 1), dtype=torch.int64, device=lm.device)
+    with _Guard(flow_cl):
+        _lib.check(_L().modet_label_warp_counts(_p(lm), _p(flow_cl), _p(lf), _p(warped), _p(counts), D, H, W, nlabels,
+                                                _stream()), "modet_label_warp_counts")
+    return warped, counts

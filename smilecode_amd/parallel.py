@@ -1,0 +1,80 @@
+"""Data-parallel plumbing for the ModeT train step: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference is single-GPU (train.py:183-189).  Volume pairs are independent units
+(InstanceNorm is per sample), so rank r takes pairs r, r+world, ... and the only
+exchange is ONE all-reduce of the flat 4.12 MB gradient buffer per step; its 1/world scale is
+folded into the fused Adam kernel.  Host-side only: no kernels here."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    Returns (rank, local_rank, world).  A single process needs no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def pairs_for_rank(n_pairs: int, rank: int, world: int):
+    """indices of the volume pairs rank `rank` processes (round robin, no data-path collective)"""
+    return list(range(rank, n_pairs, world))
+
+
+class FlatParams:
+    """All parameters (and their gradients) of a module as views into two flat fp32 buffers, so the
+    gradient all-reduce is one collective and the optimizer is one kernel."""
+
+    def __init__(self, module: torch.nn.Module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.params = params
+        n = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        self.offsets = []
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)
+                p.grad = self.grad[off:off + k].view(p.shape)
+                self.offsets.append((off, k))
+                off += k
+        self.numel = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, (off, k) in zip(self.params, self.offsets):     # re-attach if something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + k].view(p.shape)
+
+    def allreduce_grads(self, group=None):
+        """sum over ranks (in place); returns the factor the optimizer must apply (1/world)"""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            return 1.0 / dist.get_world_size(group)
+        return 1.0
+
+
+def broadcast_parameters(flat: FlatParams, src=0, group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat.flat, src=src, group=group)

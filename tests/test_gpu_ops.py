@@ -1,0 +1,314 @@
+"""-m gpu: every HIP kernel of the hot path against (a) the golden vectors captured from the real
+reference (tests/golden/*.npz, fp64) and (b) the CPU oracle (oracle/modet_torch.py) on odd, ragged shapes.
+All calls go through the C ABI (smilecode_amd.ops -> libmodet_hip.so).  Tolerance: fp32 kernels vs an fp64
+reference, |err| <= 2e-5 + 2e-5*|ref| per element unless a test states otherwise (sums over many voxels)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, cl, cu, gold, ncdhw, np64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from smilecode_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import modet_torch
+    return modet_torch
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("tag", ["h1", "h2", "h8", "h4"])
+def test_na_fused_golden(ops, tag):
+    g = gold("op_attention.npz")
+    heads = int(tag[1:])
+    q = cu(g[f"{tag}.q"]).requires_grad_(True)
+    k = cu(g[f"{tag}.k"]).requires_grad_(True)
+    rpb = cu(g[f"{tag}.rpb"]).requires_grad_(True)
+    out = ops.neighbourhood_attention(q, k, rpb, heads, float(g[f"{tag}.scale"]))
+    assert_close(ncdhw(out), g[f"{tag}.out"], what="na out")
+    gy = cl(g[f"{tag}.gy"])
+    dq, dk, drpb = torch.autograd.grad(out, [q, k, rpb], gy)
+    assert_close(np64(dq), g[f"{tag}.dq"], what="na dq")
+    assert_close(np64(dk), g[f"{tag}.dk"], what="na dk")
+    assert_close(np64(drpb), g[f"{tag}.drpb"], atol=1e-4, what="na drpb")
+
+
+@pytest.mark.parametrize("tag", ["h1", "h2", "h8"])
+def test_qk_reference_contract(tag):
+    """modetqkrpb_cu with the CUDA op's tensor contract (ModeT-cu/models.py:304-311, modet_kernel.cu)."""
+    from smilecode_amd.functional import modetqkrpb_cu
+    import torch.nn.functional as F
+    g = gold("op_attention.npz")
+    heads = int(tag[1:])
+    sc = float(g[f"{tag}.scale"])
+    q0, k0 = cu(g[f"{tag}.q"]), cu(g[f"{tag}.k"])
+    B, D, H, W, C = q0.shape
+    d = C // heads
+    rpb = cu(g[f"{tag}.rpb"]).requires_grad_(True)
+    q = (q0.reshape(B, D, H, W, heads, d).permute(0, 4, 1, 2, 3, 5) * sc).contiguous().requires_grad_(True)
+    kp = F.pad(k0.permute(0, 4, 1, 2, 3), (1, 1, 1, 1, 1, 1)).reshape(B, heads, d, D + 2, H + 2, W + 2)
+    kp = kp.permute(0, 1, 3, 4, 5, 2).contiguous().requires_grad_(True)
+    attn = modetqkrpb_cu(q, kp, rpb)
+    assert_close(np64(attn), g[f"{tag}.logits"], what="qk logits")
+    # backward vs plain torch autograd of the same contraction on the CPU in fp64
+    ga = torch.randn(attn.shape, generator=torch.Generator().manual_seed(1)).double()
+    dq, dk, dr = torch.autograd.grad(attn, [q, kp, rpb], ga.float().cuda())
+    qc, kc, rc = (t.detach().double().cpu().requires_grad_(True) for t in (q, kp, rpb))
+    cols = [(qc * kc[:, :, a:a + D, b:b + H, c:c + W]).sum(-1) for a in range(3) for b in range(3) for c in range(3)]
+    ref = torch.stack(cols, -1) + rc.reshape(1, heads, 1, 1, 1, 27)
+    rq, rk, rr = torch.autograd.grad(ref, [qc, kc, rc], ga)
+    assert_close(np64(dq), rq.numpy(), what="qk dq")
+    assert_close(np64(dk), rk.numpy(), what="qk dk (padded)")
+    assert_close(np64(dr), rr.numpy(), atol=1e-4, what="qk drpb")
+    # rpb=None path (modet.cpp:13) returns no bias gradient
+    a2 = modetqkrpb_cu(q, kp, None)
+    assert_close(np64(a2), g[f"{tag}.logits"] - g[f"{tag}.rpb"].reshape(1, heads, 1, 1, 1, 27), what="qk no-bias")
+
+
+@pytest.mark.parametrize("shape,heads", [((9, 7, 21), 1), ((5, 13, 18), 2), ((3, 3, 3), 8), ((2, 1, 2), 4)])
+def test_na_fused_vs_oracle_ragged(ops, orc, shape, heads):
+    """ragged tiles, volumes smaller than the window, all 26 border classes."""
+    gen = torch.Generator().manual_seed(7)
+    C = heads * 6
+    q = torch.randn((2,) + shape + (C,), generator=gen).double().requires_grad_(True)
+    k = torch.randn((2,) + shape + (C,), generator=gen).double().requires_grad_(True)
+    rpb = (0.5 * torch.randn((heads, 3, 3, 3), generator=gen)).double().requires_grad_(True)
+    ref = orc.mode_transformer(q, k, rpb, heads, 0.7)
+    gy = torch.randn(ref.shape, generator=gen).double()
+    rq, rk, rr = torch.autograd.grad(ref, [q, k, rpb], gy)
+    qd, kd, rd = (t.detach().float().cuda().requires_grad_(True) for t in (q, k, rpb))
+    out = ops.neighbourhood_attention(qd, kd, rd, heads, 0.7)
+    assert_close(ncdhw(out), ref.detach().numpy(), what="na out")
+    dq, dk, dr = torch.autograd.grad(out, [qd, kd, rd], gy.permute(0, 2, 3, 4, 1).float().contiguous().cuda())
+    assert_close(np64(dq), rq.numpy(), what="na dq")
+    assert_close(np64(dk), rk.numpy(), what="na dk")
+    assert_close(np64(dr), rr.numpy(), atol=2e-4, what="na drpb")
+
+
+# ------------------------------------------------------------------------------------------------ warp
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_warp_golden(ops, tag):
+    g = gold("op_warp.npz")
+    src = cl(g[f"{tag}.src"]).requires_grad_(True)
+    flow = cl(g[f"{tag}.flow"]).requires_grad_(True)
+    out = ops.warp(src, flow, 0, False)
+    assert_close(ncdhw(out), g[f"{tag}.out"], what="warp out")
+    ds, df = torch.autograd.grad(out, [src, flow], cl(g[f"{tag}.gy"]))
+    assert_close(ncdhw(ds), g[f"{tag}.dsrc"], what="warp dsrc")
+    assert_close(ncdhw(df), g[f"{tag}.dflow"], atol=1e-4, rtol=1e-4, what="warp dflow")
+    outn = ops.warp(cl(g[f"{tag}.lab"]), cl(g[f"{tag}.flow_n"]), 1, False)
+    assert np.array_equal(ncdhw(outn), g[f"{tag}.out_n"]), "nearest warp must be exact"
+
+
+def test_warp_compose_and_wide_channels(ops, orc):
+    gen = torch.Generator().manual_seed(3)
+    for C, shape in ((3, (7, 9, 11)), (64, (4, 5, 6)), (16, (6, 5, 9)), (1, (8, 8, 8))):
+        src = torch.randn((2, C) + shape, generator=gen).double().requires_grad_(True)
+        flow = (2.5 * torch.randn((2, 3) + shape, generator=gen)).double().requires_grad_(True)
+        add = C == 3
+        ref = orc.warp(src, flow) + (flow if add else 0)
+        gy = torch.randn(ref.shape, generator=gen).double()
+        rs, rf = torch.autograd.grad(ref, [src, flow], gy)
+        s, f = cl(src.detach().numpy()).requires_grad_(True), cl(flow.detach().numpy()).requires_grad_(True)
+        out = ops.warp(s, f, 0, add)
+        assert_close(ncdhw(out), ref.detach().numpy(), what=f"warp C={C}")
+        ds, df = torch.autograd.grad(out, [s, f], cl(gy.numpy()))
+        assert_close(ncdhw(ds), rs.numpy(), atol=5e-5, what=f"warp dsrc C={C}")
+        assert_close(ncdhw(df), rf.numpy(), atol=2e-4, rtol=1e-4, what=f"warp dflow C={C}")
+
+
+# ------------------------------------------------------------------------------------------------ projection
+@pytest.mark.parametrize("tag", ["p1", "p3", "p5"])
+def test_projection_golden(ops, tag):
+    g = gold("op_misc.npz")
+    x = cl(g[f"{tag}.x"]).requires_grad_(True)
+    prm = [cu(g[f"{tag}.{n}"]).requires_grad_(True) for n in ("W", "b", "gamma", "beta")]
+    y = ops.proj_ln(x, *prm)
+    assert_close(np64(y), g[f"{tag}.out"], what="proj out")
+    grads = torch.autograd.grad(y, [x] + prm, cu(g[f"{tag}.gy"]))
+    assert_close(ncdhw(grads[0]), g[f"{tag}.dx"], atol=5e-5, what="proj dx")
+    for got, n in zip(grads[1:], ("dW", "db", "dgamma", "dbeta")):
+        assert_close(np64(got), g[f"{tag}.{n}"], atol=2e-4, rtol=1e-4, what=f"proj {n}")
+
+
+@pytest.mark.parametrize("cin,dim,n", [(8, 6, 70001), (16, 6, 5003), (64, 24, 1531)])
+def test_projection_vs_oracle_large(ops, orc, cin, dim, n):
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn((1, cin, 1, 1, n), generator=gen).double().requires_grad_(True)
+    p = {"p.proj.weight": 0.3 * torch.randn((dim, cin), generator=gen).double(),
+         "p.proj.bias": 0.1 * torch.randn(dim, generator=gen).double(),
+         "p.norm.weight": 1 + 0.1 * torch.randn(dim, generator=gen).double(),
+         "p.norm.bias": 0.1 * torch.randn(dim, generator=gen).double()}
+    for t in p.values():
+        t.requires_grad_(True)
+    ref = orc.projection(p, "p", x)
+    gy = torch.randn(ref.shape, generator=gen).double()
+    rg = torch.autograd.grad(ref, [x] + list(p.values()), gy)
+    xd = cl(x.detach().numpy()).requires_grad_(True)
+    pd = [t.detach().float().cuda().requires_grad_(True) for t in p.values()]
+    y = ops.proj_ln(xd, *pd)
+    assert_close(np64(y), ref.detach().numpy(), what="proj out")
+    gd = torch.autograd.grad(y, [xd] + pd, gy.float().cuda())
+    assert_close(ncdhw(gd[0]), rg[0].numpy(), atol=5e-5, what="proj dx")
+    for a, b, nme in zip(gd[1:], rg[1:], ("dW", "db", "dgamma", "dbeta")):
+        assert_close(np64(a), b.numpy(), atol=3e-3, rtol=2e-4, what=f"proj {nme} (sum over {n} voxels)")
+
+
+# ------------------------------------------------------------------------------------------------ conv / norm / pool
+@pytest.mark.parametrize("tag", ["c0", "c1", "c2", "c3"])
+def test_conv_block_golden(ops, tag):
+    g = gold("op_misc.npz")
+    ins = bool(g[f"{tag}.ins"])
+    x = cl(g[f"{tag}.x"]).requires_grad_(True)
+    w = cu(g[f"{tag}.w"]).requires_grad_(True)
+    b = cu(g[f"{tag}.b"]).requires_grad_(True)
+    raw = ops.conv3d(x, w, b, False)
+    assert_close(ncdhw(raw), g[f"{tag}.raw"], what="conv raw")
+    y = ops.instnorm_lrelu(ops.conv3d(x, w, b, False)) if ins else ops.conv3d(x, w, b, True)
+    assert_close(ncdhw(y), g[f"{tag}.out"], what="conv block out")
+    dx, dw, db = torch.autograd.grad(y, [x, w, b], cl(g[f"{tag}.gy"]))
+    assert_close(ncdhw(dx), g[f"{tag}.dx"], atol=5e-5, what="conv dx")
+    assert_close(np64(dw), g[f"{tag}.dw"], atol=2e-4, rtol=1e-4, what="conv dw")
+    # bias gradients under InstanceNorm are analytically 0: absolute tolerance only
+    assert_close(np64(db), g[f"{tag}.db"], atol=2e-4, rtol=1e-4, what="conv db")
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(8, 8, (9, 11, 37)), (4, 8, (6, 8, 16)), (1, 4, (5, 9, 20)),
+                                            (16, 32, (4, 9, 17)), (32, 64, (5, 6, 7)), (64, 128, (3, 5, 6)),
+                                            (128, 128, (2, 3, 10)), (6, 12, (8, 6, 16)), (48, 8, (4, 6, 20)),
+                                            (12, 2, (6, 6, 18)), (24, 48, (3, 4, 5))])
+def test_conv_vs_oracle(ops, cin, cout, shape):
+    """every (Cin,Cout) the model uses, on tile-ragged shapes: fwd, dgrad, wgrad vs ATen-CPU fp64."""
+    gen = torch.Generator().manual_seed(cin * 131 + cout)
+    x = torch.randn((2, cin) + shape, generator=gen).double().requires_grad_(True)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(cin * 27)).double().requires_grad_(True)
+    b = (0.1 * torch.randn(cout, generator=gen)).double().requires_grad_(True)
+    ref = torch.nn.functional.conv3d(x, w, b, padding=1)
+    gy = torch.randn(ref.shape, generator=gen).double()
+    rx, rw, rb = torch.autograd.grad(ref, [x, w, b], gy)
+    xd = cl(x.detach().numpy()).requires_grad_(True)
+    wd, bd = w.detach().float().cuda().requires_grad_(True), b.detach().float().cuda().requires_grad_(True)
+    y = ops.conv3d(xd, wd, bd, False)
+    assert_close(ncdhw(y), ref.detach().numpy(), what="conv fwd")
+    dx, dw, db = torch.autograd.grad(y, [xd, wd, bd], cl(gy.numpy()))
+    assert_close(ncdhw(dx), rx.numpy(), atol=5e-5, what="conv dgrad")
+    assert_close(np64(dw), rw.numpy(), atol=5e-4, rtol=2e-4, what="conv wgrad")
+    assert_close(np64(db), rb.numpy(), atol=5e-4, rtol=2e-4, what="conv dbias")
+
+
+def test_instnorm_large_and_pool(ops):
+    g = gold("op_misc.npz")
+    x = cl(g["pool.x"]).requires_grad_(True)   # C=5 is not a multiple of 4 -> must be refused, not mis-computed
+    with pytest.raises(RuntimeError):
+        ops.avgpool2(x)
+    gen = torch.Generator().manual_seed(5)
+    xx = (torch.randn((2, 8, 10, 12, 38), generator=gen) * 2 + 0.7).double().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(xx, eps=1e-5), 0.1)
+    refp = torch.nn.functional.avg_pool3d(ref, 2)
+    gy = torch.randn(refp.shape, generator=gen).double()
+    rx = torch.autograd.grad(refp, xx, gy)[0]
+    xd = cl(xx.detach().numpy()).requires_grad_(True)
+    y = ops.avgpool2(ops.instnorm_lrelu(xd))
+    assert_close(ncdhw(y), refp.detach().numpy(), what="IN+LReLU+pool")
+    dx = torch.autograd.grad(y, xd, cl(gy.numpy()))[0]
+    assert_close(ncdhw(dx), rx.numpy(), atol=5e-5, what="IN+LReLU+pool dx")
+
+
+def test_upsample_golden(ops):
+    g = gold("op_misc.npz")
+    x = cl(g["up.x"]).requires_grad_(True)
+    y = ops.upsample2(x, 2.0)
+    assert_close(ncdhw(y), g["up.out"], what="upsample")
+    dx = torch.autograd.grad(y, x, cl(g["up.gy"]))[0]
+    assert_close(ncdhw(dx), g["up.dx"], atol=5e-5, what="upsample dx")
+    for C in (6, 24, 1):                     # channel-group variants
+        gen = torch.Generator().manual_seed(C)
+        xx = torch.randn((1, C, 2, 5, 3), generator=gen).double().requires_grad_(True)
+        ref = torch.nn.functional.interpolate(xx, scale_factor=2, mode="trilinear", align_corners=True)
+        gy = torch.randn(ref.shape, generator=gen).double()
+        rx = torch.autograd.grad(ref, xx, gy)[0]
+        xd = cl(xx.detach().numpy()).requires_grad_(True)
+        yd = ops.upsample2(xd, 1.0)
+        assert_close(ncdhw(yd), ref.detach().numpy(), what=f"upsample C={C}")
+        assert_close(ncdhw(torch.autograd.grad(yd, xd, cl(gy.numpy()))[0]), rx.numpy(), atol=5e-5, what="upsample dx")
+
+
+@pytest.mark.parametrize("tag,heads", [("w3", 2), ("w5", 8)])
+def test_cwm_golden(tag, heads):
+    from smilecode_amd.models import CWM
+    g = gold("op_misc.npz")
+    mod = CWM(3 * heads, 6 * heads).cuda()
+    names = [n for n, _ in mod.named_parameters()]
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            p.copy_(cu(g[f"{tag}.p.{n}"]))
+    x = cl(g[f"{tag}.x"]).requires_grad_(True)
+    y = mod(x)
+    assert_close(ncdhw(y), g[f"{tag}.out"], what="cwm out")
+    grads = torch.autograd.grad(y, [x] + list(mod.parameters()), cl(g[f"{tag}.gy"]))
+    assert_close(ncdhw(grads[0]), g[f"{tag}.dx"], atol=5e-5, what="cwm dx")
+    for n, gq in zip(names, grads[1:]):
+        assert_close(np64(gq), g[f"{tag}.g.{n}"], atol=2e-4, rtol=2e-4, what=f"cwm d{n}")
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def test_ncc_golden(ops):
+    g = gold("op_misc.npz")
+    a, b = cu(g["ncc.a"]), cu(g["ncc.b"]).requires_grad_(True)
+    l = ops.ncc_loss(a, b)
+    assert_close(np64(l), g["ncc.val"], atol=2e-5, what="ncc value")
+    db = torch.autograd.grad(l * 1.7, b)[0]
+    assert_close(np64(db), 1.7 * g["ncc.db"], atol=2e-6, rtol=2e-3, what="ncc d y_pred")
+
+
+def test_grad3d_golden(ops):
+    g = gold("op_misc.npz")
+    f = cu(g["g3d.flow"]).requires_grad_(True)
+    l = ops.grad3d_loss(f)
+    assert_close(np64(l), g["g3d.val"], what="grad3d value")
+    df = torch.autograd.grad(l, f)[0]
+    assert_close(np64(df), g["g3d.dflow"], atol=1e-7, rtol=1e-4, what="grad3d dflow")
+
+
+def test_adam_amsgrad(ops, orc):
+    gen = torch.Generator().manual_seed(9)
+    n = 100003
+    p = torch.randn(n, generator=gen)
+    st = {"w": (torch.zeros(n).double(), torch.zeros(n).double(), torch.zeros(n).double())}
+    pr = {"w": p.double().clone()}
+    pd, m, v, vm = p.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=gen) * (0.1 if step == 2 else 1.0)   # step 2: vmax keeps the old max
+        orc.adam_amsgrad_step(pr, {"w": gr.double()}, st, 1e-3, step)
+        ops.adam_amsgrad_step_(pd, gr.cuda(), m, v, vm, 1e-3, step)
+    assert_close(np64(pd), pr["w"].numpy(), atol=1e-6, rtol=1e-6, what="adam params after 3 steps")
+
+
+def test_label_warp_dice_golden(ops):
+    from smilecode_amd import synth
+    from smilecode_amd.utils import dice_from_counts, dice_val_VOI
+    g = gold("op_dice.npz")
+    shape = tuple(int(s) for s in g["shape"])
+    lm = torch.from_numpy(synth.make_labels(shape, 24)).cuda()
+    lf = torch.from_numpy(synth.make_labels(shape, 25)).cuda()
+    flow = cl(g["flow"])
+    warped, counts = ops.label_warp_counts(lm, flow, lf, 54)
+    assert np.array_equal(warped.cpu().numpy(), g["warped"]), "nearest-warped labels must be bit-exact"
+    assert abs(dice_from_counts(counts) - float(g["dice"])) < 1e-9
+    assert abs(float(dice_val_VOI(lm[None, None], lf[None, None])) - float(g["dice_raw"])) < 1e-9
+
+
+def test_errors_are_loud(ops):
+    x = torch.zeros(1, 4, 4, 4, 8)
+    with pytest.raises(RuntimeError):
+        ops.instnorm_lrelu(x)                                # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        ops.neighbourhood_attention(torch.zeros(1, 4, 4, 4, 7, device="cuda"), torch.zeros(1, 4, 4, 4, 7, device="cuda"),
+                                    torch.zeros(1, 27, device="cuda"), 1, 1.0)   # head_dim 7 unsupported
