@@ -131,7 +131,8 @@ def test_forward_vs_oracle_64_batch2():
     with torch.no_grad():
         yr, fr = orc.modet_forward(p, mov.double().cpu(), fix.double().cpu(), (8, 4, 2, 1, 1), 6, 1.0)
     ef = assert_close(np64(flow), fr.numpy(), atol=2e-3, rtol=0, what="flow vs oracle fp64")
-    ey = assert_close(np64(y), yr.numpy(), atol=5e-5, rtol=0, what="y_moved vs oracle fp64")
+    # y_moved inherits |grad(moving)| * flow error (image gradients reach ~0.5/voxel at the mask edge)
+    ey = assert_close(np64(y), yr.numpy(), atol=5e-4, rtol=0, what="y_moved vs oracle fp64")
     _note("fwd[64^3,B=2].flow_maxerr_voxels", ef)
     _note("fwd[64^3,B=2].y_moved_maxerr", ey)
 
