@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
 constexpr int WG_TZ = 2, WG_TY = 8, WG_ROWS = WG_TZ * WG_TY;
 constexpr int WG_HY = WG_TY + 2, WG_HVOX = (WG_TZ + 2) * WG_HY * HX;
 
-template <int CIT>   // 16: one tap per MFMA; 8: two taps per MFMA (rows 0-7 tap 2g, rows 8-15 tap 2g+1)
+template <int CIT>   // input channels per tap in the 16 M rows: 16 -> 1 tap, 8 -> 2 taps, 4 -> 4 taps per MFMA
 __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, int D, int H, int W, int Cin,
                                                             int Cout, int tiles_x, int tiles_y, int tiles_z,
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
   for (int g = 0; g < GPW; ++g) {
     acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int grp = wave * GPW + g;
-    const int tap = grp * TP + (TP == 2 ? (li >> 3) : 0);
+    const int tap = grp * TP + li / CIT;
     aval[g] = (grp < NG) && (tap < 27);
     const int tt = tap < 27 ? tap : 0;
     const int dz = tt / 9, dyy = (tt / 3) % 3, dx = tt % 3;
@@ -201,25 +201,53 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
     const int b = t / tiles_z;
     const int64_t vb = (int64_t)b * D * H * W;
     __syncthreads();
-    for (int idx = tid; idx < WG_HVOX * CIT; idx += NTHR) {
-      const int hv = idx / CIT, cc = idx - hv * CIT;
-      const int hx = hv % HX, t2 = hv / HX;
-      const int hy = t2 % WG_HY, hz = t2 / WG_HY;
-      const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
-      const int c = ci0 + cc;
-      float v = 0.f;
-      if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
-        v = x[(vb + ((int64_t)z * H + yy) * W + xx) * Cin + c];
-      xs[idx] = v;
+    if ((Cin & 3) == 0) {
+      constexpr int Q = CIT / 4;
+      for (int idx = tid; idx < WG_HVOX * Q; idx += NTHR) {
+        const int hv = idx / Q, c4 = idx - hv * Q;
+        const int hx = hv % HX, t2 = hv / HX;
+        const int hy = t2 % WG_HY, hz = t2 / WG_HY;
+        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+        const int c = ci0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
+          v = *reinterpret_cast<const float4*>(x + (vb + ((int64_t)z * H + yy) * W + xx) * Cin + c);
+        *reinterpret_cast<float4*>(xs + hv * CIT + c4 * 4) = v;
+      }
+    } else {
+      for (int idx = tid; idx < WG_HVOX * CIT; idx += NTHR) {
+        const int hv = idx / CIT, cc = idx - hv * CIT;
+        const int hx = hv % HX, t2 = hv / HX;
+        const int hy = t2 % WG_HY, hz = t2 / WG_HY;
+        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+        const int c = ci0 + cc;
+        float v = 0.f;
+        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
+          v = x[(vb + ((int64_t)z * H + yy) * W + xx) * Cin + c];
+        xs[idx] = v;
+      }
     }
-    for (int idx = tid; idx < WG_ROWS * TX * 16; idx += NTHR) {
-      const int vox = idx >> 4, cc = idx & 15;
-      const int row = vox / TX, xx = x0 + vox % TX;
-      const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY;
-      const int co = co0 + cc;
-      float v = 0.f;
-      if (z < D && yy < H && xx < W && co < Cout) v = dy[(vb + ((int64_t)z * H + yy) * W + xx) * Cout + co];
-      dys[idx] = v;
+    if ((Cout & 3) == 0) {
+      for (int idx = tid; idx < WG_ROWS * TX * 4; idx += NTHR) {
+        const int vox = idx >> 2, c4 = idx & 3;
+        const int row = vox / TX, xx = x0 + vox % TX;
+        const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY;
+        const int co = co0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (z < D && yy < H && xx < W && co < Cout)
+          v = *reinterpret_cast<const float4*>(dy + (vb + ((int64_t)z * H + yy) * W + xx) * Cout + co);
+        *reinterpret_cast<float4*>(dys + vox * 16 + c4 * 4) = v;
+      }
+    } else {
+      for (int idx = tid; idx < WG_ROWS * TX * 16; idx += NTHR) {
+        const int vox = idx >> 4, cc = idx & 15;
+        const int row = vox / TX, xx = x0 + vox % TX;
+        const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY;
+        const int co = co0 + cc;
+        float v = 0.f;
+        if (z < D && yy < H && xx < W && co < Cout) v = dy[(vb + ((int64_t)z * H + yy) * W + xx) * Cout + co];
+        dys[idx] = v;
+      }
     }
     __syncthreads();
 #pragma unroll 1
@@ -248,31 +276,31 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
   }
 }
 
-// d_w[co][ci][tap] = sum over workgroups bx, fp64, fixed order
-__global__ void wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cin, int Cout,
-                                      int gx, int gy, int n_ci_tiles, int cit) {
-  const int total = Cout * Cin * 27;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+// d_w[co][ci][tap] = sum over workgroups bx: one wave per element, fixed assignment + fixed tree, fp64
+__global__ __launch_bounds__(64) void wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                            int Cin, int Cout, int gx, int gy, int n_ci_tiles, int cit) {
+  const int i = blockIdx.x;
   const int tap = i % 27, ci = (i / 27) % Cin, co = i / (27 * Cin);
   const int tp = 16 / cit, ng = (27 + tp - 1) / tp;
   const int grp = tap / tp, mrow = (tap % tp) * cit + (ci % cit);
   const int by = (co / 16) * n_ci_tiles + ci / cit;
   double s = 0.0;
-  for (int bx = 0; bx < gx; ++bx) s += (double)part[(((int64_t)bx * gy + by) * ng + grp) * 256 + mrow * 16 + (co % 16)];
-  dw[i] = (float)s;
+  for (int bx = threadIdx.x; bx < gx; bx += 64)
+    s += (double)part[(((int64_t)bx * gy + by) * ng + grp) * 256 + mrow * 16 + (co % 16)];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) dw[i] = (float)s;
 }
 
 // d_bias[c] = sum_n dy[n][c]: per-workgroup partials over a chunk of voxels, then fixed-order fp64
-constexpr int DB_CHUNK = 4096;
+static inline int db_chunk(int C) { return (NTHR / C) * 32; }
 __global__ __launch_bounds__(NTHR) void dbias_partial_kernel(const float* __restrict__ dy, float* __restrict__ part,
-                                                             int64_t N, int C) {
+                                                             int64_t N, int C, int chunk) {
   __shared__ float red[NTHR];
   const int VPB = NTHR / C;
   const int c = threadIdx.x % C, vl = threadIdx.x / C;
   float s = 0.f;
-  const int64_t n0 = (int64_t)blockIdx.x * DB_CHUNK;
-  const int64_t n1 = n0 + DB_CHUNK < N ? n0 + DB_CHUNK : N;
+  const int64_t n0 = (int64_t)blockIdx.x * chunk;
+  const int64_t n1 = n0 + chunk < N ? n0 + chunk : N;
   if (vl < VPB)
     for (int64_t n = n0 + vl; n < n1; n += VPB) s += dy[n * C + c];
   red[threadIdx.x] = s;
@@ -283,20 +311,136 @@ __global__ __launch_bounds__(NTHR) void dbias_partial_kernel(const float* __rest
     part[(int64_t)blockIdx.x * C + threadIdx.x] = r;
   }
 }
-__global__ void dbias_finalize_kernel(const float* __restrict__ part, float* __restrict__ db, int nchunk, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void dbias_finalize_kernel(const float* __restrict__ part, float* __restrict__ db,
+                                                            int nchunk, int C) {
+  const int c = blockIdx.x;
   double s = 0.0;
-  for (int i = 0; i < nchunk; ++i) s += (double)part[(int64_t)i * C + c];
-  db[c] = (float)s;
+  for (int i = threadIdx.x; i < nchunk; i += 64) s += (double)part[(int64_t)i * C + c];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) db[c] = (float)s;
 }
+
+// ------------------------------------------------------------------------------------------------ Cin == 1
+// First encoder conv (1 -> 4): K = 27 is far below an MFMA tile and the op is a pure HBM-bound stencil
+// (reads 4 B, writes 16 B per voxel), so it runs on the VALU: one thread per voxel, all CO outputs in registers.
+template <int CO>
+__global__ __launch_bounds__(NTHR) void conv_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int D,
+                                                           int H, int W, int64_t total, int act) {
+  __shared__ float wsm[27 * CO + CO];
+  for (int i = threadIdx.x; i < 27 * CO; i += NTHR) wsm[(i % 27) * CO + i / 27] = w[i];     // (CO,1,27) -> [tap][co]
+  if (threadIdx.x < CO) wsm[27 * CO + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int64_t V = (int64_t)D * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * NTHR + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NTHR) {
+    const int64_t b = idx / V, v = idx - b * V;
+    const int xi = (int)(v % W);
+    const int64_t t2 = v / W;
+    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = wsm[27 * CO + c];
+#pragma unroll 1
+    for (int dz = 0; dz < 3; ++dz)             // not unrolled: keeps the 27*CO weights in LDS instead of VGPRs
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int zz = zi + dz - 1, yy = yi + dy - 1, xx = xi + dx - 1;
+          float xv = 0.f;
+          if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+            xv = x[b * V + ((int64_t)zz * H + yy) * W + xx];
+          const int tap = (dz * 3 + dy) * 3 + dx;
+#pragma unroll
+          for (int c = 0; c < CO; ++c) acc[c] = fmaf(xv, wsm[tap * CO + c], acc[c]);
+        }
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] = lrelu(acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CO; c += 4)
+      *reinterpret_cast<float4*>(y + idx * CO + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+  }
+}
+
+// d_w[co][tap] = sum_v x[v+off(tap)] * dy[v][co], d_b[co] = sum_v dy[v][co]: 27*CO+CO register accumulators per
+// thread over a grid-stride loop, workgroup reduction, partials -> fixed-order fp64 sum.
+template <int CO>
+__global__ __launch_bounds__(NTHR) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ part, int D, int H, int W,
+                                                             int64_t total) {
+  constexpr int NA = 27 * CO + CO;
+  __shared__ float red[(NTHR / 64) * NA];
+  float acc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+  const int64_t V = (int64_t)D * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * NTHR + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NTHR) {
+    const int64_t b = idx / V, v = idx - b * V;
+    const int xi = (int)(v % W);
+    const int64_t t2 = v / W;
+    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
+    float g[CO];
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) {
+      const float4 gv = *reinterpret_cast<const float4*>(dy + idx * CO + c);
+      g[c] = gv.x; g[c + 1] = gv.y; g[c + 2] = gv.z; g[c + 3] = gv.w;
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[27 * CO + c] += g[c];
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+      for (int dyy = 0; dyy < 3; ++dyy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int zz = zi + dz - 1, yy = yi + dyy - 1, xx = xi + dx - 1;
+          float xv = 0.f;
+          if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+            xv = x[b * V + ((int64_t)zz * H + yy) * W + xx];
+          const int tap = (dz * 3 + dyy) * 3 + dx;
+#pragma unroll
+          for (int c = 0; c < CO; ++c) acc[tap * CO + c] = fmaf(xv, g[c], acc[tap * CO + c]);
+        }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const float r = wave_sum(acc[i]);
+    if (lane == 0) red[wv * NA + i] = r;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NA; i += NTHR) {
+    float r = 0.f;
+    for (int w2 = 0; w2 < NTHR / 64; ++w2) r += red[w2 * NA + i];
+    part[(int64_t)blockIdx.x * NA + i] = r;
+  }
+}
+
+// one wave per output: i < 27*CO -> d_w[co][tap] (i = co*27 + tap), else d_b[i - 27*CO]
+__global__ __launch_bounds__(64) void conv_c1_wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                    float* __restrict__ db, int nblk, int CO) {
+  const int i = blockIdx.x, NA = 27 * CO + CO;
+  const int src = i < 27 * CO ? (i % 27) * CO + i / 27 : i;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[(int64_t)b * NA + src];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) {
+    if (i < 27 * CO) dw[i] = (float)s;
+    else if (db) db[i - 27 * CO] = (float)s;
+  }
+}
+
+constexpr int C1_WG_BLOCKS = 512;
 
 // ------------------------------------------------------------------------------------------------ host side
 struct FwdPlan {
   int cfg;       // 0:A 1:B 2:C 3:D
   int ncb, ck, tz, ty;
 };
-inline FwdPlan plan_fwd(int64_t BV, int Cout) {
+inline FwdPlan plan_fwd(int64_t BV, int Cin, int Cout) {
+  if (Cout <= 16 && Cin <= 4) return {4, 16, 4, 4, 8};
   if (Cout <= 16) return {0, 16, 8, 4, 8};
   if (Cout <= 32 && BV >= 200000) return {1, 32, 4, 4, 8};
   if (Cout <= 64) return {2, 64, 4, 2, 4};
@@ -311,7 +455,7 @@ inline size_t fwd_ws_elems(int Cin, int Cout) {
 
 int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
                 int Cin, int Cout, int act, int pack_mode, hipStream_t s) {
-  const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cout);
+  const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 27 * CinP * CoutP;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
@@ -324,6 +468,7 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
     case 0: CONV_LAUNCH(4, 8, 4, 1, 1, 8); break;
     case 1: CONV_LAUNCH(4, 8, 4, 1, 2, 4); break;
     case 2: CONV_LAUNCH(2, 4, 2, 2, 2, 4); break;
+    case 4: CONV_LAUNCH(4, 8, 4, 1, 1, 4); break;
     default: CONV_LAUNCH(1, 4, 1, 4, 1, 4); break;
   }
 #undef CONV_LAUNCH
@@ -333,7 +478,7 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
 struct WgPlan { int cit, n_ci, n_co, gx, gy, ng, ntiles, tiles_x, tiles_y, tiles_z; };
 inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   WgPlan p;
-  p.cit = Cin <= 8 ? 8 : 16;
+  p.cit = Cin <= 4 ? 4 : (Cin <= 8 ? 8 : 16);
   p.n_ci = cdiv(Cin, p.cit);
   p.n_co = cdiv(Cout, 16);
   p.gy = p.n_ci * p.n_co;
@@ -343,7 +488,7 @@ inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   if (gx < 1) gx = 1;
   if (gx > p.ntiles) gx = p.ntiles;
   p.gx = gx;
-  p.ng = p.cit == 8 ? 14 : 27;
+  p.ng = (27 + 16 / p.cit - 1) / (16 / p.cit);
   return p;
 }
 
@@ -361,6 +506,13 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
+  if (Cin == 1 && (Cout == 4 || Cout == 8)) {
+    const int64_t total = (int64_t)B * D * H * W;
+    const int grid = flat_grid(total, NTHR);
+    if (Cout == 4) hipLaunchKernelGGL(conv_c1_fwd_kernel<4>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, x, w, bias, y, D, H, W, total, act);
+    else hipLaunchKernelGGL(conv_c1_fwd_kernel<8>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, x, w, bias, y, D, H, W, total, act);
+    return modet_launch_status();
+  }
   return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
 }
 
@@ -376,7 +528,9 @@ int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws
 size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
   const int64_t N = (int64_t)B * D * H * W;
-  return ((size_t)p.gx * p.gy * p.ng * 256 + (size_t)cdiv64(N, DB_CHUNK) * Cout) * sizeof(float);
+  size_t fl = (size_t)p.gx * p.gy * p.ng * 256 + (size_t)cdiv64(N, db_chunk(Cout)) * Cout;
+  const size_t c1 = (size_t)C1_WG_BLOCKS * (27 * Cout + Cout);
+  return (fl > c1 ? fl : c1) * sizeof(float);
 }
 
 int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes,
@@ -386,23 +540,35 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
   if (Cout > NTHR) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_conv3d_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  if (Cin == 1 && Cout == 4) {
+    const int64_t total = (int64_t)B * D * H * W;
+    int nblk = (int)cdiv64(total, NTHR);
+    if (nblk > C1_WG_BLOCKS) nblk = C1_WG_BLOCKS;
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<4>, dim3(nblk), dim3(NTHR), 0, s, x, d_y, (float*)ws, D, H, W, total);
+    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(27 * 4 + 4), dim3(64), 0, s, (const float*)ws, d_w, d_bias, nblk, 4);
+    return modet_launch_status();
+  }
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
   float* part = (float*)ws;
   dim3 grid(p.gx, p.gy);
-  if (p.cit == 8)
+  if (p.cit == 4)
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<4>, grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, p.tiles_x,
+                       p.tiles_y, p.tiles_z, p.ntiles, p.n_ci);
+  else if (p.cit == 8)
     hipLaunchKernelGGL(conv3d_wgrad_kernel<8>, grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, p.tiles_x,
                        p.tiles_y, p.tiles_z, p.ntiles, p.n_ci);
   else
     hipLaunchKernelGGL(conv3d_wgrad_kernel<16>, grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, p.tiles_x,
                        p.tiles_y, p.tiles_z, p.ntiles, p.n_ci);
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(cdiv(Cout * Cin * 27, 256)), dim3(256), 0, s, (const float*)part, d_w,
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(Cout * Cin * 27), dim3(64), 0, s, (const float*)part, d_w,
                      Cin, Cout, p.gx, p.gy, p.n_ci, p.cit);
   if (d_bias) {
     const int64_t N = (int64_t)B * D * H * W;
-    const int nchunk = (int)cdiv64(N, DB_CHUNK);
+    const int chunk = db_chunk(Cout);
+    const int nchunk = (int)cdiv64(N, chunk);
     float* bpart = part + (size_t)p.gx * p.gy * p.ng * 256;
-    hipLaunchKernelGGL(dbias_partial_kernel, dim3(nchunk), dim3(NTHR), 0, s, d_y, bpart, N, Cout);
-    hipLaunchKernelGGL(dbias_finalize_kernel, dim3(cdiv(Cout, 64)), dim3(64), 0, s, (const float*)bpart, d_bias, nchunk,
+    hipLaunchKernelGGL(dbias_partial_kernel, dim3(nchunk), dim3(NTHR), 0, s, d_y, bpart, N, Cout, chunk);
+    hipLaunchKernelGGL(dbias_finalize_kernel, dim3(Cout), dim3(64), 0, s, (const float*)bpart, d_bias, nchunk,
                        Cout);
   }
   return modet_launch_status();

@@ -126,16 +126,20 @@ __global__ __launch_bounds__(NTHREADS) void na_fwd_kernel(const float* __restric
   o[0] = o0 * inv; o[1] = o1 * inv; o[2] = o2 * inv;
 }
 
-// ------------------------------------------------------------------------------------------ fused backward
-// d_q by gather from the LDS K tile; d_k by LDS accumulation (ds_add_f32) of dlogit*q into a halo'd tile that
-// is flushed with global float atomics (d_k pre-zeroed); d_rpb partial per workgroup -> workspace.
-__global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                          const float* __restrict__ rpb, const float* __restrict__ dout,
-                                                          float* __restrict__ dq, float* __restrict__ dk,
-                                                          float* __restrict__ drpb_part, int D, int H, int W,
-                                                          int heads, float scale, TileGeom g) {
+// ------------------------------------------------------------------------------------------ backward (two passes)
+// P: one thread per voxel n (forward tiling): softmax recompute, d_q[n], d_rpb partial, and the 27 dlogits written
+//    PLANAR to scratch dl[(b,h)][t][voxel] (27 coalesced streams);
+// C: one thread per voxel m: d_k[m] = sum_t dl[t][m - off(t)] * (scale*q)[m - off(t)], dl read back coalesced
+//    (lanes = consecutive x in plane t), q from an LDS tile with halo 1.
+// No atomics, deterministic; costs 2 x 108 B of HBM traffic per voxel-head but runs at streaming occupancy.
+// (A single-kernel variant that kept the dlogits in LDS -- producers on tile+halo scattering into per-consumer
+// slots -- needed 80 KB LDS per 256 threads, ran at 2 waves/SIMD and measured 1.5x slower at 160x192x160.)
+__global__ __launch_bounds__(NTHREADS) void na_bwd_p_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ rpb, const float* __restrict__ dout,
+                                                            float* __restrict__ dq, float* __restrict__ dl,
+                                                            float* __restrict__ drpb_part, int D, int H, int W,
+                                                            int heads, float scale, TileGeom g) {
   __shared__ __attribute__((aligned(16))) float kt[HVOX * HD];
-  __shared__ __attribute__((aligned(16))) float dkt[HVOX * HD];
   __shared__ float red[27 * (NTHREADS / 64)];
   __shared__ float rp[27];
   const int h = blockIdx.y, b = blockIdx.z;
@@ -144,28 +148,26 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
   int z0, y0, x0;
   tile_origin(blockIdx.x, g, z0, y0, x0);
   if (threadIdx.x < 27) rp[threadIdx.x] = rpb[h * 27 + threadIdx.x];
-  for (int i = threadIdx.x; i < HVOX * HD; i += NTHREADS) dkt[i] = 0.f;
   stage_k_tile(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
   __syncthreads();
-
   const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
   const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
   const bool live = (z < D && y < H && x < W);
-  float dl[27];
+  float dlv[27];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) dl[t] = 0.f;
+  for (int t = 0; t < 27; ++t) dlv[t] = 0.f;
   if (live) {
-    const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+    const int64_t v = ((int64_t)z * H + y) * W + x, n = (int64_t)b * V + v;
     float qs[HD];
     load6(q + n * C + h * HD, qs);
 #pragma unroll
     for (int c = 0; c < HD; ++c) qs[c] *= scale;
     const int lt = (tz * HY + ty) * HX + tx;
-    logits27(kt, lt, qs, rp, dl);
-    const float inv = softmax27(dl);
+    logits27(kt, lt, qs, rp, dlv);
+    const float inv = softmax27(dlv);
     const float* go = dout + n * (heads * 3) + h * 3;
     const float g0 = go[0], g1 = go[1], g2 = go[2];
-    float s = 0.f;
+    float sdot = 0.f;
 #pragma unroll
     for (int ki = 0; ki < 3; ++ki)
 #pragma unroll
@@ -173,12 +175,13 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
           const int t = ki * 9 + kj * 3 + kk;
-          dl[t] *= inv;                                                   // p[t]
-          s += dl[t] * ((float)(ki - 1) * g0 + (float)(kj - 1) * g1 + (float)(kk - 1) * g2);
+          dlv[t] *= inv;
+          sdot += dlv[t] * ((float)(ki - 1) * g0 + (float)(kj - 1) * g1 + (float)(kk - 1) * g2);
         }
     float dqa[HD];
 #pragma unroll
     for (int c = 0; c < HD; ++c) dqa[c] = 0.f;
+    float* dlp = dl + ((int64_t)(b * heads + h) * 27) * V + v;
 #pragma unroll
     for (int ki = 0; ki < 3; ++ki)
 #pragma unroll
@@ -187,26 +190,22 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
         for (int kk = 0; kk < 3; ++kk) {
           const int t = ki * 9 + kj * 3 + kk;
           const float gt = (float)(ki - 1) * g0 + (float)(kj - 1) * g1 + (float)(kk - 1) * g2;
-          const float d = dl[t] * (gt - s);                               // d loss / d logit[t]
-          dl[t] = d;
-          const int lo = (lt + (ki * HY + kj) * HX + kk) * HD;
+          const float d = dlv[t] * (gt - sdot);
+          dlv[t] = d;
+          dlp[(int64_t)t * V] = d;
           float kv[HD];
-          load6(kt + lo, kv);
+          load6(kt + (lt + (ki * HY + kj) * HX + kk) * HD, kv);
 #pragma unroll
-          for (int c = 0; c < HD; ++c) {
-            dqa[c] = fmaf(d, kv[c], dqa[c]);
-            atomicAdd(&dkt[lo + c], d * qs[c]);                           // qs carries the scale
-          }
+          for (int c = 0; c < HD; ++c) dqa[c] = fmaf(d, kv[c], dqa[c]);
         }
     float* dqp = dq + n * C + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) dqp[c] = dqa[c] * scale;
+    for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dqp + c) = make_float2(dqa[c] * scale, dqa[c + 1] * scale);
   }
-  // d_rpb partial of this workgroup: wave shuffle-reduce, then across waves through LDS
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int t = 0; t < 27; ++t) {
-    const float r = wave_sum(dl[t]);
+    const float r = wave_sum(dlv[t]);
     if (lane == 0) red[wv * 27 + t] = r;
   }
   __syncthreads();
@@ -216,36 +215,55 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
     const int64_t blk = ((int64_t)b * gridDim.y + h) * gridDim.x + blockIdx.x;
     drpb_part[blk * 27 + threadIdx.x] = r;
   }
-  // flush the d_k tile
-  for (int idx = threadIdx.x; idx < HVOX * HD; idx += NTHREADS) {
-    const int v = idx / HD, c = idx - v * HD;
-    const int hx = v % HX, t = v / HX;
-    const int hy = t % HY, hz = t / HY;
-    const int zz = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
-    if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      const float val = dkt[idx];
-      if (val != 0.f)
-        atomicAdd(dk + ((int64_t)b * V + ((int64_t)zz * H + yy) * W + xx) * C + h * HD + c, val);
-    }
-  }
 }
 
-// partial (B, heads, nblk, 27) -> out (heads,27): fixed-order sum in double (deterministic)
-__global__ void drpb_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int heads,
-                                     int64_t nblk) {
-  const int h = blockIdx.x, t = threadIdx.x & 31, sl = threadIdx.x >> 5;   // 8 slices x 32 (27 used)
-  __shared__ double acc[8][32];
-  double s = 0.0;
-  if (t < 27)
-    for (int b = 0; b < B; ++b)
-      for (int64_t i = sl; i < nblk; i += 8) s += (double)part[(((int64_t)b * heads + h) * nblk + i) * 27 + t];
-  acc[sl][t] = s;
+__global__ __launch_bounds__(NTHREADS) void na_bwd_c_kernel(const float* __restrict__ q, const float* __restrict__ dl,
+                                                            float* __restrict__ dk, int D, int H, int W, int heads,
+                                                            float scale, TileGeom g) {
+  __shared__ __attribute__((aligned(16))) float qt[HVOX * HD];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int C = heads * HD;
+  const int64_t V = (int64_t)D * H * W;
+  int z0, y0, x0;
+  tile_origin(blockIdx.x, g, z0, y0, x0);
+  stage_k_tile(qt, q, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);      // same staging, q instead of k
   __syncthreads();
-  if (sl == 0 && t < 27) {
-    double r = 0.0;
-    for (int i = 0; i < 8; ++i) r += acc[i][t];
-    out[h * 27 + t] = (float)r;
-  }
+  const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
+  const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+  if (z >= D || y >= H || x >= W) return;
+  const float* dlb = dl + ((int64_t)(b * heads + h) * 27) * V;
+  float acc[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+    for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int nz = z - (ki - 1), ny = y - (kj - 1), nx = x - (kk - 1);      // producer n = m - off(t)
+        if (nz >= 0 && nz < D && ny >= 0 && ny < H && nx >= 0 && nx < W) {
+          const float d = dlb[(int64_t)(ki * 9 + kj * 3 + kk) * V + ((int64_t)nz * H + ny) * W + nx];
+          float qv[HD];
+          load6(qt + (((tz + 2 - ki) * HY + (ty + 2 - kj)) * HX + (tx + 2 - kk)) * HD, qv);
+#pragma unroll
+          for (int c = 0; c < HD; ++c) acc[c] = fmaf(d, qv[c], acc[c]);
+        }
+      }
+  float* dkp = dk + ((int64_t)b * V + ((int64_t)z * H + y) * W + x) * C + h * HD;
+#pragma unroll
+  for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dkp + c) = make_float2(acc[c] * scale, acc[c + 1] * scale);
+}
+
+// partial (B, heads, nblk, 27) -> out (heads,27): one wave per (h,t), fixed assignment + fixed tree in fp64
+__global__ __launch_bounds__(64) void drpb_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                           int B, int heads, int64_t nblk) {
+  const int h = blockIdx.x / 27, t = blockIdx.x % 27;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int64_t i = threadIdx.x; i < nblk; i += 64) s += (double)part[(((int64_t)b * heads + h) * nblk + i) * 27 + t];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[h * 27 + t] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------ reference contract
@@ -400,7 +418,7 @@ int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, i
 
 size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads) {
   const TileGeom g = geom(D, H, W);
-  return (size_t)B * heads * g.tiles_x * g.tiles_y * g.tiles_z * 27 * sizeof(float);
+  return ((size_t)B * heads * g.tiles_x * g.tiles_y * g.tiles_z * 27 + (size_t)B * heads * 27 * D * H * W) * sizeof(float);
 }
 
 int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* d_out, float* d_q, float* d_k,
@@ -411,15 +429,15 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
   if (hd != HD) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_na_bwd_ws_bytes(B, D, H, W, heads)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
   const TileGeom g = geom(D, H, W);
   const int64_t nblk = (int64_t)g.tiles_x * g.tiles_y * g.tiles_z;
-  hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(d_k, 0, (size_t)B * D * H * W * heads * HD * sizeof(float), s);
-  if (e != hipSuccess) return (int)e;
+  float* part = (float*)ws;
+  float* dl = part + (size_t)B * heads * nblk * 27;
   dim3 grid((unsigned)nblk, heads, B);
-  hipLaunchKernelGGL(na_bwd_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, d_out, d_q, d_k, (float*)ws, D, H, W,
-                     heads, scale, g);
-  hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads), dim3(256), 0, s, (const float*)ws, d_rpb, B, heads, nblk);
+  hipLaunchKernelGGL(na_bwd_p_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, d_out, d_q, dl, part, D, H, W, heads, scale, g);
+  hipLaunchKernelGGL(na_bwd_c_kernel, grid, dim3(NTHREADS), 0, s, q, (const float*)dl, d_k, D, H, W, heads, scale, g);
+  hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads * 27), dim3(64), 0, s, (const float*)part, d_rpb, B, heads, nblk);
   return modet_launch_status();
 }
 
@@ -453,7 +471,7 @@ int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad, float* 
     const int64_t nchunk = cdiv64(V, (int64_t)QK_BLOCK * QK_RPB_ITERS);
     hipLaunchKernelGGL(qk_drpb_partial_kernel, dim3((unsigned)nchunk, B * heads), dim3(QK_BLOCK), 0, s, d_attn,
                        (float*)ws, V);
-    hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads), dim3(256), 0, s, (const float*)ws, d_rpb, B, heads, nchunk);
+    hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads * 27), dim3(64), 0, s, (const float*)ws, d_rpb, B, heads, nchunk);
   }
   hipLaunchKernelGGL(qk_dq_kernel, dim3((unsigned)cdiv64(V, QK_BLOCK), B * heads), dim3(QK_BLOCK), 0, s, d_attn, kpad,
                      d_q, D, H, W, hd);

@@ -8,13 +8,15 @@
 namespace {
 
 constexpr int BLK = 256;
-constexpr int CHUNK = 4096;           // voxels per partial-sum workgroup
+// voxels per partial-sum workgroup: 32 passes of the 256/(C/4) voxels one pass covers (keeps the serial
+// loop short at the coarse, wide-channel levels)
+static inline int in_chunk(int C) { return (BLK / (C >> 2)) * 32; }
 
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat), g = dy * lrelu'(xhat)
 template <int MODE>
 __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         float* __restrict__ part, int64_t V, int C) {
+                                                         float* __restrict__ part, int64_t V, int C, int chunk) {
   __shared__ float red[BLK * 8];
   const int G = C >> 2;                        // float4 groups per voxel
   const int VPB = BLK / G;                     // voxels per pass
@@ -27,8 +29,8 @@ __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict
 #pragma unroll
     for (int c = 0; c < 4; ++c) { mu[c] = mean[b * C + g * 4 + c]; rs[c] = rstd[b * C + g * 4 + c]; }
   }
-  const int64_t v0 = (int64_t)blockIdx.x * CHUNK;
-  const int64_t v1 = v0 + CHUNK < V ? v0 + CHUNK : V;
+  const int64_t v0 = (int64_t)blockIdx.x * chunk;
+  const int64_t v1 = v0 + chunk < V ? v0 + chunk : V;
   if (active) {
     for (int64_t v = v0 + vl; v < v1; v += VPB) {
       const int64_t off = ((int64_t)b * V + v) * C + g * 4;
@@ -66,25 +68,25 @@ __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict
 
 // MODE 0: -> mean, rstd.   MODE 1: -> (sum g)/V, (sum g*xhat)/V in out0/out1.
 template <int MODE>
-__global__ void in_finalize_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
-                                   int64_t V, int C, int nchunk, float eps) {
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < nchunk; ++i) {
-      const float* p = part + (((int64_t)b * nchunk + i) * C + c) * 2;
-      s += (double)p[0]; q += (double)p[1];
-    }
-    if (MODE == 0) {
-      const double m = s / (double)V;
-      double var = q / (double)V - m * m;
-      if (var < 0.0) var = 0.0;
-      out0[b * C + c] = (float)m;
-      out1[b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-    } else {
-      out0[b * C + c] = (float)(s / (double)V);
-      out1[b * C + c] = (float)(q / (double)V);
-    }
+__global__ __launch_bounds__(64) void in_finalize_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                         float* __restrict__ out1, int64_t V, int C, int nchunk, float eps) {
+  const int b = blockIdx.y, c = blockIdx.x;       // one wave per (b,c): fixed assignment + fixed tree, fp64
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < nchunk; i += 64) {
+    const float* p = part + (((int64_t)b * nchunk + i) * C + c) * 2;
+    s += (double)p[0]; q += (double)p[1];
+  }
+  s = wave_sum_d(s); q = wave_sum_d(q);
+  if (threadIdx.x != 0) return;
+  if (MODE == 0) {
+    const double m = s / (double)V;
+    double var = q / (double)V - m * m;
+    if (var < 0.0) var = 0.0;
+    out0[b * C + c] = (float)m;
+    out1[b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  } else {
+    out0[b * C + c] = (float)(s / (double)V);
+    out1[b * C + c] = (float)(q / (double)V);
   }
 }
 
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(BLK) void adam_kernel(float* __restrict__ p, const 
 extern "C" {
 
 size_t modet_instnorm_ws_bytes(int B, int64_t V, int C) {
-  const int64_t nchunk = cdiv64(V, CHUNK);
+  const int64_t nchunk = cdiv64(V, in_chunk(C));
   return ((size_t)B * nchunk * C * 2 + (size_t)B * C * 2) * sizeof(float);
 }
 
@@ -215,13 +217,14 @@ int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd,
                              int64_t V, int C, float eps, modet_stream_t stream) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(y); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
-  if (C % 4 != 0 || C > 4 * BLK) return MODET_ERR_UNSUPPORTED;
+  if (C % 4 != 0 || C > 512) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_instnorm_ws_bytes(B, V, C)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int nchunk = (int)cdiv64(V, CHUNK);
+  const int chunk = in_chunk(C);
+  const int nchunk = (int)cdiv64(V, chunk);
   float* part = (float*)ws;
-  hipLaunchKernelGGL(in_partial_kernel<0>, dim3(nchunk, B), dim3(BLK), 0, s, x, nullptr, nullptr, nullptr, part, V, C);
-  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3(B), dim3(128), 0, s, part, mean, rstd, V, C, nchunk, eps);
+  hipLaunchKernelGGL(in_partial_kernel<0>, dim3(nchunk, B), dim3(BLK), 0, s, x, nullptr, nullptr, nullptr, part, V, C, chunk);
+  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3(C, B), dim3(64), 0, s, part, mean, rstd, V, C, nchunk, eps);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total4);
   return modet_launch_status();
@@ -232,15 +235,16 @@ int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean
   MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x);
   MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
-  if (C % 4 != 0 || C > 4 * BLK) return MODET_ERR_UNSUPPORTED;
+  if (C % 4 != 0 || C > 512) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_instnorm_ws_bytes(B, V, C)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int nchunk = (int)cdiv64(V, CHUNK);
+  const int chunk = in_chunk(C);
+  const int nchunk = (int)cdiv64(V, chunk);
   float* part = (float*)ws;
   float* s1 = part + (size_t)B * nchunk * C * 2;
   float* s2 = s1 + (size_t)B * C;
-  hipLaunchKernelGGL(in_partial_kernel<1>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C);
-  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(B), dim3(128), 0, s, part, s1, s2, V, C, nchunk, 0.f);
+  hipLaunchKernelGGL(in_partial_kernel<1>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C, chunk);
+  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2,
                      d_x, V, C, total4);

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(BLK) void proj_ln_bwd_kernel(const float* __restric
 }
 
 // d_W partials for the wide levels: part[chunk][o*Cin + c] = sum_{n in chunk} dz[n][o] * x[n][c]
-constexpr int DW_TILE = 32, DW_CHUNK = 512, DW_MAXP = MAXW / BLK;
+constexpr int DW_TILE = 32, DW_CHUNK = 64, DW_MAXP = MAXW / BLK;
 __global__ __launch_bounds__(BLK) void proj_dw_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                       float* __restrict__ part, int64_t N, int Cin, int DIM) {
   __shared__ float xs[DW_TILE * 128];
@@ -208,18 +208,18 @@ __global__ __launch_bounds__(BLK) void proj_dw_kernel(const float* __restrict__ 
   }
 }
 
-// out[i] = sum_blk part[blk*stride + off + i], fixed order, fp64
-__global__ void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int stride, int off,
-                              int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[i] = sum_blk part[blk*stride + off + i]: one workgroup per output, fixed assignment + fixed tree, fp64
+__global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk,
+                                                     int stride, int off, int n) {
+  const int i = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * stride + off + i];
-  out[i] = (float)s;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[(int64_t)b * stride + off + i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[i] = (float)s;
 }
 
 inline int bwd_grid(int64_t N) {
-  int64_t g = cdiv64(N, (int64_t)BLK * 32);
+  int64_t g = cdiv64(N, (int64_t)BLK);
   if (g > 512) g = 512;
   if (g < 1) g = 1;
   return (int)g;
@@ -284,16 +284,16 @@ int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const 
   else return MODET_ERR_UNSUPPORTED;
 #undef LAUNCH_BWD
   const bool regw = (dim == 6 && (Cin == 8 || Cin == 16));
-  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(64), 0, s, part, d_gamma, grid, npart, 0, dim);
-  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(64), 0, s, part, d_beta, grid, npart, dim, dim);
-  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(64), 0, s, part, d_bias, grid, npart, 2 * dim, dim);
+  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_gamma, grid, npart, 0, dim);
+  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_beta, grid, npart, dim, dim);
+  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_bias, grid, npart, 2 * dim, dim);
   if (regw) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim * Cin, 64)), dim3(64), 0, s, part, d_Wt, grid, npart, 3 * dim,
+    hipLaunchKernelGGL(colsum_kernel, dim3(dim * Cin), dim3(64), 0, s, part, d_Wt, grid, npart, 3 * dim,
                        dim * Cin);
   } else {
     const int nchunk = (int)cdiv64(N, DW_CHUNK);
     hipLaunchKernelGGL(proj_dw_kernel, dim3(nchunk), dim3(BLK), 0, s, x, dz, dwpart, N, Cin, dim);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(dim * Cin, 64)), dim3(64), 0, s, dwpart, d_Wt, nchunk, dim * Cin, 0,
+    hipLaunchKernelGGL(colsum_kernel, dim3(dim * Cin), dim3(64), 0, s, dwpart, d_Wt, nchunk, dim * Cin, 0,
                        dim * Cin);
   }
   return modet_launch_status();

@@ -24,6 +24,31 @@ import torch.nn as nn
 from . import ops
 
 
+class _SplitBatch(torch.autograd.Function):
+    """(2B, ...) -> two (B, ...) views; backward writes both gradients straight into one buffer
+    (plain slicing would zero-fill two full-size tensors and add them)."""
+
+    @staticmethod
+    def forward(ctx, x, B):
+        ctx.B = B
+        return x[:B], x[B:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        B = ctx.B
+        ref = ga if ga is not None else gb
+        out = torch.empty((2 * B,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device)
+        if ga is None:
+            out[:B].zero_()
+        else:
+            out[:B].copy_(ga)
+        if gb is None:
+            out[B:].zero_()
+        else:
+            out[B:].copy_(gb)
+        return out, None
+
+
 class SpatialTransformer(nn.Module):
     """N-D spatial transformer (reference ModeT/models.py:25-67), NCDHW in / NCDHW out.
 
@@ -238,8 +263,9 @@ class ModeT(nn.Module):
         fix_cl = ops.to_channels_last(fixed.contiguous())
         # shared encoder on both images as one batch (InstanceNorm is per sample, so this is exact)
         feats = self.encoder(torch.cat([mov_cl, fix_cl], 0))
-        M = [f[:B] for f in feats]
-        Fx = [f[B:] for f in feats]
+        pairs = [_SplitBatch.apply(f, B) for f in feats]
+        M = [p[0] for p in pairs]
+        Fx = [p[1] for p in pairs]
         ST = self.transformer
 
         q5, k5 = self.projblock5(Fx[4]), self.projblock5(M[4])

@@ -41,7 +41,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.modet_hip_version() >= 100
     assert _lib.strerror(0) == "ok" and "NULL" in _lib.strerror(-1)
     # pure host entry points (no device needed)
-    assert lib.modet_na_bwd_ws_bytes(1, 160, 192, 160, 1) == 10 * 48 * 40 * 27 * 4
+    assert lib.modet_na_bwd_ws_bytes(1, 160, 192, 160, 1) >= 10 * 24 * 80 * 27 * 4
     assert lib.modet_conv3d_ws_bytes(8, 8) >= 27 * 8 * 16 * 4
 
 
