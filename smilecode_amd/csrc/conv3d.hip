@@ -36,30 +36,105 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
-template <int TZ, int TY, int WM, int WN, int NT, int CK>
+// Persistent workgroups walk (tile, Cin-chunk) stages.  Software pipeline: the global loads of stage s+1 (input
+// tile with halo and, when Cin spans several chunks, the weight slab) are issued into registers right after
+// stage s has been written to LDS, i.e. before the MFMA loop of stage s, so HBM/L2 latency hides under the
+// matrix work (PMC before this change: MFMA pipe 54 % busy, 36 % of wave cycles in s_waitcnt/barrier).
+template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4>
 __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ y, int D,
                                                            int H, int W, int Cin, int Cout, int CinP, int CoutP, int act,
-                                                           int tiles_x, int tiles_y, int tiles_z) {
+                                                           int tiles_x, int tiles_y, int tiles_z, int ntiles) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int ROWS = TZ * TY, R = ROWS / WM, NCB = WN * NT * 16;
   constexpr int HZ = TZ + 2, HY = TY + 2, HVOX = HZ * HY * HX;
   constexpr int CS = pad16mod32(HVOX);
   constexpr int NCBS = (NCB % 32 == 16) ? NCB : NCB + 16;
+  constexpr int QX = CK / 4, NXV = (HVOX * QX + NTHR - 1) / NTHR;
+  constexpr int QW = NCB / 4, NWV = (27 * CK * QW + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) float xs[CK * CS];
   __shared__ __attribute__((aligned(16))) float wsm[27 * CK * NCBS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 15, lk = lane >> 4;
-  int t = blockIdx.x;
-  const int x0 = (t % tiles_x) * TX; t /= tiles_x;
-  const int y0 = (t % tiles_y) * TY; t /= tiles_y;
-  const int z0 = (t % tiles_z) * TZ;
-  const int b = t / tiles_z;
   const int cb0 = blockIdx.y * NCB;
-  const int64_t xbase = (int64_t)b * D * H * W;
-  const bool vec4 = (Cin & 3) == 0;
+  constexpr bool vec4 = VEC4;
+  const bool multi = CinP > CK;              // weights change per stage only when Cin spans several chunks
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+
+  float4 xr[NXV], wr[NWV];
+
+  auto load_stage = [&](int tl, int c0, bool with_w) {
+    int t = tl;
+    const int x0 = (t % tiles_x) * TX; t /= tiles_x;
+    const int y0 = (t % tiles_y) * TY; t /= tiles_y;
+    const int z0 = (t % tiles_z) * TZ;
+    const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int idx = tid + i * NTHR;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < HVOX * QX) {
+        const int hv = idx / QX, c4 = idx - hv * QX;
+        const int hx = hv % HX, t2 = hv / HX;
+        const int hy = t2 % HY, hz = t2 / HY;
+        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+        const int c = c0 + c4 * 4;
+        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin) {
+          const float* p = x + (xbase + ((int64_t)z * H + yy) * W + xx) * Cin + c;
+          if (vec4) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (c + 1 < Cin) v.y = p[1];
+            if (c + 2 < Cin) v.z = p[2];
+            if (c + 3 < Cin) v.w = p[3];
+          }
+        }
+      }
+      xr[i] = v;
+    }
+    if (with_w) {
+#pragma unroll
+      for (int i = 0; i < NWV; ++i) {
+        const int idx = tid + i * NTHR;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < 27 * CK * QW) {
+          const int n4 = idx % QW, row = idx / QW;
+          const int tap = row / CK, cc = row - tap * CK;
+          v = *reinterpret_cast<const float4*>(wpk + ((int64_t)(tap * CinP + c0 + cc)) * CoutP + cb0 + n4 * 4);
+        }
+        wr[i] = v;
+      }
+    }
+  };
+
+  auto store_stage = [&](bool with_w) {
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int idx = tid + i * NTHR;
+      if (idx < HVOX * QX) {
+        const int hv = idx / QX, c4 = idx - hv * QX;
+        xs[(c4 * 4 + 0) * CS + hv] = xr[i].x;
+        xs[(c4 * 4 + 1) * CS + hv] = xr[i].y;
+        xs[(c4 * 4 + 2) * CS + hv] = xr[i].z;
+        xs[(c4 * 4 + 3) * CS + hv] = xr[i].w;
+      }
+    }
+    if (with_w) {
+#pragma unroll
+      for (int i = 0; i < NWV; ++i) {
+        const int idx = tid + i * NTHR;
+        if (idx < 27 * CK * QW) {
+          const int n4 = idx % QW, row = idx / QW;
+          *reinterpret_cast<float4*>(wsm + row * NCBS + n4 * 4) = wr[i];
+        }
+      }
+    }
+  };
 
   f32x4 acc[R][NT];
 #pragma unroll
@@ -74,91 +149,120 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
     rowbase[r] = ((rr / TY) * HY + (rr % TY)) * HX + li + lk * CS;
   }
 
-  for (int c0 = 0; c0 < CinP; c0 += CK) {
-    __syncthreads();
-    if (vec4) {
-      constexpr int Q = CK / 4;
-      for (int idx = tid; idx < HVOX * Q; idx += NTHR) {
-        const int hv = idx / Q, c4 = idx - hv * Q;
-        const int hx = hv % HX, t2 = hv / HX;
-        const int hy = t2 % HY, hz = t2 / HY;
-        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
-        const int c = c0 + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
-          v = *reinterpret_cast<const float4*>(x + (xbase + ((int64_t)z * H + yy) * W + xx) * Cin + c);
-        xs[(c4 * 4 + 0) * CS + hv] = v.x;
-        xs[(c4 * 4 + 1) * CS + hv] = v.y;
-        xs[(c4 * 4 + 2) * CS + hv] = v.z;
-        xs[(c4 * 4 + 3) * CS + hv] = v.w;
-      }
-    } else {
-      for (int idx = tid; idx < HVOX * CK; idx += NTHR) {
-        const int hv = idx / CK, cc = idx - hv * CK;
-        const int hx = hv % HX, t2 = hv / HX;
-        const int hy = t2 % HY, hz = t2 / HY;
-        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
-        const int c = c0 + cc;
-        float v = 0.f;
-        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
-          v = x[(xbase + ((int64_t)z * H + yy) * W + xx) * Cin + c];
-        xs[cc * CS + hv] = v;
-      }
-    }
-    {
-      constexpr int Q = NCB / 4;
-      for (int idx = tid; idx < 27 * CK * Q; idx += NTHR) {
-        const int n4 = idx % Q, row = idx / Q;
-        const int tap = row / CK, cc = row - tap * CK;
-        const float4 v = *reinterpret_cast<const float4*>(wpk + ((int64_t)(tap * CinP + c0 + cc)) * CoutP + cb0 + n4 * 4);
-        *reinterpret_cast<float4*>(wsm + row * NCBS + n4 * 4) = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int dz = 0; dz < 3; ++dz)
-#pragma unroll 1
-      for (int dy = 0; dy < 3; ++dy)
+  // output staging through LDS when the [voxel][NCB] tile fits in the input-tile buffer and Cout is float4-able
+  constexpr bool LDS_FITS = (ROWS * TX * NCB <= CK * CS);
+  const bool lds_epi_rt = LDS_FITS && ((Cout & 3) == 0) && (Cout <= NCB);
+  float bv[NT];
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int tap = (dz * 3 + dy) * 3 + dx;
-          const int toff = (dz * HY + dy) * HX + dx;
-#pragma unroll
-          for (int kg = 0; kg < CK / 4; ++kg) {
-            float bf[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bf[n] = wsm[(tap * CK + kg * 4 + lk) * NCBS + (wn * NT + n) * 16 + li];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              const float a = xs[rowbase[r] + toff + kg * 4 * CS];
-#pragma unroll
-              for (int n = 0; n < NT; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[n], acc[r][n], 0, 0, 0);
-            }
-          }
-        }
+  for (int n = 0; n < NT; ++n) {
+    const int co = cb0 + (wn * NT + n) * 16 + li;
+    bv[n] = (bias && co < Cout) ? bias[co] : 0.f;
   }
 
-  // epilogue: lane holds cout = li, voxels x = lk*4 + j
+  int c0 = 0;
+  bool first = true;
+  load_stage(tile, 0, true);
+  while (true) {
+    __syncthreads();                               // every wave is done reading the previous stage from LDS
+    store_stage(multi || first);
+    __syncthreads();
+    int ntile = tile, nc0 = c0 + CK;
+    bool has_next = true;
+    if (nc0 >= CinP) { nc0 = 0; ntile = tile + gridDim.x; has_next = ntile < ntiles; }
+    if (has_next) load_stage(ntile, nc0, multi);   // in flight during the MFMA loop below
+    first = false;
+
+    {
+      // K loop over (tap, 4-channel group), fully unrolled: every LDS address is base + immediate.  The A/B
+      // fragments of step ks+1 are read into a second register set before the MFMAs of step ks issue.
+      constexpr int KG = CK / 4, KS = 27 * KG;
+      float af[2][R], bfr[2][NT];
+      auto frag_load = [&](int ks, float (&a)[R], float (&bq)[NT]) {
+        const int tap = ks / KG, kg = ks - tap * KG;
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        const int toff = (dz * HY + dy) * HX + dx + kg * 4 * CS;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int rr = wm * R + r;
-    const int z = z0 + rr / TY, yy = y0 + rr % TY;
-    if (z >= D || yy >= H) continue;
+        for (int n = 0; n < NT; ++n) bq[n] = wsm[(tap * CK + kg * 4 + lk) * NCBS + (wn * NT + n) * 16 + li];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int co = cb0 + (wn * NT + n) * 16 + li;
-      if (co >= Cout) continue;
-      const float bv = bias ? bias[co] : 0.f;
+        for (int r = 0; r < R; ++r) a[r] = xs[rowbase[r] + toff];
+      };
+      frag_load(0, af[0], bfr[0]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int xx = x0 + lk * 4 + j;
-        if (xx < W) {
-          float v = acc[r][n][j] + bv;
-          if (act) v = lrelu(v);
-          y[(xbase + ((int64_t)z * H + yy) * W + xx) * Cout + co] = v;
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) frag_load(ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][r], bfr[ks & 1][n], acc[r][n], 0, 0, 0);
+      }
+    }
+
+    if (c0 + CK >= CinP) {
+      int t = tile;
+      const int x0 = (t % tiles_x) * TX; t /= tiles_x;
+      const int y0 = (t % tiles_y) * TY; t /= tiles_y;
+      const int z0 = (t % tiles_z) * TZ;
+      const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
+      if (LDS_FITS && lds_epi_rt) {
+        // stage the tile [voxel][NCB] through LDS (re-using the input-tile buffer) so the global stores are
+        // whole contiguous rows in float4 (bias + activation applied on the way out)
+        __syncthreads();                                   // all waves finished reading xs in the MFMA loop
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int rr = wm * R + r;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xs[(rr * TX + lk * 4 + j) * NCB + (wn * NT + n) * 16 + li] = acc[r][n][j];
+            acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        __syncthreads();
+        const int cq = Cout >> 2;                          // float4 groups per voxel (Cout % 4 == 0 on this path)
+        const int per_row = TX * cq;
+        for (int idx = tid; idx < ROWS * per_row; idx += NTHR) {
+          const int rr = idx / per_row, f = idx - rr * per_row;
+          const int vx = f / cq, c4 = f - vx * cq;
+          const int z = z0 + rr / TY, yy = y0 + rr % TY, xx = x0 + vx;
+          if (z < D && yy < H && xx < W) {
+            float4 v = *reinterpret_cast<const float4*>(xs + (rr * TX + vx) * NCB + c4 * 4);
+            if (bias) {
+              const float4 bv = *reinterpret_cast<const float4*>(bias + cb0 + c4 * 4);
+              v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+            *reinterpret_cast<float4*>(y + (xbase + ((int64_t)z * H + yy) * W + xx) * Cout + cb0 + c4 * 4) = v;
+          }
+        }
+      } else {
+        // direct stores: lane holds cout = li, voxels x = lk*4 + j; bias was hoisted out of the stage loop
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int rr = wm * R + r;
+          const int z = z0 + rr / TY, yy = y0 + rr % TY;
+          float* yrow = y + (xbase + ((int64_t)z * H + yy) * W + x0 + lk * 4) * Cout;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int co = cb0 + (wn * NT + n) * 16 + li;
+            if (z < D && yy < H && co < Cout) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (x0 + lk * 4 + j < W) {
+                  float v = acc[r][n][j] + bv[n];
+                  if (act) v = lrelu(v);
+                  yrow[j * Cout + co] = v;
+                }
+              }
+            }
+            acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
     }
+    if (!has_next) break;
+    tile = ntile;
+    c0 = nc0;
   }
 }
 
@@ -193,63 +297,79 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
     aoff[g] = ((dz * WG_HY + dyy) * HX + dx + lk) * CIT + (li % CIT);
   }
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int t = tile;
+  // software pipeline over the tiles this workgroup owns: next tile's x / d_y loads are issued into registers
+  // before the MFMA loop of the current tile
+  constexpr int QX = CIT / 4, NXV = (WG_HVOX * QX + NTHR - 1) / NTHR;
+  constexpr int NDV = (WG_ROWS * TX * 4) / NTHR;
+  float4 xr[NXV], dr[NDV];
+  const bool xvec = (Cin & 3) == 0, dvec = (Cout & 3) == 0;
+
+  auto load_tile = [&](int tl) {
+    int t = tl;
     const int x0 = (t % tiles_x) * TX; t /= tiles_x;
     const int y0 = (t % tiles_y) * WG_TY; t /= tiles_y;
     const int z0 = (t % tiles_z) * WG_TZ;
-    const int b = t / tiles_z;
-    const int64_t vb = (int64_t)b * D * H * W;
-    __syncthreads();
-    if ((Cin & 3) == 0) {
-      constexpr int Q = CIT / 4;
-      for (int idx = tid; idx < WG_HVOX * Q; idx += NTHR) {
-        const int hv = idx / Q, c4 = idx - hv * Q;
+    const int64_t vb = (int64_t)(t / tiles_z) * D * H * W;
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int idx = tid + i * NTHR;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < WG_HVOX * QX) {
+        const int hv = idx / QX, c4 = idx - hv * QX;
         const int hx = hv % HX, t2 = hv / HX;
         const int hy = t2 % WG_HY, hz = t2 / WG_HY;
         const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
         const int c = ci0 + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
-          v = *reinterpret_cast<const float4*>(x + (vb + ((int64_t)z * H + yy) * W + xx) * Cin + c);
-        *reinterpret_cast<float4*>(xs + hv * CIT + c4 * 4) = v;
+        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin) {
+          const float* p = x + (vb + ((int64_t)z * H + yy) * W + xx) * Cin + c;
+          if (xvec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (c + 1 < Cin) v.y = p[1];
+            if (c + 2 < Cin) v.z = p[2];
+            if (c + 3 < Cin) v.w = p[3];
+          }
+        }
       }
-    } else {
-      for (int idx = tid; idx < WG_HVOX * CIT; idx += NTHR) {
-        const int hv = idx / CIT, cc = idx - hv * CIT;
-        const int hx = hv % HX, t2 = hv / HX;
-        const int hy = t2 % WG_HY, hz = t2 / WG_HY;
-        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
-        const int c = ci0 + cc;
-        float v = 0.f;
-        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin)
-          v = x[(vb + ((int64_t)z * H + yy) * W + xx) * Cin + c];
-        xs[idx] = v;
-      }
+      xr[i] = v;
     }
-    if ((Cout & 3) == 0) {
-      for (int idx = tid; idx < WG_ROWS * TX * 4; idx += NTHR) {
-        const int vox = idx >> 2, c4 = idx & 3;
-        const int row = vox / TX, xx = x0 + vox % TX;
-        const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY;
-        const int co = co0 + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (z < D && yy < H && xx < W && co < Cout)
-          v = *reinterpret_cast<const float4*>(dy + (vb + ((int64_t)z * H + yy) * W + xx) * Cout + co);
-        *reinterpret_cast<float4*>(dys + vox * 16 + c4 * 4) = v;
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int idx = tid + i * NTHR;
+      const int vox = idx >> 2, c4 = idx & 3;
+      const int row = vox / TX, xx = x0 + vox % TX;
+      const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY;
+      const int co = co0 + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z < D && yy < H && xx < W && co < Cout) {
+        const float* p = dy + (vb + ((int64_t)z * H + yy) * W + xx) * Cout + co;
+        if (dvec) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (co + 1 < Cout) v.y = p[1];
+          if (co + 2 < Cout) v.z = p[2];
+          if (co + 3 < Cout) v.w = p[3];
+        }
       }
-    } else {
-      for (int idx = tid; idx < WG_ROWS * TX * 16; idx += NTHR) {
-        const int vox = idx >> 4, cc = idx & 15;
-        const int row = vox / TX, xx = x0 + vox % TX;
-        const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY;
-        const int co = co0 + cc;
-        float v = 0.f;
-        if (z < D && yy < H && xx < W && co < Cout) v = dy[(vb + ((int64_t)z * H + yy) * W + xx) * Cout + co];
-        dys[idx] = v;
-      }
+      dr[i] = v;
     }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int idx = tid + i * NTHR;
+      if (idx < WG_HVOX * QX) *reinterpret_cast<float4*>(xs + idx * 4) = xr[i];     // [voxel][CIT], idx = hv*QX + c4
+    }
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) *reinterpret_cast<float4*>(dys + (tid + i * NTHR) * 4) = dr[i];
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
 #pragma unroll 1
     for (int row = 0; row < WG_ROWS; ++row) {
       const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
@@ -461,15 +581,26 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
                      wpk, Cin, Cout, CinP, CoutP, pack_mode);
   const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
-  dim3 grid((unsigned)((int64_t)tiles_x * tiles_y * tiles_z * B), CoutP / p.ncb);
-#define CONV_LAUNCH(...) hipLaunchKernelGGL((conv3d_mfma_kernel<__VA_ARGS__>), grid, dim3(NTHR), 0, s, x, (const float*)wpk, \
-                                            bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z)
+  const int ntiles = tiles_x * tiles_y * tiles_z * B;
+  const int gy = CoutP / p.ncb;
+  // persistent grid: exactly the resident workgroups (occupancy query is host-only and cheap), walking the tiles
+#define CONV_LAUNCH(...)                                                                                          \
+  do {                                                                                                            \
+    int per_cu = 2;                                                                                               \
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3d_mfma_kernel<__VA_ARGS__>, NTHR, 0);        \
+    if (per_cu < 1) per_cu = 1;                                                                                   \
+    int gx = (256 * per_cu + gy - 1) / gy;                                                                        \
+    if (gx > ntiles) gx = ntiles;                                                                                 \
+    hipLaunchKernelGGL((conv3d_mfma_kernel<__VA_ARGS__>), dim3(gx, gy), dim3(NTHR), 0, s, x, (const float*)wpk,    \
+                       bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z, ntiles);         \
+  } while (0)
+  const bool v4 = (Cin & 3) == 0;
   switch (p.cfg) {
-    case 0: CONV_LAUNCH(4, 8, 4, 1, 1, 8); break;
-    case 1: CONV_LAUNCH(4, 8, 4, 1, 2, 4); break;
-    case 2: CONV_LAUNCH(2, 4, 2, 2, 2, 4); break;
-    case 4: CONV_LAUNCH(4, 8, 4, 1, 1, 4); break;
-    default: CONV_LAUNCH(1, 4, 1, 4, 1, 4); break;
+    case 0: if (v4) CONV_LAUNCH(4, 8, 4, 1, 1, 8, true); else CONV_LAUNCH(4, 8, 4, 1, 1, 8, false); break;
+    case 1: if (v4) CONV_LAUNCH(4, 8, 4, 1, 2, 4, true); else CONV_LAUNCH(4, 8, 4, 1, 2, 4, false); break;
+    case 2: if (v4) CONV_LAUNCH(2, 4, 2, 2, 2, 4, true); else CONV_LAUNCH(2, 4, 2, 2, 2, 4, false); break;
+    case 4: if (v4) CONV_LAUNCH(4, 8, 4, 1, 1, 4, true); else CONV_LAUNCH(4, 8, 4, 1, 1, 4, false); break;
+    default: if (v4) CONV_LAUNCH(1, 4, 1, 4, 1, 4, true); else CONV_LAUNCH(1, 4, 1, 4, 1, 4, false); break;
   }
 #undef CONV_LAUNCH
   return modet_launch_status();
