@@ -21,16 +21,28 @@ constexpr int TX = 16, HX = TX + 2;
 __host__ __device__ constexpr int pad16mod32(int n) { return ((n - 16 + 31) / 32) * 32 + 16; }
 
 // ------------------------------------------------------------------------------------------------ weight packing
-// mode 0 (forward): wpk[tap][c][n] = w[n][c][tap]           w: (Cout=n, Cin=c, 27)
-// mode 1 (dgrad)  : wpk[tap][c][n] = w[c][n][26 - tap]      w: (Co=c, Ci=n, 27) -> conv over d_y channels c
+// wpk[tapP][c][n], zero padded to (CinP, CoutP).  W(tap; c -> co) is
+//   mode 0 (forward): w[co][c][tap]           w: (Cout, Cin, 27)
+//   mode 1 (dgrad)  : w[c][co][26 - tap]      w: (Co=c, Ci=co, 27): a convolution over d_y's channels c
+// Row packing P (= 16/CoP output rows share one 16-wide MFMA N tile when Cout <= CoP = 16/P):
+//   tapP = (dz*(P+2) + dyp)*3 + dx with dyp = p + dy in [0, P+2);  column n = p*CoP + co holds
+//   W((dz, dyp-p, dx); c -> co) when 0 <= dyp-p <= 2, else 0.   P = 1 is the plain layout.
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int CinP,
-                                    int CoutP, int mode) {
-  const int total = 27 * CinP * CoutP;
+                                    int CoutP, int mode, int P) {
+  const int ntap = 9 * (P + 2);
+  const int total = ntap * CinP * CoutP;
+  const int CoP = P > 1 ? 16 / P : CoutP;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int n = i % CoutP, t = i / CoutP;
-    const int c = t % CinP, tap = t / CinP;
+    const int c = t % CinP, tapP = t / CinP;
+    const int dx = tapP % 3, dyp = (tapP / 3) % (P + 2), dz = tapP / (3 * (P + 2));
+    const int p = P > 1 ? n / CoP : 0, co = P > 1 ? n % CoP : n;
+    const int dy = dyp - p;
     float v = 0.f;
-    if (c < Cin && n < Cout) v = mode == 0 ? w[((int64_t)n * Cin + c) * 27 + tap] : w[((int64_t)c * Cout + n) * 27 + 26 - tap];
+    if (c < Cin && co < Cout && dy >= 0 && dy <= 2) {
+      const int tap = (dz * 3 + dy) * 3 + dx;
+      v = mode == 0 ? w[((int64_t)co * Cin + c) * 27 + tap] : w[((int64_t)c * Cout + co) * 27 + 26 - tap];
+    }
     wpk[i] = v;
   }
 }
@@ -40,20 +52,23 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // tile with halo and, when Cin spans several chunks, the weight slab) are issued into registers right after
 // stage s has been written to LDS, i.e. before the MFMA loop of stage s, so HBM/L2 latency hides under the
 // matrix work (PMC before this change: MFMA pipe 54 % busy, 36 % of wave cycles in s_waitcnt/barrier).
-template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4>
+template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P>
 __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ y, int D,
                                                            int H, int W, int Cin, int Cout, int CinP, int CoutP, int act,
                                                            int tiles_x, int tiles_y, int tiles_z, int ntiles) {
   static_assert(WM * WN == 4, "4 waves");
-  constexpr int ROWS = TZ * TY, R = ROWS / WM, NCB = WN * NT * 16;
+  static_assert(P == 1 || (WN == 1 && NT == 1 && TY % P == 0), "row packing needs a single 16-wide N tile");
+  constexpr int ROWS = TZ * TY, NCB = WN * NT * 16;
+  constexpr int R = ROWS / P / WM;           // row groups (P output rows each) per wave
+  constexpr int NTAP = 9 * (P + 2), CoP = 16 / P;
   constexpr int HZ = TZ + 2, HY = TY + 2, HVOX = HZ * HY * HX;
   constexpr int CS = pad16mod32(HVOX);
   constexpr int NCBS = (NCB % 32 == 16) ? NCB : NCB + 16;
   constexpr int QX = CK / 4, NXV = (HVOX * QX + NTHR - 1) / NTHR;
-  constexpr int QW = NCB / 4, NWV = (27 * CK * QW + NTHR - 1) / NTHR;
+  constexpr int QW = NCB / 4, NWV = (NTAP * CK * QW + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) float xs[CK * CS];
-  __shared__ __attribute__((aligned(16))) float wsm[27 * CK * NCBS];
+  __shared__ __attribute__((aligned(16))) float wsm[NTAP * CK * NCBS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -102,7 +117,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
       for (int i = 0; i < NWV; ++i) {
         const int idx = tid + i * NTHR;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < 27 * CK * QW) {
+        if (idx < NTAP * CK * QW) {
           const int n4 = idx % QW, row = idx / QW;
           const int tap = row / CK, cc = row - tap * CK;
           v = *reinterpret_cast<const float4*>(wpk + ((int64_t)(tap * CinP + c0 + cc)) * CoutP + cb0 + n4 * 4);
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < NWV; ++i) {
         const int idx = tid + i * NTHR;
-        if (idx < 27 * CK * QW) {
+        if (idx < NTAP * CK * QW) {
           const int n4 = idx % QW, row = idx / QW;
           *reinterpret_cast<float4*>(wsm + row * NCBS + n4 * 4) = wr[i];
         }
@@ -145,17 +160,17 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
   int rowbase[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int rr = wm * R + r;
+    const int rr = (wm * R + r) * P;         // first output row of the group
     rowbase[r] = ((rr / TY) * HY + (rr % TY)) * HX + li + lk * CS;
   }
 
   // output staging through LDS when the [voxel][NCB] tile fits in the input-tile buffer and Cout is float4-able
-  constexpr bool LDS_FITS = (ROWS * TX * NCB <= CK * CS);
-  const bool lds_epi_rt = LDS_FITS && ((Cout & 3) == 0) && (Cout <= NCB);
+  constexpr bool LDS_FITS = (ROWS * TX * (P > 1 ? CoP : NCB) <= CK * CS);
+  const bool lds_epi_rt = LDS_FITS && ((Cout & 3) == 0) && (Cout <= (P > 1 ? CoP : NCB));
   float bv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int co = cb0 + (wn * NT + n) * 16 + li;
+    const int co = P > 1 ? li % CoP : cb0 + (wn * NT + n) * 16 + li;
     bv[n] = (bias && co < Cout) ? bias[co] : 0.f;
   }
 
@@ -175,11 +190,11 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
     {
       // K loop over (tap, 4-channel group), fully unrolled: every LDS address is base + immediate.  The A/B
       // fragments of step ks+1 are read into a second register set before the MFMAs of step ks issue.
-      constexpr int KG = CK / 4, KS = 27 * KG;
+      constexpr int KG = CK / 4, KS = NTAP * KG;
       float af[2][R], bfr[2][NT];
       auto frag_load = [&](int ks, float (&a)[R], float (&bq)[NT]) {
         const int tap = ks / KG, kg = ks - tap * KG;
-        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        const int dz = tap / (3 * (P + 2)), dy = (tap / 3) % (P + 2), dx = tap % 3;   // dy = p + dy_orig when packed
         const int toff = (dz * HY + dy) * HX + dx + kg * 4 * CS;
 #pragma unroll
         for (int n = 0; n < NT; ++n) bq[n] = wsm[(tap * CK + kg * 4 + lk) * NCBS + (wn * NT + n) * 16 + li];
@@ -204,17 +219,19 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
       const int y0 = (t % tiles_y) * TY; t /= tiles_y;
       const int z0 = (t % tiles_z) * TZ;
       const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
+      constexpr int OC = P > 1 ? CoP : NCB;              // channel slots per voxel in the staged tile
       if (LDS_FITS && lds_epi_rt) {
-        // stage the tile [voxel][NCB] through LDS (re-using the input-tile buffer) so the global stores are
+        // stage the tile [voxel][OC] through LDS (re-using the input-tile buffer) so the global stores are
         // whole contiguous rows in float4 (bias + activation applied on the way out)
         __syncthreads();                                   // all waves finished reading xs in the MFMA loop
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int rr = wm * R + r;
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
+            const int rr = (wm * R + r) * P + (P > 1 ? li / CoP : 0);
+            const int cs = P > 1 ? li % CoP : (wn * NT + n) * 16 + li;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xs[(rr * TX + lk * 4 + j) * NCB + (wn * NT + n) * 16 + li] = acc[r][n][j];
+            for (int j = 0; j < 4; ++j) xs[(rr * TX + lk * 4 + j) * OC + cs] = acc[r][n][j];
             acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
@@ -226,25 +243,25 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
           const int vx = f / cq, c4 = f - vx * cq;
           const int z = z0 + rr / TY, yy = y0 + rr % TY, xx = x0 + vx;
           if (z < D && yy < H && xx < W) {
-            float4 v = *reinterpret_cast<const float4*>(xs + (rr * TX + vx) * NCB + c4 * 4);
+            float4 v = *reinterpret_cast<const float4*>(xs + (rr * TX + vx) * OC + c4 * 4);
             if (bias) {
-              const float4 bv = *reinterpret_cast<const float4*>(bias + cb0 + c4 * 4);
-              v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+              const float4 bq = *reinterpret_cast<const float4*>(bias + cb0 + c4 * 4);
+              v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
             }
             if (act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
             *reinterpret_cast<float4*>(y + (xbase + ((int64_t)z * H + yy) * W + xx) * Cout + cb0 + c4 * 4) = v;
           }
         }
       } else {
-        // direct stores: lane holds cout = li, voxels x = lk*4 + j; bias was hoisted out of the stage loop
+        // direct stores: lane holds (row p, cout) = li, voxels x = lk*4 + j; bias was hoisted out of the stage loop
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int rr = wm * R + r;
+          const int rr = (wm * R + r) * P + (P > 1 ? li / CoP : 0);
           const int z = z0 + rr / TY, yy = y0 + rr % TY;
           float* yrow = y + (xbase + ((int64_t)z * H + yy) * W + x0 + lk * 4) * Cout;
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            const int co = cb0 + (wn * NT + n) * 16 + li;
+            const int co = P > 1 ? li % CoP : cb0 + (wn * NT + n) * 16 + li;
             if (z < D && yy < H && co < Cout) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -556,30 +573,34 @@ constexpr int C1_WG_BLOCKS = 512;
 
 // ------------------------------------------------------------------------------------------------ host side
 struct FwdPlan {
-  int cfg;       // 0:A 1:B 2:C 3:D
+  int cfg;       // 0:A 1:B 2:C 3:D 4:A with CK=4
   int ncb, ck, tz, ty;
+  int P;         // output rows packed into the N tile (cfg 0/4 only)
 };
 inline FwdPlan plan_fwd(int64_t BV, int Cin, int Cout) {
-  if (Cout <= 16 && Cin <= 4) return {4, 16, 4, 4, 8};
-  if (Cout <= 16) return {0, 16, 8, 4, 8};
-  if (Cout <= 32 && BV >= 200000) return {1, 32, 4, 4, 8};
-  if (Cout <= 64) return {2, 64, 4, 2, 4};
-  return {3, 64, 4, 1, 4};
+  const int P = Cout <= 4 ? 4 : (Cout <= 8 ? 2 : 1);
+  if (Cout <= 16 && Cin <= 4) return {4, 16, 4, 4, 8, P};
+  if (Cout <= 16) return {0, 16, 8, 4, 8, P};
+  if (Cout <= 32 && BV >= 200000) return {1, 32, 4, 4, 8, 1};
+  if (Cout <= 64) return {2, 64, 4, 2, 4, 1};
+  return {3, 64, 4, 1, 4, 1};
 }
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 inline size_t fwd_ws_elems(int Cin, int Cout) {
-  // generous: any plan pads Cin to <= 8 and Cout to <= 64 granules
-  return (size_t)27 * round_up(Cin, 8) * round_up(Cout, 64);
+  // generous: any plan pads Cin to <= 8 and Cout to <= 64 granules; row packing uses up to 54 taps x 16 columns
+  const size_t plain = (size_t)27 * round_up(Cin, 8) * round_up(Cout, 64);
+  const size_t packed = (size_t)54 * round_up(Cin, 8) * 16;
+  return plain > packed ? plain : packed;
 }
 
 int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
                 int Cin, int Cout, int act, int pack_mode, hipStream_t s) {
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
-  const int total = 27 * CinP * CoutP;
+  const int total = 9 * (p.P + 2) * CinP * CoutP;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
-                     wpk, Cin, Cout, CinP, CoutP, pack_mode);
+                     wpk, Cin, Cout, CinP, CoutP, pack_mode, p.P);
   const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
   const int ntiles = tiles_x * tiles_y * tiles_z * B;
   const int gy = CoutP / p.ncb;
@@ -596,12 +617,20 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
   } while (0)
   const bool v4 = (Cin & 3) == 0;
   switch (p.cfg) {
-    case 0: if (v4) CONV_LAUNCH(4, 8, 4, 1, 1, 8, true); else CONV_LAUNCH(4, 8, 4, 1, 1, 8, false); break;
-    case 1: if (v4) CONV_LAUNCH(4, 8, 4, 1, 2, 4, true); else CONV_LAUNCH(4, 8, 4, 1, 2, 4, false); break;
-    case 2: if (v4) CONV_LAUNCH(2, 4, 2, 2, 2, 4, true); else CONV_LAUNCH(2, 4, 2, 2, 2, 4, false); break;
-    case 4: if (v4) CONV_LAUNCH(4, 8, 4, 1, 1, 4, true); else CONV_LAUNCH(4, 8, 4, 1, 1, 4, false); break;
-    default: if (v4) CONV_LAUNCH(1, 4, 1, 4, 1, 4, true); else CONV_LAUNCH(1, 4, 1, 4, 1, 4, false); break;
+#define CONV_CASE(...)                                     \
+    if (v4) CONV_LAUNCH(__VA_ARGS__, true, 1); else CONV_LAUNCH(__VA_ARGS__, false, 1)
+#define CONV_CASE_P(...)                                                                         \
+    if (p.P == 4) { if (v4) CONV_LAUNCH(__VA_ARGS__, true, 4); else CONV_LAUNCH(__VA_ARGS__, false, 4); } \
+    else if (p.P == 2) { if (v4) CONV_LAUNCH(__VA_ARGS__, true, 2); else CONV_LAUNCH(__VA_ARGS__, false, 2); } \
+    else { CONV_CASE(__VA_ARGS__); }
+    case 0: CONV_CASE_P(4, 8, 4, 1, 1, 8); break;
+    case 1: CONV_CASE(4, 8, 4, 1, 2, 4); break;
+    case 2: CONV_CASE(2, 4, 2, 2, 2, 4); break;
+    case 4: CONV_CASE_P(4, 8, 4, 1, 1, 4); break;
+    default: CONV_CASE(1, 4, 1, 4, 1, 4); break;
   }
+#undef CONV_CASE
+#undef CONV_CASE_P
 #undef CONV_LAUNCH
   return modet_launch_status();
 }
