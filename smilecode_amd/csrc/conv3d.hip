@@ -292,7 +292,9 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
                                                             float* __restrict__ part, int D, int H, int W, int Cin,
                                                             int Cout, int tiles_x, int tiles_y, int tiles_z,
                                                             int ntiles, int n_ci_tiles) {
-  constexpr int TP = 16 / CIT, NG = (27 + TP - 1) / TP, GPW = (NG + 3) / 4;
+  // tap index 27 is always a free slot (27 taps + 1 = 28 = 4 waves x 7 = 7 groups x 4 = 14 groups x 2): it carries
+  // the bias gradient (A = 1), so d_bias costs no extra pass over d_y
+  constexpr int TP = 16 / CIT, NG = (28 + TP - 1) / TP, GPW = (NG + 3) / 4, NSLOT = NG;
   __shared__ __attribute__((aligned(16))) float xs[WG_HVOX * CIT];
   __shared__ __attribute__((aligned(16))) float dys[WG_ROWS * TX * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -302,13 +304,14 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
 
   f32x4 acc[GPW];
   int aoff[GPW];
-  bool aval[GPW];
+  bool aval[GPW], abias[GPW];
 #pragma unroll
   for (int g = 0; g < GPW; ++g) {
     acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int grp = wave * GPW + g;
     const int tap = grp * TP + li / CIT;
     aval[g] = (grp < NG) && (tap < 27);
+    abias[g] = (tap == 27) && (grp < NSLOT) && (li % CIT == 0) && (ci_tile == 0);   // spare slot: d_bias = sum dy * 1
     const int tt = tap < 27 ? tap : 0;
     const int dz = tt / 9, dyy = (tt / 3) % 3, dx = tt % 3;
     aoff[g] = ((dz * WG_HY + dyy) * HX + dx + lk) * CIT + (li % CIT);
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
 #pragma unroll
         for (int g = 0; g < GPW; ++g) {
           float a = xs[rb + s * 4 * CIT + aoff[g]];
-          if (!aval[g]) a = 0.f;
+          if (!aval[g]) a = abias[g] ? 1.f : 0.f;
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf, acc[g], 0, 0, 0);
         }
       }
@@ -413,48 +416,28 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
   }
 }
 
-// d_w[co][ci][tap] = sum over workgroups bx: one wave per element, fixed assignment + fixed tree, fp64
-__global__ __launch_bounds__(64) void wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                            int Cin, int Cout, int gx, int gy, int n_ci_tiles, int cit) {
-  const int i = blockIdx.x;
-  const int tap = i % 27, ci = (i / 27) % Cin, co = i / (27 * Cin);
-  const int tp = 16 / cit, ng = (27 + tp - 1) / tp;
+// d_w[co][ci][tap] (i < Cout*Cin*27) and d_bias[co] (the rest) = sum over workgroups bx of the partial tiles:
+// G lanes per output (G = power of two covering gx, at most 64), fixed assignment + fixed xor tree, fp64.
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                             float* __restrict__ db, int Cin, int Cout, int gx, int gy,
+                                                             int n_ci_tiles, int cit, int G) {
+  const int nw = Cout * Cin * 27, total = nw + (db ? Cout : 0);
+  const int per_blk = 256 / G;
+  const int i = blockIdx.x * per_blk + threadIdx.x / G, l = threadIdx.x % G;
+  const bool on = i < total;
+  int tap, ci, co;
+  if (i < nw) { tap = i % 27; ci = (i / 27) % Cin; co = i / (27 * Cin); }
+  else { tap = 27; ci = 0; co = on ? i - nw : 0; }
+  const int tp = 16 / cit, ng = (28 + tp - 1) / tp;
   const int grp = tap / tp, mrow = (tap % tp) * cit + (ci % cit);
   const int by = (co / 16) * n_ci_tiles + ci / cit;
   double s = 0.0;
-  for (int bx = threadIdx.x; bx < gx; bx += 64)
-    s += (double)part[(((int64_t)bx * gy + by) * ng + grp) * 256 + mrow * 16 + (co % 16)];
-  s = wave_sum_d(s);
-  if (threadIdx.x == 0) dw[i] = (float)s;
-}
-
-// d_bias[c] = sum_n dy[n][c]: per-workgroup partials over a chunk of voxels, then fixed-order fp64
-static inline int db_chunk(int C) { return (NTHR / C) * 32; }
-__global__ __launch_bounds__(NTHR) void dbias_partial_kernel(const float* __restrict__ dy, float* __restrict__ part,
-                                                             int64_t N, int C, int chunk) {
-  __shared__ float red[NTHR];
-  const int VPB = NTHR / C;
-  const int c = threadIdx.x % C, vl = threadIdx.x / C;
-  float s = 0.f;
-  const int64_t n0 = (int64_t)blockIdx.x * chunk;
-  const int64_t n1 = n0 + chunk < N ? n0 + chunk : N;
-  if (vl < VPB)
-    for (int64_t n = n0 + vl; n < n1; n += VPB) s += dy[n * C + c];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x < C) {
-    float r = 0.f;
-    for (int j = 0; j < VPB; ++j) r += red[j * C + threadIdx.x];
-    part[(int64_t)blockIdx.x * C + threadIdx.x] = r;
+  if (on)
+    for (int bx = l; bx < gx; bx += G) s += (double)part[(((int64_t)bx * gy + by) * ng + grp) * 256 + mrow * 16 + (co % 16)];
+  for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (on && l == 0) {
+    if (i < nw) dw[i] = (float)s; else db[i - nw] = (float)s;
   }
-}
-__global__ __launch_bounds__(64) void dbias_finalize_kernel(const float* __restrict__ part, float* __restrict__ db,
-                                                            int nchunk, int C) {
-  const int c = blockIdx.x;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nchunk; i += 64) s += (double)part[(int64_t)i * C + c];
-  s = wave_sum_d(s);
-  if (threadIdx.x == 0) db[c] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------ Cin == 1
@@ -648,7 +631,7 @@ inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   if (gx < 1) gx = 1;
   if (gx > p.ntiles) gx = p.ntiles;
   p.gx = gx;
-  p.ng = (27 + 16 / p.cit - 1) / (16 / p.cit);
+  p.ng = (28 + 16 / p.cit - 1) / (16 / p.cit);
   return p;
 }
 
@@ -688,7 +671,8 @@ int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws
 size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
   const int64_t N = (int64_t)B * D * H * W;
-  size_t fl = (size_t)p.gx * p.gy * p.ng * 256 + (size_t)cdiv64(N, db_chunk(Cout)) * Cout;
+  (void)N;
+  size_t fl = (size_t)p.gx * p.gy * p.ng * 256;
   const size_t c1 = (size_t)C1_WG_BLOCKS * (27 * Cout + Cout);
   return (fl > c1 ? fl : c1) * sizeof(float);
 }
@@ -720,17 +704,11 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
   else
     hipLaunchKernelGGL(conv3d_wgrad_kernel<16>, grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, p.tiles_x,
                        p.tiles_y, p.tiles_z, p.ntiles, p.n_ci);
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(Cout * Cin * 27), dim3(64), 0, s, (const float*)part, d_w,
-                     Cin, Cout, p.gx, p.gy, p.n_ci, p.cit);
-  if (d_bias) {
-    const int64_t N = (int64_t)B * D * H * W;
-    const int chunk = db_chunk(Cout);
-    const int nchunk = (int)cdiv64(N, chunk);
-    float* bpart = part + (size_t)p.gx * p.gy * p.ng * 256;
-    hipLaunchKernelGGL(dbias_partial_kernel, dim3(nchunk), dim3(NTHR), 0, s, d_y, bpart, N, Cout, chunk);
-    hipLaunchKernelGGL(dbias_finalize_kernel, dim3(Cout), dim3(64), 0, s, (const float*)bpart, d_bias, nchunk,
-                       Cout);
-  }
+  int G = 1;
+  while (G < p.gx && G < 64) G <<= 1;
+  const int total = Cout * Cin * 27 + (d_bias ? Cout : 0);
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(cdiv(total, 256 / G)), dim3(256), 0, s, (const float*)part, d_w, d_bias,
+                     Cin, Cout, p.gx, p.gy, p.n_ci, p.cit, G);
   return modet_launch_status();
 }
 

@@ -255,15 +255,18 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_c_kernel(const float* __restr
   for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dkp + c) = make_float2(acc[c] * scale, acc[c + 1] * scale);
 }
 
-// partial (B, heads, nblk, 27) -> out (heads,27): one wave per (h,t), fixed assignment + fixed tree in fp64
-__global__ __launch_bounds__(64) void drpb_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                           int B, int heads, int64_t nblk) {
+// partial (B, heads, nblk, 27) -> out (heads,27): one workgroup per (h,t), fixed assignment + fixed tree in fp64
+__global__ __launch_bounds__(256) void drpb_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            int B, int heads, int64_t nblk) {
+  __shared__ double sm[4];
   const int h = blockIdx.x / 27, t = blockIdx.x % 27;
   double s = 0.0;
   for (int b = 0; b < B; ++b)
-    for (int64_t i = threadIdx.x; i < nblk; i += 64) s += (double)part[(((int64_t)b * heads + h) * nblk + i) * 27 + t];
+    for (int64_t i = threadIdx.x; i < nblk; i += 256) s += (double)part[(((int64_t)b * heads + h) * nblk + i) * 27 + t];
   s = wave_sum_d(s);
-  if (threadIdx.x == 0) out[h * 27 + t] = (float)s;
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[h * 27 + t] = (float)(sm[0] + sm[1] + sm[2] + sm[3]);
 }
 
 // ------------------------------------------------------------------------------------------ reference contract
@@ -437,7 +440,7 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
   dim3 grid((unsigned)nblk, heads, B);
   hipLaunchKernelGGL(na_bwd_p_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, d_out, d_q, dl, part, D, H, W, heads, scale, g);
   hipLaunchKernelGGL(na_bwd_c_kernel, grid, dim3(NTHREADS), 0, s, q, (const float*)dl, d_k, D, H, W, heads, scale, g);
-  hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads * 27), dim3(64), 0, s, (const float*)part, d_rpb, B, heads, nblk);
+  hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads * 27), dim3(256), 0, s, (const float*)part, d_rpb, B, heads, nblk);
   return modet_launch_status();
 }
 
@@ -471,7 +474,7 @@ int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad, float* 
     const int64_t nchunk = cdiv64(V, (int64_t)QK_BLOCK * QK_RPB_ITERS);
     hipLaunchKernelGGL(qk_drpb_partial_kernel, dim3((unsigned)nchunk, B * heads), dim3(QK_BLOCK), 0, s, d_attn,
                        (float*)ws, V);
-    hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads * 27), dim3(64), 0, s, (const float*)ws, d_rpb, B, heads, nchunk);
+    hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads * 27), dim3(256), 0, s, (const float*)ws, d_rpb, B, heads, nchunk);
   }
   hipLaunchKernelGGL(qk_dq_kernel, dim3((unsigned)cdiv64(V, QK_BLOCK), B * heads), dim3(QK_BLOCK), 0, s, d_attn, kpad,
                      d_q, D, H, W, hd);

@@ -88,7 +88,6 @@ __global__ __launch_bounds__(BLK) void proj_ln_bwd_kernel(const float* __restric
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;
   float* ps = smem + Cin * DIM;      // bias | gamma
-  __shared__ float red[BLK / 64];
   stage_w(Ws, ps, Wt, bias, gamma, nullptr, Cin, DIM);
   __syncthreads();
   constexpr int NW = CIN_REG > 0 ? DIM * CIN_REG : 1;
@@ -154,20 +153,21 @@ __global__ __launch_bounds__(BLK) void proj_ln_bwd_kernel(const float* __restric
       }
     }
   }
-  // workgroup reduction of the accumulators, one value at a time (tiny next to the streaming loop)
+  // per-WAVE partials (shuffle reduction only, no barriers): part[(blk*4 + wave)][...]
   const int npart = 3 * DIM + (CIN_REG > 0 ? DIM * CIN_REG : 0);
-  float* pp = part + (int64_t)blockIdx.x * npart;
+  const int lane = threadIdx.x & 63;
+  float* pp = part + ((int64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6)) * npart;
 #pragma unroll
   for (int o = 0; o < DIM; ++o) {
-    float r = block_sum(ag[o], red); if (threadIdx.x == 0) pp[o] = r;
-    r = block_sum(ab[o], red);       if (threadIdx.x == 0) pp[DIM + o] = r;
-    r = block_sum(abi[o], red);      if (threadIdx.x == 0) pp[2 * DIM + o] = r;
+    float r = wave_sum(ag[o]);  if (lane == 0) pp[o] = r;
+    r = wave_sum(ab[o]);        if (lane == 0) pp[DIM + o] = r;
+    r = wave_sum(abi[o]);       if (lane == 0) pp[2 * DIM + o] = r;
   }
   if (CIN_REG > 0) {
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-      const float r = block_sum(aw[i], red);
-      if (threadIdx.x == 0) pp[3 * DIM + i] = r;
+      const float r = wave_sum(aw[i]);
+      if (lane == 0) pp[3 * DIM + i] = r;
     }
   }
 }
@@ -251,7 +251,7 @@ int modet_proj_ln_fwd(const float* x, const float* Wt, const float* bias, const 
 
 size_t modet_proj_ln_bwd_ws_bytes(int64_t N, int Cin, int dim) {
   const int rc = reg_cin(Cin, dim);
-  size_t fl = (size_t)bwd_grid(N) * (3 * dim + (rc ? dim * Cin : 0));
+  size_t fl = (size_t)bwd_grid(N) * (BLK / 64) * (3 * dim + (rc ? dim * Cin : 0));
   if (!rc) fl += (size_t)N * dim + (size_t)cdiv64(N, DW_CHUNK) * Cin * dim;
   return fl * sizeof(float);
 }
@@ -270,7 +270,8 @@ int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const 
   const int rc = reg_cin(Cin, dim);
   const int npart = 3 * dim + (rc ? dim * Cin : 0);
   float* part = (float*)ws;
-  float* dz = part + (size_t)grid * npart;
+  const int nwp = grid * (BLK / 64);              // per-wave partial rows
+  float* dz = part + (size_t)nwp * npart;
   float* dwpart = dz + (size_t)N * dim;
   const size_t sh = ((size_t)Cin * dim + 2 * dim) * sizeof(float);
 #define LAUNCH_BWD(D_, R_) hipLaunchKernelGGL((proj_ln_bwd_kernel<D_, R_>), dim3(grid), dim3(BLK), sh, s, x, Wt, bias, \
@@ -284,11 +285,11 @@ int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const 
   else return MODET_ERR_UNSUPPORTED;
 #undef LAUNCH_BWD
   const bool regw = (dim == 6 && (Cin == 8 || Cin == 16));
-  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_gamma, grid, npart, 0, dim);
-  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_beta, grid, npart, dim, dim);
-  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_bias, grid, npart, 2 * dim, dim);
+  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_gamma, nwp, npart, 0, dim);
+  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_beta, nwp, npart, dim, dim);
+  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_bias, nwp, npart, 2 * dim, dim);
   if (regw) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(dim * Cin), dim3(64), 0, s, part, d_Wt, grid, npart, 3 * dim,
+    hipLaunchKernelGGL(colsum_kernel, dim3(dim * Cin), dim3(64), 0, s, part, d_Wt, nwp, npart, 3 * dim,
                        dim * Cin);
   } else {
     const int nchunk = (int)cdiv64(N, DW_CHUNK);

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
                                                        int64_t total, int add_flow) {
   const int64_t V = (int64_t)D * H * W;
   const int64_t total_pad = cdiv64(total, BLK) * BLK;       // keep whole waves alive for the shuffles
+  const int lane = threadIdx.x & 63;
   for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total_pad; idx += (int64_t)gridDim.x * BLK) {
     const bool inr = idx < total;
     const int64_t id = inr ? idx : total - 1;
@@ -133,31 +134,58 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
     const float go = live ? dout[n * C + cc] : 0.f;
     const float* sb = src + b * V * C + cc;
     float* db = dsrc ? dsrc + b * V * C + cc : nullptr;
+    // contributions of this (voxel, channel) to the 8 corners, index = dz*4 + dy*2 + dx
+    float cv[8];
     float gz = 0.f, gy = 0.f, gx = 0.f;
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz) {
-      const int zz = t.z0 + dz;
       const float wz = dz ? t.fz : 1.f - t.fz;
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy) {
-        const int yy = t.y0 + dy;
         const float wy = dy ? t.fy : 1.f - t.fy;
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-          const int xx = t.x0 + dx;
           const float wx = dx ? t.fx : 1.f - t.fx;
-          if (live && zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const int64_t off = (((int64_t)zz * H + yy) * W + xx) * C;
-            if (db) atomicAdd(db + off, wz * wy * wx * go);
-            if (dflow) {
-              const float dot = sb[off] * go;
-              gz += (dz ? 1.f : -1.f) * wy * wx * dot;
-              gy += (dy ? 1.f : -1.f) * wz * wx * dot;
-              gx += (dx ? 1.f : -1.f) * wz * wy * dot;
-            }
+          const int zz = t.z0 + dz, yy = t.y0 + dy, xx = t.x0 + dx;
+          const bool ok = live && zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+          cv[dz * 4 + dy * 2 + dx] = ok ? wz * wy * wx * go : 0.f;
+          if (dflow && ok) {
+            const float dot = sb[(((int64_t)zz * H + yy) * W + xx) * C] * go;
+            gz += (dz ? 1.f : -1.f) * wy * wx * dot;
+            gy += (dy ? 1.f : -1.f) * wz * wx * dot;
+            gx += (dx ? 1.f : -1.f) * wz * wy * dot;
           }
         }
       }
+    }
+    if (db) {
+      // The next voxel along x sits G lanes up.  When its footprint is this one shifted by +1 in x (the common
+      // case for a smooth flow) its dx=0 corners are this voxel's dx=1 corners: hand those four values over with
+      // a shuffle and let the neighbour issue ONE atomic for both -> up to 2x fewer L2 atomics.  Both sides
+      // evaluate the same predicate from shuffled footprints, so nothing is lost or counted twice.
+      const int up = lane + G, dn = lane - G;
+      const int nz0 = __shfl(t.z0, up, 64), ny0 = __shfl(t.y0, up, 64), nx0 = __shfl(t.x0, up, 64);
+      const int nxi = __shfl(xi, up, 64);
+      const bool give = (up < 64) && (idx + G < total) && nxi == xi + 1 && nz0 == t.z0 && ny0 == t.y0 && nx0 == t.x0 + 1;
+      const int pz0 = __shfl(t.z0, dn, 64), py0 = __shfl(t.y0, dn, 64), px0 = __shfl(t.x0, dn, 64);
+      const int pxi = __shfl(xi, dn, 64);
+      const bool take = (dn >= 0) && inr && pxi == xi - 1 && pz0 == t.z0 && py0 == t.y0 && px0 == t.x0 - 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                          // q = dz*2 + dy
+        const float from_prev = __shfl(cv[q * 2 + 1], dn, 64);
+        if (take) cv[q * 2] += from_prev;
+        if (give) cv[q * 2 + 1] = 0.f;
+      }
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const float val = cv[dz * 4 + dy * 2 + dx];
+            if (val != 0.f)
+              atomicAdd(db + (((int64_t)(t.z0 + dz) * H + (t.y0 + dy)) * W + (t.x0 + dx)) * C, val);
+          }
     }
     if (dflow) {
       if (add_flow && live) {               // C == 3: d(out_c)/d(flow_c) has the identity term
