@@ -390,7 +390,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
     for (int i = 0; i < NDV; ++i) *reinterpret_cast<float4*>(dys + (tid + i * NTHR) * 4) = dr[i];
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
-#pragma unroll 1
+#pragma unroll 4
     for (int row = 0; row < WG_ROWS; ++row) {
       const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
 #pragma unroll
