@@ -37,6 +37,19 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def family(tag):
+    """launch tag -> kernel family (= the kernel symbol rocprof reports)"""
+    if tag.startswith("conv_fwd[1->") :
+        return "conv_c1_fwd_kernel"
+    if tag.startswith("conv_wgrad[1->"):
+        return "conv_c1_wgrad_kernel"
+    if tag.startswith("conv_fwd") or tag.startswith("conv_dgrad"):
+        return "conv3d_mfma_kernel"
+    if tag.startswith("conv_wgrad"):
+        return "conv3d_wgrad_kernel"
+    return tag.split("[")[0]
+
+
 def cpu_baseline(shape, workload, budget_s=40.0):
     """oracle timed on the host cores on a bounded sample of the same workload"""
     from oracle import modet_torch as orc
@@ -118,19 +131,29 @@ def main():
     torch.cuda.synchronize()
     ops.set_kernel_timer(None)
     breakdown = tm.summary()
-    dominant = max(breakdown, key=lambda k: breakdown[k]["ms"]) if breakdown else None
+    fams = {}
+    for k, v in breakdown.items():
+        d = fams.setdefault(family(k), {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "tags": set()})
+        for f in ("calls", "ms", "flops", "bytes"):
+            d[f] += v[f]
+        d["tags"].add(k)
+    dominant = max(fams, key=lambda k: fams[k]["ms"]) if fams else None
     if rank == 0:
         tot = sum(v["ms"] for v in breakdown.values())
         log(f"[bench] per-op breakdown of one {args.workload} step (HIP events, sum {tot:.3f} ms):")
         for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]):
             log(f"   {k:26s} calls {v['calls']:3d}  {v['ms']:8.3f} ms  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:9.2f} TFLOP/s"
                 f"  {v['bytes'] / v['ms'] / 1e6 if v['ms'] else 0:9.1f} GB/s(alg)")
+        log("[bench] by kernel family:")
+        for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])[:12]:
+            log(f"   {k:26s} calls {v['calls']:3d}  {v['ms']:8.3f} ms ({100 * v['ms'] / tot:4.1f} %)")
         if args.breakdown:
             with open(args.breakdown, "w") as f:
-                json.dump(breakdown, f, indent=1, sort_keys=True)
+                json.dump({"ops": breakdown, "families": {k: {kk: vv for kk, vv in v.items() if kk != "tags"}
+                                                          for k, v in fams.items()}}, f, indent=1, sort_keys=True)
 
     # timed region: exactly K steps, only the dominant group carries events
-    tsel = ops.KernelTimer(select={dominant} if dominant else set())
+    tsel = ops.KernelTimer(select=set(fams[dominant]["tags"]) if dominant else set())
     barrier()
     ops.set_kernel_timer(tsel)
     t0 = time.perf_counter()
@@ -148,9 +171,12 @@ def main():
         pairs = args.steps * args.batch * world
         roof = None
         if dominant:
-            d = tsel.summary()[dominant]
+            d = {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
+            for v in tsel.summary().values():
+                for f in d:
+                    d[f] += v[f]
             sec = d["ms"] * 1e-3
-            if dominant.startswith("conv"):
+            if dominant.startswith("conv3d"):
                 ach = d["flops"] / sec / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None}
@@ -158,8 +184,11 @@ def main():
                 ach = d["bytes"] / sec / 1e9
                 roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": ach / PEAK_HBM_GBS, "traffic": None}
-            roof.update({"kernel": dominant, "launches": d["calls"], "avg_launch_ms": d["ms"] / d["calls"],
-                         "share_of_step": d["ms"] / (dt * 1e3)})
+            roof.update({"kernel": dominant, "launches": d["calls"], "launches_per_step": d["calls"] / args.steps,
+                         "avg_launch_ms": d["ms"] / d["calls"], "share_of_step": d["ms"] / (dt * 1e3),
+                         "note": "all launches of this kernel symbol in the K timed steps; algorithmic work summed per "
+                                 "launch shape (DESIGN.md section 4); each bracket also contains the ~4 us weight-pack launch"
+                                 if dominant.startswith("conv3d_mfma") else "all launches of this kernel in the K timed steps"})
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc runs
             if os.path.exists(pmc):
                 try:
