@@ -71,14 +71,26 @@ def cpu_baseline(shape, workload, budget_s=40.0):
 
     half = tuple(s // 2 for s in shape)
     run((32, 48, 32))                       # warm ATen / thread pool
-    t_half = run(half)
+    # ATen-CPU does not scale to every core of a big host on these shapes: time the bounded sample at two thread
+    # counts and report the faster one (cores = threads actually used)
+    best = None
+    for nt in sorted({cores, min(cores, 32)}):
+        torch.set_num_threads(nt)
+        t = run(half)
+        if best is None or t < best[0]:
+            best = (t, nt)
+    t_half, nt = best
+    torch.set_num_threads(nt)
     if 8.0 * t_half * 1.2 <= budget_s:
         t_full = run(shape)
-        return {"value": 1.0 / t_full, "unit": "volume-pairs/sec", "cores": cores, "kind": "port",
-                "sample": "1 pair %dx%dx%d %s, oracle/modet_torch.py (ATen-CPU fp32), %.2f s" % (*shape, workload, t_full)}
-    return {"value": 1.0 / (8.0 * t_half), "unit": "volume-pairs/sec", "cores": cores, "kind": "port",
-            "sample": "1 pair %dx%dx%d %s (1/8 of the voxels, %.2f s) scaled x8, oracle/modet_torch.py (ATen-CPU fp32)"
-                      % (*half, workload, t_half)}
+        out = {"value": 1.0 / t_full, "unit": "volume-pairs/sec", "cores": nt, "kind": "port",
+               "sample": "1 pair %dx%dx%d %s, oracle/modet_torch.py (ATen-CPU fp32), %.2f s" % (*shape, workload, t_full)}
+    else:
+        out = {"value": 1.0 / (8.0 * t_half), "unit": "volume-pairs/sec", "cores": nt, "kind": "port",
+               "sample": "1 pair %dx%dx%d %s (1/8 of the voxels, %.2f s) scaled x8, oracle/modet_torch.py (ATen-CPU fp32)"
+                         % (*half, workload, t_half)}
+    torch.set_num_threads(cores)
+    return out
 
 
 def main():
