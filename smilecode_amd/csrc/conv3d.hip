@@ -52,12 +52,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // tile with halo and, when Cin spans several chunks, the weight slab) are issued into registers right after
 // stage s has been written to LDS, i.e. before the MFMA loop of stage s, so HBM/L2 latency hides under the
 // matrix work (PMC before this change: MFMA pipe 54 % busy, 36 % of wave cycles in s_waitcnt/barrier).
-template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P>
-__global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P, bool MULTI>
+__global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ y, int D,
                                                            int H, int W, int Cin, int Cout, int CinP, int CoutP, int act,
                                                            int tiles_x, int tiles_y, int tiles_z, int ntiles) {
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int NTHR = WM * WN * 64;         // 4 or 8 waves per workgroup (shadows the file-level constant)
   static_assert(P == 1 || (WN == 1 && NT == 1 && TY % P == 0), "row packing needs a single 16-wide N tile");
   constexpr int ROWS = TZ * TY, NCB = WN * NT * 16;
   constexpr int R = ROWS / P / WM;           // row groups (P output rows each) per wave
@@ -69,37 +69,51 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
   constexpr int QW = NCB / 4, NWV = (NTAP * CK * QW + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) float xs[CK * CS];
   __shared__ __attribute__((aligned(16))) float wsm[NTAP * CK * NCBS];
+  // output staging [voxel][OC], one private slice per wave (rows it computed), flushed one iteration later
+  constexpr int OC = P > 1 ? CoP : NCB;
+  constexpr bool STG = (P > 1) || (NCB == 16);                     // the L1/L2 configs (16-wide N tile)
+  __shared__ __attribute__((aligned(16))) float stg[STG ? ROWS * TX * OC : 4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 15, lk = lane >> 4;
   const int cb0 = blockIdx.y * NCB;
   constexpr bool vec4 = VEC4;
-  const bool multi = CinP > CK;              // weights change per stage only when Cin spans several chunks
+  constexpr bool multi = MULTI;              // weights change per stage only when Cin spans several chunks (CinP > CK)
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
 
-  float4 xr[NXV], wr[NWV];
+  float4 xr[NXV], wr[MULTI ? NWV : 1];
+
+  // tile-invariant part of the fill, computed once per thread: halo coordinates (packed), the LDS address and the
+  // global offset of each prefetch slot relative to the tile origin
+  int xh[NXV], xrel[NXV];
+#pragma unroll
+  for (int i = 0; i < NXV; ++i) {
+    const int idx = tid + i * NTHR;
+    const bool on = idx < HVOX * QX;
+    const int hv = on ? idx / QX : 0, c4 = on ? idx - hv * QX : 0;
+    const int hx = hv % HX, t2 = hv / HX;
+    const int hy = t2 % HY, hz = t2 / HY;
+    xh[i] = on ? (hz | (hy << 8) | (hx << 16) | (c4 << 24)) : -1;
+    xrel[i] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + c4 * 4;       // |.| < 3*H*W*Cin: fits 32 bits
+  }
 
   auto load_stage = [&](int tl, int c0, bool with_w) {
     int t = tl;
     const int x0 = (t % tiles_x) * TX; t /= tiles_x;
     const int y0 = (t % tiles_y) * TY; t /= tiles_y;
     const int z0 = (t % tiles_z) * TZ;
-    const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
+    const float* xt = x + (((int64_t)(t / tiles_z) * D + z0) * H + y0) * W * Cin + (int64_t)x0 * Cin + c0;
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
-      const int idx = tid + i * NTHR;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < HVOX * QX) {
-        const int hv = idx / QX, c4 = idx - hv * QX;
-        const int hx = hv % HX, t2 = hv / HX;
-        const int hy = t2 % HY, hz = t2 / HY;
-        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
-        const int c = c0 + c4 * 4;
+      if (xh[i] >= 0) {
+        const int z = z0 + (xh[i] & 255) - 1, yy = y0 + ((xh[i] >> 8) & 255) - 1, xx = x0 + ((xh[i] >> 16) & 255) - 1;
+        const int c = c0 + (xh[i] >> 24) * 4;
         if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin) {
-          const float* p = x + (xbase + ((int64_t)z * H + yy) * W + xx) * Cin + c;
+          const float* p = xt + xrel[i];
           if (vec4) {
             v = *reinterpret_cast<const float4*>(p);
           } else {
@@ -112,17 +126,19 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
       }
       xr[i] = v;
     }
-    if (with_w) {
+    if constexpr (MULTI) {
+      if (with_w) {
 #pragma unroll
-      for (int i = 0; i < NWV; ++i) {
-        const int idx = tid + i * NTHR;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < NTAP * CK * QW) {
-          const int n4 = idx % QW, row = idx / QW;
-          const int tap = row / CK, cc = row - tap * CK;
-          v = *reinterpret_cast<const float4*>(wpk + ((int64_t)(tap * CinP + c0 + cc)) * CoutP + cb0 + n4 * 4);
+        for (int i = 0; i < NWV; ++i) {
+          const int idx = tid + i * NTHR;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < NTAP * CK * QW) {
+            const int n4 = idx % QW, row = idx / QW;
+            const int tap = row / CK, cc = row - tap * CK;
+            v = *reinterpret_cast<const float4*>(wpk + ((int64_t)(tap * CinP + c0 + cc)) * CoutP + cb0 + n4 * 4);
+          }
+          wr[i] = v;
         }
-        wr[i] = v;
       }
     }
   };
@@ -130,22 +146,23 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
   auto store_stage = [&](bool with_w) {
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
-      const int idx = tid + i * NTHR;
-      if (idx < HVOX * QX) {
-        const int hv = idx / QX, c4 = idx - hv * QX;
-        xs[(c4 * 4 + 0) * CS + hv] = xr[i].x;
-        xs[(c4 * 4 + 1) * CS + hv] = xr[i].y;
-        xs[(c4 * 4 + 2) * CS + hv] = xr[i].z;
-        xs[(c4 * 4 + 3) * CS + hv] = xr[i].w;
+      if (xh[i] >= 0) {
+        const int l = ((xh[i] >> 24) * 4) * CS + ((xh[i] & 255) * HY + ((xh[i] >> 8) & 255)) * HX + ((xh[i] >> 16) & 255);
+        xs[l] = xr[i].x;
+        xs[l + CS] = xr[i].y;
+        xs[l + 2 * CS] = xr[i].z;
+        xs[l + 3 * CS] = xr[i].w;
       }
     }
-    if (with_w) {
+    if constexpr (MULTI) {
+      if (with_w) {
 #pragma unroll
-      for (int i = 0; i < NWV; ++i) {
-        const int idx = tid + i * NTHR;
-        if (idx < NTAP * CK * QW) {
-          const int n4 = idx % QW, row = idx / QW;
-          *reinterpret_cast<float4*>(wsm + row * NCBS + n4 * 4) = wr[i];
+        for (int i = 0; i < NWV; ++i) {
+          const int idx = tid + i * NTHR;
+          if (idx < NTAP * CK * QW) {
+            const int n4 = idx % QW, row = idx / QW;
+            *reinterpret_cast<float4*>(wsm + row * NCBS + n4 * 4) = wr[i];
+          }
         }
       }
     }
@@ -165,14 +182,56 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
   }
 
   // output staging through LDS when the [voxel][NCB] tile fits in the input-tile buffer and Cout is float4-able
-  constexpr bool LDS_FITS = (ROWS * TX * (P > 1 ? CoP : NCB) <= CK * CS);
-  const bool lds_epi_rt = LDS_FITS && ((Cout & 3) == 0) && (Cout <= (P > 1 ? CoP : NCB));
+  // staged path needs float4-able channel vectors whose group index is lane-invariant (64 % (Cout/4) == 0)
+  const bool lds_epi_rt = STG && ((Cout & 3) == 0) && (Cout <= OC) && (64 % (Cout >> 2) == 0);
+  // bias for the LDS-staged epilogue: a lane always stores channel group c4 = lane % (Cout/4), so its bias float4 is
+  // loaded ONCE here.  A load inside the store loop would put an s_waitcnt vmcnt(0) in
+  // front of every store, and vmcnt also counts stores: the epilogue would wait for each store's acknowledgement.
+  float4 bq4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lds_epi_rt && bias) bq4 = *reinterpret_cast<const float4*>(bias + cb0 + (lane % (Cout >> 2)) * 4);
   float bv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = P > 1 ? li % CoP : cb0 + (wn * NT + n) * 16 + li;
     bv[n] = (bias && co < Cout) ? bias[co] : 0.f;
   }
+
+  if constexpr (!MULTI) {
+    for (int idx = tid; idx < NTAP * CK * QW; idx += NTHR) {
+      const int n4 = idx % QW, row = idx / QW;
+      const int tap = row / CK, cc = row - tap * CK;
+      *reinterpret_cast<float4*>(wsm + row * NCBS + n4 * 4) =
+          *reinterpret_cast<const float4*>(wpk + ((int64_t)(tap * CinP + cc)) * CoutP + cb0 + n4 * 4);
+    }
+  }
+  // deferred flush of a finished tile: the wave reads back ITS OWN staging slice (rows it computed) and writes whole
+  // channel vectors as float4.  Issued at the start of the next iteration, BEFORE that iteration's prefetch loads:
+  // s_waitcnt vmcnt is in-order and counts stores, so with stores issued right before the wait (as a same-iteration
+  // epilogue does) every tile would wait for a full store round trip.
+  int ptile = -1;
+  auto flush_tile = [&]() {
+    if (ptile < 0) return;
+    int t = ptile;
+    const int x0 = (t % tiles_x) * TX; t /= tiles_x;
+    const int y0 = (t % tiles_y) * TY; t /= tiles_y;
+    const int z0 = (t % tiles_z) * TZ;
+    const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
+    const int cq = Cout >> 2, per_row = TX * cq;
+    constexpr int WROWS = R * P;                       // rows owned by this wave
+    for (int i = lane; i < WROWS * per_row; i += 64) {
+      const int rl = i / per_row, f = i - rl * per_row;
+      const int rr = wm * WROWS + rl;
+      const int vx = f / cq, c4 = f - vx * cq;
+      const int z = z0 + rr / TY, yy = y0 + rr % TY, xx = x0 + vx;
+      if (z < D && yy < H && xx < W) {
+        float4 v = *reinterpret_cast<const float4*>(stg + (rr * TX + vx) * OC + c4 * 4);
+        v.x += bq4.x; v.y += bq4.y; v.z += bq4.z; v.w += bq4.w;
+        if (act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+        *reinterpret_cast<float4*>(y + (xbase + ((int64_t)z * H + yy) * W + xx) * Cout + cb0 + c4 * 4) = v;
+      }
+    }
+    ptile = -1;
+  };
 
   int c0 = 0;
   bool first = true;
@@ -184,6 +243,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
     int ntile = tile, nc0 = c0 + CK;
     bool has_next = true;
     if (nc0 >= CinP) { nc0 = 0; ntile = tile + gridDim.x; has_next = ntile < ntiles; }
+    if (STG) flush_tile();                         // previous tile's stores go out before this prefetch
     if (has_next) load_stage(ntile, nc0, multi);   // in flight during the MFMA loop below
     first = false;
 
@@ -219,11 +279,8 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
       const int y0 = (t % tiles_y) * TY; t /= tiles_y;
       const int z0 = (t % tiles_z) * TZ;
       const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
-      constexpr int OC = P > 1 ? CoP : NCB;              // channel slots per voxel in the staged tile
-      if (LDS_FITS && lds_epi_rt) {
-        // stage the tile [voxel][OC] through LDS (re-using the input-tile buffer) so the global stores are
-        // whole contiguous rows in float4 (bias + activation applied on the way out)
-        __syncthreads();                                   // all waves finished reading xs in the MFMA loop
+      if (STG && lds_epi_rt) {
+        // write this wave's accumulators into its private staging slice; the global stores happen next iteration
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
@@ -231,27 +288,11 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
             const int rr = (wm * R + r) * P + (P > 1 ? li / CoP : 0);
             const int cs = P > 1 ? li % CoP : (wn * NT + n) * 16 + li;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xs[(rr * TX + lk * 4 + j) * OC + cs] = acc[r][n][j];
+            for (int j = 0; j < 4; ++j) stg[(rr * TX + lk * 4 + j) * OC + cs] = acc[r][n][j];
             acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
-        __syncthreads();
-        const int cq = Cout >> 2;                          // float4 groups per voxel (Cout % 4 == 0 on this path)
-        const int per_row = TX * cq;
-        for (int idx = tid; idx < ROWS * per_row; idx += NTHR) {
-          const int rr = idx / per_row, f = idx - rr * per_row;
-          const int vx = f / cq, c4 = f - vx * cq;
-          const int z = z0 + rr / TY, yy = y0 + rr % TY, xx = x0 + vx;
-          if (z < D && yy < H && xx < W) {
-            float4 v = *reinterpret_cast<const float4*>(xs + (rr * TX + vx) * OC + c4 * 4);
-            if (bias) {
-              const float4 bq = *reinterpret_cast<const float4*>(bias + cb0 + c4 * 4);
-              v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
-            }
-            if (act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
-            *reinterpret_cast<float4*>(y + (xbase + ((int64_t)z * H + yy) * W + xx) * Cout + cb0 + c4 * 4) = v;
-          }
-        }
+        ptile = tile;
       } else {
         // direct stores: lane holds (row p, cout) = li, voxels x = lk*4 + j; bias was hoisted out of the stage loop
 #pragma unroll
@@ -280,6 +321,10 @@ __global__ __launch_bounds__(NTHR) void conv3d_mfma_kernel(const float* __restri
     if (!has_next) break;
     tile = ntile;
     c0 = nc0;
+  }
+  if (STG) {
+    __syncthreads();
+    flush_tile();
   }
 }
 
@@ -570,6 +615,19 @@ inline FwdPlan plan_fwd(int64_t BV, int Cin, int Cout) {
 }
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// resident 256-thread workgroups per CU from the kernel's own footprint: 160 KiB LDS per CU, 512 VGPR+AGPR per SIMD
+// lane allocated in granules of 8 (MI355X_MICROARCH.md), at most 8 waves per SIMD
+inline int resident_blocks(const void* fn, int nthreads) {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return 2;
+  const int by_lds = a.sharedSizeBytes > 0 ? (int)(163840 / round_up((int)a.sharedSizeBytes, 512)) : 8;
+  const int waves_per_simd = a.numRegs > 0 ? 512 / round_up(a.numRegs, 8) : 8;
+  const int by_reg = (waves_per_simd > 8 ? 8 : waves_per_simd) * 4 / (nthreads / 64);
+  int n = by_lds < by_reg ? by_lds : by_reg;
+  if (n > 8) n = 8;
+  return n < 1 ? 1 : n;
+}
+
 inline size_t fwd_ws_elems(int Cin, int Cout) {
   // generous: any plan pads Cin to <= 8 and Cout to <= 64 granules; row packing uses up to 54 taps x 16 columns
   const size_t plain = (size_t)27 * round_up(Cin, 8) * round_up(Cout, 64);
@@ -588,32 +646,38 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
   const int ntiles = tiles_x * tiles_y * tiles_z * B;
   const int gy = CoutP / p.ncb;
   // persistent grid: exactly the resident workgroups (occupancy query is host-only and cheap), walking the tiles
-#define CONV_LAUNCH(...)                                                                                          \
+#define CONV_LAUNCH(TZ_, TY_, WM_, WN_, ...)                                                                      \
   do {                                                                                                            \
-    int per_cu = 2;                                                                                               \
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3d_mfma_kernel<__VA_ARGS__>, NTHR, 0);        \
-    if (per_cu < 1) per_cu = 1;                                                                                   \
+    constexpr int nthr = (WM_) * (WN_) * 64;                                                                      \
+    const int per_cu = resident_blocks((const void*)conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__>, nthr);   \
     int gx = (256 * per_cu + gy - 1) / gy;                                                                        \
     if (gx > ntiles) gx = ntiles;                                                                                 \
-    hipLaunchKernelGGL((conv3d_mfma_kernel<__VA_ARGS__>), dim3(gx, gy), dim3(NTHR), 0, s, x, (const float*)wpk,    \
-                       bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z, ntiles);         \
+    hipLaunchKernelGGL((conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__>), dim3(gx, gy), dim3(nthr), 0, s, x,   \
+                       (const float*)wpk, bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z, \
+                       ntiles);                                                                                   \
   } while (0)
   const bool v4 = (Cin & 3) == 0;
+  const bool multi = CinP > p.ck;
   switch (p.cfg) {
-#define CONV_CASE(...)                                     \
-    if (v4) CONV_LAUNCH(__VA_ARGS__, true, 1); else CONV_LAUNCH(__VA_ARGS__, false, 1)
-#define CONV_CASE_P(...)                                                                         \
-    if (p.P == 4) { if (v4) CONV_LAUNCH(__VA_ARGS__, true, 4); else CONV_LAUNCH(__VA_ARGS__, false, 4); } \
-    else if (p.P == 2) { if (v4) CONV_LAUNCH(__VA_ARGS__, true, 2); else CONV_LAUNCH(__VA_ARGS__, false, 2); } \
-    else { CONV_CASE(__VA_ARGS__); }
-    case 0: CONV_CASE_P(4, 8, 4, 1, 1, 8); break;
+#define CONV_VM(PP, ...)                                                                      \
+    if (v4 && multi) CONV_LAUNCH(__VA_ARGS__, true, PP, true);                                  \
+    else if (v4) CONV_LAUNCH(__VA_ARGS__, true, PP, false);                                     \
+    else if (multi) CONV_LAUNCH(__VA_ARGS__, false, PP, true);                                  \
+    else CONV_LAUNCH(__VA_ARGS__, false, PP, false)
+#define CONV_CASE(...) CONV_VM(1, __VA_ARGS__)
+#define CONV_CASE_P(...)                          \
+    if (p.P == 4) { CONV_VM(4, __VA_ARGS__); }      \
+    else if (p.P == 2) { CONV_VM(2, __VA_ARGS__); } \
+    else { CONV_VM(1, __VA_ARGS__); }
+    case 0: CONV_CASE_P(4, 8, 8, 1, 1, 8); break;
     case 1: CONV_CASE(4, 8, 4, 1, 2, 4); break;
     case 2: CONV_CASE(2, 4, 2, 2, 2, 4); break;
-    case 4: CONV_CASE_P(4, 8, 4, 1, 1, 4); break;
+    case 4: CONV_CASE_P(4, 8, 8, 1, 1, 4); break;
     default: CONV_CASE(1, 4, 1, 4, 1, 4); break;
   }
 #undef CONV_CASE
 #undef CONV_CASE_P
+#undef CONV_VM
 #undef CONV_LAUNCH
   return modet_launch_status();
 }
