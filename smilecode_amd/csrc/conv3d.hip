@@ -609,7 +609,7 @@ inline FwdPlan plan_fwd(int64_t BV, int Cin, int Cout) {
   const int P = Cout <= 4 ? 4 : (Cout <= 8 ? 2 : 1);
   if (Cout <= 16 && Cin <= 4) return {4, 16, 4, 4, 8, P};
   if (Cout <= 16) return {0, 16, 8, 4, 8, P};
-  if (Cout <= 32 && BV >= 200000) return {1, 32, 4, 4, 8, 1};
+  if (Cout <= 32 && BV >= 60000) return {1, 32, 4, 4, 8, 1};      // NCB = 32: no half-empty N tiles at level 3
   if (Cout <= 64) return {2, 64, 4, 2, 4, 1};
   return {3, 64, 4, 1, 4, 1};
 }
