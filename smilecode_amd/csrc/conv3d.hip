@@ -485,6 +485,177 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------ wgrad, N-packed
+// Cout <= 8 and Cin <= 8 (the full-resolution layers): the 16 N columns are (q, co) with q in {0,1}; column block
+// q = 1 multiplies by d_y shifted one voxel in +x:
+//   D[(t,ci)][(q,co)] = sum_v x[v + off(t)][ci] * dy[v + q*ex][co] = sum_u x[u + off(t) - q*ex][ci] * dy[u][co],
+// i.e. the weight gradient of tap off(t) - q*ex.  With A taps dx in {0,+1} per (dz,dy) group, (t,q) = (0,1),(0,0),(1,0)
+// are dx = -1, 0, +1: 9 groups (+1 bias group) instead of 14 tap pairs -> 1.5x fewer MFMAs.  The voxel set of the
+// q = 1 columns is the tile shifted by +1 in x; the column it misses (u.x = 0, tap dx = -1) multiplies the
+// zero-padded x[-1], so nothing is lost and no correction pass is needed.
+// CIT = 8: M rows = (t in {0,1}) x 8 ci, group g = (dz,dy).   CIT = 4: M rows = (pair pp in {0,1}, t in {0,1}) x 4 ci,
+// group g = two consecutive (dz,dy) combos.
+constexpr int NP_DX = TX + 1;                          // d_y tile keeps one extra voxel column per row
+template <int CIT>
+__global__ __launch_bounds__(NTHR) void conv3d_wgrad_np_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ part, int D, int H, int W, int Cin,
+                                                               int Cout, int tiles_x, int tiles_y, int tiles_z,
+                                                               int ntiles) {
+  constexpr int NCOMBO = 9, CPG = 8 / CIT;             // (dz,dy) combos per group: 1 (CIT 8) or 2 (CIT 4)
+  constexpr int NGT = (NCOMBO + CPG - 1) / CPG;        // tap groups: 9 or 5
+  constexpr int NG = NGT + 1;                          // + bias group
+  constexpr int GPW = (NG + 3) / 4;
+  __shared__ __attribute__((aligned(16))) float xs[WG_HVOX * CIT];
+  __shared__ __attribute__((aligned(16))) float dys[WG_ROWS * NP_DX * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+
+  f32x4 acc[GPW];
+  int aoff[GPW];
+  bool aval[GPW], abias[GPW];
+#pragma unroll
+  for (int g = 0; g < GPW; ++g) {
+    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int grp = wave + 4 * g;                      // groups interleaved over the waves: (3,3,2,2) / (2,2,1,1)
+    const int t = li / CIT, ci = li % CIT;
+    const int combo = grp * CPG + (CPG == 2 ? (t >> 1) : 0), dxs = t & 1;
+    aval[g] = grp < NGT && combo < NCOMBO;
+    abias[g] = (grp == NGT) && (li == 0);
+    const int cc = combo < NCOMBO ? combo : 0;
+    aoff[g] = (((cc / 3) * WG_HY + (cc % 3)) * HX + 1 + dxs + lk) * CIT + ci;
+  }
+  const int bq = li >> 3, bco = li & 7;                // B column = (q, co)
+
+  constexpr int QX = CIT / 4, NXV = (WG_HVOX * QX + NTHR - 1) / NTHR;
+  constexpr int NDV = (WG_ROWS * NP_DX * 2 + NTHR - 1) / NTHR;
+  float4 xr[NXV], dr[NDV];
+  const bool xvec = (Cin & 3) == 0, dvec = (Cout & 3) == 0;
+
+  auto load_tile = [&](int tl) {
+    int t = tl;
+    const int x0 = (t % tiles_x) * TX; t /= tiles_x;
+    const int y0 = (t % tiles_y) * WG_TY; t /= tiles_y;
+    const int z0 = (t % tiles_z) * WG_TZ;
+    const int64_t vb = (int64_t)(t / tiles_z) * D * H * W;
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int idx = tid + i * NTHR;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < WG_HVOX * QX) {
+        const int hv = idx / QX, c4 = idx - hv * QX;
+        const int hx = hv % HX, t2 = hv / HX;
+        const int hy = t2 % WG_HY, hz = t2 / WG_HY;
+        const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+        const int c = c4 * 4;
+        if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin) {
+          const float* p = x + (vb + ((int64_t)z * H + yy) * W + xx) * Cin + c;
+          if (xvec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (c + 1 < Cin) v.y = p[1];
+            if (c + 2 < Cin) v.z = p[2];
+            if (c + 3 < Cin) v.w = p[3];
+          }
+        }
+      }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int idx = tid + i * NTHR;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < WG_ROWS * NP_DX * 2) {
+        const int vox = idx >> 1, c4 = idx & 1;
+        const int row = vox / NP_DX, xx = x0 + vox % NP_DX;
+        const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY;
+        const int co = c4 * 4;
+        if (z < D && yy < H && xx < W && co < Cout) {
+          const float* p = dy + (vb + ((int64_t)z * H + yy) * W + xx) * Cout + co;
+          if (dvec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (co + 1 < Cout) v.y = p[1];
+            if (co + 2 < Cout) v.z = p[2];
+            if (co + 3 < Cout) v.w = p[3];
+          }
+        }
+      }
+      dr[i] = v;
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int idx = tid + i * NTHR;
+      if (idx < WG_HVOX * QX) *reinterpret_cast<float4*>(xs + idx * 4) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int idx = tid + i * NTHR;
+      if (idx < WG_ROWS * NP_DX * 2) *reinterpret_cast<float4*>(dys + idx * 4) = dr[i];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+#pragma unroll 4
+    for (int row = 0; row < WG_ROWS; ++row) {
+      const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float bf = dys[(row * NP_DX + s * 4 + lk + bq) * 8 + bco];
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+          float a = xs[rb + s * 4 * CIT + aoff[g]];
+          if (!aval[g]) a = abias[g] ? 1.f : 0.f;
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf, acc[g], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < GPW; ++g) {
+    const int grp = wave + 4 * g;
+    if (grp >= NG) continue;
+    float* p = part + ((int64_t)blockIdx.x * NG + grp) * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[(lk * 4 + j) * 16 + li] = acc[g][j];
+  }
+}
+
+// finalize for the N-packed layout (Cin <= 8, Cout <= 8): G lanes per output, fixed tree, fp64
+__global__ __launch_bounds__(256) void wgrad_np_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                float* __restrict__ db, int Cin, int Cout, int gx, int cit,
+                                                                int G) {
+  const int nw = Cout * Cin * 27, total = nw + (db ? Cout : 0);
+  const int per_blk = 256 / G;
+  const int i = blockIdx.x * per_blk + threadIdx.x / G, l = threadIdx.x % G;
+  const bool on = i < total;
+  const int cpg = 8 / cit, ngt = (9 + cpg - 1) / cpg, ng = ngt + 1;
+  int grp, mrow, col;
+  if (i < nw) {
+    const int tap = i % 27, ci = (i / 27) % Cin, co = i / (27 * Cin);
+    const int combo = tap / 3, dxi = tap % 3;               // dxi 0,1,2 <-> dx -1,0,+1
+    const int t = dxi == 2 ? 1 : 0, q = dxi == 0 ? 1 : 0;   // (t,q): dx=-1 -> (0,1), 0 -> (0,0), +1 -> (1,0)
+    grp = combo / cpg;
+    mrow = ((cpg == 2 ? (combo % 2) * 2 : 0) + t) * cit + ci;
+    col = q * 8 + co;
+  } else {
+    grp = ngt; mrow = 0; col = on ? i - nw : 0;
+  }
+  double s = 0.0;
+  if (on)
+    for (int bx = l; bx < gx; bx += G) s += (double)part[((int64_t)bx * ng + grp) * 256 + mrow * 16 + col];
+  for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (on && l == 0) {
+    if (i < nw) dw[i] = (float)s; else db[i - nw] = (float)s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ Cin == 1
 // First encoder conv (1 -> 4): K = 27 is far below an MFMA tile and the op is a pure HBM-bound stencil
 // (reads 4 B, writes 16 B per voxel), so it runs on the VALU: one thread per voxel, all CO outputs in registers.
@@ -738,6 +909,8 @@ size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int
   (void)N;
   size_t fl = (size_t)p.gx * p.gy * p.ng * 256;
   const size_t c1 = (size_t)C1_WG_BLOCKS * (27 * Cout + Cout);
+  const size_t np = (Cin <= 8 && Cout <= 8) ? (size_t)1024 * 10 * 256 : 0;
+  if (np > fl) fl = np;
   return (fl > c1 ? fl : c1) * sizeof(float);
 }
 
@@ -754,6 +927,23 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
     if (nblk > C1_WG_BLOCKS) nblk = C1_WG_BLOCKS;
     hipLaunchKernelGGL(conv_c1_wgrad_kernel<4>, dim3(nblk), dim3(NTHR), 0, s, x, d_y, (float*)ws, D, H, W, total);
     hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(27 * 4 + 4), dim3(64), 0, s, (const float*)ws, d_w, d_bias, nblk, 4);
+    return modet_launch_status();
+  }
+  if (Cin > 4 && Cin <= 8 && Cout <= 8) {          // (Cin <= 4 already fills M with 4 taps; N-packing measured no gain there)
+    const int cit = 8;
+    const int tx = cdiv(W, TX), ty = cdiv(H, WG_TY), tz = cdiv(D, WG_TZ);
+    const int ntiles = B * tx * ty * tz;
+    int gx = ntiles < 1024 ? ntiles : 1024;
+    float* part = (float*)ws;
+    if (cit == 4)
+      hipLaunchKernelGGL(conv3d_wgrad_np_kernel<4>, dim3(gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, tx, ty, tz, ntiles);
+    else
+      hipLaunchKernelGGL(conv3d_wgrad_np_kernel<8>, dim3(gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, tx, ty, tz, ntiles);
+    int G = 1;
+    while (G < gx && G < 64) G <<= 1;
+    const int total = Cout * Cin * 27 + (d_bias ? Cout : 0);
+    hipLaunchKernelGGL(wgrad_np_finalize_kernel, dim3(cdiv(total, 256 / G)), dim3(256), 0, s, (const float*)part, d_w, d_bias,
+                       Cin, Cout, gx, cit, G);
     return modet_launch_status();
   }
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
