@@ -179,3 +179,45 @@ def test_full_size_train_step_runs_and_is_sane():
     assert float(l1) < float(l0) + 1e-3, "loss should not blow up over 4 Adam steps on one pair"
     _note("train[160x192x160].loss0", float(l0))
     _note("train[160x192x160].loss3", float(l1))
+
+
+def test_full_size_dice_parity_vs_oracle():
+    """north-star parity statement: Dice on (synthetic 54-label) LPBA-shaped labels matches the reference path to
+    +-0.001 at 160x192x160.  Reference path = CPU oracle forward (fp32, same op sequence as ModeT/models.py) ->
+    nearest label warp -> dice_val_VOI arithmetic (utils.py:86-106); ours = HIP forward -> fused GPU eval tail."""
+    from oracle import modet_torch as orc
+    from smilecode_amd import synth
+    from smilecode_amd.utils import warp_labels_and_dice
+    shape = (160, 192, 160)
+    model = _model(shape, 1.0)
+    mov, fix = _pair(shape)
+    with torch.no_grad():
+        _, flow = model(mov, fix)
+    lab_m = torch.from_numpy(synth.make_labels(shape, 24))[None, None]
+    lab_f = torch.from_numpy(synth.make_labels(shape, 25))[None, None]
+    warped, dice_gpu = warp_labels_and_dice(lab_m.cuda(), flow, lab_f.cuda())
+    # (1) same flow through the oracle's eval tail: the label warp must agree voxel for voxel except exact .5 ties
+    w_ref = orc.warp(lab_m.float(), flow.cpu(), "nearest")
+    mism = float((w_ref.to(torch.int16) != warped.cpu()).float().mean())
+    assert mism < 1e-5, f"label warp differs on {mism:.2e} of the voxels"
+    d_same = orc.dice_voi(w_ref.long(), lab_f.long())
+    assert abs(d_same - dice_gpu) < 1e-4
+    # (2) the oracle's own forward (CPU fp32) -> its flow -> its Dice
+    p = {n: torch.from_numpy(v) for n, v in synth.make_weights(24).items()}
+    with torch.no_grad():
+        _, f_ref = orc.modet_forward(p, mov.cpu(), fix.cpu(), (8, 4, 2, 1, 1), 6, 1.0)
+    d_ref = orc.dice_voi(orc.warp(lab_m.float(), f_ref, "nearest").long(), lab_f.long())
+    # fp64 oracle: separates our error from the fp32 CPU path's own (both are fp32 noise on |flow| up to ~17)
+    with torch.no_grad():
+        _, f64 = orc.modet_forward({n: v.double() for n, v in p.items()}, mov.double().cpu(), fix.double().cpu(),
+                                   (8, 4, 2, 1, 1), 6, 1.0)
+    e_hip = float((flow.double().cpu() - f64).abs().max())
+    e_cpu32 = float((f_ref.double() - f64).abs().max())
+    _note("fwd[160x192x160].flow_maxerr_voxels_hip_vs_fp64", e_hip)
+    _note("fwd[160x192x160].flow_maxerr_voxels_cpu_fp32_vs_fp64", e_cpu32)
+    _note("fwd[160x192x160].flow_rmserr_voxels_hip_vs_fp64", float((flow.double().cpu() - f64).pow(2).mean().sqrt()))
+    assert e_hip <= max(1e-2, 3.0 * e_cpu32), "HIP fp32 forward is much noisier than the fp32 CPU path"
+    _note("dice[160x192x160].hip", dice_gpu)
+    _note("dice[160x192x160].oracle", d_ref)
+    _note("dice[160x192x160].flow_maxerr_voxels_fp32_vs_fp32", float((flow.cpu() - f_ref).abs().max()))
+    assert abs(d_ref - dice_gpu) <= 1e-3, f"Dice {dice_gpu:.5f} vs reference path {d_ref:.5f}"
