@@ -118,9 +118,13 @@ int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const 
  * add_flow=1 (needs C==3): out = warp(src,flow) + flow, the composition of models.py:392,:398,:403,:408. */
 int modet_warp_fwd(const float* src, const float* flow, float* out, int B, int D, int H, int W, int C,
                    int mode, int add_flow, modet_stream_t stream);
-/* d_src (zeroed here, then scatter-added) and/or d_flow; either may be NULL.  Trilinear only. */
+/* d_src and/or d_flow; either may be NULL.  Trilinear only.
+ * flow_bound = 0: arbitrary flow, d_src is zeroed here and scatter-added with float atomics (as ATen does).
+ * flow_bound = 1: the CALLER guarantees |flow| <= 1 voxel everywhere (true for the attention output w of
+ *   ModeTransformer, an expectation over offsets in {-1,0,1}^3; models.py:392-408 compose with exactly that):
+ *   d_src is then gathered from the 27 neighbours -- no atomics, deterministic.  C must be 3. */
 int modet_warp_bwd(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow,
-                   int B, int D, int H, int W, int C, int add_flow, modet_stream_t stream);
+                   int B, int D, int H, int W, int C, int add_flow, int flow_bound, modet_stream_t stream);
 
 /* nn.Upsample(2,'trilinear',align_corners=True) of scale*x (models.py:354,:257-261); d,h,w = INPUT dims.
  * x (B,d,h,w,C) -> y (B,2d,2h,2w,C).  Backward is the exact transpose in gather form (no atomics). */

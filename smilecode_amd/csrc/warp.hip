@@ -204,6 +204,86 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
   }
 }
 
+// Bounded-flow backward (|flow| <= 1, C == 3: the flow compositions with an attention output).  A sample point
+// p + flow[p] lies within one voxel of p, so source voxel s only receives from the 27 voxels p = s + d, d in {-1,0,1}^3,
+// with weight prod_a max(0, 1 - |p_a + flow_a[p] - s_a|) (the trilinear hat: (1-f) at floor, f at floor+1).
+// One thread per voxel does both jobs: gathers d_src[s] (no atomics, deterministic) and, as p, its own d_flow.
+__global__ __launch_bounds__(BLK) void warp_bwd_gather3_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                               const float* __restrict__ dout, float* __restrict__ dsrc,
+                                                               float* __restrict__ dflow, int D, int H, int W,
+                                                               int64_t total, int add_flow) {
+  const int64_t V = (int64_t)D * H * W;
+  for (int64_t n = (int64_t)blockIdx.x * BLK + threadIdx.x; n < total; n += (int64_t)gridDim.x * BLK) {
+    const int64_t b = n / V, v = n - b * V;
+    const int xi = (int)(v % W);
+    const int64_t t2 = v / W;
+    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
+    if (dsrc) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int pz = zi + dz;
+        if (pz < 0 || pz >= D) continue;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int py = yi + dy;
+          if (py < 0 || py >= H) continue;
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int px = xi + dx;
+            if (px < 0 || px >= W) continue;
+            const int64_t pn = b * V + ((int64_t)pz * H + py) * W + px;
+            const float* fp = flow + pn * 3;
+            const float wz = 1.f - fabsf((float)dz + fp[0]);
+            const float wy = 1.f - fabsf((float)dy + fp[1]);
+            const float wx = 1.f - fabsf((float)dx + fp[2]);
+            if (wz > 0.f && wy > 0.f && wx > 0.f) {
+              const float wgt = wz * wy * wx;
+              const float* gp = dout + pn * 3;
+              a0 = fmaf(wgt, gp[0], a0); a1 = fmaf(wgt, gp[1], a1); a2 = fmaf(wgt, gp[2], a2);
+            }
+          }
+        }
+      }
+      float* dp = dsrc + n * 3;
+      dp[0] = a0; dp[1] = a1; dp[2] = a2;
+    }
+    if (dflow) {
+      const float* fp = flow + n * 3;
+      const Tri t = tri_setup((float)zi + fp[0], (float)yi + fp[1], (float)xi + fp[2]);
+      const float* gp = dout + n * 3;
+      const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+      const float* sb = src + b * V * 3;
+      float gz = 0.f, gy = 0.f, gx = 0.f;
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz) {
+        const int zz = t.z0 + dz;
+        const float wz = dz ? t.fz : 1.f - t.fz;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int yy = t.y0 + dy;
+          const float wy = dy ? t.fy : 1.f - t.fy;
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int xx = t.x0 + dx;
+            const float wx = dx ? t.fx : 1.f - t.fx;
+            if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+              const float* sp = sb + (((int64_t)zz * H + yy) * W + xx) * 3;
+              const float dot = sp[0] * g0 + sp[1] * g1 + sp[2] * g2;
+              gz += (dz ? 1.f : -1.f) * wy * wx * dot;
+              gy += (dy ? 1.f : -1.f) * wz * wx * dot;
+              gx += (dx ? 1.f : -1.f) * wz * wy * dot;
+            }
+          }
+        }
+      }
+      if (add_flow) { gz += g0; gy += g1; gx += g2; }
+      float* dfp = dflow + n * 3;
+      dfp[0] = gz; dfp[1] = gy; dfp[2] = gx;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ upsample x2
 struct Lin { int i0, i1; float l0, l1; };
 // ATen compute_source_index_and_lambda, align_corners=True (UpSample.h): src = ratio*dst
@@ -443,11 +523,18 @@ int modet_warp_fwd(const float* src, const float* flow, float* out, int B, int D
 }
 
 int modet_warp_bwd(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow, int B, int D,
-                   int H, int W, int C, int add_flow, modet_stream_t stream) {
+                   int H, int W, int C, int add_flow, int flow_bound, modet_stream_t stream) {
   MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(d_out);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
   if (add_flow && C != 3) return MODET_ERR_DIM;
+  if (flow_bound != 0 && (flow_bound != 1 || C != 3)) return MODET_ERR_UNSUPPORTED;
   if (!d_src && !d_flow) return MODET_OK;
+  if (flow_bound == 1) {
+    const int64_t tot = (int64_t)B * D * H * W;
+    hipLaunchKernelGGL(warp_bwd_gather3_kernel, dim3(flat_grid(tot, BLK)), dim3(BLK), 0, (hipStream_t)stream, src, flow,
+                       d_out, d_src, d_flow, D, H, W, tot, add_flow);
+    return modet_launch_status();
+  }
   int G = 1;
   while (G < C) G <<= 1;
   if (G > 64) return MODET_ERR_UNSUPPORTED;

@@ -76,8 +76,8 @@ class SpatialTransformer(nn.Module):
                        0 if self.mode == "bilinear" else 1, False)
         return ops.to_ncdhw(out)
 
-    def forward_cl(self, src_cl, flow_cl, add_flow=False):
-        return ops.warp(src_cl, flow_cl, 0 if self.mode == "bilinear" else 1, add_flow)
+    def forward_cl(self, src_cl, flow_cl, add_flow=False, flow_bound=0):
+        return ops.warp(src_cl, flow_cl, 0 if self.mode == "bilinear" else 1, add_flow, flow_bound)
 
 
 class _Conv3dParams(nn.Module):
@@ -284,12 +284,13 @@ class ModeT(nn.Module):
         M2 = ST[1].forward_cl(M[1], flow)
         q2, k2 = self.projblock2(Fx[1]), self.projblock2(M2)
         w = self.mdt2(q2, k2)
-        flow = ops.upsample2(ST[1].forward_cl(flow, w, add_flow=True), 2.0)
+        # w comes straight from the attention (expected offset in [-1,1]^3): bounded-flow backward, no atomics
+        flow = ops.upsample2(ST[1].forward_cl(flow, w, add_flow=True, flow_bound=1), 2.0)
 
         M1 = ST[0].forward_cl(M[0], flow)
         q1, k1 = self.projblock1(Fx[0]), self.projblock1(M1)
         w = self.mdt1(q1, k1)
-        flow = ST[0].forward_cl(flow, w, add_flow=True)
+        flow = ST[0].forward_cl(flow, w, add_flow=True, flow_bound=1)
 
         y_moved = ST[0].forward_cl(mov_cl, flow)
         return ops.to_ncdhw(y_moved), ops.to_ncdhw(flow)

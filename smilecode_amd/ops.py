@@ -323,7 +323,7 @@ def neighbourhood_attention(q, k, rpb, heads, scale):
 
 class _Warp(Function):
     @staticmethod
-    def forward(ctx, src, flow, mode, add_flow):
+    def forward(ctx, src, flow, mode, add_flow, flow_bound=0):
         _chk(src, flow)
         B, D, H, W, C = src.shape
         if tuple(flow.shape) != (B, D, H, W, 3):
@@ -334,7 +334,7 @@ class _Warp(Function):
             _lib.check(_L().modet_warp_fwd(_p(src), _p(flow), _p(out), B, D, H, W, C, mode, int(add_flow), _stream()),
                        "modet_warp_fwd")
         ctx.save_for_backward(src, flow)
-        ctx.mode, ctx.add_flow = mode, int(add_flow)
+        ctx.mode, ctx.add_flow, ctx.flow_bound = mode, int(add_flow), int(flow_bound)
         return out
 
     @staticmethod
@@ -349,13 +349,14 @@ class _Warp(Function):
         n = float(B) * D * H * W
         with _Guard(src, f"warp_bwd[C{C}]", n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6)):
             _lib.check(_L().modet_warp_bwd(_p(src), _p(flow), _p(dout), _p(dsrc), _p(dflow), B, D, H, W, C,
-                                           ctx.add_flow, _stream()), "modet_warp_bwd")
-        return dsrc, dflow, None, None
+                                           ctx.add_flow, ctx.flow_bound if C == 3 else 0, _stream()), "modet_warp_bwd")
+        return dsrc, dflow, None, None, None
 
 
-def warp(src, flow, mode=0, add_flow=False):
-    """SpatialTransformer on channels-last tensors; add_flow -> warp(src,flow)+flow.  reference: models.py:25-67"""
-    return _Warp.apply(src, flow, mode, add_flow)
+def warp(src, flow, mode=0, add_flow=False, flow_bound=0):
+    """SpatialTransformer on channels-last tensors; add_flow -> warp(src,flow)+flow.  reference: models.py:25-67.
+    flow_bound=1 promises |flow| <= 1 voxel (attention outputs): the backward then gathers d_src without atomics."""
+    return _Warp.apply(src, flow, mode, add_flow, flow_bound)
 
 
 class _Upsample2(Function):

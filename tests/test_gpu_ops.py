@@ -124,6 +124,28 @@ def test_warp_compose_and_wide_channels(ops, orc):
         assert_close(ncdhw(df), rf.numpy(), atol=2e-4, rtol=1e-4, what=f"warp dflow C={C}")
 
 
+def test_warp_bounded_flow_gather_equals_scatter(ops, orc):
+    """flow_bound=1 (|flow| <= 1, incl. exactly +-1 and samples leaving the volume): atomics-free gather backward."""
+    gen = torch.Generator().manual_seed(17)
+    shape = (9, 10, 21)
+    src = torch.randn((2, 3) + shape, generator=gen).double().requires_grad_(True)
+    flow = (2 * torch.rand((2, 3) + shape, generator=gen) - 1).double()
+    flow[:, :, 0, 0, :4] = torch.tensor([1.0, -1.0, 0.0, 0.5]).double()        # boundary values of the promise
+    flow.requires_grad_(True)
+    ref = orc.warp(src, flow) + flow
+    gy = torch.randn(ref.shape, generator=gen).double()
+    rs, rf = torch.autograd.grad(ref, [src, flow], gy)
+    s, f = cl(src.detach().numpy()).requires_grad_(True), cl(flow.detach().numpy()).requires_grad_(True)
+    out = ops.warp(s, f, 0, True, 1)
+    assert_close(ncdhw(out), ref.detach().numpy(), what="bounded warp out")
+    ds, df = torch.autograd.grad(out, [s, f], cl(gy.numpy()))
+    assert_close(ncdhw(ds), rs.numpy(), atol=5e-5, what="bounded warp dsrc (gather)")
+    assert_close(ncdhw(df), rf.numpy(), atol=2e-4, rtol=1e-4, what="bounded warp dflow")
+    ds2, df2 = torch.autograd.grad(ops.warp(s, f, 0, True, 0), [s, f], cl(gy.numpy()))
+    assert_close(np64(ds), np64(ds2), atol=1e-5, what="gather vs scatter")
+    assert float((df - df2).abs().max()) < 2e-5       # same math, different summation order over the 3 channels
+
+
 # ------------------------------------------------------------------------------------------------ projection
 @pytest.mark.parametrize("tag", ["p1", "p3", "p5"])
 def test_projection_golden(ops, tag):
