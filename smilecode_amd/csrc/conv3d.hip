@@ -477,8 +477,18 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
   const int grp = tap / tp, mrow = (tap % tp) * cit + (ci % cit);
   const int by = (co / 16) * n_ci_tiles + ci / cit;
   double s = 0.0;
-  if (on)
-    for (int bx = l; bx < gx; bx += G) s += (double)part[(((int64_t)bx * gy + by) * ng + grp) * 256 + mrow * 16 + (co % 16)];
+  if (on) {
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* pp = part + ((int64_t)by * ng + grp) * 256 + mrow * 16 + (co % 16);
+    const int64_t st = (int64_t)gy * ng * 256;
+    int bx = l;
+    for (; bx + 3 * G < gx; bx += 4 * G) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += (double)pp[(int64_t)(bx + u * G) * st];
+    }
+    for (; bx < gx; bx += G) s4[0] += (double)pp[(int64_t)bx * st];
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
   for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (on && l == 0) {
     if (i < nw) dw[i] = (float)s; else db[i - nw] = (float)s;
@@ -648,8 +658,18 @@ __global__ __launch_bounds__(256) void wgrad_np_finalize_kernel(const float* __r
     grp = ngt; mrow = 0; col = on ? i - nw : 0;
   }
   double s = 0.0;
-  if (on)
-    for (int bx = l; bx < gx; bx += G) s += (double)part[((int64_t)bx * ng + grp) * 256 + mrow * 16 + col];
+  if (on) {
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* pp = part + (int64_t)grp * 256 + mrow * 16 + col;
+    const int64_t st = (int64_t)ng * 256;
+    int bx = l;
+    for (; bx + 3 * G < gx; bx += 4 * G) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += (double)pp[(int64_t)(bx + u * G) * st];
+    }
+    for (; bx < gx; bx += G) s4[0] += (double)pp[(int64_t)bx * st];
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
   for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (on && l == 0) {
     if (i < nw) dw[i] = (float)s; else db[i - nw] = (float)s;

@@ -208,14 +208,26 @@ __global__ __launch_bounds__(BLK) void proj_dw_kernel(const float* __restrict__ 
   }
 }
 
-// out[i] = sum_blk part[blk*stride + off + i]: one workgroup per output, fixed assignment + fixed tree, fp64
-__global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk,
-                                                     int stride, int off, int n) {
+// column sums of the partial rows, one wave per output column, fixed assignment + fixed tree, fp64.  Column i of
+// `part` (row stride `stride`) goes to the segment it falls in: [0,n0) -> d0, [n0,n0+n1) -> d1, ... (one launch
+// finalises d_gamma, d_beta, d_bias and d_W together).
+__global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ part, int nblk, int stride, float* d0, int n0,
+                                                     float* d1, int n1, float* d2, int n2, float* d3, int n3) {
   const int i = blockIdx.x;
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[(int64_t)b * stride + off + i];
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
+  int b = threadIdx.x;
+  for (; b + 192 < nblk; b += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] += (double)part[(int64_t)(b + 64 * u) * stride + i];
+  }
+  for (; b < nblk; b += 64) s4[0] += (double)part[(int64_t)b * stride + i];
+  double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   s = wave_sum_d(s);
-  if (threadIdx.x == 0) out[i] = (float)s;
+  if (threadIdx.x != 0) return;
+  if (i < n0) d0[i] = (float)s;
+  else if (i < n0 + n1) d1[i - n0] = (float)s;
+  else if (i < n0 + n1 + n2) d2[i - n0 - n1] = (float)s;
+  else if (i < n0 + n1 + n2 + n3) d3[i - n0 - n1 - n2] = (float)s;
 }
 
 inline int bwd_grid(int64_t N) {
@@ -285,17 +297,16 @@ int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const 
   else return MODET_ERR_UNSUPPORTED;
 #undef LAUNCH_BWD
   const bool regw = (dim == 6 && (Cin == 8 || Cin == 16));
-  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_gamma, nwp, npart, 0, dim);
-  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_beta, nwp, npart, dim, dim);
-  hipLaunchKernelGGL(colsum_kernel, dim3(dim), dim3(64), 0, s, part, d_bias, nwp, npart, 2 * dim, dim);
   if (regw) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(dim * Cin), dim3(64), 0, s, part, d_Wt, nwp, npart, 3 * dim,
-                       dim * Cin);
+    hipLaunchKernelGGL(colsum_kernel, dim3(3 * dim + dim * Cin), dim3(64), 0, s, (const float*)part, nwp, npart, d_gamma, dim,
+                       d_beta, dim, d_bias, dim, d_Wt, dim * Cin);
   } else {
+    hipLaunchKernelGGL(colsum_kernel, dim3(3 * dim), dim3(64), 0, s, (const float*)part, nwp, npart, d_gamma, dim, d_beta, dim,
+                       d_bias, dim, (float*)nullptr, 0);
     const int nchunk = (int)cdiv64(N, DW_CHUNK);
     hipLaunchKernelGGL(proj_dw_kernel, dim3(nchunk), dim3(BLK), 0, s, x, dz, dwpart, N, Cin, dim);
-    hipLaunchKernelGGL(colsum_kernel, dim3(dim * Cin), dim3(64), 0, s, dwpart, d_Wt, nchunk, dim * Cin, 0,
-                       dim * Cin);
+    hipLaunchKernelGGL(colsum_kernel, dim3(dim * Cin), dim3(64), 0, s, (const float*)dwpart, nchunk, dim * Cin, d_Wt, dim * Cin,
+                       (float*)nullptr, 0, (float*)nullptr, 0, (float*)nullptr, 0);
   }
   return modet_launch_status();
 }

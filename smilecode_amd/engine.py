@@ -41,6 +41,7 @@ class Trainer:
         self.fp.zero_grad()
         loss, sim, reg = self.loss(moving, fixed)
         loss.backward()
+        self.fp.gather_grads()
         scale = self.fp.allreduce_grads(self.group)
         self.step += 1
         ops.adam_amsgrad_step_(self.fp.flat, self.fp.grad, self.m, self.v, self.vmax,

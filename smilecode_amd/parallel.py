@@ -64,10 +64,25 @@ class FlatParams:
         self.numel = n
 
     def zero_grad(self):
-        self.grad.zero_()
-        for p, (off, k) in zip(self.params, self.offsets):     # re-attach if something replaced .grad
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
-                p.grad = self.grad[off:off + k].view(p.shape)
+        """Detach the per-parameter .grad tensors: autograd then *assigns* the first incoming gradient instead of
+        launching one tiny add kernel per parameter into a pre-zeroed buffer; `gather_grads` packs them afterwards."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """pack every parameter gradient into the flat buffer (one fused multi-tensor copy)"""
+        views, srcs, missing = [], [], []
+        for p, (off, k) in zip(self.params, self.offsets):
+            v = self.grad[off:off + k].view(p.shape)
+            if p.grad is None:
+                missing.append(v)
+            else:
+                views.append(v)
+                srcs.append(p.grad)
+        if views:
+            torch._foreach_copy_(views, srcs)
+        for v in missing:
+            v.zero_()
 
     def allreduce_grads(self, group=None):
         """sum over ranks (in place); returns the factor the optimizer must apply (1/world)"""

@@ -189,7 +189,8 @@ def _dp_worker(rank, world, port, q):
     x = torch.full((4, 5), float(rank + 1))
     fp.zero_grad()
     net(x).sum().backward()
-    assert net[0].weight.grad.data_ptr() == fp.grad.data_ptr()        # grads accumulate into the flat buffer
+    fp.gather_grads()                                                 # one fused copy into the flat buffer
+    assert torch.equal(fp.grad[:35].view(7, 5), net[0].weight.grad)
     local = fp.grad.clone()
     scale = fp.allreduce_grads()
     q.put((rank, fp.flat.clone().numpy(), local.numpy(), (fp.grad * scale).numpy()))

@@ -172,7 +172,7 @@ def test_full_size_train_step_runs_and_is_sane():
     tr = Trainer(model)
     l0, s0, r0 = tr.train_step(mov, fix)
     assert torch.isfinite(tr.fp.grad).all()
-    assert float(tr.fp.grad.abs().max()) > 0
+    assert float(tr.fp.grad.abs().max()) > 0          # flat buffer holds the packed gradients of the last step
     for _ in range(3):
         l1, s1, r1 = tr.train_step(mov, fix)
     assert torch.isfinite(l1)
