@@ -1,0 +1,142 @@
+"""Training script with the reference's hyper-parameters, loop shape, log lines and checkpoint policy
+(ModeT/train.py:42-176), on the MI355X-native path.  One process per GPU:
+
+    python -m smilecode_amd.train --train-dir /LPBA_path/Train/ --val-dir /LPBA_path/Val/
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m smilecode_amd.train ...
+    python -m smilecode_amd.train --synthetic 4 --img-size 64,64,64 --max-epoch 1      # no data needed
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+import random
+import re
+import sys
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import data, utils
+from .engine import Trainer, poly_lr
+from .models import ModeT
+from .parallel import init_from_env, pairs_for_rank
+
+
+def same_seeds(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class Logger(object):
+    """tee stdout into logs/<save_dir>/logfile.log (train.py:30-40)"""
+
+    def __init__(self, save_dir):
+        self.terminal = sys.stdout
+        self.log = open(save_dir + "logfile.log", "a")
+
+    def write(self, message):
+        self.terminal.write(message)
+        self.log.write(message)
+
+    def flush(self):
+        self.terminal.flush()
+        self.log.flush()
+
+
+def _natkey(s):
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", s)]
+
+
+def save_checkpoint(state, save_dir="models", filename="checkpoint.pth.tar", max_model_num=8):
+    """keep at most 8 files, dropping the naturally-sorted first = lowest Dice (train.py:171-176)"""
+    torch.save(state, save_dir + filename)
+    model_lists = sorted(glob.glob(save_dir + "*"), key=_natkey)
+    while len(model_lists) > max_model_num:
+        os.remove(model_lists[0])
+        model_lists = sorted(glob.glob(save_dir + "*"), key=_natkey)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train-dir", default="/LPBA_path/Train/")
+    ap.add_argument("--val-dir", default="/LPBA_path/Val/")
+    ap.add_argument("--synthetic", type=int, default=0, help="use N seeded synthetic subjects instead of .pkl files")
+    ap.add_argument("--img-size", default="160,192,160")
+    ap.add_argument("--max-epoch", type=int, default=30)
+    ap.add_argument("--max-iters", type=int, default=0, help="stop each epoch after this many iterations (0 = all)")
+    ap.add_argument("--lr", type=float, default=0.0001)
+    ap.add_argument("--out", default=".")
+    args = ap.parse_args(argv)
+    same_seeds(24)
+    rank, local, world = init_from_env()
+    torch.cuda.set_device(local)
+
+    weights = [1, 1]
+    head_dim, num_heads = 6, [8, 4, 2, 1, 1]
+    img_size = tuple(int(s) for s in args.img_size.split(","))
+    save_dir = "modet-heads({}{}{}{}{})-rpe_headim_{}_ncc_{}_reg_{}_lr_{}_54r/".format(*num_heads, head_dim, weights[0],
+                                                                                       weights[1], args.lr)
+    exp_dir, log_dir = os.path.join(args.out, "experiments/" + save_dir), os.path.join(args.out, "logs/" + save_dir)
+    f = None
+    if rank == 0:
+        os.makedirs(exp_dir, exist_ok=True)
+        os.makedirs(log_dir, exist_ok=True)
+        sys.stdout = Logger(log_dir)
+        f = open(os.path.join(log_dir, "losses and dice.txt"), "a")
+
+    model = ModeT(img_size, head_dim=head_dim, num_heads=num_heads, scale=1).cuda()
+    trainer = Trainer(model, lr=args.lr, max_epoch=args.max_epoch, weights=weights)   # Adam(amsgrad) + NCC + Grad3d('l2')
+
+    if args.synthetic:
+        train_set = data.SyntheticPairs(img_size, args.synthetic, 24)
+        val_set = data.SyntheticPairs(img_size, max(2, args.synthetic // 2), 124, with_labels=True)
+    else:
+        train_set = data.LPBABrainDatasetS2S(glob.glob(args.train_dir + "*.pkl"))
+        val_set = data.LPBABrainInferDatasetS2S(glob.glob(args.val_dir + "*.pkl"))
+    val_loader = DataLoader(val_set, batch_size=1, shuffle=False, num_workers=0, pin_memory=True, drop_last=True)
+
+    best_dsc = 0
+    for epoch in range(args.max_epoch):
+        if rank == 0:
+            print("Training Starts")
+        loss_all = utils.AverageMeter()
+        order = np.random.RandomState(24 + epoch).permutation(len(train_set))      # same shuffle on every rank
+        mine = [int(order[i]) for i in pairs_for_rank(len(order), rank, world)]
+        n_iter = len(mine) if not args.max_iters else min(len(mine), args.max_iters)
+        for idx in range(1, n_iter + 1):
+            x, y = train_set[mine[idx - 1]][:2]
+            x, y = x[None].cuda(non_blocking=True), y[None].cuda(non_blocking=True)
+            loss, sim, reg = trainer.train_step(x, y, epoch=epoch)      # lr = poly_lr(epoch) inside (train.py:117)
+            loss_all.update(loss.item(), y.numel())
+            if rank == 0:
+                print("Iter {} of {} loss {:.4f}, Img Sim: {:.6f}, Reg: {:.6f}".format(idx, n_iter, loss.item(), sim.item(),
+                                                                                     reg.item()))
+        if rank != 0:
+            continue
+        print("{} Epoch {} loss {:.4f}".format(save_dir, epoch, loss_all.avg))
+        print("Epoch {} loss {:.4f}".format(epoch, loss_all.avg), file=f, end=" ")
+        eval_dsc = utils.AverageMeter()
+        with torch.no_grad():
+            model.eval()
+            for batch in val_loader:
+                x, y, x_seg, y_seg = [t.cuda() for t in batch]
+                _, flow = model(x, y)
+                _, dsc = utils.warp_labels_and_dice(x_seg, flow, y_seg)     # fused GPU eval tail (train.py:152-153)
+                eval_dsc.update(dsc, x.size(0))
+                print(epoch, ":", eval_dsc.avg)
+        best_dsc = max(eval_dsc.avg, best_dsc)
+        print(eval_dsc.avg, file=f)
+        f.flush()
+        save_checkpoint({"epoch": epoch + 1, "state_dict": model.state_dict(), "best_dsc": best_dsc,
+                         "optimizer": {"step": trainer.step, "lr": poly_lr(epoch, args.max_epoch, args.lr)}},
+                        save_dir=exp_dir, filename="dsc{:.3f}.pth.tar".format(eval_dsc.avg))
+    return best_dsc
+
+
+if __name__ == "__main__":
+    main()

@@ -72,3 +72,18 @@ def warp_labels_and_dice(x_seg, flow, y_seg, nlabels=54):
     warped, counts = ops.label_warp_counts(x_seg[0, 0].to(torch.int16).cuda(), flow_cl[:1].contiguous(),
                                            y_seg[0, 0].to(torch.int16).cuda(), nlabels)
     return warped[None, None], dice_from_counts(counts, nlabels)
+
+
+def jacobian_determinant_vxm(disp):
+    """Jacobian determinant of a (3,D,H,W) displacement field with np.gradient, as the reference evaluates it on
+    the CPU (utils.py:108-150; `pystrum.volsize2ndgrid` is just the identity index grid).  Post-processing, not part
+    of the GPU hot path."""
+    disp = np.asarray(disp).transpose(1, 2, 3, 0)
+    vol = disp.shape[:-1]
+    grid = np.stack(np.meshgrid(*[np.arange(s) for s in vol], indexing="ij"), len(vol))
+    J = np.gradient(disp + grid)
+    dx, dy, dz = J[0], J[1], J[2]
+    d0 = dx[..., 0] * (dy[..., 1] * dz[..., 2] - dy[..., 2] * dz[..., 1])
+    d1 = dx[..., 1] * (dy[..., 0] * dz[..., 2] - dy[..., 2] * dz[..., 0])
+    d2 = dx[..., 2] * (dy[..., 0] * dz[..., 1] - dy[..., 1] * dz[..., 0])
+    return d0 - d1 + d2

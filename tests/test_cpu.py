@@ -214,3 +214,31 @@ def test_data_parallel_allreduce_gloo_world2():
     mean = 0.5 * (res[0][2] + res[1][2])
     assert np.allclose(res[0][3], mean) and np.allclose(res[1][3], mean)
     assert not np.allclose(res[0][2], res[1][2])
+
+
+def test_data_pipeline_pairs_and_label_remap(tmp_path):
+    """all-ordered-pairs indexing and Seg_norm table of the reference (datasets.py:24-26, trans.py:27-39)"""
+    import pickle
+    from smilecode_amd import data
+    n = 4
+    seen = [data.pair_indices(i, n) for i in range(n * (n - 1))]
+    assert len(set(seen)) == n * (n - 1) and all(a != b for a, b in seen)
+    assert seen[:4] == [(0, 1), (0, 2), (0, 3), (1, 0)]
+    lab = np.array([[0, 21, 34], [41, 166, 999], [20, 122, 161]], dtype=np.uint16)
+    assert data.seg_norm(lab).tolist() == [[0, 1, 14], [15, 54, 0], [0, 48, 49]]
+    for i in range(3):
+        with open(tmp_path / f"s{i}.pkl", "wb") as f:
+            pickle.dump((np.full((4, 4, 4), i, np.float32), np.full((4, 4, 4), 21 + i, np.uint16)), f)
+    ds = data.LPBABrainInferDatasetS2S([str(p) for p in tmp_path.glob("*.pkl")])
+    assert len(ds) == 6
+    x, y, xs, ys = ds[2]                                   # pair (1, 0) for n = 3
+    assert x.shape == (1, 4, 4, 4) and float(x[0, 0, 0, 0]) == 1.0 and float(y[0, 0, 0, 0]) == 0.0
+    assert xs.dtype == torch.int16 and int(xs[0, 0, 0, 0]) == 2 and int(ys[0, 0, 0, 0]) == 1
+
+
+def test_jacobian_determinant_identity_and_fold():
+    from smilecode_amd.utils import jacobian_determinant_vxm
+    disp = np.zeros((3, 6, 7, 8), np.float32)
+    assert np.allclose(jacobian_determinant_vxm(disp), 1.0)
+    disp[0] = -2.0 * np.arange(6)[:, None, None]            # x -> -x: folding
+    assert (jacobian_determinant_vxm(disp) < 0).all()

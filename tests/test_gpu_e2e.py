@@ -221,3 +221,25 @@ def test_full_size_dice_parity_vs_oracle():
     _note("dice[160x192x160].oracle", d_ref)
     _note("dice[160x192x160].flow_maxerr_voxels_fp32_vs_fp32", float((flow.cpu() - f_ref).abs().max()))
     assert abs(d_ref - dice_gpu) <= 1e-3, f"Dice {dice_gpu:.5f} vs reference path {d_ref:.5f}"
+
+
+def test_train_and_infer_scripts_synthetic(tmp_path):
+    """the train.py / infer.py equivalents run end to end (synthetic subjects, 64^3, 2 iterations), write the
+    reference's checkpoint dict and log files, and the checkpoint loads back through infer."""
+    import glob as _glob
+    import sys
+    from smilecode_amd import infer, train
+    out = str(tmp_path)
+    stdout = sys.stdout
+    try:
+        train.main(["--synthetic", "3", "--img-size", "64,64,64", "--max-epoch", "1", "--max-iters", "2", "--out", out])
+    finally:
+        sys.stdout = stdout
+    ck = _glob.glob(out + "/experiments/*/dsc*.pth.tar")
+    assert len(ck) == 1
+    sd = torch.load(ck[0], map_location="cpu")
+    assert set(sd) == {"epoch", "state_dict", "best_dsc", "optimizer"} and "encoder.conv0.0.main.weight" in sd["state_dict"]
+    log = open(_glob.glob(out + "/logs/*/logfile.log")[0]).read()
+    assert "Iter 1 of 2 loss" in log and "Img Sim:" in log
+    d = infer.main(["--synthetic", "2", "--img-size", "64,64,64", "--model-dir", os.path.dirname(ck[0]) + "/"])
+    assert 0.0 <= d <= 1.0
