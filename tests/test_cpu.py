@@ -242,3 +242,49 @@ def test_jacobian_determinant_identity_and_fold():
     assert np.allclose(jacobian_determinant_vxm(disp), 1.0)
     disp[0] = -2.0 * np.arange(6)[:, None, None]            # x -> -x: folding
     assert (jacobian_determinant_vxm(disp) < 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ C oracle pins
+def test_c_oracle_against_reference_goldens(orc):
+    """oracle/modet_ref.c (plain C, fp64) vs the vectors captured from the real reference, and vs the ATen oracle."""
+    from oracle import cref
+    from smilecode_amd import synth
+    import torch.nn.functional as F
+    g = gold("op_attention.npz")
+    for tag in ("h1", "h2", "h8"):
+        heads = int(tag[1:])
+        sc = float(g[f"{tag}.scale"])
+        q0, k0, rpb = g[f"{tag}.q"], g[f"{tag}.k"], g[f"{tag}.rpb"]
+        B, D, H, W, Cc = q0.shape
+        d = Cc // heads
+        # fused form (ModeT/models.py:308-334)
+        assert_close(np.moveaxis(cref.na_fwd(q0, k0, rpb.reshape(heads, 27), heads, sc), -1, 1), g[f"{tag}.out"],
+                     atol=1e-12, rtol=0, what="C na_fwd")
+        # CUDA-operator contract (modet_kernel.cu): logits and the three gradients
+        q = np.ascontiguousarray(np.transpose(q0.reshape(B, D, H, W, heads, d), (0, 4, 1, 2, 3, 5)) * sc)
+        kp = F.pad(T(k0).permute(0, 4, 1, 2, 3), (1, 1, 1, 1, 1, 1)).reshape(B, heads, d, D + 2, H + 2, W + 2)
+        kp = kp.permute(0, 1, 3, 4, 5, 2).contiguous().numpy()
+        attn = cref.modet_fw(q, kp, rpb.reshape(heads, 27))
+        assert_close(attn, g[f"{tag}.logits"], atol=1e-12, rtol=0, what="C modet_fw")
+        ga = np.random.default_rng(3).normal(size=attn.shape)
+        dq, dk, dr = cref.modet_bw(ga, q, kp)
+        qt, kt, rt = T(q).requires_grad_(True), T(kp).requires_grad_(True), T(rpb).requires_grad_(True)
+        cols = [(qt * kt[:, :, a:a + D, b:b + H, c:c + W]).sum(-1) for a in range(3) for b in range(3) for c in range(3)]
+        ref = torch.stack(cols, -1) + rt.reshape(1, heads, 1, 1, 1, 27)
+        rq, rk, rr = torch.autograd.grad(ref, [qt, kt, rt], T(ga))
+        assert_close(dq, rq.numpy(), atol=1e-12, rtol=0); assert_close(dk, rk.numpy(), atol=1e-12, rtol=0)
+        assert_close(dr, rr.numpy(), atol=1e-11, rtol=0)
+    g = gold("op_warp.npz")
+    for tag in ("a", "b", "c"):
+        assert_close(cref.warp(g[f"{tag}.src"], g[f"{tag}.flow"], 0), g[f"{tag}.out"], atol=1e-12, rtol=0, what="C warp")
+        assert np.array_equal(cref.warp(g[f"{tag}.lab"], g[f"{tag}.flow_n"], 1), g[f"{tag}.out_n"])
+    g = gold("op_misc.npz")
+    for tag in ("c0", "c1", "c2"):
+        raw, out = cref.conv_block(g[f"{tag}.x"], g[f"{tag}.w"], g[f"{tag}.b"], bool(g[f"{tag}.ins"]))
+        assert_close(raw, g[f"{tag}.raw"], atol=1e-12, rtol=0, what="C conv")
+        assert_close(out, g[f"{tag}.out"], atol=1e-11, rtol=0, what="C conv block")
+    assert abs(cref.ncc(g["ncc.a"], g["ncc.b"]) - float(g["ncc.val"])) < 1e-12
+    assert abs(cref.grad3d(g["g3d.flow"]) - float(g["g3d.val"])) < 1e-12
+    d = gold("op_dice.npz")
+    shape = tuple(int(s) for s in d["shape"])
+    assert abs(cref.dice(d["warped"], synth.make_labels(shape, 25)) - float(d["dice"])) < 1e-12
