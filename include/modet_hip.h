@@ -99,7 +99,9 @@ int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean
 int modet_lrelu_bwd(const float* d_y, const float* y, float* d_x, int64_t n, modet_stream_t stream);
 /* AvgPool3d(2) (models.py:201,:207,:213,:219); D,H,W are the INPUT dims (even). */
 int modet_avgpool2_fwd(const float* x, float* y, int B, int D, int H, int W, int C, modet_stream_t stream);
-int modet_avgpool2_bwd(const float* d_y, float* d_x, int B, int D, int H, int W, int C, modet_stream_t stream);
+/* d_x = unpool(d_y)/8 + addend; addend (same shape as d_x, may be NULL) = gradient of the un-pooled branch */
+int modet_avgpool2_bwd(const float* d_y, const float* addend, float* d_x, int B, int D, int H, int W, int C,
+                       modet_stream_t stream);
 
 /* ProjectionLayer: Linear(Cin->dim) + LayerNorm(dim, eps) (models.py:230-241).
  * x (N,Cin) channels-last voxels, Wt = proj.weight (dim,Cin), y (N,dim). */

@@ -171,8 +171,11 @@ __global__ __launch_bounds__(BLK) void avgpool2_fwd_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(BLK) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int D,
-                                                           int H, int W, int C, int64_t total4) {
+// dx = upsample(dy)/8 (+ addend): the optional addend is the gradient arriving on the un-pooled branch of the same
+// tensor, so "pool backward" and autograd's "sum of the two consumers" become one pass
+__global__ __launch_bounds__(BLK) void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ addend,
+                                                           float* __restrict__ dx, int D, int H, int W, int C,
+                                                           int64_t total4) {
   const int G = C >> 2, h = H / 2, w = W / 2, d = D / 2;
   for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
     const int g = (int)(i % G);
@@ -184,6 +187,10 @@ __global__ __launch_bounds__(BLK) void avgpool2_bwd_kernel(const float* __restri
     const int64_t off = (((b * d + zi / 2) * h + yi / 2) * w + xi / 2) * C + g * 4;
     float4 v = *reinterpret_cast<const float4*>(dy + off);
     v.x *= 0.125f; v.y *= 0.125f; v.z *= 0.125f; v.w *= 0.125f;
+    if (addend) {
+      const float4 a = reinterpret_cast<const float4*>(addend)[i];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
     reinterpret_cast<float4*>(dx)[i] = v;
   }
 }
@@ -276,14 +283,15 @@ int modet_avgpool2_fwd(const float* x, float* y, int B, int D, int H, int W, int
   return modet_launch_status();
 }
 
-int modet_avgpool2_bwd(const float* d_y, float* d_x, int B, int D, int H, int W, int C, modet_stream_t stream) {
+int modet_avgpool2_bwd(const float* d_y, const float* addend, float* d_x, int B, int D, int H, int W, int C,
+                       modet_stream_t stream) {
   MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_x);
   MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1 && C > 0);
   MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
   if (C % 4 != 0) return MODET_ERR_UNSUPPORTED;
   const int64_t total4 = (int64_t)B * D * H * W * (C / 4);
-  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, (hipStream_t)stream, d_y, d_x, D,
-                     H, W, C, total4);
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, (hipStream_t)stream, d_y, addend,
+                     d_x, D, H, W, C, total4);
   return modet_launch_status();
 }
 

@@ -132,12 +132,15 @@ class Encoder(nn.Module):
         self.conv4 = nn.Sequential(_AvgPool(), ConvInsBlock(16 * c, 32 * c), ConvInsBlock(32 * c, 32 * c))
 
     def forward(self, x):
-        out0 = self.conv0(x)
-        out1 = self.conv1(out0)
-        out2 = self.conv2(out1)
-        out3 = self.conv3(out2)
-        out4 = self.conv4(out3)
-        return out0, out1, out2, out3, out4
+        # each level's output goes to the next level (pooled) AND to the caller: pool_tee fuses the two gradient paths
+        outs = []
+        cur = self.conv0(x)
+        for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
+            pooled, keep = ops.pool_tee(cur)
+            outs.append(keep)
+            cur = blk[2](blk[1](pooled))              # blk[0] is the AvgPool3d(2) the tee already applied
+        outs.append(cur)
+        return tuple(outs)
 
 
 class _LinearParams(nn.Module):

@@ -235,13 +235,46 @@ class _AvgPool2(Function):
         B, D, H, W, C = ctx.shape
         dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
         with _Guard(dy, "avgpool2_bwd", dx.numel(), 4.5 * dx.numel()):
-            _lib.check(_L().modet_avgpool2_bwd(_p(dy), _p(dx), B, D, H, W, C, _stream()), "modet_avgpool2_bwd")
+            _lib.check(_L().modet_avgpool2_bwd(_p(dy), None, _p(dx), B, D, H, W, C, _stream()), "modet_avgpool2_bwd")
         return dx
 
 
 def avgpool2(x):
     """nn.AvgPool3d(2), channels-last.  reference: models.py:201,:207,:213,:219"""
     return _AvgPool2.apply(x)
+
+
+class _PoolTee(Function):
+    """x -> (avgpool2(x), x): the pyramid feeds every feature map both to the next level's pooling and to the
+    attention/warp branch; one backward kernel returns g_x + unpool(g_pooled)/8 instead of a pool-backward pass
+    followed by autograd's add over two full-size tensors."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        B, D, H, W, C = x.shape
+        y = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+        with _Guard(x, "avgpool2_fwd", x.numel(), 4.5 * x.numel()):
+            _lib.check(_L().modet_avgpool2_fwd(_p(x), _p(y), B, D, H, W, C, _stream()), "modet_avgpool2_fwd")
+        ctx.shape = (B, D, H, W, C)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gx):
+        B, D, H, W, C = ctx.shape
+        if gy is None:
+            return gx
+        gy = gy.contiguous()
+        add = None if gx is None else gx.contiguous()
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=gy.device)
+        with _Guard(gy, "avgpool2_bwd", dx.numel(), 4.5 * dx.numel() + (4.0 * dx.numel() if add is not None else 0.0)):
+            _lib.check(_L().modet_avgpool2_bwd(_p(gy), _p(add), _p(dx), B, D, H, W, C, _stream()), "modet_avgpool2_bwd")
+        return dx
+
+
+def pool_tee(x):
+    """(avgpool2(x), x) with a fused backward; see _PoolTee"""
+    return _PoolTee.apply(x)
 
 
 class _ProjLN(Function):
