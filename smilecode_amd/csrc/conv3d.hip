@@ -329,16 +329,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
-constexpr int WG_TZ = 2, WG_TY = 8, WG_ROWS = WG_TZ * WG_TY;
-constexpr int WG_HY = WG_TY + 2, WG_HVOX = (WG_TZ + 2) * WG_HY * HX;
+constexpr int WG_TY = 8, WG_HY = WG_TY + 2;         // wgrad voxel tile: WG_TZ (template) x 8 x 16
 
-template <int CIT>   // input channels per tap in the 16 M rows: 16 -> 1 tap, 8 -> 2 taps, 4 -> 4 taps per MFMA
+template <int CIT, int WG_TZ>   // CIT: input channels per tap in the 16 M rows (16 -> 1 tap, 8 -> 2, 4 -> 4 taps per MFMA)
 __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, int D, int H, int W, int Cin,
                                                             int Cout, int tiles_x, int tiles_y, int tiles_z,
                                                             int ntiles, int n_ci_tiles) {
   // tap index 27 is always a free slot (27 taps + 1 = 28 = 4 waves x 7 = 7 groups x 4 = 14 groups x 2): it carries
   // the bias gradient (A = 1), so d_bias costs no extra pass over d_y
+  constexpr int WG_ROWS = WG_TZ * WG_TY, WG_HVOX = (WG_TZ + 2) * WG_HY * HX;
   constexpr int TP = 16 / CIT, NG = (28 + TP - 1) / TP, GPW = (NG + 3) / 4, NSLOT = NG;
   __shared__ __attribute__((aligned(16))) float xs[WG_HVOX * CIT];
   __shared__ __attribute__((aligned(16))) float dys[WG_ROWS * TX * 16];
@@ -506,11 +506,12 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
 // CIT = 8: M rows = (t in {0,1}) x 8 ci, group g = (dz,dy).   CIT = 4: M rows = (pair pp in {0,1}, t in {0,1}) x 4 ci,
 // group g = two consecutive (dz,dy) combos.
 constexpr int NP_DX = TX + 1;                          // d_y tile keeps one extra voxel column per row
-template <int CIT>
+template <int CIT, int WG_TZ>
 __global__ __launch_bounds__(NTHR) void conv3d_wgrad_np_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ part, int D, int H, int W, int Cin,
                                                                int Cout, int tiles_x, int tiles_y, int tiles_z,
                                                                int ntiles) {
+  constexpr int WG_ROWS = WG_TZ * WG_TY, WG_HVOX = (WG_TZ + 2) * WG_HY * HX;
   constexpr int NCOMBO = 9, CPG = 8 / CIT;             // (dz,dy) combos per group: 1 (CIT 8) or 2 (CIT 4)
   constexpr int NGT = (NCOMBO + CPG - 1) / CPG;        // tap groups: 9 or 5
   constexpr int NG = NGT + 1;                          // + bias group
@@ -873,14 +874,15 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
   return modet_launch_status();
 }
 
-struct WgPlan { int cit, n_ci, n_co, gx, gy, ng, ntiles, tiles_x, tiles_y, tiles_z; };
+struct WgPlan { int cit, n_ci, n_co, gx, gy, ng, ntiles, tiles_x, tiles_y, tiles_z, tz; };
 inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   WgPlan p;
   p.cit = Cin <= 4 ? 4 : (Cin <= 8 ? 8 : 16);
   p.n_ci = cdiv(Cin, p.cit);
   p.n_co = cdiv(Cout, 16);
   p.gy = p.n_ci * p.n_co;
-  p.tiles_x = cdiv(W, TX); p.tiles_y = cdiv(H, WG_TY); p.tiles_z = cdiv(D, WG_TZ);
+  p.tz = (p.cit <= 8 && (int64_t)B * D * H * W >= 1000000) ? 4 : 2;     // big tiles for the full-resolution, few-channel layers
+  p.tiles_x = cdiv(W, TX); p.tiles_y = cdiv(H, WG_TY); p.tiles_z = cdiv(D, p.tz);
   p.ntiles = B * p.tiles_x * p.tiles_y * p.tiles_z;
   int gx = 1024 / p.gy;
   if (gx < 1) gx = 1;
@@ -951,14 +953,15 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
   }
   if (Cin > 4 && Cin <= 8 && Cout <= 8) {          // (Cin <= 4 already fills M with 4 taps; N-packing measured no gain there)
     const int cit = 8;
-    const int tx = cdiv(W, TX), ty = cdiv(H, WG_TY), tz = cdiv(D, WG_TZ);
+    const int tzv = ((int64_t)B * D * H * W >= 1000000) ? 4 : 2;
+    const int tx = cdiv(W, TX), ty = cdiv(H, WG_TY), tz = cdiv(D, tzv);
     const int ntiles = B * tx * ty * tz;
     int gx = ntiles < 1024 ? ntiles : 1024;
     float* part = (float*)ws;
-    if (cit == 4)
-      hipLaunchKernelGGL(conv3d_wgrad_np_kernel<4>, dim3(gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, tx, ty, tz, ntiles);
+    if (tzv == 4)
+      hipLaunchKernelGGL((conv3d_wgrad_np_kernel<8, 4>), dim3(gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, tx, ty, tz, ntiles);
     else
-      hipLaunchKernelGGL(conv3d_wgrad_np_kernel<8>, dim3(gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, tx, ty, tz, ntiles);
+      hipLaunchKernelGGL((conv3d_wgrad_np_kernel<8, 2>), dim3(gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, tx, ty, tz, ntiles);
     int G = 1;
     while (G < gx && G < 64) G <<= 1;
     const int total = Cout * Cin * 27 + (d_bias ? Cout : 0);
@@ -969,15 +972,12 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
   float* part = (float*)ws;
   dim3 grid(p.gx, p.gy);
-  if (p.cit == 4)
-    hipLaunchKernelGGL(conv3d_wgrad_kernel<4>, grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, p.tiles_x,
-                       p.tiles_y, p.tiles_z, p.ntiles, p.n_ci);
-  else if (p.cit == 8)
-    hipLaunchKernelGGL(conv3d_wgrad_kernel<8>, grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, p.tiles_x,
-                       p.tiles_y, p.tiles_z, p.ntiles, p.n_ci);
-  else
-    hipLaunchKernelGGL(conv3d_wgrad_kernel<16>, grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, p.tiles_x,
-                       p.tiles_y, p.tiles_z, p.ntiles, p.n_ci);
+#define WG_LAUNCH(CIT_, TZ_) hipLaunchKernelGGL((conv3d_wgrad_kernel<CIT_, TZ_>), grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, \
+                                               Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles, p.n_ci)
+  if (p.cit == 4) { if (p.tz == 4) WG_LAUNCH(4, 4); else WG_LAUNCH(4, 2); }
+  else if (p.cit == 8) { if (p.tz == 4) WG_LAUNCH(8, 4); else WG_LAUNCH(8, 2); }
+  else WG_LAUNCH(16, 2);
+#undef WG_LAUNCH
   int G = 1;
   while (G < p.gx && G < 64) G <<= 1;
   const int total = Cout * Cin * 27 + (d_bias ? Cout : 0);
