@@ -164,6 +164,16 @@ def main():
                 json.dump({"ops": breakdown, "families": {k: {kk: vv for kk, vv in v.items() if kk != "tags"}
                                                           for k, v in fams.items()}}, f, indent=1, sort_keys=True)
 
+    # host-side cost of one step (Python + autograd + ~500 launches), measured as the time to enqueue a step on an
+    # idle GPU: the device runs behind the host as long as this stays below ms_per_step
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    host_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"[bench] host enqueue time of one step: {host_ms:.2f} ms")
+
     # timed region: exactly K steps, only the dominant group carries events
     tsel = ops.KernelTimer(select=set(fams[dominant]["tags"]) if dominant else set())
     barrier()
@@ -216,7 +226,7 @@ def main():
                 *shape, args.batch, "full train step NCC+Grad3d fwd+bwd+Adam-amsgrad" + (" + RCCL grad all-reduce" if world > 1 else "")
                 if args.workload == "train" else "forward+warp")),
                 "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-            "roofline": roof,
+            "roofline": roof, "host_enqueue_ms_per_step": host_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -80,6 +80,14 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
 size_t modet_conv3d_ws_bytes(int Cin, int Cout);
 int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                      int B, int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream);
+/* Forward + fused InstanceNorm statistics (ConvInsBlock, models.py:135-151): the staged epilogue also emits
+ * per-(tile, wave) partial sums (sum, sum of squares) of the output.  modet_conv3d_stats_bytes() == 0 means this
+ * (Cin, Cout) cannot fuse them (use modet_conv3d_fwd + modet_instnorm_lrelu_fwd).  Consume with
+ * modet_instnorm_lrelu_fwd_stats (same stats_bytes). */
+size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                           float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                           modet_stream_t stream);
 /* d_x = conv(d_y, flipped/transposed w) */
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes,
                           int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
@@ -93,6 +101,9 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
 size_t modet_instnorm_ws_bytes(int B, int64_t V, int C);
 int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes,
                              int B, int64_t V, int C, float eps, modet_stream_t stream);
+/* same, with the statistics taken from modet_conv3d_fwd_stats' partials instead of a pass over x */
+int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, const float* stats,
+                                   size_t stats_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream);
 int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
                              void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream);
 /* d_x = d_y * (y > 0 ? 1 : 0.1): backward of the LeakyReLU fused into modet_conv3d_fwd(act=1) */

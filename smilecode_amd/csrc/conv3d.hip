@@ -56,7 +56,7 @@ template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P, bool
 __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ y, int D,
                                                            int H, int W, int Cin, int Cout, int CinP, int CoutP, int act,
-                                                           int tiles_x, int tiles_y, int tiles_z, int ntiles) {
+                                                           int tiles_x, int tiles_y, int tiles_z, int ntiles, float* __restrict__ stats) {
   constexpr int NTHR = WM * WN * 64;         // 4 or 8 waves per workgroup (shadows the file-level constant)
   static_assert(P == 1 || (WN == 1 && NT == 1 && TY % P == 0), "row packing needs a single 16-wide N tile");
   constexpr int ROWS = TZ * TY, NCB = WN * NT * 16;
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
     const int cq = Cout >> 2, per_row = TX * cq;
     constexpr int WROWS = R * P;                       // rows owned by this wave
+    float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = lane; i < WROWS * per_row; i += 64) {
       const int rl = i / per_row, f = i - rl * per_row;
       const int rr = wm * WROWS + rl;
@@ -226,8 +227,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
       if (z < D && yy < H && xx < W) {
         float4 v = *reinterpret_cast<const float4*>(stg + (rr * TX + vx) * OC + c4 * 4);
         v.x += bq4.x; v.y += bq4.y; v.z += bq4.z; v.w += bq4.w;
+        if (stats) {       // InstanceNorm statistics of the conv output, fused (act == 0 on this path)
+          sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+          sq[0] = fmaf(v.x, v.x, sq[0]); sq[1] = fmaf(v.y, v.y, sq[1]);
+          sq[2] = fmaf(v.z, v.z, sq[2]); sq[3] = fmaf(v.w, v.w, sq[3]);
+        }
         if (act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
         *reinterpret_cast<float4*>(y + (xbase + ((int64_t)z * H + yy) * W + xx) * Cout + cb0 + c4 * 4) = v;
+      }
+    }
+    if (stats) {
+      // lanes with equal (lane % cq) hold the same channel group: xor-tree over the other lane bits, then lanes
+      // 0..cq-1 write this (tile, wave)'s partial sums: stats[tile][wave][channel][2]
+      for (int o = cq; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sx[j] += __shfl_xor(sx[j], o, 64); sq[j] += __shfl_xor(sq[j], o, 64); }
+      }
+      if (lane < cq) {
+        float* sp = stats + (((int64_t)ptile * WM + wm) * Cout + lane * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sp[j * 2] = sx[j]; sp[j * 2 + 1] = sq[j]; }
       }
     }
     ptile = -1;
@@ -828,7 +847,7 @@ inline size_t fwd_ws_elems(int Cin, int Cout) {
 }
 
 int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
-                int Cin, int Cout, int act, int pack_mode, hipStream_t s) {
+                int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr) {
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 9 * (p.P + 2) * CinP * CoutP;
@@ -846,7 +865,7 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
     if (gx > ntiles) gx = ntiles;                                                                                 \
     hipLaunchKernelGGL((conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__>), dim3(gx, gy), dim3(nthr), 0, s, x,   \
                        (const float*)wpk, bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z, \
-                       ntiles);                                                                                   \
+                       ntiles, stats);                                                                                   \
   } while (0)
   const bool v4 = (Cin & 3) == 0;
   const bool multi = CinP > p.ck;
@@ -914,6 +933,28 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
     return modet_launch_status();
   }
   return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
+}
+
+// InstanceNorm statistics can be fused into the conv when it takes the staged epilogue of the 16-wide configs:
+// 8-wave workgroups, Cout in {4, 8, 16}
+static bool conv_stats_ok(int Cin, int Cout) { return Cin != 1 && (Cout == 4 || Cout == 8 || Cout == 16); }
+
+size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  if (!conv_stats_ok(Cin, Cout)) return 0;
+  const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
+  const int64_t ntiles = (int64_t)cdiv(W, TX) * cdiv(H, p.ty) * cdiv(D, p.tz) * B;
+  return (size_t)ntiles * 8 * Cout * 2 * sizeof(float);
+}
+
+int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                           float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                           modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws); MODET_CHECK_PTR(stats);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
+  if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
+  return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats);
 }
 
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,

@@ -111,7 +111,7 @@ class ConvInsBlock(nn.Module):
         self.main = _Conv3dParams(in_channels, out_channels)
 
     def forward(self, x):
-        return ops.instnorm_lrelu(ops.conv3d(x, self.main.weight, self.main.bias, False))
+        return ops.conv3d_instnorm_lrelu(x, self.main.weight, self.main.bias)
 
 
 class _AvgPool(nn.Module):
@@ -141,6 +141,21 @@ class Encoder(nn.Module):
             cur = blk[2](blk[1](pooled))              # blk[0] is the AvgPool3d(2) the tee already applied
         outs.append(cur)
         return tuple(outs)
+
+    def forward_pair(self, x, B):
+        """x = [moving; fixed] as one batch of 2B (InstanceNorm is per sample, so this is exact); returns the per-level
+        features of each half: ([M1..M5], [F1..F5])"""
+        Ms, Fs = [], []
+        cur = self.conv0(x)
+        for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
+            pooled, m, f = ops.pool_tee_split(cur, B)
+            Ms.append(m)
+            Fs.append(f)
+            cur = blk[2](blk[1](pooled))
+        m, f = _SplitBatch.apply(cur, B)
+        Ms.append(m)
+        Fs.append(f)
+        return Ms, Fs
 
 
 class _LinearParams(nn.Module):
@@ -265,10 +280,7 @@ class ModeT(nn.Module):
         mov_cl = ops.to_channels_last(moving.contiguous())
         fix_cl = ops.to_channels_last(fixed.contiguous())
         # shared encoder on both images as one batch (InstanceNorm is per sample, so this is exact)
-        feats = self.encoder(torch.cat([mov_cl, fix_cl], 0))
-        pairs = [_SplitBatch.apply(f, B) for f in feats]
-        M = [p[0] for p in pairs]
-        Fx = [p[1] for p in pairs]
+        M, Fx = self.encoder.forward_pair(torch.cat([mov_cl, fix_cl], 0), B)
         ST = self.transformer
 
         q5, k5 = self.projblock5(Fx[4]), self.projblock5(M[4])

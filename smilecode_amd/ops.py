@@ -174,6 +174,48 @@ class _Conv3d(Function):
         return dx, dw, db, None
 
 
+class _Conv3dStats(Function):
+    """conv3d whose epilogue also produces InstanceNorm partial statistics (second output, not differentiable)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _chk(x, w, b)
+        B, D, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        L = _L()
+        y = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=x.device)
+        nb = L.modet_conv3d_ws_bytes(Cin, Cout)
+        ws = _ws(nb, x)
+        sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)
+        stats = torch.empty(sb // 4, dtype=torch.float32, device=x.device)
+        n = float(B) * D * H * W
+        with _Guard(x, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+            _lib.check(L.modet_conv3d_fwd_stats(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
+                                                Cout, _stream()), "modet_conv3d_fwd_stats")
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = conv3d_backward_data(dy, w, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias)
+        return dx, dw, db
+
+
+def conv3d_instnorm_lrelu(x, w, b, eps=1e-5):
+    """ConvInsBlock = conv + InstanceNorm3d + LeakyReLU(0.1) (reference models.py:135-151); the norm statistics are
+    fused into the conv epilogue when the configuration supports it"""
+    B, D, H, W, Cin = x.shape
+    if _L().modet_conv3d_stats_bytes(B, D, H, W, Cin, w.shape[0]) > 0:
+        y, stats = _Conv3dStats.apply(x, w, b)
+        return _InstNormLReLU.apply(y, eps, stats)
+    return _InstNormLReLU.apply(_Conv3d.apply(x, w, b, False), eps, None)
+
+
 def conv3d(x, w, b=None, act=False):
     """3x3x3 conv, zero pad 1 (+ fused LeakyReLU(0.1) if act).  reference: nn.Conv3d, models.py:127,:144,:254"""
     return _Conv3d.apply(x, w, b, act)
@@ -181,7 +223,7 @@ def conv3d(x, w, b=None, act=False):
 
 class _InstNormLReLU(Function):
     @staticmethod
-    def forward(ctx, x, eps):
+    def forward(ctx, x, eps, stats=None):
         _chk(x)
         B, C = x.shape[0], x.shape[-1]
         V = x.numel() // (B * C)
@@ -189,11 +231,16 @@ class _InstNormLReLU(Function):
         mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         L = _L()
-        nb = L.modet_instnorm_ws_bytes(B, V, C)
-        ws = _ws(nb, x)
-        with _Guard(x, "instnorm_lrelu_fwd", 8.0 * x.numel(), 8.0 * x.numel()):
-            _lib.check(L.modet_instnorm_lrelu_fwd(_p(x), _p(y), _p(mean), _p(rstd), _p(ws), nb, B, V, C, eps,
-                                                  _stream()), "modet_instnorm_lrelu_fwd")
+        if stats is not None:
+            with _Guard(x, "instnorm_lrelu_fwd", 8.0 * x.numel(), 8.0 * x.numel()):
+                _lib.check(L.modet_instnorm_lrelu_fwd_stats(_p(x), _p(y), _p(mean), _p(rstd), _p(stats), stats.numel() * 4,
+                                                            B, V, C, eps, _stream()), "modet_instnorm_lrelu_fwd_stats")
+        else:
+            nb = L.modet_instnorm_ws_bytes(B, V, C)
+            ws = _ws(nb, x)
+            with _Guard(x, "instnorm_lrelu_fwd", 8.0 * x.numel(), 8.0 * x.numel()):
+                _lib.check(L.modet_instnorm_lrelu_fwd(_p(x), _p(y), _p(mean), _p(rstd), _p(ws), nb, B, V, C, eps,
+                                                      _stream()), "modet_instnorm_lrelu_fwd")
         ctx.save_for_backward(x, mean, rstd)
         return y
 
@@ -210,12 +257,12 @@ class _InstNormLReLU(Function):
         with _Guard(x, "instnorm_lrelu_bwd", 14.0 * x.numel(), 12.0 * x.numel()):
             _lib.check(L.modet_instnorm_lrelu_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C,
                                                   _stream()), "modet_instnorm_lrelu_bwd")
-        return dx, None
+        return dx, None, None
 
 
 def instnorm_lrelu(x, eps=1e-5):
     """InstanceNorm3d(affine=False) + LeakyReLU(0.1), channels-last.  reference: models.py:144-150"""
-    return _InstNormLReLU.apply(x, eps)
+    return _InstNormLReLU.apply(x, eps, None)
 
 
 class _AvgPool2(Function):
@@ -275,6 +322,49 @@ class _PoolTee(Function):
 def pool_tee(x):
     """(avgpool2(x), x) with a fused backward; see _PoolTee"""
     return _PoolTee.apply(x)
+
+
+class _PoolTeeSplit(Function):
+    """x (2B,...) -> (avgpool2(x), x[:B], x[B:]): _PoolTee for the [moving; fixed] batch whose two halves go to
+    different consumers (warp / projection).  The backward runs the fused unpool+add once per half, each with its own
+    addend, so the two half gradients are never concatenated."""
+
+    @staticmethod
+    def forward(ctx, x, Bh):
+        _chk(x)
+        B, D, H, W, C = x.shape
+        y = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+        with _Guard(x, "avgpool2_fwd", x.numel(), 4.5 * x.numel()):
+            _lib.check(_L().modet_avgpool2_fwd(_p(x), _p(y), B, D, H, W, C, _stream()), "modet_avgpool2_fwd")
+        ctx.shape = (B, D, H, W, C)
+        ctx.Bh = Bh
+        return y, x[:Bh], x[Bh:]
+
+    @staticmethod
+    def backward(ctx, gy, ga, gb):
+        B, D, H, W, C = ctx.shape
+        Bh = ctx.Bh
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=(gy if gy is not None else ga if ga is not None else gb).device)
+        if gy is None:
+            for sl, g in ((slice(0, Bh), ga), (slice(Bh, B), gb)):
+                if g is None:
+                    dx[sl].zero_()
+                else:
+                    dx[sl].copy_(g)
+            return dx, None
+        gy = gy.contiguous()
+        L = _L()
+        with _Guard(gy, "avgpool2_bwd", dx.numel(), 8.5 * dx.numel()):
+            for lo, hi, g in ((0, Bh, ga), (Bh, B, gb)):
+                add = None if g is None else g.contiguous()
+                _lib.check(L.modet_avgpool2_bwd(_p(gy[lo:hi]), _p(add), _p(dx[lo:hi]), hi - lo, D, H, W, C, _stream()),
+                           "modet_avgpool2_bwd")
+        return dx, None
+
+
+def pool_tee_split(x, Bh):
+    """(avgpool2(x), x[:Bh], x[Bh:]) with a fused backward; see _PoolTeeSplit"""
+    return _PoolTeeSplit.apply(x, Bh)
 
 
 class _ProjLN(Function):
