@@ -11,6 +11,9 @@
 //   Cin<=8 packs two taps into the 16 M rows.  Workgroups walk tiles persistently, partial d_w goes to a
 //   workspace and is summed in fixed order in fp64 (deterministic, no atomics).
 #include "common.h"
+#ifdef MODET_TUNING
+#include <cstdlib>
+#endif
 
 namespace {
 
@@ -366,20 +369,22 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
   const int ci_tile = blockIdx.y % n_ci_tiles, co_tile = blockIdx.y / n_ci_tiles;
   const int ci0 = ci_tile * CIT, co0 = co_tile * 16;
 
+  // No per-MFMA select: groups past NG (CIT = 8 only) multiply real tile data into accumulators nobody reads, and
+  // the bias slot (tap 27: A = 1) lives in exactly one (wave, g) = (BIAS_W, BIAS_G), so only that g carries a
+  // v_cndmask (a select in front of every MFMA cost 11-14 % of the kernel: VALU issue + the VALU->MFMA hazard nops).
+  constexpr int BIAS_GRP = 27 / TP, BIAS_W = BIAS_GRP / GPW, BIAS_G = BIAS_GRP % GPW;
   f32x4 acc[GPW];
   int aoff[GPW];
-  bool aval[GPW], abias[GPW];
 #pragma unroll
   for (int g = 0; g < GPW; ++g) {
     acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int grp = wave * GPW + g;
     const int tap = grp * TP + li / CIT;
-    aval[g] = (grp < NG) && (tap < 27);
-    abias[g] = (tap == 27) && (grp < NSLOT) && (li % CIT == 0) && (ci_tile == 0);   // spare slot: d_bias = sum dy * 1
     const int tt = tap < 27 ? tap : 0;
     const int dz = tt / 9, dyy = (tt / 3) % 3, dx = tt % 3;
     aoff[g] = ((dz * WG_HY + dyy) * HX + dx + lk) * CIT + (li % CIT);
   }
+  const bool bsel = (wave == BIAS_W) && (li / CIT == 27 % TP);        // rows of tap 27: d_bias = sum dy * 1
 
   // software pipeline over the tiles this workgroup owns: next tile's x / d_y loads are issued into registers
   // before the MFMA loop of the current tile
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
     for (int i = 0; i < NDV; ++i) *reinterpret_cast<float4*>(dys + (tid + i * NTHR) * 4) = dr[i];
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
-#pragma unroll 4
+#pragma unroll(CIT == 16 ? 16 : 4)
     for (int row = 0; row < WG_ROWS; ++row) {
       const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
 #pragma unroll
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
 #pragma unroll
         for (int g = 0; g < GPW; ++g) {
           float a = xs[rb + s * 4 * CIT + aoff[g]];
-          if (!aval[g]) a = abias[g] ? 1.f : 0.f;
+          if (g == BIAS_G) a = bsel ? 1.f : a;
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf, acc[g], 0, 0, 0);
         }
       }
@@ -542,18 +547,19 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_np_kernel(const float* __re
 
   f32x4 acc[GPW];
   int aoff[GPW];
-  bool aval[GPW], abias[GPW];
+  // as in conv3d_wgrad_kernel: no select in front of the MFMAs except for the one g that can hold the bias group
+  // (grp == NGT: A = 1); slots past it accumulate tile data nobody reads
+  constexpr int BIAS_W = NGT % 4, BIAS_G = NGT / 4;
 #pragma unroll
   for (int g = 0; g < GPW; ++g) {
     acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int grp = wave + 4 * g;                      // groups interleaved over the waves: (3,3,2,2) / (2,2,1,1)
     const int t = li / CIT, ci = li % CIT;
     const int combo = grp * CPG + (CPG == 2 ? (t >> 1) : 0), dxs = t & 1;
-    aval[g] = grp < NGT && combo < NCOMBO;
-    abias[g] = (grp == NGT) && (li == 0);
     const int cc = combo < NCOMBO ? combo : 0;
     aoff[g] = (((cc / 3) * WG_HY + (cc % 3)) * HX + 1 + dxs + lk) * CIT + ci;
   }
+  const bool bsel = wave == BIAS_W;
   const int bq = li >> 3, bco = li & 7;                // B column = (q, co)
 
   constexpr int QX = CIT / 4, NXV = (WG_HVOX * QX + NTHR - 1) / NTHR;
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_np_kernel(const float* __re
 #pragma unroll
         for (int g = 0; g < GPW; ++g) {
           float a = xs[rb + s * 4 * CIT + aoff[g]];
-          if (!aval[g]) a = abias[g] ? 1.f : 0.f;
+          if (g == BIAS_G) a = bsel ? 1.f : a;
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf, acc[g], 0, 0, 0);
         }
       }
@@ -815,12 +821,37 @@ struct FwdPlan {
   int cfg;       // 0:A 1:B 2:C 3:D 4:A with CK=4
   int ncb, ck, tz, ty;
   int P;         // output rows packed into the N tile (cfg 0/4 only)
+  int wm() const { return cfg == 0 || cfg == 4 ? 8 : (cfg == 8 ? 4 : 0); }   // waves along M of the staged-epilogue configs
 };
 inline FwdPlan plan_fwd(int64_t BV, int Cin, int Cout) {
   const int P = Cout <= 4 ? 4 : (Cout <= 8 ? 2 : 1);
+#ifdef MODET_TUNING
+  if (const char* e = getenv("MODET_CONV_CFG")) {
+    switch (atoi(e)) {
+      case 0: if (Cout <= 16) return {0, 16, 8, 4, 8, P}; break;
+      case 1: return {1, 32, 4, 4, 8, 1};
+      case 2: return {2, 64, 4, 2, 4, 1};
+      case 3: return {3, 64, 4, 1, 4, 1};
+      case 4: if (Cout <= 16) return {4, 16, 4, 4, 8, P}; break;
+      case 5: return {5, 32, 4, 2, 4, 1};
+      case 6: return {6, 32, 8, 1, 4, 1};
+      case 7: return {7, 64, 8, 1, 4, 1};
+      case 8: return {8, 16, 4, 1, 4, 1};
+      default: break;
+    }
+  }
+#endif
+  // small volumes (pyramid levels 3-5, measured with tools/sweep_conv.py): parallelism first -- 4-row tiles, narrow N
+  // blocks, 8-channel stages (half the barriers)
+  if (BV < 60000) {
+    if (Cout <= 16) return {8, 16, 4, 1, 4, 1};
+    if (Cout % 64 == 0 && BV >= 8000) return {7, 64, 8, 1, 4, 1};
+    return {6, 32, 8, 1, 4, 1};
+  }
   if (Cout <= 16 && Cin <= 4) return {4, 16, 4, 4, 8, P};
   if (Cout <= 16) return {0, 16, 8, 4, 8, P};
-  if (Cout <= 32 && BV >= 60000) return {1, 32, 4, 4, 8, 1};      // NCB = 32: no half-empty N tiles at level 3
+  if (Cout <= 32 && BV >= 600000) return {1, 32, 4, 4, 8, 1};     // NCB = 32: no half-empty N tiles
+  if (Cout <= 32) return {5, 32, 4, 2, 4, 1};                      // level 3: smaller tiles fill the chip
   if (Cout <= 64) return {2, 64, 4, 2, 4, 1};
   return {3, 64, 4, 1, 4, 1};
 }
@@ -884,6 +915,10 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
     case 1: CONV_CASE(4, 8, 4, 1, 2, 4); break;
     case 2: CONV_CASE(2, 4, 2, 2, 2, 4); break;
     case 4: CONV_CASE_P(4, 8, 8, 1, 1, 4); break;
+    case 5: CONV_CASE(2, 4, 4, 1, 2, 4); break;      // 8 rows x N=32, 2 rows per wave            (level 3)
+    case 6: CONV_CASE(1, 4, 2, 2, 1, 8); break;      // 4 rows x N=32, 8-channel stages           (levels 4-5)
+    case 7: CONV_CASE(1, 4, 2, 4, 1, 8); break;      // 4 rows x N=64, 8 waves, 8-channel stages  (level 4, Cout % 64 == 0)
+    case 8: CONV_CASE(1, 4, 4, 1, 1, 4); break;      // 4 rows x N=16, no row packing             (small volumes, Cout <= 16)
     default: CONV_CASE(1, 4, 1, 4, 1, 4); break;
   }
 #undef CONV_CASE
@@ -943,7 +978,7 @@ size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout)) return 0;
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int64_t ntiles = (int64_t)cdiv(W, TX) * cdiv(H, p.ty) * cdiv(D, p.tz) * B;
-  return (size_t)ntiles * 8 * Cout * 2 * sizeof(float);
+  return (size_t)ntiles * p.wm() * Cout * 2 * sizeof(float);
 }
 
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
