@@ -485,37 +485,59 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
   }
 }
 
-// d_w[co][ci][tap] (i < Cout*Cin*27) and d_bias[co] (the rest) = sum over workgroups bx of the partial tiles:
-// G lanes per output (G = power of two covering gx, at most 64), fixed assignment + fixed xor tree, fp64.
-__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                             float* __restrict__ db, int Cin, int Cout, int gx, int gy,
-                                                             int n_ci_tiles, int cit, int G) {
-  const int nw = Cout * Cin * 27, total = nw + (db ? Cout : 0);
-  const int per_blk = 256 / G;
-  const int i = blockIdx.x * per_blk + threadIdx.x / G, l = threadIdx.x % G;
-  const bool on = i < total;
-  int tap, ci, co;
-  if (i < nw) { tap = i % 27; ci = (i / 27) % Cin; co = i / (27 * Cin); }
-  else { tap = 27; ci = 0; co = on ? i - nw : 0; }
-  const int tp = 16 / cit, ng = (28 + tp - 1) / tp;
-  const int grp = tap / tp, mrow = (tap % tp) * cit + (ci % cit);
-  const int by = (co / 16) * n_ci_tiles + ci / cit;
-  double s = 0.0;
-  if (on) {
-    double s4[4] = {0.0, 0.0, 0.0, 0.0};
-    const float* pp = part + ((int64_t)by * ng + grp) * 256 + mrow * 16 + (co % 16);
-    const int64_t st = (int64_t)gy * ng * 256;
-    int bx = l;
-    for (; bx + 3 * G < gx; bx += 4 * G) {
+// d_w / d_bias = sum over the gx workgroups of their partial tiles.  One 256-thread workgroup per quarter tile (64
+// consecutive floats): wave p adds the partials bx = p, p+4, ... (each load is a coalesced 256 B row segment, eight
+// independent fp64 accumulators), the four waves are combined in fixed order through LDS, then every lane scatters
+// its element to d_w[co][ci][tap] / d_bias[co].  Fixed assignment + fixed order: deterministic.
+//   MODE 0: tiles of conv3d_wgrad_kernel     part[(bx*gy + by)*ng + grp][mrow][col]
+//   MODE 1: tiles of conv3d_wgrad_np_kernel  part[bx*ng + grp][mrow][(q, co)]        (gy == 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           float* __restrict__ db, int Cin, int Cout, int gx, int gy,
+                                                           int n_ci_tiles, int cit, int ng) {
+  __shared__ double sm[3][64];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int quarter = blockIdx.x & 3, tl = blockIdx.x >> 2;       // tl = by*ng + grp
+  const int by = tl / ng, grp = tl - by * ng;
+  const float* pp = part + (int64_t)tl * 256 + quarter * 64 + lane;
+  const int64_t st = (int64_t)gy * ng * 256;
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int bx = ph;
+  for (; bx + 28 < gx; bx += 32) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s4[u] += (double)pp[(int64_t)(bx + u * G) * st];
-    }
-    for (; bx < gx; bx += G) s4[0] += (double)pp[(int64_t)bx * st];
-    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    for (int u = 0; u < 8; ++u) a[u] += (double)pp[(int64_t)(bx + 4 * u) * st];
   }
-  for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (on && l == 0) {
-    if (i < nw) dw[i] = (float)s; else db[i - nw] = (float)s;
+  for (int u = 0; bx < gx; bx += 4, ++u) a[u & 7] += (double)pp[(int64_t)bx * st];
+  double v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  if (ph > 0) sm[ph - 1][lane] = v;
+  __syncthreads();
+  if (ph > 0) return;
+  v = ((v + sm[0][lane]) + sm[1][lane]) + sm[2][lane];
+  const int e = quarter * 64 + lane, mrow = e >> 4, col = e & 15;
+  if (MODE == 0) {
+    const int tp = 16 / cit;
+    const int tap = grp * tp + mrow / cit;
+    const int ci = (by % n_ci_tiles) * cit + mrow % cit, co = (by / n_ci_tiles) * 16 + col;
+    if (co >= Cout) return;
+    if (tap < 27) {
+      if (ci < Cin) dw[((int64_t)co * Cin + ci) * 27 + tap] = (float)v;
+    } else if (tap == 27 && db && mrow % cit == 0 && by % n_ci_tiles == 0) {
+      db[co] = (float)v;
+    }
+  } else {
+    const int cpg = 8 / cit, ngt = ng - 1;
+    const int q = col >> 3, co = col & 7;
+    if (co >= Cout) return;
+    if (grp == ngt) {
+      if (db && mrow == 0 && q == 0) db[co] = (float)v;
+      return;
+    }
+    const int tq = mrow / cit, ci = mrow % cit;              // tq = (combo within group)*2 + t
+    const int combo = grp * cpg + (cpg == 2 ? (tq >> 1) : 0), t = tq & 1;
+    // (t, q): dx = -1 <-> (0,1), 0 <-> (0,0), +1 <-> (1,0); (1,1) is not a tap
+    if (combo >= 9 || ci >= Cin || (t == 1 && q == 1)) return;
+    const int dxi = t == 1 ? 2 : (q == 1 ? 0 : 1);
+    dw[((int64_t)co * Cin + ci) * 27 + combo * 3 + dxi] = (float)v;
   }
 }
 
@@ -660,45 +682,6 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_np_kernel(const float* __re
     float* p = part + ((int64_t)blockIdx.x * NG + grp) * 256;
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[(lk * 4 + j) * 16 + li] = acc[g][j];
-  }
-}
-
-// finalize for the N-packed layout (Cin <= 8, Cout <= 8): G lanes per output, fixed tree, fp64
-__global__ __launch_bounds__(256) void wgrad_np_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                float* __restrict__ db, int Cin, int Cout, int gx, int cit,
-                                                                int G) {
-  const int nw = Cout * Cin * 27, total = nw + (db ? Cout : 0);
-  const int per_blk = 256 / G;
-  const int i = blockIdx.x * per_blk + threadIdx.x / G, l = threadIdx.x % G;
-  const bool on = i < total;
-  const int cpg = 8 / cit, ngt = (9 + cpg - 1) / cpg, ng = ngt + 1;
-  int grp, mrow, col;
-  if (i < nw) {
-    const int tap = i % 27, ci = (i / 27) % Cin, co = i / (27 * Cin);
-    const int combo = tap / 3, dxi = tap % 3;               // dxi 0,1,2 <-> dx -1,0,+1
-    const int t = dxi == 2 ? 1 : 0, q = dxi == 0 ? 1 : 0;   // (t,q): dx=-1 -> (0,1), 0 -> (0,0), +1 -> (1,0)
-    grp = combo / cpg;
-    mrow = ((cpg == 2 ? (combo % 2) * 2 : 0) + t) * cit + ci;
-    col = q * 8 + co;
-  } else {
-    grp = ngt; mrow = 0; col = on ? i - nw : 0;
-  }
-  double s = 0.0;
-  if (on) {
-    double s4[4] = {0.0, 0.0, 0.0, 0.0};
-    const float* pp = part + (int64_t)grp * 256 + mrow * 16 + col;
-    const int64_t st = (int64_t)ng * 256;
-    int bx = l;
-    for (; bx + 3 * G < gx; bx += 4 * G) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) s4[u] += (double)pp[(int64_t)(bx + u * G) * st];
-    }
-    for (; bx < gx; bx += G) s4[0] += (double)pp[(int64_t)bx * st];
-    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-  }
-  for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (on && l == 0) {
-    if (i < nw) dw[i] = (float)s; else db[i - nw] = (float)s;
   }
 }
 
@@ -928,21 +911,32 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
   return modet_launch_status();
 }
 
-struct WgPlan { int cit, n_ci, n_co, gx, gy, ng, ntiles, tiles_x, tiles_y, tiles_z, tz; };
+struct WgPlan { int cit, n_ci, n_co, gx, gy, ng, ntiles, tiles_x, tiles_y, tiles_z, tz; bool np; };
+// persistent grid = the resident workgroups (all tiles in ONE round, and as few partial d_w copies as possible)
+inline int wgrad_resident(int cit, int tz, bool np) {
+  const void* fn;
+  if (np) fn = tz == 4 ? (const void*)conv3d_wgrad_np_kernel<8, 4> : (const void*)conv3d_wgrad_np_kernel<8, 2>;
+  else if (cit == 4) fn = tz == 4 ? (const void*)conv3d_wgrad_kernel<4, 4> : (const void*)conv3d_wgrad_kernel<4, 2>;
+  else if (cit == 8) fn = tz == 4 ? (const void*)conv3d_wgrad_kernel<8, 4> : (const void*)conv3d_wgrad_kernel<8, 2>;
+  else fn = (const void*)conv3d_wgrad_kernel<16, 2>;
+  int r = 256 * resident_blocks(fn, NTHR);
+  return r > 1024 ? 1024 : r;
+}
 inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   WgPlan p;
+  p.np = Cin > 4 && Cin <= 8 && Cout <= 8;   // N-packed kernel (Cin <= 4 already fills M with 4 taps: no gain there)
   p.cit = Cin <= 4 ? 4 : (Cin <= 8 ? 8 : 16);
-  p.n_ci = cdiv(Cin, p.cit);
-  p.n_co = cdiv(Cout, 16);
+  p.n_ci = p.np ? 1 : cdiv(Cin, p.cit);
+  p.n_co = p.np ? 1 : cdiv(Cout, 16);
   p.gy = p.n_ci * p.n_co;
   p.tz = (p.cit <= 8 && (int64_t)B * D * H * W >= 1000000) ? 4 : 2;     // big tiles for the full-resolution, few-channel layers
   p.tiles_x = cdiv(W, TX); p.tiles_y = cdiv(H, WG_TY); p.tiles_z = cdiv(D, p.tz);
   p.ntiles = B * p.tiles_x * p.tiles_y * p.tiles_z;
-  int gx = 1024 / p.gy;
+  int gx = wgrad_resident(p.cit, p.tz, p.np) / p.gy;
   if (gx < 1) gx = 1;
   if (gx > p.ntiles) gx = p.ntiles;
   p.gx = gx;
-  p.ng = (28 + 16 / p.cit - 1) / (16 / p.cit);
+  p.ng = p.np ? 10 : (28 + 16 / p.cit - 1) / (16 / p.cit);
   return p;
 }
 
@@ -1003,12 +997,10 @@ int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws
 
 size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
-  const int64_t N = (int64_t)B * D * H * W;
-  (void)N;
-  size_t fl = (size_t)p.gx * p.gy * p.ng * 256;
+  // sized for the largest persistent grid (1024 workgroups) so the value does not depend on the occupancy query
+  const int gx = p.gy >= 1024 ? 1 : 1024 / p.gy;
+  const size_t fl = (size_t)gx * p.gy * p.ng * 256;
   const size_t c1 = (size_t)C1_WG_BLOCKS * (27 * Cout + Cout);
-  const size_t np = (Cin <= 8 && Cout <= 8) ? (size_t)1024 * 10 * 256 : 0;
-  if (np > fl) fl = np;
   return (fl > c1 ? fl : c1) * sizeof(float);
 }
 
@@ -1027,26 +1019,19 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
     hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(27 * 4 + 4), dim3(64), 0, s, (const float*)ws, d_w, d_bias, nblk, 4);
     return modet_launch_status();
   }
-  if (Cin > 4 && Cin <= 8 && Cout <= 8) {          // (Cin <= 4 already fills M with 4 taps; N-packing measured no gain there)
-    const int cit = 8;
-    const int tzv = ((int64_t)B * D * H * W >= 1000000) ? 4 : 2;
-    const int tx = cdiv(W, TX), ty = cdiv(H, WG_TY), tz = cdiv(D, tzv);
-    const int ntiles = B * tx * ty * tz;
-    int gx = ntiles < 1024 ? ntiles : 1024;
-    float* part = (float*)ws;
-    if (tzv == 4)
-      hipLaunchKernelGGL((conv3d_wgrad_np_kernel<8, 4>), dim3(gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, tx, ty, tz, ntiles);
-    else
-      hipLaunchKernelGGL((conv3d_wgrad_np_kernel<8, 2>), dim3(gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout, tx, ty, tz, ntiles);
-    int G = 1;
-    while (G < gx && G < 64) G <<= 1;
-    const int total = Cout * Cin * 27 + (d_bias ? Cout : 0);
-    hipLaunchKernelGGL(wgrad_np_finalize_kernel, dim3(cdiv(total, 256 / G)), dim3(256), 0, s, (const float*)part, d_w, d_bias,
-                       Cin, Cout, gx, cit, G);
-    return modet_launch_status();
-  }
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
   float* part = (float*)ws;
+  if (p.np) {
+    if (p.tz == 4)
+      hipLaunchKernelGGL((conv3d_wgrad_np_kernel<8, 4>), dim3(p.gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout,
+                         p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles);
+    else
+      hipLaunchKernelGGL((conv3d_wgrad_np_kernel<8, 2>), dim3(p.gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout,
+                         p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(p.ng * 4), dim3(256), 0, s, (const float*)part, d_w, d_bias, Cin, Cout,
+                       p.gx, 1, 1, p.cit, p.ng);
+    return modet_launch_status();
+  }
   dim3 grid(p.gx, p.gy);
 #define WG_LAUNCH(CIT_, TZ_) hipLaunchKernelGGL((conv3d_wgrad_kernel<CIT_, TZ_>), grid, dim3(NTHR), 0, s, x, d_y, part, D, H, W, \
                                                Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles, p.n_ci)
@@ -1054,11 +1039,8 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
   else if (p.cit == 8) { if (p.tz == 4) WG_LAUNCH(8, 4); else WG_LAUNCH(8, 2); }
   else WG_LAUNCH(16, 2);
 #undef WG_LAUNCH
-  int G = 1;
-  while (G < p.gx && G < 64) G <<= 1;
-  const int total = Cout * Cin * 27 + (d_bias ? Cout : 0);
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(cdiv(total, 256 / G)), dim3(256), 0, s, (const float*)part, d_w, d_bias,
-                     Cin, Cout, p.gx, p.gy, p.n_ci, p.cit, G);
+  hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(p.gy * p.ng * 4), dim3(256), 0, s, (const float*)part, d_w, d_bias, Cin,
+                     Cout, p.gx, p.gy, p.n_ci, p.cit, p.ng);
   return modet_launch_status();
 }
 
