@@ -1,7 +1,10 @@
 // ProjectionLayer = Linear(Cin -> dim) + LayerNorm(dim) on channels-last voxels, fused (one pass over HBM).
 // reference: ModeT/models.py:230-241 (permute -> nn.Linear -> nn.LayerNorm(eps=1e-5, affine)).
-// (Cin, dim) per level 1..5: (8,6) (16,6) (32,12) (64,24) (128,48).  HBM-bound: one thread per voxel, the
-// weight matrix is broadcast from LDS, all `dim` outputs and the LayerNorm statistics stay in registers.
+// (Cin, dim) per level 1..5: (8,6) (16,6) (32,12) (64,24) (128,48).
+//
+// The model's five shapes run on the grouped kernels (proj_ln_*_g_kernel, further down): G lanes per voxel
+// (1 at levels 1-2, 4/8/16 at levels 3-5), weights broadcast from LDS, d_W as an MFMA contraction over voxels.
+// Any other (Cin % 4 == 0, dim in {6,12,24,48}) takes the generic thread-per-voxel kernels at the top of the file.
 //
 // Backward recomputes z = Wx+b and the LN statistics (cheaper than saving them), writes d_x, and reduces the
 // five parameter gradients in two deterministic stages (per-workgroup partials -> fixed-order fp64 sum).
@@ -230,13 +233,300 @@ __global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ pa
   else if (i < n0 + n1 + n2 + n3) d3[i - n0 - n1 - n2] = (float)s;
 }
 
+// ------------------------------------------------------------------------------------------------ grouped kernels
+// The five (Cin, dim) pairs of the model run here.  G lanes share one voxel (G = 1 at levels 1-2 where N is huge,
+// 4 / 8 / 16 at levels 3-5 where a thread per voxel would leave the chip empty: level 5 has 1 200 voxels):
+//   lane g computes the outputs o = j*G + g (LayerNorm statistics by xor-shuffles inside the group), publishes
+//   d_z in LDS, then computes d_x for the channels c = i*G + g.
+//   d_W = d_z^T x is an MFMA contraction over the voxels of the tile (A = d_z from LDS, B = the staged x tile), so no
+//   lane carries a dim x Cin accumulator matrix; a workgroup accumulates it over all its tiles and writes ONE partial
+//   row [d_gamma | d_beta | d_bias | d_W], summed over workgroups by colsum_kernel (fixed order, fp64).
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int DIM, int CIN, int G>
+struct ProjCfg {
+  static constexpr int OS = DIM / G, CS = CIN / G;       // outputs / channels per lane
+  static constexpr int VPB = BLK / G;                    // voxels per workgroup tile
+  static constexpr int DIMS = G == 1 ? DIM : DIM + 1;    // W row stride in LDS (odd: lanes over c hit distinct banks)
+  static constexpr int XS = CIN + 4;                     // x row stride in LDS
+  static constexpr int OT = (DIM + 15) / 16, DZS = OT * 16 + 4;
+  static constexpr int CT = (CIN + 15) / 16;
+  static constexpr int PAIRS = OT * CT;                  // 16x16 tiles of d_W
+  static constexpr int NSPLIT = PAIRS >= 4 ? 1 : 4 / PAIRS;   // waves splitting the voxels of one tile pair
+  static constexpr int NACC = (PAIRS + 3) / 4;
+  static constexpr int NPART = 3 * DIM + DIM * CIN;
+  static_assert(DIM % G == 0 && CIN % G == 0 && CIN % 4 == 0 && VPB % (4 * NSPLIT) == 0, "shape");
+};
+
+template <int DIM, int CIN, int G>
+__device__ __forceinline__ void stage_group(float* Ws, float* ps, float* xs, const float* __restrict__ Wt,
+                                            const float* __restrict__ p0, const float* __restrict__ p1,
+                                            const float* __restrict__ p2) {
+  using C = ProjCfg<DIM, CIN, G>;
+  for (int i = threadIdx.x; i < CIN * DIM; i += BLK) {
+    const int o = i / CIN, c = i - o * CIN;              // Wt is (dim, Cin) row-major
+    Ws[c * C::DIMS + o] = Wt[i];
+  }
+  for (int i = threadIdx.x; i < DIM; i += BLK) {
+    ps[i] = p0[i];
+    ps[DIM + i] = p1[i];
+    if (p2) ps[2 * DIM + i] = p2[i];
+  }
+  (void)xs;
+}
+
+// x tile -> LDS (coalesced float4), rows past N zero filled
+template <int DIM, int CIN, int G>
+__device__ __forceinline__ void load_x_tile(float* xs, const float* __restrict__ x, int64_t n0, int64_t N) {
+  using C = ProjCfg<DIM, CIN, G>;
+  constexpr int Q = CIN / 4;
+  for (int i = threadIdx.x; i < C::VPB * Q; i += BLK) {
+    const int v = i / Q, c4 = i - v * Q;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n0 + v < N) val = *reinterpret_cast<const float4*>(x + (n0 + v) * CIN + c4 * 4);
+    *reinterpret_cast<float4*>(xs + v * C::XS + c4 * 4) = val;
+  }
+}
+
+// z = Wx + b for this lane's outputs, LayerNorm statistics over the group
+template <int DIM, int CIN, int G>
+__device__ __forceinline__ void linear_ln_group(const float* xrow, const float* Ws, const float* ps, int g, float eps,
+                                                float (&zh)[DIM / G], float& rstd) {
+  using C = ProjCfg<DIM, CIN, G>;
+  float z[C::OS];
+#pragma unroll
+  for (int j = 0; j < C::OS; ++j) z[j] = ps[j * G + g];
+#pragma unroll 2
+  for (int c = 0; c < CIN; c += 4) {
+    const float4 xv = *reinterpret_cast<const float4*>(xrow + c);
+    const float xq[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < C::OS; ++j) z[j] = fmaf(xq[q], Ws[(c + q) * C::DIMS + j * G + g], z[j]);
+  }
+  float mu = 0.f;
+#pragma unroll
+  for (int j = 0; j < C::OS; ++j) mu += z[j];
+  mu = group_sum<G>(mu) * (1.f / DIM);
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < C::OS; ++j) { const float d = z[j] - mu; var = fmaf(d, d, var); }
+  var = group_sum<G>(var);
+  rstd = rsqrtf(var * (1.f / DIM) + eps);
+#pragma unroll
+  for (int j = 0; j < C::OS; ++j) zh[j] = (z[j] - mu) * rstd;
+}
+
+template <int DIM, int CIN, int G>
+__global__ __launch_bounds__(BLK) void proj_ln_fwd_g_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            int64_t N, float eps) {
+  using C = ProjCfg<DIM, CIN, G>;
+  __shared__ __attribute__((aligned(16))) float Ws[CIN * C::DIMS];
+  __shared__ float ps[3 * DIM];
+  __shared__ __attribute__((aligned(16))) float xs[C::VPB * C::XS];
+  stage_group<DIM, CIN, G>(Ws, ps, xs, Wt, bias, gamma, beta);
+  const int v = threadIdx.x / G, g = threadIdx.x % G;
+  const int64_t ntiles = cdiv64(N, (int64_t)C::VPB);
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t n0 = t * C::VPB, n = n0 + v;
+    __syncthreads();
+    load_x_tile<DIM, CIN, G>(xs, x, n0, N);
+    __syncthreads();
+    float zh[C::OS], rstd;
+    linear_ln_group<DIM, CIN, G>(xs + v * C::XS, Ws, ps, g, eps, zh, rstd);
+    if (n < N) {
+#pragma unroll
+      for (int j = 0; j < C::OS; ++j) {
+        const int o = j * G + g;
+        y[n * DIM + o] = fmaf(zh[j], ps[DIM + o], ps[2 * DIM + o]);
+      }
+    }
+  }
+}
+
+template <int DIM, int CIN, int G>
+__global__ __launch_bounds__(BLK) void proj_ln_bwd_g_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, float* __restrict__ dx,
+                                                            float* __restrict__ part, int64_t N, float eps) {
+  using C = ProjCfg<DIM, CIN, G>;
+  __shared__ __attribute__((aligned(16))) float Ws[CIN * C::DIMS];
+  __shared__ float ps[2 * DIM];
+  __shared__ __attribute__((aligned(16))) float xs[C::VPB * C::XS + 16];
+  __shared__ __attribute__((aligned(16))) float dzs[C::VPB * C::DZS];
+  __shared__ float red[4 * (3 * DIM > 256 * C::NACC ? 3 * DIM : 256 * C::NACC)];
+  stage_group<DIM, CIN, G>(Ws, ps, xs, Wt, bias, gamma, nullptr);
+  for (int i = threadIdx.x; i < C::VPB * C::DZS; i += BLK) dzs[i] = 0.f;      // padding rows of the MFMA A operand
+  for (int i = threadIdx.x; i < 16; i += BLK) xs[C::VPB * C::XS + i] = 0.f;
+  const int v = threadIdx.x / G, g = threadIdx.x % G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  float ag[C::OS], ab[C::OS], abi[C::OS];
+#pragma unroll
+  for (int j = 0; j < C::OS; ++j) { ag[j] = 0.f; ab[j] = 0.f; abi[j] = 0.f; }
+  pf32x4 acc[C::NACC];
+#pragma unroll
+  for (int a = 0; a < C::NACC; ++a) acc[a] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int64_t ntiles = cdiv64(N, (int64_t)C::VPB);
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t n0 = t * C::VPB, n = n0 + v;
+    __syncthreads();                                   // previous tile's MFMA reads of xs / dzs are done
+    load_x_tile<DIM, CIN, G>(xs, x, n0, N);
+    __syncthreads();
+    float zh[C::OS], rstd;
+    linear_ln_group<DIM, CIN, G>(xs + v * C::XS, Ws, ps, g, eps, zh, rstd);
+    float dzh[C::OS];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < C::OS; ++j) {
+      const int o = j * G + g;
+      const float gy = n < N ? dy[n * DIM + o] : 0.f;
+      ag[j] = fmaf(gy, zh[j], ag[j]);
+      ab[j] += gy;
+      dzh[j] = gy * ps[DIM + o];
+      m1 += dzh[j];
+      m2 = fmaf(dzh[j], zh[j], m2);
+    }
+    m1 = group_sum<G>(m1) * (1.f / DIM);
+    m2 = group_sum<G>(m2) * (1.f / DIM);
+#pragma unroll
+    for (int j = 0; j < C::OS; ++j) {
+      dzh[j] = rstd * (dzh[j] - m1 - zh[j] * m2);      // d loss / d z[o]
+      abi[j] += dzh[j];
+      dzs[v * C::DZS + j * G + g] = dzh[j];
+    }
+    __syncthreads();
+    // d_x for the channels c = i*G + g
+    if (n < N) {
+      if constexpr (G == 1) {
+#pragma unroll
+        for (int c = 0; c < CIN; c += 4) {
+          float o4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int o = 0; o < DIM; ++o) sacc = fmaf(dzh[o], Ws[(c + q) * C::DIMS + o], sacc);
+            o4[q] = sacc;
+          }
+          *reinterpret_cast<float4*>(dx + n * CIN + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        }
+      } else {
+        float da[C::CS];
+#pragma unroll
+        for (int i = 0; i < C::CS; ++i) da[i] = 0.f;
+#pragma unroll 4
+        for (int o = 0; o < DIM; ++o) {
+          const float d = dzs[v * C::DZS + o];
+#pragma unroll
+          for (int i = 0; i < C::CS; ++i) da[i] = fmaf(d, Ws[(i * G + g) * C::DIMS + o], da[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < C::CS; ++i) dx[n * CIN + i * G + g] = da[i];
+      }
+    }
+    // d_W += d_z^T x over the tile's voxels: D[o][c] += A[o][voxel] * B[voxel][c]
+    if constexpr (C::NSPLIT == 1) {
+#pragma unroll
+      for (int a = 0; a < C::NACC; ++a) {
+        const int pr = wave + 4 * a;
+        if (pr < C::PAIRS) {
+          const int ot = pr / C::CT, ct = pr % C::CT;
+#pragma unroll 4
+          for (int ks = 0; ks < C::VPB / 4; ++ks) {
+            const float av = dzs[(ks * 4 + lk) * C::DZS + ot * 16 + li];
+            const float bv = xs[(ks * 4 + lk) * C::XS + ct * 16 + li];
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      const int pr = wave % C::PAIRS, sub = wave / C::PAIRS;
+      const int ot = pr / C::CT, ct = pr % C::CT;
+#pragma unroll 4
+      for (int ks = sub; ks < C::VPB / 4; ks += C::NSPLIT) {
+        const float av = dzs[(ks * 4 + lk) * C::DZS + ot * 16 + li];
+        const float bv = xs[(ks * 4 + lk) * C::XS + ct * 16 + li];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[0], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- one partial row per workgroup: [d_gamma | d_beta | d_bias | d_W (dim, Cin)]
+  float* prow = part + (int64_t)blockIdx.x * C::NPART;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < C::OS; ++j) {
+    float r0 = ag[j], r1 = ab[j], r2 = abi[j];
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) { r0 += __shfl_xor(r0, o, 64); r1 += __shfl_xor(r1, o, 64); r2 += __shfl_xor(r2, o, 64); }
+    if (lane < G) {
+      const int o = j * G + lane;
+      red[wave * 3 * DIM + o] = r0; red[wave * 3 * DIM + DIM + o] = r1; red[wave * 3 * DIM + 2 * DIM + o] = r2;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * DIM; i += BLK)
+    prow[i] = ((red[i] + red[3 * DIM + i]) + red[2 * 3 * DIM + i]) + red[3 * 3 * DIM + i];
+  if constexpr (C::NSPLIT == 1) {
+#pragma unroll
+    for (int a = 0; a < C::NACC; ++a) {
+      const int pr = wave + 4 * a;
+      if (pr < C::PAIRS) {
+        const int ot = pr / C::CT, ct = pr % C::CT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int o = ot * 16 + lk * 4 + j, c = ct * 16 + li;
+          if (o < DIM && c < CIN) prow[3 * DIM + o * CIN + c] = acc[a][j];
+        }
+      }
+    }
+  } else {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave * 256 + (lk * 4 + j) * 16 + li] = acc[0][j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < C::PAIRS * 256; i += BLK) {
+      const int pr = i >> 8, e = i & 255;
+      float sacc = red[pr * 256 + e];
+#pragma unroll
+      for (int k = 1; k < C::NSPLIT; ++k) sacc += red[(pr + k * C::PAIRS) * 256 + e];
+      const int ot = pr / C::CT, ct = pr % C::CT;
+      const int o = ot * 16 + (e >> 4), c = ct * 16 + (e & 15);
+      if (o < DIM && c < CIN) prow[3 * DIM + o * CIN + c] = sacc;
+    }
+  }
+}
+
+inline int group_of(int Cin, int dim) {      // 0: not one of the model's five (Cin, dim) pairs -> generic kernels
+  if (dim == 6 && (Cin == 8 || Cin == 16)) return 1;
+  if (dim == 12 && Cin == 32) return 4;
+  if (dim == 24 && Cin == 64) return 8;
+  if (dim == 48 && Cin == 128) return 16;
+  return 0;
+}
+inline int group_grid(int64_t N, int G) {
+  int64_t tiles = cdiv64(N, (int64_t)(BLK / G));
+  return (int)(tiles < 1024 ? tiles : 1024);
+}
+
 inline int bwd_grid(int64_t N) {
   int64_t g = cdiv64(N, (int64_t)BLK);
   if (g > 512) g = 512;
   if (g < 1) g = 1;
   return (int)g;
 }
-inline int reg_cin(int Cin, int dim) { return (dim == 6 && (Cin == 8 || Cin == 16)) ? Cin : 0; }
+inline int reg_cin(int, int) { return 0; }     // generic path: d_z to the workspace, d_W by proj_dw_kernel
 
 }  // namespace
 
@@ -251,6 +541,14 @@ int modet_proj_ln_fwd(const float* x, const float* Wt, const float* bias, const 
   const size_t sh = ((size_t)Cin * dim + 3 * dim) * sizeof(float);
   const int grid = flat_grid(N, BLK);
   hipStream_t s = (hipStream_t)stream;
+  const int G = group_of(Cin, dim);
+  if (G > 1) {          // levels 3-5: several lanes per voxel
+    const int gg = group_grid(N, G);
+    if (G == 4) hipLaunchKernelGGL((proj_ln_fwd_g_kernel<12, 32, 4>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, beta, y, N, eps);
+    else if (G == 8) hipLaunchKernelGGL((proj_ln_fwd_g_kernel<24, 64, 8>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, beta, y, N, eps);
+    else hipLaunchKernelGGL((proj_ln_fwd_g_kernel<48, 128, 16>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, beta, y, N, eps);
+    return modet_launch_status();
+  }
   switch (dim) {
     case 6:  hipLaunchKernelGGL(proj_ln_fwd_kernel<6>,  dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
     case 12: hipLaunchKernelGGL(proj_ln_fwd_kernel<12>, dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
@@ -262,6 +560,7 @@ int modet_proj_ln_fwd(const float* x, const float* Wt, const float* bias, const 
 }
 
 size_t modet_proj_ln_bwd_ws_bytes(int64_t N, int Cin, int dim) {
+  if (const int G = group_of(Cin, dim)) return (size_t)group_grid(N, G) * (3 * dim + dim * Cin) * sizeof(float);
   const int rc = reg_cin(Cin, dim);
   size_t fl = (size_t)bwd_grid(N) * (BLK / 64) * (3 * dim + (rc ? dim * Cin : 0));
   if (!rc) fl += (size_t)N * dim + (size_t)cdiv64(N, DW_CHUNK) * Cin * dim;
@@ -278,6 +577,21 @@ int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const 
   if (Cin % 4 != 0 || Cin > 128) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_proj_ln_bwd_ws_bytes(N, Cin, dim)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  if (const int G = group_of(Cin, dim)) {
+    const int gg = group_grid(N, G);
+    float* gpart = (float*)ws;
+#define LAUNCH_G(D_, C_, G_) hipLaunchKernelGGL((proj_ln_bwd_g_kernel<D_, C_, G_>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, \
+                                                d_y, d_x, gpart, N, eps)
+    if (G == 1 && Cin == 8) LAUNCH_G(6, 8, 1);
+    else if (G == 1) LAUNCH_G(6, 16, 1);
+    else if (G == 4) LAUNCH_G(12, 32, 4);
+    else if (G == 8) LAUNCH_G(24, 64, 8);
+    else LAUNCH_G(48, 128, 16);
+#undef LAUNCH_G
+    hipLaunchKernelGGL(colsum_kernel, dim3(3 * dim + dim * Cin), dim3(64), 0, s, (const float*)gpart, gg, 3 * dim + dim * Cin,
+                       d_gamma, dim, d_beta, dim, d_bias, dim, d_Wt, dim * Cin);
+    return modet_launch_status();
+  }
   const int grid = bwd_grid(N);
   const int rc = reg_cin(Cin, dim);
   const int npart = 3 * dim + (rc ? dim * Cin : 0);
@@ -288,15 +602,13 @@ int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const 
   const size_t sh = ((size_t)Cin * dim + 2 * dim) * sizeof(float);
 #define LAUNCH_BWD(D_, R_) hipLaunchKernelGGL((proj_ln_bwd_kernel<D_, R_>), dim3(grid), dim3(BLK), sh, s, x, Wt, bias, \
                                               gamma, d_y, d_x, dz, part, N, Cin, eps)
-  if (dim == 6 && Cin == 8) LAUNCH_BWD(6, 8);
-  else if (dim == 6 && Cin == 16) LAUNCH_BWD(6, 16);
-  else if (dim == 6) LAUNCH_BWD(6, 0);
+  if (dim == 6) LAUNCH_BWD(6, 0);
   else if (dim == 12) LAUNCH_BWD(12, 0);
   else if (dim == 24) LAUNCH_BWD(24, 0);
   else if (dim == 48) LAUNCH_BWD(48, 0);
   else return MODET_ERR_UNSUPPORTED;
 #undef LAUNCH_BWD
-  const bool regw = (dim == 6 && (Cin == 8 || Cin == 16));
+  const bool regw = rc != 0;
   if (regw) {
     hipLaunchKernelGGL(colsum_kernel, dim3(3 * dim + dim * Cin), dim3(64), 0, s, (const float*)part, nwp, npart, d_gamma, dim,
                        d_beta, dim, d_bias, dim, d_Wt, dim * Cin);

@@ -160,7 +160,8 @@ def test_projection_golden(ops, tag):
         assert_close(np64(got), g[f"{tag}.{n}"], atol=2e-4, rtol=1e-4, what=f"proj {n}")
 
 
-@pytest.mark.parametrize("cin,dim,n", [(8, 6, 70001), (16, 6, 5003), (64, 24, 1531)])
+@pytest.mark.parametrize("cin,dim,n", [(8, 6, 70001), (16, 6, 5003), (32, 12, 9001), (64, 24, 1531), (128, 48, 1203),
+                                       (128, 48, 7), (24, 12, 777)])
 def test_projection_vs_oracle_large(ops, orc, cin, dim, n):
     gen = torch.Generator().manual_seed(11)
     x = torch.randn((1, cin, 1, 1, n), generator=gen).double().requires_grad_(True)
