@@ -101,9 +101,12 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
 size_t modet_instnorm_ws_bytes(int B, int64_t V, int C);
 int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes,
                              int B, int64_t V, int C, float eps, modet_stream_t stream);
-/* same, with the statistics taken from modet_conv3d_fwd_stats' partials instead of a pass over x */
-int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, const float* stats,
-                                   size_t stats_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream);
+/* same, with the statistics taken from modet_conv3d_fwd_stats' partials instead of a pass over x.  `stats` is the
+ * buffer modet_conv3d_fwd_stats filled (stats_bytes = modet_conv3d_stats_bytes(...)); its tail of
+ * modet_instnorm_stats_scratch_bytes(B, C) bytes is scratch for the two-stage reduction, so the buffer is consumed. */
+size_t modet_instnorm_stats_scratch_bytes(int B, int C);
+int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, float* stats, size_t stats_bytes,
+                                   int B, int64_t V, int C, float eps, modet_stream_t stream);
 int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
                              void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream);
 /* d_x = d_y * (y > 0 ? 1 : 0.1): backward of the LeakyReLU fused into modet_conv3d_fwd(act=1) */

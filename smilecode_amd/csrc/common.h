@@ -55,3 +55,34 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats 
   }
   return r;
 }
+
+// Column sums of a row-major [rows][ncol] float matrix over the rows [r0, r1), by one 256-thread workgroup, in fp64:
+// thread t reads element t of each group of 256/ncol consecutive rows (fully coalesced), four independent
+// accumulators, then a fixed-order sum over the row lanes.  out[ncol] is written by threads < ncol.  ncol <= 256.
+// Fixed assignment + fixed order: deterministic.  Used as stage 1 of the two-stage statistics reductions
+// (stage 2 adds the per-slice results in slice order).
+constexpr int COLSUM_SLICES = 64;
+__device__ __forceinline__ void block_colsum_256(const float* __restrict__ base, int64_t r0, int64_t r1, int ncol,
+                                                 double* __restrict__ out, double* sm /* [256] shared */) {
+  const int per = 256 / ncol;
+  const int col = threadIdx.x % ncol, rl = threadIdx.x / ncol;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (rl < per) {
+    int64_t r = r0 + rl;
+    for (; r + 3 * per < r1; r += 4 * per) {
+      a0 += (double)base[r * ncol + col];
+      a1 += (double)base[(r + per) * ncol + col];
+      a2 += (double)base[(r + 2 * per) * ncol + col];
+      a3 += (double)base[(r + 3 * per) * ncol + col];
+    }
+    for (; r < r1; r += per) a0 += (double)base[r * ncol + col];
+  }
+  sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < ncol) {
+    double t = 0.0;
+    for (int k = 0; k < per; ++k) t += sm[k * ncol + threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+}
+

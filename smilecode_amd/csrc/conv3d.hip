@@ -972,7 +972,8 @@ size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout)) return 0;
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int64_t ntiles = (int64_t)cdiv(W, TX) * cdiv(H, p.ty) * cdiv(D, p.tz) * B;
-  return (size_t)ntiles * p.wm() * Cout * 2 * sizeof(float);
+  // [tile][wave][Cout][2] partials + the scratch tail modet_instnorm_lrelu_fwd_stats reduces them in
+  return (size_t)ntiles * p.wm() * Cout * 2 * sizeof(float) + modet_instnorm_stats_scratch_bytes(B, Cout);
 }
 
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,

@@ -255,18 +255,35 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_c_kernel(const float* __restr
   for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dkp + c) = make_float2(acc[c] * scale, acc[c + 1] * scale);
 }
 
-// partial (B, heads, nblk, 27) -> out (heads,27): one workgroup per (h,t), fixed assignment + fixed tree in fp64
-__global__ __launch_bounds__(256) void drpb_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                            int B, int heads, int64_t nblk) {
-  __shared__ double sm[4];
-  const int h = blockIdx.x / 27, t = blockIdx.x % 27;
-  double s = 0.0;
-  for (int b = 0; b < B; ++b)
-    for (int64_t i = threadIdx.x; i < nblk; i += 256) s += (double)part[(((int64_t)b * heads + h) * nblk + i) * 27 + t];
-  s = wave_sum_d(s);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) out[h * 27 + t] = (float)(sm[0] + sm[1] + sm[2] + sm[3]);
+// partial (B, heads, nblk, 27) -> out (heads,27), two deterministic fp64 stages:
+//   1: grid (COLSUM_SLICES, heads, B): coalesced column sums of a slice of the nblk rows -> scratch[b][h][slice][27]
+//   2: one workgroup: (b, slice) added in order per (h, t)
+__global__ __launch_bounds__(256) void drpb_stage1_kernel(const float* __restrict__ part, double* __restrict__ scratch,
+                                                          int heads, int64_t nblk) {
+  __shared__ double sm[256];
+  const int sl = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int64_t per = cdiv64(nblk, COLSUM_SLICES);
+  const int64_t r0 = sl * per, r1 = r0 + per < nblk ? r0 + per : nblk;
+  const int64_t bh = (int64_t)b * heads + h;
+  block_colsum_256(part + bh * nblk * 27, r0 < r1 ? r0 : r1, r1, 27, scratch + (bh * COLSUM_SLICES + sl) * 27, sm);
+}
+__global__ __launch_bounds__(256) void drpb_stage2_kernel(const double* __restrict__ scratch, float* __restrict__ out,
+                                                          int B, int heads) {
+  for (int i = threadIdx.x; i < heads * 27; i += 256) {
+    const int h = i / 27, t = i - h * 27;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b)
+      for (int sl = 0; sl < COLSUM_SLICES; ++sl) s += scratch[(((int64_t)b * heads + h) * COLSUM_SLICES + sl) * 27 + t];
+    out[i] = (float)s;
+  }
+}
+inline size_t drpb_scratch_bytes(int B, int heads) { return (size_t)B * heads * COLSUM_SLICES * 27 * sizeof(double); }
+// `part` rows start at ws; the scratch sits at byte offset `scratch_off` (8-byte aligned) of the same workspace
+inline void drpb_reduce(const float* part, void* ws, size_t scratch_off, float* d_rpb, int B, int heads, int64_t nblk,
+                        hipStream_t s) {
+  double* scr = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + scratch_off);
+  hipLaunchKernelGGL(drpb_stage1_kernel, dim3(COLSUM_SLICES, heads, B), dim3(256), 0, s, part, scr, heads, nblk);
+  hipLaunchKernelGGL(drpb_stage2_kernel, dim3(1), dim3(256), 0, s, (const double*)scr, d_rpb, B, heads);
 }
 
 // ------------------------------------------------------------------------------------------ reference contract
@@ -421,7 +438,9 @@ int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, i
 
 size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads) {
   const TileGeom g = geom(D, H, W);
-  return ((size_t)B * heads * g.tiles_x * g.tiles_y * g.tiles_z * 27 + (size_t)B * heads * 27 * D * H * W) * sizeof(float);
+  size_t fl = (size_t)B * heads * g.tiles_x * g.tiles_y * g.tiles_z * 27 + (size_t)B * heads * 27 * D * H * W;
+  fl += fl & 1;                                        // keep the fp64 scratch that follows 8-byte aligned
+  return fl * sizeof(float) + drpb_scratch_bytes(B, heads);
 }
 
 int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* d_out, float* d_q, float* d_k,
@@ -440,7 +459,9 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
   dim3 grid((unsigned)nblk, heads, B);
   hipLaunchKernelGGL(na_bwd_p_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, d_out, d_q, dl, part, D, H, W, heads, scale, g);
   hipLaunchKernelGGL(na_bwd_c_kernel, grid, dim3(NTHREADS), 0, s, q, (const float*)dl, d_k, D, H, W, heads, scale, g);
-  hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads * 27), dim3(256), 0, s, (const float*)part, d_rpb, B, heads, nblk);
+  size_t fl = (size_t)B * heads * nblk * 27 + (size_t)B * heads * 27 * D * H * W;
+  fl += fl & 1;
+  drpb_reduce(part, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
   return modet_launch_status();
 }
 
@@ -458,7 +479,9 @@ int modet_qk_fwd(const float* q, const float* kpad, const float* rpb, float* att
 
 size_t modet_qk_bwd_ws_bytes(int B, int heads, int D, int H, int W) {
   const int64_t V = (int64_t)D * H * W;
-  return (size_t)B * heads * cdiv64(V, (int64_t)QK_BLOCK * QK_RPB_ITERS) * 27 * sizeof(float);
+  size_t fl = (size_t)B * heads * cdiv64(V, (int64_t)QK_BLOCK * QK_RPB_ITERS) * 27;
+  fl += fl & 1;
+  return fl * sizeof(float) + drpb_scratch_bytes(B, heads);
 }
 
 int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad, float* d_q, float* d_kpad, float* d_rpb,
@@ -474,7 +497,9 @@ int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad, float* 
     const int64_t nchunk = cdiv64(V, (int64_t)QK_BLOCK * QK_RPB_ITERS);
     hipLaunchKernelGGL(qk_drpb_partial_kernel, dim3((unsigned)nchunk, B * heads), dim3(QK_BLOCK), 0, s, d_attn,
                        (float*)ws, V);
-    hipLaunchKernelGGL(drpb_finalize_kernel, dim3(heads * 27), dim3(256), 0, s, (const float*)ws, d_rpb, B, heads, nchunk);
+    size_t fl = (size_t)B * heads * nchunk * 27;
+    fl += fl & 1;
+    drpb_reduce((const float*)ws, ws, fl * sizeof(float), d_rpb, B, heads, nchunk, s);
   }
   hipLaunchKernelGGL(qk_dq_kernel, dim3((unsigned)cdiv64(V, QK_BLOCK), B * heads), dim3(QK_BLOCK), 0, s, d_attn, kpad,
                      d_q, D, H, W, hd);

@@ -90,33 +90,27 @@ __global__ __launch_bounds__(64) void in_finalize_kernel(const float* __restrict
   }
 }
 
-// statistics from the conv epilogue's partials: stats[(b*tiles_per_b + tile)*8 + wave][C][2]; one workgroup per
-// (b,c), fixed assignment + fixed tree, fp64
-__global__ __launch_bounds__(BLK) void in_finalize_tiles_kernel(const float* __restrict__ stats, float* __restrict__ mean,
-                                                                float* __restrict__ rstd, int64_t V, int C,
-                                                                int64_t rows_per_b, float eps) {
-  __shared__ double sm[2][BLK / 64];
-  const int b = blockIdx.y, c = blockIdx.x;
-  const float* p = stats + ((int64_t)b * rows_per_b * C + c) * 2;
-  double s4[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0};
-  int64_t i = threadIdx.x;
-  for (; i + 3 * BLK < rows_per_b; i += 4 * BLK) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float2 v = *reinterpret_cast<const float2*>(p + (i + u * BLK) * C * 2);
-      s4[u] += (double)v.x; q4[u] += (double)v.y;
+// statistics from the conv epilogue's partials stats[(b*rows_per_b + r)][C][2], two stages:
+//   1: grid (COLSUM_SLICES, B): column sums of a slice of rows -> scratch[b][slice][2C] (fp64)
+//   2: grid B: slices added in order, mean / rstd per channel
+__global__ __launch_bounds__(256) void in_tiles_stage1_kernel(const float* __restrict__ stats, double* __restrict__ scratch,
+                                                              int C, int64_t rows_per_b) {
+  __shared__ double sm[256];
+  const int b = blockIdx.y, sl = blockIdx.x;
+  const int64_t per = cdiv64(rows_per_b, COLSUM_SLICES);
+  const int64_t r0 = sl * per, r1 = r0 + per < rows_per_b ? r0 + per : rows_per_b;
+  block_colsum_256(stats + (int64_t)b * rows_per_b * 2 * C, r0 < r1 ? r0 : r1, r1, 2 * C,
+                   scratch + ((int64_t)b * COLSUM_SLICES + sl) * 2 * C, sm);
+}
+__global__ __launch_bounds__(64) void in_tiles_stage2_kernel(const double* __restrict__ scratch, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int64_t V, int C, float eps) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 64) {
+    double s = 0.0, q = 0.0;
+    for (int sl = 0; sl < COLSUM_SLICES; ++sl) {
+      const double* p = scratch + ((int64_t)b * COLSUM_SLICES + sl) * 2 * C + 2 * c;
+      s += p[0]; q += p[1];
     }
-  }
-  for (; i < rows_per_b; i += BLK) {
-    const float2 v = *reinterpret_cast<const float2*>(p + i * C * 2);
-    s4[0] += (double)v.x; q4[0] += (double)v.y;
-  }
-  double s = wave_sum_d((s4[0] + s4[1]) + (s4[2] + s4[3])), q = wave_sum_d((q4[0] + q4[1]) + (q4[2] + q4[3]));
-  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = s; sm[1][threadIdx.x >> 6] = q; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    s = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
-    q = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
     const double m = s / (double)V;
     double var = q / (double)V - m * m;
     if (var < 0.0) var = 0.0;
@@ -272,15 +266,22 @@ int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd,
   return modet_launch_status();
 }
 
-int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, const float* stats,
-                                   size_t stats_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream) {
+size_t modet_instnorm_stats_scratch_bytes(int B, int C) { return (size_t)B * COLSUM_SLICES * 2 * C * sizeof(double); }
+
+int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, float* stats, size_t stats_bytes,
+                                   int B, int64_t V, int C, float eps, modet_stream_t stream) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(y); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(stats);
   MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
-  if (C % 4 != 0 || C > 512) return MODET_ERR_UNSUPPORTED;
-  const int64_t rows = (int64_t)(stats_bytes / sizeof(float)) / ((int64_t)B * C * 2);
-  MODET_CHECK_DIM(rows > 0 && (size_t)rows * B * C * 2 * sizeof(float) == stats_bytes);
+  if (C % 4 != 0 || 2 * C > 256) return MODET_ERR_UNSUPPORTED;
+  const size_t scratch = modet_instnorm_stats_scratch_bytes(B, C);
+  if (stats_bytes <= scratch) return MODET_ERR_WORKSPACE;
+  const size_t body = stats_bytes - scratch;
+  const int64_t rows = (int64_t)(body / sizeof(float)) / ((int64_t)B * C * 2);
+  MODET_CHECK_DIM(rows > 0 && (size_t)rows * B * C * 2 * sizeof(float) == body);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3(C, B), dim3(BLK), 0, s, stats, mean, rstd, V, C, rows, eps);
+  double* scr = reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + body);   // body is a multiple of 8 bytes
+  hipLaunchKernelGGL(in_tiles_stage1_kernel, dim3(COLSUM_SLICES, B), dim3(256), 0, s, (const float*)stats, scr, C, rows);
+  hipLaunchKernelGGL(in_tiles_stage2_kernel, dim3(B), dim3(64), 0, s, (const double*)scr, mean, rstd, V, C, eps);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total4);
   return modet_launch_status();

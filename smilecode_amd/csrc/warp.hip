@@ -349,13 +349,19 @@ __device__ __forceinline__ void lin_range(int i, float ratio, int n_in, int& lo,
   hi = min(n_out - 1, (int)ceilf((float)(i + 1) / ratio) + 1);
 }
 
+// gather form of the transposed interpolation: eight adjacent lanes share one (coarse voxel, channel group) and split
+// the fine x range it touches (at most 5 voxels), so neighbouring lanes read neighbouring fine voxels and the small
+// pyramid levels still fill the chip; fixed xor-tree over the eight lanes -> deterministic
 template <int CPT>
 __global__ __launch_bounds__(BLK) void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int d,
                                                             int h, int w, int C, int G, int64_t total, float scale) {
   const int H = 2 * h, W = 2 * w;
   const float rz = up_ratio(d), ry = up_ratio(h), rx = up_ratio(w);
   const int64_t Vo = (int64_t)8 * d * h * w, Vi = (int64_t)d * h * w;
-  for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+  const int kx = threadIdx.x & 7;
+  const int64_t stride = (int64_t)gridDim.x * (BLK / 8);
+  // the eight lanes of a group share idx, so they enter and leave the loop together (the shuffles stay inside a group)
+  for (int64_t idx = (int64_t)blockIdx.x * (BLK / 8) + (threadIdx.x >> 3); idx < total; idx += stride) {
     const int g = (int)(idx % G);
     const int64_t n = idx / G;
     const int64_t b = n / Vi, v = n - b * Vi;
@@ -370,15 +376,15 @@ __global__ __launch_bounds__(BLK) void upsample2_bwd_kernel(const float* __restr
     float acc[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
-    for (int zo = zlo; zo <= zhi; ++zo) {
-      const float wz = lin_wt(zo, zi, rz, d);
-      if (wz == 0.f) continue;
-      for (int yo = ylo; yo <= yhi; ++yo) {
-        const float wy = lin_wt(yo, yi, ry, h);
-        if (wy == 0.f) continue;
-        for (int xo = xlo; xo <= xhi; ++xo) {
-          const float wx = lin_wt(xo, xi, rx, w);
-          if (wx == 0.f) continue;
+    for (int xo = xlo + kx; xo <= xhi; xo += 8) {
+      const float wx = lin_wt(xo, xi, rx, w);
+      if (wx == 0.f) continue;
+      for (int zo = zlo; zo <= zhi; ++zo) {
+        const float wz = lin_wt(zo, zi, rz, d);
+        if (wz == 0.f) continue;
+        for (int yo = ylo; yo <= yhi; ++yo) {
+          const float wy = lin_wt(yo, yi, ry, h);
+          if (wy == 0.f) continue;
           float s[CPT];
           ldv<CPT>(gb + (((int64_t)zo * H + yo) * W + xo) * C, s);
           const float wgt = wz * wy * wx;
@@ -388,8 +394,12 @@ __global__ __launch_bounds__(BLK) void upsample2_bwd_kernel(const float* __restr
       }
     }
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) acc[c] *= scale;
-    stv<CPT>(dx + n * C + g * CPT, acc);
+    for (int c = 0; c < CPT; ++c) {
+      float r = acc[c];
+      r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64);
+      acc[c] = r * scale;
+    }
+    if (kx == 0) stv<CPT>(dx + n * C + g * CPT, acc);
   }
 }
 
@@ -566,7 +576,7 @@ int modet_upsample2_bwd(const float* d_y, float* d_x, int B, int d, int h, int w
   MODET_CHECK_DIM(B > 0 && d > 0 && h > 0 && w > 0 && C > 0);
   const int cpt = pick_cpt(C), G = C / cpt;
   const int64_t total = (int64_t)B * d * h * w * G;
-  DISPATCH_CPT(cpt, upsample2_bwd_kernel, flat_grid(total, BLK), (hipStream_t)stream, d_y, d_x, d, h, w, C, G, total,
+  DISPATCH_CPT(cpt, upsample2_bwd_kernel, flat_grid(total * 8, BLK), (hipStream_t)stream, d_y, d_x, d, h, w, C, G, total,
                scale);
   return modet_launch_status();
 }
