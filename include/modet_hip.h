@@ -64,12 +64,15 @@ int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad,
  *   logits = scale*q.k(n+off) + rpb, softmax over the 27 modes, out = sum_t p[t]*off(t).
  *   q,k (B,D,H,W,heads*hd) channels-last, unpadded, unscaled; rpb (heads,27);
  *   out (B,D,H,W,heads*3), channel = head*3+axis (models.py:332).  hd must be 6 (train.py:49).
- * Never materialises the (..,27) attention tensor.  Backward recomputes the softmax. */
-int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out,
+ * Never materialises the (..,27) attention tensor.
+ * lse (B,D,H,W,heads) or NULL: log-sum-exp of the 27 logits per voxel-head, written for the backward (NULL when no
+ * gradient is needed).  The backward takes q, k, rpb, the forward's out and lse, and d_out; it recomputes each softmax
+ * probability from lse in a single pass (no 27-wide scratch), d_rpb through a deterministic two-stage reduction. */
+int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, float* lse,
                  int B, int D, int H, int W, int heads, int hd, float scale, modet_stream_t stream);
 size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads);
-int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* d_out,
-                 float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes,
+int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* out, const float* lse,
+                 const float* d_out, float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes,
                  int B, int D, int H, int W, int heads, int hd, float scale, modet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -71,8 +71,8 @@ __device__ __forceinline__ void logits27(const float* __restrict__ kt, int lt, c
       }
 }
 
-__device__ __forceinline__ float softmax27(float (&lg)[27]) {   // lg -> exp(lg - max); returns 1/sum
-  float m = lg[0];
+__device__ __forceinline__ float softmax27(float (&lg)[27], float& m) {   // lg -> exp(lg - max); returns 1/sum
+  m = lg[0];
 #pragma unroll
   for (int t = 1; t < 27; ++t) m = fmaxf(m, lg[t]);
   float s = 0.f;
@@ -87,7 +87,8 @@ __device__ __forceinline__ float softmax27(float (&lg)[27]) {   // lg -> exp(lg 
 // ------------------------------------------------------------------------------------------ fused forward
 __global__ __launch_bounds__(NTHREADS) void na_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ rpb, float* __restrict__ out,
-                                                          int D, int H, int W, int heads, float scale, TileGeom g) {
+                                                          float* __restrict__ lse, int D, int H, int W, int heads,
+                                                          float scale, TileGeom g) {
   __shared__ __attribute__((aligned(16))) float kt[HVOX * HD];
   __shared__ float rp[27];
   const int h = blockIdx.y, b = blockIdx.z;
@@ -109,7 +110,9 @@ __global__ __launch_bounds__(NTHREADS) void na_fwd_kernel(const float* __restric
   for (int c = 0; c < HD; ++c) qs[c] *= scale;
   float p[27];
   logits27(kt, (tz * HY + ty) * HX + tx, qs, rp, p);
-  const float inv = softmax27(p);
+  float mx;
+  const float inv = softmax27(p, mx);
+  if (lse) lse[n * heads + h] = mx - __logf(inv);      // log-sum-exp of the 27 logits, for the single-pass backward
   float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
   for (int ki = 0; ki < 3; ++ki)
@@ -126,20 +129,50 @@ __global__ __launch_bounds__(NTHREADS) void na_fwd_kernel(const float* __restric
   o[0] = o0 * inv; o[1] = o1 * inv; o[2] = o2 * inv;
 }
 
-// ------------------------------------------------------------------------------------------ backward (two passes)
-// P: one thread per voxel n (forward tiling): softmax recompute, d_q[n], d_rpb partial, and the 27 dlogits written
-//    PLANAR to scratch dl[(b,h)][t][voxel] (27 coalesced streams);
-// C: one thread per voxel m: d_k[m] = sum_t dl[t][m - off(t)] * (scale*q)[m - off(t)], dl read back coalesced
-//    (lanes = consecutive x in plane t), q from an LDS tile with halo 1.
-// No atomics, deterministic; costs 2 x 108 B of HBM traffic per voxel-head but runs at streaming occupancy.
-// (A single-kernel variant that kept the dlogits in LDS -- producers on tile+halo scattering into per-consumer
-// slots -- needed 80 KB LDS per 256 threads, ran at 2 waves/SIMD and measured 1.5x slower at 160x192x160.)
-__global__ __launch_bounds__(NTHREADS) void na_bwd_p_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                            const float* __restrict__ rpb, const float* __restrict__ dout,
-                                                            float* __restrict__ dq, float* __restrict__ dl,
-                                                            float* __restrict__ drpb_part, int D, int H, int W,
-                                                            int heads, float scale, TileGeom g) {
+// Sum 27 per-lane values over the 64 lanes of a wave: butterfly reduce-scatter over a 32-slot array (slots 27..31
+// zero).  At step M the lanes with bit M set keep the upper half of the live slots and hand the lower half to their
+// partner (and vice versa), halving the live slots; after M = 32,16,8,4,2 one slot is left, summed over 32 lanes, and
+// the last exchange (M = 1) completes it.  Lane l returns the wave total of slot (l >> 1) (bits 5..1 select it).
+template <int N>     // one butterfly step: N live slots -> N/2, partner = lane ^ N
+__device__ __forceinline__ void rs_step(float (&v)[32], int lane) {
+  const bool up = (lane & N) != 0;
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {
+    const float keep = up ? v[i + N / 2] : v[i];
+    const float send = up ? v[i] : v[i + N / 2];
+    v[i] = keep + __shfl_xor(send, N, 64);
+  }
+}
+__device__ __forceinline__ float wave_reduce_scatter32(const float (&v27)[27], int lane) {
+  float v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = i < 27 ? v27[i] : 0.f;
+  // live slots 32 -> 16 -> 8 -> 4 -> 2 -> 1 with partners lane ^ 32, 16, 8, 4, 2 (slot count == xor mask here)
+  rs_step<32>(v, lane); rs_step<16>(v, lane); rs_step<8>(v, lane); rs_step<4>(v, lane); rs_step<2>(v, lane);
+  return v[0] + __shfl_xor(v[0], 1, 64);
+}
+
+// ------------------------------------------------------------------------------------------ backward (one pass)
+// With lse[n] = logsumexp_t logit[n][t] saved by the forward and u[n] = d_out[n].out[n] (out = E[offset]),
+//   dlogit[n][t] = p[n][t] * (d_out[n].off(t) - u[n]),   p[n][t] = exp(logit[n][t] - lse[n]).
+// A thread owns voxel n in two roles:
+//   query role: its 27 logits against the K tile -> d_q[n] = scale * sum_t dlogit[n][t] k[n+off(t)], d_rpb partial;
+//   key role  : for each t the query voxel m = n - off(t) has logit[m][t] = scale q[m].k[n] + rpb[t] (k[n] is its own
+//               key), so p[m][t] needs only q[m], lse[m]: d_k[n] = scale * sum_t dlogit[m][t] q[m].
+// q (pre-scaled), k, d_out, u and lse tiles with a 1-voxel halo live in LDS; nothing 27-wide ever goes to HBM (the
+// previous two-pass version wrote and re-read a 27-plane dlogit scratch: 216 B of its 324 B per voxel-head).
+// No atomics, deterministic.
+constexpr int AUX = 5;      // per halo voxel: d_out[3], u, lse
+
+__global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ rpb, const float* __restrict__ out,
+                                                          const float* __restrict__ lse, const float* __restrict__ dout,
+                                                          float* __restrict__ dq, float* __restrict__ dk,
+                                                          float* __restrict__ drpb_part, int D, int H, int W, int heads,
+                                                          float scale, TileGeom g) {
   __shared__ __attribute__((aligned(16))) float kt[HVOX * HD];
+  __shared__ __attribute__((aligned(16))) float qt[HVOX * HD];
+  __shared__ float ax[HVOX * AUX];
   __shared__ float red[27 * (NTHREADS / 64)];
   __shared__ float rp[27];
   const int h = blockIdx.y, b = blockIdx.z;
@@ -149,6 +182,23 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_p_kernel(const float* __restr
   tile_origin(blockIdx.x, g, z0, y0, x0);
   if (threadIdx.x < 27) rp[threadIdx.x] = rpb[h * 27 + threadIdx.x];
   stage_k_tile(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
+  stage_k_tile(qt, q, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
+  for (int v = threadIdx.x; v < HVOX; v += NTHREADS) {
+    const int hx = v % HX, t = v / HX;
+    const int hy = t % HY, hz = t / HY;
+    const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, u = 0.f, l = 0.f;
+    if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
+      const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+      const float* go = dout + n * (heads * 3) + h * 3;
+      const float* oo = out + n * (heads * 3) + h * 3;
+      g0 = go[0]; g1 = go[1]; g2 = go[2];
+      u = g0 * oo[0] + g1 * oo[1] + g2 * oo[2];
+      l = lse[n * heads + h];
+    }
+    float* a = ax + v * AUX;
+    a[0] = g0; a[1] = g1; a[2] = g2; a[3] = u; a[4] = l;
+  }
   __syncthreads();
   const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
   const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
@@ -157,31 +207,20 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_p_kernel(const float* __restr
 #pragma unroll
   for (int t = 0; t < 27; ++t) dlv[t] = 0.f;
   if (live) {
-    const int64_t v = ((int64_t)z * H + y) * W + x, n = (int64_t)b * V + v;
+    const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+    const int lt = (tz * HY + ty) * HX + tx;             // halo index of the (-1,-1,-1) neighbour
+    const int lc = lt + (HY + 1) * HX + 1;               // halo index of the voxel itself
+    // ---- query role
     float qs[HD];
-    load6(q + n * C + h * HD, qs);
+    load6(qt + lc * HD, qs);
 #pragma unroll
     for (int c = 0; c < HD; ++c) qs[c] *= scale;
-    const int lt = (tz * HY + ty) * HX + tx;
     logits27(kt, lt, qs, rp, dlv);
-    const float inv = softmax27(dlv);
-    const float* go = dout + n * (heads * 3) + h * 3;
-    const float g0 = go[0], g1 = go[1], g2 = go[2];
-    float sdot = 0.f;
-#pragma unroll
-    for (int ki = 0; ki < 3; ++ki)
-#pragma unroll
-      for (int kj = 0; kj < 3; ++kj)
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          const int t = ki * 9 + kj * 3 + kk;
-          dlv[t] *= inv;
-          sdot += dlv[t] * ((float)(ki - 1) * g0 + (float)(kj - 1) * g1 + (float)(kk - 1) * g2);
-        }
+    const float* ac = ax + lc * AUX;
+    const float g0 = ac[0], g1 = ac[1], g2 = ac[2], u = ac[3], l = ac[4];
     float dqa[HD];
 #pragma unroll
     for (int c = 0; c < HD; ++c) dqa[c] = 0.f;
-    float* dlp = dl + ((int64_t)(b * heads + h) * 27) * V + v;
 #pragma unroll
     for (int ki = 0; ki < 3; ++ki)
 #pragma unroll
@@ -190,9 +229,8 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_p_kernel(const float* __restr
         for (int kk = 0; kk < 3; ++kk) {
           const int t = ki * 9 + kj * 3 + kk;
           const float gt = (float)(ki - 1) * g0 + (float)(kj - 1) * g1 + (float)(kk - 1) * g2;
-          const float d = dlv[t] * (gt - sdot);
+          const float d = __expf(dlv[t] - l) * (gt - u);
           dlv[t] = d;
-          dlp[(int64_t)t * V] = d;
           float kv[HD];
           load6(kt + (lt + (ki * HY + kj) * HX + kk) * HD, kv);
 #pragma unroll
@@ -201,58 +239,50 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_p_kernel(const float* __restr
     float* dqp = dq + n * C + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dqp + c) = make_float2(dqa[c] * scale, dqa[c + 1] * scale);
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // ---- key role
+    float kn[HD];
+    load6(kt + lc * HD, kn);
 #pragma unroll
-  for (int t = 0; t < 27; ++t) {
-    const float r = wave_sum(dlv[t]);
-    if (lane == 0) red[wv * 27 + t] = r;
+    for (int c = 0; c < HD; ++c) kn[c] *= scale;
+    float dka[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dka[c] = 0.f;
+#pragma unroll
+    for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+      for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          // query voxel m = n - off(t).  No bounds test: a halo voxel outside the volume was staged with
+          // d_out = u = 0, so its dlogit is p * (0 - 0) = 0 (p stays finite: logit = rpb[t], lse = 0)
+          const int lm = lc + ((1 - ki) * HY + (1 - kj)) * HX + (1 - kk);
+          float qv[HD];
+          load6(qt + lm * HD, qv);
+          float lg = rp[ki * 9 + kj * 3 + kk];
+#pragma unroll
+          for (int c = 0; c < HD; ++c) lg = fmaf(qv[c], kn[c], lg);
+          const float* am = ax + lm * AUX;
+          const float gt = (float)(ki - 1) * am[0] + (float)(kj - 1) * am[1] + (float)(kk - 1) * am[2];
+          const float d = __expf(lg - am[4]) * (gt - am[3]);
+#pragma unroll
+          for (int c = 0; c < HD; ++c) dka[c] = fmaf(d, qv[c], dka[c]);
+        }
+    float* dkp = dk + n * C + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dkp + c) = make_float2(dka[c] * scale, dka[c + 1] * scale);
   }
+  // wave sums of the 27 dlogits as one butterfly reduce-scatter (32 shuffles instead of 27 x 6): lane l ends up
+  // with the wave total of tap slot(l); fixed pattern -> deterministic
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float r = wave_reduce_scatter32(dlv, lane);
+  if ((lane & 1) == 0 && (lane >> 1) < 27) red[wv * 27 + (lane >> 1)] = r;
   __syncthreads();
   if (threadIdx.x < 27) {
-    float r = 0.f;
-    for (int w = 0; w < NTHREADS / 64; ++w) r += red[w * 27 + threadIdx.x];
+    float t = 0.f;
+    for (int w = 0; w < NTHREADS / 64; ++w) t += red[w * 27 + threadIdx.x];
     const int64_t blk = ((int64_t)b * gridDim.y + h) * gridDim.x + blockIdx.x;
-    drpb_part[blk * 27 + threadIdx.x] = r;
+    drpb_part[blk * 27 + threadIdx.x] = t;
   }
-}
-
-__global__ __launch_bounds__(NTHREADS) void na_bwd_c_kernel(const float* __restrict__ q, const float* __restrict__ dl,
-                                                            float* __restrict__ dk, int D, int H, int W, int heads,
-                                                            float scale, TileGeom g) {
-  __shared__ __attribute__((aligned(16))) float qt[HVOX * HD];
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int C = heads * HD;
-  const int64_t V = (int64_t)D * H * W;
-  int z0, y0, x0;
-  tile_origin(blockIdx.x, g, z0, y0, x0);
-  stage_k_tile(qt, q, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);      // same staging, q instead of k
-  __syncthreads();
-  const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
-  const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
-  if (z >= D || y >= H || x >= W) return;
-  const float* dlb = dl + ((int64_t)(b * heads + h) * 27) * V;
-  float acc[HD];
-#pragma unroll
-  for (int c = 0; c < HD; ++c) acc[c] = 0.f;
-#pragma unroll
-  for (int ki = 0; ki < 3; ++ki)
-#pragma unroll
-    for (int kj = 0; kj < 3; ++kj)
-#pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        const int nz = z - (ki - 1), ny = y - (kj - 1), nx = x - (kk - 1);      // producer n = m - off(t)
-        if (nz >= 0 && nz < D && ny >= 0 && ny < H && nx >= 0 && nx < W) {
-          const float d = dlb[(int64_t)(ki * 9 + kj * 3 + kk) * V + ((int64_t)nz * H + ny) * W + nx];
-          float qv[HD];
-          load6(qt + (((tz + 2 - ki) * HY + (ty + 2 - kj)) * HX + (tx + 2 - kk)) * HD, qv);
-#pragma unroll
-          for (int c = 0; c < HD; ++c) acc[c] = fmaf(d, qv[c], acc[c]);
-        }
-      }
-  float* dkp = dk + ((int64_t)b * V + ((int64_t)z * H + y) * W + x) * C + h * HD;
-#pragma unroll
-  for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dkp + c) = make_float2(acc[c] * scale, acc[c + 1] * scale);
 }
 
 // partial (B, heads, nblk, 27) -> out (heads,27), two deterministic fp64 stages:
@@ -424,30 +454,30 @@ inline TileGeom geom(int D, int H, int W) { return TileGeom{cdiv(W, TX), cdiv(H,
 
 extern "C" {
 
-int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, int B, int D, int H, int W,
+int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, float* lse, int B, int D, int H, int W,
                  int heads, int hd, float scale, modet_stream_t stream) {
   MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(out);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
   if (hd != HD) return MODET_ERR_UNSUPPORTED;
   const TileGeom g = geom(D, H, W);
   dim3 grid(g.tiles_x * g.tiles_y * g.tiles_z, heads, B);
-  hipLaunchKernelGGL(na_fwd_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, q, k, rpb, out, D, H, W, heads,
+  hipLaunchKernelGGL(na_fwd_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, q, k, rpb, out, lse, D, H, W, heads,
                      scale, g);
   return modet_launch_status();
 }
 
 size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads) {
   const TileGeom g = geom(D, H, W);
-  size_t fl = (size_t)B * heads * g.tiles_x * g.tiles_y * g.tiles_z * 27 + (size_t)B * heads * 27 * D * H * W;
+  size_t fl = (size_t)B * heads * g.tiles_x * g.tiles_y * g.tiles_z * 27;
   fl += fl & 1;                                        // keep the fp64 scratch that follows 8-byte aligned
   return fl * sizeof(float) + drpb_scratch_bytes(B, heads);
 }
 
-int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* d_out, float* d_q, float* d_k,
-                 float* d_rpb, void* ws, size_t ws_bytes, int B, int D, int H, int W, int heads, int hd, float scale,
-                 modet_stream_t stream) {
-  MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(d_out);
-  MODET_CHECK_PTR(d_q); MODET_CHECK_PTR(d_k); MODET_CHECK_PTR(d_rpb); MODET_CHECK_PTR(ws);
+int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* out, const float* lse,
+                 const float* d_out, float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes, int B, int D,
+                 int H, int W, int heads, int hd, float scale, modet_stream_t stream) {
+  MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(out); MODET_CHECK_PTR(lse);
+  MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_q); MODET_CHECK_PTR(d_k); MODET_CHECK_PTR(d_rpb); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
   if (hd != HD) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_na_bwd_ws_bytes(B, D, H, W, heads)) return MODET_ERR_WORKSPACE;
@@ -455,11 +485,10 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
   const TileGeom g = geom(D, H, W);
   const int64_t nblk = (int64_t)g.tiles_x * g.tiles_y * g.tiles_z;
   float* part = (float*)ws;
-  float* dl = part + (size_t)B * heads * nblk * 27;
   dim3 grid((unsigned)nblk, heads, B);
-  hipLaunchKernelGGL(na_bwd_p_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, d_out, d_q, dl, part, D, H, W, heads, scale, g);
-  hipLaunchKernelGGL(na_bwd_c_kernel, grid, dim3(NTHREADS), 0, s, q, (const float*)dl, d_k, D, H, W, heads, scale, g);
-  size_t fl = (size_t)B * heads * nblk * 27 + (size_t)B * heads * 27 * D * H * W;
+  hipLaunchKernelGGL(na_bwd_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, out, lse, d_out, d_q, d_k, part, D, H, W, heads,
+                     scale, g);
+  size_t fl = (size_t)B * heads * nblk * 27;
   fl += fl & 1;
   drpb_reduce(part, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
   return modet_launch_status();

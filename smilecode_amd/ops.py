@@ -414,17 +414,20 @@ class _NA(Function):
             raise RuntimeError("neighbourhood attention: q and k shapes differ")
         hd = C // heads
         out = torch.empty((B, D, H, W, heads * 3), dtype=torch.float32, device=q.device)
+        need_grad = any(ctx.needs_input_grad[:3])
+        lse = torch.empty((B, D, H, W, heads), dtype=torch.float32, device=q.device) if need_grad else None
         nvh = float(B) * D * H * W * heads      # 60 B and ~620 flop per voxel-head
         with _Guard(q, f"na_fwd[h{heads}]", 620.0 * nvh, 60.0 * nvh):
-            _lib.check(_L().modet_na_fwd(_p(q), _p(k), _p(rpb), _p(out), B, D, H, W, heads, hd, float(scale),
+            _lib.check(_L().modet_na_fwd(_p(q), _p(k), _p(rpb), _p(out), _p(lse), B, D, H, W, heads, hd, float(scale),
                                          _stream()), "modet_na_fwd")
-        ctx.save_for_backward(q, k, rpb)
+        if need_grad:
+            ctx.save_for_backward(q, k, rpb, out, lse)
         ctx.heads, ctx.scale = heads, float(scale)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, rpb = ctx.saved_tensors
+        q, k, rpb, out, lse = ctx.saved_tensors
         dout = dout.contiguous()
         B, D, H, W, C = q.shape
         heads = ctx.heads
@@ -432,10 +435,10 @@ class _NA(Function):
         L = _L()
         nb = L.modet_na_bwd_ws_bytes(B, D, H, W, heads)
         ws = _ws(nb, q)
-        nvh = float(B) * D * H * W * heads      # reads q,k,d_out (15 floats), writes d_q,d_k (12)
-        with _Guard(q, f"na_bwd[h{heads}]", 1600.0 * nvh, 108.0 * nvh):
-            _lib.check(L.modet_na_bwd(_p(q), _p(k), _p(rpb), _p(dout), _p(dq), _p(dk), _p(drpb), _p(ws), nb, B, D, H,
-                                      W, heads, C // heads, ctx.scale, _stream()), "modet_na_bwd")
+        nvh = float(B) * D * H * W * heads      # reads q,k,d_out,out,lse (19 floats), writes d_q,d_k (12)
+        with _Guard(q, f"na_bwd[h{heads}]", 1900.0 * nvh, 124.0 * nvh):
+            _lib.check(L.modet_na_bwd(_p(q), _p(k), _p(rpb), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(drpb), _p(ws),
+                                      nb, B, D, H, W, heads, C // heads, ctx.scale, _stream()), "modet_na_bwd")
         return dq, dk, drpb, None, None
 
 
