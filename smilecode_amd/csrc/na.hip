@@ -239,6 +239,18 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
     float* dqp = dq + n * C + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dqp + c) = make_float2(dqa[c] * scale, dqa[c + 1] * scale);
+  }
+  // wave sums of the 27 dlogits as one butterfly reduce-scatter (32 shuffles instead of 27 x 6): lane l ends up
+  // with the wave total of tap slot(l); fixed pattern -> deterministic.  Done here so the 27 registers are free
+  // during the key role.
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    const float r = wave_reduce_scatter32(dlv, lane);
+    if ((lane & 1) == 0 && (lane >> 1) < 27) red[wv * 27 + (lane >> 1)] = r;
+  }
+  if (live) {
+    const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+    const int lc = ((tz + 1) * HY + ty + 1) * HX + tx + 1;
     // ---- key role
     float kn[HD];
     load6(kt + lc * HD, kn);
@@ -271,11 +283,6 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
 #pragma unroll
     for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dkp + c) = make_float2(dka[c] * scale, dka[c + 1] * scale);
   }
-  // wave sums of the 27 dlogits as one butterfly reduce-scatter (32 shuffles instead of 27 x 6): lane l ends up
-  // with the wave total of tap slot(l); fixed pattern -> deterministic
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float r = wave_reduce_scatter32(dlv, lane);
-  if ((lane & 1) == 0 && (lane >> 1) < 27) red[wv * 27 + (lane >> 1)] = r;
   __syncthreads();
   if (threadIdx.x < 27) {
     float t = 0.f;
