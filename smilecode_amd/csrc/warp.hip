@@ -111,95 +111,130 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
 // 1.4-1.9 ms for smooth AND rough flows vs 5.4-7.5 ms with 4 channels per thread; an LDS-privatised variant was
 // 1.7 ms on smooth but 14 ms on rough flows and was dropped).  d_flow: per-voxel gather; the G (= C rounded up
 // to a power of two) channel lanes of a voxel are adjacent and combined with xor-shuffles.
+// Threads <-> (voxel, channel); a thread walks a run of ZRUN voxels along z.  Two merges cut the L2 atomics (the
+// bound of this kernel, ~270 G dword-atomics/s) without any LDS:
+//  * x: the next voxel along x sits G lanes up.  When its footprint is this one shifted by +1 in x (the common case
+//    for a smooth flow) its dx=0 corners are this voxel's dx=1 corners: hand those four values over with a shuffle
+//    and let the neighbour issue ONE atomic for both.  Both sides evaluate the same predicate from shuffled
+//    footprints, so nothing is lost or counted twice.
+//  * z: the dz=1 half of a voxel's footprint is kept in registers; if the next voxel of the run lands exactly one
+//    source plane higher it absorbs them into its dz=0 half, otherwise they are flushed.
+// Smooth flow: ~2 atomics per (voxel, channel) instead of 8.
+constexpr int ZRUN = 8;
 __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                        const float* __restrict__ dout, float* __restrict__ dsrc,
                                                        float* __restrict__ dflow, int D, int H, int W, int C, int G,
                                                        int64_t total, int add_flow) {
+  // total = B * ceil(D/ZRUN) * H * W * G items (one per run)
   const int64_t V = (int64_t)D * H * W;
+  const int nrun = (D + ZRUN - 1) / ZRUN;
+  const int64_t HW = (int64_t)H * W;
   const int64_t total_pad = cdiv64(total, BLK) * BLK;       // keep whole waves alive for the shuffles
   const int lane = threadIdx.x & 63;
   for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total_pad; idx += (int64_t)gridDim.x * BLK) {
     const bool inr = idx < total;
     const int64_t id = inr ? idx : total - 1;
     const int c = (int)(id % G);
-    const bool live = inr && c < C;
-    const int64_t n = id / G;
-    const int64_t b = n / V, v = n - b * V;
-    const int xi = (int)(v % W);
-    const int64_t t2 = v / W;
-    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
-    const float* fp = flow + n * 3;
-    const Tri t = tri_setup((float)zi + fp[0], (float)yi + fp[1], (float)xi + fp[2]);
-    const int cc = live ? c : 0;
-    const float go = live ? dout[n * C + cc] : 0.f;
+    const bool livec = inr && c < C;
+    int64_t r = id / G;
+    const int xi = (int)(r % W); r /= W;
+    const int yi = (int)(r % H); r /= H;
+    const int zr = (int)(r % nrun);
+    const int64_t b = r / nrun;
+    const int cc = livec ? c : 0;
     const float* sb = src + b * V * C + cc;
     float* db = dsrc ? dsrc + b * V * C + cc : nullptr;
-    // contributions of this (voxel, channel) to the 8 corners, index = dz*4 + dy*2 + dx
-    float cv[8];
-    float gz = 0.f, gy = 0.f, gx = 0.f;
+    // x-neighbour bookkeeping that does not depend on z
+    const int up = lane + G, dn = lane - G;
+    const int nxi = __shfl(xi, up, 64), pxi = __shfl(xi, dn, 64);
+    const bool up_ok = (up < 64) && (idx + G < total) && nxi == xi + 1;
+    const bool dn_ok = (dn >= 0) && inr && pxi == xi - 1;
+    float pend[4] = {0.f, 0.f, 0.f, 0.f};                    // dz=1 half of the previous voxel, index dy*2 + dx
+    int pz = 0, py = 0, px = 0;
+    bool have = false;
+    for (int k = 0; k < ZRUN; ++k) {
+      const int zi = zr * ZRUN + k;
+      const bool zin = zi < D;                               // uniform over the wave except at the run tail
+      const bool live = livec && zin;
+      const int64_t n = b * V + (int64_t)(zin ? zi : D - 1) * HW + (int64_t)yi * W + xi;
+      const float* fp = flow + n * 3;
+      const Tri t = tri_setup((float)zi + fp[0], (float)yi + fp[1], (float)xi + fp[2]);
+      const float go = live ? dout[n * C + cc] : 0.f;
+      // contributions of this (voxel, channel) to the 8 corners, index = dz*4 + dy*2 + dx
+      float cv[8];
+      float gz = 0.f, gy = 0.f, gx = 0.f;
 #pragma unroll
-    for (int dz = 0; dz < 2; ++dz) {
-      const float wz = dz ? t.fz : 1.f - t.fz;
+      for (int dz = 0; dz < 2; ++dz) {
+        const float wz = dz ? t.fz : 1.f - t.fz;
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const float wy = dy ? t.fy : 1.f - t.fy;
+        for (int dy = 0; dy < 2; ++dy) {
+          const float wy = dy ? t.fy : 1.f - t.fy;
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          const float wx = dx ? t.fx : 1.f - t.fx;
-          const int zz = t.z0 + dz, yy = t.y0 + dy, xx = t.x0 + dx;
-          const bool ok = live && zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
-          cv[dz * 4 + dy * 2 + dx] = ok ? wz * wy * wx * go : 0.f;
-          if (dflow && ok) {
-            const float dot = sb[(((int64_t)zz * H + yy) * W + xx) * C] * go;
-            gz += (dz ? 1.f : -1.f) * wy * wx * dot;
-            gy += (dy ? 1.f : -1.f) * wz * wx * dot;
-            gx += (dx ? 1.f : -1.f) * wz * wy * dot;
+          for (int dx = 0; dx < 2; ++dx) {
+            const float wx = dx ? t.fx : 1.f - t.fx;
+            const int zz = t.z0 + dz, yy = t.y0 + dy, xx = t.x0 + dx;
+            const bool ok = live && zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            cv[dz * 4 + dy * 2 + dx] = ok ? wz * wy * wx * go : 0.f;
+            if (dflow && ok) {
+              const float dot = sb[(((int64_t)zz * H + yy) * W + xx) * C] * go;
+              gz += (dz ? 1.f : -1.f) * wy * wx * dot;
+              gy += (dy ? 1.f : -1.f) * wz * wx * dot;
+              gx += (dx ? 1.f : -1.f) * wz * wy * dot;
+            }
           }
         }
       }
-    }
-    if (db) {
-      // The next voxel along x sits G lanes up.  When its footprint is this one shifted by +1 in x (the common
-      // case for a smooth flow) its dx=0 corners are this voxel's dx=1 corners: hand those four values over with
-      // a shuffle and let the neighbour issue ONE atomic for both -> up to 2x fewer L2 atomics.  Both sides
-      // evaluate the same predicate from shuffled footprints, so nothing is lost or counted twice.
-      const int up = lane + G, dn = lane - G;
-      const int nz0 = __shfl(t.z0, up, 64), ny0 = __shfl(t.y0, up, 64), nx0 = __shfl(t.x0, up, 64);
-      const int nxi = __shfl(xi, up, 64);
-      const bool give = (up < 64) && (idx + G < total) && nxi == xi + 1 && nz0 == t.z0 && ny0 == t.y0 && nx0 == t.x0 + 1;
-      const int pz0 = __shfl(t.z0, dn, 64), py0 = __shfl(t.y0, dn, 64), px0 = __shfl(t.x0, dn, 64);
-      const int pxi = __shfl(xi, dn, 64);
-      const bool take = (dn >= 0) && inr && pxi == xi - 1 && pz0 == t.z0 && py0 == t.y0 && px0 == t.x0 - 1;
+      if (db) {
+        // ---- x merge
+        const int nz0 = __shfl(t.z0, up, 64), ny0 = __shfl(t.y0, up, 64), nx0 = __shfl(t.x0, up, 64);
+        const bool give = up_ok && zin && nz0 == t.z0 && ny0 == t.y0 && nx0 == t.x0 + 1;
+        const int pz0 = __shfl(t.z0, dn, 64), py0 = __shfl(t.y0, dn, 64), px0 = __shfl(t.x0, dn, 64);
+        const bool take = dn_ok && zin && pz0 == t.z0 && py0 == t.y0 && px0 == t.x0 - 1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {                          // q = dz*2 + dy
-        const float from_prev = __shfl(cv[q * 2 + 1], dn, 64);
-        if (take) cv[q * 2] += from_prev;
-        if (give) cv[q * 2 + 1] = 0.f;
-      }
+        for (int q = 0; q < 4; ++q) {                        // q = dz*2 + dy
+          const float from_prev = __shfl(cv[q * 2 + 1], dn, 64);
+          if (take) cv[q * 2] += from_prev;
+          if (give) cv[q * 2 + 1] = 0.f;
+        }
+        // ---- z merge
+        if (have) {
+          if (zin && t.z0 == pz && t.y0 == py && t.x0 == px) {
 #pragma unroll
-      for (int dz = 0; dz < 2; ++dz)
+            for (int q = 0; q < 4; ++q) cv[q] += pend[q];
+          } else {
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            const float val = cv[dz * 4 + dy * 2 + dx];
-            if (val != 0.f)
-              atomicAdd(db + (((int64_t)(t.z0 + dz) * H + (t.y0 + dy)) * W + (t.x0 + dx)) * C, val);
+            for (int q = 0; q < 4; ++q)
+              if (pend[q] != 0.f) atomicAdd(db + (((int64_t)pz * H + (py + (q >> 1))) * W + (px + (q & 1))) * C, pend[q]);
           }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                        // the dz=0 half is final now
+          if (cv[q] != 0.f)
+            atomicAdd(db + (((int64_t)t.z0 * H + (t.y0 + (q >> 1))) * W + (t.x0 + (q & 1))) * C, cv[q]);
+          pend[q] = cv[4 + q];
+        }
+        pz = t.z0 + 1; py = t.y0; px = t.x0;
+        have = zin;
+      }
+      if (dflow) {
+        if (add_flow && live) {             // C == 3: d(out_c)/d(flow_c) has the identity term
+          gz += c == 0 ? go : 0.f; gy += c == 1 ? go : 0.f; gx += c == 2 ? go : 0.f;
+        }
+        for (int o = 1; o < G; o <<= 1) {
+          gz += __shfl_xor(gz, o, 64);
+          gy += __shfl_xor(gy, o, 64);
+          gx += __shfl_xor(gx, o, 64);
+        }
+        if (inr && zin && c == 0) {
+          float* dfp = dflow + n * 3;
+          dfp[0] = gz; dfp[1] = gy; dfp[2] = gx;
+        }
+      }
     }
-    if (dflow) {
-      if (add_flow && live) {               // C == 3: d(out_c)/d(flow_c) has the identity term
-        gz += c == 0 ? go : 0.f; gy += c == 1 ? go : 0.f; gx += c == 2 ? go : 0.f;
-      }
-      for (int o = 1; o < G; o <<= 1) {
-        gz += __shfl_xor(gz, o, 64);
-        gy += __shfl_xor(gy, o, 64);
-        gx += __shfl_xor(gx, o, 64);
-      }
-      if (inr && c == 0) {
-        float* dfp = dflow + n * 3;
-        dfp[0] = gz; dfp[1] = gy; dfp[2] = gx;
-      }
+    if (db && have) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (pend[q] != 0.f) atomicAdd(db + (((int64_t)pz * H + (py + (q >> 1))) * W + (px + (q & 1))) * C, pend[q]);
     }
   }
 }
@@ -553,7 +588,7 @@ int modet_warp_bwd(const float* src, const float* flow, const float* d_out, floa
     hipError_t e = hipMemsetAsync(d_src, 0, (size_t)B * D * H * W * C * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
   }
-  const int64_t total = (int64_t)B * D * H * W * G;
+  const int64_t total = (int64_t)B * cdiv(D, ZRUN) * H * W * G;       // one item per (z run, y, x, channel slot)
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow, D,
                      H, W, C, G, total, add_flow);
   return modet_launch_status();
