@@ -269,6 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     if (has_next) load_stage(ntile, nc0, multi);   // in flight during the MFMA loop below
     first = false;
 
+    __builtin_amdgcn_s_setprio(1);
     {
       // K loop over (tap, 4-channel group), fully unrolled: every LDS address is base + immediate.  The A/B
       // fragments of step ks+1 are read into a second register set before the MFMAs of step ks issue.
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
             acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][r], bfr[ks & 1][n], acc[r][n], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
 
     if (c0 + CK >= CinP) {
       int t = tile;
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
     for (int i = 0; i < NDV; ++i) *reinterpret_cast<float4*>(dys + (tid + i * NTHR) * 4) = dr[i];
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll(CIT == 16 ? 16 : 4)
     for (int row = 0; row < WG_ROWS; ++row) {
       const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
@@ -473,6 +476,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   }
   // partial[(bx*gridDim.y + by)*NG + grp][i = M row][col = cout]
 #pragma unroll
@@ -660,6 +664,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_np_kernel(const float* __re
     }
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll 4
     for (int row = 0; row < WG_ROWS; ++row) {
       const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
@@ -674,6 +679,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_np_kernel(const float* __re
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   }
 #pragma unroll
   for (int g = 0; g < GPW; ++g) {
