@@ -243,79 +243,95 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
 // p + flow[p] lies within one voxel of p, so source voxel s only receives from the 27 voxels p = s + d, d in {-1,0,1}^3,
 // with weight prod_a max(0, 1 - |p_a + flow_a[p] - s_a|) (the trilinear hat: (1-f) at floor, f at floor+1).
 // One thread per voxel does both jobs: gathers d_src[s] (no atomics, deterministic) and, as p, its own d_flow.
-__global__ __launch_bounds__(BLK) void warp_bwd_gather3_kernel(const float* __restrict__ src, const float* __restrict__ flow,
-                                                               const float* __restrict__ dout, float* __restrict__ dsrc,
-                                                               float* __restrict__ dflow, int D, int H, int W,
-                                                               int64_t total, int add_flow) {
+// Runs on 4x4x16 voxel tiles: flow and d_out of the tile + 1-voxel halo are staged in LDS once (6 floats per voxel;
+// d_out = 0 outside the volume, so the 27-neighbour loop needs no bounds tests).
+constexpr int G3Z = 4, G3Y = 4, G3X = 16, G3HZ = G3Z + 2, G3HY = G3Y + 2, G3HX = G3X + 2, G3HV = G3HZ * G3HY * G3HX;
+__global__ __launch_bounds__(BLK) void warp_bwd_gather3_tiled_kernel(const float* __restrict__ src,
+                                                                     const float* __restrict__ flow,
+                                                                     const float* __restrict__ dout,
+                                                                     float* __restrict__ dsrc, float* __restrict__ dflow,
+                                                                     int D, int H, int W, int tiles_x, int tiles_y,
+                                                                     int add_flow) {
+  __shared__ __attribute__((aligned(8))) float fg[G3HV * 6];
   const int64_t V = (int64_t)D * H * W;
-  for (int64_t n = (int64_t)blockIdx.x * BLK + threadIdx.x; n < total; n += (int64_t)gridDim.x * BLK) {
-    const int64_t b = n / V, v = n - b * V;
-    const int xi = (int)(v % W);
-    const int64_t t2 = v / W;
-    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
-    if (dsrc) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  const int b = blockIdx.y;
+  int t = blockIdx.x;
+  const int x0 = (t % tiles_x) * G3X; t /= tiles_x;
+  const int y0 = (t % tiles_y) * G3Y;
+  const int z0 = (t / tiles_y) * G3Z;
+  for (int i = threadIdx.x; i < G3HV * 3; i += BLK) {
+    const int v = i / 3, part = i - v * 3;               // part 0: flow[0..1]; 1: flow[2], d_out[0]; 2: d_out[1..2]
+    const int hx = v % G3HX, r = v / G3HX;
+    const int hy = r % G3HY, hz = r / G3HY;
+    const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+    float2 val = make_float2(0.f, 0.f);
+    if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
+      const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+      if (part == 0) val = make_float2(flow[n * 3], flow[n * 3 + 1]);
+      else if (part == 1) val = make_float2(flow[n * 3 + 2], dout[n * 3]);
+      else val = make_float2(dout[n * 3 + 1], dout[n * 3 + 2]);
+    }
+    *reinterpret_cast<float2*>(fg + v * 6 + part * 2) = val;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % G3X, ty = (threadIdx.x / G3X) % G3Y, tz = threadIdx.x / (G3X * G3Y);
+  const int zi = z0 + tz, yi = y0 + ty, xi = x0 + tx;
+  if (zi >= D || yi >= H || xi >= W) return;
+  const int64_t n = (int64_t)b * V + ((int64_t)zi * H + yi) * W + xi;
+  const int lc = ((tz + 1) * G3HY + ty + 1) * G3HX + tx + 1;
+  if (dsrc) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-      for (int dz = -1; dz <= 1; ++dz) {
-        const int pz = zi + dz;
-        if (pz < 0 || pz >= D) continue;
+    for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-          const int py = yi + dy;
-          if (py < 0 || py >= H) continue;
+      for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-          for (int dx = -1; dx <= 1; ++dx) {
-            const int px = xi + dx;
-            if (px < 0 || px >= W) continue;
-            const int64_t pn = b * V + ((int64_t)pz * H + py) * W + px;
-            const float* fp = flow + pn * 3;
-            const float wz = 1.f - fabsf((float)dz + fp[0]);
-            const float wy = 1.f - fabsf((float)dy + fp[1]);
-            const float wx = 1.f - fabsf((float)dx + fp[2]);
-            if (wz > 0.f && wy > 0.f && wx > 0.f) {
-              const float wgt = wz * wy * wx;
-              const float* gp = dout + pn * 3;
-              a0 = fmaf(wgt, gp[0], a0); a1 = fmaf(wgt, gp[1], a1); a2 = fmaf(wgt, gp[2], a2);
-            }
+        for (int dx = -1; dx <= 1; ++dx) {
+          const float* p = fg + (lc + (dz * G3HY + dy) * G3HX + dx) * 6;
+          const float2 q0 = *reinterpret_cast<const float2*>(p), q1 = *reinterpret_cast<const float2*>(p + 2),
+                       q2 = *reinterpret_cast<const float2*>(p + 4);
+          const float wz = 1.f - fabsf((float)dz + q0.x);
+          const float wy = 1.f - fabsf((float)dy + q0.y);
+          const float wx = 1.f - fabsf((float)dx + q1.x);
+          if (wz > 0.f && wy > 0.f && wx > 0.f) {
+            const float wgt = wz * wy * wx;
+            a0 = fmaf(wgt, q1.y, a0); a1 = fmaf(wgt, q2.x, a1); a2 = fmaf(wgt, q2.y, a2);
+          }
+        }
+    float* dp = dsrc + n * 3;
+    dp[0] = a0; dp[1] = a1; dp[2] = a2;
+  }
+  if (dflow) {
+    const float* pc = fg + lc * 6;
+    const Tri tr = tri_setup((float)zi + pc[0], (float)yi + pc[1], (float)xi + pc[2]);
+    const float g0 = pc[3], g1 = pc[4], g2 = pc[5];
+    const float* sb = src + (int64_t)b * V * 3;
+    float gz = 0.f, gy = 0.f, gx = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz) {
+      const int zz = tr.z0 + dz;
+      const float wz = dz ? tr.fz : 1.f - tr.fz;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int yy = tr.y0 + dy;
+        const float wy = dy ? tr.fy : 1.f - tr.fy;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int xx = tr.x0 + dx;
+          const float wx = dx ? tr.fx : 1.f - tr.fx;
+          if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const float* sp = sb + (((int64_t)zz * H + yy) * W + xx) * 3;
+            const float dot = sp[0] * g0 + sp[1] * g1 + sp[2] * g2;
+            gz += (dz ? 1.f : -1.f) * wy * wx * dot;
+            gy += (dy ? 1.f : -1.f) * wz * wx * dot;
+            gx += (dx ? 1.f : -1.f) * wz * wy * dot;
           }
         }
       }
-      float* dp = dsrc + n * 3;
-      dp[0] = a0; dp[1] = a1; dp[2] = a2;
     }
-    if (dflow) {
-      const float* fp = flow + n * 3;
-      const Tri t = tri_setup((float)zi + fp[0], (float)yi + fp[1], (float)xi + fp[2]);
-      const float* gp = dout + n * 3;
-      const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
-      const float* sb = src + b * V * 3;
-      float gz = 0.f, gy = 0.f, gx = 0.f;
-#pragma unroll
-      for (int dz = 0; dz < 2; ++dz) {
-        const int zz = t.z0 + dz;
-        const float wz = dz ? t.fz : 1.f - t.fz;
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-          const int yy = t.y0 + dy;
-          const float wy = dy ? t.fy : 1.f - t.fy;
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            const int xx = t.x0 + dx;
-            const float wx = dx ? t.fx : 1.f - t.fx;
-            if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-              const float* sp = sb + (((int64_t)zz * H + yy) * W + xx) * 3;
-              const float dot = sp[0] * g0 + sp[1] * g1 + sp[2] * g2;
-              gz += (dz ? 1.f : -1.f) * wy * wx * dot;
-              gy += (dy ? 1.f : -1.f) * wz * wx * dot;
-              gx += (dx ? 1.f : -1.f) * wz * wy * dot;
-            }
-          }
-        }
-      }
-      if (add_flow) { gz += g0; gy += g1; gx += g2; }
-      float* dfp = dflow + n * 3;
-      dfp[0] = gz; dfp[1] = gy; dfp[2] = gx;
-    }
+    if (add_flow) { gz += g0; gy += g1; gx += g2; }
+    float* dfp = dflow + n * 3;
+    dfp[0] = gz; dfp[1] = gy; dfp[2] = gx;
   }
 }
 
@@ -575,9 +591,9 @@ int modet_warp_bwd(const float* src, const float* flow, const float* d_out, floa
   if (flow_bound != 0 && (flow_bound != 1 || C != 3)) return MODET_ERR_UNSUPPORTED;
   if (!d_src && !d_flow) return MODET_OK;
   if (flow_bound == 1) {
-    const int64_t tot = (int64_t)B * D * H * W;
-    hipLaunchKernelGGL(warp_bwd_gather3_kernel, dim3(flat_grid(tot, BLK)), dim3(BLK), 0, (hipStream_t)stream, src, flow,
-                       d_out, d_src, d_flow, D, H, W, tot, add_flow);
+    const int tx = cdiv(W, G3X), ty = cdiv(H, G3Y), tz = cdiv(D, G3Z);
+    hipLaunchKernelGGL(warp_bwd_gather3_tiled_kernel, dim3(tx * ty * tz, B), dim3(BLK), 0, (hipStream_t)stream, src, flow,
+                       d_out, d_src, d_flow, D, H, W, tx, ty, add_flow);
     return modet_launch_status();
   }
   int G = 1;
