@@ -849,6 +849,9 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // resident 256-thread workgroups per CU from the kernel's own footprint: 160 KiB LDS per CU, 512 VGPR+AGPR per SIMD
 // lane allocated in granules of 8 (MI355X_MICROARCH.md), at most 8 waves per SIMD
 inline int resident_blocks(const void* fn, int nthreads) {
+#ifdef MODET_TUNING
+  if (const char* e = getenv("MODET_CONV_PERCU")) return atoi(e);
+#endif
   hipFuncAttributes a;
   if (hipFuncGetAttributes(&a, fn) != hipSuccess) return 2;
   const int by_lds = a.sharedSizeBytes > 0 ? (int)(163840 / round_up((int)a.sharedSizeBytes, 512)) : 8;
