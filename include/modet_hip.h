@@ -98,6 +98,13 @@ int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws
 size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes,
                             int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+/* ConvBlock (conv + LeakyReLU, models.py:119-133) weight gradient with the activation's derivative folded into the
+ * d_y load: y_act is the block's output, d_y the gradient w.r.t. it.  Supported for the first encoder block
+ * (Cin = 1, Cout = 4; its input needs no gradient, so this replaces the separate modet_lrelu_bwd pass);
+ * MODET_ERR_UNSUPPORTED otherwise. */
+int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias,
+                                void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                                modet_stream_t stream);
 
 /* InstanceNorm3d(affine=False, eps, biased variance) + LeakyReLU(0.1) (ConvInsBlock, models.py:135-151).
  * x,y (B,V,C) channels-last with V = D*H*W; mean,rstd (B*C) are outputs of fwd / inputs of bwd. */

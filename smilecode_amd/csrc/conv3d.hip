@@ -739,8 +739,8 @@ __global__ __launch_bounds__(NTHR) void conv_c1_fwd_kernel(const float* __restri
 // thread over a grid-stride loop, workgroup reduction, partials -> fixed-order fp64 sum.
 template <int CO>
 __global__ __launch_bounds__(NTHR) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             float* __restrict__ part, int D, int H, int W,
-                                                             int64_t total) {
+                                                             const float* __restrict__ yact, float* __restrict__ part,
+                                                             int D, int H, int W, int64_t total) {
   constexpr int NA = 27 * CO + CO;
   __shared__ float red[(NTHR / 64) * NA];
   float acc[NA];
@@ -755,7 +755,12 @@ __global__ __launch_bounds__(NTHR) void conv_c1_wgrad_kernel(const float* __rest
     float g[CO];
 #pragma unroll
     for (int c = 0; c < CO; c += 4) {
-      const float4 gv = *reinterpret_cast<const float4*>(dy + idx * CO + c);
+      float4 gv = *reinterpret_cast<const float4*>(dy + idx * CO + c);
+      if (yact) {      // ConvBlock: d_y is the gradient of LeakyReLU(conv); fold the activation's derivative in here
+        const float4 yv = *reinterpret_cast<const float4*>(yact + idx * CO + c);
+        gv.x *= yv.x > 0.f ? 1.f : LRELU_SLOPE; gv.y *= yv.y > 0.f ? 1.f : LRELU_SLOPE;
+        gv.z *= yv.z > 0.f ? 1.f : LRELU_SLOPE; gv.w *= yv.w > 0.f ? 1.f : LRELU_SLOPE;
+      }
       g[c] = gv.x; g[c + 1] = gv.y; g[c + 2] = gv.z; g[c + 3] = gv.w;
     }
 #pragma unroll
@@ -1014,8 +1019,24 @@ size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int
   return (fl > c1 ? fl : c1) * sizeof(float);
 }
 
+static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
+                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+
 int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes,
                             int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+  return conv_bwd_weight_impl(x, d_y, nullptr, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream);
+}
+
+int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias,
+                                void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                                modet_stream_t stream) {
+  MODET_CHECK_PTR(y_act);
+  if (!(Cin == 1 && Cout == 4)) return MODET_ERR_UNSUPPORTED;     // only the first encoder block (ConvBlock 1 -> 4)
+  return conv_bwd_weight_impl(x, d_y, y_act, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream);
+}
+
+static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
+                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (Cout > NTHR) return MODET_ERR_UNSUPPORTED;
@@ -1025,7 +1046,7 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
     const int64_t total = (int64_t)B * D * H * W;
     int nblk = (int)cdiv64(total, NTHR);
     if (nblk > C1_WG_BLOCKS) nblk = C1_WG_BLOCKS;
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel<4>, dim3(nblk), dim3(NTHR), 0, s, x, d_y, (float*)ws, D, H, W, total);
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<4>, dim3(nblk), dim3(NTHR), 0, s, x, d_y, y_act, (float*)ws, D, H, W, total);
     hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(27 * 4 + 4), dim3(64), 0, s, (const float*)ws, d_w, d_bias, nblk, 4);
     return modet_launch_status();
   }

@@ -134,7 +134,9 @@ def conv3d_backward_data(dy, w, Cin):
     return dx
 
 
-def conv3d_backward_weight(x, dy, want_bias):
+def conv3d_backward_weight(x, dy, want_bias, y_act=None):
+    """d_w, d_bias; with y_act (ConvBlock 1 -> 4 only) dy is the gradient w.r.t. LeakyReLU(conv) and the activation's
+    derivative is applied while loading it"""
     _chk(x, dy)
     B, D, H, W, Cin = x.shape
     Cout = dy.shape[-1]
@@ -145,8 +147,12 @@ def conv3d_backward_weight(x, dy, want_bias):
     ws = _ws(nb, x)
     n = float(B) * D * H * W
     with _Guard(x, f"conv_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
-        _lib.check(L.modet_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
-                                             _stream()), "modet_conv3d_bwd_weight")
+        if y_act is not None:
+            _lib.check(L.modet_conv3d_bwd_weight_act(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
+                                                     Cout, _stream()), "modet_conv3d_bwd_weight_act")
+        else:
+            _lib.check(L.modet_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
+                                                 _stream()), "modet_conv3d_bwd_weight")
     return dw, db
 
 
@@ -164,6 +170,10 @@ class _Conv3d(Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         dy = dy.contiguous()
+        if ctx.act and not ctx.needs_input_grad[0] and x.shape[-1] == 1 and w.shape[0] == 4:
+            # first encoder block: no d_x, and the weight-gradient kernel folds LeakyReLU' into its d_y load
+            dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, y_act=y)
+            return None, dw, db, None
         if ctx.act:
             g = torch.empty_like(dy)
             with _Guard(dy, "lrelu_bwd", dy.numel(), 12.0 * dy.numel()):
