@@ -1,0 +1,27 @@
+"""Worker for tests/test_gpu_e2e.py::test_data_parallel_two_ranks_equal_batch_two (launched by torch.distributed.run,
+two ranks on ONE GPU over gloo): each rank takes one volume pair, runs one Trainer.train_step and saves the updated flat
+parameter buffer and the averaged gradient."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smilecode_amd import models, synth                       # noqa: E402
+from smilecode_amd.engine import Trainer                       # noqa: E402
+from smilecode_amd.parallel import init_from_env               # noqa: E402
+
+out_dir, shape = sys.argv[1], tuple(int(s) for s in sys.argv[2].split(","))
+rank, local, world = init_from_env("gloo")
+torch.cuda.set_device(0)
+model = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).cuda()
+models.load_numpy_weights(model, synth.make_weights(24 + rank))      # rank 1 starts different: the broadcast must fix it
+tr = Trainer(model)
+mov, fix = synth.make_pair(shape, 24, world)                          # the same batch the single-process run uses
+mov, fix = torch.from_numpy(mov[rank:rank + 1]).cuda(), torch.from_numpy(fix[rank:rank + 1]).cuda()
+tr.train_step(mov, fix, epoch=0)
+torch.cuda.synchronize()
+np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=tr.fp.flat.cpu().numpy(), grad=(tr.fp.grad / world).cpu().numpy())
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()

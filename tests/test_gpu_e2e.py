@@ -223,6 +223,40 @@ def test_full_size_dice_parity_vs_oracle():
     assert abs(d_ref - dice_gpu) <= 1e-3, f"Dice {dice_gpu:.5f} vs reference path {d_ref:.5f}"
 
 
+def test_data_parallel_two_ranks_equal_batch_two(tmp_path):
+    """N ranks x 1 pair with one averaged all-reduce == one process with batch N (N = 2 ranks sharing
+    this GPU over gloo; on the 8-GPU node the same code runs over RCCL)."""
+    import subprocess
+    import sys
+    from smilecode_amd import models, synth
+    from smilecode_amd.engine import Trainer
+    shape = (32, 48, 32)
+    env = dict(os.environ, MODET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path),
+           ",".join(map(str, shape))]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ranks = [np.load(tmp_path / f"rank{i}.npz") for i in range(2)]
+    assert np.array_equal(ranks[0]["flat"], ranks[1]["flat"]), "ranks must hold identical parameters after the step"
+    assert np.array_equal(ranks[0]["grad"], ranks[1]["grad"])
+    # single process, batch 2 (the loss is a mean over the batch, so its gradient is the rank average)
+    model = _model(shape, 1.0)
+    tr = Trainer(model)
+    mov, fix = _pair(shape, 2)
+    tr.train_step(mov, fix, epoch=0)
+    g1, f1 = tr.fp.grad.cpu().numpy(), tr.fp.flat.cpu().numpy()
+    gerr = np.abs(ranks[0]["grad"] - g1).max() / np.abs(g1).max()
+    _note("dp2_vs_batch2_grad_relerr", gerr)
+    assert gerr < 2e-4, gerr
+    # the first Adam step moves every parameter by lr * g/(|g| + eps) ~ +-1e-4: compare where the gradient is not pure
+    # rounding noise (biases in front of an InstanceNorm have analytically zero gradient, their sign is arbitrary)
+    sig = np.abs(g1) > 1e-4 * np.abs(g1).max()
+    assert sig.mean() > 0.5
+    assert np.abs(ranks[0]["flat"] - f1)[sig].max() < 2e-5
+
+
 def test_train_and_infer_scripts_synthetic(tmp_path):
     """the train.py / infer.py equivalents run end to end (synthetic subjects, 64^3, 2 iterations), write the
     reference's checkpoint dict and log files, and the checkpoint loads back through infer."""
