@@ -63,7 +63,8 @@ int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad,
 /* Fused ModeTransformer.forward (ModeT/models.py:308-334 == ModeT-cu/models.py:300-316):
  *   logits = scale*q.k(n+off) + rpb, softmax over the 27 modes, out = sum_t p[t]*off(t).
  *   q,k (B,D,H,W,heads*hd) channels-last, unpadded, unscaled; rpb (heads,27);
- *   out (B,D,H,W,heads*3), channel = head*3+axis (models.py:332).  hd must be 6 (train.py:49).
+ *   out (B,D,H,W,heads*3), channel = head*3+axis (models.py:332).  hd = 6 (train.py:49) takes the specialised
+ *   kernels; any multiple of 8 up to 128 a chunked generic path (Im2Grid's CoTr: heads = 1, hd = C, rpb = 0, scale = 1).
  * Never materialises the (..,27) attention tensor.
  * lse (B,D,H,W,heads) or NULL: log-sum-exp of the 27 logits per voxel-head, written for the backward (NULL when no
  * gradient is needed).  The backward takes q, k, rpb, the forward's out and lse, and d_out; it recomputes each softmax

@@ -292,6 +292,232 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------ any head_dim % 8 == 0
+// The same two kernels for head dimensions other than ModeT's 6 (8 ... 128): e.g. Im2Grid's CoTr
+// ("Baseline methods/Im2Grid/models.py":276-322) is this attention with one head over all C channels, no bias, no
+// scale.  Channels are walked in chunks of 8: the K (and, backward, Q) halo tile of the current chunk lives in LDS and
+// the 27 logits accumulate in registers.  The backward makes two passes over the chunks: logits of both roles first,
+// then d_q / d_k chunk by chunk.
+constexpr int GC = 8;       // channels per chunk
+
+__device__ __forceinline__ void stage_chunk(float* __restrict__ dst, const float* __restrict__ srcp, int64_t bbase, int z0,
+                                            int y0, int x0, int D, int H, int W, int C, int coff) {
+  for (int idx = threadIdx.x; idx < HVOX * 2; idx += NTHREADS) {
+    const int v = idx >> 1, part = idx & 1;
+    const int hx = v % HX, t = v / HX;
+    const int hy = t % HY, hz = t / HY;
+    const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W)
+      val = *reinterpret_cast<const float4*>(srcp + (bbase + ((int64_t)z * H + y) * W + x) * C + coff + part * 4);
+    *reinterpret_cast<float4*>(dst + v * GC + part * 4) = val;
+  }
+}
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&r)[GC]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+}
+__device__ __forceinline__ float dot8(const float (&a)[GC], const float (&b)[GC]) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < GC; ++c) s = fmaf(a[c], b[c], s);
+  return s;
+}
+
+__global__ __launch_bounds__(NTHREADS) void na_fwd_gen_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ rpb, float* __restrict__ out,
+                                                              float* __restrict__ lse, int D, int H, int W, int heads,
+                                                              int hd, float scale, TileGeom g) {
+  __shared__ __attribute__((aligned(16))) float kt[HVOX * GC];
+  __shared__ float rp[27];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int C = heads * hd;
+  const int64_t V = (int64_t)D * H * W;
+  int z0, y0, x0;
+  tile_origin(blockIdx.x, g, z0, y0, x0);
+  if (threadIdx.x < 27) rp[threadIdx.x] = rpb[h * 27 + threadIdx.x];
+  const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
+  const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+  const bool live = z < D && y < H && x < W;
+  const int64_t n = (int64_t)b * V + ((int64_t)(live ? z : 0) * H + (live ? y : 0)) * W + (live ? x : 0);
+  const int lt = (tz * HY + ty) * HX + tx;
+  float p[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) p[t] = 0.f;
+  for (int c0 = 0; c0 < hd; c0 += GC) {
+    __syncthreads();
+    stage_chunk(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * hd + c0);
+    __syncthreads();
+    if (live) {
+      float qs[GC];
+      load8(q + n * C + h * hd + c0, qs);
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            float kv[GC];
+            load8(kt + (lt + (ki * HY + kj) * HX + kk) * GC, kv);
+            p[ki * 9 + kj * 3 + kk] += dot8(qs, kv);
+          }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) p[t] = fmaf(p[t], scale, rp[t]);
+  float mx;
+  const float inv = softmax27(p, mx);
+  if (lse) lse[n * heads + h] = mx - __logf(inv);
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+  for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+    for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const float pv = p[ki * 9 + kj * 3 + kk];
+        o0 += pv * (float)(ki - 1);
+        o1 += pv * (float)(kj - 1);
+        o2 += pv * (float)(kk - 1);
+      }
+  float* o = out + n * (heads * 3) + h * 3;
+  o[0] = o0 * inv; o[1] = o1 * inv; o[2] = o2 * inv;
+}
+
+__global__ __launch_bounds__(NTHREADS) void na_bwd_gen_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ rpb, const float* __restrict__ out,
+                                                              const float* __restrict__ lse, const float* __restrict__ dout,
+                                                              float* __restrict__ dq, float* __restrict__ dk,
+                                                              float* __restrict__ drpb_part, int D, int H, int W,
+                                                              int heads, int hd, float scale, TileGeom g) {
+  __shared__ __attribute__((aligned(16))) float kt[HVOX * GC];
+  __shared__ __attribute__((aligned(16))) float qt[HVOX * GC];
+  __shared__ float ax[HVOX * AUX];
+  __shared__ float red[27 * (NTHREADS / 64)];
+  __shared__ float rp[27];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int C = heads * hd;
+  const int64_t V = (int64_t)D * H * W;
+  int z0, y0, x0;
+  tile_origin(blockIdx.x, g, z0, y0, x0);
+  if (threadIdx.x < 27) rp[threadIdx.x] = rpb[h * 27 + threadIdx.x];
+  for (int v = threadIdx.x; v < HVOX; v += NTHREADS) {
+    const int hx = v % HX, t = v / HX;
+    const int hy = t % HY, hz = t / HY;
+    const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, u = 0.f, l = 0.f;
+    if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
+      const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+      const float* go = dout + n * (heads * 3) + h * 3;
+      const float* oo = out + n * (heads * 3) + h * 3;
+      g0 = go[0]; g1 = go[1]; g2 = go[2];
+      u = g0 * oo[0] + g1 * oo[1] + g2 * oo[2];
+      l = lse[n * heads + h];
+    }
+    float* a = ax + v * AUX;
+    a[0] = g0; a[1] = g1; a[2] = g2; a[3] = u; a[4] = l;
+  }
+  const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
+  const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+  const bool live = (z < D && y < H && x < W);
+  const int lt = (tz * HY + ty) * HX + tx;
+  const int lc = lt + (HY + 1) * HX + 1;
+  // ---- pass A: logits of both roles, accumulated over the channel chunks
+  float dlq[27], dlk[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) { dlq[t] = 0.f; dlk[t] = 0.f; }
+  for (int c0 = 0; c0 < hd; c0 += GC) {
+    __syncthreads();
+    stage_chunk(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * hd + c0);
+    stage_chunk(qt, q, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * hd + c0);
+    __syncthreads();
+    if (live) {
+      float qn[GC], kn[GC];
+      load8(qt + lc * GC, qn);
+      load8(kt + lc * GC, kn);
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            const int t = ki * 9 + kj * 3 + kk;
+            float v8[GC];
+            load8(kt + (lt + (ki * HY + kj) * HX + kk) * GC, v8);
+            dlq[t] += dot8(qn, v8);
+            load8(qt + (lc + ((1 - ki) * HY + (1 - kj)) * HX + (1 - kk)) * GC, v8);
+            dlk[t] += dot8(v8, kn);
+          }
+    }
+  }
+  if (live) {
+    const float* ac = ax + lc * AUX;
+    const float g0 = ac[0], g1 = ac[1], g2 = ac[2], u = ac[3], l = ac[4];
+#pragma unroll
+    for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+      for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          const int t = ki * 9 + kj * 3 + kk;
+          const float gt = (float)(ki - 1) * g0 + (float)(kj - 1) * g1 + (float)(kk - 1) * g2;
+          dlq[t] = __expf(fmaf(dlq[t], scale, rp[t]) - l) * (gt - u);
+          const float* am = ax + (lc + ((1 - ki) * HY + (1 - kj)) * HX + (1 - kk)) * AUX;
+          const float gm = (float)(ki - 1) * am[0] + (float)(kj - 1) * am[1] + (float)(kk - 1) * am[2];
+          dlk[t] = __expf(fmaf(dlk[t], scale, rp[t]) - am[4]) * (gm - am[3]);
+        }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    const float r = wave_reduce_scatter32(dlq, lane);       // dlq is all zero on dead lanes
+    if ((lane & 1) == 0 && (lane >> 1) < 27) red[wv * 27 + (lane >> 1)] = r;
+  }
+  // ---- pass B: d_q / d_k chunk by chunk
+  const int64_t n = (int64_t)b * V + ((int64_t)(live ? z : 0) * H + (live ? y : 0)) * W + (live ? x : 0);
+  for (int c0 = 0; c0 < hd; c0 += GC) {
+    __syncthreads();
+    stage_chunk(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * hd + c0);
+    stage_chunk(qt, q, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * hd + c0);
+    __syncthreads();
+    if (live) {
+      float dqa[GC], dka[GC];
+#pragma unroll
+      for (int c = 0; c < GC; ++c) { dqa[c] = 0.f; dka[c] = 0.f; }
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            const int t = ki * 9 + kj * 3 + kk;
+            float v8[GC];
+            load8(kt + (lt + (ki * HY + kj) * HX + kk) * GC, v8);
+#pragma unroll
+            for (int c = 0; c < GC; ++c) dqa[c] = fmaf(dlq[t], v8[c], dqa[c]);
+            load8(qt + (lc + ((1 - ki) * HY + (1 - kj)) * HX + (1 - kk)) * GC, v8);
+#pragma unroll
+            for (int c = 0; c < GC; ++c) dka[c] = fmaf(dlk[t], v8[c], dka[c]);
+          }
+      float* dqp = dq + n * C + h * hd + c0;
+      float* dkp = dk + n * C + h * hd + c0;
+      *reinterpret_cast<float4*>(dqp) = make_float4(dqa[0] * scale, dqa[1] * scale, dqa[2] * scale, dqa[3] * scale);
+      *reinterpret_cast<float4*>(dqp + 4) = make_float4(dqa[4] * scale, dqa[5] * scale, dqa[6] * scale, dqa[7] * scale);
+      *reinterpret_cast<float4*>(dkp) = make_float4(dka[0] * scale, dka[1] * scale, dka[2] * scale, dka[3] * scale);
+      *reinterpret_cast<float4*>(dkp + 4) = make_float4(dka[4] * scale, dka[5] * scale, dka[6] * scale, dka[7] * scale);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    float t = 0.f;
+    for (int w = 0; w < NTHREADS / 64; ++w) t += red[w * 27 + threadIdx.x];
+    const int64_t blk = ((int64_t)b * gridDim.y + h) * gridDim.x + blockIdx.x;
+    drpb_part[blk * 27 + threadIdx.x] = t;
+  }
+}
+
+inline bool gen_hd_ok(int hd) { return hd >= GC && hd <= 128 && hd % GC == 0; }
+
 // partial (B, heads, nblk, 27) -> out (heads,27), two deterministic fp64 stages:
 //   1: grid (COLSUM_SLICES, heads, B): coalesced column sums of a slice of the nblk rows -> scratch[b][h][slice][27]
 //   2: one workgroup: (b, slice) added in order per (h, t)
@@ -465,11 +691,15 @@ int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, f
                  int heads, int hd, float scale, modet_stream_t stream) {
   MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(out);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
-  if (hd != HD) return MODET_ERR_UNSUPPORTED;
+  if (hd != HD && !gen_hd_ok(hd)) return MODET_ERR_UNSUPPORTED;
   const TileGeom g = geom(D, H, W);
   dim3 grid(g.tiles_x * g.tiles_y * g.tiles_z, heads, B);
-  hipLaunchKernelGGL(na_fwd_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, q, k, rpb, out, lse, D, H, W, heads,
-                     scale, g);
+  if (hd == HD)
+    hipLaunchKernelGGL(na_fwd_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, q, k, rpb, out, lse, D, H, W, heads,
+                       scale, g);
+  else
+    hipLaunchKernelGGL(na_fwd_gen_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, q, k, rpb, out, lse, D, H, W,
+                       heads, hd, scale, g);
   return modet_launch_status();
 }
 
@@ -486,15 +716,19 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
   MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(out); MODET_CHECK_PTR(lse);
   MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_q); MODET_CHECK_PTR(d_k); MODET_CHECK_PTR(d_rpb); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
-  if (hd != HD) return MODET_ERR_UNSUPPORTED;
+  if (hd != HD && !gen_hd_ok(hd)) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_na_bwd_ws_bytes(B, D, H, W, heads)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const TileGeom g = geom(D, H, W);
   const int64_t nblk = (int64_t)g.tiles_x * g.tiles_y * g.tiles_z;
   float* part = (float*)ws;
   dim3 grid((unsigned)nblk, heads, B);
-  hipLaunchKernelGGL(na_bwd_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, out, lse, d_out, d_q, d_k, part, D, H, W, heads,
-                     scale, g);
+  if (hd == HD)
+    hipLaunchKernelGGL(na_bwd_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, out, lse, d_out, d_q, d_k, part, D, H, W,
+                       heads, scale, g);
+  else
+    hipLaunchKernelGGL(na_bwd_gen_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, out, lse, d_out, d_q, d_k, part, D, H, W,
+                       heads, hd, scale, g);
   size_t fl = (size_t)B * heads * nblk * 27;
   fl += fl & 1;
   drpb_reduce(part, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);

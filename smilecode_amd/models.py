@@ -239,6 +239,26 @@ class ModeTransformer(nn.Module):
         return ops.neighbourhood_attention(q, k, rpb, self.num_heads, self.scale)
 
 
+class CoTr(nn.Module):
+    """Coordinate translator of the Im2Grid baseline ("Baseline methods/Im2Grid/models.py":276-322): the same 3x3x3
+    neighbourhood attention with ONE head over all C channels, no bias, no scale -- SURVEY.md 8(f) rank 4: it runs on
+    the attention kernels' generic head-dimension path (C a multiple of 8, up to 128).
+
+    ``forward(q, k)``: q, k (B,H,W,T,C) channels-last as in the reference -> expected offset (B,3,H,W,T)."""
+
+    def __init__(self, kernel_size=3):
+        super().__init__()
+        if kernel_size != 3:
+            raise RuntimeError("CoTr does not support kernel size %d" % kernel_size)
+        self.kernel_size = kernel_size
+        r = torch.arange(-1, 2)
+        self.register_buffer("grid", torch.stack(torch.meshgrid(r, r, r, indexing="ij"), -1).float())
+
+    def forward(self, q, k):
+        rpb = torch.zeros(1, 3, 3, 3, dtype=q.dtype, device=q.device)
+        return ops.to_ncdhw(ops.neighbourhood_attention(q.contiguous(), k.contiguous(), rpb, 1, 1.0))
+
+
 class ModeT(nn.Module):
     """reference ModeT/models.py:338-412 (scale=None -> head_dim**-0.5)."""
 

@@ -146,6 +146,42 @@ def test_warp_bounded_flow_gather_equals_scatter(ops, orc):
     assert float((df - df2).abs().max()) < 2e-5       # same math, different summation order over the 3 channels
 
 
+@pytest.mark.parametrize("tag", ["c8", "c16", "c32", "c128"])
+def test_cotr_golden(ops, tag):
+    """Im2Grid's CoTr (one head over C channels) on the generic head-dimension kernels vs the reference's fp64 output"""
+    from smilecode_amd import models
+    g = gold("op_cotr.npz")
+    q = cu(g[f"{tag}.q"]).requires_grad_(True)
+    k = cu(g[f"{tag}.k"]).requires_grad_(True)
+    y = models.CoTr().cuda()(q, k)
+    assert_close(np64(y), g[f"{tag}.out"], what="CoTr out")
+    dq, dk = torch.autograd.grad(y, [q, k], cu(g[f"{tag}.gy"]))
+    assert_close(np64(dq), g[f"{tag}.dq"], atol=5e-5, what="CoTr dq")
+    assert_close(np64(dk), g[f"{tag}.dk"], atol=5e-5, what="CoTr dk")
+
+
+@pytest.mark.parametrize("heads,hd,shape", [(2, 8, (9, 6, 21)), (1, 64, (5, 9, 18)), (3, 16, (4, 4, 16))])
+def test_attention_generic_head_dim_vs_oracle(ops, orc, heads, hd, shape):
+    """generic path with several heads, a bias and a scale, ragged tiles: out, d_q, d_k, d_rpb vs the fp64 oracle"""
+    gen = torch.Generator().manual_seed(heads * 100 + hd)
+    C = heads * hd
+    q = (0.5 * torch.randn((2,) + shape + (C,), generator=gen)).double().requires_grad_(True)
+    k = (0.5 * torch.randn((2,) + shape + (C,), generator=gen)).double().requires_grad_(True)
+    rpb = (0.5 * torch.randn((heads, 27), generator=gen)).double().requires_grad_(True)
+    scale = hd ** -0.5
+    ref = orc.mode_transformer(q, k, rpb, heads, scale)                 # (B, heads*3, D,H,W)
+    gy = torch.randn(ref.shape, generator=gen).double()
+    rq, rk, rr = torch.autograd.grad(ref, [q, k, rpb], gy)
+    qd, kd = q.detach().float().cuda().requires_grad_(True), k.detach().float().cuda().requires_grad_(True)
+    rd = rpb.detach().float().cuda().reshape(heads, 3, 3, 3).requires_grad_(True)
+    y = ops.neighbourhood_attention(qd, kd, rd, heads, scale)
+    assert_close(ncdhw(y), ref.detach().numpy(), what="generic attention out")
+    dq, dk, dr = torch.autograd.grad(y, [qd, kd, rd], cl(gy.numpy()))
+    assert_close(np64(dq), rq.numpy(), atol=5e-5, what="generic attention dq")
+    assert_close(np64(dk), rk.numpy(), atol=5e-5, what="generic attention dk")
+    assert_close(np64(dr).reshape(heads, 27), rr.numpy(), atol=2e-4, rtol=1e-4, what="generic attention drpb")
+
+
 # ------------------------------------------------------------------------------------------------ projection
 @pytest.mark.parametrize("tag", ["p1", "p3", "p5"])
 def test_projection_golden(ops, tag):
