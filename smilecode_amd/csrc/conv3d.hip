@@ -19,6 +19,14 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NTHR = 256;
+#ifdef MODET_TUNING
+// phase timing of conv3d_mfma_kernel (tools/exp_conv_phases.py): per (workgroup, wave) cycle sums of
+// [barrier1, LDS fill, barrier2, flush, prefetch issue, MFMA loop, epilogue staging, stages]
+__device__ long long* g_conv_dbg = nullptr;
+#define DBG_T(i) if (dbgp) { const long long now_ = clock64(); dsum[i] += now_ - tprev; tprev = now_; }
+#else
+#define DBG_T(i)
+#endif
 constexpr int TX = 16, HX = TX + 2;
 
 __host__ __device__ constexpr int pad16mod32(int n) { return ((n - 16 + 31) / 32) * 32 + 16; }
@@ -109,6 +117,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     const int y0 = (t % tiles_y) * TY; t /= tiles_y;
     const int z0 = (t % tiles_z) * TZ;
     const float* xt = x + (((int64_t)(t / tiles_z) * D + z0) * H + y0) * W * Cin + (int64_t)x0 * Cin + c0;
+    // a tile whose halo lies inside the volume (70 % of them at 160x192x160) and a full channel chunk: plain loads
+    const bool interior = vec4 && z0 > 0 && z0 + TZ < D && y0 > 0 && y0 + TY < H && x0 > 0 && x0 + TX < W && c0 + CK <= Cin;
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < NXV; ++i)
+        xr[i] = xh[i] >= 0 ? *reinterpret_cast<const float4*>(xt + xrel[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -212,6 +227,46 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   // s_waitcnt vmcnt is in-order and counts stores, so with stores issued right before the wait (as a same-iteration
   // epilogue does) every tile would wait for a full store round trip.
   int ptile = -1;
+  // per-lane constants of the flush: item i = lane + 64*it of this wave's WROWS x TX x (Cout/4) float4s decomposes into
+  // (row, voxel, channel group) once per kernel (runtime divisions by Cout/4), not once per tile
+  constexpr int WROWS = R * P;                         // rows owned by this wave
+  constexpr int FL_MAX = (WROWS * TX * (OC / 4) + 63) / 64;
+  int fl_stg[FL_MAX], fl_pos[FL_MAX], fl_rel[FL_MAX];
+  {
+    const int cq = lds_epi_rt ? (Cout >> 2) : 1, per_row = TX * cq;
+#pragma unroll
+    for (int it = 0; it < FL_MAX; ++it) {
+      const int i = lane + 64 * it;
+      const bool on = lds_epi_rt && i < WROWS * per_row;
+      const int rl = on ? i / per_row : 0, f = on ? i - rl * per_row : 0;
+      const int rr = wm * WROWS + rl;
+      const int vx = f / cq, c4 = f - vx * cq;
+      fl_stg[it] = on ? (rr * TX + vx) * OC + c4 * 4 : -1;
+      fl_pos[it] = (rr / TY) | ((rr % TY) << 8) | (vx << 16);
+      fl_rel[it] = (((rr / TY) * H + (rr % TY)) * W + vx) * Cout + c4 * 4;
+    }
+  }
+  // fused InstanceNorm statistics: per-lane sums live in registers across ALL tiles of one batch sample this
+  // workgroup walks (tiles are sample-major, so the sample index only ever increases); the cross-lane reduction and the
+  // store happen once per (workgroup, wave, sample): stats[sample][workgroup][wave][channel][2]
+  float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+  int stat_b = -1;
+  unsigned stat_done = 0;                              // samples this workgroup already wrote (B <= 32)
+  auto emit_stats = [&](int bsamp) {
+    const int cq = Cout >> 2;
+    for (int o = cq; o < 64; o <<= 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sx[j] += __shfl_xor(sx[j], o, 64); sq[j] += __shfl_xor(sq[j], o, 64); }
+    }
+    if (lane < cq) {
+      float* sp = stats + ((((int64_t)bsamp * gridDim.x + blockIdx.x) * WM + wm) * Cout + lane * 4) * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sp[j * 2] = sx[j]; sp[j * 2 + 1] = sq[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sx[j] = 0.f; sq[j] = 0.f; }
+    stat_done |= 1u << bsamp;
+  };
   auto flush_tile = [&]() {
     if (ptile < 0) return;
     int t = ptile;
@@ -219,16 +274,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     const int y0 = (t % tiles_y) * TY; t /= tiles_y;
     const int z0 = (t % tiles_z) * TZ;
     const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
-    const int cq = Cout >> 2, per_row = TX * cq;
-    constexpr int WROWS = R * P;                       // rows owned by this wave
-    float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = lane; i < WROWS * per_row; i += 64) {
-      const int rl = i / per_row, f = i - rl * per_row;
-      const int rr = wm * WROWS + rl;
-      const int vx = f / cq, c4 = f - vx * cq;
-      const int z = z0 + rr / TY, yy = y0 + rr % TY, xx = x0 + vx;
+    const int cq = Cout >> 2;
+    float* ytile = y + (xbase + ((int64_t)z0 * H + y0) * W + x0) * Cout + cb0;
+    if (stats) {
+      const int bs = t / tiles_z;
+      if (bs != stat_b) {
+        if (stat_b >= 0) emit_stats(stat_b);
+        stat_b = bs;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < FL_MAX; ++it) {
+      if (fl_stg[it] < 0) continue;
+      const int z = z0 + (fl_pos[it] & 255), yy = y0 + ((fl_pos[it] >> 8) & 255), xx = x0 + (fl_pos[it] >> 16);
       if (z < D && yy < H && xx < W) {
-        float4 v = *reinterpret_cast<const float4*>(stg + (rr * TX + vx) * OC + c4 * 4);
+        float4 v = *reinterpret_cast<const float4*>(stg + fl_stg[it]);
         v.x += bq4.x; v.y += bq4.y; v.z += bq4.z; v.w += bq4.w;
         if (stats) {       // InstanceNorm statistics of the conv output, fused (act == 0 on this path)
           sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
@@ -236,20 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
           sq[2] = fmaf(v.z, v.z, sq[2]); sq[3] = fmaf(v.w, v.w, sq[3]);
         }
         if (act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
-        *reinterpret_cast<float4*>(y + (xbase + ((int64_t)z * H + yy) * W + xx) * Cout + cb0 + c4 * 4) = v;
-      }
-    }
-    if (stats) {
-      // lanes with equal (lane % cq) hold the same channel group: xor-tree over the other lane bits, then lanes
-      // 0..cq-1 write this (tile, wave)'s partial sums: stats[tile][wave][channel][2]
-      for (int o = cq; o < 64; o <<= 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sx[j] += __shfl_xor(sx[j], o, 64); sq[j] += __shfl_xor(sq[j], o, 64); }
-      }
-      if (lane < cq) {
-        float* sp = stats + (((int64_t)ptile * WM + wm) * Cout + lane * 4) * 2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sp[j * 2] = sx[j]; sp[j * 2 + 1] = sq[j]; }
+        *reinterpret_cast<float4*>(ytile + fl_rel[it]) = v;
       }
     }
     ptile = -1;
@@ -257,16 +304,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
 
   int c0 = 0;
   bool first = true;
+#ifdef MODET_TUNING
+  long long* dbgp = g_conv_dbg;
+  long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+#endif
   load_stage(tile, 0, true);
   while (true) {
+    DBG_T(7)
     __syncthreads();                               // every wave is done reading the previous stage from LDS
+    DBG_T(0)
     store_stage(multi || first);
+    DBG_T(1)
     __syncthreads();
+    DBG_T(2)
     int ntile = tile, nc0 = c0 + CK;
     bool has_next = true;
     if (nc0 >= CinP) { nc0 = 0; ntile = tile + gridDim.x; has_next = ntile < ntiles; }
     if (STG) flush_tile();                         // previous tile's stores go out before this prefetch
+    DBG_T(3)
     if (has_next) load_stage(ntile, nc0, multi);   // in flight during the MFMA loop below
+    DBG_T(4)
     first = false;
 
     __builtin_amdgcn_s_setprio(1);
@@ -296,6 +354,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
       }
     }
     __builtin_amdgcn_s_setprio(0);
+    DBG_T(5)
 
     if (c0 + CK >= CinP) {
       int t = tile;
@@ -342,6 +401,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
         }
       }
     }
+    DBG_T(6)
     if (!has_next) break;
     tile = ntile;
     c0 = nc0;
@@ -349,7 +409,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   if (STG) {
     __syncthreads();
     flush_tile();
+    if (stats) {
+      if (stat_b >= 0) emit_stats(stat_b);
+      const int nb = ntiles / (tiles_x * tiles_y * tiles_z);
+      for (int bsamp = 0; bsamp < nb; ++bsamp)           // samples this workgroup never touched: zero rows
+        if (!((stat_done >> bsamp) & 1u)) emit_stats(bsamp);
+    }
   }
+#ifdef MODET_TUNING
+  if (dbgp && lane == 0) {
+    long long* o = dbgp + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NTHR / 64) + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = dsum[i];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -874,13 +946,15 @@ inline size_t fwd_ws_elems(int Cin, int Cout) {
   return plain > packed ? plain : packed;
 }
 
+// query_gx != null: only report the persistent grid's x size (the statistics layout depends on it), launch nothing
 int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
-                int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr) {
+                int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr, int* query_gx = nullptr) {
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 9 * (p.P + 2) * CinP * CoutP;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
-                     wpk, Cin, Cout, CinP, CoutP, pack_mode, p.P);
+  if (!query_gx)
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
+                       wpk, Cin, Cout, CinP, CoutP, pack_mode, p.P);
   const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
   const int ntiles = tiles_x * tiles_y * tiles_z * B;
   const int gy = CoutP / p.ncb;
@@ -891,6 +965,7 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
     const int per_cu = resident_blocks((const void*)conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__>, nthr);   \
     int gx = (256 * per_cu + gy - 1) / gy;                                                                        \
     if (gx > ntiles) gx = ntiles;                                                                                 \
+    if (query_gx) { *query_gx = gx; break; }                                                                      \
     hipLaunchKernelGGL((conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__>), dim3(gx, gy), dim3(nthr), 0, s, x,   \
                        (const float*)wpk, bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z, \
                        ntiles, stats);                                                                                   \
@@ -922,7 +997,13 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
 #undef CONV_CASE_P
 #undef CONV_VM
 #undef CONV_LAUNCH
-  return modet_launch_status();
+  return query_gx ? MODET_OK : modet_launch_status();
+}
+
+inline int conv_grid_x(int B, int D, int H, int W, int Cin, int Cout) {
+  int gx = 0;
+  conv_launch(nullptr, nullptr, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, nullptr, nullptr, &gx);
+  return gx;
 }
 
 struct WgPlan { int cit, n_ci, n_co, gx, gy, ng, ntiles, tiles_x, tiles_y, tiles_z, tz; bool np; };
@@ -958,6 +1039,12 @@ inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
 
 extern "C" {
 
+#ifdef MODET_TUNING
+int modet_debug_conv_timing(long long* buf) {       // not in the header: tuning builds only
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_dbg), &buf, sizeof(buf));
+}
+#endif
+
 size_t modet_conv3d_ws_bytes(int Cin, int Cout) {
   const int m = Cin > Cout ? Cin : Cout;       // bwd_data swaps the roles
   return fwd_ws_elems(m, m) * sizeof(float);
@@ -983,11 +1070,11 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
 static bool conv_stats_ok(int Cin, int Cout) { return Cin != 1 && (Cout == 4 || Cout == 8 || Cout == 16); }
 
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
-  if (!conv_stats_ok(Cin, Cout)) return 0;
+  if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
-  const int64_t ntiles = (int64_t)cdiv(W, TX) * cdiv(H, p.ty) * cdiv(D, p.tz) * B;
-  // [tile][wave][Cout][2] partials + the scratch tail modet_instnorm_lrelu_fwd_stats reduces them in
-  return (size_t)ntiles * p.wm() * Cout * 2 * sizeof(float) + modet_instnorm_stats_scratch_bytes(B, Cout);
+  const int gx = conv_grid_x(B, D, H, W, Cin, Cout);
+  // [sample][workgroup][wave][Cout][2] partials + the scratch tail modet_instnorm_lrelu_fwd_stats reduces them in
+  return (size_t)B * gx * p.wm() * Cout * 2 * sizeof(float) + modet_instnorm_stats_scratch_bytes(B, Cout);
 }
 
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
