@@ -137,6 +137,38 @@ def test_forward_vs_oracle_64_batch2():
     _note("fwd[64^3,B=2].y_moved_maxerr", ey)
 
 
+@pytest.mark.parametrize("shape,batch", [((16, 32, 16), 1), ((32, 32, 48), 3), ((16, 48, 80), 2)])
+def test_forward_and_grads_vs_oracle_edge_shapes(shape, batch):
+    """smallest volume the reference's pure path accepts (16x32x16: level 5 is 1x2x1, smaller than the 3^3 window, every
+    neighbour of most voxels is zero padding), an odd batch, and a strongly anisotropic volume: forward and the full
+    gradient dict of one loss against the fp64 oracle."""
+    from oracle import modet_torch as orc
+    from smilecode_amd import losses, synth
+    w = synth.make_weights(24)
+    mov_np, fix_np = synth.make_pair(shape, 31, batch)
+    p64 = {n: torch.from_numpy(v).double().requires_grad_(True) for n, v in w.items()}
+    heads = (8, 4, 2, 1, 1)
+    loss64, _, _, y64, f64 = orc.train_loss(p64, torch.from_numpy(mov_np).double(), torch.from_numpy(fix_np).double(), heads, 6, 1.0)
+    g64 = torch.autograd.grad(loss64, list(p64.values()))
+    y64, f64 = y64.detach(), f64.detach()
+    model = _model(shape, 1.0)
+    mov, fix = torch.from_numpy(mov_np).cuda(), torch.from_numpy(fix_np).cuda()
+    y, flow = model(mov, fix)
+    tag = "x".join(map(str, shape)) + f"_B{batch}"
+    _note(f"edge_{tag}_flow_maxerr", assert_close(np64(flow), f64.numpy(), atol=2e-3, rtol=0, what="flow (voxels)"))
+    assert_close(np64(y), y64.numpy(), atol=5e-4, rtol=0, what="y_moved")
+    loss = losses.NCC_vxm()(fix, y) + losses.Grad3d(penalty="l2")(flow, fix)
+    assert abs(float(loss.detach()) - float(loss64.detach())) < 2e-6
+    loss.backward()
+    worst = 0.0
+    for (n, prm), gref in zip(model.named_parameters(), g64):
+        g = prm.grad.double().cpu()
+        scale = max(float(gref.abs().max()), 1e-7)
+        worst = max(worst, float((g - gref).abs().max()) / scale if float(gref.abs().max()) > 1e-6 else 0.0)
+    _note(f"edge_{tag}_grad_relerr", worst)
+    assert worst < 2e-2, worst
+
+
 def test_full_size_properties():
     """BASELINE size 160x192x160: size-independent properties of the forward."""
     shape = (160, 192, 160)
