@@ -628,7 +628,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // CIT = 8: M rows = (t in {0,1}) x 8 ci, group g = (dz,dy).   CIT = 4: M rows = (pair pp in {0,1}, t in {0,1}) x 4 ci,
 // group g = two consecutive (dz,dy) combos.
 constexpr int NP_DX = TX + 1;                          // d_y tile keeps one extra voxel column per row
-template <int CIT, int WG_TZ>
+// ROWLD (Cin == Cout == 8): the prefetch is issued as whole halo rows -- a wave owns rows w, w+4, ..., lane l loads the
+// l-th float4 of the row -- so a load's address is a wave-uniform row base (scalar unit) plus a per-lane constant and its
+// bounds test one uniform row test and one per-tile lane mask: almost no VALU, where the per-element form spent 35-44 %
+// of a wave's cycles (tools/exp_conv_phases.py) issuing the next tile behind the other waves' MFMAs.
+template <int CIT, int WG_TZ, bool ROWLD>
 __global__ __launch_bounds__(NTHR) void conv3d_wgrad_np_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ part, int D, int H, int W, int Cin,
                                                                int Cout, int tiles_x, int tiles_y, int tiles_z,
@@ -720,34 +724,97 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_np_kernel(const float* __re
     }
   };
 
+  // ---- row-wise prefetch (ROWLD)
+  constexpr int XROWS = (WG_TZ + 2) * WG_HY, XRW = XROWS / 4;          // halo rows of x, rows per wave (60 / 4)
+  constexpr int XQ = HX * 2, DQ = NP_DX * 2;                            // float4 per x row (36) / d_y row (34)
+  constexpr int DRW = WG_ROWS / 4;                                      // d_y rows per wave
+  static_assert(!ROWLD || (CIT == 8 && XROWS % 4 == 0 && WG_ROWS % 4 == 0), "row prefetch shape");
+  float4 xq[ROWLD ? XRW : 1], dq[ROWLD ? DRW : 1];
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto load_rows = [&](int tl) {
+    int t = tl;
+    const int x0 = (t % tiles_x) * TX; t /= tiles_x;
+    const int y0 = (t % tiles_y) * WG_TY; t /= tiles_y;
+    const int z0 = (t % tiles_z) * WG_TZ;
+    const int bz = (t / tiles_z) * D;
+    const int xx = x0 - 1 + (lane >> 1);
+    const bool xl_ok = lane < XQ && xx >= 0 && xx < W;
+    const bool dl_ok = lane < DQ && x0 + (lane >> 1) < W;
+#pragma unroll
+    for (int i = 0; i < XRW; ++i) {
+      const int r = wv + 4 * i, hz = r / WG_HY, hy = r - hz * WG_HY;
+      const int z = z0 + hz - 1, yy = y0 + hy - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z >= 0 && z < D && yy >= 0 && yy < H) {                        // wave-uniform
+        const float* rp = x + (((int64_t)(bz + z) * H + yy) * W + (x0 - 1)) * 8;
+        if (xl_ok) v = *reinterpret_cast<const float4*>(rp + lane * 4);
+      }
+      xq[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < DRW; ++i) {
+      const int r = wv + 4 * i, rz = r / WG_TY, ry = r - rz * WG_TY;
+      const int z = z0 + rz, yy = y0 + ry;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z < D && yy < H) {
+        const float* rp = dy + (((int64_t)(bz + z) * H + yy) * W + x0) * 8;
+        if (dl_ok) v = *reinterpret_cast<const float4*>(rp + lane * 4);
+      }
+      dq[i] = v;
+    }
+  };
+  auto store_rows = [&]() {
+#pragma unroll
+    for (int i = 0; i < XRW; ++i)
+      if (lane < XQ) *reinterpret_cast<float4*>(xs + (wv + 4 * i) * (HX * 8) + lane * 4) = xq[i];
+#pragma unroll
+    for (int i = 0; i < DRW; ++i)
+      if (lane < DQ) *reinterpret_cast<float4*>(dys + (wv + 4 * i) * (NP_DX * 8) + lane * 4) = dq[i];
+  };
+
   int tile = blockIdx.x;
-  if (tile < ntiles) load_tile(tile);
+  if (tile < ntiles) { if (ROWLD) load_rows(tile); else load_tile(tile); }
   for (; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+    if (ROWLD) {
+      store_rows();
+    } else {
 #pragma unroll
-    for (int i = 0; i < NXV; ++i) {
-      const int idx = tid + i * NTHR;
-      if (idx < WG_HVOX * QX) *reinterpret_cast<float4*>(xs + idx * 4) = xr[i];
-    }
+      for (int i = 0; i < NXV; ++i) {
+        const int idx = tid + i * NTHR;
+        if (idx < WG_HVOX * QX) *reinterpret_cast<float4*>(xs + idx * 4) = xr[i];
+      }
 #pragma unroll
-    for (int i = 0; i < NDV; ++i) {
-      const int idx = tid + i * NTHR;
-      if (idx < WG_ROWS * NP_DX * 2) *reinterpret_cast<float4*>(dys + idx * 4) = dr[i];
+      for (int i = 0; i < NDV; ++i) {
+        const int idx = tid + i * NTHR;
+        if (idx < WG_ROWS * NP_DX * 2) *reinterpret_cast<float4*>(dys + idx * 4) = dr[i];
+      }
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    if (tile + (int)gridDim.x < ntiles) { if (ROWLD) load_rows(tile + gridDim.x); else load_tile(tile + gridDim.x); }
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll 4
-    for (int row = 0; row < WG_ROWS; ++row) {
-      const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
+    {
+      // explicit two-deep software pipeline over the (row, s) steps: the fragments of step i+1 are read from LDS
+      // before the MFMAs of step i issue (-8 % on the 8->8 layer; the same rewrite made the generic kernel slower,
+      // hipcc's own schedule of its fully unrolled rows is better there)
+      constexpr int NSTEP = WG_ROWS * 4;
+      float af[2][GPW], bfv[2];
+      auto frag = [&](int st, float (&a)[GPW], float& b) {
+        const int row = st >> 2, sq = st & 3;
+        const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
+        b = dys[(row * NP_DX + sq * 4 + lk + bq) * 8 + bco];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float bf = dys[(row * NP_DX + s * 4 + lk + bq) * 8 + bco];
+        for (int g = 0; g < GPW; ++g) a[g] = xs[rb + sq * 4 * CIT + aoff[g]];
+      };
+      frag(0, af[0], bfv[0]);
+#pragma unroll 32
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) frag(st + 1, af[(st + 1) & 1], bfv[(st + 1) & 1]);
 #pragma unroll
         for (int g = 0; g < GPW; ++g) {
-          float a = xs[rb + s * 4 * CIT + aoff[g]];
+          float a = af[st & 1][g];
           if (g == BIAS_G) a = bsel ? 1.f : a;
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfv[st & 1], acc[g], 0, 0, 0);
         }
       }
     }
@@ -1010,7 +1077,7 @@ struct WgPlan { int cit, n_ci, n_co, gx, gy, ng, ntiles, tiles_x, tiles_y, tiles
 // persistent grid = the resident workgroups (all tiles in ONE round, and as few partial d_w copies as possible)
 inline int wgrad_resident(int cit, int tz, bool np) {
   const void* fn;
-  if (np) fn = tz == 4 ? (const void*)conv3d_wgrad_np_kernel<8, 4> : (const void*)conv3d_wgrad_np_kernel<8, 2>;
+  if (np) fn = tz == 4 ? (const void*)conv3d_wgrad_np_kernel<8, 4, false> : (const void*)conv3d_wgrad_np_kernel<8, 2, false>;
   else if (cit == 4) fn = tz == 4 ? (const void*)conv3d_wgrad_kernel<4, 4> : (const void*)conv3d_wgrad_kernel<4, 2>;
   else if (cit == 8) fn = tz == 4 ? (const void*)conv3d_wgrad_kernel<8, 4> : (const void*)conv3d_wgrad_kernel<8, 2>;
   else fn = (const void*)conv3d_wgrad_kernel<16, 2>;
@@ -1140,12 +1207,12 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
   float* part = (float*)ws;
   if (p.np) {
-    if (p.tz == 4)
-      hipLaunchKernelGGL((conv3d_wgrad_np_kernel<8, 4>), dim3(p.gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout,
-                         p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles);
-    else
-      hipLaunchKernelGGL((conv3d_wgrad_np_kernel<8, 2>), dim3(p.gx), dim3(NTHR), 0, s, x, d_y, part, D, H, W, Cin, Cout,
-                         p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles);
+    const bool rowld = Cin == 8 && Cout == 8;
+#define NP_LAUNCH(TZ_, R_) hipLaunchKernelGGL((conv3d_wgrad_np_kernel<8, TZ_, R_>), dim3(p.gx), dim3(NTHR), 0, s, x, d_y, part, D, \
+                                               H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles)
+    if (p.tz == 4) { if (rowld) NP_LAUNCH(4, true); else NP_LAUNCH(4, false); }
+    else { if (rowld) NP_LAUNCH(2, true); else NP_LAUNCH(2, false); }
+#undef NP_LAUNCH
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(p.ng * 4), dim3(256), 0, s, (const float*)part, d_w, d_bias, Cin, Cout,
                        p.gx, 1, 1, p.cit, p.ng);
     return modet_launch_status();
