@@ -534,7 +534,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll(CIT == 16 ? 16 : 4)
+#pragma unroll 16
     for (int row = 0; row < WG_ROWS; ++row) {
       const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX * CIT;
 #pragma unroll
