@@ -874,80 +874,105 @@ __global__ __launch_bounds__(NTHR) void conv_c1_fwd_kernel(const float* __restri
   }
 }
 
-// d_w[co][tap] = sum_v x[v+off(tap)] * dy[v][co], d_b[co] = sum_v dy[v][co]: 27*CO+CO register accumulators per
-// thread over a grid-stride loop, workgroup reduction, partials -> fixed-order fp64 sum.
-template <int CO>
-__global__ __launch_bounds__(NTHR) void conv_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             const float* __restrict__ yact, float* __restrict__ part,
-                                                             int D, int H, int W, int64_t total) {
-  constexpr int NA = 27 * CO + CO;
-  __shared__ float red[(NTHR / 64) * NA];
-  float acc[NA];
+constexpr int C1_MFMA_BLOCKS = 1024;
+
+// Weight gradient of the first conv (Cin = 1, Cout = 4) on the matrix pipe: M = 16 taps per MFMA (two groups cover the
+// 27 taps + the bias slot), N = cout (columns 4..15 repeat 0..3 and are never read), K = 4 voxels.  (A VALU version
+// with 112 accumulators per thread -- 192 VGPRs, 2 waves/SIMD -- ran at 0.26-0.29 ms for 196 MB of traffic; this: 0.17.)
+// Tile 4x8x16 voxels; wave w owns tile rows 8w..8w+7 with both tap groups; per-wave partial tiles go through
+// wgrad_reduce_kernel<0> (cit = 1).  yact != null folds LeakyReLU' into the d_y staging (ConvBlock backward).
+constexpr int C1_TZ = 4, C1_ROWS = C1_TZ * WG_TY, C1_HVOX = (C1_TZ + 2) * WG_HY * HX;
+__global__ __launch_bounds__(NTHR) void conv_c1_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  const float* __restrict__ yact, float* __restrict__ part,
+                                                                  int D, int H, int W, int tiles_x, int tiles_y,
+                                                                  int tiles_z, int ntiles) {
+  __shared__ float xs[C1_HVOX + 64];
+  __shared__ __attribute__((aligned(16))) float dys[C1_ROWS * TX * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  int aoff[2];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) acc[i] = 0.f;
-  const int64_t V = (int64_t)D * H * W;
-  for (int64_t idx = (int64_t)blockIdx.x * NTHR + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NTHR) {
-    const int64_t b = idx / V, v = idx - b * V;
-    const int xi = (int)(v % W);
-    const int64_t t2 = v / W;
-    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
-    float g[CO];
+  for (int g = 0; g < 2; ++g) {
+    const int tap = g * 16 + li, tt = tap < 27 ? tap : 0;
+    aoff[g] = ((tt / 9) * WG_HY + (tt / 3) % 3) * HX + tt % 3 + lk;
+  }
+  const bool bsel = li == 11;                          // group 1, row 11 = tap 27: the bias slot (A = 1)
+  for (int i = tid; i < 64; i += NTHR) xs[C1_HVOX + i] = 0.f;
+  // register prefetch of the next tile (x: C1_HVOX scalars, d_y: one float4 per voxel) under the MFMA loop
+  constexpr int NXS = (C1_HVOX + NTHR - 1) / NTHR, NDS = C1_ROWS * TX / NTHR;
+  float xr[NXS];
+  float4 dr[NDS];
+  auto load_tile = [&](int tl) {
+    int t = tl;
+    const int x0 = (t % tiles_x) * TX; t /= tiles_x;
+    const int y0 = (t % tiles_y) * WG_TY; t /= tiles_y;
+    const int z0 = (t % tiles_z) * C1_TZ;
+    const int64_t vb = (int64_t)(t / tiles_z) * D * H * W;
 #pragma unroll
-    for (int c = 0; c < CO; c += 4) {
-      float4 gv = *reinterpret_cast<const float4*>(dy + idx * CO + c);
-      if (yact) {      // ConvBlock: d_y is the gradient of LeakyReLU(conv); fold the activation's derivative in here
-        const float4 yv = *reinterpret_cast<const float4*>(yact + idx * CO + c);
-        gv.x *= yv.x > 0.f ? 1.f : LRELU_SLOPE; gv.y *= yv.y > 0.f ? 1.f : LRELU_SLOPE;
-        gv.z *= yv.z > 0.f ? 1.f : LRELU_SLOPE; gv.w *= yv.w > 0.f ? 1.f : LRELU_SLOPE;
-      }
-      g[c] = gv.x; g[c + 1] = gv.y; g[c + 2] = gv.z; g[c + 3] = gv.w;
+    for (int k = 0; k < NXS; ++k) {
+      const int i = tid + k * NTHR;
+      const int hx = i % HX, r = i / HX;
+      const int z = z0 + r / WG_HY - 1, yy = y0 + r % WG_HY - 1, xx = x0 + hx - 1;
+      xr[k] = (i < C1_HVOX && z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                  ? x[vb + ((int64_t)z * H + yy) * W + xx] : 0.f;
     }
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[27 * CO + c] += g[c];
-#pragma unroll
-    for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-      for (int dyy = 0; dyy < 3; ++dyy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int zz = zi + dz - 1, yy = yi + dyy - 1, xx = xi + dx - 1;
-          float xv = 0.f;
-          if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
-            xv = x[b * V + ((int64_t)zz * H + yy) * W + xx];
-          const int tap = (dz * 3 + dyy) * 3 + dx;
-#pragma unroll
-          for (int c = 0; c < CO; ++c) acc[tap * CO + c] = fmaf(xv, g[c], acc[tap * CO + c]);
+    for (int k = 0; k < NDS; ++k) {
+      const int i = tid + k * NTHR;
+      const int vx = i % TX, row = i / TX;
+      const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY, xx = x0 + vx;
+      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z < D && yy < H && xx < W) {
+        const int64_t o = (vb + ((int64_t)z * H + yy) * W + xx) * 4;
+        gv = *reinterpret_cast<const float4*>(dy + o);
+        if (yact) {
+          const float4 yv = *reinterpret_cast<const float4*>(yact + o);
+          gv.x *= yv.x > 0.f ? 1.f : LRELU_SLOPE; gv.y *= yv.y > 0.f ? 1.f : LRELU_SLOPE;
+          gv.z *= yv.z > 0.f ? 1.f : LRELU_SLOPE; gv.w *= yv.w > 0.f ? 1.f : LRELU_SLOPE;
         }
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      }
+      dr[k] = gv;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const float r = wave_sum(acc[i]);
-    if (lane == 0) red[wv * NA + i] = r;
+    for (int k = 0; k < NXS; ++k) {
+      const int i = tid + k * NTHR;
+      if (i < C1_HVOX) xs[i] = xr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NDS; ++k) *reinterpret_cast<float4*>(dys + (tid + k * NTHR) * 4) = dr[k];
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int rr = 0; rr < C1_ROWS / 4; ++rr) {
+      const int row = wave * (C1_ROWS / 4) + rr;
+      const int rb = ((row / WG_TY) * WG_HY + (row % WG_TY)) * HX;
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) {
+        const float bf = dys[(row * TX + sq * 4 + lk) * 4 + (li & 3)];
+        const float a0 = xs[rb + sq * 4 + aoff[0]];
+        float a1 = xs[rb + sq * 4 + aoff[1]];
+        a1 = bsel ? 1.f : a1;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < NA; i += NTHR) {
-    float r = 0.f;
-    for (int w2 = 0; w2 < NTHR / 64; ++w2) r += red[w2 * NA + i];
-    part[(int64_t)blockIdx.x * NA + i] = r;
+  // part[(blk*4 + wave)*2 + grp][tap row][col]
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    float* pp = part + (((int64_t)blockIdx.x * 4 + wave) * 2 + g) * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pp[(lk * 4 + j) * 16 + li] = acc[g][j];
   }
 }
-
-// one wave per output: i < 27*CO -> d_w[co][tap] (i = co*27 + tap), else d_b[i - 27*CO]
-__global__ __launch_bounds__(64) void conv_c1_wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                    float* __restrict__ db, int nblk, int CO) {
-  const int i = blockIdx.x, NA = 27 * CO + CO;
-  const int src = i < 27 * CO ? (i % 27) * CO + i / 27 : i;
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[(int64_t)b * NA + src];
-  s = wave_sum_d(s);
-  if (threadIdx.x == 0) {
-    if (i < 27 * CO) dw[i] = (float)s;
-    else if (db) db[i - 27 * CO] = (float)s;
-  }
-}
-
-constexpr int C1_WG_BLOCKS = 512;
 
 // ------------------------------------------------------------------------------------------------ host side
 struct FwdPlan {
@@ -1169,7 +1194,7 @@ size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int
   // sized for the largest persistent grid (1024 workgroups) so the value does not depend on the occupancy query
   const int gx = p.gy >= 1024 ? 1 : 1024 / p.gy;
   const size_t fl = (size_t)gx * p.gy * p.ng * 256;
-  const size_t c1 = (size_t)C1_WG_BLOCKS * (27 * Cout + Cout);
+  const size_t c1 = (size_t)C1_MFMA_BLOCKS * 4 * 2 * 256;       // per-wave partial tiles of conv_c1_wgrad_mfma_kernel
   return (fl > c1 ? fl : c1) * sizeof(float);
 }
 
@@ -1197,11 +1222,13 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
   if (ws_bytes < modet_conv3d_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   if (Cin == 1 && Cout == 4) {
-    const int64_t total = (int64_t)B * D * H * W;
-    int nblk = (int)cdiv64(total, NTHR);
-    if (nblk > C1_WG_BLOCKS) nblk = C1_WG_BLOCKS;
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel<4>, dim3(nblk), dim3(NTHR), 0, s, x, d_y, y_act, (float*)ws, D, H, W, total);
-    hipLaunchKernelGGL(conv_c1_wgrad_finalize_kernel, dim3(27 * 4 + 4), dim3(64), 0, s, (const float*)ws, d_w, d_bias, nblk, 4);
+    const int tx = cdiv(W, TX), ty = cdiv(H, WG_TY), tz = cdiv(D, C1_TZ);
+    const int ntiles = B * tx * ty * tz;
+    const int nblk = ntiles < C1_MFMA_BLOCKS ? ntiles : C1_MFMA_BLOCKS;
+    hipLaunchKernelGGL(conv_c1_wgrad_mfma_kernel, dim3(nblk), dim3(NTHR), 0, s, x, d_y, y_act, (float*)ws, D, H, W, tx, ty, tz,
+                       ntiles);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(2 * 4), dim3(256), 0, s, (const float*)ws, d_w, d_bias, 1, 4, nblk * 4, 1,
+                       1, 1, 2);
     return modet_launch_status();
   }
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
