@@ -133,16 +133,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warmup (untimed); the last warmup step is profiled per op to find the dominant kernel group
-    for _ in range(max(args.warmup - 1, 0)):
+    # warmup (untimed); the last (up to three) warmup steps are profiled per op to find the dominant kernel group.  The
+    # per-family time is the MEDIAN over those steps: a single profiled step can contain a one-off stall (a 10 ms
+    # hiccup inside a 35 us kernel was observed once) that would crown the wrong family.
+    nprof = max(1, min(3, args.warmup))       # --warmup 0 still gets one untimed profiled step
+    for _ in range(max(args.warmup - nprof, 0)):
         step()
     torch.cuda.synchronize()
-    tm = ops.KernelTimer()
-    ops.set_kernel_timer(tm)
-    step()
-    torch.cuda.synchronize()
-    ops.set_kernel_timer(None)
-    breakdown = tm.summary()
+    summaries = []
+    for _ in range(nprof):
+        tm = ops.KernelTimer()
+        ops.set_kernel_timer(tm)
+        step()
+        torch.cuda.synchronize()
+        ops.set_kernel_timer(None)
+        summaries.append(tm.summary())
+    breakdown = {}
+    for k in (summaries[0] if summaries else {}):
+        runs = sorted((sm[k] for sm in summaries if k in sm), key=lambda v: v["ms"])
+        breakdown[k] = dict(runs[len(runs) // 2])            # the median run of this tag
     fams = {}
     for k, v in breakdown.items():
         d = fams.setdefault(family(k), {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "tags": set()})
@@ -152,7 +161,7 @@ def main():
     dominant = max(fams, key=lambda k: fams[k]["ms"]) if fams else None
     if rank == 0:
         tot = sum(v["ms"] for v in breakdown.values())
-        log(f"[bench] per-op breakdown of one {args.workload} step (HIP events, sum {tot:.3f} ms):")
+        log(f"[bench] per-op breakdown of one {args.workload} step (HIP events, median of {nprof} profiled steps, sum {tot:.3f} ms):")
         for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]):
             log(f"   {k:26s} calls {v['calls']:3d}  {v['ms']:8.3f} ms  {v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:9.2f} TFLOP/s"
                 f"  {v['bytes'] / v['ms'] / 1e6 if v['ms'] else 0:9.1f} GB/s(alg)")
