@@ -1,8 +1,8 @@
 // NCC_vxm(win=9) and Grad3d('l2') forward + gradient (reference ModeT/losses.py:34-94, :6-31).
 //
 // The reference evaluates five dense 9x9x9 all-ones conv3d (729 taps each, ~36 GFLOP at 160x192x160); the box
-// filter is separable, so here each is three 9-tap passes (W, H, D) over channels-last-free (B,D,H,W) volumes:
-// HBM-bound streams.  The backward uses that the zero-padded box sum S is self-adjoint:
+// filter is separable, so here each is a fused W+H pass over LDS tiles and a D pass with register windows over
+// (B,D,H,W) volumes: HBM-bound streams.  The backward uses that the zero-padded box sum S is self-adjoint:
 //   d(-mean cc)/dJ = g * ( S(cB) + 2 J S(cD) + I S(cE) ),  g = -1/N,
 //   cE = d cc/d IJ_sum, cD = d cc/d J2_sum, cB = d cc/d J_sum  (pointwise in the five sums).
 // Scalar losses are reduced in two deterministic stages (workgroup partials -> fixed-order fp64 sum).
@@ -23,43 +23,71 @@ __device__ __forceinline__ void decode(int64_t i, const Dims d, int& z, int& y, 
   z = (int)((t / d.H) % d.D);
 }
 
-// pass along W fused with the five products: T[k][p] = sum_{|dx|<=4} {I, J, I*I, J*J, I*J}[p+dx]
-__global__ __launch_bounds__(BLK) void ncc_pass_w_kernel(const float* __restrict__ I, const float* __restrict__ J,
-                                                         float* __restrict__ T, Dims d, int64_t N) {
-  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
-    const int x = (int)(i % d.W);
-    float a = 0.f, b = 0.f, c = 0.f, e = 0.f, f = 0.f;
+// W and H box passes in one kernel over 32x32 tiles of a z-slice staged in LDS (+4 halo each side, zeros outside the
+// volume): rows are box-summed along W into a second LDS array, then columns along H.  PROD: the inputs are I and J and
+// the five box-summed quantities {I, J, I*I, J*J, I*J} are formed on the fly (forward); otherwise NARR stacked volumes
+// are filtered as they are (the three coefficient volumes of the backward).  Replaces two full HBM passes
+// (a W pass and an H pass) by one.
+constexpr int HW_T = 32, HW_H = HW_T + 2 * PAD, HW_LD = HW_H + 1;
+template <int NARR, bool PROD>
+__global__ __launch_bounds__(BLK) void box_hw_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                     float* __restrict__ out, Dims d, int64_t N, int tiles_w) {
+  constexpr int NIN = PROD ? 2 : NARR;
+  __shared__ float raw[NIN][HW_H * HW_LD];
+  __shared__ float tmp[NARR][HW_H * HW_T];
+  const int x0 = (blockIdx.x % tiles_w) * HW_T, y0 = (blockIdx.x / tiles_w) * HW_T;
+  const int z = blockIdx.y, b = blockIdx.z;
+  const int64_t slice = ((int64_t)b * d.D + z) * d.H * d.W;
+  for (int i = threadIdx.x; i < HW_H * HW_H; i += BLK) {
+    const int r = i / HW_H, c = i - r * HW_H;
+    const int y = y0 + r - PAD, x = x0 + c - PAD;
+    const bool ok = y >= 0 && y < d.H && x >= 0 && x < d.W;
+    const int64_t o = slice + (int64_t)y * d.W + x;
+    if (PROD) {
+      raw[0][r * HW_LD + c] = ok ? in0[o] : 0.f;
+      raw[1][r * HW_LD + c] = ok ? in1[o] : 0.f;
+    } else {
 #pragma unroll
-    for (int k = -PAD; k <= PAD; ++k) {
-      const int xx = x + k;
-      if (xx >= 0 && xx < d.W) {
-        const float iv = I[i + k], jv = J[i + k];
-        a += iv; b += jv; c = fmaf(iv, iv, c); e = fmaf(jv, jv, e); f = fmaf(iv, jv, f);
+      for (int v = 0; v < NARR; ++v) raw[v][r * HW_LD + c] = ok ? in0[(int64_t)v * N + o] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW_H * HW_T; i += BLK) {          // W pass: (halo row r, output column c)
+    const int r = i / HW_T, c = i - r * HW_T;
+    if (PROD) {
+      float a = 0.f, bb = 0.f, cc = 0.f, e = 0.f, f = 0.f;
+#pragma unroll
+      for (int k = 0; k < WIN; ++k) {
+        const float iv = raw[0][r * HW_LD + c + k], jv = raw[1][r * HW_LD + c + k];
+        a += iv; bb += jv; cc = fmaf(iv, iv, cc); e = fmaf(jv, jv, e); f = fmaf(iv, jv, f);
+      }
+      tmp[0][i] = a; tmp[1][i] = bb; tmp[2][i] = cc; tmp[3][i] = e; tmp[4][i] = f;
+    } else {
+#pragma unroll
+      for (int v = 0; v < NARR; ++v) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) a += raw[v][r * HW_LD + c + k];
+        tmp[v][i] = a;
       }
     }
-    T[i] = a; T[N + i] = b; T[2 * N + i] = c; T[3 * N + i] = e; T[4 * N + i] = f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW_T * HW_T; i += BLK) {          // H pass + store
+    const int r = i / HW_T, c = i - r * HW_T;
+    const int y = y0 + r, x = x0 + c;
+    if (y >= d.H || x >= d.W) continue;
+    const int64_t o = slice + (int64_t)y * d.W + x;
+#pragma unroll
+    for (int v = 0; v < NARR; ++v) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < WIN; ++k) a += tmp[v][(r + k) * HW_T + c];
+      out[(int64_t)v * N + o] = a;
+    }
   }
 }
 
-// generic 9-tap pass along axis (0 = D, 1 = H, 2 = W) over `nvol` stacked volumes
-__global__ __launch_bounds__(BLK) void box_pass_kernel(const float* __restrict__ in, float* __restrict__ out, Dims d,
-                                                       int64_t N, int nvol, int axis) {
-  const int64_t stride = axis == 0 ? (int64_t)d.H * d.W : (axis == 1 ? d.W : 1);
-  const int len = axis == 0 ? d.D : (axis == 1 ? d.H : d.W);
-  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
-    int z, y, x;
-    decode(i, d, z, y, x);
-    const int pos = axis == 0 ? z : (axis == 1 ? y : x);
-    for (int v = 0; v < nvol; ++v) {
-      const float* p = in + (int64_t)v * N + i;
-      float s = 0.f;
-#pragma unroll
-      for (int k = -PAD; k <= PAD; ++k)
-        if (pos + k >= 0 && pos + k < len) s += p[(int64_t)k * stride];
-      out[(int64_t)v * N + i] = s;
-    }
-  }
-}
 
 // 9-tap pass along D (axis 0) or H (axis 1) over `nvol` stacked volumes: each thread produces SEG consecutive
 // outputs along the axis from a (SEG+8)-value register window (lanes run along W, so every load is coalesced):
@@ -97,25 +125,6 @@ __device__ __forceinline__ float win_sum(const float (&win)[SEG + 2 * PAD], int 
   return s;
 }
 
-template <int AXIS>
-__global__ __launch_bounds__(BLK) void box_seg_kernel(const float* __restrict__ in, float* __restrict__ out, Dims d,
-                                                      int64_t N, int nvol, int64_t nthreads) {
-  const int len = AXIS == 0 ? d.D : d.H;
-  const int64_t stride = AXIS == 0 ? (int64_t)d.H * d.W : d.W;
-  for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < nthreads; t += (int64_t)gridDim.x * BLK) {
-    int z, y, x, b;
-    seg_decode<AXIS>(t, d, z, y, x, b);
-    const int p0 = AXIS == 0 ? z : y;
-    const int64_t o0 = (((int64_t)b * d.D + z) * d.H + y) * d.W + x;
-    for (int v = 0; v < nvol; ++v) {
-      float win[SEG + 2 * PAD];
-      seg_window<AXIS>(in + (int64_t)v * N, d, b, z, y, x, win);
-#pragma unroll
-      for (int i = 0; i < SEG; ++i)
-        if (p0 + i < len) out[(int64_t)v * N + o0 + (int64_t)i * stride] = win_sum(win, i);
-    }
-  }
-}
 
 // last forward pass (along D) fused with cc and the three backward coefficients; arithmetic in the
 // reference's own (expanded) order, losses.py:85-91
@@ -250,18 +259,20 @@ int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, v
   float* T1 = (float*)ws;
   float* T2 = T1 + 5 * N;
   float* part = T2 + 5 * N;
-  const int grid = flat_grid(N, BLK);
-  const int64_t nth_d = (int64_t)B * cdiv(D, SEG) * H * W, nth_h = (int64_t)B * D * cdiv(H, SEG) * W;
+  const int64_t nth_d = (int64_t)B * cdiv(D, SEG) * H * W;
   int rg = flat_grid(nth_d, BLK);
   if (rg > 2048) rg = 2048;
-  hipLaunchKernelGGL(ncc_pass_w_kernel, dim3(grid), dim3(BLK), 0, s, I, J, T1, d, N);
-  hipLaunchKernelGGL(box_seg_kernel<1>, dim3(flat_grid(nth_h, BLK)), dim3(BLK), 0, s, (const float*)T1, T2, d, N, 5, nth_h);
+  // forward: W+H box sums of the five products (one kernel) -> D pass fused with cc and the loss partials
+  const int tw = cdiv(W, HW_T), th = cdiv(H, HW_T);
+  const dim3 hwgrid(tw * th, D, B);
+  hipLaunchKernelGGL((box_hw_kernel<5, true>), hwgrid, dim3(BLK), 0, s, I, J, T2, d, N, tw);
   hipLaunchKernelGGL(ncc_pass_d_fwd_kernel, dim3(rg), dim3(BLK), 0, s, (const float*)T2, d_J ? T1 : nullptr, part, d, N, nth_d);
   hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(BLK), 0, s, (const float*)part, rg, -1.0 / (double)N, loss);
   if (d_J) {
-    hipLaunchKernelGGL(box_pass_kernel, dim3(grid), dim3(BLK), 0, s, (const float*)T1, T2, d, N, 3, 2);
-    hipLaunchKernelGGL(box_seg_kernel<1>, dim3(flat_grid(nth_h, BLK)), dim3(BLK), 0, s, (const float*)T2, T1, d, N, 3, nth_h);
-    hipLaunchKernelGGL(ncc_pass_d_bwd_kernel, dim3(flat_grid(nth_d, BLK)), dim3(BLK), 0, s, (const float*)T1, I, J, d_J, d, N,
+    // backward: the box sum is self-adjoint: W+H on the three coefficient volumes, D pass fused with the final formula
+    hipLaunchKernelGGL((box_hw_kernel<3, false>), hwgrid, dim3(BLK), 0, s, (const float*)T1, (const float*)nullptr, T2, d, N,
+                       tw);
+    hipLaunchKernelGGL(ncc_pass_d_bwd_kernel, dim3(flat_grid(nth_d, BLK)), dim3(BLK), 0, s, (const float*)T2, I, J, d_J, d, N,
                        -1.f / (float)N, nth_d);
   }
   return modet_launch_status();
