@@ -92,6 +92,13 @@ size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                            float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
                            modet_stream_t stream);
+/* Forward whose input is the RAW output of the previous ConvInsBlock: LeakyReLU((x_raw - in_mean) * in_rstd) is applied
+ * while the input tile is staged (zero padding stays zero), so the normalised tensor is never written
+ * (ConvInsBlock -> ConvInsBlock chains, models.py:186-219; used when no gradient is needed: inference).  in_mean / in_rstd: (B*Cin) from modet_instnorm_stats.
+ * stats (+stats_bytes) may be NULL (0): no fused output statistics.  Cin % 4 == 0. */
+int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* w,
+                            const float* bias, float* y, void* ws, size_t ws_bytes, float* stats, size_t stats_bytes, int B,
+                            int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
 /* d_x = conv(d_y, flipped/transposed w) */
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes,
                           int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
@@ -107,6 +114,7 @@ int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y
                                 void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
                                 modet_stream_t stream);
 
+
 /* InstanceNorm3d(affine=False, eps, biased variance) + LeakyReLU(0.1) (ConvInsBlock, models.py:135-151).
  * x,y (B,V,C) channels-last with V = D*H*W; mean,rstd (B*C) are outputs of fwd / inputs of bwd. */
 size_t modet_instnorm_ws_bytes(int B, int64_t V, int C);
@@ -118,6 +126,10 @@ int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd,
 size_t modet_instnorm_stats_scratch_bytes(int B, int C);
 int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, float* stats, size_t stats_bytes,
                                    int B, int64_t V, int C, float eps, modet_stream_t stream);
+/* mean / rstd only, no apply pass: from modet_conv3d_fwd_stats' partials (x, ws may be NULL) or, with stats == NULL, by a
+ * statistics pass over x (ws_bytes >= modet_instnorm_ws_bytes) */
+int modet_instnorm_stats(const float* x, float* mean, float* rstd, float* stats, size_t stats_bytes, void* ws,
+                         size_t ws_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream);
 int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
                              void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream);
 /* d_x = d_y * (y > 0 ? 1 : 0.1): backward of the LeakyReLU fused into modet_conv3d_fwd(act=1) */

@@ -30,6 +30,7 @@ SIGNATURES = {
     "modet_conv3d_fwd": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P]),
     "modet_conv3d_stats_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_fwd_stats": (I, [P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P]),
+    "modet_conv3d_fwd_normin": (I, [P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P]),
     "modet_conv3d_bwd_data": (I, [P, P, P, P, SZ, I, I, I, I, I, I, P]),
     "modet_conv3d_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
@@ -38,6 +39,7 @@ SIGNATURES = {
     "modet_instnorm_lrelu_fwd": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_stats_scratch_bytes": (SZ, [I, I]),
     "modet_instnorm_lrelu_fwd_stats": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
+    "modet_instnorm_stats": (I, [P, P, P, P, SZ, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_bwd": (I, [P, P, P, P, P, P, SZ, I, I64, I, P]),
     "modet_lrelu_bwd": (I, [P, P, P, I64, P]),
     "modet_avgpool2_fwd": (I, [P, P, I, I, I, I, I, P]),

@@ -58,6 +58,18 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// Optional input transform of the forward kernel ("lazy InstanceNorm", inference): x is the RAW output of a
+// ConvInsBlock whose per-(sample, channel) mean / rstd are given; LeakyReLU((x - mean) * rstd) is applied to the
+// prefetched registers right before they are written to LDS (zero padding stays zero), so the normalised tensor never
+// exists in HBM.  A thread's prefetch slots all belong to one channel group (slot index = tid + i*NTHR,
+// NTHR % (CK/4) == 0), so the transform needs one float4 of mean and rstd per thread and stage.
+// (The same transform in the weight-gradient kernels was measured too: +60 us per level-1/2 layer, more than the
+// apply pass it saves, so training keeps the materialised tensor.)
+struct ConvIn {
+  const float* mean;
+  const float* rstd;
+};
+
 // ------------------------------------------------------------------------------------------------ forward / dgrad
 // Persistent workgroups walk (tile, Cin-chunk) stages.  Software pipeline: the global loads of stage s+1 (input
 // tile with halo and, when Cin spans several chunks, the weight slab) are issued into registers right after
@@ -67,7 +79,7 @@ template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P, bool
 __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ y, int D,
                                                            int H, int W, int Cin, int Cout, int CinP, int CoutP, int act,
-                                                           int tiles_x, int tiles_y, int tiles_z, int ntiles, float* __restrict__ stats) {
+                                                           int tiles_x, int tiles_y, int tiles_z, int ntiles, float* __restrict__ stats, ConvIn inorm) {
   constexpr int NTHR = WM * WN * 64;         // 4 or 8 waves per workgroup (shadows the file-level constant)
   static_assert(P == 1 || (WN == 1 && NT == 1 && TY % P == 0), "row packing needs a single 16-wide N tile");
   constexpr int ROWS = TZ * TY, NCB = WN * NT * 16;
@@ -111,18 +123,30 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     xrel[i] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + c4 * 4;       // |.| < 3*H*W*Cin: fits 32 bits
   }
 
+  float4 im4 = make_float4(0.f, 0.f, 0.f, 0.f), ir4 = make_float4(1.f, 1.f, 1.f, 1.f);   // lazy InstanceNorm of the input
+  unsigned vmask = 0;                                    // which prefetch slots hold in-volume data (NXV <= 32)
+  static_assert(NXV <= 32, "slot mask");
   auto load_stage = [&](int tl, int c0, bool with_w) {
     int t = tl;
     const int x0 = (t % tiles_x) * TX; t /= tiles_x;
     const int y0 = (t % tiles_y) * TY; t /= tiles_y;
     const int z0 = (t % tiles_z) * TZ;
     const float* xt = x + (((int64_t)(t / tiles_z) * D + z0) * H + y0) * W * Cin + (int64_t)x0 * Cin + c0;
+    if (inorm.mean) {
+      const int cg = c0 + (tid % QX) * 4;
+      if (cg < Cin) {
+        im4 = *reinterpret_cast<const float4*>(inorm.mean + (t / tiles_z) * Cin + cg);
+        ir4 = *reinterpret_cast<const float4*>(inorm.rstd + (t / tiles_z) * Cin + cg);
+      }
+      vmask = 0;
+    }
     // a tile whose halo lies inside the volume (70 % of them at 160x192x160) and a full channel chunk: plain loads
     const bool interior = vec4 && z0 > 0 && z0 + TZ < D && y0 > 0 && y0 + TY < H && x0 > 0 && x0 + TX < W && c0 + CK <= Cin;
     if (interior) {
 #pragma unroll
       for (int i = 0; i < NXV; ++i)
         xr[i] = xh[i] >= 0 ? *reinterpret_cast<const float4*>(xt + xrel[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vmask = 0xffffffffu;
     } else
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
@@ -132,6 +156,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
         const int c = c0 + (xh[i] >> 24) * 4;
         if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin) {
           const float* p = xt + xrel[i];
+          vmask |= 1u << i;
           if (vec4) {
             v = *reinterpret_cast<const float4*>(p);
           } else {
@@ -162,6 +187,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   };
 
   auto store_stage = [&](bool with_w) {
+    if (inorm.mean) {
+#pragma unroll
+      for (int i = 0; i < NXV; ++i) {
+        if ((vmask >> i) & 1u) {
+          xr[i].x = lrelu((xr[i].x - im4.x) * ir4.x); xr[i].y = lrelu((xr[i].y - im4.y) * ir4.y);
+          xr[i].z = lrelu((xr[i].z - im4.z) * ir4.z); xr[i].w = lrelu((xr[i].w - im4.w) * ir4.w);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
       if (xh[i] >= 0) {
@@ -1040,7 +1074,8 @@ inline size_t fwd_ws_elems(int Cin, int Cout) {
 
 // query_gx != null: only report the persistent grid's x size (the statistics layout depends on it), launch nothing
 int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
-                int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr, int* query_gx = nullptr) {
+                int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr, int* query_gx = nullptr,
+                ConvIn inorm = ConvIn{nullptr, nullptr}) {
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 9 * (p.P + 2) * CinP * CoutP;
@@ -1060,7 +1095,7 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
     if (query_gx) { *query_gx = gx; break; }                                                                      \
     hipLaunchKernelGGL((conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__>), dim3(gx, gy), dim3(nthr), 0, s, x,   \
                        (const float*)wpk, bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z, \
-                       ntiles, stats);                                                                                   \
+                       ntiles, stats, inorm);                                                                            \
   } while (0)
   const bool v4 = (Cin & 3) == 0;
   const bool multi = CinP > p.ck;
@@ -1178,6 +1213,22 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
   if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats);
+}
+
+int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* w,
+                            const float* bias, float* y, void* ws, size_t ws_bytes, float* stats, size_t stats_bytes, int B,
+                            int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+  MODET_CHECK_PTR(x_raw); MODET_CHECK_PTR(in_mean); MODET_CHECK_PTR(in_rstd); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y);
+  MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  if (Cin % 4 != 0 || Cin == 1) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
+  if (stats) {
+    if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
+    if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
+  }
+  return conv_launch(x_raw, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
+                     ConvIn{in_mean, in_rstd});
 }
 
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,

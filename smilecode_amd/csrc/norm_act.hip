@@ -287,6 +287,36 @@ int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float*
   return modet_launch_status();
 }
 
+/* mean / rstd only (no apply pass): from the conv epilogue's partials if `stats` is given, else by a statistics pass
+ * over x (ws as for modet_instnorm_lrelu_fwd) */
+int modet_instnorm_stats(const float* x, float* mean, float* rstd, float* stats, size_t stats_bytes, void* ws,
+                         size_t ws_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream) {
+  MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd);
+  MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
+  if (C % 4 != 0 || C > 512) return MODET_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (stats) {
+    if (2 * C > 256) return MODET_ERR_UNSUPPORTED;
+    const size_t scratch = modet_instnorm_stats_scratch_bytes(B, C);
+    if (stats_bytes <= scratch) return MODET_ERR_WORKSPACE;
+    const size_t body = stats_bytes - scratch;
+    const int64_t rows = (int64_t)(body / sizeof(float)) / ((int64_t)B * C * 2);
+    MODET_CHECK_DIM(rows > 0 && (size_t)rows * B * C * 2 * sizeof(float) == body);
+    double* scr = reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + body);
+    hipLaunchKernelGGL(in_tiles_stage1_kernel, dim3(COLSUM_SLICES, B), dim3(256), 0, s, (const float*)stats, scr, C, rows);
+    hipLaunchKernelGGL(in_tiles_stage2_kernel, dim3(B), dim3(64), 0, s, (const double*)scr, mean, rstd, V, C, eps);
+    return modet_launch_status();
+  }
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(ws);
+  if (ws_bytes < modet_instnorm_ws_bytes(B, V, C)) return MODET_ERR_WORKSPACE;
+  const int chunk = in_chunk(C);
+  const int nchunk = (int)cdiv64(V, chunk);
+  float* part = (float*)ws;
+  hipLaunchKernelGGL(in_partial_kernel<0>, dim3(nchunk, B), dim3(BLK), 0, s, x, nullptr, nullptr, nullptr, part, V, C, chunk);
+  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3(C, B), dim3(64), 0, s, part, mean, rstd, V, C, nchunk, eps);
+  return modet_launch_status();
+}
+
 int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
                              void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream) {
   MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x);

@@ -114,6 +114,14 @@ class ConvInsBlock(nn.Module):
         return ops.conv3d_instnorm_lrelu(x, self.main.weight, self.main.bias)
 
 
+def _two_blocks(inp, first, second):
+    """ConvInsBlock -> ConvInsBlock: the first block's normalised output exists only inside the second conv's kernels
+    (ops.lazy_instnorm_conv3d); the second block's InstanceNorm is applied for real (its output has several consumers)"""
+    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias)
+    raw2, st2 = ops.lazy_instnorm_conv3d(raw, st, second.main.weight, second.main.bias)
+    return ops._InstNormLReLU.apply(raw2, 1e-5, st2)
+
+
 class _AvgPool(nn.Module):
     def forward(self, x):
         return ops.avgpool2(x)
@@ -134,11 +142,11 @@ class Encoder(nn.Module):
     def forward(self, x):
         # each level's output goes to the next level (pooled) AND to the caller: pool_tee fuses the two gradient paths
         outs = []
-        cur = self.conv0(x)
+        cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2])
         for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
             pooled, keep = ops.pool_tee(cur)
             outs.append(keep)
-            cur = blk[2](blk[1](pooled))              # blk[0] is the AvgPool3d(2) the tee already applied
+            cur = _two_blocks(pooled, blk[1], blk[2])    # blk[0] is the AvgPool3d(2) the tee already applied
         outs.append(cur)
         return tuple(outs)
 
@@ -146,12 +154,12 @@ class Encoder(nn.Module):
         """x = [moving; fixed] as one batch of 2B (InstanceNorm is per sample, so this is exact); returns the per-level
         features of each half: ([M1..M5], [F1..F5])"""
         Ms, Fs = [], []
-        cur = self.conv0(x)
+        cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2])
         for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
             pooled, m, f = ops.pool_tee_split(cur, B)
             Ms.append(m)
             Fs.append(f)
-            cur = blk[2](blk[1](pooled))
+            cur = _two_blocks(pooled, blk[1], blk[2])            # blk[0] is the AvgPool3d(2) the tee already applied
         m, f = _SplitBatch.apply(cur, B)
         Ms.append(m)
         Fs.append(f)
@@ -197,8 +205,10 @@ class CWM(nn.Module):
 
     def forward(self, x):
         x = ops.upsample2(x, 1.0)
-        h = self.conv[1](self.conv[0](x))
-        logits = ops.conv3d(h, self.conv[2].weight, self.conv[2].bias, False)
+        # ConvIns -> ConvIns -> Conv: both normalised intermediates live only inside the consuming conv's kernels
+        raw0, st0 = ops.conv3d_with_stats(x, self.conv[0].main.weight, self.conv[0].main.bias)
+        raw1, st1 = ops.lazy_instnorm_conv3d(raw0, st0, self.conv[1].main.weight, self.conv[1].main.bias)
+        logits, _ = ops.lazy_instnorm_conv3d(raw1, st1, self.conv[2].weight, self.conv[2].bias)
         return ops.cwm_tail(x, logits)
 
 

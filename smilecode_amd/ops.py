@@ -120,6 +120,46 @@ def conv3d_forward(x, w, b, act):
     return y
 
 
+def instnorm_stats(x_raw, stats=None, eps=1e-5):
+    """per-(sample, channel) mean / rstd of a raw conv output, without the apply pass: from the conv epilogue's partial
+    statistics when given, else by one statistics pass over x_raw"""
+    _chk(x_raw)
+    B, C = x_raw.shape[0], x_raw.shape[-1]
+    V = x_raw.numel() // (B * C)
+    mean = torch.empty(B * C, dtype=torch.float32, device=x_raw.device)
+    rstd = torch.empty_like(mean)
+    L = _L()
+    with _Guard(x_raw, "instnorm_stats", 2.0 * x_raw.numel(), 0.0 if stats is not None else 4.0 * x_raw.numel()):
+        if stats is not None:
+            _lib.check(L.modet_instnorm_stats(None, _p(mean), _p(rstd), _p(stats), stats.numel() * 4, None, 0, B, V, C, eps,
+                                              _stream()), "modet_instnorm_stats")
+        else:
+            nb = L.modet_instnorm_ws_bytes(B, V, C)
+            ws = _ws(nb, x_raw)
+            _lib.check(L.modet_instnorm_stats(_p(x_raw), _p(mean), _p(rstd), None, 0, _p(ws), nb, B, V, C, eps, _stream()),
+                       "modet_instnorm_stats")
+    return mean, rstd
+
+
+def conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats=True):
+    """conv3d(LeakyReLU((x_raw - mean) * rstd), w, b) with the normalisation applied while the input tile is staged;
+    returns (y, stats or None)"""
+    _chk(x_raw, w, b)
+    B, D, H, W, Cin = x_raw.shape
+    Cout = w.shape[0]
+    L = _L()
+    y = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=x_raw.device)
+    nb = L.modet_conv3d_ws_bytes(Cin, Cout)
+    ws = _ws(nb, x_raw)
+    sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout) if want_stats else 0
+    stats = torch.empty(sb // 4, dtype=torch.float32, device=x_raw.device) if sb > 0 else None
+    n = float(B) * D * H * W
+    with _Guard(x_raw, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+        _lib.check(L.modet_conv3d_fwd_normin(_p(x_raw), _p(mean), _p(rstd), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb,
+                                             B, D, H, W, Cin, Cout, _stream()), "modet_conv3d_fwd_normin")
+    return y, stats
+
+
 def conv3d_backward_data(dy, w, Cin):
     _chk(dy, w)
     B, D, H, W, Cout = dy.shape
@@ -224,6 +264,31 @@ def conv3d_instnorm_lrelu(x, w, b, eps=1e-5):
         y, stats = _Conv3dStats.apply(x, w, b)
         return _InstNormLReLU.apply(y, eps, stats)
     return _InstNormLReLU.apply(_Conv3d.apply(x, w, b, False), eps, None)
+
+
+def lazy_instnorm_conv3d(x_raw, stats_in, w, b, eps=1e-5):
+    """conv3d(LeakyReLU(InstanceNorm(x_raw)), w, b) -> (z_raw, z_stats or None).
+
+    Without gradients (inference) the normalised tensor is never materialised: the statistics come from the previous
+    conv's epilogue (or one statistics pass) and the conv kernel normalises its input tile while staging it (-3.5 % on the
+    forward pass).  With gradients the tensor is needed by the weight gradient anyway (normalising on the fly there was
+    measured slower), so the block runs as InstanceNorm + conv."""
+    Cin = x_raw.shape[-1]
+    needs_grad = torch.is_grad_enabled() and (x_raw.requires_grad or w.requires_grad)
+    if not needs_grad and Cin % 4 == 0 and Cin > 1:
+        mean, rstd = instnorm_stats(x_raw, stats_in, eps)
+        return conv3d_forward_normin(x_raw, mean, rstd, w, b, True)
+    y = _InstNormLReLU.apply(x_raw, eps, stats_in)
+    return conv3d_with_stats(y, w, b)
+
+
+def conv3d_with_stats(x, w, b):
+    """raw 3x3x3 conv output plus, when the configuration supports it, the InstanceNorm partial statistics from its
+    epilogue (else None)"""
+    B, D, H, W, Cin = x.shape
+    if _L().modet_conv3d_stats_bytes(B, D, H, W, Cin, w.shape[0]) > 0:
+        return _Conv3dStats.apply(x, w, b)
+    return _Conv3d.apply(x, w, b, False), None
 
 
 def conv3d(x, w, b=None, act=False):

@@ -295,6 +295,27 @@ def test_conv_instnorm_fused_vs_oracle(ops, cin, cout, shape):
     assert_close(np64(dw), rw.numpy(), atol=5e-4, rtol=2e-4, what="fused block dw")
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(8, 8, (33, 40, 48)), (16, 16, (9, 11, 37)), (32, 32, (12, 10, 20)),
+                                            (12, 2, (7, 9, 18)), (48, 48, (5, 6, 7))])
+def test_lazy_instnorm_conv_inference(ops, cin, cout, shape):
+    """without gradients ConvIns -> Conv runs with the normalisation inside the conv kernel (modet_conv3d_fwd_normin +
+    modet_instnorm_stats): same result as InstanceNorm -> conv, statistics from the epilogue or from a statistics pass"""
+    gen = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn((2, cin) + shape, generator=gen).double() * 1.5 + 0.3
+    w0 = (torch.randn((cin, cin, 3, 3, 3), generator=gen) / np.sqrt(cin * 27)).double()
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(cin * 27)).double()
+    b = (0.1 * torch.randn(cout, generator=gen)).double()
+    raw_ref = torch.nn.functional.conv3d(x, w0, None, padding=1)
+    act = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(raw_ref, eps=1e-5), 0.1)
+    ref = torch.nn.functional.conv3d(act, w, b, padding=1)
+    with torch.no_grad():
+        raw, st = ops.conv3d_with_stats(cl(x.numpy()), w0.float().cuda(), None)
+        y, _ = ops.lazy_instnorm_conv3d(raw, st, w.float().cuda(), b.float().cuda())
+        y2 = ops.conv3d(ops.instnorm_lrelu(raw), w.float().cuda(), b.float().cuda(), False)
+    assert_close(ncdhw(y), ref.numpy(), atol=1e-4, what="lazy IN -> conv")
+    assert_close(np64(y), np64(y2), atol=2e-5, what="lazy vs materialised")
+
+
 def test_instnorm_large_and_pool(ops):
     g = gold("op_misc.npz")
     x = cl(g["pool.x"]).requires_grad_(True)   # C=5 is not a multiple of 4 -> must be refused, not mis-computed
