@@ -85,7 +85,7 @@ size_t modet_conv3d_ws_bytes(int Cin, int Cout);
 int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                      int B, int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream);
 /* Forward + fused InstanceNorm statistics (ConvInsBlock, models.py:135-151): the staged epilogue also emits
- * per-(tile, wave) partial sums (sum, sum of squares) of the output.  modet_conv3d_stats_bytes() == 0 means this
+ * per-(sample, workgroup) partial sums (sum, sum of squares) of the output.  modet_conv3d_stats_bytes() == 0 means this
  * (Cin, Cout) cannot fuse them (use modet_conv3d_fwd + modet_instnorm_lrelu_fwd).  Consume with
  * modet_instnorm_lrelu_fwd_stats (same stats_bytes). */
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
@@ -120,15 +120,13 @@ int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y
 size_t modet_instnorm_ws_bytes(int B, int64_t V, int C);
 int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes,
                              int B, int64_t V, int C, float eps, modet_stream_t stream);
-/* same, with the statistics taken from modet_conv3d_fwd_stats' partials instead of a pass over x.  `stats` is the
- * buffer modet_conv3d_fwd_stats filled (stats_bytes = modet_conv3d_stats_bytes(...)); its tail of
- * modet_instnorm_stats_scratch_bytes(B, C) bytes is scratch for the two-stage reduction, so the buffer is consumed. */
-size_t modet_instnorm_stats_scratch_bytes(int B, int C);
-int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, float* stats, size_t stats_bytes,
-                                   int B, int64_t V, int C, float eps, modet_stream_t stream);
-/* mean / rstd only, no apply pass: from modet_conv3d_fwd_stats' partials (x, ws may be NULL) or, with stats == NULL, by a
- * statistics pass over x (ws_bytes >= modet_instnorm_ws_bytes) */
-int modet_instnorm_stats(const float* x, float* mean, float* rstd, float* stats, size_t stats_bytes, void* ws,
+/* same, with the statistics taken from modet_conv3d_fwd_stats' partial rows (stats_bytes = modet_conv3d_stats_bytes(...))
+ * instead of a pass over x */
+int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, const float* stats,
+                                   size_t stats_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream);
+/* mean / rstd only, no apply pass: from modet_conv3d_fwd_stats' partial rows (x, ws may be NULL) or, with stats == NULL,
+ * by a statistics pass over x (ws_bytes >= modet_instnorm_ws_bytes) */
+int modet_instnorm_stats(const float* x, float* mean, float* rstd, const float* stats, size_t stats_bytes, void* ws,
                          size_t ws_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream);
 int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
                              void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream);

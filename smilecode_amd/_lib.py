@@ -37,7 +37,6 @@ SIGNATURES = {
     "modet_conv3d_bwd_weight_act": (I, [P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
     "modet_instnorm_ws_bytes": (SZ, [I, I64, I]),
     "modet_instnorm_lrelu_fwd": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
-    "modet_instnorm_stats_scratch_bytes": (SZ, [I, I]),
     "modet_instnorm_lrelu_fwd_stats": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_stats": (I, [P, P, P, P, SZ, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_bwd": (I, [P, P, P, P, P, P, SZ, I, I64, I, P]),

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   constexpr int OC = P > 1 ? CoP : NCB;
   constexpr bool STG = (P > 1) || (NCB == 16);                     // the L1/L2 configs (16-wide N tile)
   __shared__ __attribute__((aligned(16))) float stg[STG ? ROWS * TX * OC : 4];
+  __shared__ float sred[STG ? WM : 1][32];                         // per-wave partial statistics (Cout <= 16)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -281,11 +282,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     }
   }
   // fused InstanceNorm statistics: per-lane sums live in registers across ALL tiles of one batch sample this
-  // workgroup walks (tiles are sample-major, so the sample index only ever increases); the cross-lane reduction and the
-  // store happen once per (workgroup, wave, sample): stats[sample][workgroup][wave][channel][2]
+  // workgroup walks (tiles are sample-major, so the sample index only ever increases); the cross-lane / cross-wave
+  // reduction and the store happen once per (workgroup, sample): stats[sample][workgroup][channel][2]
   float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
   int stat_b = -1;
   unsigned stat_done = 0;                              // samples this workgroup already wrote (B <= 32)
+  // called by every wave at the same point (the sample index changes for the whole workgroup at once): wave sums ->
+  // LDS -> one row per (sample, workgroup) in fixed wave order
   auto emit_stats = [&](int bsamp) {
     const int cq = Cout >> 2;
     for (int o = cq; o < 64; o <<= 1) {
@@ -293,10 +296,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
       for (int j = 0; j < 4; ++j) { sx[j] += __shfl_xor(sx[j], o, 64); sq[j] += __shfl_xor(sq[j], o, 64); }
     }
     if (lane < cq) {
-      float* sp = stats + ((((int64_t)bsamp * gridDim.x + blockIdx.x) * WM + wm) * Cout + lane * 4) * 2;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { sp[j * 2] = sx[j]; sp[j * 2 + 1] = sq[j]; }
+      for (int j = 0; j < 4; ++j) { sred[wm][(lane * 4 + j) * 2] = sx[j]; sred[wm][(lane * 4 + j) * 2 + 1] = sq[j]; }
     }
+    __syncthreads();
+    if (tid < 2 * Cout) {
+      float acc_s = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < WM; ++w8) acc_s += sred[w8][tid];
+      stats[((int64_t)bsamp * gridDim.x + blockIdx.x) * Cout * 2 + tid] = acc_s;
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sx[j] = 0.f; sq[j] = 0.f; }
     stat_done |= 1u << bsamp;
@@ -1200,8 +1210,8 @@ size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int gx = conv_grid_x(B, D, H, W, Cin, Cout);
-  // [sample][workgroup][wave][Cout][2] partials + the scratch tail modet_instnorm_lrelu_fwd_stats reduces them in
-  return (size_t)B * gx * p.wm() * Cout * 2 * sizeof(float) + modet_instnorm_stats_scratch_bytes(B, Cout);
+  // [sample][workgroup][Cout][2] partial sums, reduced by modet_instnorm_lrelu_fwd_stats / modet_instnorm_stats
+  return (size_t)B * gx * Cout * 2 * sizeof(float);
 }
 
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,

@@ -90,29 +90,20 @@ __global__ __launch_bounds__(64) void in_finalize_kernel(const float* __restrict
   }
 }
 
-// statistics from the conv epilogue's partials stats[(b*rows_per_b + r)][C][2], two stages:
-//   1: grid (COLSUM_SLICES, B): column sums of a slice of rows -> scratch[b][slice][2C] (fp64)
-//   2: grid B: slices added in order, mean / rstd per channel
-__global__ __launch_bounds__(256) void in_tiles_stage1_kernel(const float* __restrict__ stats, double* __restrict__ scratch,
-                                                              int C, int64_t rows_per_b) {
+// statistics from the conv epilogue's partial rows stats[(b*rows_per_b + r)][C][2] (one row per workgroup of the conv):
+// one workgroup per sample, coalesced fixed-order fp64 column sums, then mean / rstd per channel
+__global__ __launch_bounds__(256) void in_rows_finalize_kernel(const float* __restrict__ stats, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, int64_t V, int C,
+                                                               int64_t rows_per_b, float eps) {
   __shared__ double sm[256];
-  const int b = blockIdx.y, sl = blockIdx.x;
-  const int64_t per = cdiv64(rows_per_b, COLSUM_SLICES);
-  const int64_t r0 = sl * per, r1 = r0 + per < rows_per_b ? r0 + per : rows_per_b;
-  block_colsum_256(stats + (int64_t)b * rows_per_b * 2 * C, r0 < r1 ? r0 : r1, r1, 2 * C,
-                   scratch + ((int64_t)b * COLSUM_SLICES + sl) * 2 * C, sm);
-}
-__global__ __launch_bounds__(64) void in_tiles_stage2_kernel(const double* __restrict__ scratch, float* __restrict__ mean,
-                                                             float* __restrict__ rstd, int64_t V, int C, float eps) {
+  __shared__ double tot[256];
   const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 64) {
-    double s = 0.0, q = 0.0;
-    for (int sl = 0; sl < COLSUM_SLICES; ++sl) {
-      const double* p = scratch + ((int64_t)b * COLSUM_SLICES + sl) * 2 * C + 2 * c;
-      s += p[0]; q += p[1];
-    }
-    const double m = s / (double)V;
-    double var = q / (double)V - m * m;
+  block_colsum_256(stats + (int64_t)b * rows_per_b * 2 * C, 0, rows_per_b, 2 * C, tot, sm);
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x;
+    const double m = tot[2 * c] / (double)V;
+    double var = tot[2 * c + 1] / (double)V - m * m;
     if (var < 0.0) var = 0.0;
     mean[b * C + c] = (float)m;
     rstd[b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -266,22 +257,20 @@ int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd,
   return modet_launch_status();
 }
 
-size_t modet_instnorm_stats_scratch_bytes(int B, int C) { return (size_t)B * COLSUM_SLICES * 2 * C * sizeof(double); }
+static int rows_from_bytes(size_t stats_bytes, int B, int C, int64_t* rows) {
+  *rows = (int64_t)(stats_bytes / sizeof(float)) / ((int64_t)B * C * 2);
+  return (*rows > 0 && (size_t)*rows * B * C * 2 * sizeof(float) == stats_bytes) ? MODET_OK : MODET_ERR_DIM;
+}
 
-int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, float* stats, size_t stats_bytes,
-                                   int B, int64_t V, int C, float eps, modet_stream_t stream) {
+int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, const float* stats,
+                                   size_t stats_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(y); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(stats);
   MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
   if (C % 4 != 0 || 2 * C > 256) return MODET_ERR_UNSUPPORTED;
-  const size_t scratch = modet_instnorm_stats_scratch_bytes(B, C);
-  if (stats_bytes <= scratch) return MODET_ERR_WORKSPACE;
-  const size_t body = stats_bytes - scratch;
-  const int64_t rows = (int64_t)(body / sizeof(float)) / ((int64_t)B * C * 2);
-  MODET_CHECK_DIM(rows > 0 && (size_t)rows * B * C * 2 * sizeof(float) == body);
+  int64_t rows;
+  if (rows_from_bytes(stats_bytes, B, C, &rows) != MODET_OK) return MODET_ERR_DIM;
   hipStream_t s = (hipStream_t)stream;
-  double* scr = reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + body);   // body is a multiple of 8 bytes
-  hipLaunchKernelGGL(in_tiles_stage1_kernel, dim3(COLSUM_SLICES, B), dim3(256), 0, s, (const float*)stats, scr, C, rows);
-  hipLaunchKernelGGL(in_tiles_stage2_kernel, dim3(B), dim3(64), 0, s, (const double*)scr, mean, rstd, V, C, eps);
+  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, mean, rstd, V, C, rows, eps);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total4);
   return modet_launch_status();
@@ -289,7 +278,7 @@ int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float*
 
 /* mean / rstd only (no apply pass): from the conv epilogue's partials if `stats` is given, else by a statistics pass
  * over x (ws as for modet_instnorm_lrelu_fwd) */
-int modet_instnorm_stats(const float* x, float* mean, float* rstd, float* stats, size_t stats_bytes, void* ws,
+int modet_instnorm_stats(const float* x, float* mean, float* rstd, const float* stats, size_t stats_bytes, void* ws,
                          size_t ws_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream) {
   MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd);
   MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
@@ -297,14 +286,9 @@ int modet_instnorm_stats(const float* x, float* mean, float* rstd, float* stats,
   hipStream_t s = (hipStream_t)stream;
   if (stats) {
     if (2 * C > 256) return MODET_ERR_UNSUPPORTED;
-    const size_t scratch = modet_instnorm_stats_scratch_bytes(B, C);
-    if (stats_bytes <= scratch) return MODET_ERR_WORKSPACE;
-    const size_t body = stats_bytes - scratch;
-    const int64_t rows = (int64_t)(body / sizeof(float)) / ((int64_t)B * C * 2);
-    MODET_CHECK_DIM(rows > 0 && (size_t)rows * B * C * 2 * sizeof(float) == body);
-    double* scr = reinterpret_cast<double*>(reinterpret_cast<char*>(stats) + body);
-    hipLaunchKernelGGL(in_tiles_stage1_kernel, dim3(COLSUM_SLICES, B), dim3(256), 0, s, (const float*)stats, scr, C, rows);
-    hipLaunchKernelGGL(in_tiles_stage2_kernel, dim3(B), dim3(64), 0, s, (const double*)scr, mean, rstd, V, C, eps);
+    int64_t rows;
+    if (rows_from_bytes(stats_bytes, B, C, &rows) != MODET_OK) return MODET_ERR_DIM;
+    hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, (const float*)stats, mean, rstd, V, C, rows, eps);
     return modet_launch_status();
   }
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(ws);
