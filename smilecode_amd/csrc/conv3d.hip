@@ -96,7 +96,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   constexpr int OC = P > 1 ? CoP : NCB;
   constexpr bool STG = (P > 1) || (NCB == 16);                     // the L1/L2 configs (16-wide N tile)
   __shared__ __attribute__((aligned(16))) float stg[STG ? ROWS * TX * OC : 4];
-  __shared__ float sred[STG ? WM : 1][32];                         // per-wave partial statistics (Cout <= 16)
+  __shared__ float sred[WM * WN][NT * 16 * 2 > 32 ? NT * 16 * 2 : 32];    // per-wave partial statistics of the epilogue
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -289,7 +289,31 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   unsigned stat_done = 0;                              // samples this workgroup already wrote (B <= 32)
   // called by every wave at the same point (the sample index changes for the whole workgroup at once): wave sums ->
   // LDS -> one row per (sample, workgroup) in fixed wave order
+  float dsx[NT], dsq[NT];                              // direct-store epilogue: this lane's cout per n tile
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { dsx[n] = 0.f; dsq[n] = 0.f; }
   auto emit_stats = [&](int bsamp) {
+    if (!lds_epi_rt) {
+      // direct-store configs: lane = (cout li, voxel group lk); sum over lk, then over the WM waves of this wn
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        dsx[n] += __shfl_xor(dsx[n], 16, 64); dsq[n] += __shfl_xor(dsq[n], 16, 64);
+        dsx[n] += __shfl_xor(dsx[n], 32, 64); dsq[n] += __shfl_xor(dsq[n], 32, 64);
+        if (lane < 16) { sred[wave][(n * 16 + lane) * 2] = dsx[n]; sred[wave][(n * 16 + lane) * 2 + 1] = dsq[n]; }
+        dsx[n] = 0.f; dsq[n] = 0.f;
+      }
+      __syncthreads();
+      if (tid < NCB * 2) {
+        const int cc = tid >> 1, wnc = cc / (NT * 16), within = (cc % (NT * 16)) * 2 + (tid & 1);
+        float acc_s = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < WM; ++w8) acc_s += sred[w8 * WN + wnc][within];
+        if (cb0 + cc < Cout) stats[(((int64_t)bsamp * gridDim.x + blockIdx.x) * Cout + cb0 + cc) * 2 + (tid & 1)] = acc_s;
+      }
+      __syncthreads();
+      stat_done |= 1u << bsamp;
+      return;
+    }
     const int cq = Cout >> 2;
     for (int o = cq; o < 64; o <<= 1) {
 #pragma unroll
@@ -297,13 +321,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     }
     if (lane < cq) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { sred[wm][(lane * 4 + j) * 2] = sx[j]; sred[wm][(lane * 4 + j) * 2 + 1] = sq[j]; }
+      for (int j = 0; j < 4; ++j) { sred[wave][(lane * 4 + j) * 2] = sx[j]; sred[wave][(lane * 4 + j) * 2 + 1] = sq[j]; }
     }
     __syncthreads();
     if (tid < 2 * Cout) {
       float acc_s = 0.f;
 #pragma unroll
-      for (int w8 = 0; w8 < WM; ++w8) acc_s += sred[w8][tid];
+      for (int w8 = 0; w8 < WM; ++w8) acc_s += sred[w8 * WN][tid];          // staged configs have WN == 1
       stats[((int64_t)bsamp * gridDim.x + blockIdx.x) * Cout * 2 + tid] = acc_s;
     }
     __syncthreads();
@@ -422,6 +446,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
         ptile = tile;
       } else {
         // direct stores: lane holds (row p, cout) = li, voxels x = lk*4 + j; bias was hoisted out of the stage loop
+        if (stats) {
+          const int bs = t / tiles_z;
+          if (bs != stat_b) {
+            if (stat_b >= 0) emit_stats(stat_b);
+            stat_b = bs;
+          }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int rr = (wm * R + r) * P + (P > 1 ? li / CoP : 0);
@@ -435,6 +466,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
               for (int j = 0; j < 4; ++j) {
                 if (x0 + lk * 4 + j < W) {
                   float v = acc[r][n][j] + bv[n];
+                  if (stats) { dsx[n] += v; dsq[n] = fmaf(v, v, dsq[n]); }
                   if (act) v = lrelu(v);
                   yrow[j * Cout + co] = v;
                 }
@@ -453,12 +485,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   if (STG) {
     __syncthreads();
     flush_tile();
-    if (stats) {
-      if (stat_b >= 0) emit_stats(stat_b);
-      const int nb = ntiles / (tiles_x * tiles_y * tiles_z);
-      for (int bsamp = 0; bsamp < nb; ++bsamp)           // samples this workgroup never touched: zero rows
-        if (!((stat_done >> bsamp) & 1u)) emit_stats(bsamp);
-    }
+  }
+  if (stats) {
+    if (stat_b >= 0) emit_stats(stat_b);
+    const int nb = ntiles / (tiles_x * tiles_y * tiles_z);
+    for (int bsamp = 0; bsamp < nb; ++bsamp)             // samples this workgroup never touched: zero rows
+      if (!((stat_done >> bsamp) & 1u)) emit_stats(bsamp);
   }
 #ifdef MODET_TUNING
   if (dbgp && lane == 0) {
@@ -1023,7 +1055,6 @@ struct FwdPlan {
   int cfg;       // 0:A 1:B 2:C 3:D 4:A with CK=4
   int ncb, ck, tz, ty;
   int P;         // output rows packed into the N tile (cfg 0/4 only)
-  int wm() const { return cfg == 0 || cfg == 4 ? 8 : (cfg == 8 ? 4 : 0); }   // waves along M of the staged-epilogue configs
 };
 inline FwdPlan plan_fwd(int64_t BV, int Cin, int Cout) {
   const int P = Cout <= 4 ? 4 : (Cout <= 8 ? 2 : 1);
@@ -1202,9 +1233,9 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
   return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
 }
 
-// InstanceNorm statistics can be fused into the conv when it takes the staged epilogue of the 16-wide configs:
-// 8-wave workgroups, Cout in {4, 8, 16}
-static bool conv_stats_ok(int Cin, int Cout) { return Cin != 1 && (Cout == 4 || Cout == 8 || Cout == 16); }
+// InstanceNorm statistics are fused into the conv epilogue (staged or direct-store) for every Cout the model
+// normalises (a multiple of 4, at most 128: 2*Cout columns fit the 256-thread finalize)
+static bool conv_stats_ok(int Cin, int Cout) { return Cin != 1 && Cout % 4 == 0 && Cout <= 128; }
 
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
