@@ -96,7 +96,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   constexpr int OC = P > 1 ? CoP : NCB;
   constexpr bool STG = (P > 1) || (NCB == 16);                     // the L1/L2 configs (16-wide N tile)
   __shared__ __attribute__((aligned(16))) float stg[STG ? ROWS * TX * OC : 4];
-  __shared__ float sred[WM * WN][NT * 16 * 2 > 32 ? NT * 16 * 2 : 32];    // per-wave partial statistics of the epilogue
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -292,14 +291,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   float dsx[NT], dsq[NT];                              // direct-store epilogue: this lane's cout per n tile
 #pragma unroll
   for (int n = 0; n < NT; ++n) { dsx[n] = 0.f; dsq[n] = 0.f; }
+  // The per-wave partials go through LDS that is free at the time of the call -- the output staging for the staged
+  // epilogue (emission happens after a flush), the input tile for the direct-store epilogue (after the MFMA loop) -- so
+  // the statistics add no LDS (an extra 1 KB array pushed two configurations over an occupancy step).
+  constexpr int SRW = NT * 16 * 2 > 32 ? NT * 16 * 2 : 32;
   auto emit_stats = [&](int bsamp) {
+    float* sredp = lds_epi_rt ? stg : xs;
+    __syncthreads();                                   // every wave is done with that buffer
     if (!lds_epi_rt) {
       // direct-store configs: lane = (cout li, voxel group lk); sum over lk, then over the WM waves of this wn
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         dsx[n] += __shfl_xor(dsx[n], 16, 64); dsq[n] += __shfl_xor(dsq[n], 16, 64);
         dsx[n] += __shfl_xor(dsx[n], 32, 64); dsq[n] += __shfl_xor(dsq[n], 32, 64);
-        if (lane < 16) { sred[wave][(n * 16 + lane) * 2] = dsx[n]; sred[wave][(n * 16 + lane) * 2 + 1] = dsq[n]; }
+        if (lane < 16) { sredp[wave * SRW + (n * 16 + lane) * 2] = dsx[n]; sredp[wave * SRW + (n * 16 + lane) * 2 + 1] = dsq[n]; }
         dsx[n] = 0.f; dsq[n] = 0.f;
       }
       __syncthreads();
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
         const int cc = tid >> 1, wnc = cc / (NT * 16), within = (cc % (NT * 16)) * 2 + (tid & 1);
         float acc_s = 0.f;
 #pragma unroll
-        for (int w8 = 0; w8 < WM; ++w8) acc_s += sred[w8 * WN + wnc][within];
+        for (int w8 = 0; w8 < WM; ++w8) acc_s += sredp[(w8 * WN + wnc) * SRW + within];
         if (cb0 + cc < Cout) stats[(((int64_t)bsamp * gridDim.x + blockIdx.x) * Cout + cb0 + cc) * 2 + (tid & 1)] = acc_s;
       }
       __syncthreads();
@@ -321,13 +326,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     }
     if (lane < cq) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { sred[wave][(lane * 4 + j) * 2] = sx[j]; sred[wave][(lane * 4 + j) * 2 + 1] = sq[j]; }
+      for (int j = 0; j < 4; ++j) { sredp[wave * SRW + (lane * 4 + j) * 2] = sx[j]; sredp[wave * SRW + (lane * 4 + j) * 2 + 1] = sq[j]; }
     }
     __syncthreads();
     if (tid < 2 * Cout) {
       float acc_s = 0.f;
 #pragma unroll
-      for (int w8 = 0; w8 < WM; ++w8) acc_s += sred[w8 * WN][tid];          // staged configs have WN == 1
+      for (int w8 = 0; w8 < WM; ++w8) acc_s += sredp[w8 * WN * SRW + tid];  // staged configs have WN == 1
       stats[((int64_t)bsamp * gridDim.x + blockIdx.x) * Cout * 2 + tid] = acc_s;
     }
     __syncthreads();
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     for (int j = 0; j < 4; ++j) { sx[j] = 0.f; sq[j] = 0.f; }
     stat_done |= 1u << bsamp;
   };
-  auto flush_tile = [&]() {
+  auto flush_tile = [&](int next_tile) {                // next_tile: the tile the NEXT flush will write, -1 = none
     if (ptile < 0) return;
     int t = ptile;
     const int x0 = (t % tiles_x) * TX; t /= tiles_x;
@@ -344,13 +349,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
     const int cq = Cout >> 2;
     float* ytile = y + (xbase + ((int64_t)z0 * H + y0) * W + x0) * Cout + cb0;
-    if (stats) {
-      const int bs = t / tiles_z;
-      if (bs != stat_b) {
-        if (stat_b >= 0) emit_stats(stat_b);
-        stat_b = bs;
-      }
-    }
+    if (stats) stat_b = t / tiles_z;
 #pragma unroll
     for (int it = 0; it < FL_MAX; ++it) {
       if (fl_stg[it] < 0) continue;
@@ -368,6 +367,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
       }
     }
     ptile = -1;
+    // last tile of this sample for this workgroup?  emit now, while the staging buffer is free
+    if (stats && next_tile >= 0 && next_tile / (tiles_x * tiles_y * tiles_z) != stat_b) {
+      emit_stats(stat_b);
+      stat_b = -1;
+    }
   };
 
   int c0 = 0;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     int ntile = tile, nc0 = c0 + CK;
     bool has_next = true;
     if (nc0 >= CinP) { nc0 = 0; ntile = tile + gridDim.x; has_next = ntile < ntiles; }
-    if (STG) flush_tile();                         // previous tile's stores go out before this prefetch
+    if (STG) flush_tile(tile);                     // previous tile's stores go out before this prefetch
     DBG_T(3)
     if (has_next) load_stage(ntile, nc0, multi);   // in flight during the MFMA loop below
     DBG_T(4)
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   }
   if (STG) {
     __syncthreads();
-    flush_tile();
+    flush_tile(-1);
   }
   if (stats) {
     if (stat_b >= 0) emit_stats(stat_b);

@@ -256,18 +256,29 @@ class _Conv3dStats(Function):
         return dx, dw, db
 
 
+def _fuse_stats(x, w):
+    """fuse the InstanceNorm statistics into this conv's epilogue?  The staged epilogue of the 16-wide configurations
+    (Cout 4/8/16) carries them for free; in the direct-store configurations they cost the conv ~3 % and only pay off when
+    no backward pass follows (measured: training +0.07 ms, inference -0.05 ms)."""
+    B, D, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if _L().modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout) == 0:
+        return False
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+    return Cout in (4, 8, 16) or not needs_grad
+
+
 def conv3d_instnorm_lrelu(x, w, b, eps=1e-5):
     """ConvInsBlock = conv + InstanceNorm3d + LeakyReLU(0.1) (reference models.py:135-151); the norm statistics are
     fused into the conv epilogue when the configuration supports it"""
-    B, D, H, W, Cin = x.shape
-    if _L().modet_conv3d_stats_bytes(B, D, H, W, Cin, w.shape[0]) > 0:
+    if _fuse_stats(x, w):
         y, stats = _Conv3dStats.apply(x, w, b)
         return _InstNormLReLU.apply(y, eps, stats)
     return _InstNormLReLU.apply(_Conv3d.apply(x, w, b, False), eps, None)
 
 
-def lazy_instnorm_conv3d(x_raw, stats_in, w, b, eps=1e-5):
-    """conv3d(LeakyReLU(InstanceNorm(x_raw)), w, b) -> (z_raw, z_stats or None).
+def lazy_instnorm_conv3d(x_raw, stats_in, w, b, eps=1e-5, want_stats=True):
+    """conv3d(LeakyReLU(InstanceNorm(x_raw)), w, b) -> (z_raw, z_stats or None); want_stats=False when z is not normalised.
 
     Without gradients (inference) the normalised tensor is never materialised: the statistics come from the previous
     conv's epilogue (or one statistics pass) and the conv kernel normalises its input tile while staging it (-3.5 % on the
@@ -277,16 +288,17 @@ def lazy_instnorm_conv3d(x_raw, stats_in, w, b, eps=1e-5):
     needs_grad = torch.is_grad_enabled() and (x_raw.requires_grad or w.requires_grad)
     if not needs_grad and Cin % 4 == 0 and Cin > 1:
         mean, rstd = instnorm_stats(x_raw, stats_in, eps)
-        return conv3d_forward_normin(x_raw, mean, rstd, w, b, True)
+        return conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats)
     y = _InstNormLReLU.apply(x_raw, eps, stats_in)
+    if not want_stats:
+        return _Conv3d.apply(y, w, b, False), None
     return conv3d_with_stats(y, w, b)
 
 
 def conv3d_with_stats(x, w, b):
     """raw 3x3x3 conv output plus, when the configuration supports it, the InstanceNorm partial statistics from its
     epilogue (else None)"""
-    B, D, H, W, Cin = x.shape
-    if _L().modet_conv3d_stats_bytes(B, D, H, W, Cin, w.shape[0]) > 0:
+    if _fuse_stats(x, w):
         return _Conv3dStats.apply(x, w, b)
     return _Conv3d.apply(x, w, b, False), None
 
