@@ -68,6 +68,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 struct ConvIn {
   const float* mean;
   const float* rstd;
+  int stats_rows;      // rows per sample of the statistics buffer (>= gridDim.x; the tail is zero-filled by workgroup 0)
 };
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
@@ -75,7 +76,9 @@ struct ConvIn {
 // tile with halo and, when Cin spans several chunks, the weight slab) are issued into registers right after
 // stage s has been written to LDS, i.e. before the MFMA loop of stage s, so HBM/L2 latency hides under the
 // matrix work (PMC before this change: MFMA pipe 54 % busy, 36 % of wave cycles in s_waitcnt/barrier).
-template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P, bool MULTI>
+// XF ("extra features", inference): the lazy-InstanceNorm input transform (ConvIn) and statistics from the direct-store
+// epilogue.  Compiled out of the kernels training uses: carrying them as run-time options cost those 4 %.
+template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P, bool MULTI, bool XF>
 __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ y, int D,
                                                            int H, int W, int Cin, int Cout, int CinP, int CoutP, int act,
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     const int y0 = (t % tiles_y) * TY; t /= tiles_y;
     const int z0 = (t % tiles_z) * TZ;
     const float* xt = x + (((int64_t)(t / tiles_z) * D + z0) * H + y0) * W * Cin + (int64_t)x0 * Cin + c0;
-    if (inorm.mean) {
+    if (XF && inorm.mean) {
       const int cg = c0 + (tid % QX) * 4;
       if (cg < Cin) {
         im4 = *reinterpret_cast<const float4*>(inorm.mean + (t / tiles_z) * Cin + cg);
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
 #pragma unroll
       for (int i = 0; i < NXV; ++i)
         xr[i] = xh[i] >= 0 ? *reinterpret_cast<const float4*>(xt + xrel[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      vmask = 0xffffffffu;
+      if (XF) vmask = 0xffffffffu;
     } else
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
         const int c = c0 + (xh[i] >> 24) * 4;
         if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin) {
           const float* p = xt + xrel[i];
-          vmask |= 1u << i;
+          if (XF) vmask |= 1u << i;
           if (vec4) {
             v = *reinterpret_cast<const float4*>(p);
           } else {
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   };
 
   auto store_stage = [&](bool with_w) {
-    if (inorm.mean) {
+    if (XF && inorm.mean) {
 #pragma unroll
       for (int i = 0; i < NXV; ++i) {
         if ((vmask >> i) & 1u) {
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   auto emit_stats = [&](int bsamp) {
     float* sredp = lds_epi_rt ? stg : xs;
     __syncthreads();                                   // every wave is done with that buffer
-    if (!lds_epi_rt) {
+    if (XF && !lds_epi_rt) {
       // direct-store configs: lane = (cout li, voxel group lk); sum over lk, then over the WM waves of this wn
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
         float acc_s = 0.f;
 #pragma unroll
         for (int w8 = 0; w8 < WM; ++w8) acc_s += sredp[(w8 * WN + wnc) * SRW + within];
-        if (cb0 + cc < Cout) stats[(((int64_t)bsamp * gridDim.x + blockIdx.x) * Cout + cb0 + cc) * 2 + (tid & 1)] = acc_s;
+        if (cb0 + cc < Cout) stats[(((int64_t)bsamp * inorm.stats_rows + blockIdx.x) * Cout + cb0 + cc) * 2 + (tid & 1)] = acc_s;
       }
       __syncthreads();
       stat_done |= 1u << bsamp;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
       float acc_s = 0.f;
 #pragma unroll
       for (int w8 = 0; w8 < WM; ++w8) acc_s += sredp[w8 * WN * SRW + tid];  // staged configs have WN == 1
-      stats[((int64_t)bsamp * gridDim.x + blockIdx.x) * Cout * 2 + tid] = acc_s;
+      stats[((int64_t)bsamp * inorm.stats_rows + blockIdx.x) * Cout * 2 + tid] = acc_s;
     }
     __syncthreads();
 #pragma unroll
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
         ptile = tile;
       } else {
         // direct stores: lane holds (row p, cout) = li, voxels x = lk*4 + j; bias was hoisted out of the stage loop
-        if (stats) {
+        if (XF && stats) {
           const int bs = t / tiles_z;
           if (bs != stat_b) {
             if (stat_b >= 0) emit_stats(stat_b);
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
               for (int j = 0; j < 4; ++j) {
                 if (x0 + lk * 4 + j < W) {
                   float v = acc[r][n][j] + bv[n];
-                  if (stats) { dsx[n] += v; dsq[n] = fmaf(v, v, dsq[n]); }
+                  if (XF && stats) { dsx[n] += v; dsq[n] = fmaf(v, v, dsq[n]); }
                   if (act) v = lrelu(v);
                   yrow[j * Cout + co] = v;
                 }
@@ -490,11 +493,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     __syncthreads();
     flush_tile(-1);
   }
-  if (stats) {
+  if (stats && (XF || lds_epi_rt)) {
     if (stat_b >= 0) emit_stats(stat_b);
     const int nb = ntiles / (tiles_x * tiles_y * tiles_z);
     for (int bsamp = 0; bsamp < nb; ++bsamp)             // samples this workgroup never touched: zero rows
       if (!((stat_done >> bsamp) & 1u)) emit_stats(bsamp);
+    if (blockIdx.x == 0) {                               // rows the buffer has beyond this launch's grid
+      const int tail = (inorm.stats_rows - (int)gridDim.x) * Cout * 2;
+      for (int bsamp = 0; bsamp < nb; ++bsamp)
+        for (int i = tid; i < tail; i += NTHR)
+          if (i % (Cout * 2) >= cb0 * 2 && i % (Cout * 2) < (cb0 + NCB) * 2)
+            stats[((int64_t)bsamp * inorm.stats_rows + gridDim.x) * Cout * 2 + i] = 0.f;
+    }
   }
 #ifdef MODET_TUNING
   if (dbgp && lane == 0) {
@@ -1120,7 +1130,7 @@ inline size_t fwd_ws_elems(int Cin, int Cout) {
 // query_gx != null: only report the persistent grid's x size (the statistics layout depends on it), launch nothing
 int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
                 int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr, int* query_gx = nullptr,
-                ConvIn inorm = ConvIn{nullptr, nullptr}) {
+                ConvIn inorm = ConvIn{nullptr, nullptr, 0}, bool query_xf = false) {
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 9 * (p.P + 2) * CinP * CoutP;
@@ -1131,16 +1141,25 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
   const int ntiles = tiles_x * tiles_y * tiles_z * B;
   const int gy = CoutP / p.ncb;
   // persistent grid: exactly the resident workgroups (occupancy query is host-only and cheap), walking the tiles
-#define CONV_LAUNCH(TZ_, TY_, WM_, WN_, ...)                                                                      \
+#define CONV_LAUNCH_X(XF_, TZ_, TY_, WM_, WN_, ...)                                                                \
   do {                                                                                                            \
     constexpr int nthr = (WM_) * (WN_) * 64;                                                                      \
-    const int per_cu = resident_blocks((const void*)conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__>, nthr);   \
+    const int per_cu = resident_blocks((const void*)conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__, XF_>, nthr); \
     int gx = (256 * per_cu + gy - 1) / gy;                                                                        \
     if (gx > ntiles) gx = ntiles;                                                                                 \
     if (query_gx) { *query_gx = gx; break; }                                                                      \
-    hipLaunchKernelGGL((conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__>), dim3(gx, gy), dim3(nthr), 0, s, x,   \
+    hipLaunchKernelGGL((conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__, XF_>), dim3(gx, gy), dim3(nthr), 0, s, x, \
                        (const float*)wpk, bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z, \
                        ntiles, stats, inorm);                                                                            \
+  } while (0)
+  // XF kernels only where their features are used: a lazily normalised input, or statistics from a direct-store epilogue
+  // (the staged epilogue of Cout 4/8/16 carries its statistics in the plain kernels)
+  const bool xf = inorm.mean != nullptr || (stats != nullptr && !(Cout == 4 || Cout == 8 || Cout == 16)) ||
+                  (query_gx != nullptr && query_xf);
+#define CONV_LAUNCH(TZ_, TY_, WM_, WN_, ...)                                                                      \
+  do {                                                                                                            \
+    if (xf) CONV_LAUNCH_X(true, TZ_, TY_, WM_, WN_, __VA_ARGS__);                                                 \
+    else CONV_LAUNCH_X(false, TZ_, TY_, WM_, WN_, __VA_ARGS__);                                                   \
   } while (0)
   const bool v4 = (Cin & 3) == 0;
   const bool multi = CinP > p.ck;
@@ -1169,12 +1188,16 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
 #undef CONV_CASE_P
 #undef CONV_VM
 #undef CONV_LAUNCH
+#undef CONV_LAUNCH_X
   return query_gx ? MODET_OK : modet_launch_status();
 }
 
-inline int conv_grid_x(int B, int D, int H, int W, int Cin, int Cout) {
+// persistent grid (x) of the plain or the XF instantiation for this shape (they can differ in registers, hence in
+// residency); the statistics buffer is sized by the larger one (conv_stats_rows)
+inline int conv_grid_x(int B, int D, int H, int W, int Cin, int Cout, bool xf) {
   int gx = 0;
-  conv_launch(nullptr, nullptr, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, nullptr, nullptr, &gx);
+  conv_launch(nullptr, nullptr, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, nullptr, nullptr, &gx,
+              ConvIn{nullptr, nullptr, 0}, xf);
   return gx;
 }
 
@@ -1241,12 +1264,16 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
 // normalises (a multiple of 4, at most 128: 2*Cout columns fit the 256-thread finalize)
 static bool conv_stats_ok(int Cin, int Cout) { return Cin != 1 && Cout % 4 == 0 && Cout <= 128; }
 
+// rows per sample of the statistics buffer: the larger persistent grid of the two instantiations (plain / XF)
+static int conv_stats_rows(int B, int D, int H, int W, int Cin, int Cout) {
+  const int a = conv_grid_x(B, D, H, W, Cin, Cout, false), b = conv_grid_x(B, D, H, W, Cin, Cout, true);
+  return a > b ? a : b;
+}
+
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
-  const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
-  const int gx = conv_grid_x(B, D, H, W, Cin, Cout);
   // [sample][workgroup][Cout][2] partial sums, reduced by modet_instnorm_lrelu_fwd_stats / modet_instnorm_stats
-  return (size_t)B * gx * Cout * 2 * sizeof(float);
+  return (size_t)B * conv_stats_rows(B, D, H, W, Cin, Cout) * Cout * 2 * sizeof(float);
 }
 
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
@@ -1257,7 +1284,8 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
   if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
   if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
-  return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats);
+  return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
+                     ConvIn{nullptr, nullptr, conv_stats_rows(B, D, H, W, Cin, Cout)});
 }
 
 int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* w,
@@ -1273,7 +1301,7 @@ int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const floa
     if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   }
   return conv_launch(x_raw, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
-                     ConvIn{in_mean, in_rstd});
+                     ConvIn{in_mean, in_rstd, stats ? conv_stats_rows(B, D, H, W, Cin, Cout) : 0});
 }
 
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,
