@@ -53,13 +53,17 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ out, int D, int H, int W, int C, int G,
                                                        int64_t total, int mode, int add_flow) {
   const int64_t V = (int64_t)D * H * W;
-  for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
-    const int g = (int)(idx % G);
-    const int64_t n = idx / G;                 // b*V + voxel
-    const int64_t b = n / V, v = n - b * V;
-    const int xi = (int)(v % W);
-    const int64_t t2 = v / W;
-    const int yi = (int)(t2 % H), zi = (int)(t2 / H);
+  // 32-bit index arithmetic (the host guarantees total < 2^31): 64-bit div/mod are ~100-instruction software routines
+  const unsigned utotal = (unsigned)total, uG = (unsigned)G, uW = (unsigned)W, uH = (unsigned)H, uD = (unsigned)D;
+  for (unsigned idx = blockIdx.x * BLK + threadIdx.x; idx < utotal; idx += gridDim.x * BLK) {
+    const int g = (int)(idx % uG);
+    const unsigned nn = idx / uG;              // b*V + voxel
+    const int xi = (int)(nn % uW);
+    const unsigned t2 = nn / uW;
+    const int yi = (int)(t2 % uH);
+    const unsigned t3 = t2 / uH;
+    const int zi = (int)(t3 % uD);
+    const int64_t b = t3 / uD, n = nn;
     const float* fp = flow + n * 3;
     const float f0 = fp[0], f1 = fp[1], f2 = fp[2];
     const float z = (float)zi + f0, y = (float)yi + f1, x = (float)xi + f2;
@@ -578,6 +582,7 @@ int modet_warp_fwd(const float* src, const float* flow, float* out, int B, int D
   if (add_flow && (C != 3 || mode != 0)) return MODET_ERR_DIM;
   const int cpt = pick_cpt(C), G = C / cpt;
   const int64_t total = (int64_t)B * D * H * W * G;
+  if (total >= ((int64_t)1 << 31) - (int64_t)256 * 16 * BLK) return MODET_ERR_UNSUPPORTED;     // 32-bit item index
   DISPATCH_CPT(cpt, warp_fwd_kernel, flat_grid(total, BLK), (hipStream_t)stream, src, flow, out, D, H, W, C, G, total,
                mode, add_flow);
   return modet_launch_status();
