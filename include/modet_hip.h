@@ -204,6 +204,17 @@ int modet_label_warp_counts(const int16_t* lab_moving, const float* flow, const 
                             int16_t* warped, int64_t* counts, int D, int H, int W, int nlabels,
                             modet_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * PR++ Correlation3D ("Baseline methods/PR++/models.py":205-232; kernel_size 3, d = 3, sw = 1, sf = 2), SURVEY.md 8(f):
+ *   corr[b][t][p] = (1/27) sum_c box3(mov)[b,p,c] * box3(fix)[b, p + 2*off(t), c],  t = 9i+3j+k, off = (i-1,j-1,k-1),
+ * box3 = zero-padded 3x3x3 box sum (fix's also on the ring just outside the volume, as the reference's padding 3 does).
+ * mov, fix (B,D,H,W,C) channels-last, C % 4 == 0; corr / d_corr (B,27,D,H,W). */
+size_t modet_corr3d_ws_bytes(int B, int D, int H, int W, int C);
+int modet_corr3d_fwd(const float* mov, const float* fix, float* corr, void* ws, size_t ws_bytes, int B, int D, int H,
+                     int W, int C, modet_stream_t stream);
+int modet_corr3d_bwd(const float* mov, const float* fix, const float* d_corr, float* d_mov, float* d_fix, void* ws,
+                     size_t ws_bytes, int B, int D, int H, int W, int C, modet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

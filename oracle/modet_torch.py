@@ -103,6 +103,23 @@ def mode_transformer(q, k, rpb, heads, scale):
     return x.permute(0, 1, 5, 2, 3, 4).reshape(B, heads * 3, D, H, W)
 
 
+def correlation3d(mov, fix, kernel_size=3, d=3, sw=1, sf=2):
+    """PR++ Correlation3D ("Baseline methods/PR++/models.py":205-232): NCDHW features -> (B, d^3, D,H,W).
+    Box sums of both feature maps (grouped all-ones conv), then the channel dot product of mov's with fix's shifted
+    by (i,j,k)*sf - sf voxels, / kernel_size^3."""
+    B, C, H, W, T = mov.shape
+    w = torch.ones((C, 1, kernel_size, kernel_size, kernel_size), dtype=mov.dtype)
+    pm = F.conv3d(mov, w, stride=sw, padding=1, groups=C)
+    pf = F.conv3d(fix, w, stride=sw, padding=sf + 1, groups=C)
+    out = []
+    for i in range(d):
+        for j in range(d):
+            for k in range(d):
+                crop = pf[:, :, i * sf:i * sf + H, j * sf:j * sf + W, k * sf:k * sf + T]
+                out.append((pm * crop).sum(1, keepdim=True))
+    return torch.cat(out, 1) / kernel_size ** 3
+
+
 # ----------------------------------------------------------------------------- warp
 def warp(src, flow, mode="bilinear"):
     """out[b,c,p] = sample(src[b,c], p + flow[b,:,p]), zero padding

@@ -269,6 +269,21 @@ class CoTr(nn.Module):
         return ops.to_ncdhw(ops.neighbourhood_attention(q.contiguous(), k.contiguous(), rpb, 1, 1.0))
 
 
+class Correlation3D(nn.Module):
+    """27-displacement local correlation of the PR++ baseline ("Baseline methods/PR++/models.py":205-232; the only
+    configuration used there: kernel_size 3, d = 3, sw = 1, sf = 2) -- SURVEY.md 8(f) rank 4.
+    ``forward(mov, fix)``: NCDHW features (B,C,H,W,T) -> (B,27,H,W,T); C must be a multiple of 4."""
+
+    def __init__(self, in_channel, kernel_size=3, d=3, sw=1, sf=2):
+        super().__init__()
+        if (kernel_size, d, sw, sf) != (3, 3, 1, 2):
+            raise RuntimeError("Correlation3D supports kernel_size=3, d=3, sw=1, sf=2 only")
+        self.in_channel = in_channel
+
+    def forward(self, mov, fix):
+        return ops.correlation3d(ops.to_channels_last(mov.contiguous()), ops.to_channels_last(fix.contiguous()))
+
+
 class ModeT(nn.Module):
     """reference ModeT/models.py:338-412 (scale=None -> head_dim**-0.5)."""
 

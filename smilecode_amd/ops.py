@@ -529,6 +529,44 @@ class _NA(Function):
         return dq, dk, drpb, None, None
 
 
+class _Corr3d(Function):
+    @staticmethod
+    def forward(ctx, mov, fix):
+        _chk(mov, fix)
+        B, D, H, W, C = mov.shape
+        if fix.shape != mov.shape:
+            raise RuntimeError("correlation3d: mov and fix shapes differ")
+        L = _L()
+        corr = torch.empty((B, 27, D, H, W), dtype=torch.float32, device=mov.device)
+        nb = L.modet_corr3d_ws_bytes(B, D, H, W, C)
+        ws = _ws(nb, mov)
+        n = float(B) * D * H * W
+        with _Guard(mov, f"corr3d_fwd[C{C}]", n * C * (54.0 + 54.0), 4.0 * n * (2 * C + 27)):
+            _lib.check(L.modet_corr3d_fwd(_p(mov), _p(fix), _p(corr), _p(ws), nb, B, D, H, W, C, _stream()), "modet_corr3d_fwd")
+        ctx.save_for_backward(mov, fix)
+        return corr
+
+    @staticmethod
+    def backward(ctx, dcorr):
+        mov, fix = ctx.saved_tensors
+        dcorr = dcorr.contiguous()
+        B, D, H, W, C = mov.shape
+        L = _L()
+        dmov, dfix = torch.empty_like(mov), torch.empty_like(fix)
+        nb = L.modet_corr3d_ws_bytes(B, D, H, W, C)
+        ws = _ws(nb, mov)
+        n = float(B) * D * H * W
+        with _Guard(mov, f"corr3d_bwd[C{C}]", n * C * 4 * 54.0, 4.0 * n * (4 * C + 27)):
+            _lib.check(L.modet_corr3d_bwd(_p(mov), _p(fix), _p(dcorr), _p(dmov), _p(dfix), _p(ws), nb, B, D, H, W, C,
+                                          _stream()), "modet_corr3d_bwd")
+        return dmov, dfix
+
+
+def correlation3d(mov, fix):
+    """PR++ Correlation3D on channels-last features (B,D,H,W,C) -> (B,27,D,H,W); see csrc/corr3d.hip"""
+    return _Corr3d.apply(mov, fix)
+
+
 def neighbourhood_attention(q, k, rpb, heads, scale):
     """Fused ModeTransformer.forward: (B,D,H,W,heads*6) x2 -> (B,D,H,W,heads*3).  reference: models.py:308-334"""
     return _NA.apply(q, k, rpb.contiguous(), heads, scale)

@@ -182,6 +182,37 @@ def test_attention_generic_head_dim_vs_oracle(ops, orc, heads, hd, shape):
     assert_close(np64(dr).reshape(heads, 27), rr.numpy(), atol=2e-4, rtol=1e-4, what="generic attention drpb")
 
 
+@pytest.mark.parametrize("tag", ["c8", "c16", "c4"])
+def test_correlation3d_golden(ops, tag):
+    """PR++ Correlation3D vs the reference's own fp64 output and gradients"""
+    from smilecode_amd import models
+    g = gold("op_corr3d.npz")
+    mov = cu(g[f"{tag}.mov"]).requires_grad_(True)
+    fix = cu(g[f"{tag}.fix"]).requires_grad_(True)
+    y = models.Correlation3D(mov.shape[1]).cuda()(mov, fix)
+    assert_close(np64(y), g[f"{tag}.out"], atol=5e-5, what="corr3d out")
+    dm, df = torch.autograd.grad(y, [mov, fix], cu(g[f"{tag}.gy"]))
+    assert_close(np64(dm), g[f"{tag}.dmov"], atol=1e-4, what="corr3d dmov")
+    assert_close(np64(df), g[f"{tag}.dfix"], atol=1e-4, what="corr3d dfix")
+
+
+@pytest.mark.parametrize("C,shape", [(8, (1, 1, 3)), (12, (9, 10, 33)), (32, (6, 5, 7))])
+def test_correlation3d_vs_oracle(ops, orc, C, shape):
+    """volumes thinner than the displacement, odd channel counts, ragged sizes"""
+    gen = torch.Generator().manual_seed(C + shape[2])
+    mov = torch.randn((2, C) + shape, generator=gen).double().requires_grad_(True)
+    fix = torch.randn((2, C) + shape, generator=gen).double().requires_grad_(True)
+    ref = orc.correlation3d(mov, fix)
+    gy = torch.randn(ref.shape, generator=gen).double()
+    rm, rf = torch.autograd.grad(ref, [mov, fix], gy)
+    md, fd = cl(mov.detach().numpy()).requires_grad_(True), cl(fix.detach().numpy()).requires_grad_(True)
+    y = ops.correlation3d(md, fd)
+    assert_close(np64(y), ref.detach().numpy(), atol=1e-4, rtol=1e-5, what="corr3d out")
+    dm, df = torch.autograd.grad(y, [md, fd], gy.float().cuda())
+    assert_close(ncdhw(dm), rm.numpy(), atol=2e-4, rtol=1e-5, what="corr3d dmov")
+    assert_close(ncdhw(df), rf.numpy(), atol=2e-4, rtol=1e-5, what="corr3d dfix")
+
+
 # ------------------------------------------------------------------------------------------------ projection
 @pytest.mark.parametrize("tag", ["p1", "p3", "p5"])
 def test_projection_golden(ops, tag):
