@@ -93,12 +93,86 @@ def cpu_baseline(shape, workload, budget_s=40.0):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a torchrun environment: re-exec this script under torch.distributed.run with one
+    rank per GPU (what the driver's multi-GPU tier does itself).  Fails loudly when the node has fewer than N devices."""
+    import socket
+    import subprocess
+    backend = os.environ.get("MODET_DIST_BACKEND") or "nccl"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend == "nccl" and have < n:
+        log(f"[bench] ERROR: --gpus {n} requested but only {have} GPU(s) are visible on this node; "
+            "one rank per GPU is required (RCCL over xGMI), refusing to oversubscribe")
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def allreduce_probe(buf, world, iters=20):
+    """average time of one all-reduce(SUM) of the flat gradient buffer and the bus bandwidth it implies
+    (ring convention: 2*(world-1)/world * bytes / t); HIP events on the current stream when the buffer is on a GPU"""
+    if world < 2:
+        return None
+    for _ in range(3):
+        dist.all_reduce(buf)
+    if buf.is_cuda:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        e0.record()
+        for _ in range(iters):
+            dist.all_reduce(buf)
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+    else:
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            dist.all_reduce(buf)
+        us = (time.perf_counter() - t0) * 1e6 / iters
+    t = torch.tensor([us], dtype=torch.float64, device=buf.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    us = float(t.item())
+    nbytes = buf.numel() * buf.element_size()
+    return {"bytes": nbytes, "us": us, "bus_GBps": 2.0 * (world - 1) / world * nbytes / (us * 1e-6) / 1e9,
+            "algbw_GBps": nbytes / (us * 1e-6) / 1e9}
+
+
+def allreduce_only(args, rank, local, world):
+    """--workload allreduce: only the step's one exchange -- the flat 1 029 670-float (4.12 MB) gradient all-reduce --
+    timed K times.  Runs on any backend (gloo on CPU in the tests), so the N-rank launch path can be exercised
+    without GPUs."""
+    on_gpu = dist.is_initialized() and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    buf = torch.ones(1029670, dtype=torch.float32, device=dev)
+    probe = allreduce_probe(buf, world, iters=max(args.steps, 1))
+    if world > 1:
+        assert float(buf[0]) > 1.0                       # the ranks really summed
+    if rank == 0:
+        print(json.dumps({"metric": "gradient all-reduce (1 029 670 fp32)", "value": probe["us"] if probe else None,
+                          "unit": "us", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": False,
+                          "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                          "allreduce": probe, "data": "synthetic", "dtype": "f32",
+                          "config": {"workload": "flat gradient all-reduce only", "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["train", "fwd"], default="train")
+    ap.add_argument("--workload", choices=["train", "fwd", "allreduce"], default="train")
     ap.add_argument("--shape", default="160,192,160")
     ap.add_argument("--batch", type=int, default=1, help="volume pairs per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,9 +184,17 @@ def main():
     from smilecode_amd.engine import Trainer
     from smilecode_amd.parallel import init_from_env
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                       # does not return
     rank, local, world = init_from_env()
     if world != args.gpus:
-        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        log(f"[bench] ERROR: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        sys.exit(2)
+    if args.workload == "allreduce":
+        return allreduce_only(args, rank, local, world)
+    if world > 1 and dist.get_backend() == "nccl" and torch.cuda.device_count() < world:
+        log(f"[bench] ERROR: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -198,6 +280,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    ar_probe = allreduce_probe(trainer.fp.grad, world) if world > 1 else None     # after the timed region, every rank
     if rank == 0:
         pairs = args.steps * args.batch * world
         roof = None
@@ -236,6 +319,10 @@ def main():
                 if args.workload == "train" else "forward+warp")),
                 "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": roof, "host_enqueue_ms_per_step": host_ms,
+            # proof of the N-rank run: what torch.distributed itself reports, and the step's one collective timed alone
+            "backend": dist.get_backend() if world > 1 else None,
+            "world_size": dist.get_world_size() if world > 1 else 1,
+            "allreduce": ar_probe,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -183,10 +183,11 @@ int modet_cwm_tail_bwd(const float* x, const float* logits, const float* d_out, 
 size_t modet_ncc_ws_bytes(int B, int D, int H, int W);
 int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes,
                       int B, int D, int H, int W, modet_stream_t stream);
-/* Grad3d('l2') (losses.py:6-31) on a planar flow (B,3,D,H,W): loss[0], d_flow (NULL to skip). */
+/* Grad3d (losses.py:6-31) on a planar flow (B,3,D,H,W): loss[0], d_flow (NULL to skip).
+ * penalty = 1 ('l1', |forward differences|, the class default) or 2 ('l2', squared; what train.py:104 uses). */
 size_t modet_grad3d_ws_bytes(int B, int D, int H, int W);
 int modet_grad3d_fwd_bwd(const float* flow, float* loss, float* d_flow, void* ws, size_t ws_bytes,
-                         int B, int D, int H, int W, modet_stream_t stream);
+                         int B, int D, int H, int W, int penalty, modet_stream_t stream);
 /* y = x * s[0] with s a DEVICE scalar (chains an upstream scalar gradient without a host sync) */
 int modet_scale_by_dev_scalar(const float* x, const float* s, float* y, int64_t n, modet_stream_t stream);
 
@@ -203,6 +204,13 @@ int modet_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float*
 int modet_label_warp_counts(const int16_t* lab_moving, const float* flow, const int16_t* lab_fixed,
                             int16_t* warped, int64_t* counts, int D, int H, int W, int nlabels,
                             modet_stream_t stream);
+
+/* Evaluation tail, part 2 (utils.py:108-150 jacobian_determinant_vxm, infer.py:89-90): counts[b] (int64, zeroed here) =
+ * number of voxels of sample b whose Jacobian determinant of (identity + flow) is <= 0.  flow (B,D,H,W,3) channels-last
+ * fp32; fp64 arithmetic in the reference's operation order (np.gradient differences, first-row expansion), so the count
+ * is integer-exact.  det_out (B,D,H,W fp64) may be NULL.  Every dim must be >= 2 (np.gradient's own requirement). */
+int modet_jacdet_nonpos_count(const float* flow, int64_t* counts, double* det_out, int B, int D, int H, int W,
+                              modet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PR++ Correlation3D ("Baseline methods/PR++/models.py":205-232; kernel_size 3, d = 3, sw = 1, sf = 2), SURVEY.md 8(f):

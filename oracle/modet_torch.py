@@ -43,17 +43,22 @@ def conv_ins_block(p, name, x):
     return F.leaky_relu(F.instance_norm(y, eps=1e-5), LRELU)
 
 
-def encoder(p, x):
-    """Five-level pyramid (ModeT/models.py:181-228)."""
-    o = conv_block(p, "encoder.conv0.0", x)
-    o = conv_ins_block(p, "encoder.conv0.1", o)
-    o0 = conv_ins_block(p, "encoder.conv0.2", o)
+def encoder(p, x, taps=None, tag=""):
+    """Five-level pyramid (ModeT/models.py:181-228).  ``taps`` receives every block output as ``enc{tag}.{lvl}.{i}``."""
+    def tap(name, t):
+        if taps is not None:
+            taps[f"enc{tag}.{name}"] = t
+        return t
+
+    o = tap("0.0", conv_block(p, "encoder.conv0.0", x))
+    o = tap("0.1", conv_ins_block(p, "encoder.conv0.1", o))
+    o0 = tap("0.2", conv_ins_block(p, "encoder.conv0.2", o))
     outs = [o0]
     cur = o0
     for lvl in range(1, 5):
         cur = F.avg_pool3d(cur, 2)
-        cur = conv_ins_block(p, f"encoder.conv{lvl}.1", cur)
-        cur = conv_ins_block(p, f"encoder.conv{lvl}.2", cur)
+        cur = tap(f"{lvl}.1", conv_ins_block(p, f"encoder.conv{lvl}.1", cur))
+        cur = tap(f"{lvl}.2", conv_ins_block(p, f"encoder.conv{lvl}.2", cur))
         outs.append(cur)
     return outs
 
@@ -180,8 +185,8 @@ def modet_forward(p, moving, fixed, num_heads=(8, 4, 2, 1, 1), head_dim=6, scale
     """ModeT.forward (ModeT/models.py:377-412).  ``scale=None`` -> head_dim**-0.5 (:285).
     ``taps`` (dict) receives named intermediates for per-stage parity tests."""
     sc = scale if scale else head_dim ** -0.5
-    M = encoder(p, moving)
-    Fx = encoder(p, fixed)
+    M = encoder(p, moving, taps, "M")
+    Fx = encoder(p, fixed, taps, "F")
 
     def level(lvl, Ff, Mf):
         heads = num_heads[5 - lvl]
@@ -196,14 +201,19 @@ def modet_forward(p, moving, fixed, num_heads=(8, 4, 2, 1, 1), head_dim=6, scale
             taps[f"w{lvl}"] = w
         return w
 
-    flow = level(5, Fx[4], M[4])
-    w = level(4, Fx[3], warp(M[3], flow))
-    flow = warp(upsample2(2 * flow), w) + w
-    w = level(3, Fx[2], warp(M[2], flow))
-    flow = warp(upsample2(2 * flow), w) + w
-    w = level(2, Fx[1], warp(M[1], flow))
-    flow = upsample2(2 * (warp(flow, w) + w))
-    w = level(1, Fx[0], warp(M[0], flow))
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    flow = tap("flow5", level(5, Fx[4], M[4]))
+    w = level(4, Fx[3], tap("Mw4", warp(M[3], flow)))
+    flow = tap("flow4", warp(upsample2(2 * flow), w) + w)
+    w = level(3, Fx[2], tap("Mw3", warp(M[2], flow)))
+    flow = tap("flow3", warp(upsample2(2 * flow), w) + w)
+    w = level(2, Fx[1], tap("Mw2", warp(M[1], flow)))
+    flow = tap("flow2", upsample2(2 * (warp(flow, w) + w)))
+    w = level(1, Fx[0], tap("Mw1", warp(M[0], flow)))
     flow = warp(flow, w) + w
     y_moved = warp(moving, flow)
     if taps is not None:
@@ -283,3 +293,45 @@ def dice_voi(pred, true, nlabels=54):
         union = float(a.sum()) + float(b.sum())
         tot += 2.0 * inter / (union + 1e-5)
     return tot / nlabels
+
+
+def jacobian_determinant(disp):
+    """jacobian_determinant_vxm (ModeT/utils.py:108-150) for a (3,D,H,W) displacement field -> (D,H,W) float64.
+
+    The reference adds the int64 identity grid to the float32 field (numpy promotes to float64, utils.py:126-130), takes
+    np.gradient (central differences (f[i+1]-f[i-1])/2 inside, one-sided f[1]-f[0] / f[n-1]-f[n-2] at the ends) and
+    expands the 3x3 determinant along its first row (utils.py:139-144).  Same fp64 operations in the same order here,
+    written with explicit slices instead of np.gradient, so the result is bit-identical and `det <= 0` counts are exact."""
+    import numpy as np
+    disp = np.asarray(disp)
+    D, H, W = disp.shape[1:]
+    f = disp.transpose(1, 2, 3, 0).astype(np.float64)
+    grid = np.stack(np.meshgrid(np.arange(D), np.arange(H), np.arange(W), indexing="ij"), 3)
+    f = f + grid
+
+    def grad(ax):
+        g = np.empty_like(f)
+        n = f.shape[ax]
+        ix = [slice(None)] * 4
+
+        def s(a, b=None):
+            j = list(ix)
+            j[ax] = slice(a, b) if b is not None or a != -1 else -1
+            return tuple(j)
+
+        def at(i):
+            j = list(ix)
+            j[ax] = i
+            return tuple(j)
+
+        if n > 2:
+            g[s(1, -1)] = (f[s(2, None)] - f[s(None, -2)]) / 2.0
+        g[at(0)] = (f[at(1)] - f[at(0)]) / 1.0
+        g[at(n - 1)] = (f[at(n - 1)] - f[at(n - 2)]) / 1.0
+        return g
+
+    dx, dy, dz = grad(0), grad(1), grad(2)
+    d0 = dx[..., 0] * (dy[..., 1] * dz[..., 2] - dy[..., 2] * dz[..., 1])
+    d1 = dx[..., 1] * (dy[..., 0] * dz[..., 2] - dy[..., 2] * dz[..., 0])
+    d2 = dx[..., 2] * (dy[..., 0] * dz[..., 1] - dy[..., 1] * dz[..., 0])
+    return d0 - d1 + d2

@@ -57,13 +57,14 @@ SIGNATURES = {
     "modet_ncc_ws_bytes": (SZ, [I, I, I, I]),
     "modet_ncc_fwd_bwd": (I, [P, P, P, P, P, SZ, I, I, I, I, P]),
     "modet_grad3d_ws_bytes": (SZ, [I, I, I, I]),
-    "modet_grad3d_fwd_bwd": (I, [P, P, P, P, SZ, I, I, I, I, P]),
+    "modet_grad3d_fwd_bwd": (I, [P, P, P, P, SZ, I, I, I, I, I, P]),
     "modet_scale_by_dev_scalar": (I, [P, P, P, I64, P]),
     "modet_adam_amsgrad_step": (I, [P, P, P, P, P, I64, F, F, F, F, I, F, P]),
     "modet_corr3d_ws_bytes": (SZ, [I, I, I, I, I]),
     "modet_corr3d_fwd": (I, [P, P, P, P, SZ, I, I, I, I, I, P]),
     "modet_corr3d_bwd": (I, [P, P, P, P, P, P, SZ, I, I, I, I, I, P]),
     "modet_label_warp_counts": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "modet_jacdet_nonpos_count": (I, [P, P, P, I, I, I, I, P]),
 }
 
 _lib = None

@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 100; /* 0.1.0 */ }
+int modet_hip_version(void) { return 200; /* 0.2.0 */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {

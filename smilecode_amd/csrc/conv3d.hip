@@ -69,7 +69,40 @@ struct ConvIn {
   const float* mean;
   const float* rstd;
   int stats_rows;      // rows per sample of the statistics buffer (>= gridDim.x; the tail is zero-filled by workgroup 0)
+  const float* shift;  // [sample][Cout] shift K of the fused statistics (sums of (y - K), (y - K)^2); see conv_shift_kernel
 };
+
+// Shift of the fused InstanceNorm statistics.  The epilogue accumulates sum(y - K) and sum((y - K)^2) in fp32 and the
+// finalize (norm_act.hip) rebuilds mean = K + s1/V, var = s2/V - (s1/V)^2 in fp64.  K[b][co] is the conv output at voxel
+// (1,1,1) of sample b -- for skull-stripped volumes (exact zeros outside the brain, reference makePklDataset.py:19-20) that
+// is the constant every background voxel produces, so more than half of the summands become exact zeros.  Without the
+// shift those identical summands round the SAME way every time they are added to a growing fp32 accumulator: a coherent
+// (not random) error of ~1e-5 in sum(y^2), which var = E[y^2] - E[y]^2 then amplifies by E[y^2]/var (~100 for the first
+// ConvInsBlock, whose input is a LeakyReLU of a non-negative image): 1.5e-4 on the normalised tensor at 160x192x160
+// against 1e-5 for ATen (profiles/r02_attrib_fullsize_before.json), and 5-9e-3 voxels on the final flow.
+// K only has to be NEAR the data (any value is exact in exact arithmetic), so this kernel may sum in any order:
+// one wave per (sample, cout), lanes over (tap, cin).
+__global__ __launch_bounds__(256) void conv_shift_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const float* __restrict__ in_mean,
+                                                         const float* __restrict__ in_rstd, float* __restrict__ shift, int B,
+                                                         int D, int H, int W, int Cin, int Cout) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);          // (b, co)
+  if (item >= B * Cout) return;
+  const int b = item / Cout, co = item - b * Cout;
+  const int z = D > 1 ? 1 : 0, y = H > 1 ? 1 : 0, xx = W > 1 ? 1 : 0;
+  float acc = 0.f;
+  for (int i = lane; i < 27 * Cin; i += 64) {
+    const int tap = i / Cin, c = i - tap * Cin;
+    const int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xq = xx + tap % 3 - 1;
+    if (zz < 0 || zz >= D || yy < 0 || yy >= H || xq < 0 || xq >= W) continue;
+    float v = x[((((int64_t)b * D + zz) * H + yy) * W + xq) * Cin + c];
+    if (in_mean) v = lrelu((v - in_mean[b * Cin + c]) * in_rstd[b * Cin + c]);
+    acc = fmaf(v, w[((int64_t)co * Cin + c) * 27 + tap], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) shift[item] = acc + (bias ? bias[co] : 0.f);
+}
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
 // Persistent workgroups walk (tile, Cin-chunk) stages.  Software pipeline: the global loads of stage s+1 (input
@@ -242,8 +275,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   // bias for the LDS-staged epilogue: a lane always stores channel group c4 = lane % (Cout/4), so its bias float4 is
   // loaded ONCE here.  A load inside the store loop would put an s_waitcnt vmcnt(0) in
   // front of every store, and vmcnt also counts stores: the epilogue would wait for each store's acknowledgement.
-  float4 bq4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (lds_epi_rt && bias) bq4 = *reinterpret_cast<const float4*>(bias + cb0 + (lane % (Cout >> 2)) * 4);
   float bv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -352,7 +383,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     const int64_t xbase = (int64_t)(t / tiles_z) * D * H * W;
     const int cq = Cout >> 2;
     float* ytile = y + (xbase + ((int64_t)z0 * H + y0) * W + x0) * Cout + cb0;
-    if (stats) stat_b = t / tiles_z;
+    // statistics shift of this lane's channel group (see ConvIn): a transient of the flush, NOT held across the MFMA loop
+    // (four more persistent registers cost several configurations a wave of occupancy)
+    float4 bq4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bq4 = *reinterpret_cast<const float4*>(bias + cb0 + (lane % cq) * 4);
+    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (stats) {
+      stat_b = t / tiles_z;
+      k4 = *reinterpret_cast<const float4*>(inorm.shift + stat_b * Cout + cb0 + (lane % cq) * 4);
+    }
 #pragma unroll
     for (int it = 0; it < FL_MAX; ++it) {
       if (fl_stg[it] < 0) continue;
@@ -361,9 +400,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
         float4 v = *reinterpret_cast<const float4*>(stg + fl_stg[it]);
         v.x += bq4.x; v.y += bq4.y; v.z += bq4.z; v.w += bq4.w;
         if (stats) {       // InstanceNorm statistics of the conv output, fused (act == 0 on this path)
-          sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
-          sq[0] = fmaf(v.x, v.x, sq[0]); sq[1] = fmaf(v.y, v.y, sq[1]);
-          sq[2] = fmaf(v.z, v.z, sq[2]); sq[3] = fmaf(v.w, v.w, sq[3]);
+          const float e0 = v.x - k4.x, e1 = v.y - k4.y, e2 = v.z - k4.z, e3 = v.w - k4.w;
+          sx[0] += e0; sx[1] += e1; sx[2] += e2; sx[3] += e3;
+          sq[0] = fmaf(e0, e0, sq[0]); sq[1] = fmaf(e1, e1, sq[1]);
+          sq[2] = fmaf(e2, e2, sq[2]); sq[3] = fmaf(e3, e3, sq[3]);
         }
         if (act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
         *reinterpret_cast<float4*>(ytile + fl_rel[it]) = v;
@@ -460,6 +500,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
             stat_b = bs;
           }
         }
+        float kv[NT];                                          // statistics shift of this lane's couts (see ConvIn)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int co = P > 1 ? li % CoP : cb0 + (wn * NT + n) * 16 + li;
+          kv[n] = (XF && stats && co < Cout) ? inorm.shift[(t / tiles_z) * Cout + co] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int rr = (wm * R + r) * P + (P > 1 ? li / CoP : 0);
@@ -473,7 +519,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
               for (int j = 0; j < 4; ++j) {
                 if (x0 + lk * 4 + j < W) {
                   float v = acc[r][n][j] + bv[n];
-                  if (XF && stats) { dsx[n] += v; dsq[n] = fmaf(v, v, dsq[n]); }
+                  if (XF && stats) { const float e = v - kv[n]; dsx[n] += e; dsq[n] = fmaf(e, e, dsq[n]); }
                   if (act) v = lrelu(v);
                   yrow[j * Cout + co] = v;
                 }
@@ -1130,13 +1176,21 @@ inline size_t fwd_ws_elems(int Cin, int Cout) {
 // query_gx != null: only report the persistent grid's x size (the statistics layout depends on it), launch nothing
 int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
                 int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr, int* query_gx = nullptr,
-                ConvIn inorm = ConvIn{nullptr, nullptr, 0}, bool query_xf = false) {
+                ConvIn inorm = ConvIn{nullptr, nullptr, 0, nullptr}, bool query_xf = false) {
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 9 * (p.P + 2) * CinP * CoutP;
-  if (!query_gx)
+  if (!query_gx) {
     hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
                        wpk, Cin, Cout, CinP, CoutP, pack_mode, p.P);
+    if (stats) {
+      // the statistics buffer starts with the [B][Cout] shift header; the partial rows follow it
+      hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, s, x, w, bias, inorm.mean, inorm.rstd,
+                         stats, B, D, H, W, Cin, Cout);
+      inorm.shift = stats;
+      stats += (size_t)B * Cout;
+    }
+  }
   const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
   const int ntiles = tiles_x * tiles_y * tiles_z * B;
   const int gy = CoutP / p.ncb;
@@ -1197,7 +1251,7 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
 inline int conv_grid_x(int B, int D, int H, int W, int Cin, int Cout, bool xf) {
   int gx = 0;
   conv_launch(nullptr, nullptr, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, nullptr, nullptr, &gx,
-              ConvIn{nullptr, nullptr, 0}, xf);
+              ConvIn{nullptr, nullptr, 0, nullptr}, xf);
   return gx;
 }
 
@@ -1272,8 +1326,9 @@ static int conv_stats_rows(int B, int D, int H, int W, int Cin, int Cout) {
 
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
-  // [sample][workgroup][Cout][2] partial sums, reduced by modet_instnorm_lrelu_fwd_stats / modet_instnorm_stats
-  return (size_t)B * conv_stats_rows(B, D, H, W, Cin, Cout) * Cout * 2 * sizeof(float);
+  // [sample][Cout] shift header, then [sample][workgroup][Cout][2] partial sums of (y - shift), (y - shift)^2; reduced by
+  // modet_instnorm_lrelu_fwd_stats / modet_instnorm_stats
+  return ((size_t)B * Cout + (size_t)B * conv_stats_rows(B, D, H, W, Cin, Cout) * Cout * 2) * sizeof(float);
 }
 
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
@@ -1285,7 +1340,7 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
   if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
-                     ConvIn{nullptr, nullptr, conv_stats_rows(B, D, H, W, Cin, Cout)});
+                     ConvIn{nullptr, nullptr, conv_stats_rows(B, D, H, W, Cin, Cout), nullptr});
 }
 
 int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* w,
@@ -1301,7 +1356,7 @@ int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const floa
     if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   }
   return conv_launch(x_raw, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
-                     ConvIn{in_mean, in_rstd, stats ? conv_stats_rows(B, D, H, W, Cin, Cout) : 0});
+                     ConvIn{in_mean, in_rstd, stats ? conv_stats_rows(B, D, H, W, Cin, Cout) : 0, nullptr});
 }
 
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,

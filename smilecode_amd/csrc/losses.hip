@@ -210,7 +210,9 @@ __global__ void scalar_finalize_kernel(const float* __restrict__ part, int n, do
   }
 }
 
-// Grad3d('l2'): flow (B,3,D,H,W) planar.  loss = (mean dH^2 + mean dD^2 + mean dW^2)/3 (losses.py:17-27).
+// Grad3d: flow (B,3,D,H,W) planar.  'l2': loss = (mean dH^2 + mean dD^2 + mean dW^2)/3; 'l1' (L1 = true): the same with
+// |d| instead of d^2 (losses.py:11-27); the gradient of |t| at t = 0 is 0, as torch.abs's backward (sign(0) = 0).
+template <bool L1>
 __global__ __launch_bounds__(BLK) void grad3d_kernel(const float* __restrict__ f, float* __restrict__ df,
                                                      float* __restrict__ part, Dims d, int64_t N, float inD, float inH,
                                                      float inW) {
@@ -222,13 +224,16 @@ __global__ __launch_bounds__(BLK) void grad3d_kernel(const float* __restrict__ f
     decode(i, d, z, y, x);
     const float v = f[i];
     float g = 0.f;
-    if (z + 1 < d.D) { const float t = f[i + sD] - v; lsum = fmaf(t * t, inD, lsum); g -= t * inD; }
-    if (z > 0)       { const float t = v - f[i - sD]; g += t * inD; }
-    if (y + 1 < d.H) { const float t = f[i + sH] - v; lsum = fmaf(t * t, inH, lsum); g -= t * inH; }
-    if (y > 0)       { const float t = v - f[i - sH]; g += t * inH; }
-    if (x + 1 < d.W) { const float t = f[i + 1] - v;  lsum = fmaf(t * t, inW, lsum); g -= t * inW; }
-    if (x > 0)       { const float t = v - f[i - 1];  g += t * inW; }
-    if (df) df[i] = g * (2.f / 3.f);
+    // pen(t) = t^2 (l2) or |t| (l1); dpen(t) = t (the factor 2 is applied at the end) or sign(t)
+    auto pen = [](float t) { return L1 ? fabsf(t) : t * t; };
+    auto dpen = [](float t) { return L1 ? (t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f)) : t; };
+    if (z + 1 < d.D) { const float t = f[i + sD] - v; lsum = fmaf(pen(t), inD, lsum); g -= dpen(t) * inD; }
+    if (z > 0)       { const float t = v - f[i - sD]; g += dpen(t) * inD; }
+    if (y + 1 < d.H) { const float t = f[i + sH] - v; lsum = fmaf(pen(t), inH, lsum); g -= dpen(t) * inH; }
+    if (y > 0)       { const float t = v - f[i - sH]; g += dpen(t) * inH; }
+    if (x + 1 < d.W) { const float t = f[i + 1] - v;  lsum = fmaf(pen(t), inW, lsum); g -= dpen(t) * inW; }
+    if (x > 0)       { const float t = v - f[i - 1];  g += dpen(t) * inW; }
+    if (df) df[i] = g * (L1 ? 1.f / 3.f : 2.f / 3.f);
   }
   const float r = block_sum(lsum, red);
   if (threadIdx.x == 0) part[blockIdx.x] = r;
@@ -281,7 +286,8 @@ int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, v
 size_t modet_grad3d_ws_bytes(int, int, int, int) { return 2048 * sizeof(float); }
 
 int modet_grad3d_fwd_bwd(const float* flow, float* loss, float* d_flow, void* ws, size_t ws_bytes, int B, int D, int H,
-                         int W, modet_stream_t stream) {
+                         int W, int penalty, modet_stream_t stream) {
+  MODET_CHECK_DIM(penalty == 1 || penalty == 2);
   MODET_CHECK_PTR(flow); MODET_CHECK_PTR(loss); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1);
   if (ws_bytes < modet_grad3d_ws_bytes(B, D, H, W)) return MODET_ERR_WORKSPACE;
@@ -292,7 +298,8 @@ int modet_grad3d_fwd_bwd(const float* flow, float* loss, float* d_flow, void* ws
   const float inH = (float)(1.0 / ((double)B * 3 * D * (H - 1) * W));
   const float inW = (float)(1.0 / ((double)B * 3 * D * H * (W - 1)));
   const int rg = red_grid(N);
-  hipLaunchKernelGGL(grad3d_kernel, dim3(rg), dim3(BLK), 0, s, flow, d_flow, (float*)ws, d, N, inD, inH, inW);
+  if (penalty == 1) hipLaunchKernelGGL(grad3d_kernel<true>, dim3(rg), dim3(BLK), 0, s, flow, d_flow, (float*)ws, d, N, inD, inH, inW);
+  else hipLaunchKernelGGL(grad3d_kernel<false>, dim3(rg), dim3(BLK), 0, s, flow, d_flow, (float*)ws, d, N, inD, inH, inW);
   hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(BLK), 0, s, (const float*)ws, rg, 1.0 / 3.0, loss);
   return modet_launch_status();
 }

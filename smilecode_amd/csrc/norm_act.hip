@@ -55,14 +55,14 @@ __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict
   for (int c = 0; c < 4; ++c) { red[threadIdx.x * 8 + c] = a[c]; red[threadIdx.x * 8 + 4 + c] = q[c]; }
   __syncthreads();
   if (threadIdx.x < G) {
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // fp64: no coherent rounding when the lanes' sums are alike
     for (int j = 0; j < VPB; ++j) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) s[c] += red[(j * G + threadIdx.x) * 8 + c];
+      for (int c = 0; c < 8; ++c) s[c] += (double)red[(j * G + threadIdx.x) * 8 + c];
     }
     float* p = part + (((int64_t)b * gridDim.x + blockIdx.x) * C + threadIdx.x * 4) * 2;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { p[c * 2] = s[c]; p[c * 2 + 1] = s[4 + c]; }
+    for (int c = 0; c < 4; ++c) { p[c * 2] = (float)s[c]; p[c * 2 + 1] = (float)s[4 + c]; }
   }
 }
 
@@ -90,22 +90,23 @@ __global__ __launch_bounds__(64) void in_finalize_kernel(const float* __restrict
   }
 }
 
-// statistics from the conv epilogue's partial rows stats[(b*rows_per_b + r)][C][2] (one row per workgroup of the conv):
-// one workgroup per sample, coalesced fixed-order fp64 column sums, then mean / rstd per channel
+// statistics from the conv epilogue: stats = [B][C] shift K, then partial rows [(b*rows_per_b + r)][C][2] of
+// sum(y - K), sum((y - K)^2) (one row per workgroup of the conv; see ConvIn in conv3d.hip for why they are shifted):
+// one workgroup per sample, coalesced fixed-order fp64 column sums, then mean = K + s1/V, var = s2/V - (s1/V)^2 in fp64
 __global__ __launch_bounds__(256) void in_rows_finalize_kernel(const float* __restrict__ stats, float* __restrict__ mean,
                                                                float* __restrict__ rstd, int64_t V, int C,
                                                                int64_t rows_per_b, float eps) {
   __shared__ double sm[256];
   __shared__ double tot[256];
-  const int b = blockIdx.x;
-  block_colsum_256(stats + (int64_t)b * rows_per_b * 2 * C, 0, rows_per_b, 2 * C, tot, sm);
+  const int b = blockIdx.x, B = gridDim.x;
+  block_colsum_256(stats + (int64_t)B * C + (int64_t)b * rows_per_b * 2 * C, 0, rows_per_b, 2 * C, tot, sm);
   __syncthreads();
   if ((int)threadIdx.x < C) {
     const int c = threadIdx.x;
     const double m = tot[2 * c] / (double)V;
     double var = tot[2 * c + 1] / (double)V - m * m;
     if (var < 0.0) var = 0.0;
-    mean[b * C + c] = (float)m;
+    mean[b * C + c] = (float)((double)stats[b * C + c] + m);
     rstd[b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
@@ -258,8 +259,10 @@ int modet_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd,
 }
 
 static int rows_from_bytes(size_t stats_bytes, int B, int C, int64_t* rows) {
-  *rows = (int64_t)(stats_bytes / sizeof(float)) / ((int64_t)B * C * 2);
-  return (*rows > 0 && (size_t)*rows * B * C * 2 * sizeof(float) == stats_bytes) ? MODET_OK : MODET_ERR_DIM;
+  // B*C shift header + rows * B*C*2 partial sums (modet_conv3d_stats_bytes)
+  const int64_t n = (int64_t)(stats_bytes / sizeof(float)), bc = (int64_t)B * C;
+  *rows = (n / bc - 1) / 2;
+  return (*rows > 0 && (size_t)(bc + *rows * bc * 2) * sizeof(float) == stats_bytes) ? MODET_OK : MODET_ERR_DIM;
 }
 
 int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float* rstd, const float* stats,

@@ -26,6 +26,7 @@ class Trainer:
         self.v = torch.zeros_like(self.fp.flat)
         self.vmax = torch.zeros_like(self.fp.flat)
         self.step = 0
+        self.lr_last = lr
         self.sim = NCC_vxm()
         self.reg = Grad3d(penalty="l2")
 
@@ -44,10 +45,60 @@ class Trainer:
         self.fp.gather_grads()
         scale = self.fp.allreduce_grads(self.group)
         self.step += 1
-        ops.adam_amsgrad_step_(self.fp.flat, self.fp.grad, self.m, self.v, self.vmax,
-                               poly_lr(epoch, self.max_epoch, self.lr0), self.step, self.betas[0], self.betas[1],
-                               self.eps, scale)
+        self.lr_last = poly_lr(epoch, self.max_epoch, self.lr0)
+        ops.adam_amsgrad_step_(self.fp.flat, self.fp.grad, self.m, self.v, self.vmax, self.lr_last, self.step,
+                               self.betas[0], self.betas[1], self.eps, scale)
         return loss.detach(), sim.detach(), reg.detach()
+
+    # ---------------------------------------------------------------- optimizer state, torch.optim.Adam's format
+    def state_dict(self):
+        """The dict ``torch.optim.Adam(model.parameters(), amsgrad=True).state_dict()`` would hold at this point -- what the
+        reference saves under ``'optimizer'`` (train.py:158-163): ``state[i] = {step, exp_avg, exp_avg_sq,
+        max_exp_avg_sq}`` per parameter (in ``model.parameters()`` order, sliced out of the flat fused buffers) and one
+        ``param_groups`` entry.  A consumer can ``optimizer.load_state_dict()`` it into a real torch Adam."""
+        state = {}
+        if self.step > 0:
+            for i, (p, (off, k)) in enumerate(zip(self.fp.params, self.fp.offsets)):
+                state[i] = {"step": torch.tensor(float(self.step)),
+                            "exp_avg": self.m[off:off + k].view(p.shape).clone(),
+                            "exp_avg_sq": self.v[off:off + k].view(p.shape).clone(),
+                            "max_exp_avg_sq": self.vmax[off:off + k].view(p.shape).clone()}
+        group = {"lr": self.lr_last, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": True,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.fp.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """restore Adam's moments and step count from ``state_dict()``'s format (ours or a checkpoint the reference's
+        torch.optim.Adam wrote for the same model)"""
+        if "state" not in sd or "param_groups" not in sd:
+            raise RuntimeError("Trainer.load_state_dict: not a torch.optim.Adam state dict (keys: %s)" % sorted(sd))
+        st = sd["state"]
+        n = len(self.fp.params)
+        if len(st) not in (0, n):
+            raise RuntimeError(f"Trainer.load_state_dict: optimizer state has {len(st)} entries, the model {n} parameters")
+        self.m.zero_(); self.v.zero_(); self.vmax.zero_()
+        self.step = 0
+        steps = set()
+        for i, (p, (off, k)) in enumerate(zip(self.fp.params, self.fp.offsets)):
+            e = st.get(i, st.get(str(i)))
+            if e is None:
+                continue
+            if e.get("max_exp_avg_sq", None) is None:
+                raise RuntimeError("Trainer.load_state_dict: the checkpoint's Adam was not amsgrad=True")
+            for buf, key in ((self.m, "exp_avg"), (self.v, "exp_avg_sq"), (self.vmax, "max_exp_avg_sq")):
+                t = e[key]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise RuntimeError(f"Trainer.load_state_dict: parameter {i}: {key} {tuple(t.shape)} vs {tuple(p.shape)}")
+                buf[off:off + k].copy_(t.reshape(-1).to(buf.device, torch.float32))
+            steps.add(int(float(e["step"])))
+        if len(steps) > 1:
+            raise RuntimeError(f"Trainer.load_state_dict: parameters disagree on the step count: {sorted(steps)}")
+        if steps:
+            self.step = steps.pop()
+        g = sd["param_groups"][0]
+        self.betas, self.eps = tuple(g.get("betas", self.betas)), g.get("eps", self.eps)
+        self.lr_last = g.get("lr", self.lr_last)
 
     @torch.no_grad()
     def infer(self, moving, fixed):

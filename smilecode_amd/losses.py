@@ -8,17 +8,17 @@ from . import ops
 
 
 class Grad3d(torch.nn.Module):
-    """N-D gradient loss (reference losses.py:6-31).  Only penalty='l2' (what train.py:104 uses) is native."""
+    """N-D gradient loss (reference losses.py:6-31): penalty 'l1' (the class default) or 'l2' (what train.py:104 uses)."""
 
     def __init__(self, penalty="l1", loss_mult=None):
         super().__init__()
+        if penalty not in ("l1", "l2"):
+            raise RuntimeError(f"Grad3d: unknown penalty {penalty!r} (the reference knows 'l1' and 'l2', losses.py:21)")
         self.penalty = penalty
         self.loss_mult = loss_mult
 
     def forward(self, y_pred, y_true=None):
-        if self.penalty != "l2":
-            raise RuntimeError("Grad3d: only penalty='l2' is implemented on the HIP path (train.py:104)")
-        grad = ops.grad3d_loss(y_pred.contiguous())
+        grad = ops.grad3d_loss(y_pred.contiguous(), self.penalty)
         if self.loss_mult is not None:
             grad = grad * self.loss_mult
         return grad

@@ -722,32 +722,46 @@ def _scale_by(x, s):
     return y
 
 
+def _ncc_launch(I, J, want_grad):
+    """modet_ncc_fwd_bwd(I, J): (loss (1,), d loss / d J or None)"""
+    B, _, D, H, W = I.shape
+    loss = torch.empty(1, dtype=torch.float32, device=I.device)
+    dJ = torch.empty_like(J) if want_grad else None
+    L = _L()
+    nb = L.modet_ncc_ws_bytes(B, D, H, W)
+    ws = _ws(nb, I)
+    nv = float(I.numel())               # reads I,J once, writes d_J once
+    with _Guard(I, "ncc_fwd_bwd", 400.0 * nv, 12.0 * nv):
+        _lib.check(L.modet_ncc_fwd_bwd(_p(I), _p(J), _p(loss), _p(dJ), _p(ws), nb, B, D, H, W, _stream()), "modet_ncc_fwd_bwd")
+    return loss, dJ
+
+
 class _NCC(Function):
+    """cc is symmetric in its two arguments (losses.py:85-93), so the gradient w.r.t. y_true is the kernel's d_J with
+    the roles swapped.  The reference's train loop differentiates the FIRST argument (train.py:127:
+    ``loss_function(output[n], y)`` = NCC_vxm.forward(y_true=y_moved, y_pred=fixed))."""
+
     @staticmethod
     def forward(ctx, y_true, y_pred):
         _chk(y_true, y_pred)
         if y_true.shape != y_pred.shape or y_true.dim() != 5 or y_true.shape[1] != 1:
             raise RuntimeError("NCC: expects two (B,1,D,H,W) volumes")
-        B, _, D, H, W = y_true.shape
-        loss = torch.empty(1, dtype=torch.float32, device=y_true.device)
-        need = ctx.needs_input_grad[1]
-        if ctx.needs_input_grad[0]:
-            raise RuntimeError("NCC: gradient w.r.t. y_true is not implemented (the fixed image is an input)")
-        dJ = torch.empty_like(y_pred) if need else None
-        L = _L()
-        nb = L.modet_ncc_ws_bytes(B, D, H, W)
-        ws = _ws(nb, y_true)
-        nv = float(y_true.numel())               # reads I,J once, writes d_J once
-        with _Guard(y_true, "ncc_fwd_bwd", 400.0 * nv, 12.0 * nv):
-            _lib.check(L.modet_ncc_fwd_bwd(_p(y_true), _p(y_pred), _p(loss), _p(dJ), _p(ws), nb, B, D, H, W, _stream()),
-                       "modet_ncc_fwd_bwd")
-        ctx.save_for_backward(dJ)
+        need_t, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_t = d_p = None
+        if need_t and not need_p:
+            loss, d_t = _ncc_launch(y_pred, y_true, True)
+        else:
+            loss, d_p = _ncc_launch(y_true, y_pred, need_p)
+            if need_t:
+                _, d_t = _ncc_launch(y_pred, y_true, True)
+        ctx.save_for_backward(d_t, d_p)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        (dJ,) = ctx.saved_tensors
-        return None, _scale_by(dJ, g.contiguous().reshape(1))
+        d_t, d_p = ctx.saved_tensors
+        g = g.contiguous().reshape(1)
+        return (None if d_t is None else _scale_by(d_t, g)), (None if d_p is None else _scale_by(d_p, g))
 
 
 def ncc_loss(y_true, y_pred):
@@ -757,7 +771,7 @@ def ncc_loss(y_true, y_pred):
 
 class _Grad3d(Function):
     @staticmethod
-    def forward(ctx, flow):
+    def forward(ctx, flow, penalty):
         _chk(flow)
         if flow.dim() != 5 or flow.shape[1] != 3:
             raise RuntimeError("Grad3d: expects a (B,3,D,H,W) flow")
@@ -768,7 +782,7 @@ class _Grad3d(Function):
         nb = L.modet_grad3d_ws_bytes(B, D, H, W)
         ws = _ws(nb, flow)
         with _Guard(flow, "grad3d_fwd_bwd", 20.0 * flow.numel(), 8.0 * flow.numel()):
-            _lib.check(L.modet_grad3d_fwd_bwd(_p(flow), _p(loss), _p(df), _p(ws), nb, B, D, H, W, _stream()),
+            _lib.check(L.modet_grad3d_fwd_bwd(_p(flow), _p(loss), _p(df), _p(ws), nb, B, D, H, W, int(penalty), _stream()),
                        "modet_grad3d_fwd_bwd")
         ctx.save_for_backward(df)
         return loss.reshape(())
@@ -776,12 +790,14 @@ class _Grad3d(Function):
     @staticmethod
     def backward(ctx, g):
         (df,) = ctx.saved_tensors
-        return _scale_by(df, g.contiguous().reshape(1))
+        return _scale_by(df, g.contiguous().reshape(1)), None
 
 
-def grad3d_loss(flow):
-    """Grad3d(penalty='l2') on a planar (B,3,D,H,W) flow.  reference: losses.py:6-31"""
-    return _Grad3d.apply(flow)
+def grad3d_loss(flow, penalty="l2"):
+    """Grad3d(penalty='l1' | 'l2') on a planar (B,3,D,H,W) flow.  reference: losses.py:6-31"""
+    if penalty not in ("l1", "l2"):
+        raise RuntimeError(f"Grad3d: unknown penalty {penalty!r}")
+    return _Grad3d.apply(flow, 1 if penalty == "l1" else 2)
 
 
 # ------------------------------------------------------------------------------------------------ non-autograd
@@ -808,3 +824,19 @@ def label_warp_counts(lab_moving, flow_cl, lab_fixed, nlabels=54, want_warped=Tr
         _lib.check(_L().modet_label_warp_counts(_p(lm), _p(flow_cl), _p(lf), _p(warped), _p(counts), D, H, W, nlabels,
                                                 _stream()), "modet_label_warp_counts")
     return warped, counts
+
+
+def jacdet_nonpos_count(flow_cl, want_det=False):
+    """number of voxels per sample whose Jacobian determinant of (identity + flow) is <= 0, on the GPU, in the
+    reference's fp64 operation order (utils.py:108-150, infer.py:89-90).  flow_cl (B,D,H,W,3) channels-last fp32.
+    Returns (counts int64 (B,), det float64 (B,D,H,W) or None)."""
+    _chk(flow_cl)
+    B, D, H, W, C = flow_cl.shape
+    if C != 3:
+        raise RuntimeError("jacdet_nonpos_count: expects a (B,D,H,W,3) channels-last flow")
+    counts = torch.empty(B, dtype=torch.int64, device=flow_cl.device)
+    det = torch.empty((B, D, H, W), dtype=torch.float64, device=flow_cl.device) if want_det else None
+    with _Guard(flow_cl, "jacdet", 60.0 * flow_cl.numel() / 3, 4.0 * flow_cl.numel()):
+        _lib.check(_L().modet_jacdet_nonpos_count(_p(flow_cl), _p(counts), _p(det), B, D, H, W, _stream()),
+                   "modet_jacdet_nonpos_count")
+    return counts, det

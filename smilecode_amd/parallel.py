@@ -40,6 +40,15 @@ def pairs_for_rank(n_pairs: int, rank: int, world: int):
     return list(range(rank, n_pairs, world))
 
 
+def lockstep_pairs_for_rank(n_pairs: int, rank: int, world: int):
+    """round-robin shard with the SAME number of entries on every rank: when ``n_pairs % world != 0`` the list wraps
+    around (as torch's DistributedSampler pads), so every rank runs ``ceil(n_pairs / world)`` steps.  Each step holds a
+    blocking gradient all-reduce; ranks with different step counts would pair all-reduces of different steps (and of
+    different epochs' learning rates) and hang at the end of training."""
+    per_rank = (n_pairs + world - 1) // world
+    return [(rank + i * world) % n_pairs for i in range(per_rank)]
+
+
 class FlatParams:
     """All parameters (and their gradients) of a module as views into two flat fp32 buffers, so the
     gradient all-reduce is one collective and the optimizer is one kernel."""

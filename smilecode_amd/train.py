@@ -16,12 +16,11 @@ import sys
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader
 
 from . import data, utils
 from .engine import Trainer, poly_lr
 from .models import ModeT
-from .parallel import init_from_env, pairs_for_rank
+from .parallel import init_from_env, lockstep_pairs_for_rank
 
 
 def same_seeds(seed):
@@ -61,6 +60,14 @@ def save_checkpoint(state, save_dir="models", filename="checkpoint.pth.tar", max
         model_lists = sorted(glob.glob(save_dir + "*"), key=_natkey)
 
 
+def latest_checkpoint(model_dir):
+    """the file the reference resumes from: the naturally-sorted LAST one = highest Dice (train.py:83)"""
+    files = sorted(os.listdir(model_dir), key=_natkey)
+    if not files:
+        raise RuntimeError(f"--cont-training: no checkpoint in {model_dir}")
+    return os.path.join(model_dir, files[-1])
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--train-dir", default="/LPBA_path/Train/")
@@ -71,6 +78,12 @@ def main(argv=None):
     ap.add_argument("--max-iters", type=int, default=0, help="stop each epoch after this many iterations (0 = all)")
     ap.add_argument("--lr", type=float, default=0.0001)
     ap.add_argument("--out", default=".")
+    ap.add_argument("--cont-training", action="store_true", help="resume from the best checkpoint (train.py:61,:80-85)")
+    ap.add_argument("--epoch-start", type=int, default=0, help="first epoch of a resumed run (train.py:59)")
+    ap.add_argument("--no-restore-optimizer", action="store_true",
+                    help="resume exactly like the reference: weights only, Adam restarts from zero moments (train.py:84)")
+    ap.add_argument("--host-loader", action="store_true",
+                    help="read the .pkl pair from the host every iteration instead of caching all subjects in HBM")
     args = ap.parse_args(argv)
     same_seeds(24)
     rank, local, world = init_from_env()
@@ -90,7 +103,21 @@ def main(argv=None):
         f = open(os.path.join(log_dir, "losses and dice.txt"), "a")
 
     model = ModeT(img_size, head_dim=head_dim, num_heads=num_heads, scale=1).cuda()
+    best_dsc = 0
+    resume = None
+    if args.cont_training:
+        ck = latest_checkpoint(exp_dir)
+        resume = torch.load(ck, map_location="cpu")
+        model.load_state_dict(resume["state_dict"])
+        if rank == 0:
+            print(ck)
     trainer = Trainer(model, lr=args.lr, max_epoch=args.max_epoch, weights=weights)   # Adam(amsgrad) + NCC + Grad3d('l2')
+    if resume is not None and not args.no_restore_optimizer and isinstance(resume.get("optimizer"), dict) \
+            and "state" in resume["optimizer"]:
+        # the reference saves optimizer.state_dict() but never loads it back (train.py:80-85): a resumed run restarts
+        # Adam's moments from zero.  We restore them, so save -> resume -> next step is identical to never stopping.
+        trainer.load_state_dict(resume["optimizer"])
+        best_dsc = resume.get("best_dsc", 0)
 
     if args.synthetic:
         train_set = data.SyntheticPairs(img_size, args.synthetic, 24)
@@ -98,43 +125,57 @@ def main(argv=None):
     else:
         train_set = data.LPBABrainDatasetS2S(glob.glob(args.train_dir + "*.pkl"))
         val_set = data.LPBABrainInferDatasetS2S(glob.glob(args.val_dir + "*.pkl"))
-    val_loader = DataLoader(val_set, batch_size=1, shuffle=False, num_workers=0, pin_memory=True, drop_last=True)
+    # every subject resident in HBM, pairs indexed there; rank 0 alone validates
+    train_cache = None if args.host_loader else data.DeviceVolumeCache(train_set)
+    val_cache = None if (args.host_loader or rank != 0) else data.DeviceVolumeCache(val_set, with_labels=True)
 
-    best_dsc = 0
-    for epoch in range(args.max_epoch):
+    def train_pair(i):
+        if train_cache is not None:
+            return train_cache.pair(i)
+        x, y = train_set[i][:2]
+        return x[None].pin_memory().cuda(non_blocking=True), y[None].pin_memory().cuda(non_blocking=True)
+
+    def val_pairs():
+        for i in range(len(val_set)):
+            if val_cache is not None:
+                yield val_cache.pair(i)
+            else:
+                yield tuple(t[None].cuda() for t in val_set[i])
+
+    for epoch in range(args.epoch_start, args.max_epoch):
         if rank == 0:
             print("Training Starts")
         loss_all = utils.AverageMeter()
         order = np.random.RandomState(24 + epoch).permutation(len(train_set))      # same shuffle on every rank
-        mine = [int(order[i]) for i in pairs_for_rank(len(order), rank, world)]
+        # identical step count on every rank (wrap-around padding): each step holds a blocking all-reduce
+        mine = [int(order[i]) for i in lockstep_pairs_for_rank(len(order), rank, world)]
         n_iter = len(mine) if not args.max_iters else min(len(mine), args.max_iters)
         for idx in range(1, n_iter + 1):
-            x, y = train_set[mine[idx - 1]][:2]
-            x, y = x[None].cuda(non_blocking=True), y[None].cuda(non_blocking=True)
+            x, y = train_pair(mine[idx - 1])
             loss, sim, reg = trainer.train_step(x, y, epoch=epoch)      # lr = poly_lr(epoch) inside (train.py:117)
-            loss_all.update(loss.item(), y.numel())
             if rank == 0:
-                print("Iter {} of {} loss {:.4f}, Img Sim: {:.6f}, Reg: {:.6f}".format(idx, n_iter, loss.item(), sim.item(),
-                                                                                     reg.item()))
-        if rank != 0:
-            continue
-        print("{} Epoch {} loss {:.4f}".format(save_dir, epoch, loss_all.avg))
-        print("Epoch {} loss {:.4f}".format(epoch, loss_all.avg), file=f, end=" ")
-        eval_dsc = utils.AverageMeter()
-        with torch.no_grad():
-            model.eval()
-            for batch in val_loader:
-                x, y, x_seg, y_seg = [t.cuda() for t in batch]
-                _, flow = model(x, y)
-                _, dsc = utils.warp_labels_and_dice(x_seg, flow, y_seg)     # fused GPU eval tail (train.py:152-153)
-                eval_dsc.update(dsc, x.size(0))
-                print(epoch, ":", eval_dsc.avg)
-        best_dsc = max(eval_dsc.avg, best_dsc)
-        print(eval_dsc.avg, file=f)
-        f.flush()
-        save_checkpoint({"epoch": epoch + 1, "state_dict": model.state_dict(), "best_dsc": best_dsc,
-                         "optimizer": {"step": trainer.step, "lr": poly_lr(epoch, args.max_epoch, args.lr)}},
-                        save_dir=exp_dir, filename="dsc{:.3f}.pth.tar".format(eval_dsc.avg))
+                lv = loss.item()                                        # one host sync per iteration, as train.py:130
+                loss_all.update(lv, y.numel())
+                print("Iter {} of {} loss {:.4f}, Img Sim: {:.6f}, Reg: {:.6f}".format(idx, n_iter, lv, sim.item(), reg.item()))
+        if rank == 0:
+            print("{} Epoch {} loss {:.4f}".format(save_dir, epoch, loss_all.avg))
+            print("Epoch {} loss {:.4f}".format(epoch, loss_all.avg), file=f, end=" ")
+            eval_dsc = utils.AverageMeter()
+            with torch.no_grad():
+                model.eval()
+                for x, y, x_seg, y_seg in val_pairs():
+                    _, flow = model(x, y)
+                    _, dsc = utils.warp_labels_and_dice(x_seg, flow, y_seg)     # fused GPU eval tail (train.py:152-153)
+                    eval_dsc.update(dsc, x.size(0))
+                    print(epoch, ":", eval_dsc.avg)
+            best_dsc = max(eval_dsc.avg, best_dsc)
+            print(eval_dsc.avg, file=f)
+            f.flush()
+            save_checkpoint({"epoch": epoch + 1, "state_dict": model.state_dict(), "best_dsc": best_dsc,
+                             "optimizer": trainer.state_dict()},
+                            save_dir=exp_dir, filename="dsc{:.3f}.pth.tar".format(eval_dsc.avg))
+        if world > 1:
+            torch.distributed.barrier()             # nobody starts the next epoch's all-reduces while rank 0 validates
     return best_dsc
 
 

@@ -74,16 +74,20 @@ def warp_labels_and_dice(x_seg, flow, y_seg, nlabels=54):
     return warped[None, None], dice_from_counts(counts, nlabels)
 
 
+def jacobian_nonpositive_fraction(flow):
+    """fraction of voxels with det(J) <= 0 per sample, as infer.py:89-90 reports it (np.sum(jac_det <= 0) / n_voxels),
+    computed on the GPU from the model's flow (B,3,D,H,W): no D2H of the field, one integer per sample comes back."""
+    flow_cl = ops.to_channels_last(flow.float().contiguous())
+    counts, _ = ops.jacdet_nonpos_count(flow_cl)
+    nvox = float(flow.shape[2] * flow.shape[3] * flow.shape[4])
+    return [float(c) / nvox for c in counts.tolist()]
+
+
 def jacobian_determinant_vxm(disp):
-    """Jacobian determinant of a (3,D,H,W) displacement field with np.gradient, as the reference evaluates it on
-    the CPU (utils.py:108-150; `pystrum.volsize2ndgrid` is just the identity index grid).  Post-processing, not part
-    of the GPU hot path."""
-    disp = np.asarray(disp).transpose(1, 2, 3, 0)
-    vol = disp.shape[:-1]
-    grid = np.stack(np.meshgrid(*[np.arange(s) for s in vol], indexing="ij"), len(vol))
-    J = np.gradient(disp + grid)
-    dx, dy, dz = J[0], J[1], J[2]
-    d0 = dx[..., 0] * (dy[..., 1] * dz[..., 2] - dy[..., 2] * dz[..., 1])
-    d1 = dx[..., 1] * (dy[..., 0] * dz[..., 2] - dy[..., 2] * dz[..., 0])
-    d2 = dx[..., 2] * (dy[..., 0] * dz[..., 1] - dy[..., 1] * dz[..., 0])
-    return d0 - d1 + d2
+    """Jacobian determinant of a (3,D,H,W) displacement field (reference utils.py:108-150): float64 (D,H,W) numpy array,
+    computed by the HIP kernel in the reference's operation order (np.gradient differences of flow + identity grid,
+    first-row expansion).  Accepts a numpy array or a tensor, as the reference's callers pass `flow.cpu().numpy()[0]`."""
+    t = torch.as_tensor(np.ascontiguousarray(disp) if isinstance(disp, np.ndarray) else disp).float().cuda()
+    flow_cl = t.permute(1, 2, 3, 0).contiguous()[None]
+    _, det = ops.jacdet_nonpos_count(flow_cl, want_det=True)
+    return det[0].cpu().numpy()

@@ -1,0 +1,97 @@
+"""Golden vectors for the evaluation tail and the loss variants, generated from the REAL reference (build container only).
+
+    python tests/golden/make_goldens_eval.py
+
+Imports /root/reference/ModeT/{utils,losses}.py read-only (never copied, never shipped):
+  * ``utils.jacobian_determinant_vxm`` (utils.py:108-150) on seeded float32 displacement fields -> the determinant
+    volume's summary and the integer count of voxels with det <= 0 that infer.py:89-90 reports.  ``pystrum`` is absent
+    from this image; its ``volsize2ndgrid`` is the identity index grid and is stubbed as such;
+  * ``losses.Grad3d(penalty='l1')`` value and gradient (losses.py:11-27);
+  * ``losses.NCC_vxm`` differentiated w.r.t. its FIRST argument, the way train.py:127 calls it.
+Writes tests/golden/op_eval.npz (data only) and appends the oracle-vs-reference deviations to REPORT_eval.txt.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/ModeT")
+warnings.filterwarnings("ignore")
+
+# pystrum.pynd.ndutils.volsize2ndgrid(volsize) == np.meshgrid(*[np.arange(s)], indexing='ij') (identity index grid)
+nd = types.ModuleType("pystrum.pynd.ndutils")
+nd.volsize2ndgrid = lambda volsize: np.meshgrid(*[np.arange(s) for s in volsize], indexing="ij")
+pynd = types.ModuleType("pystrum.pynd")
+pynd.ndutils = nd
+pystrum = types.ModuleType("pystrum")
+pystrum.pynd = pynd
+sys.modules.update({"pystrum": pystrum, "pystrum.pynd": pynd, "pystrum.pynd.ndutils": nd})
+
+import utils as ref_utils      # noqa: E402  (reference)
+import losses as ref_losses    # noqa: E402  (reference)
+
+from smilecode_amd import synth            # noqa: E402
+from oracle import modet_torch as orc      # noqa: E402
+
+REPORT = []
+out = {}
+
+# ---------------------------------------------------------------- Jacobian determinant (three fields: smooth, folding, tiny)
+cases = [("a", (20, 24, 28), 3, 1.5), ("b", (16, 12, 10), 5, 6.0), ("c", (2, 3, 2), 7, 2.0)]
+for tag, shape, seed, amp in cases:
+    flow = synth.make_flow(shape, seed=seed, amp=amp)[0]                 # (3,D,H,W) float32
+    det = ref_utils.jacobian_determinant_vxm(flow)
+    assert det.dtype == np.float64
+    out[f"jac.{tag}.shape"] = np.array(shape)
+    out[f"jac.{tag}.seed"] = np.array([seed])
+    out[f"jac.{tag}.amp"] = np.array([amp])
+    out[f"jac.{tag}.flow"] = flow
+    out[f"jac.{tag}.det"] = det
+    out[f"jac.{tag}.nonpos"] = np.array([int(np.sum(det <= 0))], dtype=np.int64)
+    d_or = orc.jacobian_determinant(flow)
+    REPORT.append(f"jacdet[{tag}] {shape}: max|oracle-ref| = {np.abs(d_or - det).max():.3e}, nonpos ref {int(np.sum(det <= 0))} "
+                  f"oracle {int(np.sum(d_or <= 0))} of {det.size}")
+    assert np.array_equal(d_or, det), "oracle restatement must be bit-identical (same fp64 operation order)"
+
+# ---------------------------------------------------------------- Grad3d l1
+fl = torch.from_numpy(synth.make_flow((10, 12, 14), seed=9, amp=2.0, batch=2)).double().requires_grad_(True)
+l = ref_losses.Grad3d(penalty="l1")(fl, None)
+(gf,) = torch.autograd.grad(l, fl)
+out["g3d_l1.flow"], out["g3d_l1.val"], out["g3d_l1.dflow"] = fl.detach().numpy(), np.array(float(l)), gf.numpy()
+REPORT.append(f"grad3d l1: |oracle-ref| = {abs(float(orc.grad3d_loss(fl.detach(), 'l1')) - float(l)):.3e}")
+
+# ---------------------------------------------------------------- NCC, gradient w.r.t. the first argument (train.py:127 order)
+_to, _ones = torch.Tensor.to, torch.ones
+
+
+def _cpu_to(self, *a, **k):          # losses.py:57 hard-codes .to("cuda")
+    a = tuple("cpu" if (isinstance(x, str) and x == "cuda") else x for x in a)
+    return _to(self, *a, **k)
+
+
+torch.Tensor.to = _cpu_to
+torch.ones = lambda *a, **k: _ones(*a, **{**k, "dtype": torch.float64})     # the all-ones filter in the inputs' dtype
+try:
+    mov, fix = synth.make_pair((20, 24, 20), 41)
+    a = torch.from_numpy(mov).double().requires_grad_(True)      # y_true slot = the warped image in train.py:127
+    b = torch.from_numpy(fix).double()
+    lv = ref_losses.NCC_vxm()(a, b)
+    (ga,) = torch.autograd.grad(lv, a)
+finally:
+    torch.Tensor.to, torch.ones = _to, _ones
+out["ncc1.a"], out["ncc1.b"], out["ncc1.val"], out["ncc1.da"] = mov, fix, np.array(float(lv)), ga.numpy()
+a2 = torch.from_numpy(mov).double().requires_grad_(True)
+lo = orc.ncc_loss(a2, b)
+(gao,) = torch.autograd.grad(lo, a2)
+REPORT.append(f"ncc first-arg: |oracle-ref| value {abs(float(lo) - float(lv)):.3e}, grad {float((gao - ga).abs().max()):.3e}")
+
+np.savez_compressed(os.path.join(HERE, "op_eval.npz"), **out)
+with open(os.path.join(HERE, "REPORT_eval.txt"), "w") as f:
+    f.write("\n".join(REPORT) + "\n")
+print("\n".join(REPORT))

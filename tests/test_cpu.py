@@ -38,7 +38,7 @@ def test_library_builds_loads_and_exports_header_symbols():
         assert hasattr(lib, name), f"{name} declared in include/modet_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(declared)
-    assert lib.modet_hip_version() >= 100
+    assert lib.modet_hip_version() >= 200
     assert _lib.strerror(0) == "ok" and "NULL" in _lib.strerror(-1)
     # pure host entry points (no device needed)
     assert lib.modet_na_bwd_ws_bytes(1, 160, 192, 160, 1) >= 10 * 24 * 80 * 27 * 4
@@ -216,6 +216,144 @@ def test_data_parallel_allreduce_gloo_world2():
     assert not np.allclose(res[0][2], res[1][2])
 
 
+def _lockstep_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from smilecode_amd.parallel import FlatParams, broadcast_parameters, init_from_env, lockstep_pairs_for_rank
+    init_from_env("gloo")
+    torch.manual_seed(3)
+    net = torch.nn.Linear(4, 2)
+    fp = FlatParams(net)
+    broadcast_parameters(fp)
+    n_pairs, steps = 5, 0                                   # 5 % 2 != 0: the ADVICE r1 case (870 pairs over 8 ranks)
+    samples = torch.arange(n_pairs * 4, dtype=torch.float32).view(n_pairs, 4)
+    for epoch in range(2):
+        order = np.random.RandomState(24 + epoch).permutation(n_pairs)
+        for i in lockstep_pairs_for_rank(n_pairs, rank, world):
+            fp.zero_grad()
+            net(samples[int(order[i])][None]).sum().backward()
+            fp.gather_grads()
+            scale = fp.allreduce_grads()                     # blocking: every rank must arrive the same number of times
+            with torch.no_grad():
+                fp.flat.add_(fp.grad, alpha=-0.01 * (epoch + 1) * scale)
+            steps += 1
+        dist.barrier()
+    q.put((rank, steps, fp.flat.clone().numpy()))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_lockstep_uneven_pairs_gloo_world2():
+    """n_pairs % world != 0 over several steps and epochs: every rank runs the same number of all-reduces (wrap-around
+    padding), nobody hangs, replicas stay bit-identical (train.py gave ranks 109 vs 108 steps)"""
+    import torch.multiprocessing as mp
+    from smilecode_amd.parallel import lockstep_pairs_for_rank
+    for n, w in ((5, 2), (870, 8), (7, 8), (16, 8)):
+        shards = [lockstep_pairs_for_rank(n, r, w) for r in range(w)]
+        assert len({len(sh) for sh in shards}) == 1 and len(shards[0]) == -(-n // w)
+        assert set(sum(shards, [])) == set(range(n))                     # every pair is visited
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29411 + os.getpid() % 200
+    procs = [ctx.Process(target=_lockstep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 6
+    assert np.array_equal(res[0][2], res[1][2])
+
+
+def test_bench_self_launches_n_ranks_and_refuses_missing_gpus():
+    """`python bench.py --gpus N` (no torchrun env) must itself start N ranks and prove it in the JSON line; with fewer
+    than N GPUs it must fail loudly instead of silently running world=1.  Exercised on gloo with the
+    all-reduce-only workload: same launcher, same rendezvous, no GPU needed."""
+    import json
+    env = dict(os.environ, MODET_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "allreduce", "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["backend"] == "gloo"
+    assert line["allreduce"]["bytes"] == 1029670 * 4 and line["allreduce"]["us"] > 0
+    if not torch.cuda.is_available():
+        env.pop("MODET_DIST_BACKEND")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 2 and "only 0 GPU(s)" in r.stderr and r.stdout.strip() == ""
+
+
+def test_trainer_state_dict_is_torch_adam_compatible():
+    """'optimizer' entry of the checkpoint (train.py:158-163): what we save loads into a real torch.optim.Adam(amsgrad) and
+    what torch saves loads into the Trainer (host-side logic, runs on CPU tensors)"""
+    from smilecode_amd.engine import Trainer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    tr = Trainer(net, lr=1e-4)
+    assert tr.state_dict()["state"] == {}                                 # nothing stepped yet, like a fresh Adam
+    tr.m.normal_(); tr.v.uniform_(0.1, 1.0); tr.vmax.copy_(tr.v * 2)
+    tr.step, tr.lr_last = 3, 5e-5
+    sd = tr.state_dict()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0, amsgrad=True)
+    opt.load_state_dict(sd)                                               # strict: raises on any format mismatch
+    for i, p in enumerate(net.parameters()):
+        off, k = tr.fp.offsets[i]
+        st = opt.state[p]
+        assert float(st["step"]) == 3.0
+        assert torch.equal(st["exp_avg"].reshape(-1), tr.m[off:off + k])
+        assert torch.equal(st["max_exp_avg_sq"].reshape(-1), tr.vmax[off:off + k])
+    assert opt.param_groups[0]["lr"] == 5e-5 and opt.param_groups[0]["amsgrad"] is True
+    # a torch optimizer that really stepped -> Trainer
+    for p in net.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()
+    tr2 = Trainer(torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3)))
+    tr2.load_state_dict(opt.state_dict())
+    assert tr2.step == 4
+    sd2 = tr2.state_dict()
+    for i, p in enumerate(net.parameters()):
+        for key in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            assert torch.equal(sd2["state"][i][key], opt.state[p][key])
+    with pytest.raises(RuntimeError):
+        tr2.load_state_dict({"step": 1, "lr": 1e-4})                       # round 1's stub format is rejected loudly
+
+
+def test_save_checkpoint_rotation_keeps_the_eight_best(tmp_path):
+    """save_checkpoint (train.py:171-176): at most 8 files, the naturally-sorted first (lowest Dice) goes first"""
+    from smilecode_amd.train import latest_checkpoint, save_checkpoint
+    d = str(tmp_path) + "/"
+    dscs = [0.512, 0.498, 0.530, 0.100, 0.527, 0.610, 0.605, 0.590, 0.611, 0.045, 0.700]
+    for v in dscs:
+        save_checkpoint({"epoch": 1, "dsc": v}, save_dir=d, filename="dsc{:.3f}.pth.tar".format(v))
+    left = sorted(os.listdir(d))
+    assert len(left) == 8
+    assert left == sorted("dsc{:.3f}.pth.tar".format(v) for v in sorted(dscs)[-8:])
+    assert latest_checkpoint(d).endswith("dsc0.700.pth.tar")             # what --cont-training resumes from (train.py:83)
+
+
+def test_device_volume_cache_indexes_pairs_like_the_datasets(tmp_path):
+    """DeviceVolumeCache (here on the CPU device) hands out the same pairs as the reference-shaped datasets"""
+    import pickle
+    from smilecode_amd import data
+    rng = np.random.default_rng(0)
+    for i in range(4):
+        with open(tmp_path / f"s{i}.pkl", "wb") as f:
+            pickle.dump((rng.random((4, 6, 5), dtype=np.float32), rng.choice([0, 21, 34, 166, 999], (4, 6, 5)).astype(np.uint16)), f)
+    ds = data.LPBABrainInferDatasetS2S([str(p) for p in tmp_path.glob("*.pkl")])
+    cache = data.DeviceVolumeCache(ds, device="cpu", with_labels=True, workers=2)
+    assert len(cache) == len(ds) == 12
+    for i in range(len(ds)):
+        want, got = ds[i], cache.pair(i)
+        for w, g in zip(want, got):
+            assert g.shape == (1,) + tuple(w.shape) and g.dtype == w.dtype and torch.equal(g[0], w)
+    syn = data.SyntheticPairs((8, 8, 8), 3, 24)
+    c2 = data.DeviceVolumeCache(syn, device="cpu")
+    x, y = c2.pair(4)
+    assert torch.equal(x[0], syn[4][0]) and torch.equal(y[0], syn[4][1])
+
+
 def test_data_pipeline_pairs_and_label_remap(tmp_path):
     """all-ordered-pairs indexing and Seg_norm table of the reference (datasets.py:24-26, trans.py:27-39)"""
     import pickle
@@ -236,12 +374,26 @@ def test_data_pipeline_pairs_and_label_remap(tmp_path):
     assert xs.dtype == torch.int16 and int(xs[0, 0, 0, 0]) == 2 and int(ys[0, 0, 0, 0]) == 1
 
 
-def test_jacobian_determinant_identity_and_fold():
-    from smilecode_amd.utils import jacobian_determinant_vxm
+def test_oracle_eval_goldens(orc):
+    """oracle restatements of jacobian_determinant_vxm / Grad3d('l1') / first-argument NCC against the vectors captured
+    from the reference itself (tests/golden/make_goldens_eval.py)"""
+    g = gold("op_eval.npz")
+    for tag in "abc":
+        det = orc.jacobian_determinant(g[f"jac.{tag}.flow"])
+        assert np.array_equal(det, g[f"jac.{tag}.det"]), "same fp64 operations in the same order: bit-identical"
+        assert int(np.sum(det <= 0)) == int(g[f"jac.{tag}.nonpos"][0])
     disp = np.zeros((3, 6, 7, 8), np.float32)
-    assert np.allclose(jacobian_determinant_vxm(disp), 1.0)
+    assert np.array_equal(orc.jacobian_determinant(disp), np.ones((6, 7, 8)))
     disp[0] = -2.0 * np.arange(6)[:, None, None]            # x -> -x: folding
-    assert (jacobian_determinant_vxm(disp) < 0).all()
+    assert (orc.jacobian_determinant(disp) < 0).all()
+    f = T(g["g3d_l1.flow"]).requires_grad_(True)
+    l = orc.grad3d_loss(f, "l1")
+    assert abs(float(l) - float(g["g3d_l1.val"])) < 1e-12
+    assert_close(torch.autograd.grad(l, f)[0].numpy(), g["g3d_l1.dflow"], atol=1e-15, rtol=1e-12, what="grad3d l1 dflow")
+    a = T(g["ncc1.a"]).requires_grad_(True)
+    l = orc.ncc_loss(a, T(g["ncc1.b"]))
+    assert abs(float(l) - float(g["ncc1.val"])) < 1e-12
+    assert_close(torch.autograd.grad(l, a)[0].numpy(), g["ncc1.da"], atol=1e-15, rtol=1e-9, what="ncc d y_true")
 
 
 # ------------------------------------------------------------------------------------------------ C oracle pins

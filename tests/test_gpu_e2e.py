@@ -289,6 +289,63 @@ def test_data_parallel_two_ranks_equal_batch_two(tmp_path):
     assert np.abs(ranks[0]["flat"] - f1)[sig].max() < 2e-5
 
 
+def test_checkpoint_resume_is_identical_to_never_stopping(tmp_path):
+    """save {'state_dict','optimizer'} -> load into a fresh model/Trainer -> the next step lands on exactly
+    the parameters an uninterrupted run reaches (Adam m/v/vmax/step restored; all kernels deterministic -> bitwise)"""
+    from smilecode_amd.engine import Trainer
+    shape = (32, 48, 32)
+    mov, fix = _pair(shape)
+    a = Trainer(_model(shape, 1.0))
+    for _ in range(3):
+        a.train_step(mov, fix, epoch=1)
+    b = Trainer(_model(shape, 1.0))
+    for _ in range(2):
+        b.train_step(mov, fix, epoch=1)
+    path = str(tmp_path / "ck.pth.tar")
+    torch.save({"epoch": 2, "state_dict": b.model.state_dict(), "best_dsc": 0.5, "optimizer": b.state_dict()}, path)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck["optimizer"]) == {"state", "param_groups"} and len(ck["optimizer"]["state"]) == len(list(b.model.parameters()))
+    from smilecode_amd import models
+    m = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).cuda()
+    m.load_state_dict(ck["state_dict"])
+    c = Trainer(m)
+    c.load_state_dict(ck["optimizer"])
+    assert c.step == 2
+    c.train_step(mov, fix, epoch=1)
+    assert torch.equal(c.fp.flat, a.fp.flat), "resumed run diverged from the uninterrupted one"
+    assert torch.equal(c.vmax, a.vmax) and torch.equal(c.m, a.m)
+    # without the optimizer state (the reference's own resume, train.py:80-85) the step differs: the test is not vacuous
+    m2 = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).cuda()
+    m2.load_state_dict(ck["state_dict"])
+    d = Trainer(m2)
+    d.train_step(mov, fix, epoch=1)
+    assert not torch.equal(d.fp.flat, a.fp.flat)
+
+
+def test_reference_train_loop_call_order(tmp_path):
+    """the reference's own loop body (train.py:122-133) on our modules: losses are called as
+    loss_function(output[n], y), i.e. the tensor that needs gradients is NCC's FIRST argument"""
+    from smilecode_amd import losses
+    shape = (32, 48, 32)
+    model = _model(shape, 1.0)
+    x, y = _pair(shape)
+    criterions = [losses.NCC_vxm(), losses.Grad3d(penalty="l2")]
+    weights = [1, 1]
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, amsgrad=True)
+    output = model(x, y)
+    loss = 0
+    for n, loss_function in enumerate(criterions):
+        loss = loss + loss_function(output[n], y) * weights[n]
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    g = gold("e2e_32x48x32.npz")
+    assert abs(float(loss) - float(g["loss"][0])) < 2e-4
+    ref = g["grad.mdt1.rpb"]
+    got = np64(model.mdt1.rpb.grad).reshape(-1)
+    assert np.abs(got - ref.reshape(-1)).max() <= 2e-2 * np.abs(ref).max()
+
+
 def test_train_and_infer_scripts_synthetic(tmp_path):
     """the train.py / infer.py equivalents run end to end (synthetic subjects, 64^3, 2 iterations), write the
     reference's checkpoint dict and log files, and the checkpoint loads back through infer."""
@@ -305,6 +362,15 @@ def test_train_and_infer_scripts_synthetic(tmp_path):
     assert len(ck) == 1
     sd = torch.load(ck[0], map_location="cpu")
     assert set(sd) == {"epoch", "state_dict", "best_dsc", "optimizer"} and "encoder.conv0.0.main.weight" in sd["state_dict"]
+    assert set(sd["optimizer"]) == {"state", "param_groups"} and float(sd["optimizer"]["state"][0]["step"]) == 2.0
+    # resume (train.py:59-62,:80-85): --cont-training --epoch-start 1 picks the checkpoint up and runs epoch 1
+    try:
+        train.main(["--synthetic", "3", "--img-size", "64,64,64", "--max-epoch", "2", "--max-iters", "1", "--out", out,
+                    "--cont-training", "--epoch-start", "1"])
+    finally:
+        sys.stdout = stdout
+    cks = [torch.load(c, map_location="cpu") for c in _glob.glob(out + "/experiments/*/dsc*.pth.tar")]
+    assert max(float(c["optimizer"]["state"][0]["step"]) for c in cks) == 3.0 and max(c["epoch"] for c in cks) == 2
     log = open(_glob.glob(out + "/logs/*/logfile.log")[0]).read()
     assert "Iter 1 of 2 loss" in log and "Img Sim:" in log
     d = infer.main(["--synthetic", "2", "--img-size", "64,64,64", "--model-dir", os.path.dirname(ck[0]) + "/"])

@@ -421,6 +421,69 @@ def test_grad3d_golden(ops):
     assert_close(np64(df), g["g3d.dflow"], atol=1e-7, rtol=1e-4, what="grad3d dflow")
 
 
+def test_ncc_first_argument_gradient_golden(ops):
+    """the reference's train loop differentiates the FIRST argument: loss_function(output[n], y) = NCC_vxm.forward(
+    y_true=y_moved, y_pred=fixed) (train.py:127); golden from the reference's own NCC_vxm in that order"""
+    from smilecode_amd import losses
+    g = gold("op_eval.npz")
+    a, b = cu(g["ncc1.a"]).requires_grad_(True), cu(g["ncc1.b"])
+    l = losses.NCC_vxm()(a, b)
+    assert_close(np64(l), g["ncc1.val"], atol=2e-5, what="ncc value")
+    l.backward()
+    assert_close(np64(a.grad), g["ncc1.da"], atol=2e-6, rtol=2e-3, what="ncc d y_true")
+    # both arguments at once: each gradient equals its one-sided counterpart
+    g2 = gold("op_misc.npz")
+    a2, b2 = cu(g2["ncc.a"]).requires_grad_(True), cu(g2["ncc.b"]).requires_grad_(True)
+    da, db = torch.autograd.grad(ops.ncc_loss(a2, b2), [a2, b2])
+    assert_close(np64(da), g2["ncc.da"], atol=2e-6, rtol=2e-3, what="ncc d y_true (both)")
+    assert_close(np64(db), g2["ncc.db"], atol=2e-6, rtol=2e-3, what="ncc d y_pred (both)")
+
+
+def test_grad3d_l1_golden(ops):
+    """Grad3d's class default penalty (losses.py:11), golden from the reference's own Grad3d('l1')"""
+    from smilecode_amd import losses
+    g = gold("op_eval.npz")
+    f = cu(g["g3d_l1.flow"]).requires_grad_(True)
+    l = losses.Grad3d()(f, None)                 # default-constructed, as the reference allows
+    assert_close(np64(l), g["g3d_l1.val"], what="grad3d l1 value")
+    df = torch.autograd.grad(l, f)[0]
+    assert_close(np64(df), g["g3d_l1.dflow"], atol=1e-7, rtol=1e-4, what="grad3d l1 dflow")
+    with pytest.raises(RuntimeError):
+        losses.Grad3d(penalty="l3")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_jacobian_determinant_golden(ops, tag):
+    """det(J) <= 0 count of infer.py:89-90 on the GPU: integer-exact against the reference's jacobian_determinant_vxm
+    (float64 np.gradient arithmetic reproduced operation for operation), incl. a field that folds and a 2x3x2 volume
+    where every difference is one-sided"""
+    from smilecode_amd import utils
+    g = gold("op_eval.npz")
+    flow = torch.from_numpy(g[f"jac.{tag}.flow"]).cuda()             # (3,D,H,W) float32
+    fcl = flow.permute(1, 2, 3, 0).contiguous()[None]
+    counts, det = ops.jacdet_nonpos_count(fcl, want_det=True)
+    assert np.array_equal(det[0].cpu().numpy(), g[f"jac.{tag}.det"]), "determinant must be bit-identical to the reference's"
+    assert int(counts[0]) == int(g[f"jac.{tag}.nonpos"][0])
+    assert np.array_equal(utils.jacobian_determinant_vxm(g[f"jac.{tag}.flow"]), g[f"jac.{tag}.det"])
+    frac = utils.jacobian_nonpositive_fraction(flow[None])
+    assert frac[0] == int(g[f"jac.{tag}.nonpos"][0]) / float(np.prod(g[f"jac.{tag}.shape"]))
+    # batch of two: per-sample counts
+    c2, _ = ops.jacdet_nonpos_count(torch.cat([fcl, torch.zeros_like(fcl)], 0).contiguous())
+    assert c2.tolist() == [int(g[f"jac.{tag}.nonpos"][0]), 0]
+
+
+def test_jacobian_count_full_size_vs_oracle(ops, orc):
+    """160x192x160: the GPU count equals the oracle's numpy restatement of the reference function, voxel for voxel"""
+    from smilecode_amd import synth
+    shape = (160, 192, 160)
+    flow = synth.make_flow(shape, seed=11, amp=5.0)[0]
+    det = orc.jacobian_determinant(flow)
+    fcl = torch.from_numpy(flow).cuda().permute(1, 2, 3, 0).contiguous()[None]
+    counts, d = ops.jacdet_nonpos_count(fcl, want_det=True)
+    assert int(counts[0]) == int(np.sum(det <= 0)) and int(counts[0]) > 0
+    assert np.array_equal(d[0].cpu().numpy(), det)
+
+
 def test_adam_amsgrad(ops, orc):
     gen = torch.Generator().manual_seed(9)
     n = 100003
