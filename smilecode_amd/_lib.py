@@ -11,7 +11,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmodet_hip.so")
+# MODET_HIP_LIB: load another build of the same library (A/B timing of kernel variants on one box, tools/ab_kernels.py)
+LIB_PATH = os.environ.get("MODET_HIP_LIB") or os.path.join(_HERE, "lib", "libmodet_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "modet_hip.h")
 
 P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -88,6 +89,8 @@ def load():
             "(the ModeT hot path has no CPU / eager fallback)")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if not hasattr(lib, name) and os.environ.get("MODET_HIP_LIB"):
+            continue        # an older build loaded for A/B timing may predate an entry point; the product library may not
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -111,7 +111,10 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(const float* __restrict
 // matrix work (PMC before this change: MFMA pipe 54 % busy, 36 % of wave cycles in s_waitcnt/barrier).
 // XF ("extra features", inference): the lazy-InstanceNorm input transform (ConvIn) and statistics from the direct-store
 // epilogue.  Compiled out of the kernels training uses: carrying them as run-time options cost those 4 %.
-template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P, bool MULTI, bool XF>
+// ST: the staged epilogue also produces the fused InstanceNorm statistics (forward convs of ConvInsBlocks with
+// Cout 4/8/16).  A compile-time switch: as a run-time option the statistics registers and the shift load cost the
+// kernels that never use them (dgrad, plain convs) 4-5 % (tools/ab_kernels.py, r01 vs r02a builds on one box).
+template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P, bool MULTI, bool XF, bool ST = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ y, int D,
                                                            int H, int W, int Cin, int Cout, int CinP, int CoutP, int act,
@@ -132,6 +135,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   constexpr int OC = P > 1 ? CoP : NCB;
   constexpr bool STG = (P > 1) || (NCB == 16);                     // the L1/L2 configs (16-wide N tile)
   __shared__ __attribute__((aligned(16))) float stg[STG ? ROWS * TX * OC : 4];
+  constexpr bool HAS_STATS = XF || ST;       // statistics code exists in this instantiation
+  // statistics shift K of the CURRENT sample for this block's <= 16 channels (staged epilogue): read back with the
+  // staging tile's own LDS reads, so the flush waits for no extra global load (see ConvIn)
+  __shared__ __attribute__((aligned(16))) float ksm[(HAS_STATS && STG) ? 16 : 4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -275,12 +282,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
   // bias for the LDS-staged epilogue: a lane always stores channel group c4 = lane % (Cout/4), so its bias float4 is
   // loaded ONCE here.  A load inside the store loop would put an s_waitcnt vmcnt(0) in
   // front of every store, and vmcnt also counts stores: the epilogue would wait for each store's acknowledgement.
+  float4 bq4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lds_epi_rt && bias) bq4 = *reinterpret_cast<const float4*>(bias + cb0 + (lane % (Cout >> 2)) * 4);
   float bv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = P > 1 ? li % CoP : cb0 + (wn * NT + n) * 16 + li;
     bv[n] = (bias && co < Cout) ? bias[co] : 0.f;
   }
+  const int tiles_per_b = tiles_x * tiles_y * tiles_z;
+  if (HAS_STATS && STG && stats && lds_epi_rt && tid < 16)        // shift of the first tile's sample (visible after the
+    ksm[tid] = cb0 + tid < Cout ? inorm.shift[(tile / tiles_per_b) * Cout + cb0 + tid] : 0.f;   // loop's first barrier)
 
   if constexpr (!MULTI) {
     for (int idx = tid; idx < NTAP * CK * QW; idx += NTHR) {
@@ -384,13 +396,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     const int cq = Cout >> 2;
     float* ytile = y + (xbase + ((int64_t)z0 * H + y0) * W + x0) * Cout + cb0;
     // statistics shift of this lane's channel group (see ConvIn): a transient of the flush, NOT held across the MFMA loop
-    // (four more persistent registers cost several configurations a wave of occupancy)
-    float4 bq4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) bq4 = *reinterpret_cast<const float4*>(bias + cb0 + (lane % cq) * 4);
+    // (four more persistent registers cost several configurations a wave of occupancy), read from LDS
     float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (stats) {
+    if (HAS_STATS && stats) {
       stat_b = t / tiles_z;
-      k4 = *reinterpret_cast<const float4*>(inorm.shift + stat_b * Cout + cb0 + (lane % cq) * 4);
+      k4 = *reinterpret_cast<const float4*>(ksm + (lane % cq) * 4);
     }
 #pragma unroll
     for (int it = 0; it < FL_MAX; ++it) {
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
       if (z < D && yy < H && xx < W) {
         float4 v = *reinterpret_cast<const float4*>(stg + fl_stg[it]);
         v.x += bq4.x; v.y += bq4.y; v.z += bq4.z; v.w += bq4.w;
-        if (stats) {       // InstanceNorm statistics of the conv output, fused (act == 0 on this path)
+        if (HAS_STATS && stats) {       // InstanceNorm statistics of the conv output, fused (act == 0 on this path)
           const float e0 = v.x - k4.x, e1 = v.y - k4.y, e2 = v.z - k4.z, e3 = v.w - k4.w;
           sx[0] += e0; sx[1] += e1; sx[2] += e2; sx[3] += e3;
           sq[0] = fmaf(e0, e0, sq[0]); sq[1] = fmaf(e1, e1, sq[1]);
@@ -411,9 +421,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     }
     ptile = -1;
     // last tile of this sample for this workgroup?  emit now, while the staging buffer is free
-    if (stats && next_tile >= 0 && next_tile / (tiles_x * tiles_y * tiles_z) != stat_b) {
-      emit_stats(stat_b);
+    if (HAS_STATS && stats && next_tile >= 0 && next_tile / tiles_per_b != stat_b) {
+      emit_stats(stat_b);              // ends with a barrier: every wave has finished reading ksm for this sample
       stat_b = -1;
+      if (tid < 16) ksm[tid] = cb0 + tid < Cout ? inorm.shift[(next_tile / tiles_per_b) * Cout + cb0 + tid] : 0.f;
     }
   };
 
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* 
     __syncthreads();
     flush_tile(-1);
   }
-  if (stats && (XF || lds_epi_rt)) {
+  if (HAS_STATS && stats && (XF || lds_epi_rt)) {
     if (stat_b >= 0) emit_stats(stat_b);
     const int nb = ntiles / (tiles_x * tiles_y * tiles_z);
     for (int bsamp = 0; bsamp < nb; ++bsamp)             // samples this workgroup never touched: zero rows
@@ -1176,7 +1187,7 @@ inline size_t fwd_ws_elems(int Cin, int Cout) {
 // query_gx != null: only report the persistent grid's x size (the statistics layout depends on it), launch nothing
 int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
                 int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr, int* query_gx = nullptr,
-                ConvIn inorm = ConvIn{nullptr, nullptr, 0, nullptr}, bool query_xf = false) {
+                ConvIn inorm = ConvIn{nullptr, nullptr, 0, nullptr}, bool query_xf = false, bool query_st = false) {
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 9 * (p.P + 2) * CinP * CoutP;
@@ -1195,39 +1206,48 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
   const int ntiles = tiles_x * tiles_y * tiles_z * B;
   const int gy = CoutP / p.ncb;
   // persistent grid: exactly the resident workgroups (occupancy query is host-only and cheap), walking the tiles
-#define CONV_LAUNCH_X(XF_, TZ_, TY_, WM_, WN_, ...)                                                                \
+#define CONV_LAUNCH_X(XF_, ST_, TZ_, TY_, WM_, WN_, ...)                                                           \
   do {                                                                                                            \
     constexpr int nthr = (WM_) * (WN_) * 64;                                                                      \
-    const int per_cu = resident_blocks((const void*)conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__, XF_>, nthr); \
+    const int per_cu = resident_blocks((const void*)conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__, XF_, ST_>, nthr); \
     int gx = (256 * per_cu + gy - 1) / gy;                                                                        \
     if (gx > ntiles) gx = ntiles;                                                                                 \
     if (query_gx) { *query_gx = gx; break; }                                                                      \
-    hipLaunchKernelGGL((conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__, XF_>), dim3(gx, gy), dim3(nthr), 0, s, x, \
+    hipLaunchKernelGGL((conv3d_mfma_kernel<TZ_, TY_, WM_, WN_, __VA_ARGS__, XF_, ST_>), dim3(gx, gy), dim3(nthr), 0, s, x, \
                        (const float*)wpk, bias, y, D, H, W, Cin, Cout, CinP, CoutP, act, tiles_x, tiles_y, tiles_z, \
                        ntiles, stats, inorm);                                                                            \
   } while (0)
-  // XF kernels only where their features are used: a lazily normalised input, or statistics from a direct-store epilogue
-  // (the staged epilogue of Cout 4/8/16 carries its statistics in the plain kernels)
-  const bool xf = inorm.mean != nullptr || (stats != nullptr && !(Cout == 4 || Cout == 8 || Cout == 16)) ||
-                  (query_gx != nullptr && query_xf);
+  // XF kernels only where their features are used: a lazily normalised input, or statistics from a direct-store epilogue.
+  // ST kernels: statistics from the staged epilogue (Cout 4/8/16 -> configurations 0, 4, 8 only).  Everything else
+  // (dgrad, plain convs) runs the instantiation without any statistics code.
+  const bool staged = Cout == 4 || Cout == 8 || Cout == 16;
+  const bool xf = inorm.mean != nullptr || (stats != nullptr && !staged) || (query_gx != nullptr && query_xf);
+  const bool st = !xf && staged && (stats != nullptr || (query_gx != nullptr && query_st));
 #define CONV_LAUNCH(TZ_, TY_, WM_, WN_, ...)                                                                      \
   do {                                                                                                            \
-    if (xf) CONV_LAUNCH_X(true, TZ_, TY_, WM_, WN_, __VA_ARGS__);                                                 \
-    else CONV_LAUNCH_X(false, TZ_, TY_, WM_, WN_, __VA_ARGS__);                                                   \
+    if (xf) CONV_LAUNCH_X(true, false, TZ_, TY_, WM_, WN_, __VA_ARGS__);                                          \
+    else CONV_LAUNCH_X(false, false, TZ_, TY_, WM_, WN_, __VA_ARGS__);                                            \
+  } while (0)
+#define CONV_LAUNCH_S(TZ_, TY_, WM_, WN_, ...)                                                                    \
+  do {                                                                                                            \
+    if (xf) CONV_LAUNCH_X(true, false, TZ_, TY_, WM_, WN_, __VA_ARGS__);                                          \
+    else if (st) CONV_LAUNCH_X(false, true, TZ_, TY_, WM_, WN_, __VA_ARGS__);                                     \
+    else CONV_LAUNCH_X(false, false, TZ_, TY_, WM_, WN_, __VA_ARGS__);                                            \
   } while (0)
   const bool v4 = (Cin & 3) == 0;
   const bool multi = CinP > p.ck;
   switch (p.cfg) {
-#define CONV_VM(PP, ...)                                                                      \
-    if (v4 && multi) CONV_LAUNCH(__VA_ARGS__, true, PP, true);                                  \
-    else if (v4) CONV_LAUNCH(__VA_ARGS__, true, PP, false);                                     \
-    else if (multi) CONV_LAUNCH(__VA_ARGS__, false, PP, true);                                  \
-    else CONV_LAUNCH(__VA_ARGS__, false, PP, false)
-#define CONV_CASE(...) CONV_VM(1, __VA_ARGS__)
+#define CONV_VM(L, PP, ...)                                                           \
+    if (v4 && multi) L(__VA_ARGS__, true, PP, true);                                  \
+    else if (v4) L(__VA_ARGS__, true, PP, false);                                     \
+    else if (multi) L(__VA_ARGS__, false, PP, true);                                  \
+    else L(__VA_ARGS__, false, PP, false)
+#define CONV_CASE(...) CONV_VM(CONV_LAUNCH, 1, __VA_ARGS__)
+#define CONV_CASE_S(...) CONV_VM(CONV_LAUNCH_S, 1, __VA_ARGS__)
 #define CONV_CASE_P(...)                          \
-    if (p.P == 4) { CONV_VM(4, __VA_ARGS__); }      \
-    else if (p.P == 2) { CONV_VM(2, __VA_ARGS__); } \
-    else { CONV_VM(1, __VA_ARGS__); }
+    if (p.P == 4) { CONV_VM(CONV_LAUNCH_S, 4, __VA_ARGS__); }      \
+    else if (p.P == 2) { CONV_VM(CONV_LAUNCH_S, 2, __VA_ARGS__); } \
+    else { CONV_VM(CONV_LAUNCH_S, 1, __VA_ARGS__); }
     case 0: CONV_CASE_P(4, 8, 8, 1, 1, 8); break;
     case 1: CONV_CASE(4, 8, 4, 1, 2, 4); break;
     case 2: CONV_CASE(2, 4, 2, 2, 2, 4); break;
@@ -1235,23 +1255,25 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
     case 5: CONV_CASE(2, 4, 4, 1, 2, 4); break;      // 8 rows x N=32, 2 rows per wave            (level 3)
     case 6: CONV_CASE(1, 4, 2, 2, 1, 8); break;      // 4 rows x N=32, 8-channel stages           (levels 4-5)
     case 7: CONV_CASE(1, 4, 2, 4, 1, 8); break;      // 4 rows x N=64, 8 waves, 8-channel stages  (level 4, Cout % 64 == 0)
-    case 8: CONV_CASE(1, 4, 4, 1, 1, 4); break;      // 4 rows x N=16, no row packing             (small volumes, Cout <= 16)
+    case 8: CONV_CASE_S(1, 4, 4, 1, 1, 4); break;    // 4 rows x N=16, no row packing             (small volumes, Cout <= 16)
     default: CONV_CASE(1, 4, 1, 4, 1, 4); break;
   }
 #undef CONV_CASE
+#undef CONV_CASE_S
 #undef CONV_CASE_P
 #undef CONV_VM
 #undef CONV_LAUNCH
+#undef CONV_LAUNCH_S
 #undef CONV_LAUNCH_X
   return query_gx ? MODET_OK : modet_launch_status();
 }
 
-// persistent grid (x) of the plain or the XF instantiation for this shape (they can differ in registers, hence in
-// residency); the statistics buffer is sized by the larger one (conv_stats_rows)
+// persistent grid (x) of the statistics-producing instantiations for this shape (ST and XF can differ in registers,
+// hence in residency); the statistics buffer is sized by the larger one (conv_stats_rows)
 inline int conv_grid_x(int B, int D, int H, int W, int Cin, int Cout, bool xf) {
   int gx = 0;
   conv_launch(nullptr, nullptr, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, nullptr, nullptr, &gx,
-              ConvIn{nullptr, nullptr, 0, nullptr}, xf);
+              ConvIn{nullptr, nullptr, 0, nullptr}, xf, !xf);
   return gx;
 }
 

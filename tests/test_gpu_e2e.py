@@ -248,11 +248,49 @@ def test_full_size_dice_parity_vs_oracle():
     _note("fwd[160x192x160].flow_maxerr_voxels_hip_vs_fp64", e_hip)
     _note("fwd[160x192x160].flow_maxerr_voxels_cpu_fp32_vs_fp64", e_cpu32)
     _note("fwd[160x192x160].flow_rmserr_voxels_hip_vs_fp64", float((flow.double().cpu() - f64).pow(2).mean().sqrt()))
-    assert e_hip <= max(1e-2, 3.0 * e_cpu32), "HIP fp32 forward is much noisier than the fp32 CPU path"
+    # the stated end-to-end tolerance: max |flow error| <= 2e-3 voxels, at the full size too
+    assert e_hip <= 2e-3, f"HIP flow deviates {e_hip:.2e} voxels from the fp64 oracle (fp32 CPU path: {e_cpu32:.2e})"
     _note("dice[160x192x160].hip", dice_gpu)
     _note("dice[160x192x160].oracle", d_ref)
     _note("dice[160x192x160].flow_maxerr_voxels_fp32_vs_fp32", float((flow.cpu() - f_ref).abs().max()))
     assert abs(d_ref - dice_gpu) <= 1e-3, f"Dice {dice_gpu:.5f} vs reference path {d_ref:.5f}"
+
+
+def test_full_size_gradient_parity_vs_oracle():
+    """BASELINE size 160x192x160: loss and EVERY parameter gradient of one train step against the fp64 CPU oracle's
+    autograd (ModeT/train.py:122-131 on ModeT/models.py:377-412), same tolerance as the small shapes: worst error per
+    tensor <= 2e-2 of that tensor's max |g| (biases in front of an InstanceNorm have an analytically zero gradient and
+    are compared absolutely)."""
+    from oracle import modet_torch as orc
+    from smilecode_amd import losses, synth
+    shape = (160, 192, 160)
+    w = synth.make_weights(24)
+    mov_np, fix_np = synth.make_pair(shape, 24)
+    p64 = {n: torch.from_numpy(v).double().requires_grad_(True) for n, v in w.items()}
+    loss64, sim64, reg64, _, _ = orc.train_loss(p64, torch.from_numpy(mov_np).double(), torch.from_numpy(fix_np).double(),
+                                                (8, 4, 2, 1, 1), 6, 1.0)
+    g64 = dict(zip(p64, torch.autograd.grad(loss64, list(p64.values()))))
+    model = _model(shape, 1.0)
+    mov, fix = torch.from_numpy(mov_np).cuda(), torch.from_numpy(fix_np).cuda()
+    y, flow = model(mov, fix)
+    sim = losses.NCC_vxm()(fix, y)
+    reg = losses.Grad3d(penalty="l2")(flow, fix)
+    loss = sim + reg
+    assert abs(float(sim.detach()) - float(sim64)) < 2e-5 and abs(float(reg.detach()) - float(reg64)) < 2e-6
+    loss.backward()
+    worst, worst_name = 0.0, ""
+    for n, prm in model.named_parameters():
+        ref = g64[n]
+        gmax = float(ref.abs().max())
+        err = float((prm.grad.double().cpu() - ref).abs().max())
+        if gmax < 1e-8:                                     # conv bias under InstanceNorm: analytically zero
+            assert err < 1e-5, (n, err)
+            continue
+        if err / gmax > worst:
+            worst, worst_name = err / gmax, n
+    _note("train[160x192x160].grad_worst_rel_to_max", worst)
+    _note("train[160x192x160].loss_abs_err", abs(float(loss.detach()) - float(loss64)))
+    assert worst <= 2e-2, f"worst gradient error {worst:.3e} of max|g| in {worst_name}"
 
 
 def test_data_parallel_two_ranks_equal_batch_two(tmp_path):
@@ -290,14 +328,14 @@ def test_data_parallel_two_ranks_equal_batch_two(tmp_path):
 
 
 def test_checkpoint_resume_is_identical_to_never_stopping(tmp_path):
-    """save {'state_dict','optimizer'} -> load into a fresh model/Trainer -> the next step lands on exactly
-    the parameters an uninterrupted run reaches (Adam m/v/vmax/step restored; all kernels deterministic -> bitwise)"""
+    """save {'state_dict','optimizer'} -> load into a fresh model/Trainer -> parameters, Adam m/v/vmax and the
+    step count are restored BIT FOR BIT, so the next step is the step an uninterrupted run takes.  (A step itself is not
+    bitwise reproducible run to run -- the feature-warp backward scatters with float atomics, as ATen's grid_sampler
+    backward does -- so the continued step is compared at the level two identical resumes differ from each other.)"""
+    from smilecode_amd import models
     from smilecode_amd.engine import Trainer
     shape = (32, 48, 32)
     mov, fix = _pair(shape)
-    a = Trainer(_model(shape, 1.0))
-    for _ in range(3):
-        a.train_step(mov, fix, epoch=1)
     b = Trainer(_model(shape, 1.0))
     for _ in range(2):
         b.train_step(mov, fix, epoch=1)
@@ -305,21 +343,37 @@ def test_checkpoint_resume_is_identical_to_never_stopping(tmp_path):
     torch.save({"epoch": 2, "state_dict": b.model.state_dict(), "best_dsc": 0.5, "optimizer": b.state_dict()}, path)
     ck = torch.load(path, map_location="cpu")
     assert set(ck["optimizer"]) == {"state", "param_groups"} and len(ck["optimizer"]["state"]) == len(list(b.model.parameters()))
-    from smilecode_amd import models
-    m = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).cuda()
-    m.load_state_dict(ck["state_dict"])
-    c = Trainer(m)
-    c.load_state_dict(ck["optimizer"])
-    assert c.step == 2
-    c.train_step(mov, fix, epoch=1)
-    assert torch.equal(c.fp.flat, a.fp.flat), "resumed run diverged from the uninterrupted one"
-    assert torch.equal(c.vmax, a.vmax) and torch.equal(c.m, a.m)
-    # without the optimizer state (the reference's own resume, train.py:80-85) the step differs: the test is not vacuous
-    m2 = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).cuda()
-    m2.load_state_dict(ck["state_dict"])
-    d = Trainer(m2)
-    d.train_step(mov, fix, epoch=1)
-    assert not torch.equal(d.fp.flat, a.fp.flat)
+
+    def resumed(with_optimizer=True):
+        m = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).cuda()
+        m.load_state_dict(ck["state_dict"])
+        t = Trainer(m)
+        if with_optimizer:
+            t.load_state_dict(ck["optimizer"])
+        return t
+
+    c1, c2, d = resumed(), resumed(), resumed(False)
+    assert c1.step == 2 and torch.equal(c1.fp.flat, b.fp.flat)
+    assert torch.equal(c1.m, b.m) and torch.equal(c1.v, b.v) and torch.equal(c1.vmax, b.vmax), "Adam state not restored bit for bit"
+    for t in (b, c1, c2, d):
+        t.train_step(mov, fix, epoch=1)
+    # parameters with a real gradient (Adam turns the pure-noise gradient of a conv bias in front of an InstanceNorm --
+    # analytically zero -- into a +-lr step of arbitrary sign)
+    sig = torch.zeros_like(b.fp.flat, dtype=torch.bool)
+    for (n, p), (off, k) in zip(b.model.named_parameters(), b.fp.offsets):
+        if not (n.endswith("main.bias") and "conv.2" not in n and "conv0.0" not in n):
+            sig[off:off + k] = True
+
+    def mean_diff(x, y):
+        return float((x.fp.flat - y.fp.flat)[sig].abs().mean())
+
+    noise, resume_err, restart_err = mean_diff(c1, c2), mean_diff(c1, b), mean_diff(d, b)
+    _note("resume.mean_param_diff_between_two_resumes", noise)
+    _note("resume.mean_param_diff_vs_uninterrupted", resume_err)
+    _note("resume.mean_param_diff_without_optimizer_state", restart_err)
+    assert resume_err <= 3.0 * noise + 1e-8, f"resumed step differs from the uninterrupted one: {resume_err:.2e} (run-to-run {noise:.2e})"
+    # without the optimizer state (the reference's own resume, train.py:80-85) Adam restarts: the step differs by ~lr
+    assert restart_err > 1e-5 and restart_err > 30.0 * resume_err
 
 
 def test_reference_train_loop_call_order(tmp_path):
