@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--shape", default="160,192,160")
     ap.add_argument("--batch", type=int, default=1, help="volume pairs per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="train workload: replay forward+backward as one hipGraph in the timed region (auto = if capture succeeds)")
     ap.add_argument("--breakdown", default="", help="write the per-op breakdown of one profiled step to this JSON file")
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.split(","))
@@ -265,10 +267,43 @@ def main():
     if rank == 0:
         log(f"[bench] host enqueue time of one step: {host_ms:.2f} ms")
 
-    # timed region: exactly K steps, only the dominant group carries events
+    # hipGraph: forward + losses + backward + gradient packing captured once, replayed per step (engine.Trainer.capture);
+    # the all-reduce and the Adam kernel stay eager.  A replayed graph cannot carry per-kernel events, so the roofline leg
+    # below is measured over eager steps right after the timed region.
+    graphed = False
+    if args.workload == "train" and args.graph != "off":
+        try:
+            trainer.capture(mov, fix)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            graphed = True
+        except Exception as e:
+            trainer.release_graph()
+            if args.graph == "on":
+                raise
+            log(f"[bench] hipGraph capture failed ({e!r}); timing the eager path")
+    if world > 1:                       # every rank must take the same path
+        flag = torch.tensor([1 if graphed else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if graphed and int(flag.item()) == 0:
+            trainer.release_graph()
+            graphed = False
+    host_graph_ms = None
+    if graphed:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        host_graph_ms = (time.perf_counter() - t0) * 1e3
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"[bench] hipGraph replay: host enqueue time of one step {host_graph_ms:.2f} ms")
+
+    # timed region: exactly K steps.  Eager: only the dominant group carries events.  Graph: no events inside.
     tsel = ops.KernelTimer(select=set(fams[dominant]["tags"]) if dominant else set())
     barrier()
-    ops.set_kernel_timer(tsel)
+    if not graphed:
+        ops.set_kernel_timer(tsel)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -279,6 +314,20 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    roof_steps, dt_eager = args.steps, None
+    if graphed:
+        # roofline leg: the same K steps again, eager, with HIP events around every launch of the dominant kernel
+        trainer.release_graph()
+        for _ in range(2):
+            step()
+        barrier()
+        ops.set_kernel_timer(tsel)
+        t0 = time.perf_counter()
+        for _ in range(roof_steps):
+            step()
+        barrier()
+        dt_eager = time.perf_counter() - t0
+        ops.set_kernel_timer(None)
 
     ar_probe = allreduce_probe(trainer.fp.grad, world) if world > 1 else None     # after the timed region, every rank
     if rank == 0:
@@ -298,8 +347,10 @@ def main():
                 ach = d["bytes"] / sec / 1e9
                 roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": ach / PEAK_HBM_GBS, "traffic": None}
-            roof.update({"kernel": dominant, "launches": d["calls"], "launches_per_step": d["calls"] / args.steps,
-                         "avg_launch_ms": d["ms"] / d["calls"], "share_of_step": d["ms"] / (dt * 1e3),
+            roof.update({"kernel": dominant, "launches": d["calls"], "launches_per_step": d["calls"] / roof_steps,
+                         "avg_launch_ms": d["ms"] / d["calls"], "share_of_step": d["ms"] / ((dt_eager or dt) * 1e3),
+                         "measured_over": ("%d eager steps right after the timed region (the timed region replays a hipGraph, "
+                                           "which cannot carry per-kernel events)" % roof_steps) if graphed else "the timed region",
                          "note": "all launches of this kernel symbol in the K timed steps; algorithmic work summed per "
                                  "launch shape (DESIGN.md section 4); each bracket also contains the ~4 us weight-pack launch"
                                  if dominant.startswith("conv3d_mfma") else "all launches of this kernel in the K timed steps"})
@@ -318,7 +369,9 @@ def main():
                 *shape, args.batch, "full train step NCC+Grad3d fwd+bwd+Adam-amsgrad" + (" + RCCL grad all-reduce" if world > 1 else "")
                 if args.workload == "train" else "forward+warp")),
                 "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-            "roofline": roof, "host_enqueue_ms_per_step": host_ms,
+            "roofline": roof, "host_enqueue_ms_per_step": host_graph_ms if graphed else host_ms,
+            "hip_graph": graphed, "eager": {"host_enqueue_ms_per_step": host_ms,
+                                            "ms_per_step": dt_eager / roof_steps * 1e3 if dt_eager else None},
             # proof of the N-rank run: what torch.distributed itself reports, and the step's one collective timed alone
             "backend": dist.get_backend() if world > 1 else None,
             "world_size": dist.get_world_size() if world > 1 else 1,

@@ -12,8 +12,11 @@
  *  - fp32 everywhere.  Activations are channels-last "(B,D,H,W,C)" unless a comment says
  *    otherwise; (D,H,W) are the reference's (H,W,T) = the three spatial axes in memory order.
  *  - caller allocates every output and workspace; the library never allocates, frees or retains
- *    device memory, keeps no global/thread-local mutable state, and is re-entrant (the autograd
- *    engine calls the backward entry points from another thread).
+ *    device memory and is re-entrant (the autograd engine calls the backward entry points from
+ *    another thread).  Its only process-wide state is a mutex-guarded memo of
+ *    per-kernel occupancy constants (filled on first use, never changed afterwards).
+ *  - every entry point only enqueues stream work (kernels, hipMemsetAsync): a sequence of calls
+ *    can be captured into a hipGraph once each kernel has been launched at least once.
  *  - all launches are asynchronous on `stream`; nothing synchronises.
  *  - return value: 0 = ok, <0 = argument error (enum below), >0 = hipError_t from the launch.
  *  - `ws`/`ws_bytes`: scratch from the matching *_ws_bytes(); contents undefined afterwards.

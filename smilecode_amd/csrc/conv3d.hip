@@ -11,6 +11,8 @@
 //   Cin<=8 packs two taps into the 16 M rows.  Workgroups walk tiles persistently, partial d_w goes to a
 //   workspace and is summed in fixed order in fp64 (deterministic, no atomics).
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 #ifdef MODET_TUNING
 #include <cstdlib>
 #endif
@@ -1163,10 +1165,20 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // resident 256-thread workgroups per CU from the kernel's own footprint: 160 KiB LDS per CU, 512 VGPR+AGPR per SIMD
 // lane allocated in granules of 8 (MI355X_MICROARCH.md), at most 8 waves per SIMD
+// The answer is a constant of the code object: it is queried once per kernel and memoised (a read-mostly table behind a
+// mutex -- the only process-wide state of the library, immutable once filled), so that the hundreds of launches of a
+// step make no runtime queries and a step can be captured into a hipGraph (no non-stream API calls while capturing).
 inline int resident_blocks(const void* fn, int nthreads) {
 #ifdef MODET_TUNING
   if (const char* e = getenv("MODET_CONV_PERCU")) return atoi(e);
 #endif
+  static std::mutex mu;
+  static std::unordered_map<const void*, int> memo;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = memo.find(fn);
+    if (it != memo.end()) return it->second;
+  }
   hipFuncAttributes a;
   if (hipFuncGetAttributes(&a, fn) != hipSuccess) return 2;
   const int by_lds = a.sharedSizeBytes > 0 ? (int)(163840 / round_up((int)a.sharedSizeBytes, 512)) : 8;
@@ -1174,7 +1186,10 @@ inline int resident_blocks(const void* fn, int nthreads) {
   const int by_reg = (waves_per_simd > 8 ? 8 : waves_per_simd) * 4 / (nthreads / 64);
   int n = by_lds < by_reg ? by_lds : by_reg;
   if (n > 8) n = 8;
-  return n < 1 ? 1 : n;
+  n = n < 1 ? 1 : n;
+  std::lock_guard<std::mutex> lk(mu);
+  memo[fn] = n;
+  return n;
 }
 
 inline size_t fwd_ws_elems(int Cin, int Cout) {

@@ -82,6 +82,7 @@ def main(argv=None):
     ap.add_argument("--epoch-start", type=int, default=0, help="first epoch of a resumed run (train.py:59)")
     ap.add_argument("--no-restore-optimizer", action="store_true",
                     help="resume exactly like the reference: weights only, Adam restarts from zero moments (train.py:84)")
+    ap.add_argument("--no-graph", action="store_true", help="issue every kernel of a step from Python instead of replaying a hipGraph")
     ap.add_argument("--host-loader", action="store_true",
                     help="read the .pkl pair from the host every iteration instead of caching all subjects in HBM")
     args = ap.parse_args(argv)
@@ -152,6 +153,8 @@ def main(argv=None):
         n_iter = len(mine) if not args.max_iters else min(len(mine), args.max_iters)
         for idx in range(1, n_iter + 1):
             x, y = train_pair(mine[idx - 1])
+            if not args.no_graph and trainer._graph is None:
+                trainer.capture(x, y)               # forward+backward as one hipGraph from here on (engine.Trainer.capture)
             loss, sim, reg = trainer.train_step(x, y, epoch=epoch)      # lr = poly_lr(epoch) inside (train.py:117)
             if rank == 0:
                 lv = loss.item()                                        # one host sync per iteration, as train.py:130
