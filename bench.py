@@ -43,6 +43,10 @@ def family(tag):
         return "conv_c1_fwd_kernel"
     if tag.startswith("conv_wgrad[1->"):
         return "conv_c1_wgrad_kernel"
+    if tag.startswith("conv_bf16_fwd") or tag.startswith("conv_bf16_dgrad"):
+        return "conv3d_bf16_kernel"
+    if tag.startswith("conv_bf16_wgrad"):
+        return "conv3d_bf16_wgrad_kernel"
     if tag.startswith("conv_fwd") or tag.startswith("conv_dgrad"):
         return "conv3d_mfma_kernel"
     if tag.startswith("conv_wgrad"):
@@ -167,6 +171,31 @@ def allreduce_only(args, rank, local, world):
         dist.destroy_process_group()
 
 
+def cpu_cfg1():
+    """BASELINE.json configs[0]: single 64x64x64 synthetic pair, CPU forward of the oracle (ATen-CPU, the reference's op
+    sequence), at all host threads and at one thread"""
+    from oracle import modet_torch as orc
+    from smilecode_amd import synth
+    p = {n: torch.from_numpy(v) for n, v in synth.make_weights(24).items()}
+    mov, fix = (torch.from_numpy(a) for a in synth.make_pair((64, 64, 64), 24))
+    cores = torch.get_num_threads()
+    out = {"unit": "volume-pairs/sec", "kind": "port", "sample": "1 pair 64x64x64 forward, oracle/modet_torch.py (ATen-CPU fp32), best of 3"}
+    for nt, key in ((min(cores, 32), "value"), (1, "value_1_thread")):
+        torch.set_num_threads(nt)
+        best = 1e9
+        with torch.no_grad():
+            orc.modet_forward(p, mov, fix, (8, 4, 2, 1, 1), 6, 1.0)
+            for _ in range(3):
+                t0 = time.perf_counter()
+                orc.modet_forward(p, mov, fix, (8, 4, 2, 1, 1), 6, 1.0)
+                best = min(best, time.perf_counter() - t0)
+        out[key] = 1.0 / best
+        if key == "value":
+            out["cores"] = nt
+    torch.set_num_threads(cores)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +204,10 @@ def main():
     ap.add_argument("--workload", choices=["train", "fwd", "allreduce"], default="train")
     ap.add_argument("--shape", default="160,192,160")
     ap.add_argument("--batch", type=int, default=1, help="volume pairs per rank per step")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16 = BASELINE.json configs[4]: bf16 storage / fp32 accumulate in the ConvInsBlock chains (separate line; the headline is f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cfg-2 (forward+warp) and cfg-1 (CPU 64^3) side legs")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="train workload: replay forward+backward as one hipGraph in the timed region (auto = if capture succeeds)")
     ap.add_argument("--breakdown", default="", help="write the per-op breakdown of one profiled step to this JSON file")
@@ -200,7 +232,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    model = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).to(dev)
+    model = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1,
+                         act_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32).to(dev)
     models.load_numpy_weights(model, synth.make_weights(24))
     trainer = Trainer(model)
     mov, fix = synth.make_pair(shape, 24 + 2 * args.batch * rank, args.batch)      # per-rank pairs, weak scaling
@@ -330,6 +363,24 @@ def main():
         ops.set_kernel_timer(None)
 
     ar_probe = allreduce_probe(trainer.fp.grad, world) if world > 1 else None     # after the timed region, every rank
+    extra = {}
+    if world == 1 and args.workload == "train" and not args.no_extra:
+        # cfg 2 (forward + final warp, no grad) on the same pair, and the cfg-1 CPU leg (64^3 forward of the oracle)
+        for _ in range(3):
+            trainer.infer(mov, fix)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.infer(mov, fix)
+        torch.cuda.synchronize()
+        tf = (time.perf_counter() - t0) / args.steps
+        extra["cfg2_forward_warp"] = {"value": args.batch / tf, "unit": "volume-pairs/sec", "ms_per_step": tf * 1e3,
+                                      "workload": "ModeT LPBA %dx%dx%d fp32, batch=%d, forward+warp, no grad" % (*shape, args.batch)}
+        if not args.no_cpu_baseline:
+            try:
+                extra["cfg1_cpu_forward_64"] = cpu_cfg1()
+            except Exception as e:
+                extra["cfg1_cpu_forward_64"] = {"value": None, "sample": f"failed: {e!r}"}
     if rank == 0:
         pairs = args.steps * args.batch * world
         roof = None
@@ -364,9 +415,9 @@ def main():
             "metric": "volume-pairs/sec (160x192x160) fwd+bwd" if args.workload == "train" else "volume-pairs/sec (160x192x160) fwd+warp",
             "value": pairs / dt, "unit": "volume-pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("ModeT LPBA %dx%dx%d fp32, batch=%d/GPU, %s" % (
-                *shape, args.batch, "full train step NCC+Grad3d fwd+bwd+Adam-amsgrad" + (" + RCCL grad all-reduce" if world > 1 else "")
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("ModeT %dx%dx%d %s, batch=%d/GPU, %s" % (
+                *shape, "fp32" if args.dtype == "f32" else "bf16 storage / fp32 accumulate (ConvInsBlock chains), fp32 elsewhere", args.batch, "full train step NCC+Grad3d fwd+bwd+Adam-amsgrad" + (" + RCCL grad all-reduce" if world > 1 else "")
                 if args.workload == "train" else "forward+warp")),
                 "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": roof, "host_enqueue_ms_per_step": host_graph_ms if graphed else host_ms,
@@ -376,6 +427,7 @@ def main():
             "backend": dist.get_backend() if world > 1 else None,
             "world_size": dist.get_world_size() if world > 1 else 1,
             "allreduce": ar_probe,
+            "extra": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -216,6 +216,36 @@ int modet_jacdet_nonpos_count(const float* flow, int64_t* counts, double* det_ou
                               modet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * bf16 STORAGE / fp32 ACCUMULATE variants of the ConvInsBlock chain (BASELINE.json configs[4]; csrc/conv3d_bf16.hip).
+ * Activations marked "bf16" are (B,D,H,W,C) channels-last arrays of 16-bit brain floats; weights, bias, statistics and
+ * weight gradients stay fp32.  `*_bf16` int flags: 0 = that tensor is fp32, 1 = bf16.  Convolutions run on the bf16 matrix
+ * pipe (v_mfma_f32_16x16x32_bf16) with fp32 accumulators; fp32 inputs are rounded to bf16 (nearest even) when staged.
+ *   fwd:      y (bf16) = conv(x (fp32 | bf16), w) + bias; stats (optional, modet_conv3d_bf16_stats_bytes) = InstanceNorm
+ *             partial sums taken from the fp32 accumulators, same buffer format as modet_conv3d_fwd_stats
+ *             (consumed by modet_instnorm_lrelu_fwd_stats_bf16).  Cout % 8 == 0; Cin % 8 == 0 (bf16 x) or % 4 == 0 (fp32 x).
+ *   bwd_data: d_x (fp32 | bf16) from d_y (bf16).
+ *   bwd_weight: d_w, d_bias (fp32) from x (fp32 | bf16) and d_y (bf16). */
+size_t modet_conv3d_bf16_ws_bytes(int Cin, int Cout);
+size_t modet_conv3d_bf16_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modet_conv3d_bf16_fwd(const void* x, int x_bf16, const float* w, const float* bias, void* y, void* ws, size_t ws_bytes,
+                          float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                          modet_stream_t stream);
+int modet_conv3d_bf16_bwd_data(const void* d_y, const float* w, void* d_x, int dx_bf16, void* ws, size_t ws_bytes,
+                               int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+size_t modet_conv3d_bf16_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modet_conv3d_bf16_bwd_weight(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
+                                 size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+/* InstanceNorm3d + LeakyReLU(0.1) on a bf16 raw conv output x: forward from the conv's statistics buffer (y fp32 | bf16,
+ * mean / rstd (B*C) fp32 out); backward d_x (bf16) from d_y (fp32 | bf16), x, mean, rstd. */
+size_t modet_instnorm_bf16_ws_bytes(int B, int64_t V, int C);
+int modet_instnorm_lrelu_fwd_stats_bf16(const void* x, void* y, int y_bf16, float* mean, float* rstd, const float* stats,
+                                        size_t stats_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream);
+int modet_instnorm_lrelu_bwd_bf16(const void* d_y, int dy_bf16, const void* x, const float* mean, const float* rstd,
+                                  void* d_x, void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream);
+/* element-wise cast between fp32 and bf16 (round to nearest even), n % 8 == 0 */
+int modet_cast_bf16(const void* x, void* y, int64_t n, int to_bf16, modet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * PR++ Correlation3D ("Baseline methods/PR++/models.py":205-232; kernel_size 3, d = 3, sw = 1, sf = 2), SURVEY.md 8(f):
  *   corr[b][t][p] = (1/27) sum_c box3(mov)[b,p,c] * box3(fix)[b, p + 2*off(t), c],  t = 9i+3j+k, off = (i-1,j-1,k-1),
  * box3 = zero-padded 3x3x3 box sum (fix's also on the ring just outside the volume, as the reference's padding 3 does).

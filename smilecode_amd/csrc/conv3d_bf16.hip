@@ -1,0 +1,671 @@
+// 3x3x3 / stride 1 / zero-pad 1 convolution with bf16 STORAGE and fp32 ACCUMULATION on gfx950's bf16 matrix pipe
+// (v_mfma_f32_16x16x32_bf16: 16x the rate of the exact-f32 MFMA the fp32 path uses) -- BASELINE.json configs[4]
+// ("bf16 storage / fp32 accumulate").  Channels-last activations; fp32 master weights are packed to bf16 per launch;
+// bias, InstanceNorm statistics and weight gradients stay fp32.
+//   reference call sites: nn.Conv3d in ConvInsBlock, ModeT/models.py:135-151 (arithmetic lives in ATen/MIOpen there;
+//   the reference itself has no reduced-precision path: cfg 5 is this build's own configuration).
+//
+// forward / dgrad:  D[voxel(16 along W)][cout(16)] += A[voxel][k(32)] * B[k(32)][cout],  k = (tap, cin) with cin fastest.
+//   A: one ds_read_b128 per lane = 8 consecutive input channels of one tap at one voxel, from an LDS tile
+//      [halo'd voxel][CK channels] (bf16; fp32 inputs are converted while the tile is staged, zero padding included);
+//   B: one 16-byte global load per lane from weights packed [stage][k-step][cout][32 k] (L2-resident, no LDS copy),
+//      re-used by all the M tiles (output rows) of the wave;
+//   epilogue: + bias, fused InstanceNorm statistics from the fp32 accumulators (shifted sums, one row per workgroup,
+//      same buffer format as the fp32 path: see ConvIn in conv3d.hip), transpose through LDS, coalesced 16-byte stores
+//      of bf16 (or fp32) channel vectors.
+// One workgroup = one output tile (no persistence: the tile's arithmetic is a few hundred MFMAs, the kernel is bound by
+// staging the halo'd tile; 3-5 workgroups per CU overlap each other's phases).
+// dgrad is the same kernel on flipped + transposed weights.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NTHR = 256;
+constexpr int TX = 16, HX = TX + 2;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {        // round to nearest even (v_cvt_pk_bf16_f32)
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ unsigned short to_bf16(float a) {
+  const __bf16 x = (__bf16)a;
+  return __builtin_bit_cast(unsigned short, x);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// wpk[stage][step][n < CoutP][32] bf16: element j of k-step `step` is k' = step*32 + j within the stage,
+//   tap = k' / CK, channel c = stage*CK + k' % CK; zero for tap >= 27, c >= Cin, n >= Cout.
+//   mode 0 (forward): w[n][c][tap]   (w: (Cout, Cin, 27));   mode 1 (dgrad): w[c][n][26 - tap]  (w: (Co = c, Ci = n, 27))
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cin, int Cout,
+                                         int CoutP, int CK, int nstage, int ksteps, int mode) {
+  const int total = nstage * ksteps * CoutP * 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 31;
+    int t = i >> 5;
+    const int n = t % CoutP; t /= CoutP;
+    const int step = t % ksteps, stage = t / ksteps;
+    const int kp = step * 32 + j;
+    const int tap = kp / CK, c = stage * CK + kp % CK;
+    float v = 0.f;
+    if (tap < 27 && c < Cin && n < Cout)
+      v = mode == 0 ? w[((int64_t)n * Cin + c) * 27 + tap] : w[((int64_t)c * Cout + n) * 27 + 26 - tap];
+    wpk[i] = to_bf16(v);
+  }
+}
+
+// shift K of the fused statistics (see conv_shift_kernel in conv3d.hip): the conv output at voxel (1,1,1), any summation order
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void conv_shift_bf16_kernel(const void* __restrict__ xv, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ shift,
+                                                              int B, int D, int H, int W, int Cin, int Cout) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= B * Cout) return;
+  const int b = item / Cout, co = item - b * Cout;
+  const int z = D > 1 ? 1 : 0, y = H > 1 ? 1 : 0, xx = W > 1 ? 1 : 0;
+  float acc = 0.f;
+  for (int i = lane; i < 27 * Cin; i += 64) {
+    const int tap = i / Cin, c = i - tap * Cin;
+    const int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xq = xx + tap % 3 - 1;
+    if (zz < 0 || zz >= D || yy < 0 || yy >= H || xq < 0 || xq >= W) continue;
+    const int64_t off = ((((int64_t)b * D + zz) * H + yy) * W + xq) * Cin + c;
+    const float v = IN_BF16 ? bf16_to_f32(((const unsigned short*)xv)[off]) : ((const float*)xv)[off];
+    acc = fmaf(v, w[((int64_t)co * Cin + c) * 27 + tap], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) shift[item] = acc + (bias ? bias[co] : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+template <int TZ, int TY, int CK, int NT, bool IN_BF16, bool OUT_BF16, bool STATS>
+__global__ __launch_bounds__(NTHR) void conv3d_bf16_kernel(const void* __restrict__ xin, const uint4* __restrict__ wpk,
+                                                           const float* __restrict__ bias, void* __restrict__ yout,
+                                                           float* __restrict__ stats_rows, const float* __restrict__ shift,
+                                                           int D, int H, int W, int Cin, int Cout, int CoutP, int nstage,
+                                                           int tiles_x, int tiles_y) {
+  constexpr int HZ = TZ + 2, HY = TY + 2, HVOX = HZ * HY * HX;
+  constexpr int ROWS = TZ * TY, RW = ROWS / 4;            // output rows (M tiles of 16 voxels) per workgroup / per wave
+  constexpr int NCB = NT * 16;
+  constexpr int KSTEPS = (27 * CK + 31) / 32;
+  constexpr int CKB = CK / 8;                             // 16-byte channel blocks per voxel in the LDS tile
+  constexpr int OSZ = OUT_BF16 ? 2 : 4;
+  constexpr int XS_BYTES = HVOX * CK * 2, ST_BYTES = ROWS * TX * NCB * OSZ;
+  constexpr int LDS_BYTES = XS_BYTES > ST_BYTES ? XS_BYTES : ST_BYTES;
+  static_assert(ROWS % 4 == 0, "rows split over 4 waves");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  __shared__ float sred[STATS ? 4 * NCB * 2 : 2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int cb0 = blockIdx.y * NCB, b = blockIdx.z;
+  int t = blockIdx.x;
+  const int x0 = (t % tiles_x) * TX; t /= tiles_x;
+  const int y0 = (t % tiles_y) * TY;
+  const int z0 = (t / tiles_y) * TZ;
+  const int64_t vbase = (int64_t)b * D * H * W;
+
+  f32x4 acc[RW][NT];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int rowoff[RW];                                          // element offset of (row, voxel li) in the LDS tile, tap (0,0,0)
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int rr = wave * RW + r;
+    rowoff[r] = (((rr / TY) * HY + (rr % TY)) * HX + li) * CK;
+  }
+
+  for (int s = 0; s < nstage; ++s) {
+    if (s > 0) __syncthreads();                            // every wave is done reading the previous stage's tile
+    // ---- stage the halo'd input tile: [voxel][CK] bf16, zeros outside the volume and beyond Cin
+    for (int idx = tid; idx < HVOX * CKB; idx += NTHR) {
+      const int hv = idx / CKB, cb = idx - hv * CKB;
+      const int hx = hv % HX, t2 = hv / HX;
+      const int hy = t2 % HY, hz = t2 / HY;
+      const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+      const int c = s * CK + cb * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin) {
+        const int64_t off = (vbase + ((int64_t)z * H + yy) * W + xx) * Cin + c;
+        if (IN_BF16) {
+          v = *reinterpret_cast<const uint4*>((const unsigned short*)xin + off);       // Cin % 8 == 0 (host checks)
+        } else {
+          const float* p = (const float*)xin + off;
+          const float4 a = *reinterpret_cast<const float4*>(p);                         // Cin % 4 == 0 (host checks)
+          v.x = pack_bf16x2(a.x, a.y); v.y = pack_bf16x2(a.z, a.w);
+          if (c + 4 < Cin) {
+            const float4 q = *reinterpret_cast<const float4*>(p + 4);
+            v.z = pack_bf16x2(q.x, q.y); v.w = pack_bf16x2(q.z, q.w);
+          }
+        }
+      }
+      *reinterpret_cast<uint4*>(lds + ((size_t)hv * CK + cb * 8) * 2) = v;
+    }
+    __syncthreads();
+    // ---- K loop: k-step = 32 k values = 4 lane groups x 8 consecutive channels of one tap
+    const uint4* wst = wpk + ((size_t)s * KSTEPS * CoutP + cb0) * 4;
+    uint4 bq[2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bq[0][n] = wst[(size_t)(n * 16 + li) * 4 + lk];
+#pragma unroll
+    for (int step = 0; step < KSTEPS; ++step) {
+      if (step + 1 < KSTEPS) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bq[(step + 1) & 1][n] = wst[((size_t)(step + 1) * CoutP + n * 16 + li) * 4 + lk];
+      }
+      const int kb = step * 4 + lk;                        // this lane group's block of 8 k values
+      int tap = (kb * 8) / CK;
+      const int c0 = (kb * 8) % CK;
+      if (tap > 26) tap = 26;                              // padded k: finite data times zero weights
+      const int toff = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK + c0;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const uint4 av = *reinterpret_cast<const uint4*>(lds + (size_t)(rowoff[r] + toff) * 2);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bq[step & 1][n]), acc[r][n], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: bias, statistics, transpose through LDS, coalesced stores
+  __syncthreads();                                         // the input tile is dead: its LDS becomes the output staging
+  float sx[NT], sq[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { sx[n] = 0.f; sq[n] = 0.f; }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = n * 16 + li, co = cb0 + col;
+    const float bv = (bias && co < Cout) ? bias[co] : 0.f;
+    const float kv = (STATS && co < Cout) ? shift[b * Cout + co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int rr = wave * RW + r;
+      const bool rowin = (z0 + rr / TY < D) && (y0 + rr % TY < H);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xv = lk * 4 + j;                         // C/D layout: row = (lane >> 4) * 4 + reg, col = lane & 15
+        const float v = acc[r][n][j] + bv;
+        if (STATS && rowin && x0 + xv < W) { const float e = v - kv; sx[n] += e; sq[n] = fmaf(e, e, sq[n]); }
+        const int so = (rr * TX + xv) * NCB + col;
+        if (OUT_BF16) reinterpret_cast<unsigned short*>(lds)[so] = to_bf16(v);
+        else reinterpret_cast<float*>(lds)[so] = v;
+      }
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      sx[n] += __shfl_xor(sx[n], 16, 64); sq[n] += __shfl_xor(sq[n], 16, 64);
+      sx[n] += __shfl_xor(sx[n], 32, 64); sq[n] += __shfl_xor(sq[n], 32, 64);
+      if (lane < 16) { sred[(wave * NCB + n * 16 + lane) * 2] = sx[n]; sred[(wave * NCB + n * 16 + lane) * 2 + 1] = sq[n]; }
+    }
+  }
+  __syncthreads();
+  if (STATS && tid < NCB * 2) {
+    const int col = tid >> 1, which = tid & 1;
+    if (cb0 + col < Cout) {
+      float a = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) a += sred[(w4 * NCB + col) * 2 + which];
+      // one row per (sample, tile): [b][tile][Cout][2]
+      stats_rows[(((int64_t)b * gridDim.x + blockIdx.x) * Cout + cb0 + col) * 2 + which] = a;
+    }
+  }
+  constexpr int CPV = NCB * OSZ / 16;                      // 16-byte chunks per voxel of the staged tile
+  constexpr int EPC = 16 / OSZ;                            // channels per chunk
+  for (int idx = tid; idx < ROWS * TX * CPV; idx += NTHR) {
+    const int vox = idx / CPV, ch = idx - vox * CPV;
+    const int xv = vox % TX, rr = vox / TX;
+    const int z = z0 + rr / TY, yy = y0 + rr % TY, xx = x0 + xv;
+    const int co = cb0 + ch * EPC;
+    if (z < D && yy < H && xx < W && co < Cout) {
+      const uint4 v = *reinterpret_cast<const uint4*>(lds + ((size_t)vox * NCB + ch * EPC) * OSZ);
+      const int64_t off = (vbase + ((int64_t)z * H + yy) * W + xx) * Cout + co;
+      if (OUT_BF16) *reinterpret_cast<uint4*>((unsigned short*)yout + off) = v;
+      else *reinterpret_cast<uint4*>((float*)yout + off) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// d_w[co][ci][tap] = sum_v d_y[v][co] * x[v + off(tap)][ci]  as  D[m][n] += A[m][k] B[k][n]  with  k = 32 voxels along W,
+// m = (tap, ci) in tiles of 16 rows, n = cout.  Both operands need 8 CONSECUTIVE VOXELS of one channel per lane, so the
+// tiles are staged channel-planar in LDS (the global reads stay channels-last; two x-adjacent voxels are packed per
+// ds_write_b32):  xs[ci][z][y][48] with the tile's x origin at element 8, dys[co][row][32].
+// The three x taps of one (dz, dy, ci) row come from ONE set of aligned reads: with P, Q, R the 16-byte blocks at
+// elements 8*lk, 8*lk+8, 8*lk+16, the runs starting at elements 8*lk+7 / +8 / +9 (dx = 0 / 1 / 2) are funnel shifts
+// (v_alignbit) of {P.w, Q, R.x}.  An M tile is 16 rows sharing one dx: 16 channels of one (dz,dy) (CIB = 16), 2 (dz,dy)
+// combinations x 8 channels (CIB = 8) or 4 x 4 (CIB = 4); a "group" = the 3 M tiles (dx) built from one set of reads.
+// Workgroups are persistent over voxel tiles, each wave takes every 4th row (k-step) of a tile and keeps private fp32
+// accumulators for all tiles; at the end the 4 waves are summed through LDS and the workgroup writes ONE partial per
+// (group, dx, n tile), which wgrad_bf16_reduce_kernel sums over workgroups in fixed order in fp64 (deterministic).
+// Slot U*3 (row 0 of an all-ones A) carries d_bias.
+constexpr int WTX = 32, WHXP = 48;
+template <int CIB, int U, int NTB, int TZ, int TY, bool X_BF16>
+__global__ __launch_bounds__(NTHR) void conv3d_bf16_wgrad_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ dy,
+                                                                 float* __restrict__ part, int D, int H, int W, int Cin, int Cout,
+                                                                 int tiles_x, int tiles_y, int tiles_z, int ntiles, int n_coblk) {
+  constexpr int HZ = TZ + 2, HY = TY + 2, ROWS = TZ * TY;
+  constexpr int PX = HZ * HY * WHXP + 8;                    // plane stride (elements); +8 spreads the channel planes over the banks
+  constexpr int PD = ROWS * WTX + 8;
+  constexpr int NCO = NTB * 16;
+  constexpr int SLOTS = U * 3 + 1;
+  constexpr int XS_EL = CIB * PX, DS_EL = NCO * PD;
+  constexpr int RED_FL = SLOTS * NTB * 256;                 // floats of the cross-wave reduction buffer
+  constexpr int LDS_BYTES = ((XS_EL + DS_EL) * 2 > RED_FL * 4 ? (XS_EL + DS_EL) * 2 : RED_FL * 4);
+  static_assert(ROWS % 4 == 0, "rows split over 4 waves");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  unsigned short* xs = reinterpret_cast<unsigned short*>(lds);
+  unsigned short* dys = xs + XS_EL;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int chunk = blockIdx.y / n_coblk, yb = blockIdx.y - chunk * n_coblk;   // group chunk, cout block
+  const int co0 = yb * NCO;
+  // this workgroup's channel block and first group
+  constexpr int GPB = CIB == 16 ? 9 : (CIB == 8 ? 5 : 3);    // groups per channel block
+  const int g0 = chunk * U;                                   // global group index of local group 0
+  const int cblk = g0 / GPB;                                  // (U divides GPB, so a chunk never straddles blocks)
+  const int ci0 = cblk * CIB;
+  const bool do_bias = chunk == 0;
+
+  // per-lane A row: channel and the (dz,dy) combination of each local group
+  const int myci = CIB == 16 ? li : (CIB == 8 ? (li & 7) : (li & 3));
+  int aoff[U];                                                // element offset of (ci plane, dz, dy, 8*lk) for row (0,0)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int gl = (g0 + u) % GPB;
+    int combo = CIB == 16 ? gl : (CIB == 8 ? 2 * gl + (li >> 3) : 4 * gl + (li >> 2));
+    if (combo > 8) combo = 8;                                 // dummy rows: finite data, never written out
+    aoff[u] = myci * PX + ((combo / 3) * HY + combo % 3) * WHXP + 8 * lk;
+  }
+
+  f32x4 acc[U][3][NTB];
+  f32x4 accb[NTB];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int n = 0; n < NTB; ++n) acc[u][d][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < NTB; ++n) accb[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned one2 = li == 0 ? 0x3f803f80u : 0u;           // bf16 (1, 1): row 0 of the bias tile
+  const uint4 ones = make_uint4(one2, one2, one2, one2);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int x0 = (t % tiles_x) * WTX; t /= tiles_x;
+    const int y0 = (t % tiles_y) * TY; t /= tiles_y;
+    const int z0 = (t % tiles_z) * TZ;
+    const int64_t vbase = (int64_t)(t / tiles_z) * D * H * W;
+    __syncthreads();                                          // every wave is done with the previous tile
+    // ---- x tile: elements 6..41 of each (z,y) row (volume x = x0 - 8 + e), 18 voxel pairs per row
+    for (int idx = tid; idx < HZ * HY * 18; idx += NTHR) {
+      const int p = idx % 18 + 3, r2 = idx / 18;
+      const int hy = r2 % HY, hz = r2 / HY;
+      const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 - 8 + 2 * p;
+      float v0[CIB], v1[CIB];
+      unsigned short h0[CIB], h1[CIB];
+      const bool rowin = z >= 0 && z < D && yy >= 0 && yy < H;
+#pragma unroll
+      for (int c = 0; c < CIB; ++c) { v0[c] = 0.f; v1[c] = 0.f; h0[c] = 0; h1[c] = 0; }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int xq = xx + q;
+        if (rowin && xq >= 0 && xq < W) {
+          const int64_t off = (vbase + ((int64_t)z * H + yy) * W + xq) * Cin + ci0;
+          if (X_BF16) {
+#pragma unroll
+            for (int c8 = 0; c8 < CIB / 8; ++c8) {
+              const uint4 v = *reinterpret_cast<const uint4*>((const unsigned short*)xin + off + c8 * 8);
+              const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                (q ? h1 : h0)[c8 * 8 + 2 * j] = (unsigned short)(wds[j] & 0xffffu);
+                (q ? h1 : h0)[c8 * 8 + 2 * j + 1] = (unsigned short)(wds[j] >> 16);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int c4 = 0; c4 < CIB / 4; ++c4) {
+              const float4 v = *reinterpret_cast<const float4*>((const float*)xin + off + c4 * 4);
+              (q ? v1 : v0)[c4 * 4] = v.x; (q ? v1 : v0)[c4 * 4 + 1] = v.y; (q ? v1 : v0)[c4 * 4 + 2] = v.z; (q ? v1 : v0)[c4 * 4 + 3] = v.w;
+            }
+          }
+        }
+      }
+      unsigned* dst = reinterpret_cast<unsigned*>(xs) + ((hz * HY + hy) * WHXP) / 2 + p;
+#pragma unroll
+      for (int c = 0; c < CIB; ++c)
+        dst[(c * PX) / 2] = X_BF16 ? ((unsigned)h0[c] | ((unsigned)h1[c] << 16)) : pack_bf16x2(v0[c], v1[c]);
+    }
+    // ---- d_y tile: [co][row][32], 16 voxel pairs per row; couts beyond Cout are zero
+    for (int idx = tid; idx < ROWS * 16; idx += NTHR) {
+      const int p = idx & 15, rr = idx >> 4;
+      const int z = z0 + rr / TY, yy = y0 + rr % TY, xx = x0 + 2 * p;
+      unsigned short h0[NCO], h1[NCO];
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) { h0[c] = 0; h1[c] = 0; }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (z < D && yy < H && xx + q < W) {
+          const int64_t off = (vbase + ((int64_t)z * H + yy) * W + xx + q) * Cout + co0;
+#pragma unroll
+          for (int c8 = 0; c8 < NCO / 8; ++c8) {
+            if (co0 + c8 * 8 < Cout) {
+              const uint4 v = *reinterpret_cast<const uint4*>(dy + off + c8 * 8);
+              const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                (q ? h1 : h0)[c8 * 8 + 2 * j] = (unsigned short)(wds[j] & 0xffffu);
+                (q ? h1 : h0)[c8 * 8 + 2 * j + 1] = (unsigned short)(wds[j] >> 16);
+              }
+            }
+          }
+        }
+      }
+      unsigned* dst = reinterpret_cast<unsigned*>(dys) + (rr * WTX) / 2 + p;
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) dst[(c * PD) / 2] = (unsigned)h0[c] | ((unsigned)h1[c] << 16);
+    }
+    __syncthreads();
+    // ---- k-steps: this wave's rows of the tile
+    for (int rr = wave; rr < ROWS; rr += 4) {
+      const int roff = ((rr / TY) * HY + (rr % TY)) * WHXP;
+      uint4 bq[NTB];
+#pragma unroll
+      for (int n = 0; n < NTB; ++n)
+        bq[n] = *reinterpret_cast<const uint4*>(dys + (n * 16 + li) * PD + rr * WTX + 8 * lk);
+      if (do_bias) {
+#pragma unroll
+        for (int n = 0; n < NTB; ++n)
+          accb[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, bq[n]), accb[n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned short* pa = xs + aoff[u] + roff;
+        const unsigned p3 = *reinterpret_cast<const unsigned*>(pa + 6);
+        const uint4 q = *reinterpret_cast<const uint4*>(pa + 8);
+        const unsigned r0 = *reinterpret_cast<const unsigned*>(pa + 16);
+        const unsigned a0 = __builtin_amdgcn_alignbit(q.x, p3, 16), a1 = __builtin_amdgcn_alignbit(q.y, q.x, 16),
+                       a2 = __builtin_amdgcn_alignbit(q.z, q.y, 16), a3 = __builtin_amdgcn_alignbit(q.w, q.z, 16),
+                       a4 = __builtin_amdgcn_alignbit(r0, q.w, 16);
+        const bf16x8 f0 = __builtin_bit_cast(bf16x8, make_uint4(a0, a1, a2, a3));
+        const bf16x8 f1 = __builtin_bit_cast(bf16x8, q);
+        const bf16x8 f2 = __builtin_bit_cast(bf16x8, make_uint4(a1, a2, a3, a4));
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+          const bf16x8 bb = __builtin_bit_cast(bf16x8, bq[n]);
+          acc[u][0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, bb, acc[u][0][n], 0, 0, 0);
+          acc[u][1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, bb, acc[u][1][n], 0, 0, 0);
+          acc[u][2][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2, bb, acc[u][2][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- sum the 4 waves through LDS (fixed order), one partial per workgroup
+  float* red = reinterpret_cast<float*>(lds);
+  for (int w4 = 0; w4 < 4; ++w4) {
+    __syncthreads();
+    if (wave == w4) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+          for (int n = 0; n < NTB; ++n) {
+            float4* slot = reinterpret_cast<float4*>(red + ((u * 3 + d) * NTB + n) * 256) + lane;
+            float4 v = make_float4(acc[u][d][n][0], acc[u][d][n][1], acc[u][d][n][2], acc[u][d][n][3]);
+            if (w4 > 0) { const float4 o = *slot; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *slot = v;
+          }
+#pragma unroll
+      for (int n = 0; n < NTB; ++n) {
+        float4* slot = reinterpret_cast<float4*>(red + (U * 3 * NTB + n) * 256) + lane;
+        float4 v = make_float4(accb[n][0], accb[n][1], accb[n][2], accb[n][3]);
+        if (w4 > 0) { const float4 o = *slot; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *slot = v;
+      }
+    }
+  }
+  __syncthreads();
+  float* out = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * RED_FL;
+  for (int i = tid; i < RED_FL; i += NTHR) out[i] = red[i];
+}
+
+// stage 1 of the partial reduction: red[j] = sum_g part[g][j] over the gx workgroup partials, j over gy * RED_FL floats.
+// 1024 threads = 64 consecutive j x 16 g-lanes: coalesced 256-byte rows, fixed assignment and fixed order (fp64):
+// deterministic.  (One thread per output element walking 512 partials 28 KB apart took longer than the MFMA kernel.)
+__global__ __launch_bounds__(1024) void wgrad_bf16_colsum_kernel(const float* __restrict__ part, float* __restrict__ red,
+                                                                 int gx, int64_t row_fl) {
+  __shared__ double sm[16][64];
+  const int o = threadIdx.x & 63, gl = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + o;
+  double a = 0.0;
+  if (j < row_fl)
+    for (int g = gl; g < gx; g += 16) a += (double)part[(int64_t)g * row_fl + j];
+  sm[gl][o] = a;
+  __syncthreads();
+  if (gl == 0 && j < row_fl) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][o];
+    red[j] = (float)t;
+  }
+}
+
+// stage 2: d_w[co][ci][tap] / d_bias[co] gathered out of the reduced fragment-layout buffer (call with gx = 1).
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                float* __restrict__ dbias, int Cin, int Cout, int CIB, int U,
+                                                                int NTB, int gx, int gy, int n_coblk) {
+  const int nW = Cout * Cin * 27;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nW + Cout) return;
+  const int SLOTS = U * 3 + 1, RED_FL = SLOTS * NTB * 256;
+  const int GPB = CIB == 16 ? 9 : (CIB == 8 ? 5 : 3);
+  int co, slot, m, chunk;
+  if (i < nW) {
+    const int tap = i % 27, ci = (i / 27) % Cin;
+    co = i / (27 * Cin);
+    const int combo = tap / 3, dx = tap % 3;
+    int gl;
+    if (CIB == 16) { gl = combo; m = ci % 16; }
+    else if (CIB == 8) { gl = combo / 2; m = (combo % 2) * 8 + ci; }
+    else { gl = combo / 4; m = (combo % 4) * 4 + ci; }
+    const int gg = (CIB == 16 ? (ci / 16) * GPB : 0) + gl;
+    chunk = gg / U;
+    slot = (gg % U) * 3 + dx;
+  } else {
+    co = i - nW; chunk = 0; slot = U * 3; m = 0;
+  }
+  const int nbg = co / 16, yb = nbg / NTB, nb = nbg % NTB, n = co % 16;
+  const int lane = (m / 4) * 16 + n, reg = m % 4;
+  const size_t off = (size_t)(chunk * n_coblk + yb) * RED_FL + (size_t)(slot * NTB + nb) * 256 + lane * 4 + reg;
+  double a = 0.0;
+  for (int g = 0; g < gx; ++g) a += (double)part[(size_t)g * gy * RED_FL + off];
+  if (i < nW) dw[i] = (float)a;
+  else if (dbias) dbias[co] = (float)a;
+}
+
+struct WgBf16Plan { int cib, u, ntb, tz, ty, n_chunk, n_coblk, gy, gx, ntiles, tiles_x, tiles_y, tiles_z, red_fl; };
+inline WgBf16Plan plan_wgrad_bf16(int B, int D, int H, int W, int Cin, int Cout) {
+  WgBf16Plan p;
+  if (Cin <= 4) { p.cib = 4; p.u = 3; p.ntb = 1; p.tz = 4; p.ty = 8; }
+  else if (Cin <= 8) { p.cib = 8; p.u = 5; p.ntb = 1; p.tz = 4; p.ty = 8; }
+  else if (Cout <= 16) { p.cib = 16; p.u = 9; p.ntb = 1; p.tz = 2; p.ty = 8; }
+  else { p.cib = 16; p.u = 3; p.ntb = 2; p.tz = 2; p.ty = 4; }
+  const int gpb = p.cib == 16 ? 9 : (p.cib == 8 ? 5 : 3);
+  const int nblk = p.cib == 16 ? cdiv(Cin, 16) : 1;
+  p.n_chunk = nblk * gpb / p.u;
+  p.n_coblk = cdiv(Cout, p.ntb * 16);
+  p.gy = p.n_chunk * p.n_coblk;
+  p.tiles_x = cdiv(W, WTX); p.tiles_y = cdiv(H, p.ty); p.tiles_z = cdiv(D, p.tz);
+  p.ntiles = B * p.tiles_x * p.tiles_y * p.tiles_z;
+  int gx = (256 * 2) / p.gy;
+  if (gx < 1) gx = 1;
+  if (gx > p.ntiles) gx = p.ntiles;
+  p.gx = gx;
+  p.red_fl = (p.u * 3 + 1) * p.ntb * 256;
+  return p;
+}
+
+struct Bf16Plan { int tz, ty, ck, nt, nstage, cinp, coutp, ksteps; };
+inline int round_up_i(int a, int b) { return (a + b - 1) / b * b; }
+inline Bf16Plan plan_bf16(int64_t V, int Cin, int Cout) {
+  Bf16Plan p;
+  p.cinp = round_up_i(Cin, 8);
+  p.ck = p.cinp % 32 == 0 ? 32 : (p.cinp % 16 == 0 ? 16 : 8);
+  p.nstage = p.cinp / p.ck;
+  p.nt = Cout <= 16 ? 1 : 2;
+  p.coutp = round_up_i(Cout, p.nt * 16);
+  p.ksteps = (27 * p.ck + 31) / 32;
+  if (V >= 500000 && p.ck <= 16 && p.nt == 1) { p.tz = 8; p.ty = 8; }
+  else if (V >= 60000) { p.tz = 4; p.ty = 8; }
+  else { p.tz = 2; p.ty = 4; }
+  return p;
+}
+
+inline size_t bf16_wpk_elems(int Cin, int Cout) {
+  // generous: any plan pads Cin to a multiple of 8 (k to 32 per step) and Cout to a multiple of 32
+  return (size_t)round_up_i(27 * round_up_i(Cin, 32), 32) * round_up_i(Cout, 32) + 1024;
+}
+
+template <bool IN_BF16, bool OUT_BF16, bool STATS>
+int launch_bf16(const void* x, const float* w, const float* bias, void* y, void* ws, float* stats, int B, int D, int H, int W,
+                int Cin, int Cout, int mode, hipStream_t s) {
+  const int64_t V = (int64_t)D * H * W;
+  const Bf16Plan p = plan_bf16(V, Cin, Cout);
+  unsigned short* wpk = (unsigned short*)ws;
+  const int total = p.nstage * p.ksteps * p.coutp * 32;
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w, wpk,
+                     Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode);
+  const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
+  const dim3 grid(tiles_x * tiles_y * tiles_z, p.coutp / (p.nt * 16), B);
+  float* shift = nullptr;
+  float* rows = nullptr;
+  if (STATS) {
+    shift = stats;
+    rows = stats + (size_t)B * Cout;
+    hipLaunchKernelGGL(conv_shift_bf16_kernel<IN_BF16>, dim3(cdiv(B * Cout, 4)), dim3(256), 0, s, x, w, bias, shift, B, D, H, W,
+                       Cin, Cout);
+  }
+#define BF_LAUNCH(TZ_, TY_, CK_, NT_)                                                                                     \
+  hipLaunchKernelGGL((conv3d_bf16_kernel<TZ_, TY_, CK_, NT_, IN_BF16, OUT_BF16, STATS>), grid, dim3(NTHR), 0, s, x,        \
+                     (const uint4*)wpk, bias, y, rows, (const float*)shift, D, H, W, Cin, Cout, p.coutp, p.nstage, tiles_x, tiles_y)
+#define BF_CK(TZ_, TY_, NT_)                                  \
+  do {                                                        \
+    if (p.ck == 8) BF_LAUNCH(TZ_, TY_, 8, NT_);               \
+    else if (p.ck == 16) BF_LAUNCH(TZ_, TY_, 16, NT_);        \
+    else BF_LAUNCH(TZ_, TY_, 32, NT_);                        \
+  } while (0)
+  if (p.tz == 8) {                       // ck <= 16, nt == 1 by construction
+    if (p.ck == 8) BF_LAUNCH(8, 8, 8, 1); else BF_LAUNCH(8, 8, 16, 1);
+  } else if (p.tz == 4) {
+    if (p.nt == 1) BF_CK(4, 8, 1); else BF_CK(4, 8, 2);
+  } else {
+    if (p.nt == 1) BF_CK(2, 4, 1); else BF_CK(2, 4, 2);
+  }
+#undef BF_CK
+#undef BF_LAUNCH
+  return modet_launch_status();
+}
+
+inline int bf16_tiles_per_sample(int D, int H, int W, int Cin, int Cout) {
+  const Bf16Plan p = plan_bf16((int64_t)D * H * W, Cin, Cout);
+  return cdiv(W, TX) * cdiv(H, p.ty) * cdiv(D, p.tz);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t modet_conv3d_bf16_ws_bytes(int Cin, int Cout) {
+  const int m = Cin > Cout ? Cin : Cout;
+  return bf16_wpk_elems(m, m) * sizeof(unsigned short);
+}
+
+size_t modet_conv3d_bf16_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  if (Cout % 4 != 0 || Cout > 128) return 0;
+  // [sample][Cout] shift header, then one row [Cout][2] per (sample, output tile); reduced by modet_instnorm_*_stats*
+  return ((size_t)B * Cout + (size_t)B * bf16_tiles_per_sample(D, H, W, Cin, Cout) * Cout * 2) * sizeof(float);
+}
+
+int modet_conv3d_bf16_fwd(const void* x, int x_bf16, const float* w, const float* bias, void* y, void* ws, size_t ws_bytes,
+                          float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                          modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && B <= 65535);
+  if (Cout % 8 != 0 || (x_bf16 ? Cin % 8 != 0 : Cin % 4 != 0)) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < bf16_wpk_elems(Cin, Cout) * sizeof(unsigned short)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  if (stats) {
+    if (stats_bytes < modet_conv3d_bf16_stats_bytes(B, D, H, W, Cin, Cout) || stats_bytes == 0) return MODET_ERR_WORKSPACE;
+    return x_bf16 ? launch_bf16<true, true, true>(x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, s)
+                  : launch_bf16<false, true, true>(x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, s);
+  }
+  return x_bf16 ? launch_bf16<true, true, false>(x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, s)
+                : launch_bf16<false, true, false>(x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, s);
+}
+
+int modet_conv3d_bf16_bwd_data(const void* d_y, const float* w, void* d_x, int dx_bf16, void* ws, size_t ws_bytes, int B, int D,
+                               int H, int W, int Cin, int Cout, modet_stream_t stream) {
+  MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(w); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && B <= 65535);
+  if (Cout % 8 != 0 || (dx_bf16 ? Cin % 8 != 0 : Cin % 4 != 0)) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < bf16_wpk_elems(Cout, Cin) * sizeof(unsigned short)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  // a convolution of d_y (Cout channels, bf16) producing Cin channels
+  return dx_bf16 ? launch_bf16<true, true, false>(d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, s)
+                 : launch_bf16<true, false, false>(d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, s);
+}
+
+size_t modet_conv3d_bf16_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  const WgBf16Plan p = plan_wgrad_bf16(B, D, H, W, Cin, Cout);
+  return ((size_t)p.gx + 1) * p.gy * p.red_fl * sizeof(float);        // workgroup partials + their column sums
+}
+
+int modet_conv3d_bf16_bwd_weight(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
+                                 size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  if (Cout % 8 != 0 || (x_bf16 ? Cin % 8 != 0 : Cin % 4 != 0)) return MODET_ERR_UNSUPPORTED;
+  if (Cin > 8 && Cin % 16 != 0) return MODET_ERR_UNSUPPORTED;            // channel blocks of 16 beyond Cin = 8
+  if (Cin == 4 && x_bf16) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_conv3d_bf16_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
+  const WgBf16Plan p = plan_wgrad_bf16(B, D, H, W, Cin, Cout);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(p.gx, p.gy);
+#define WG_BF(CIB_, U_, NTB_, TZ_, TY_)                                                                                     \
+  do {                                                                                                                     \
+    if (x_bf16) hipLaunchKernelGGL((conv3d_bf16_wgrad_kernel<CIB_, U_, NTB_, TZ_, TY_, true>), grid, dim3(NTHR), 0, s, x,  \
+                                   (const unsigned short*)d_y, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, \
+                                   p.ntiles, p.n_coblk);                                                                    \
+    else hipLaunchKernelGGL((conv3d_bf16_wgrad_kernel<CIB_, U_, NTB_, TZ_, TY_, false>), grid, dim3(NTHR), 0, s, x,        \
+                            (const unsigned short*)d_y, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z,    \
+                            p.ntiles, p.n_coblk);                                                                           \
+  } while (0)
+  if (p.cib == 4) hipLaunchKernelGGL((conv3d_bf16_wgrad_kernel<4, 3, 1, 4, 8, false>), grid, dim3(NTHR), 0, s, x,
+                                     (const unsigned short*)d_y, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z,
+                                     p.ntiles, p.n_coblk);
+  else if (p.cib == 8) WG_BF(8, 5, 1, 4, 8);
+  else if (p.u == 9) WG_BF(16, 9, 1, 2, 8);
+  else WG_BF(16, 3, 2, 2, 4);
+#undef WG_BF
+  const int nout = Cout * Cin * 27 + Cout;
+  const int64_t row_fl = (int64_t)p.gy * p.red_fl;
+  float* red = (float*)ws + (size_t)p.gx * row_fl;
+  hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, (const float*)ws, red, p.gx, row_fl);
+  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, s, (const float*)red, d_w, d_bias, Cin, Cout,
+                     p.cib, p.u, p.ntb, 1, p.gy, p.n_coblk);
+  return modet_launch_status();
+}
+
+}  // extern "C"

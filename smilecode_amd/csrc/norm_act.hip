@@ -232,6 +232,139 @@ __global__ __launch_bounds__(BLK) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 storage (cfg 5)
+// InstanceNorm + LeakyReLU on bf16-stored conv outputs (csrc/conv3d_bf16.hip): 8 channels = 16 bytes per thread,
+// all arithmetic in fp32, statistics (mean / rstd, the backward sums) fp32 as in the fp32 path.
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned bf_pack(float a, float b) {            // round to nearest even (v_cvt_pk_bf16_f32)
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ void bf_unpack8(const uint4 v, float (&f)[8]) {
+  f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+  f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+template <bool BF>
+__device__ __forceinline__ void load8(const void* base, int64_t i8, float (&f)[8]) {      // i8: index in units of 8 elements
+  if (BF) {
+    bf_unpack8(reinterpret_cast<const uint4*>(base)[i8], f);
+  } else {
+    const float4 a = reinterpret_cast<const float4*>(base)[2 * i8], b = reinterpret_cast<const float4*>(base)[2 * i8 + 1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+}
+template <bool BF>
+__device__ __forceinline__ void store8(void* base, int64_t i8, const float (&f)[8]) {
+  if (BF) {
+    reinterpret_cast<uint4*>(base)[i8] = make_uint4(bf_pack(f[0], f[1]), bf_pack(f[2], f[3]), bf_pack(f[4], f[5]), bf_pack(f[6], f[7]));
+  } else {
+    reinterpret_cast<float4*>(base)[2 * i8] = make_float4(f[0], f[1], f[2], f[3]);
+    reinterpret_cast<float4*>(base)[2 * i8 + 1] = make_float4(f[4], f[5], f[6], f[7]);
+  }
+}
+
+static inline int in_chunk8(int C) { return (BLK / (C >> 3)) * 32; }
+
+template <bool OUT_BF>
+__global__ __launch_bounds__(BLK) void in_apply_bf16_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            int64_t V, int C, int64_t total8) {
+  const int G = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total8; i += (int64_t)gridDim.x * BLK) {
+    const int g = (int)(i % G);
+    const int64_t b = (i / G) / V;
+    float xv[8], o[8];
+    load8<true>(x, i, xv);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = lrelu((xv[c] - mean[b * C + g * 8 + c]) * rstd[b * C + g * 8 + c]);
+    store8<OUT_BF>(y, i, o);
+  }
+}
+
+// (sum g, sum g*xhat), g = dy * lrelu'(xhat); x is the bf16 raw conv output
+template <bool DY_BF>
+__global__ __launch_bounds__(BLK) void in_partial_bf16_kernel(const void* __restrict__ x, const void* __restrict__ dy,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              float* __restrict__ part, int64_t V, int C, int chunk) {
+  __shared__ float red[BLK * 16];
+  const int G = C >> 3, VPB = BLK / G;
+  const int b = blockIdx.y;
+  const int g = threadIdx.x % G, vl = threadIdx.x / G;
+  const bool active = vl < VPB;
+  float a[8], q[8], mu[8], rs[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { a[c] = 0.f; q[c] = 0.f; mu[c] = 0.f; rs[c] = 1.f; }
+  if (active) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { mu[c] = mean[b * C + g * 8 + c]; rs[c] = rstd[b * C + g * 8 + c]; }
+  }
+  const int64_t v0 = (int64_t)blockIdx.x * chunk;
+  const int64_t v1 = v0 + chunk < V ? v0 + chunk : V;
+  if (active) {
+    for (int64_t v = v0 + vl; v < v1; v += VPB) {
+      const int64_t i8 = ((int64_t)b * V + v) * G + g;
+      float xs[8], gs[8];
+      load8<true>(x, i8, xs);
+      load8<DY_BF>(dy, i8, gs);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float xh = (xs[c] - mu[c]) * rs[c];
+        const float gg = gs[c] * (xh > 0.f ? 1.f : LRELU_SLOPE);
+        a[c] += gg; q[c] = fmaf(gg, xh, q[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { red[threadIdx.x * 16 + c] = a[c]; red[threadIdx.x * 16 + 8 + c] = q[c]; }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    double s[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s[c] = 0.0;
+    for (int j = 0; j < VPB; ++j) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) s[c] += (double)red[(j * G + threadIdx.x) * 16 + c];
+    }
+    float* p = part + (((int64_t)b * gridDim.x + blockIdx.x) * C + threadIdx.x * 8) * 2;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { p[c * 2] = (float)s[c]; p[c * 2 + 1] = (float)s[8 + c]; }
+  }
+}
+
+template <bool DY_BF>
+__global__ __launch_bounds__(BLK) void in_bwd_apply_bf16_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ s1, const float* __restrict__ s2,
+                                                                void* __restrict__ dx, int64_t V, int C, int64_t total8) {
+  const int G = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total8; i += (int64_t)gridDim.x * BLK) {
+    const int g = (int)(i % G);
+    const int64_t b = (i / G) / V;
+    float xs[8], gs[8], o[8];
+    load8<true>(x, i, xs);
+    load8<DY_BF>(dy, i, gs);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int bc = (int)b * C + g * 8 + c;
+      const float r = rstd[bc];
+      const float xh = (xs[c] - mean[bc]) * r;
+      const float gg = gs[c] * (xh > 0.f ? 1.f : LRELU_SLOPE);
+      o[c] = r * (gg - s1[bc] - xh * s2[bc]);
+    }
+    store8<true>(dx, i, o);
+  }
+}
+
+template <bool TO_BF>
+__global__ __launch_bounds__(BLK) void cast8_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t total8) {
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total8; i += (int64_t)gridDim.x * BLK) {
+    float f[8];
+    load8<!TO_BF>(x, i, f);
+    store8<TO_BF>(y, i, f);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -372,6 +505,59 @@ int modet_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float*
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n, BLK)), dim3(BLK), 0, (hipStream_t)stream, p, g, m, v, vmax, n,
                      step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
+  return modet_launch_status();
+}
+
+// ---- bf16 storage (cfg 5): x is always the bf16 raw conv output, statistics fp32
+size_t modet_instnorm_bf16_ws_bytes(int B, int64_t V, int C) {
+  const int64_t nchunk = cdiv64(V, in_chunk8(C));
+  return ((size_t)B * nchunk * C * 2 + (size_t)B * C * 2) * sizeof(float);
+}
+
+int modet_instnorm_lrelu_fwd_stats_bf16(const void* x, void* y, int y_bf16, float* mean, float* rstd, const float* stats,
+                                        size_t stats_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(y); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(stats);
+  MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
+  if (C % 8 != 0 || 2 * C > 256) return MODET_ERR_UNSUPPORTED;
+  int64_t rows;
+  if (rows_from_bytes(stats_bytes, B, C, &rows) != MODET_OK) return MODET_ERR_DIM;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, mean, rstd, V, C, rows, eps);
+  const int64_t total8 = (int64_t)B * V * (C / 8);
+  if (y_bf16) hipLaunchKernelGGL(in_apply_bf16_kernel<true>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total8);
+  else hipLaunchKernelGGL(in_apply_bf16_kernel<false>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total8);
+  return modet_launch_status();
+}
+
+int modet_instnorm_lrelu_bwd_bf16(const void* d_y, int dy_bf16, const void* x, const float* mean, const float* rstd, void* d_x,
+                                  void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream) {
+  MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x);
+  MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
+  if (C % 8 != 0 || C > 512) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_instnorm_bf16_ws_bytes(B, V, C)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunk = in_chunk8(C);
+  const int nchunk = (int)cdiv64(V, chunk);
+  float* part = (float*)ws;
+  float* s1 = part + (size_t)B * nchunk * C * 2;
+  float* s2 = s1 + (size_t)B * C;
+  const int64_t total8 = (int64_t)B * V * (C / 8);
+  if (dy_bf16) hipLaunchKernelGGL(in_partial_bf16_kernel<true>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C, chunk);
+  else hipLaunchKernelGGL(in_partial_bf16_kernel<false>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C, chunk);
+  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f);
+  if (dy_bf16) hipLaunchKernelGGL(in_bwd_apply_bf16_kernel<true>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2, d_x, V, C, total8);
+  else hipLaunchKernelGGL(in_bwd_apply_bf16_kernel<false>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2, d_x, V, C, total8);
+  return modet_launch_status();
+}
+
+/* y = cast(x), n % 8 == 0: to_bf16 != 0: fp32 -> bf16 (round to nearest even), else bf16 -> fp32 */
+int modet_cast_bf16(const void* x, void* y, int64_t n, int to_bf16, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(y);
+  MODET_CHECK_DIM(n > 0 && n % 8 == 0);
+  const int64_t total8 = n / 8;
+  if (to_bf16) hipLaunchKernelGGL(cast8_kernel<true>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, y, total8);
+  else hipLaunchKernelGGL(cast8_kernel<false>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, y, total8);
   return modet_launch_status();
 }
 

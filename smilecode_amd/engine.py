@@ -40,9 +40,11 @@ class Trainer:
     # ---------------------------------------------------------------- hipGraph replay of forward + backward
     def _fwd_bwd(self, moving, fixed):
         self.fp.zero_grad()
-        loss, sim, reg = self.loss(moving, fixed)
-        loss.backward()
-        self.fp.gather_grads()
+        with ops.trace_range("forward+loss"):
+            loss, sim, reg = self.loss(moving, fixed)
+        with ops.trace_range("backward"):
+            loss.backward()
+            self.fp.gather_grads()
         return loss.detach(), sim.detach(), reg.detach()
 
     def capture(self, moving, fixed, warmup=2):

@@ -114,9 +114,12 @@ class ConvInsBlock(nn.Module):
         return ops.conv3d_instnorm_lrelu(x, self.main.weight, self.main.bias)
 
 
-def _two_blocks(inp, first, second):
+def _two_blocks(inp, first, second, bf16=False):
     """ConvInsBlock -> ConvInsBlock: the first block's normalised output exists only inside the second conv's kernels
-    (ops.lazy_instnorm_conv3d); the second block's InstanceNorm is applied for real (its output has several consumers)"""
+    (ops.lazy_instnorm_conv3d); the second block's InstanceNorm is applied for real (its output has several consumers).
+    bf16: the chain's internal tensors are stored in bf16 and the convs run on the bf16 matrix pipe (cfg 5)."""
+    if bf16:
+        return ops.conv_ins_pair_bf16(inp, first.main.weight, first.main.bias, second.main.weight, second.main.bias)
     raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias)
     raw2, st2 = ops.lazy_instnorm_conv3d(raw, st, second.main.weight, second.main.bias)
     return ops._InstNormLReLU.apply(raw2, 1e-5, st2)
@@ -130,8 +133,9 @@ class _AvgPool(nn.Module):
 class Encoder(nn.Module):
     """five-level conv pyramid (reference models.py:181-228); channels-last in/out."""
 
-    def __init__(self, in_channel=1, first_out_channel=4):
+    def __init__(self, in_channel=1, first_out_channel=4, bf16=False):
         super().__init__()
+        self.bf16 = bf16
         c = first_out_channel
         self.conv0 = nn.Sequential(ConvBlock(in_channel, c), ConvInsBlock(c, 2 * c), ConvInsBlock(2 * c, 2 * c))
         self.conv1 = nn.Sequential(_AvgPool(), ConvInsBlock(2 * c, 4 * c), ConvInsBlock(4 * c, 4 * c))
@@ -142,11 +146,11 @@ class Encoder(nn.Module):
     def forward(self, x):
         # each level's output goes to the next level (pooled) AND to the caller: pool_tee fuses the two gradient paths
         outs = []
-        cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2])
+        cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2], self.bf16)
         for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
             pooled, keep = ops.pool_tee(cur)
             outs.append(keep)
-            cur = _two_blocks(pooled, blk[1], blk[2])    # blk[0] is the AvgPool3d(2) the tee already applied
+            cur = _two_blocks(pooled, blk[1], blk[2], self.bf16)    # blk[0] is the AvgPool3d(2) the tee already applied
         outs.append(cur)
         return tuple(outs)
 
@@ -154,12 +158,12 @@ class Encoder(nn.Module):
         """x = [moving; fixed] as one batch of 2B (InstanceNorm is per sample, so this is exact); returns the per-level
         features of each half: ([M1..M5], [F1..F5])"""
         Ms, Fs = [], []
-        cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2])
+        cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2], self.bf16)
         for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
             pooled, m, f = ops.pool_tee_split(cur, B)
             Ms.append(m)
             Fs.append(f)
-            cur = _two_blocks(pooled, blk[1], blk[2])            # blk[0] is the AvgPool3d(2) the tee already applied
+            cur = _two_blocks(pooled, blk[1], blk[2], self.bf16)            # blk[0] is the AvgPool3d(2) the tee already applied
         m, f = _SplitBatch.apply(cur, B)
         Ms.append(m)
         Fs.append(f)
@@ -290,8 +294,14 @@ class ModeT(nn.Module):
     _flavour = "grid"
 
     def __init__(self, inshape=(160, 192, 160), in_channel=1, channels=4, head_dim=6, num_heads=[8, 4, 2, 1, 1],
-                 scale=None, legacy_grid_buffers=False):
+                 scale=None, legacy_grid_buffers=False, act_dtype=torch.float32):
+        """``act_dtype=torch.bfloat16`` (not in the reference, BASELINE.json configs[4]): the encoder's ConvInsBlock chains
+        store their activations in bf16 and run on the bf16 matrix pipe with fp32 accumulation; parameters, statistics,
+        level features, flows, losses and the optimizer stay fp32, so checkpoints are unchanged."""
         super().__init__()
+        if act_dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError("ModeT: act_dtype must be torch.float32 or torch.bfloat16")
+        self.act_dtype = act_dtype
         for s in inshape:
             if s % 16 != 0:
                 raise RuntimeError("ModeT: every input dimension must be a multiple of 16 (four 2x poolings)")
@@ -300,7 +310,7 @@ class ModeT(nn.Module):
         self.inshape = tuple(inshape)
         c = channels
         fl = self._flavour
-        self.encoder = Encoder(in_channel=in_channel, first_out_channel=c)
+        self.encoder = Encoder(in_channel=in_channel, first_out_channel=c, bf16=act_dtype == torch.bfloat16)
         self.projblock1 = ProjectionLayer(2 * c, dim=head_dim * num_heads[4])
         self.mdt1 = ModeTransformer(head_dim * num_heads[4], num_heads[4], qk_scale=scale, buffer_flavour=fl)
         self.projblock2 = ProjectionLayer(4 * c, dim=head_dim * num_heads[3])
@@ -325,34 +335,39 @@ class ModeT(nn.Module):
         mov_cl = ops.to_channels_last(moving.contiguous())
         fix_cl = ops.to_channels_last(fixed.contiguous())
         # shared encoder on both images as one batch (InstanceNorm is per sample, so this is exact)
-        M, Fx = self.encoder.forward_pair(torch.cat([mov_cl, fix_cl], 0), B)
+        with ops.trace_range("encoder"):
+            M, Fx = self.encoder.forward_pair(torch.cat([mov_cl, fix_cl], 0), B)
         ST = self.transformer
 
-        q5, k5 = self.projblock5(Fx[4]), self.projblock5(M[4])
-        flow = self.cwm5(self.mdt5(q5, k5))
+        with ops.trace_range("level5"):
+            q5, k5 = self.projblock5(Fx[4]), self.projblock5(M[4])
+            flow = self.cwm5(self.mdt5(q5, k5))
 
-        M4 = ST[3].forward_cl(M[3], flow)
-        q4, k4 = self.projblock4(Fx[3]), self.projblock4(M4)
-        w = self.cwm4(self.mdt4(q4, k4))
-        flow = ST[2].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
+        with ops.trace_range("level4"):
+            M4 = ST[3].forward_cl(M[3], flow)
+            q4, k4 = self.projblock4(Fx[3]), self.projblock4(M4)
+            w = self.cwm4(self.mdt4(q4, k4))
+            flow = ST[2].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
-        M3 = ST[2].forward_cl(M[2], flow)
-        q3, k3 = self.projblock3(Fx[2]), self.projblock3(M3)
-        w = self.cwm3(self.mdt3(q3, k3))
-        flow = ST[1].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
+        with ops.trace_range("level3"):
+            M3 = ST[2].forward_cl(M[2], flow)
+            q3, k3 = self.projblock3(Fx[2]), self.projblock3(M3)
+            w = self.cwm3(self.mdt3(q3, k3))
+            flow = ST[1].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
-        M2 = ST[1].forward_cl(M[1], flow)
-        q2, k2 = self.projblock2(Fx[1]), self.projblock2(M2)
-        w = self.mdt2(q2, k2)
-        # w comes straight from the attention (expected offset in [-1,1]^3): bounded-flow backward, no atomics
-        flow = ops.upsample2(ST[1].forward_cl(flow, w, add_flow=True, flow_bound=1), 2.0)
+        with ops.trace_range("level2"):
+            M2 = ST[1].forward_cl(M[1], flow)
+            q2, k2 = self.projblock2(Fx[1]), self.projblock2(M2)
+            w = self.mdt2(q2, k2)
+            # w comes straight from the attention (expected offset in [-1,1]^3): bounded-flow backward, no atomics
+            flow = ops.upsample2(ST[1].forward_cl(flow, w, add_flow=True, flow_bound=1), 2.0)
 
-        M1 = ST[0].forward_cl(M[0], flow)
-        q1, k1 = self.projblock1(Fx[0]), self.projblock1(M1)
-        w = self.mdt1(q1, k1)
-        flow = ST[0].forward_cl(flow, w, add_flow=True, flow_bound=1)
-
-        y_moved = ST[0].forward_cl(mov_cl, flow)
+        with ops.trace_range("level1"):
+            M1 = ST[0].forward_cl(M[0], flow)
+            q1, k1 = self.projblock1(Fx[0]), self.projblock1(M1)
+            w = self.mdt1(q1, k1)
+            flow = ST[0].forward_cl(flow, w, add_flow=True, flow_bound=1)
+            y_moved = ST[0].forward_cl(mov_cl, flow)
         return ops.to_ncdhw(y_moved), ops.to_ncdhw(flow)
 
 
@@ -362,8 +377,8 @@ class ModeT_cu(ModeT):
     _flavour = "v"
 
     def __init__(self, inshape=(160, 192, 160), in_channel=1, channels=4, head_dim=6, num_heads=[8, 4, 2, 1, 1],
-                 scale=1, legacy_grid_buffers=False):
-        super().__init__(inshape, in_channel, channels, head_dim, num_heads, scale, legacy_grid_buffers)
+                 scale=1, legacy_grid_buffers=False, act_dtype=torch.float32):
+        super().__init__(inshape, in_channel, channels, head_dim, num_heads, scale, legacy_grid_buffers, act_dtype)
 
 
 def load_numpy_weights(model: nn.Module, weights) -> None:

@@ -102,6 +102,51 @@ class _Guard:
             torch.cuda.set_device(self.prev)
 
 
+class _Roctx:
+    """roctx ranges around the pyramid levels / phases of a step (SURVEY.md §5 tracing row): visible in
+    ``rocprofv3 --marker-trace`` timelines.  Off unless MODET_ROCTX=1 (two ctypes calls per range otherwise wasted)."""
+
+    def __init__(self):
+        import ctypes
+        import os
+        self.lib = None
+        if os.environ.get("MODET_ROCTX") == "1":
+            for name in ("libroctx64.so", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so"):
+                try:
+                    self.lib = ctypes.CDLL(name)
+                    self.lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    break
+                except OSError:
+                    continue
+
+    def push(self, name):
+        if self.lib is not None:
+            self.lib.roctxRangePushA(name.encode())
+
+    def pop(self):
+        if self.lib is not None:
+            self.lib.roctxRangePop()
+
+
+_ROCTX = None
+
+
+class trace_range:
+    """``with ops.trace_range("level3"):`` -- a roctx range when MODET_ROCTX=1, nothing otherwise"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _ROCTX
+        if _ROCTX is None:
+            _ROCTX = _Roctx()
+        _ROCTX.push(self.name)
+
+    def __exit__(self, *a):
+        _ROCTX.pop()
+
+
 # ------------------------------------------------------------------------------------------------ raw calls
 def conv3d_forward(x, w, b, act):
     _chk(x, w, b)
@@ -840,3 +885,153 @@ def jacdet_nonpos_count(flow_cl, want_det=False):
         _lib.check(_L().modet_jacdet_nonpos_count(_p(flow_cl), _p(counts), _p(det), B, D, H, W, _stream()),
                    "modet_jacdet_nonpos_count")
     return counts, det
+
+
+# ------------------------------------------------------------------------------------------------ bf16 storage (cfg 5)
+# BASELINE.json configs[4] "bf16 storage / fp32 accumulate": the ConvInsBlock chains (94 % of the step's FLOPs, half of its
+# bytes) keep their activations in bf16 and run on the bf16 matrix pipe; everything that crosses a chain's boundary (level
+# inputs / outputs, all parameters, statistics, weight gradients) stays fp32.  csrc/conv3d_bf16.hip, norm_act.hip.
+def _chk16(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("smilecode_amd: tensor must live on the GPU (the HIP path has no CPU fallback)")
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError(f"smilecode_amd: expected float32 or bfloat16, got {t.dtype}")
+        if not t.is_contiguous():
+            raise RuntimeError("smilecode_amd: tensor must be contiguous")
+
+
+def _isbf(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def cast_bf16(x, to_bf16):
+    """fp32 <-> bf16 copy (round to nearest even) by the library's own kernel"""
+    _chk16(x)
+    y = torch.empty(x.shape, dtype=torch.bfloat16 if to_bf16 else torch.float32, device=x.device)
+    with _Guard(x, "cast_bf16", 0.0, 6.0 * x.numel()):
+        _lib.check(_L().modet_cast_bf16(_p(x), _p(y), x.numel(), int(to_bf16), _stream()), "modet_cast_bf16")
+    return y
+
+
+def conv3d_bf16_forward(x, w, b, want_stats=True):
+    """y (bf16) = conv3d(x (fp32 | bf16), w) + b on the bf16 matrix pipe, fp32 accumulate; (y, stats | None)"""
+    _chk16(x)
+    _chk(w, b)
+    B, D, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, Cin, 3, 3, 3):
+        raise RuntimeError(f"conv3d_bf16: weight {tuple(w.shape)} does not match input channels {Cin}")
+    L = _L()
+    y = torch.empty((B, D, H, W, Cout), dtype=torch.bfloat16, device=x.device)
+    nb = L.modet_conv3d_bf16_ws_bytes(Cin, Cout)
+    ws = _ws(nb, x)
+    sb = L.modet_conv3d_bf16_stats_bytes(B, D, H, W, Cin, Cout) if want_stats else 0
+    stats = torch.empty(sb // 4, dtype=torch.float32, device=x.device) if sb > 0 else None
+    n = float(B) * D * H * W
+    with _Guard(x, f"conv_bf16_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
+        _lib.check(L.modet_conv3d_bf16_fwd(_p(x), _isbf(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin, Cout,
+                                           _stream()), "modet_conv3d_bf16_fwd")
+    return y, stats
+
+
+def conv3d_bf16_backward_data(dy, w, Cin, dx_bf16):
+    _chk16(dy)
+    _chk(w)
+    B, D, H, W, Cout = dy.shape
+    dx = torch.empty((B, D, H, W, Cin), dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=dy.device)
+    L = _L()
+    nb = L.modet_conv3d_bf16_ws_bytes(Cin, Cout)
+    ws = _ws(nb, dy)
+    n = float(B) * D * H * W
+    with _Guard(dy, f"conv_bf16_dgrad[{Cout}->{Cin}]", 54.0 * Cin * Cout * n, n * (2.0 * Cout + (2.0 if dx_bf16 else 4.0) * Cin)):
+        _lib.check(L.modet_conv3d_bf16_bwd_data(_p(dy), _p(w), _p(dx), int(dx_bf16), _p(ws), nb, B, D, H, W, Cin, Cout, _stream()),
+                   "modet_conv3d_bf16_bwd_data")
+    return dx
+
+
+def conv3d_bf16_backward_weight(x, dy):
+    """d_w, d_bias (fp32) from x (fp32 | bf16) and d_y (bf16)"""
+    _chk16(x, dy)
+    L = _L()
+    if hasattr(L, "modet_conv3d_bf16_bwd_weight"):
+        B, D, H, W, Cin = x.shape
+        Cout = dy.shape[-1]
+        dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+        db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+        nb = L.modet_conv3d_bf16_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)
+        ws = _ws(nb, x)
+        n = float(B) * D * H * W
+        with _Guard(x, f"conv_bf16_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
+            _lib.check(L.modet_conv3d_bf16_bwd_weight(_p(x), _isbf(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
+                                                      _stream()), "modet_conv3d_bf16_bwd_weight")
+        return dw, db
+    x32 = x if x.dtype == torch.float32 else cast_bf16(x, False)
+    return conv3d_backward_weight(x32, cast_bf16(dy, False), True)
+
+
+class _Conv3dBF16(Function):
+    """conv3d with bf16 output (+ InstanceNorm partial statistics from the fp32 accumulators, not differentiable)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y, stats = conv3d_bf16_forward(x, w, b, True)
+        ctx.save_for_backward(x, w)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = conv3d_bf16_backward_data(dy, w, x.shape[-1], x.dtype == torch.bfloat16) if ctx.needs_input_grad[0] else None
+        dw, db = conv3d_bf16_backward_weight(x, dy)
+        return dx, dw, db
+
+
+class _InstNormLReLUBF16(Function):
+    """InstanceNorm3d + LeakyReLU(0.1) of a bf16 raw conv output; y is bf16 (inside a chain) or fp32 (a level's output)"""
+
+    @staticmethod
+    def forward(ctx, x, stats, eps, out_bf16):
+        _chk16(x)
+        if x.dtype != torch.bfloat16:
+            raise RuntimeError("instnorm bf16: the raw conv output must be bfloat16")
+        B, C = x.shape[0], x.shape[-1]
+        V = x.numel() // (B * C)
+        y = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        nel = float(x.numel())
+        with _Guard(x, "instnorm_bf16_fwd", 8.0 * nel, nel * (4.0 if out_bf16 else 6.0)):
+            _lib.check(_L().modet_instnorm_lrelu_fwd_stats_bf16(_p(x), _p(y), int(out_bf16), _p(mean), _p(rstd), _p(stats),
+                                                                stats.numel() * 4, B, V, C, eps, _stream()),
+                       "modet_instnorm_lrelu_fwd_stats_bf16")
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        V = x.numel() // (B * C)
+        dx = torch.empty_like(x)
+        L = _L()
+        nb = L.modet_instnorm_bf16_ws_bytes(B, V, C)
+        ws = _ws(nb, x)
+        nel = float(x.numel())
+        with _Guard(x, "instnorm_bf16_bwd", 14.0 * nel, nel * (6.0 + 2.0 * (2.0 if _isbf(dy) else 4.0))):
+            _lib.check(L.modet_instnorm_lrelu_bwd_bf16(_p(dy), _isbf(dy), _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C,
+                                                       _stream()), "modet_instnorm_lrelu_bwd_bf16")
+        return dx, None, None, None
+
+
+def conv_ins_pair_bf16(inp, w1, b1, w2, b2, eps=1e-5):
+    """ConvInsBlock -> ConvInsBlock with bf16 storage inside the chain: fp32 (or bf16) in, fp32 out"""
+    raw1, st1 = _Conv3dBF16.apply(inp, w1, b1)
+    y1 = _InstNormLReLUBF16.apply(raw1, st1, eps, True)
+    raw2, st2 = _Conv3dBF16.apply(y1, w2, b2)
+    return _InstNormLReLUBF16.apply(raw2, st2, eps, False)

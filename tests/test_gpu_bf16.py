@@ -1,0 +1,172 @@
+"""-m gpu: BASELINE.json configs[4] -- bf16 storage / fp32 accumulate in the ConvInsBlock chains (csrc/conv3d_bf16.hip).
+
+The reference has no reduced-precision path, so the oracle for the KERNELS is exact arithmetic on the bf16-rounded
+operands (fp64 ATen on the CPU): a bf16-input / fp32-accumulate kernel must reproduce it to fp32 accumulation error, plus
+one bf16 rounding (8 significand bits, round to nearest even: at most 2^-8 relative) where the output is stored in bf16.
+End to end the tolerance against the fp64 oracle of the REFERENCE path is re-derived and stated in
+test_bf16_end_to_end_tolerances."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF_ULP = 2.0 ** -8
+
+
+def r16(t):
+    return t.bfloat16().double()
+
+
+def cl(t):
+    return t.permute(0, 2, 3, 4, 1).contiguous().cuda()
+
+
+def ncdhw(t):
+    return t.float().permute(0, 4, 1, 2, 3).double().cpu()
+
+
+CASES = [(2, 20, 24, 28, 4, 8, False), (2, 20, 24, 28, 8, 8, True), (1, 17, 12, 40, 8, 16, False), (2, 16, 16, 16, 16, 16, True),
+         (1, 9, 12, 10, 16, 32, False), (1, 33, 17, 40, 32, 32, True), (1, 9, 12, 10, 32, 64, False), (1, 5, 6, 7, 64, 64, True),
+         (1, 9, 12, 10, 64, 128, False), (2, 10, 12, 14, 128, 128, True), (1, 1, 2, 1, 64, 128, False)]
+
+
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout,inbf", CASES)
+def test_conv_bf16_fwd_dgrad_wgrad_vs_exact_on_rounded_operands(B, D, H, W, Cin, Cout, inbf):
+    from smilecode_amd import ops
+    g = torch.Generator().manual_seed(Cin * 131 + Cout)
+    x = torch.randn(B, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / np.sqrt(27 * Cin)
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(B, Cout, D, H, W, generator=g)
+    xin = cl(x).bfloat16() if inbf else cl(x)
+    # forward: bf16 output = one rounding of the exact result
+    ref = F.conv3d(r16(x), r16(w), b.double(), padding=1)
+    y, stats = ops.conv3d_bf16_forward(xin, w.cuda(), b.cuda(), True)
+    assert y.dtype == torch.bfloat16
+    err = (ncdhw(y) - ref).abs()
+    assert float((err - (1.01 * BF_ULP * ref.abs() + 2e-5 * ref.abs().max())).max()) <= 0, float(err.max())
+    # fused statistics (from the fp32 accumulators): InstanceNorm + LeakyReLU of the stored tensor, fp32 output
+    if D * H * W >= 100:          # (with a handful of voxels the variance is comparable to eps and to the rounding itself)
+        yn = ncdhw(ops._InstNormLReLUBF16.apply(y, stats, 1e-5, False))
+        refn = F.leaky_relu(F.instance_norm(ref, eps=1e-5), 0.1)
+        assert float((yn - refn).abs().max()) <= 2.5e-2        # raw tensor carries a bf16 rounding (~0.4 % of |x|/std)
+    # dgrad: fp32 output is exact to accumulation error; bf16 output adds one rounding
+    refdx = torch.nn.grad.conv3d_input(x.shape, r16(w), r16(dy), padding=1)
+    dycl = cl(dy).bfloat16()
+    dx32 = ncdhw(ops.conv3d_bf16_backward_data(dycl, w.cuda(), Cin, False))
+    assert float((dx32 - refdx).abs().max()) <= 2e-5 * float(refdx.abs().max()) + 1e-6
+    if Cin % 8 == 0:
+        dx16 = ncdhw(ops.conv3d_bf16_backward_data(dycl, w.cuda(), Cin, True))
+        e = (dx16 - refdx).abs()
+        assert float((e - (1.01 * BF_ULP * refdx.abs() + 2e-5 * refdx.abs().max())).max()) <= 0
+    # wgrad: fp32 accumulators over all voxels, deterministic fixed-order fp64 reduction over workgroups
+    refdw = torch.nn.grad.conv3d_weight(r16(x), w.shape, r16(dy), padding=1)
+    refdb = r16(dy).sum((0, 2, 3, 4))
+    dw, db = ops.conv3d_bf16_backward_weight(xin, dycl)
+    assert float((dw.double().cpu() - refdw).abs().max()) <= 3e-5 * float(refdw.abs().max()) + 1e-5
+    assert float((db.double().cpu() - refdb).abs().max()) <= 3e-5 * float(refdb.abs().max()) + 1e-5
+    dw2, db2 = ops.conv3d_bf16_backward_weight(xin, dycl)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "weight gradient must be run-to-run deterministic"
+
+
+@pytest.mark.parametrize("C,dybf", [(8, True), (8, False), (16, True), (64, False), (128, True)])
+def test_instnorm_bf16_forward_backward(C, dybf):
+    """InstanceNorm + LeakyReLU on a bf16 raw tensor: vs fp64 autograd on the SAME (bf16-valued) tensor"""
+    from smilecode_amd import ops
+    g = torch.Generator().manual_seed(C)
+    B, D, H, W = 2, 10, 12, 14
+    x = (torch.randn(B, C, D, H, W, generator=g) * 1.7 + 0.8).bfloat16()
+    dy = torch.randn(B, C, D, H, W, generator=g)
+    dy = dy.bfloat16() if dybf else dy
+    xr = x.double().requires_grad_(True)
+    yr = F.leaky_relu(F.instance_norm(xr, eps=1e-5), 0.1)
+    (gr,) = torch.autograd.grad(yr, xr, dy.double())
+    xc = cl(x.float()).bfloat16().requires_grad_(True)
+    # statistics buffer in the conv-epilogue format: a zero shift header and one row of plain sums per sample
+    xs = cl(x.float())
+    rows = torch.stack([xs.sum((1, 2, 3)), (xs * xs).sum((1, 2, 3))], -1).reshape(B, 1, C, 2)
+    stats = torch.cat([torch.zeros(B * C, device="cuda"), rows.reshape(-1)]).contiguous()
+    for out_bf in (False, True):
+        y = ops._InstNormLReLUBF16.apply(xc, stats, 1e-5, out_bf)
+        e = (ncdhw(y) - yr.detach()).abs()
+        tol = 1e-4 if not out_bf else 1.01 * BF_ULP * float(yr.abs().max()) + 1e-4
+        assert float(e.max()) <= tol, float(e.max())
+    y = ops._InstNormLReLUBF16.apply(xc, stats, 1e-5, dybf)
+    (gx,) = torch.autograd.grad(y, xc, cl(dy.float()).to(y.dtype))
+    assert gx.dtype == torch.bfloat16
+    e = (ncdhw(gx) - gr).abs()
+    assert float((e - (1.01 * BF_ULP * gr.abs() + 1e-4 * gr.abs().max())).max()) <= 0, float(e.max())
+
+
+def test_cast_kernel_round_to_nearest_even():
+    from smilecode_amd import ops
+    x = torch.randn(4096, device="cuda") * 3
+    assert torch.equal(ops.cast_bf16(x, True), x.bfloat16())
+    assert torch.equal(ops.cast_bf16(x.bfloat16(), False), x.bfloat16().float())
+
+
+def _e2e(shape, dtype, seed=24, batch=1):
+    from oracle import modet_torch as orc
+    from smilecode_amd import losses, models, synth
+    w = synth.make_weights(24)
+    mov_np, fix_np = synth.make_pair(shape, seed, batch)
+    p64 = {n: torch.from_numpy(v).double().requires_grad_(True) for n, v in w.items()}
+    loss64, _, _, y64, f64 = orc.train_loss(p64, torch.from_numpy(mov_np).double(), torch.from_numpy(fix_np).double(), (8, 4, 2, 1, 1), 6, 1.0)
+    g64 = dict(zip(p64, torch.autograd.grad(loss64, list(p64.values()))))
+    m = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1, act_dtype=dtype).cuda()
+    models.load_numpy_weights(m, w)
+    mov, fix = torch.from_numpy(mov_np).cuda(), torch.from_numpy(fix_np).cuda()
+    y, flow = m(mov, fix)
+    loss = losses.NCC_vxm()(fix, y) + losses.Grad3d(penalty="l2")(flow, fix)
+    loss.backward()
+    gv, rv = [], []
+    for n, prm in m.named_parameters():
+        if float(g64[n].abs().max()) < 1e-8:
+            continue
+        gv.append(prm.grad.double().cpu().reshape(-1)); rv.append(g64[n].reshape(-1))
+    gv, rv = torch.cat(gv), torch.cat(rv)
+    ef = (flow.double().cpu() - f64.detach())
+    return {"flow_rms": float(ef.pow(2).mean().sqrt()), "flow_p999": float(ef.abs().flatten().kthvalue(int(0.999 * ef.numel())).values),
+            "loss_err": abs(float(loss.detach()) - float(loss64)), "grad_cos": float(F.cosine_similarity(gv, rv, 0)),
+            "grad_rel_l2": float((gv - rv).norm() / rv.norm()), "flow_absmax": float(f64.abs().max())}
+
+
+@pytest.mark.parametrize("shape", [(32, 48, 32), (64, 64, 64)])
+def test_bf16_end_to_end_tolerances(shape):
+    """cfg 5 stated tolerance vs the fp64 oracle of the reference path (random non-degenerate weights, |flow| up to 9-14
+    voxels): flow rms <= 0.1 voxel and 99.9 % of the voxels within 0.75 voxel, loss within 5e-3, the full parameter
+    gradient within 20 % (relative L2) and cosine >= 0.98 -- bf16 carries 8 significand bits, and the LayerNorm over 6
+    nearly equal projections amplifies the 0.4 % feature error exactly as it amplifies fp32's 6e-8.  Measured
+    (profiles/r02_parity_bf16_*.json): rms 0.024 / 0.045 voxels, p99.9 0.23 / 0.33, gradient rel. L2 0.088 / 0.105,
+    cosine 0.9962 / 0.9951 at 32x48x32 / 64^3; the same harness on the fp32 path: rms 2e-6 / 5e-6, gradient 6e-4 / 9e-5."""
+    import json
+    import os
+    r = _e2e(shape, torch.bfloat16)
+    r32 = _e2e(shape, torch.float32)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "parity_bf16_%dx%dx%d.json" % shape), "w") as f:
+        json.dump({"bf16": r, "fp32": r32}, f, indent=1, sort_keys=True)
+    assert r["flow_rms"] <= 0.1 and r["flow_p999"] <= 0.75, r
+    assert r["loss_err"] <= 5e-3, r
+    assert r["grad_cos"] >= 0.98 and r["grad_rel_l2"] <= 0.20, r
+    assert r32["flow_rms"] <= 1e-4 and r32["grad_rel_l2"] <= 1e-2, r32       # the same harness on the fp32 path
+
+
+def test_bf16_train_steps_track_fp32_and_checkpoints_stay_fp32():
+    """a few Adam steps in bf16-storage mode follow the fp32 run's loss curve; parameters / state_dict stay fp32"""
+    from smilecode_amd import models, synth
+    from smilecode_amd.engine import Trainer
+    shape = (32, 48, 32)
+    mov, fix = (torch.from_numpy(a).cuda() for a in synth.make_pair(shape, 24))
+    curves = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1, act_dtype=dt).cuda()
+        models.load_numpy_weights(m, synth.make_weights(24))
+        tr = Trainer(m)
+        curves[dt] = [float(tr.train_step(mov, fix)[0]) for _ in range(6)]
+        assert all(v.dtype == torch.float32 for v in m.state_dict().values())
+    a, b = np.array(curves[torch.float32]), np.array(curves[torch.bfloat16])
+    assert np.abs(a - b).max() < 5e-3, (a, b)
+    assert b[-1] < b[0]
