@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="volume pairs per rank per step")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = BASELINE.json configs[4]: bf16 storage / fp32 accumulate in the ConvInsBlock chains (separate line; the headline is f32)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N>1: all-reduce the gradients in three buckets launched from backward hooks (eager steps, no hipGraph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg-2 (forward+warp) and cfg-1 (CPU 64^3) side legs")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
@@ -235,7 +237,7 @@ def main():
     model = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1,
                          act_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32).to(dev)
     models.load_numpy_weights(model, synth.make_weights(24))
-    trainer = Trainer(model)
+    trainer = Trainer(model, overlap_allreduce=args.overlap)
     mov, fix = synth.make_pair(shape, 24 + 2 * args.batch * rank, args.batch)      # per-rank pairs, weak scaling
     mov, fix = torch.from_numpy(mov).to(dev), torch.from_numpy(fix).to(dev)
 
@@ -304,7 +306,7 @@ def main():
     # the all-reduce and the Adam kernel stay eager.  A replayed graph cannot carry per-kernel events, so the roofline leg
     # below is measured over eager steps right after the timed region.
     graphed = False
-    if args.workload == "train" and args.graph != "off":
+    if args.workload == "train" and args.graph != "off" and not args.overlap:
         try:
             trainer.capture(mov, fix)
             for _ in range(2):
@@ -412,14 +414,15 @@ def main():
                 except Exception:
                     pass
         out = {
-            "metric": "volume-pairs/sec (160x192x160) fwd+bwd" if args.workload == "train" else "volume-pairs/sec (160x192x160) fwd+warp",
+            "metric": "volume-pairs/sec (%dx%dx%d) %s" % (*shape, "fwd+bwd" if args.workload == "train" else "fwd+warp"),
             "value": pairs / dt, "unit": "volume-pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("ModeT %dx%dx%d %s, batch=%d/GPU, %s" % (
                 *shape, "fp32" if args.dtype == "f32" else "bf16 storage / fp32 accumulate (ConvInsBlock chains), fp32 elsewhere", args.batch, "full train step NCC+Grad3d fwd+bwd+Adam-amsgrad" + (" + RCCL grad all-reduce" if world > 1 else "")
                 if args.workload == "train" else "forward+warp")),
-                "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                "allreduce": "3 buckets from backward hooks, overlapped" if args.overlap else "one flat all-reduce after backward"},
             "roofline": roof, "host_enqueue_ms_per_step": host_graph_ms if graphed else host_ms,
             "hip_graph": graphed, "eager": {"host_enqueue_ms_per_step": host_ms,
                                             "ms_per_step": dt_eager / roof_steps * 1e3 if dt_eager else None},

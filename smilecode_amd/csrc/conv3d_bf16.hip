@@ -10,9 +10,9 @@
 //      [halo'd voxel][CK channels] (bf16; fp32 inputs are converted while the tile is staged, zero padding included);
 //   B: one 16-byte global load per lane from weights packed [stage][k-step][cout][32 k] (L2-resident, no LDS copy),
 //      re-used by all the M tiles (output rows) of the wave;
-//   epilogue: + bias, fused InstanceNorm statistics from the fp32 accumulators (shifted sums, one row per workgroup,
-//      same buffer format as the fp32 path: see ConvIn in conv3d.hip), transpose through LDS, coalesced 16-byte stores
-//      of bf16 (or fp32) channel vectors.
+//   the MFMA takes the weights as its A and the voxels as its B operand, so a lane ends up with 4 consecutive couts
+//      of one voxel; epilogue: + bias, fused InstanceNorm statistics from the fp32 accumulators (shifted sums, one row
+//      per workgroup, same buffer format as the fp32 path: see ConvIn in conv3d.hip), direct 8/16-byte stores.
 // One workgroup = one output tile (no persistence: the tile's arithmetic is a few hundred MFMAs, the kernel is bound by
 // staging the halo'd tile; 3-5 workgroups per CU overlap each other's phases).
 // dgrad is the same kernel on flipped + transposed weights.
@@ -91,9 +91,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_bf16_kernel(const void* __restric
   constexpr int NCB = NT * 16;
   constexpr int KSTEPS = (27 * CK + 31) / 32;
   constexpr int CKB = CK / 8;                             // 16-byte channel blocks per voxel in the LDS tile
-  constexpr int OSZ = OUT_BF16 ? 2 : 4;
-  constexpr int XS_BYTES = HVOX * CK * 2, ST_BYTES = ROWS * TX * NCB * OSZ;
-  constexpr int LDS_BYTES = XS_BYTES > ST_BYTES ? XS_BYTES : ST_BYTES;
+  constexpr int LDS_BYTES = HVOX * CK * 2;
   static_assert(ROWS % 4 == 0, "rows split over 4 waves");
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   __shared__ float sred[STATS ? 4 * NCB * 2 : 2];
@@ -169,67 +167,69 @@ __global__ __launch_bounds__(NTHR) void conv3d_bf16_kernel(const void* __restric
         const bf16x8 a = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bq[step & 1][n]), acc[r][n], 0, 0, 0);
+          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[step & 1][n]), a, acc[r][n], 0, 0, 0);
       }
     }
   }
 
-  // ---- epilogue: bias, statistics, transpose through LDS, coalesced stores
-  __syncthreads();                                         // the input tile is dead: its LDS becomes the output staging
-  float sx[NT], sq[NT];
+  // ---- epilogue.  The MFMA ran with the operands swapped (A = weights, B = voxels), so D is [cout][voxel]: this lane
+  // holds voxel x = li and the 4 CONSECUTIVE couts 4*lk .. 4*lk+3 of each n tile: bias, statistics and the store need no
+  // transpose -- one 8-byte (bf16) or 16-byte (fp32) store per (row, n tile), 16 voxels x 32 contiguous bytes per wave.
+  constexpr int OSZ = OUT_BF16 ? 2 : 4;
+  float sx[NT][4], sq[NT][4];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) { sx[n] = 0.f; sq[n] = 0.f; }
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sx[n][j] = 0.f; sq[n][j] = 0.f; }
+  const bool xin_ok = x0 + li < W;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int col = n * 16 + li, co = cb0 + col;
-    const float bv = (bias && co < Cout) ? bias[co] : 0.f;
-    const float kv = (STATS && co < Cout) ? shift[b * Cout + co] : 0.f;
+    const int co = cb0 + n * 16 + lk * 4;                  // first of this lane's 4 couts (Cout % 4 == 0)
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, kv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (co < Cout) {
+      if (bias) { const float4 t4 = *reinterpret_cast<const float4*>(bias + co); bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w; }
+      if (STATS) { const float4 t4 = *reinterpret_cast<const float4*>(shift + b * Cout + co); kv[0] = t4.x; kv[1] = t4.y; kv[2] = t4.z; kv[3] = t4.w; }
+    }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const int rr = wave * RW + r;
-      const bool rowin = (z0 + rr / TY < D) && (y0 + rr % TY < H);
+      const int z = z0 + rr / TY, yy = y0 + rr % TY;
+      const bool ok = xin_ok && z < D && yy < H && co < Cout;
+      float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int xv = lk * 4 + j;                         // C/D layout: row = (lane >> 4) * 4 + reg, col = lane & 15
-        const float v = acc[r][n][j] + bv;
-        if (STATS && rowin && x0 + xv < W) { const float e = v - kv; sx[n] += e; sq[n] = fmaf(e, e, sq[n]); }
-        const int so = (rr * TX + xv) * NCB + col;
-        if (OUT_BF16) reinterpret_cast<unsigned short*>(lds)[so] = to_bf16(v);
-        else reinterpret_cast<float*>(lds)[so] = v;
+        v[j] = acc[r][n][j] + bv[j];
+        if (STATS && ok) { const float e = v[j] - kv[j]; sx[n][j] += e; sq[n][j] = fmaf(e, e, sq[n][j]); }
+      }
+      if (ok) {
+        const int64_t off = (vbase + ((int64_t)z * H + yy) * W + x0 + li) * Cout + co;
+        if (OUT_BF16) *reinterpret_cast<uint2*>((unsigned short*)yout + off) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else *reinterpret_cast<float4*>((float*)yout + off) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }
   if (STATS) {
+    // sum over the 16 voxel lanes (li), then over the 4 waves through LDS: one row per (sample, tile)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      sx[n] += __shfl_xor(sx[n], 16, 64); sq[n] += __shfl_xor(sq[n], 16, 64);
-      sx[n] += __shfl_xor(sx[n], 32, 64); sq[n] += __shfl_xor(sq[n], 32, 64);
-      if (lane < 16) { sred[(wave * NCB + n * 16 + lane) * 2] = sx[n]; sred[(wave * NCB + n * 16 + lane) * 2 + 1] = sq[n]; }
-    }
-  }
-  __syncthreads();
-  if (STATS && tid < NCB * 2) {
-    const int col = tid >> 1, which = tid & 1;
-    if (cb0 + col < Cout) {
-      float a = 0.f;
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) a += sred[(w4 * NCB + col) * 2 + which];
-      // one row per (sample, tile): [b][tile][Cout][2]
-      stats_rows[(((int64_t)b * gridDim.x + blockIdx.x) * Cout + cb0 + col) * 2 + which] = a;
-    }
-  }
-  constexpr int CPV = NCB * OSZ / 16;                      // 16-byte chunks per voxel of the staged tile
-  constexpr int EPC = 16 / OSZ;                            // channels per chunk
-  for (int idx = tid; idx < ROWS * TX * CPV; idx += NTHR) {
-    const int vox = idx / CPV, ch = idx - vox * CPV;
-    const int xv = vox % TX, rr = vox / TX;
-    const int z = z0 + rr / TY, yy = y0 + rr % TY, xx = x0 + xv;
-    const int co = cb0 + ch * EPC;
-    if (z < D && yy < H && xx < W && co < Cout) {
-      const uint4 v = *reinterpret_cast<const uint4*>(lds + ((size_t)vox * NCB + ch * EPC) * OSZ);
-      const int64_t off = (vbase + ((int64_t)z * H + yy) * W + xx) * Cout + co;
-      if (OUT_BF16) *reinterpret_cast<uint4*>((unsigned short*)yout + off) = v;
-      else *reinterpret_cast<uint4*>((float*)yout + off) = v;
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { sx[n][j] += __shfl_xor(sx[n][j], o, 64); sq[n][j] += __shfl_xor(sq[n][j], o, 64); }
+        if (li == 0) {
+          sred[(wave * NCB + n * 16 + lk * 4 + j) * 2] = sx[n][j];
+          sred[(wave * NCB + n * 16 + lk * 4 + j) * 2 + 1] = sq[n][j];
+        }
+      }
+    __syncthreads();
+    if (tid < NCB * 2) {
+      const int col = tid >> 1, which = tid & 1;
+      if (cb0 + col < Cout) {
+        float a = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) a += sred[(w4 * NCB + col) * 2 + which];
+        stats_rows[(((int64_t)b * gridDim.x + blockIdx.x) * Cout + cb0 + col) * 2 + which] = a;    // [b][tile][Cout][2]
+      }
     }
   }
 }

@@ -16,7 +16,10 @@ def poly_lr(epoch, max_epoch=30, init_lr=1e-4, power=0.9):
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-4, max_epoch=30, weights=(1.0, 1.0), betas=(0.9, 0.999), eps=1e-8, group=None):
+    def __init__(self, model, lr=1e-4, max_epoch=30, weights=(1.0, 1.0), betas=(0.9, 0.999), eps=1e-8, group=None,
+                 overlap_allreduce=False):
+        """``overlap_allreduce``: all-reduce the gradients in three buckets launched from backward hooks (eager steps only;
+        a hipGraph-replayed step reduces the whole 4 MB buffer in one call after the replay)"""
         self.model = model
         self.lr0, self.max_epoch, self.weights = lr, max_epoch, weights
         self.betas, self.eps, self.group = betas, eps, group
@@ -30,6 +33,10 @@ class Trainer:
         self.lr_last = lr
         self.sim = NCC_vxm()
         self.reg = Grad3d(penalty="l2")
+        self.buckets = None
+        if overlap_allreduce:
+            from .parallel import MODET_BUCKETS, BucketedAllReduce
+            self.buckets = BucketedAllReduce(self.fp, list(model.named_parameters()), MODET_BUCKETS, group)
 
     def loss(self, moving, fixed):
         y_moved, flow = self.model(moving, fixed)
@@ -84,9 +91,19 @@ class Trainer:
             self._static_in[1].copy_(fixed, non_blocking=True)
             self._graph.replay()
             loss, sim, reg = self._static_out
+            scale = self.fp.allreduce_grads(self.group)
+        elif self.buckets is not None:
+            self.fp.zero_grad()
+            with ops.trace_range("forward+loss"):
+                loss, sim, reg = self.loss(moving, fixed)
+            self.buckets.begin()
+            with ops.trace_range("backward+allreduce"):
+                loss.backward()
+                scale = self.buckets.finish()
+            loss, sim, reg = loss.detach(), sim.detach(), reg.detach()
         else:
             loss, sim, reg = self._fwd_bwd(moving, fixed)
-        scale = self.fp.allreduce_grads(self.group)
+            scale = self.fp.allreduce_grads(self.group)
         self.step += 1
         self.lr_last = poly_lr(epoch, self.max_epoch, self.lr0)
         ops.adam_amsgrad_step_(self.fp.flat, self.fp.grad, self.m, self.v, self.vmax, self.lr_last, self.step,

@@ -104,3 +104,93 @@ class FlatParams:
 def broadcast_parameters(flat: FlatParams, src=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat.flat, src=src, group=group)
+
+
+class BucketedAllReduce:
+    """Gradient all-reduce in a few buckets launched from backward hooks, so the collective overlaps the rest of the
+    backward pass (BASELINE.json configs[4] "overlapped all-reduce").
+
+    Buckets are contiguous ranges of the flat gradient buffer, given as lists of parameter-name prefixes in the order
+    they become READY during backward (ModeT: the per-level projection / attention / CWM parameters first, then the coarse
+    encoder levels -- 86 % of all parameters -- and the full-resolution encoder blocks last).  A bucket fires when every
+    one of its parameters has received its gradient: one fused copy into the flat range, then
+    ``all_reduce(range, async_op=True)``: torch.distributed's RCCL stream waits for the copy and runs beside the
+    remaining backward kernels; ``finish()`` joins the streams before the optimizer kernel.  Parameters that never receive
+    a gradient are zero-filled and their bucket is reduced in ``finish()``."""
+
+    def __init__(self, flat: FlatParams, named_parameters, bucket_prefixes, group=None):
+        self.flat, self.group = flat, group
+        names = [n for n, p in named_parameters if p.requires_grad]
+        if len(names) != len(flat.params):
+            raise RuntimeError("BucketedAllReduce: named_parameters does not match the flat buffer")
+        self.bucket_of = []
+        for n in names:
+            hit = [i for i, pre in enumerate(bucket_prefixes) if any(n.startswith(q) for q in pre)]
+            if len(hit) != 1:
+                raise RuntimeError(f"BucketedAllReduce: parameter {n} matches {len(hit)} buckets")
+            self.bucket_of.append(hit[0])
+        self.nb = len(bucket_prefixes)
+        self.members = [[i for i, b in enumerate(self.bucket_of) if b == k] for k in range(self.nb)]
+        for k, mem in enumerate(self.members):
+            if not mem or mem != list(range(mem[0], mem[-1] + 1)):
+                raise RuntimeError(f"BucketedAllReduce: bucket {k} is empty or not contiguous in the flat buffer")
+        self.ranges = [(flat.offsets[m[0]][0], flat.offsets[m[-1]][0] + flat.offsets[m[-1]][1]) for m in self.members]
+        self.pending, self.works, self.fired = [0] * self.nb, [], [False] * self.nb
+        self.enabled = False
+        for i, prm in enumerate(flat.params):
+            prm.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            if not self.enabled:
+                return
+            k = self.bucket_of[i]
+            self.pending[k] -= 1
+            if self.pending[k] == 0:
+                self._fire(k)
+        return hook
+
+    def _fire(self, k):
+        views, srcs = [], []
+        for i in self.members[k]:
+            off, n = self.flat.offsets[i]
+            v = self.flat.grad[off:off + n].view(self.flat.params[i].shape)
+            g = self.flat.params[i].grad
+            if g is None:
+                v.zero_()
+            else:
+                views.append(v)
+                srcs.append(g)
+        if views:
+            torch._foreach_copy_(views, srcs)
+        a, b = self.ranges[k]
+        self.fired[k] = True
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            self.works.append(dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def begin(self):
+        """call right before backward()"""
+        self.pending = [len(m) for m in self.members]
+        self.works, self.fired = [], [False] * self.nb
+        self.enabled = True
+
+    def finish(self):
+        """after backward(): reduce whatever did not fire (unused parameters), join every collective; returns 1/world"""
+        self.enabled = False
+        for k in range(self.nb):
+            if not self.fired[k]:
+                self._fire(k)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if dist.is_available() and dist.is_initialized():
+            return 1.0 / dist.get_world_size(self.group)
+        return 1.0
+
+
+# readiness order of ModeT's parameters during backward (reference ModeT/models.py:377-412 run in reverse)
+MODET_BUCKETS = (
+    ("projblock", "mdt", "cwm"),                                     # per-level heads: ready before the encoder's backward starts
+    ("encoder.conv4", "encoder.conv3", "encoder.conv2"),             # coarse encoder levels: 86 % of the parameters
+    ("encoder.conv1", "encoder.conv0"),                              # full / half resolution blocks: last
+)

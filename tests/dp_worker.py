@@ -17,7 +17,7 @@ rank, local, world = init_from_env("gloo")
 torch.cuda.set_device(0)
 model = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).cuda()
 models.load_numpy_weights(model, synth.make_weights(24 + rank))      # rank 1 starts different: the broadcast must fix it
-tr = Trainer(model)
+tr = Trainer(model, overlap_allreduce=os.environ.get("MODET_OVERLAP") == "1")
 mov, fix = synth.make_pair(shape, 24, world)                          # the same batch the single-process run uses
 mov, fix = torch.from_numpy(mov[rank:rank + 1]).cuda(), torch.from_numpy(fix[rank:rank + 1]).cuda()
 tr.train_step(mov, fix, epoch=0)

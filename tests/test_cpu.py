@@ -265,6 +265,67 @@ def test_data_parallel_lockstep_uneven_pairs_gloo_world2():
     assert np.array_equal(res[0][2], res[1][2])
 
 
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from smilecode_amd.parallel import BucketedAllReduce, FlatParams, broadcast_parameters, init_from_env
+    init_from_env("gloo")
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 3),
+                              torch.nn.Linear(3, 3))            # module 5 is never used: its bucket must still be reduced
+    fp = FlatParams(net)
+    broadcast_parameters(fp)
+    bk = BucketedAllReduce(fp, list(net.named_parameters()), (("4.", "5."), ("2.",), ("0.",)))
+    fired = []
+    orig = bk._fire
+    bk._fire = lambda k: (fired.append(k), orig(k))[1]
+    x = torch.full((5, 6), 0.1 * (rank + 1))
+    out = []
+    for it in range(2):                                         # two steps: the hooks re-arm
+        fp.zero_grad()
+        loss = net[4](net[3](net[2](net[1](net[0](x))))).square().sum() * (it + 1)
+        fired.clear()
+        bk.begin()
+        loss.backward()
+        order_in_backward = list(fired)
+        scale = bk.finish()
+        out.append((fp.grad * scale).clone().numpy())
+        # reference: plain path on the same local gradient
+        fp.zero_grad()
+        loss = net[4](net[3](net[2](net[1](net[0](x))))).square().sum() * (it + 1)
+        loss.backward()
+        fp.gather_grads()
+        s2 = fp.allreduce_grads()
+        out.append((fp.grad * s2).clone().numpy())
+    q.put((rank, out, order_in_backward, list(fired)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_allreduce_gloo_world2():
+    """cfg 5's overlapped all-reduce: buckets fire from backward hooks in readiness order (last layers first), the result
+    equals the single all-reduce after backward, unused parameters do not hang the step"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29211 + os.getpid() % 200
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, out, in_bwd, all_fired in res:
+        assert np.allclose(out[0], out[1], rtol=0, atol=1e-7) and np.allclose(out[2], out[3], rtol=0, atol=1e-7)
+        assert in_bwd == [1, 2], in_bwd          # buckets 1 (layer 2) then 2 (layer 0) fired DURING backward, in readiness order
+        assert all_fired == [1, 2, 0]            # bucket 0 holds the unused layer 5: reduced by finish()
+    assert np.array_equal(res[0][1][0], res[1][1][0]), "ranks must end with identical averaged gradients"
+    from smilecode_amd.parallel import MODET_BUCKETS
+    from smilecode_amd import synth
+    for n in synth.param_spec():
+        assert sum(any(n.startswith(q) for q in pre) for pre in MODET_BUCKETS) == 1, n
+
+
 def test_bench_self_launches_n_ranks_and_refuses_missing_gpus():
     """`python bench.py --gpus N` (no torchrun env) must itself start N ranks and prove it in the JSON line; with fewer
     than N GPUs it must fail loudly instead of silently running world=1.  Exercised on gloo with the
