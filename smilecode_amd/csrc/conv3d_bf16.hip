@@ -120,41 +120,65 @@ __global__ __launch_bounds__(NTHR) void conv3d_bf16_kernel(const void* __restric
 
   for (int s = 0; s < nstage; ++s) {
     if (s > 0) __syncthreads();                            // every wave is done reading the previous stage's tile
-    // ---- stage the halo'd input tile: [voxel][CK] bf16, zeros outside the volume and beyond Cin
-    for (int idx = tid; idx < HVOX * CKB; idx += NTHR) {
-      const int hv = idx / CKB, cb = idx - hv * CKB;
-      const int hx = hv % HX, t2 = hv / HX;
-      const int hy = t2 % HY, hz = t2 / HY;
-      const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
-      const int c = s * CK + cb * 8;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin) {
-        const int64_t off = (vbase + ((int64_t)z * H + yy) * W + xx) * Cin + c;
-        if (IN_BF16) {
-          v = *reinterpret_cast<const uint4*>((const unsigned short*)xin + off);       // Cin % 8 == 0 (host checks)
-        } else {
-          const float* p = (const float*)xin + off;
-          const float4 a = *reinterpret_cast<const float4*>(p);                         // Cin % 4 == 0 (host checks)
-          v.x = pack_bf16x2(a.x, a.y); v.y = pack_bf16x2(a.z, a.w);
-          if (c + 4 < Cin) {
-            const float4 q = *reinterpret_cast<const float4*>(p + 4);
-            v.z = pack_bf16x2(q.x, q.y); v.w = pack_bf16x2(q.z, q.w);
+    // ---- stage the halo'd input tile: [voxel][CK] bf16, zeros outside the volume and beyond Cin.  All global loads of a
+    // batch are issued before the first LDS write (a load -> write -> load chain exposed one memory round trip per item:
+    // 7-15 per tile, 24 us per tile against 1 us of MFMA work).
+    constexpr int NITEM = HVOX * CKB, NIT = (NITEM + NTHR - 1) / NTHR;
+    constexpr int BATCH = IN_BF16 ? 8 : 4;
+#pragma unroll
+    for (int it0 = 0; it0 < NIT; it0 += BATCH) {
+      uint4 raw[BATCH];
+      float4 rf[IN_BF16 ? 1 : BATCH][2];
+#pragma unroll
+      for (int q = 0; q < BATCH; ++q) {
+        const int idx = tid + (it0 + q) * NTHR;
+        raw[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (!IN_BF16) { rf[q][0] = make_float4(0.f, 0.f, 0.f, 0.f); rf[q][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (it0 + q < NIT && idx < NITEM) {
+          const int hv = idx / CKB, cb = idx - hv * CKB;
+          const int hx = hv % HX, t2 = hv / HX;
+          const int hy = t2 % HY, hz = t2 / HY;
+          const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+          const int c = s * CK + cb * 8;
+          if (z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin) {
+            const int64_t off = (vbase + ((int64_t)z * H + yy) * W + xx) * Cin + c;
+            if (IN_BF16) {
+              raw[q] = *reinterpret_cast<const uint4*>((const unsigned short*)xin + off);       // Cin % 8 == 0 (host checks)
+            } else {
+              const float* p = (const float*)xin + off;
+              rf[q][0] = *reinterpret_cast<const float4*>(p);                                   // Cin % 4 == 0 (host checks)
+              if (c + 4 < Cin) rf[q][1] = *reinterpret_cast<const float4*>(p + 4);
+            }
           }
         }
       }
-      *reinterpret_cast<uint4*>(lds + ((size_t)hv * CK + cb * 8) * 2) = v;
+#pragma unroll
+      for (int q = 0; q < BATCH; ++q) {
+        const int idx = tid + (it0 + q) * NTHR;
+        if (it0 + q < NIT && idx < NITEM) {
+          uint4 v = raw[q];
+          if (!IN_BF16) {
+            v.x = pack_bf16x2(rf[q][0].x, rf[q][0].y); v.y = pack_bf16x2(rf[q][0].z, rf[q][0].w);
+            v.z = pack_bf16x2(rf[q][1].x, rf[q][1].y); v.w = pack_bf16x2(rf[q][1].z, rf[q][1].w);
+          }
+          const int hv = idx / CKB, cb = idx - hv * CKB;
+          *reinterpret_cast<uint4*>(lds + ((size_t)hv * CK + cb * 8) * 2) = v;
+        }
+      }
     }
     __syncthreads();
     // ---- K loop: k-step = 32 k values = 4 lane groups x 8 consecutive channels of one tap
     const uint4* wst = wpk + ((size_t)s * KSTEPS * CoutP + cb0) * 4;
-    uint4 bq[2][NT];
+    // a RUN-TIME loop over the k-steps (fully unrolled, the compiler hoisted the LDS reads of all 7..27 steps and the
+    // kernel needed 244..418 registers: 1-2 waves per SIMD, latency-bound); the next step's weights are prefetched
+    uint4 bcur[NT], bnext[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bq[0][n] = wst[(size_t)(n * 16 + li) * 4 + lk];
-#pragma unroll
+    for (int n = 0; n < NT; ++n) bcur[n] = wst[(size_t)(n * 16 + li) * 4 + lk];
+#pragma unroll 1
     for (int step = 0; step < KSTEPS; ++step) {
       if (step + 1 < KSTEPS) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bq[(step + 1) & 1][n] = wst[((size_t)(step + 1) * CoutP + n * 16 + li) * 4 + lk];
+        for (int n = 0; n < NT; ++n) bnext[n] = wst[((size_t)(step + 1) * CoutP + n * 16 + li) * 4 + lk];
       }
       const int kb = step * 4 + lk;                        // this lane group's block of 8 k values
       int tap = (kb * 8) / CK;
@@ -167,8 +191,10 @@ __global__ __launch_bounds__(NTHR) void conv3d_bf16_kernel(const void* __restric
         const bf16x8 a = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[step & 1][n]), a, acc[r][n], 0, 0, 0);
+          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bcur[n]), a, acc[r][n], 0, 0, 0);
       }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bcur[n] = bnext[n];
     }
   }
 
@@ -527,7 +553,7 @@ inline Bf16Plan plan_bf16(int64_t V, int Cin, int Cout) {
   p.nt = Cout <= 16 ? 1 : 2;
   p.coutp = round_up_i(Cout, p.nt * 16);
   p.ksteps = (27 * p.ck + 31) / 32;
-  if (V >= 500000 && p.ck <= 16 && p.nt == 1) { p.tz = 8; p.ty = 8; }
+  if (false && V >= 500000 && p.ck <= 16 && p.nt == 1) { p.tz = 8; p.ty = 8; }
   else if (V >= 60000) { p.tz = 4; p.ty = 8; }
   else { p.tz = 2; p.ty = 4; }
   return p;

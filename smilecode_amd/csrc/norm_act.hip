@@ -51,6 +51,31 @@ __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict
       }
     }
   }
+  if ((G & (G - 1)) == 0 && G <= 64) {
+    // channel group = lane % G: a fixed xor-shuffle tree over the lanes of equal group, then the 4 waves through LDS
+    // (the former tail -- G threads walking BLK/G entries each, serially -- cost 40 us of a 157 us kernel at C = 8)
+    for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { a[c] += __shfl_xor(a[c], o, 64); q[c] += __shfl_xor(q[c], o, 64); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < G) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { red[(wave * G + lane) * 8 + c] = a[c]; red[(wave * G + lane) * 8 + 4 + c] = q[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+      double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int w = 0; w < BLK / 64; ++w) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s[c] += (double)red[(w * G + threadIdx.x) * 8 + c];
+      }
+      float* p = part + (((int64_t)b * gridDim.x + blockIdx.x) * C + threadIdx.x * 4) * 2;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { p[c * 2] = (float)s[c]; p[c * 2 + 1] = (float)s[4 + c]; }
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) { red[threadIdx.x * 8 + c] = a[c]; red[threadIdx.x * 8 + 4 + c] = q[c]; }
   __syncthreads();
@@ -264,7 +289,8 @@ __device__ __forceinline__ void store8(void* base, int64_t i8, const float (&f)[
   }
 }
 
-static inline int in_chunk8(int C) { return (BLK / (C >> 3)) * 32; }
+// voxels per partial-sum workgroup: 16 passes (twice the workgroups of the fp32 kernel per byte: a pass moves half the bytes)
+static inline int in_chunk8(int C) { return (BLK / (C >> 3)) * 16; }
 
 template <bool OUT_BF>
 __global__ __launch_bounds__(BLK) void in_apply_bf16_kernel(const void* __restrict__ x, void* __restrict__ y,
@@ -302,6 +328,7 @@ __global__ __launch_bounds__(BLK) void in_partial_bf16_kernel(const void* __rest
   const int64_t v0 = (int64_t)blockIdx.x * chunk;
   const int64_t v1 = v0 + chunk < V ? v0 + chunk : V;
   if (active) {
+#pragma unroll 4
     for (int64_t v = v0 + vl; v < v1; v += VPB) {
       const int64_t i8 = ((int64_t)b * V + v) * G + g;
       float xs[8], gs[8];
@@ -314,6 +341,31 @@ __global__ __launch_bounds__(BLK) void in_partial_bf16_kernel(const void* __rest
         a[c] += gg; q[c] = fmaf(gg, xh, q[c]);
       }
     }
+  }
+  if ((G & (G - 1)) == 0 && G <= 64) {                   // see in_partial_kernel: shuffle tree, then the 4 waves through LDS
+    for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { a[c] += __shfl_xor(a[c], o, 64); q[c] += __shfl_xor(q[c], o, 64); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < G) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { red[(wave * G + lane) * 16 + c] = a[c]; red[(wave * G + lane) * 16 + 8 + c] = q[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+      double s[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) s[c] = 0.0;
+      for (int w = 0; w < BLK / 64; ++w) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s[c] += (double)red[(w * G + threadIdx.x) * 16 + c];
+      }
+      float* p = part + (((int64_t)b * gridDim.x + blockIdx.x) * C + threadIdx.x * 8) * 2;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { p[c * 2] = (float)s[c]; p[c * 2 + 1] = (float)s[8 + c]; }
+    }
+    return;
   }
 #pragma unroll
   for (int c = 0; c < 8; ++c) { red[threadIdx.x * 16 + c] = a[c]; red[threadIdx.x * 16 + 8 + c] = q[c]; }
