@@ -84,6 +84,10 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
  * as an fp32 MFMA implicit GEMM.  x (B,D,H,W,Cin), y (B,D,H,W,Cout) channels-last;
  * w in the reference's parameter layout (Cout,Cin,3,3,3); bias (Cout) or NULL.
  * act: 0 = none, 1 = LeakyReLU(0.1) fused (ConvBlock, models.py:119-133). */
+/* 1 if the fp32 conv entry points run the opt-in "bf16x3" fp32 emulation (env MODET_CONV_SPLIT=1 at first use: fp32
+ * tensors, every product as six exact bf16 piece products on the bf16 matrix pipe, error <= 3 * 2^-24 |a b|), else 0
+ * (default: exact-f32 MFMA, bitwise an fmaf chain). */
+int modet_conv3d_uses_bf16x3(void);
 size_t modet_conv3d_ws_bytes(int Cin, int Cout);
 int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                      int B, int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream);
@@ -92,6 +96,7 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
  * (Cin, Cout) cannot fuse them (use modet_conv3d_fwd + modet_instnorm_lrelu_fwd).  Consume with
  * modet_instnorm_lrelu_fwd_stats (same stats_bytes). */
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
+size_t modet_conv3d_normin_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);   /* stats of modet_conv3d_fwd_normin */
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                            float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
                            modet_stream_t stream);

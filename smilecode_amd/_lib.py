@@ -27,9 +27,11 @@ SIGNATURES = {
     "modet_na_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, P]),
     "modet_na_bwd_ws_bytes": (SZ, [I, I, I, I, I]),
     "modet_na_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, F, P]),
+    "modet_conv3d_uses_bf16x3": (I, []),
     "modet_conv3d_ws_bytes": (SZ, [I, I]),
     "modet_conv3d_fwd": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P]),
     "modet_conv3d_stats_bytes": (SZ, [I, I, I, I, I, I]),
+    "modet_conv3d_normin_stats_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_fwd_stats": (I, [P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P]),
     "modet_conv3d_fwd_normin": (I, [P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P]),
     "modet_conv3d_bwd_data": (I, [P, P, P, P, SZ, I, I, I, I, I, I, P]),

@@ -11,11 +11,9 @@
 //   Cin<=8 packs two taps into the 16 M rows.  Workgroups walk tiles persistently, partial d_w goes to a
 //   workspace and is summed in fixed order in fp64 (deterministic, no atomics).
 #include "common.h"
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
-#ifdef MODET_TUNING
-#include <cstdlib>
-#endif
 
 namespace {
 
@@ -1323,6 +1321,22 @@ inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
 
 }  // namespace
 
+// fp32 emulation on the bf16 matrix pipe (conv3d_bf16.hip, "bf16x3"): fp32 tensors, six exact bf16 piece products per
+// multiply, error <= 3 * 2^-24 |a b| -- the accuracy class of an fp32 FMA at 2.7x less matrix-pipe time.  OPT-IN
+// (MODET_CONV_SPLIT=1) for every eligible shape (Cin % 4 == 0, Cin > 1, Cout % 4 == 0, no fused activation): all parity
+// tests pass with it, but as measured in round 2 (profiles/r02d_split_vs_exact.txt) it wins 1.2-1.4x only at pyramid levels
+// 2-3, ties at level 1 (those kernels are bound by staging the fp32 tile, not by the matrix pipe) and loses at levels
+// 4-5, so the train step does not move (12.37 vs 12.46 ms) and the default stays the exact-f32 MFMA kernels of this file.
+bool modetx_split_eligible(int Cin, int Cout);
+size_t modetx_split_ws_bytes(int Cin, int Cout);
+size_t modetx_split_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modetx_split_conv(const float* x, const float* w, const float* bias, float* y, void* ws, float* stats, int B, int D, int H,
+                      int W, int Cin, int Cout, int mode, hipStream_t s);
+static bool use_split(int Cin, int Cout) {
+  static const bool on = [] { const char* e = getenv("MODET_CONV_SPLIT"); return e && e[0] == '1'; }();
+  return on && modetx_split_eligible(Cin, Cout);
+}
+
 extern "C" {
 
 #ifdef MODET_TUNING
@@ -1331,9 +1345,12 @@ int modet_debug_conv_timing(long long* buf) {       // not in the header: tuning
 }
 #endif
 
+int modet_conv3d_uses_bf16x3(void) { return use_split(4, 4) ? 1 : 0; }
+
 size_t modet_conv3d_ws_bytes(int Cin, int Cout) {
   const int m = Cin > Cout ? Cin : Cout;       // bwd_data swaps the roles
-  return fwd_ws_elems(m, m) * sizeof(float);
+  const size_t a = fwd_ws_elems(m, m) * sizeof(float), b = modetx_split_ws_bytes(Cin, Cout);
+  return a > b ? a : b;
 }
 
 int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
@@ -1348,6 +1365,10 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
     else hipLaunchKernelGGL(conv_c1_fwd_kernel<8>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, x, w, bias, y, D, H, W, total, act);
     return modet_launch_status();
   }
+  if (!act && use_split(Cin, Cout)) {
+    if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
+    return modetx_split_conv(x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
+  }
   return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
 }
 
@@ -1361,8 +1382,14 @@ static int conv_stats_rows(int B, int D, int H, int W, int Cin, int Cout) {
   return a > b ? a : b;
 }
 
+size_t modet_conv3d_normin_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
+  return ((size_t)B * Cout + (size_t)B * conv_stats_rows(B, D, H, W, Cin, Cout) * Cout * 2) * sizeof(float);
+}
+
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
+  if (use_split(Cin, Cout)) return modetx_split_stats_bytes(B, D, H, W, Cin, Cout);     // one row per output tile
   // [sample][Cout] shift header, then [sample][workgroup][Cout][2] partial sums of (y - shift), (y - shift)^2; reduced by
   // modet_instnorm_lrelu_fwd_stats / modet_instnorm_stats
   return ((size_t)B * Cout + (size_t)B * conv_stats_rows(B, D, H, W, Cin, Cout) * Cout * 2) * sizeof(float);
@@ -1376,6 +1403,10 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
   if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
   if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
+  if (use_split(Cin, Cout)) {
+    if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
+    return modetx_split_conv(x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
+  }
   return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
                      ConvIn{nullptr, nullptr, conv_stats_rows(B, D, H, W, Cin, Cout), nullptr});
 }
@@ -1390,7 +1421,7 @@ int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const floa
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
   if (stats) {
     if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
-    if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
+    if (stats_bytes < modet_conv3d_normin_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   }
   return conv_launch(x_raw, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
                      ConvIn{in_mean, in_rstd, stats ? conv_stats_rows(B, D, H, W, Cin, Cout) : 0, nullptr});
@@ -1402,6 +1433,10 @@ int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (ws_bytes < fwd_ws_elems(Cout, Cin) * sizeof(float)) return MODET_ERR_WORKSPACE;
   // a convolution of d_y (Cout channels) producing Cin channels
+  if (use_split(Cout, Cin)) {
+    if (ws_bytes < modetx_split_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
+    return modetx_split_conv(d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, (hipStream_t)stream);
+  }
   return conv_launch(d_y, w, nullptr, d_x, (float*)ws, B, D, H, W, Cout, Cin, 0, 1, (hipStream_t)stream);
 }
 

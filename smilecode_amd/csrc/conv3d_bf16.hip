@@ -34,13 +34,24 @@ __device__ __forceinline__ unsigned short to_bf16(float a) {
   return __builtin_bit_cast(unsigned short, x);
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+// x = hi + mid + lo exactly to 2^-24 relative (three 8-bit significands, each piece rounded to nearest even; the
+// remainders x - hi and (x - hi) - mid are exact in fp32)
+__device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+  hi = to_bf16(x);
+  const float r1 = x - bf16_to_f32(hi);
+  mid = to_bf16(r1);
+  const float r2 = r1 - bf16_to_f32(mid);
+  lo = to_bf16(r2);
+}
 
 // ------------------------------------------------------------------------------------------------ weight packing
 // wpk[stage][step][n < CoutP][32] bf16: element j of k-step `step` is k' = step*32 + j within the stage,
 //   tap = k' / CK, channel c = stage*CK + k' % CK; zero for tap >= 27, c >= Cin, n >= Cout.
 //   mode 0 (forward): w[n][c][tap]   (w: (Cout, Cin, 27));   mode 1 (dgrad): w[c][n][26 - tap]  (w: (Co = c, Ci = n, 27))
+//   npiece = 3 (fp32 emulation, see conv3d_bf16_kernel SP = 3): three such arrays back to back holding the hi / mid / lo
+//   bf16 pieces of every weight.
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int Cin, int Cout,
-                                         int CoutP, int CK, int nstage, int ksteps, int mode) {
+                                         int CoutP, int CK, int nstage, int ksteps, int mode, int npiece) {
   const int total = nstage * ksteps * CoutP * 32;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int j = i & 31;
@@ -52,7 +63,13 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned s
     float v = 0.f;
     if (tap < 27 && c < Cin && n < Cout)
       v = mode == 0 ? w[((int64_t)n * Cin + c) * 27 + tap] : w[((int64_t)c * Cout + n) * 27 + 26 - tap];
-    wpk[i] = to_bf16(v);
+    if (npiece == 1) {
+      wpk[i] = to_bf16(v);
+    } else {
+      unsigned short h, m, l;
+      split3(v, h, m, l);
+      wpk[i] = h; wpk[(size_t)total + i] = m; wpk[(size_t)2 * total + i] = l;
+    }
   }
 }
 
@@ -80,19 +97,27 @@ __global__ __launch_bounds__(256) void conv_shift_bf16_kernel(const void* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
-template <int TZ, int TY, int CK, int NT, bool IN_BF16, bool OUT_BF16, bool STATS>
+// SP = 3: fp32 EMULATION on the bf16 pipe ("bf16x3").  Inputs and weights are fp32; each is split into three bf16 pieces
+// (hi + mid + lo = the fp32 value to 2^-24) while it is staged, and every product a*b is evaluated as the six piece
+// products of total order <= 2 (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi -- small terms first), each EXACT in the
+// fp32 accumulator: the three dropped terms are <= 3 * 2^-24 |a b|, the same class as the single rounding of an fp32 FMA.
+// Six bf16 MFMAs replace 8 passes of the exact-f32 MFMA at 1/16 of the rate: 2.7x less matrix-pipe time at fp32
+// accuracy (outputs, statistics and the tensors in HBM stay fp32).
+template <int TZ, int TY, int CK, int NT, bool IN_BF16, bool OUT_BF16, bool STATS, int SP = 1>
 __global__ __launch_bounds__(NTHR) void conv3d_bf16_kernel(const void* __restrict__ xin, const uint4* __restrict__ wpk,
                                                            const float* __restrict__ bias, void* __restrict__ yout,
                                                            float* __restrict__ stats_rows, const float* __restrict__ shift,
                                                            int D, int H, int W, int Cin, int Cout, int CoutP, int nstage,
-                                                           int tiles_x, int tiles_y) {
+                                                           int tiles_x, int tiles_y, int wpiece) {
   constexpr int HZ = TZ + 2, HY = TY + 2, HVOX = HZ * HY * HX;
   constexpr int ROWS = TZ * TY, RW = ROWS / 4;            // output rows (M tiles of 16 voxels) per workgroup / per wave
   constexpr int NCB = NT * 16;
   constexpr int KSTEPS = (27 * CK + 31) / 32;
   constexpr int CKB = CK / 8;                             // 16-byte channel blocks per voxel in the LDS tile
-  constexpr int LDS_BYTES = HVOX * CK * 2;
+  constexpr int PLANE = HVOX * CK * 2;                    // bytes of one piece's tile
+  constexpr int LDS_BYTES = PLANE * SP;
   static_assert(ROWS % 4 == 0, "rows split over 4 waves");
+  static_assert(SP == 1 || (SP == 3 && !IN_BF16), "the fp32 emulation takes fp32 inputs");
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   __shared__ float sred[STATS ? 4 * NCB * 2 : 2];
 
@@ -156,13 +181,31 @@ __global__ __launch_bounds__(NTHR) void conv3d_bf16_kernel(const void* __restric
       for (int q = 0; q < BATCH; ++q) {
         const int idx = tid + (it0 + q) * NTHR;
         if (it0 + q < NIT && idx < NITEM) {
-          uint4 v = raw[q];
-          if (!IN_BF16) {
-            v.x = pack_bf16x2(rf[q][0].x, rf[q][0].y); v.y = pack_bf16x2(rf[q][0].z, rf[q][0].w);
-            v.z = pack_bf16x2(rf[q][1].x, rf[q][1].y); v.w = pack_bf16x2(rf[q][1].z, rf[q][1].w);
-          }
           const int hv = idx / CKB, cb = idx - hv * CKB;
-          *reinterpret_cast<uint4*>(lds + ((size_t)hv * CK + cb * 8) * 2) = v;
+          unsigned char* dst = lds + ((size_t)hv * CK + cb * 8) * 2;
+          if constexpr (SP == 3) {
+            const float f[8] = {rf[q][0].x, rf[q][0].y, rf[q][0].z, rf[q][0].w, rf[q][1].x, rf[q][1].y, rf[q][1].z, rf[q][1].w};
+            unsigned pw[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              unsigned short h0, m0, l0, h1, m1, l1;
+              split3(f[2 * e], h0, m0, l0);
+              split3(f[2 * e + 1], h1, m1, l1);
+              pw[0][e] = (unsigned)h0 | ((unsigned)h1 << 16);
+              pw[1][e] = (unsigned)m0 | ((unsigned)m1 << 16);
+              pw[2][e] = (unsigned)l0 | ((unsigned)l1 << 16);
+            }
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+              *reinterpret_cast<uint4*>(dst + (size_t)pc * PLANE) = make_uint4(pw[pc][0], pw[pc][1], pw[pc][2], pw[pc][3]);
+          } else {
+            uint4 v = raw[q];
+            if (!IN_BF16) {
+              v.x = pack_bf16x2(rf[q][0].x, rf[q][0].y); v.y = pack_bf16x2(rf[q][0].z, rf[q][0].w);
+              v.z = pack_bf16x2(rf[q][1].x, rf[q][1].y); v.w = pack_bf16x2(rf[q][1].z, rf[q][1].w);
+            }
+            *reinterpret_cast<uint4*>(dst) = v;
+          }
         }
       }
     }
@@ -171,14 +214,19 @@ __global__ __launch_bounds__(NTHR) void conv3d_bf16_kernel(const void* __restric
     const uint4* wst = wpk + ((size_t)s * KSTEPS * CoutP + cb0) * 4;
     // a RUN-TIME loop over the k-steps (fully unrolled, the compiler hoisted the LDS reads of all 7..27 steps and the
     // kernel needed 244..418 registers: 1-2 waves per SIMD, latency-bound); the next step's weights are prefetched
-    uint4 bcur[NT], bnext[NT];
+    uint4 bcur[SP][NT], bnext[SP][NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bcur[n] = wst[(size_t)(n * 16 + li) * 4 + lk];
+    for (int pc = 0; pc < SP; ++pc)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bcur[pc][n] = wst[(size_t)pc * wpiece + (size_t)(n * 16 + li) * 4 + lk];
 #pragma unroll 1
     for (int step = 0; step < KSTEPS; ++step) {
       if (step + 1 < KSTEPS) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bnext[n] = wst[((size_t)(step + 1) * CoutP + n * 16 + li) * 4 + lk];
+        for (int pc = 0; pc < SP; ++pc)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            bnext[pc][n] = wst[(size_t)pc * wpiece + ((size_t)(step + 1) * CoutP + n * 16 + li) * 4 + lk];
       }
       const int kb = step * 4 + lk;                        // this lane group's block of 8 k values
       int tap = (kb * 8) / CK;
@@ -187,14 +235,22 @@ __global__ __launch_bounds__(NTHR) void conv3d_bf16_kernel(const void* __restric
       const int toff = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * CK + c0;
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
-        const uint4 av = *reinterpret_cast<const uint4*>(lds + (size_t)(rowoff[r] + toff) * 2);
-        const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+        bf16x8 a[SP];
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bcur[n]), a, acc[r][n], 0, 0, 0);
+        for (int pc = 0; pc < SP; ++pc)
+          a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (size_t)pc * PLANE + (size_t)(rowoff[r] + toff) * 2));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#define MM(WP, AP) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bcur[WP][n]), a[AP], acc[r][n], 0, 0, 0)
+          if constexpr (SP == 3) { MM(2, 0); MM(0, 2); MM(1, 1); MM(1, 0); MM(0, 1); MM(0, 0); }
+          else MM(0, 0);
+#undef MM
+        }
       }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bcur[n] = bnext[n];
+      for (int pc = 0; pc < SP; ++pc)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bcur[pc][n] = bnext[pc][n];
     }
   }
 
@@ -560,8 +616,9 @@ inline Bf16Plan plan_bf16(int64_t V, int Cin, int Cout) {
 }
 
 inline size_t bf16_wpk_elems(int Cin, int Cout) {
-  // generous: any plan pads Cin to a multiple of 8 (k to 32 per step) and Cout to a multiple of 32
-  return (size_t)round_up_i(27 * round_up_i(Cin, 32), 32) * round_up_i(Cout, 32) + 1024;
+  // generous: any plan pads Cin to a multiple of 8 and the k index to 32 per step (7 steps per 8 channels, 14 per 16,
+  // 27 per 32: at most 28 k slots per channel), Cout to a multiple of 32
+  return (size_t)28 * round_up_i(Cin, 32) * round_up_i(Cout, 32) + 1024;
 }
 
 template <bool IN_BF16, bool OUT_BF16, bool STATS>
@@ -572,7 +629,7 @@ int launch_bf16(const void* x, const float* w, const float* bias, void* y, void*
   unsigned short* wpk = (unsigned short*)ws;
   const int total = p.nstage * p.ksteps * p.coutp * 32;
   hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w, wpk,
-                     Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode);
+                     Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 1);
   const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
   const dim3 grid(tiles_x * tiles_y * tiles_z, p.coutp / (p.nt * 16), B);
   float* shift = nullptr;
@@ -585,7 +642,7 @@ int launch_bf16(const void* x, const float* w, const float* bias, void* y, void*
   }
 #define BF_LAUNCH(TZ_, TY_, CK_, NT_)                                                                                     \
   hipLaunchKernelGGL((conv3d_bf16_kernel<TZ_, TY_, CK_, NT_, IN_BF16, OUT_BF16, STATS>), grid, dim3(NTHR), 0, s, x,        \
-                     (const uint4*)wpk, bias, y, rows, (const float*)shift, D, H, W, Cin, Cout, p.coutp, p.nstage, tiles_x, tiles_y)
+                     (const uint4*)wpk, bias, y, rows, (const float*)shift, D, H, W, Cin, Cout, p.coutp, p.nstage, tiles_x, tiles_y, 0)
 #define BF_CK(TZ_, TY_, NT_)                                  \
   do {                                                        \
     if (p.ck == 8) BF_LAUNCH(TZ_, TY_, 8, NT_);               \
@@ -604,12 +661,75 @@ int launch_bf16(const void* x, const float* w, const float* bias, void* y, void*
   return modet_launch_status();
 }
 
+// ---- fp32 emulation ("bf16x3", SP = 3): fp32 in, fp32 out.  Channel chunks of at most 16 (three LDS planes per tile).
+inline Bf16Plan plan_split(int64_t V, int Cin, int Cout) {
+  Bf16Plan p;
+  p.cinp = round_up_i(Cin, 8);
+  p.ck = p.cinp % 16 == 0 ? 16 : 8;
+  p.nstage = p.cinp / p.ck;
+  p.nt = Cout <= 16 ? 1 : 2;
+  p.coutp = round_up_i(Cout, p.nt * 16);
+  p.ksteps = (27 * p.ck + 31) / 32;
+  if (V >= 60000) { p.tz = p.ck == 8 ? 4 : 2; p.ty = 8; }
+  else { p.tz = 2; p.ty = 4; }
+  return p;
+}
+
+template <bool STATS>
+int launch_split(const float* x, const float* w, const float* bias, float* y, void* ws, float* stats, int B, int D, int H, int W,
+                 int Cin, int Cout, int mode, hipStream_t s) {
+  const int64_t V = (int64_t)D * H * W;
+  const Bf16Plan p = plan_split(V, Cin, Cout);
+  unsigned short* wpk = (unsigned short*)ws;
+  const int total = p.nstage * p.ksteps * p.coutp * 32;
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w, wpk,
+                     Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 3);
+  const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
+  const dim3 grid(tiles_x * tiles_y * tiles_z, p.coutp / (p.nt * 16), B);
+  float* shift = nullptr;
+  float* rows = nullptr;
+  if (STATS) {
+    shift = stats;
+    rows = stats + (size_t)B * Cout;
+    hipLaunchKernelGGL(conv_shift_bf16_kernel<false>, dim3(cdiv(B * Cout, 4)), dim3(256), 0, s, (const void*)x, w, bias, shift, B, D,
+                       H, W, Cin, Cout);
+  }
+  const int wpiece = total / 8;                            // uint4 units between the hi / mid / lo weight arrays
+#define SP_LAUNCH(TZ_, TY_, CK_, NT_)                                                                                     \
+  hipLaunchKernelGGL((conv3d_bf16_kernel<TZ_, TY_, CK_, NT_, false, false, STATS, 3>), grid, dim3(NTHR), 0, s, (const void*)x, \
+                     (const uint4*)wpk, bias, (void*)y, rows, (const float*)shift, D, H, W, Cin, Cout, p.coutp, p.nstage, tiles_x, \
+                     tiles_y, wpiece)
+  if (p.tz == 4) { if (p.nt == 1) SP_LAUNCH(4, 8, 8, 1); else SP_LAUNCH(4, 8, 8, 2); }
+  else if (p.ty == 8) { if (p.nt == 1) SP_LAUNCH(2, 8, 16, 1); else SP_LAUNCH(2, 8, 16, 2); }
+  else if (p.ck == 8) { if (p.nt == 1) SP_LAUNCH(2, 4, 8, 1); else SP_LAUNCH(2, 4, 8, 2); }
+  else { if (p.nt == 1) SP_LAUNCH(2, 4, 16, 1); else SP_LAUNCH(2, 4, 16, 2); }
+#undef SP_LAUNCH
+  return modet_launch_status();
+}
+
 inline int bf16_tiles_per_sample(int D, int H, int W, int Cin, int Cout) {
   const Bf16Plan p = plan_bf16((int64_t)D * H * W, Cin, Cout);
   return cdiv(W, TX) * cdiv(H, p.ty) * cdiv(D, p.tz);
 }
 
 }  // namespace
+
+// ---- internal interface for conv3d.hip (C++ linkage, not part of the ABI): the fp32 entry points route eligible shapes here
+bool modetx_split_eligible(int Cin, int Cout) { return Cin > 1 && Cin % 4 == 0 && Cout % 4 == 0; }
+size_t modetx_split_ws_bytes(int Cin, int Cout) {
+  const int m = Cin > Cout ? Cin : Cout;
+  return 3 * bf16_wpk_elems(m, m) * sizeof(unsigned short);
+}
+size_t modetx_split_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  const Bf16Plan p = plan_split((int64_t)D * H * W, Cin, Cout);
+  const size_t tiles = (size_t)cdiv(W, TX) * cdiv(H, p.ty) * cdiv(D, p.tz);
+  return ((size_t)B * Cout + (size_t)B * tiles * Cout * 2) * sizeof(float);
+}
+int modetx_split_conv(const float* x, const float* w, const float* bias, float* y, void* ws, float* stats, int B, int D, int H, int W,
+                      int Cin, int Cout, int mode, hipStream_t s) {
+  return stats ? launch_split<true>(x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, mode, s)
+               : launch_split<false>(x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, mode, s);
+}
 
 extern "C" {
 

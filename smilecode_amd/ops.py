@@ -196,7 +196,7 @@ def conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats=True):
     y = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=x_raw.device)
     nb = L.modet_conv3d_ws_bytes(Cin, Cout)
     ws = _ws(nb, x_raw)
-    sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout) if want_stats else 0
+    sb = L.modet_conv3d_normin_stats_bytes(B, D, H, W, Cin, Cout) if want_stats else 0
     stats = torch.empty(sb // 4, dtype=torch.float32, device=x_raw.device) if sb > 0 else None
     n = float(B) * D * H * W
     with _Guard(x_raw, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
@@ -307,8 +307,11 @@ def _fuse_stats(x, w):
     no backward pass follows (measured: training +0.07 ms, inference -0.05 ms)."""
     B, D, H, W, Cin = x.shape
     Cout = w.shape[0]
-    if _L().modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout) == 0:
+    L = _L()
+    if L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout) == 0:
         return False
+    if L.modet_conv3d_uses_bf16x3():        # opt-in fp32 emulation kernels carry the statistics for every shape at no cost
+        return True
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
     return Cout in (4, 8, 16) or not needs_grad
 
