@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(const float* __restrict
 // Cout 4/8/16).  A compile-time switch: as a run-time option the statistics registers and the shift load cost the
 // kernels that never use them (dgrad, plain convs) 4-5 % (tools/ab_kernels.py, r01 vs r02a builds on one box).
 template <int TZ, int TY, int WM, int WN, int NT, int CK, bool VEC4, int P, bool MULTI, bool XF, bool ST = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && CK == 8 && !XF && P >= 2) ? 4 : 1) void conv3d_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                            const float* __restrict__ bias, float* __restrict__ y, int D,
                                                            int H, int W, int Cin, int Cout, int CinP, int CoutP, int act,
                                                            int tiles_x, int tiles_y, int tiles_z, int ntiles, float* __restrict__ stats, ConvIn inorm) {
