@@ -740,8 +740,9 @@ size_t modet_conv3d_bf16_ws_bytes(int Cin, int Cout) {
 
 size_t modet_conv3d_bf16_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (Cout % 4 != 0 || Cout > 128) return 0;
-  // [sample][Cout] shift header, then one row [Cout][2] per (sample, output tile); reduced by modet_instnorm_*_stats*
-  return ((size_t)B * Cout + (size_t)B * bf16_tiles_per_sample(D, H, W, Cin, Cout) * Cout * 2) * sizeof(float);
+  // [sample][Cout] shift header, one row [Cout][2] per (sample, output tile), and a tail of 64 rows per sample for the
+  // first stage of modet_instnorm_lrelu_fwd_stats_bf16's reduction
+  return ((size_t)B * Cout + (size_t)B * (bf16_tiles_per_sample(D, H, W, Cin, Cout) + 64) * Cout * 2) * sizeof(float);
 }
 
 int modet_conv3d_bf16_fwd(const void* x, int x_bf16, const float* w, const float* bias, void* y, void* ws, size_t ws_bytes,

@@ -118,13 +118,13 @@ __global__ __launch_bounds__(64) void in_finalize_kernel(const float* __restrict
 // statistics from the conv epilogue: stats = [B][C] shift K, then partial rows [(b*rows_per_b + r)][C][2] of
 // sum(y - K), sum((y - K)^2) (one row per workgroup of the conv; see ConvIn in conv3d.hip for why they are shifted):
 // one workgroup per sample, coalesced fixed-order fp64 column sums, then mean = K + s1/V, var = s2/V - (s1/V)^2 in fp64
-__global__ __launch_bounds__(256) void in_rows_finalize_kernel(const float* __restrict__ stats, float* __restrict__ mean,
-                                                               float* __restrict__ rstd, int64_t V, int C,
-                                                               int64_t rows_per_b, float eps) {
+__global__ __launch_bounds__(256) void in_rows_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ rows,
+                                                               float* __restrict__ mean, float* __restrict__ rstd, int64_t V,
+                                                               int C, int64_t rows_per_b, float eps) {
   __shared__ double sm[256];
   __shared__ double tot[256];
-  const int b = blockIdx.x, B = gridDim.x;
-  block_colsum_256(stats + (int64_t)B * C + (int64_t)b * rows_per_b * 2 * C, 0, rows_per_b, 2 * C, tot, sm);
+  const int b = blockIdx.x;
+  block_colsum_256(rows + (int64_t)b * rows_per_b * 2 * C, 0, rows_per_b, 2 * C, tot, sm);
   __syncthreads();
   if ((int)threadIdx.x < C) {
     const int c = threadIdx.x;
@@ -134,6 +134,23 @@ __global__ __launch_bounds__(256) void in_rows_finalize_kernel(const float* __re
     mean[b * C + c] = (float)((double)stats[b * C + c] + m);
     rstd[b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
   }
+}
+
+// stage 1 for statistics with one row per OUTPUT TILE (bf16 convs: thousands of rows per sample): IN_SLICES workgroups per
+// sample sum a slice of the rows each (fixed order, fp64) into one row of the buffer's tail; the finalize then reads
+// IN_SLICES rows.  (One workgroup walking 9 600 rows took 71 us per level-1 layer.)
+constexpr int IN_SLICES = 64;
+__global__ __launch_bounds__(256) void in_rows_slice_kernel(const float* __restrict__ rows, float* __restrict__ tail, int C,
+                                                            int64_t rows_per_b) {
+  __shared__ double sm[256];
+  __shared__ double tot[256];
+  const int b = blockIdx.y, sl = blockIdx.x;
+  const int64_t per = (rows_per_b + IN_SLICES - 1) / IN_SLICES;
+  const int64_t r0 = sl * per < rows_per_b ? sl * per : rows_per_b;                 // empty slices sum nothing
+  const int64_t r1 = r0 + per < rows_per_b ? r0 + per : rows_per_b;
+  block_colsum_256(rows + (int64_t)b * rows_per_b * 2 * C, r0, r1, 2 * C, tot, sm);
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * C) tail[((int64_t)b * IN_SLICES + sl) * 2 * C + threadIdx.x] = (float)tot[threadIdx.x];
 }
 
 __global__ __launch_bounds__(BLK) void in_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -458,7 +475,7 @@ int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float*
   int64_t rows;
   if (rows_from_bytes(stats_bytes, B, C, &rows) != MODET_OK) return MODET_ERR_DIM;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, mean, rstd, V, C, rows, eps);
+  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, stats + (size_t)B * C, mean, rstd, V, C, rows, eps);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total4);
   return modet_launch_status();
@@ -476,7 +493,8 @@ int modet_instnorm_stats(const float* x, float* mean, float* rstd, const float* 
     if (2 * C > 256) return MODET_ERR_UNSUPPORTED;
     int64_t rows;
     if (rows_from_bytes(stats_bytes, B, C, &rows) != MODET_OK) return MODET_ERR_DIM;
-    hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, (const float*)stats, mean, rstd, V, C, rows, eps);
+    hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, (const float*)stats, (const float*)stats + (size_t)B * C,
+                       mean, rstd, V, C, rows, eps);
     return modet_launch_status();
   }
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(ws);
@@ -574,7 +592,14 @@ int modet_instnorm_lrelu_fwd_stats_bf16(const void* x, void* y, int y_bf16, floa
   int64_t rows;
   if (rows_from_bytes(stats_bytes, B, C, &rows) != MODET_OK) return MODET_ERR_DIM;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, mean, rstd, V, C, rows, eps);
+  // layout (modet_conv3d_bf16_stats_bytes): [B][C] shift | [B][tiles][C][2] | tail [B][IN_SLICES][C][2]
+  const int64_t tiles = rows - IN_SLICES;
+  if (tiles <= 0) return MODET_ERR_DIM;
+  const float* trows = stats + (size_t)B * C;
+  float* tail = const_cast<float*>(trows) + (size_t)B * tiles * 2 * C;
+  hipLaunchKernelGGL(in_rows_slice_kernel, dim3(IN_SLICES, B), dim3(256), 0, s, trows, tail, C, tiles);
+  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, (const float*)tail, mean, rstd, V, C,
+                     (int64_t)IN_SLICES, eps);
   const int64_t total8 = (int64_t)B * V * (C / 8);
   if (y_bf16) hipLaunchKernelGGL(in_apply_bf16_kernel<true>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total8);
   else hipLaunchKernelGGL(in_apply_bf16_kernel<false>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total8);

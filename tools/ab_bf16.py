@@ -17,7 +17,7 @@ with torch.no_grad():
         out["dgrad" + tag] = timeit(lambda: ops.conv3d_bf16_backward_data(dy, w, cin, inbf), 20)
         out["wgrad" + tag] = timeit(lambda: ops.conv3d_bf16_backward_weight(x, dy), 20)
     x = torch.randn(*L1, 8, device="cuda").bfloat16()
-    st = torch.cat([torch.zeros(16, device="cuda"), torch.ones(2 * 1 * 8 * 2, device="cuda")])
+    st = torch.cat([torch.zeros(16, device="cuda"), torch.ones(2 * 1 * 8 * 2, device="cuda"), torch.zeros(2 * 64 * 8 * 2, device="cuda")])
     out["in_apply_bf16[C8]@160"] = timeit(lambda: ops._InstNormLReLUBF16.apply(x, st, 1e-5, True), 20)
 xr = torch.randn(*L1, 8, device="cuda").bfloat16().requires_grad_(True)
 y = ops._InstNormLReLUBF16.apply(xr, st, 1e-5, True)

@@ -9,11 +9,11 @@ TAG=${1:-r01e}
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_t -o tr -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_t -o tr -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extra --graph off > /dev/null 2>&1
 f=$(find /tmp/prof_t -name "*kernel_trace.csv" | head -1)
 python $R/tools/trace_stats.py $f --csv $OUT/${TAG}_kernel_stats_train_160x192x160.csv --top 12
-timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o t -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o t -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o t -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extra --graph off > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o t -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extra --graph off > /dev/null 2>&1
 ff=$(find /tmp/prof_f -name "*counter_collection.csv" | head -1)
 fw=$(find /tmp/prof_w -name "*counter_collection.csv" | head -1)
 python $R/tools/pmc_traffic.py $ff $fw $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic_by_kernel.csv
