@@ -2,7 +2,8 @@
 
 PyTorch is plumbing here (device memory from the caching allocator, the current HIP
 stream, autograd's tape); every arithmetic kernel is hand-written HIP behind the C ABI of
-include/modet_hip.h.  Activations are channels-last ``(B, D, H, W, C)`` fp32, contiguous.
+include/modet_hip.h.  Activations are channels-last ``(B, D, H, W, C)`` fp32 (bf16 inside the ConvInsBlock chains when the model is built with
+``act_dtype=torch.bfloat16``, see the end of this file), contiguous.
 There is no eager / CPU fallback: a missing library or a non-GPU tensor raises.
 """
 from __future__ import annotations
