@@ -74,7 +74,11 @@ class Trainer:
         torch.cuda.synchronize(moving.device)
         self.fp.zero_grad()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # with a process group alive, RCCL's watchdog thread polls events while we capture: only THIS thread's calls may
+        # invalidate the capture then (kernels the autograd thread launches into the capturing stream are captured either way)
+        import torch.distributed as dist
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with torch.cuda.graph(g, capture_error_mode=mode):
             self._static_out = self._fwd_bwd(*self._static_in)
         self._graph = g
         self._graph_key = (tuple(moving.shape), moving.device)
