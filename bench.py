@@ -305,8 +305,21 @@ def main():
     # hipGraph: forward + losses + backward + gradient packing captured once, replayed per step (engine.Trainer.capture);
     # the all-reduce and the Adam kernel stay eager.  A replayed graph cannot carry per-kernel events, so the roofline leg
     # below is measured over eager steps right after the timed region.
+    def quick(n=3):
+        """max over ranks of the wall time of n steps (untimed probe used to choose between graph replay and eager)"""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / n
+
     graphed = False
     if args.workload == "train" and args.graph != "off" and not args.overlap:
+        t_eager = quick()
         try:
             trainer.capture(mov, fix)
             for _ in range(2):
@@ -318,12 +331,22 @@ def main():
             if args.graph == "on":
                 raise
             log(f"[bench] hipGraph capture failed ({e!r}); timing the eager path")
-    if world > 1:                       # every rank must take the same path
-        flag = torch.tensor([1 if graphed else 0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if graphed and int(flag.item()) == 0:
-            trainer.release_graph()
-            graphed = False
+        if world > 1:                       # every rank must take the same path
+            flag = torch.tensor([1 if graphed else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if graphed and int(flag.item()) == 0:
+                trainer.release_graph()
+                graphed = False
+        if graphed and args.graph == "auto":
+            t_graph = quick()
+            if t_graph > 1.05 * t_eager:     # never let the replay cost throughput (same decision on every rank: both are maxima)
+                log(f"[bench] hipGraph replay is slower here ({t_graph * 1e3:.2f} vs {t_eager * 1e3:.2f} ms/step eager): using the eager path")
+                trainer.release_graph()
+                graphed = False
+                torch.cuda.empty_cache()
+                for _ in range(2):           # absorb the one-off cost of returning the graph's memory pool
+                    step()
+                torch.cuda.synchronize()
     host_graph_ms = None
     if graphed:
         torch.cuda.synchronize()
