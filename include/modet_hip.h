@@ -62,6 +62,14 @@ size_t modet_qk_bwd_ws_bytes(int B, int heads, int D, int H, int W);
 int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad,
                  float* d_q, float* d_kpad, float* d_rpb, void* ws, size_t ws_bytes,
                  int B, int heads, int D, int H, int W, int hd, modet_stream_t stream);
+/* double instantiation of the same operator: the reference dispatches float and double
+ * (AT_DISPATCH_FLOATING_TYPES, modet_kernel.cu:134 and :364); same contract, fp64 arithmetic throughout. */
+int modet_qk_fwd_f64(const double* q, const double* kpad, const double* rpb, double* attn,
+                     int B, int heads, int D, int H, int W, int hd, modet_stream_t stream);
+size_t modet_qk_bwd_ws_bytes_f64(int B, int heads, int D, int H, int W);
+int modet_qk_bwd_f64(const double* d_attn, const double* q, const double* kpad,
+                     double* d_q, double* d_kpad, double* d_rpb, void* ws, size_t ws_bytes,
+                     int B, int heads, int D, int H, int W, int hd, modet_stream_t stream);
 
 /* Fused ModeTransformer.forward (ModeT/models.py:308-334 == ModeT-cu/models.py:300-316):
  *   logits = scale*q.k(n+off) + rpb, softmax over the 27 modes, out = sum_t p[t]*off(t).

@@ -24,6 +24,9 @@ SIGNATURES = {
     "modet_qk_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "modet_qk_bwd_ws_bytes": (SZ, [I, I, I, I, I]),
     "modet_qk_bwd": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
+    "modet_qk_fwd_f64": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "modet_qk_bwd_ws_bytes_f64": (SZ, [I, I, I, I, I]),
+    "modet_qk_bwd_f64": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
     "modet_na_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, P]),
     "modet_na_bwd_ws_bytes": (SZ, [I, I, I, I, I]),
     "modet_na_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, F, P]),

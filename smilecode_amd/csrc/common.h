@@ -62,7 +62,8 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats 
 // Fixed assignment + fixed order: deterministic.  Used as stage 1 of the two-stage statistics reductions
 // (stage 2 adds the per-slice results in slice order).
 constexpr int COLSUM_SLICES = 64;
-__device__ __forceinline__ void block_colsum_256(const float* __restrict__ base, int64_t r0, int64_t r1, int ncol,
+template <typename T>
+__device__ __forceinline__ void block_colsum_256(const T* __restrict__ base, int64_t r0, int64_t r1, int ncol,
                                                  double* __restrict__ out, double* sm /* [256] shared */) {
   const int per = 256 / ncol;
   const int col = threadIdx.x % ncol, rl = threadIdx.x / ncol;

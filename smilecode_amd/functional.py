@@ -19,8 +19,15 @@ def _check_input(t, name):
         raise RuntimeError(f"{name} must be a CUDA tensor")            # CHECK_CUDA, utils.h:7
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")               # CHECK_CONTIGUOUS, utils.h:8
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"{name}: only float32 is built on the HIP path")
+    if t.dtype not in (torch.float32, torch.float64):                  # AT_DISPATCH_FLOATING_TYPES, modet_kernel.cu:134
+        raise RuntimeError(f'"modet_cu" not implemented for \'{str(t.dtype).replace("torch.", "")}\'')
+
+
+def _same_dtype(ref, *others):
+    for t in others:
+        if t is not None and t.dtype != ref.dtype:
+            raise RuntimeError(f"expected scalar type {ref.dtype} but found {t.dtype}")   # packed_accessor32<scalar_t>
+    return "_f64" if ref.dtype == torch.float64 else ""
 
 
 def modet_fw(query, key, rpb=None):
@@ -34,10 +41,11 @@ def modet_fw(query, key, rpb=None):
         _check_input(rpb, "rpb")
         if rpb.shape[1] != 3:
             raise RuntimeError("modet_fw does not support kernel size %d" % rpb.shape[1])
-    attn = torch.empty((B, heads, D, H, W, 27), dtype=torch.float32, device=query.device)
+    sfx = _same_dtype(query, key, rpb)
+    attn = torch.empty((B, heads, D, H, W, 27), dtype=query.dtype, device=query.device)
     with _Guard(query):
-        _lib.check(_lib.load().modet_qk_fwd(_p(query), _p(key), _p(rpb), _p(attn), B, heads, D, H, W, d, _stream()),
-                   "modet_qk_fwd")
+        fn = getattr(_lib.load(), "modet_qk_fwd" + sfx)
+        _lib.check(fn(_p(query), _p(key), _p(rpb), _p(attn), B, heads, D, H, W, d, _stream()), "modet_qk_fwd" + sfx)
     return attn
 
 
@@ -45,13 +53,14 @@ def modet_bw(d_attn, query, key, biasEnabled):
     _check_input(d_attn, "d_attn"); _check_input(query, "query"); _check_input(key, "key")
     B, heads, D, H, W, d = query.shape
     d_query, d_key = torch.empty_like(query), torch.empty_like(key)
-    d_rpb = torch.empty((heads, 3, 3, 3), dtype=torch.float32, device=query.device) if biasEnabled else None
+    sfx = _same_dtype(query, key, d_attn)
+    d_rpb = torch.empty((heads, 3, 3, 3), dtype=query.dtype, device=query.device) if biasEnabled else None
     L = _lib.load()
-    nb = L.modet_qk_bwd_ws_bytes(B, heads, D, H, W)
+    nb = getattr(L, "modet_qk_bwd_ws_bytes" + sfx)(B, heads, D, H, W)
     ws = _ws(nb, query)
     with _Guard(query):
-        _lib.check(L.modet_qk_bwd(_p(d_attn), _p(query), _p(key), _p(d_query), _p(d_key), _p(d_rpb), _p(ws), nb, B,
-                                  heads, D, H, W, d, _stream()), "modet_qk_bwd")
+        _lib.check(getattr(L, "modet_qk_bwd" + sfx)(_p(d_attn), _p(query), _p(key), _p(d_query), _p(d_key), _p(d_rpb),
+                                                    _p(ws), nb, B, heads, D, H, W, d, _stream()), "modet_qk_bwd" + sfx)
     return [d_query, d_key, d_rpb]
 
 

@@ -72,6 +72,41 @@ def test_qk_reference_contract(tag):
     assert_close(np64(a2), g[f"{tag}.logits"] - g[f"{tag}.rpb"].reshape(1, heads, 1, 1, 1, 27), what="qk no-bias")
 
 
+@pytest.mark.parametrize("shape,heads,d", [((5, 6, 7), 2, 6), ((3, 3, 3), 1, 4), ((9, 17, 33), 3, 8)])
+def test_qk_reference_contract_double(shape, heads, d):
+    """The operator dispatches double like the reference (AT_DISPATCH_FLOATING_TYPES, modet_kernel.cu:134,:364):
+    fp64 in, fp64 arithmetic, fp64 out -- compared with torch fp64 autograd of the same contraction at 1e-12,
+    and torch.autograd.gradcheck passes through the boundary (it needs double)."""
+    from smilecode_amd.functional import modetqkrpb_cu, modet_fw
+    D, H, W = shape
+    gen = torch.Generator().manual_seed(3)
+    qc = torch.randn((2, heads, D, H, W, d), generator=gen, dtype=torch.float64).requires_grad_(True)
+    kc = torch.zeros((2, heads, D + 2, H + 2, W + 2, d), dtype=torch.float64)
+    kc[:, :, 1:-1, 1:-1, 1:-1] = torch.randn((2, heads, D, H, W, d), generator=gen, dtype=torch.float64)
+    kc.requires_grad_(True)
+    rc = torch.randn((heads, 3, 3, 3), generator=gen, dtype=torch.float64).requires_grad_(True)
+    ga = torch.randn((2, heads, D, H, W, 27), generator=gen, dtype=torch.float64)
+    cols = [(qc * kc[:, :, a:a + D, b:b + H, c:c + W]).sum(-1) for a in range(3) for b in range(3) for c in range(3)]
+    ref = torch.stack(cols, -1) + rc.reshape(1, heads, 1, 1, 1, 27)
+    rq, rk, rr = torch.autograd.grad(ref, [qc, kc, rc], ga)
+    q, kp, rpb = (t.detach().cuda().requires_grad_(True) for t in (qc, kc, rc))
+    attn = modetqkrpb_cu(q, kp, rpb)
+    assert attn.dtype == torch.float64
+    dq, dk, dr = torch.autograd.grad(attn, [q, kp, rpb], ga.cuda())
+    assert dq.dtype == dk.dtype == dr.dtype == torch.float64 and dr.shape == (heads, 3, 3, 3)
+    for got, want, what in [(attn, ref, "logits"), (dq, rq, "dq"), (dk, rk, "dk (padded)"), (dr, rr, "drpb")]:
+        err = float((got.detach().cpu() - want.detach()).abs().max())
+        assert err <= 1e-12 * max(1.0, float(want.detach().abs().max())), (what, err)
+    a2 = modetqkrpb_cu(q, kp, None)
+    assert float((a2.detach().cpu() - (ref.detach() - rc.detach().reshape(1, heads, 1, 1, 1, 27))).abs().max()) <= 1e-12
+    with pytest.raises(RuntimeError, match="scalar type"):
+        modet_fw(q.detach(), kp.detach().float(), None)                  # mixed dtypes are rejected, as packed_accessor does
+    with pytest.raises(RuntimeError, match="not implemented"):
+        modet_fw(q.detach().half(), kp.detach().half(), None)
+    if D * H * W <= 27:
+        assert torch.autograd.gradcheck(modetqkrpb_cu, (q, kp, rpb), eps=1e-6, atol=1e-7, nondet_tol=1e-12)
+
+
 @pytest.mark.parametrize("shape,heads", [((9, 7, 21), 1), ((5, 13, 18), 2), ((3, 3, 3), 8), ((2, 1, 2), 4)])
 def test_na_fused_vs_oracle_ragged(ops, orc, shape, heads):
     """ragged tiles, volumes smaller than the window, all 26 border classes."""
