@@ -7,6 +7,7 @@
 //  * modet_qk_fwd / modet_qk_bwd : the reference CUDA operator's exact tensor contract
 //    (ModeT-cu/modet/modet_kernel.cu:17-381), for callers shaped like ModeT-cu/functional.py.
 #include "common.h"
+#include "drpb_reduce.h"
 
 namespace {
 
@@ -518,228 +519,7 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_gen_kernel(const float* __res
 
 inline bool gen_hd_ok(int hd) { return hd >= GC && hd <= 128 && hd % GC == 0; }
 
-// partial (B, heads, nblk, 27) -> out (heads,27), two deterministic fp64 stages:
-//   1: grid (COLSUM_SLICES, heads, B): coalesced column sums of a slice of the nblk rows -> scratch[b][h][slice][27]
-//   2: one workgroup: (b, slice) added in order per (h, t)
-template <typename T>
-__global__ __launch_bounds__(256) void drpb_stage1_kernel(const T* __restrict__ part, double* __restrict__ scratch,
-                                                          int heads, int64_t nblk) {
-  __shared__ double sm[256];
-  const int sl = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int64_t per = cdiv64(nblk, COLSUM_SLICES);
-  const int64_t r0 = sl * per, r1 = r0 + per < nblk ? r0 + per : nblk;
-  const int64_t bh = (int64_t)b * heads + h;
-  block_colsum_256(part + bh * nblk * 27, r0 < r1 ? r0 : r1, r1, 27, scratch + (bh * COLSUM_SLICES + sl) * 27, sm);
-}
-template <typename T>
-__global__ __launch_bounds__(256) void drpb_stage2_kernel(const double* __restrict__ scratch, T* __restrict__ out,
-                                                          int B, int heads) {
-  for (int i = threadIdx.x; i < heads * 27; i += 256) {
-    const int h = i / 27, t = i - h * 27;
-    double s = 0.0;
-    for (int b = 0; b < B; ++b)
-      for (int sl = 0; sl < COLSUM_SLICES; ++sl) s += scratch[(((int64_t)b * heads + h) * COLSUM_SLICES + sl) * 27 + t];
-    out[i] = (T)s;
-  }
-}
-inline size_t drpb_scratch_bytes(int B, int heads) { return (size_t)B * heads * COLSUM_SLICES * 27 * sizeof(double); }
-// `part` rows start at ws; the scratch sits at byte offset `scratch_off` (8-byte aligned) of the same workspace
-template <typename T>
-inline void drpb_reduce(const T* part, void* ws, size_t scratch_off, T* d_rpb, int B, int heads, int64_t nblk, hipStream_t s) {
-  double* scr = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + scratch_off);
-  hipLaunchKernelGGL(drpb_stage1_kernel<T>, dim3(COLSUM_SLICES, heads, B), dim3(256), 0, s, part, scr, heads, nblk);
-  hipLaunchKernelGGL(drpb_stage2_kernel<T>, dim3(1), dim3(256), 0, s, (const double*)scr, d_rpb, B, heads);
-}
-
-// ------------------------------------------------------------------------------------------ reference contract
-// one thread per (b,h,voxel); 256 consecutive voxels per workgroup so the (voxel,27) slab it produces is one
-// contiguous 27 KB range of attn, written/read through LDS in fully coalesced rows.
-constexpr int QK_BLOCK = 256;
-
-template <typename T>
-__device__ __forceinline__ void qk_decode(int64_t v, int H, int W, T& z, T& y, T& x) {
-  x = (T)(v % W);
-  const int64_t t = v / W;
-  y = (T)(t % H);
-  z = (T)(t / H);
-}
-
-// the operator dispatches float and double like the reference (AT_DISPATCH_FLOATING_TYPES, modet_kernel.cu:134,:364)
-__device__ __forceinline__ float tfma(float a, float b, float c) { return fmaf(a, b, c); }
-__device__ __forceinline__ double tfma(double a, double b, double c) { return fma(a, b, c); }
-__device__ __forceinline__ float twave_sum(float v) { return wave_sum(v); }
-__device__ __forceinline__ double twave_sum(double v) { return wave_sum_d(v); }
-
-template <typename T>
-__global__ __launch_bounds__(QK_BLOCK) void qk_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kpad,
-                                                          const T* __restrict__ rpb, T* __restrict__ attn,
-                                                          int heads, int D, int H, int W, int hd) {
-  __shared__ T slab[QK_BLOCK * 27];
-  const int64_t V = (int64_t)D * H * W;
-  const int bh = blockIdx.y, h = bh % heads;
-  const int64_t v0 = (int64_t)blockIdx.x * QK_BLOCK, v = v0 + threadIdx.x;
-  const int Hp = H + 2, Wp = W + 2;
-  const int64_t Vp = (int64_t)(D + 2) * Hp * Wp;
-  if (v < V) {
-    int z, y, x;
-    qk_decode(v, H, W, z, y, x);
-    const T* qp = q + ((int64_t)bh * V + v) * hd;
-    for (int ki = 0; ki < 3; ++ki)
-      for (int kj = 0; kj < 3; ++kj)
-        for (int kk = 0; kk < 3; ++kk) {
-          const T* kp = kpad + ((int64_t)bh * Vp + ((int64_t)(z + ki) * Hp + (y + kj)) * Wp + (x + kk)) * hd;
-          T s = (T)0;
-          for (int c = 0; c < hd; ++c) s = tfma(qp[c], kp[c], s);
-          const int t = ki * 9 + kj * 3 + kk;
-          slab[threadIdx.x * 27 + t] = s + (rpb ? rpb[h * 27 + t] : (T)0);
-        }
-  }
-  __syncthreads();
-  const int64_t nvalid = (V - v0 < QK_BLOCK ? V - v0 : QK_BLOCK) * 27;
-  T* dst = attn + ((int64_t)bh * V + v0) * 27;
-  for (int64_t i = threadIdx.x; i < nvalid; i += QK_BLOCK) dst[i] = slab[i];
-}
-
-template <typename T>
-__global__ __launch_bounds__(QK_BLOCK) void qk_dq_kernel(const T* __restrict__ dattn, const T* __restrict__ kpad,
-                                                         T* __restrict__ dq, int D, int H, int W, int hd) {
-  __shared__ T slab[QK_BLOCK * 27];
-  const int64_t V = (int64_t)D * H * W;
-  const int bh = blockIdx.y;
-  const int64_t v0 = (int64_t)blockIdx.x * QK_BLOCK, v = v0 + threadIdx.x;
-  const int64_t nvalid = (V - v0 < QK_BLOCK ? V - v0 : QK_BLOCK) * 27;
-  const T* src = dattn + ((int64_t)bh * V + v0) * 27;
-  for (int64_t i = threadIdx.x; i < nvalid; i += QK_BLOCK) slab[i] = src[i];
-  __syncthreads();
-  if (v >= V) return;
-  const int Hp = H + 2, Wp = W + 2;
-  const int64_t Vp = (int64_t)(D + 2) * Hp * Wp;
-  int z, y, x;
-  qk_decode(v, H, W, z, y, x);
-  T* dqp = dq + ((int64_t)bh * V + v) * hd;
-  for (int c = 0; c < hd; ++c) {
-    T s = (T)0;
-    for (int ki = 0; ki < 3; ++ki)
-      for (int kj = 0; kj < 3; ++kj)
-        for (int kk = 0; kk < 3; ++kk)
-          s = tfma(slab[threadIdx.x * 27 + ki * 9 + kj * 3 + kk],
-                   kpad[((int64_t)bh * Vp + ((int64_t)(z + ki) * Hp + (y + kj)) * Wp + (x + kk)) * hd + c], s);
-    dqp[c] = s;
-  }
-}
-
-// gather over the PADDED key volume (pad ring included, as modetdk_bw_kernel :209-267 returns it)
-template <typename T>
-__global__ __launch_bounds__(QK_BLOCK) void qk_dk_kernel(const T* __restrict__ dattn, const T* __restrict__ q,
-                                                         T* __restrict__ dkpad, int D, int H, int W, int hd) {
-  const int Hp = H + 2, Wp = W + 2;
-  const int64_t Vp = (int64_t)(D + 2) * Hp * Wp, V = (int64_t)D * H * W;
-  const int bh = blockIdx.y;
-  const int64_t pv = (int64_t)blockIdx.x * QK_BLOCK + threadIdx.x;
-  if (pv >= Vp) return;
-  int pz, py, px;
-  qk_decode(pv, Hp, Wp, pz, py, px);
-  T* dkp = dkpad + ((int64_t)bh * Vp + pv) * hd;
-  for (int c = 0; c < hd; ++c) {
-    T s = (T)0;
-    for (int ki = 0; ki < 3; ++ki) {
-      const int z = pz - ki;
-      if (z < 0 || z >= D) continue;
-      for (int kj = 0; kj < 3; ++kj) {
-        const int y = py - kj;
-        if (y < 0 || y >= H) continue;
-        for (int kk = 0; kk < 3; ++kk) {
-          const int x = px - kk;
-          if (x < 0 || x >= W) continue;
-          const int64_t n = (int64_t)bh * V + ((int64_t)z * H + y) * W + x;
-          s = tfma(q[n * hd + c], dattn[n * 27 + ki * 9 + kj * 3 + kk], s);
-        }
-      }
-    }
-    dkp[c] = s;
-  }
-}
-
-// d_rpb partials: workgroup (chunk, b*heads+h) sums its 256*QK_RPB_ITERS voxels for all 27 tokens
-constexpr int QK_RPB_ITERS = 16;
-template <typename T>
-__global__ __launch_bounds__(QK_BLOCK) void qk_drpb_partial_kernel(const T* __restrict__ dattn,
-                                                                   T* __restrict__ part, int64_t V) {
-  __shared__ T red[27 * (QK_BLOCK / 64)];
-  const int bh = blockIdx.y;
-  T acc[27];
-#pragma unroll
-  for (int t = 0; t < 27; ++t) acc[t] = (T)0;
-  const int64_t base = (int64_t)blockIdx.x * QK_BLOCK * QK_RPB_ITERS;
-  for (int it = 0; it < QK_RPB_ITERS; ++it) {
-    const int64_t v = base + (int64_t)it * QK_BLOCK + threadIdx.x;
-    if (v < V) {
-      const T* p = dattn + ((int64_t)bh * V + v) * 27;
-#pragma unroll
-      for (int t = 0; t < 27; ++t) acc[t] += p[t];
-    }
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int t = 0; t < 27; ++t) {
-    const T r = twave_sum(acc[t]);
-    if (lane == 0) red[wv * 27 + t] = r;
-  }
-  __syncthreads();
-  if (threadIdx.x < 27) {
-    T r = (T)0;
-    for (int w = 0; w < QK_BLOCK / 64; ++w) r += red[w * 27 + threadIdx.x];
-    part[((int64_t)bh * gridDim.x + blockIdx.x) * 27 + threadIdx.x] = r;
-  }
-}
-
 inline TileGeom geom(int D, int H, int W) { return TileGeom{cdiv(W, TX), cdiv(H, TY), cdiv(D, TZ)}; }
-
-// float / double bodies of the operator boundary (the reference dispatches both, modet_kernel.cu:134,:364)
-template <typename T>
-int qk_fwd_impl(const T* q, const T* kpad, const T* rpb, T* attn, int B, int heads, int D, int H, int W, int hd,
-                modet_stream_t stream) {
-  MODET_CHECK_PTR(q); MODET_CHECK_PTR(kpad); MODET_CHECK_PTR(attn);
-  MODET_CHECK_DIM(B > 0 && heads > 0 && hd > 0);
-  MODET_CHECK_DIM(D >= 3 && H >= 3 && W >= 3);   // CHECK_3DFEATMAP, utils.h:10
-  const int64_t V = (int64_t)D * H * W;
-  dim3 grid((unsigned)cdiv64(V, QK_BLOCK), B * heads);
-  hipLaunchKernelGGL(qk_fwd_kernel<T>, grid, dim3(QK_BLOCK), 0, (hipStream_t)stream, q, kpad, rpb, attn, heads, D, H, W,
-                     hd);
-  return modet_launch_status();
-}
-
-inline size_t qk_ws_bytes(int B, int heads, int D, int H, int W, size_t elem) {
-  const int64_t V = (int64_t)D * H * W;
-  size_t fl = (size_t)B * heads * cdiv64(V, (int64_t)QK_BLOCK * QK_RPB_ITERS) * 27;
-  fl += fl & 1;                                        // keep the fp64 scratch that follows 8-byte aligned
-  return fl * elem + drpb_scratch_bytes(B, heads);
-}
-
-template <typename T>
-int qk_bwd_impl(const T* d_attn, const T* q, const T* kpad, T* d_q, T* d_kpad, T* d_rpb, void* ws, size_t ws_bytes,
-                int B, int heads, int D, int H, int W, int hd, modet_stream_t stream) {
-  MODET_CHECK_PTR(d_attn); MODET_CHECK_PTR(q); MODET_CHECK_PTR(kpad); MODET_CHECK_PTR(d_q); MODET_CHECK_PTR(d_kpad);
-  MODET_CHECK_DIM(B > 0 && heads > 0 && hd > 0);
-  MODET_CHECK_DIM(D >= 3 && H >= 3 && W >= 3);
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t V = (int64_t)D * H * W, Vp = (int64_t)(D + 2) * (H + 2) * (W + 2);
-  if (d_rpb) {
-    MODET_CHECK_PTR(ws);
-    if (ws_bytes < qk_ws_bytes(B, heads, D, H, W, sizeof(T))) return MODET_ERR_WORKSPACE;
-    const int64_t nchunk = cdiv64(V, (int64_t)QK_BLOCK * QK_RPB_ITERS);
-    hipLaunchKernelGGL(qk_drpb_partial_kernel<T>, dim3((unsigned)nchunk, B * heads), dim3(QK_BLOCK), 0, s, d_attn,
-                       (T*)ws, V);
-    size_t fl = (size_t)B * heads * nchunk * 27;
-    fl += fl & 1;
-    drpb_reduce<T>((const T*)ws, ws, fl * sizeof(T), d_rpb, B, heads, nchunk, s);
-  }
-  hipLaunchKernelGGL(qk_dq_kernel<T>, dim3((unsigned)cdiv64(V, QK_BLOCK), B * heads), dim3(QK_BLOCK), 0, s, d_attn,
-                     kpad, d_q, D, H, W, hd);
-  hipLaunchKernelGGL(qk_dk_kernel<T>, dim3((unsigned)cdiv64(Vp, QK_BLOCK), B * heads), dim3(QK_BLOCK), 0, s, d_attn, q,
-                     d_kpad, D, H, W, hd);
-  return modet_launch_status();
-}
 
 }  // namespace
 
@@ -791,30 +571,6 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
   fl += fl & 1;
   drpb_reduce(part, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
   return modet_launch_status();
-}
-
-int modet_qk_fwd(const float* q, const float* kpad, const float* rpb, float* attn, int B, int heads, int D, int H,
-                 int W, int hd, modet_stream_t stream) {
-  return qk_fwd_impl<float>(q, kpad, rpb, attn, B, heads, D, H, W, hd, stream);
-}
-int modet_qk_fwd_f64(const double* q, const double* kpad, const double* rpb, double* attn, int B, int heads, int D,
-                     int H, int W, int hd, modet_stream_t stream) {
-  return qk_fwd_impl<double>(q, kpad, rpb, attn, B, heads, D, H, W, hd, stream);
-}
-
-size_t modet_qk_bwd_ws_bytes(int B, int heads, int D, int H, int W) { return qk_ws_bytes(B, heads, D, H, W, sizeof(float)); }
-size_t modet_qk_bwd_ws_bytes_f64(int B, int heads, int D, int H, int W) {
-  return qk_ws_bytes(B, heads, D, H, W, sizeof(double));
-}
-
-int modet_qk_bwd(const float* d_attn, const float* q, const float* kpad, float* d_q, float* d_kpad, float* d_rpb,
-                 void* ws, size_t ws_bytes, int B, int heads, int D, int H, int W, int hd, modet_stream_t stream) {
-  return qk_bwd_impl<float>(d_attn, q, kpad, d_q, d_kpad, d_rpb, ws, ws_bytes, B, heads, D, H, W, hd, stream);
-}
-int modet_qk_bwd_f64(const double* d_attn, const double* q, const double* kpad, double* d_q, double* d_kpad,
-                     double* d_rpb, void* ws, size_t ws_bytes, int B, int heads, int D, int H, int W, int hd,
-                     modet_stream_t stream) {
-  return qk_bwd_impl<double>(d_attn, q, kpad, d_q, d_kpad, d_rpb, ws, ws_bytes, B, heads, D, H, W, hd, stream);
 }
 
 }  // extern "C"

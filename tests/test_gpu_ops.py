@@ -107,6 +107,37 @@ def test_qk_reference_contract_double(shape, heads, d):
         assert torch.autograd.gradcheck(modetqkrpb_cu, (q, kp, rpb), eps=1e-6, atol=1e-7, nondet_tol=1e-12)
 
 
+@pytest.mark.parametrize("shape,heads,d,B", [((40, 20, 70), 1, 6, 1), ((17, 9, 65), 2, 6, 2), ((3, 3, 3), 1, 6, 1),
+                                             ((12, 35, 34), 3, 8, 1), ((33, 8, 32), 2, 4, 1), ((8, 9, 10), 2, 3, 2)])
+def test_qk_operator_ragged_multichunk(shape, heads, d, B):
+    """The operator's plane-marching kernels (head_dim 4/6/8) on ragged tiles, several (y,x) tiles and several z chunks,
+    and the one-thread-per-voxel kernels every other head_dim takes: forward, d_q, d_kpad (ring included), d_rpb
+    against torch fp64 autograd of the same contraction."""
+    from smilecode_amd.functional import modetqkrpb_cu
+    D, H, W = shape
+    gen = torch.Generator().manual_seed(11)
+    qc = torch.randn((B, heads, D, H, W, d), generator=gen, dtype=torch.float64).requires_grad_(True)
+    kc = torch.randn((B, heads, D + 2, H + 2, W + 2, d), generator=gen, dtype=torch.float64).requires_grad_(True)  # ring too
+    rc = torch.randn((heads, 3, 3, 3), generator=gen, dtype=torch.float64).requires_grad_(True)
+    ga = torch.randn((B, heads, D, H, W, 27), generator=gen, dtype=torch.float64)
+    cols = [(qc * kc[:, :, a:a + D, b:b + H, c:c + W]).sum(-1) for a in range(3) for b in range(3) for c in range(3)]
+    ref = torch.stack(cols, -1) + rc.reshape(1, heads, 1, 1, 1, 27)
+    rq, rk, rr = torch.autograd.grad(ref, [qc, kc, rc], ga)
+    q, kp, rpb = (t.detach().float().cuda().requires_grad_(True) for t in (qc, kc, rc))
+    attn = modetqkrpb_cu(q, kp, rpb)
+    assert_close(np64(attn), ref.detach().numpy(), what="qk logits")
+    dq, dk, dr = torch.autograd.grad(attn, [q, kp, rpb], ga.float().cuda())
+    assert_close(np64(dq), rq.numpy(), atol=1e-4, what="qk dq")
+    assert_close(np64(dk), rk.numpy(), atol=1e-4, what="qk dk (padded)")
+    assert_close(np64(dr), rr.numpy(), atol=2e-5 * (B * D * H * W) ** 0.5 * 4, what="qk drpb")
+    # run-to-run determinism (no atomics anywhere on this path)
+    dq2, dk2, dr2 = torch.autograd.grad(modetqkrpb_cu(q, kp, rpb), [q, kp, rpb], ga.float().cuda())
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dr, dr2)
+    a0 = modetqkrpb_cu(q, kp, None)
+    (dq0, dk0) = torch.autograd.grad(a0, [q, kp], ga.float().cuda())
+    assert torch.equal(dq0, dq) and torch.equal(dk0, dk)
+
+
 @pytest.mark.parametrize("shape,heads", [((9, 7, 21), 1), ((5, 13, 18), 2), ((3, 3, 3), 8), ((2, 1, 2), 4)])
 def test_na_fused_vs_oracle_ragged(ops, orc, shape, heads):
     """ragged tiles, volumes smaller than the window, all 26 border classes."""
