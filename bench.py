@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: ModeT volume-pairs/sec on synthetic 160x192x160 fp32 pairs (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|fwd]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|fwd|op|allreduce]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one pass of the hot path over one volume pair per rank:
@@ -171,6 +171,39 @@ def allreduce_only(args, rank, local, world):
         dist.destroy_process_group()
 
 
+def operator_only(args, rank, local, world):
+    """--workload op: the reference's own operator boundary on its own -- ``modetqkrpb_cu`` forward + backward
+    (smilecode_amd/functional.py -> modet_qk_fwd / modet_qk_bwd) at the five shapes one ModeT-cu training step calls it
+    with (ModeT-cu/models.py:323-352).  One step = the five forward and five backward calls; value = steps/s = volume
+    pairs/s through the operator alone.  roofline = the level-1 backward (the longest launch), algorithmic bytes
+    d_attn 27 + q 6 + kpad 6 + d_q 6 + d_kpad 6 elements per voxel, HIP events on the launch stream."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_operator", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                                "tools", "bench_operator.py"))
+    bo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bo)
+    torch.cuda.set_device(local)
+    rows = bo.run(max(args.steps, 3))
+    ms = sum(r["fwd_ms"] + r["bwd_ms"] for r in rows)
+    t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t)
+    l1 = rows[0]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "volume-pairs/sec through modetqkrpb_cu fwd+bwd (5 levels of 160x192x160)", "value": world * 1e3 / ms,
+            "unit": "volume-pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": 3, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "modetqkrpb_cu operator only, head_dim 6, heads 8/4/2/1/1, batch 1/GPU, median of per-call HIP events"},
+            "roofline": {"bound": "hbm", "kernel": "qk_bwd_plane_kernel<float,6> @160x192x160", "achieved": l1["bwd_GBps"],
+                         "peak": 8000.0, "unit": "GB/s", "frac": l1["bwd_GBps"] / 8000.0, "traffic": None},
+            "levels": rows}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def cpu_cfg1():
     """BASELINE.json configs[0]: single 64x64x64 synthetic pair, CPU forward of the oracle (ATen-CPU, the reference's op
     sequence), at all host threads and at one thread"""
@@ -201,7 +234,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["train", "fwd", "allreduce"], default="train")
+    ap.add_argument("--workload", choices=["train", "fwd", "allreduce", "op"], default="train")
     ap.add_argument("--shape", default="160,192,160")
     ap.add_argument("--batch", type=int, default=1, help="volume pairs per rank per step")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -228,6 +261,8 @@ def main():
         sys.exit(2)
     if args.workload == "allreduce":
         return allreduce_only(args, rank, local, world)
+    if args.workload == "op":
+        return operator_only(args, rank, local, world)
     if world > 1 and dist.get_backend() == "nccl" and torch.cuda.device_count() < world:
         log(f"[bench] ERROR: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
         sys.exit(2)

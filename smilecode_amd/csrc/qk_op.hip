@@ -153,12 +153,7 @@ __global__ __launch_bounds__(QK_BLOCK) void qk_drpb_partial_kernel(const T* __re
 // lives in LDS, everything in HBM is touched in contiguous row segments:
 //   forward : three rolling kpad planes (tile + 1-voxel halo) in LDS; thread = voxel, 27 logits in registers, written
 //             through a per-wave (64 voxel x 27) LDS slab so that attn leaves in contiguous 256-byte pieces.
-//   d_q     : same rolling planes; the wave's d_attn rows come in through the slab (coalesced), each lane picks up its
-//             27 values; the thread's running sum of them is the workgroup's d_rpb partial row (no second read of d_attn).
-//   d_kpad  : gather over the padded key volume, streamed by SOURCE plane: plane z of (d_attn, q) (tile + 2-voxel
-//             halo on the low side) is staged once and feeds the three target planes z, z+1, z+2 (ki = 0,1,2) whose
-//             accumulators rotate through registers; a target plane is written when its third source plane is done.
-//             d_attn is read 1.33x (the (y,x) halo), deterministically, no atomics.
+//   backward: one march for d_q, d_kpad and the d_rpb partials (qk_bwd_plane_kernel below).
 constexpr int OTY = 8, OTX = 32, ONT = OTY * OTX;
 constexpr int OHY = OTY + 2, OHX = OTX + 2, OCELLS = OHY * OHX;   // 340 cells
 constexpr int OROW27 = OHX * 27;                                   // d_attn elements of one staged row (918)
@@ -330,129 +325,42 @@ __global__ __launch_bounds__(ONT, sizeof(T) == 4 ? 3 : 1) void qk_fwd_plane_kern
   }
 }
 
-// d_q and the d_rpb partial row of the workgroup
+// The whole backward in one march over SOURCE planes.  The tile is in PADDED (py,px) coordinates:
+//   d_kpad : target (pz,py,px) gathers d_attn[z][y][x][t] * q[z][y][x] over z = pz-ki, y = py-kj, x = px-kk; plane z of
+//            (d_attn, q) -- tile + 2-voxel halo on the low side -- is staged once and feeds target planes z, z+1, z+2,
+//            whose accumulators rotate through registers; a target plane is written when its third source plane is done.
+//   d_q    : for the plane just staged, the tile's own voxels (source (py0-1+ty, px0-1+tx)): d_attn straight from the
+//            staged plane (stride 27 across lanes: conflict-free), three rolling kpad planes with origin (py0-1, px0-1).
+//   d_rpb  : the thread's running sum of its own voxels' d_attn -> one partial row per workgroup (two-stage fp64 reduce).
+// d_attn is read once (+ the (y,x) halo, 1.33x) for all three outputs, deterministically, no atomics.  (Measured against
+// the same march split into a d_q and a d_kpad kernel: 0.364 vs 0.427 ms at 160x192x160, profiles/r02f_operator_*.json.)
 template <typename T, int HD>
-__global__ __launch_bounds__(ONT, sizeof(T) == 4 ? 2 : 1) void qk_dq_plane_kernel(const T* __restrict__ dattn, const T* __restrict__ kpad,
-                                                          T* __restrict__ dq, T* __restrict__ part, int D, int H, int W,
-                                                          int tiles_x, int zlen) {
-  using V2 = typename Vec2<T>::type;
-  extern __shared__ __attribute__((aligned(16))) unsigned char op_smem[];
-  T* kpl = reinterpret_cast<T*>(op_smem);
-  T* slab = kpl + 3 * OCELLS * HD;
-  const int tid = threadIdx.x, ty = tid / OTX, tx = tid - ty * OTX, lane = tid & 63, wv = tid >> 6;
-  const int y0 = (blockIdx.x / tiles_x) * OTY, x0 = (blockIdx.x % tiles_x) * OTX;
-  const int z0 = blockIdx.y * zlen, z1 = z0 + zlen < D ? z0 + zlen : D;
-  const int bh = blockIdx.z;
-  const int Hp = H + 2, Wp = W + 2;
-  const int64_t V = (int64_t)D * H * W, planeV = (int64_t)Hp * Wp * (HD / 2);
-  const V2* k2 = reinterpret_cast<const V2*>(kpad) + (int64_t)bh * (D + 2) * planeV;
-  RowStage<T, HD> ks;
-  ks.init();
-  const int kcells = Wp - x0 < OHX ? Wp - x0 : OHX;
-  auto kload = [&](int pz) { ks.load(reinterpret_cast<const T*>(k2 + (int64_t)pz * planeV), y0, Hp, Wp, x0, kcells); };
-  kload(z0);
-  ks.store(kpl + (z0 % 3) * OCELLS * HD, 0);
-  kload(z0 + 1);
-  ks.store(kpl + ((z0 + 1) % 3) * OCELLS * HD, 0);
-  kload(z0 + 2);
-  const bool vox = (y0 + ty < H) && (x0 + tx < W);
-  const int nx27 = (W - x0 < OTX ? W - x0 : OTX) * 27;
-  T* slw = slab + wv * 64 * 27;
-  // the wave's two d_attn rows of one plane (2 x 32 voxels x 27), 64 consecutive elements per load
-  constexpr int DRL = (OTX * 27 + 63) / 64;          // loads per row (14, the last one half used)
-  const T* dsrc = dattn + (int64_t)bh * V * 27;
-  const int64_t HW27 = (int64_t)H * W * 27;
-  T dn[2 * DRL];
-  auto dload = [&](int z) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int y = y0 + 2 * wv + r;
-      const BufRsrc rs = plane_rsrc(dsrc + z * HW27 + ((int64_t)y * W + x0) * 27, y < H ? (unsigned)(nx27 * sizeof(T)) : 0u);
-#pragma unroll
-      for (int k = 0; k < DRL; ++k) dn[r * DRL + k] = buf_ld1(rs, (unsigned)(lane + 64 * k) * (unsigned)sizeof(T), (const T*)nullptr);
-    }
-  };
-  dload(z0);
-  T racc[27];
-#pragma unroll
-  for (int t = 0; t < 27; ++t) racc[t] = (T)0;
-  for (int z = z0; z < z1; ++z) {
-    ks.store(kpl + ((z + 2) % 3) * OCELLS * HD, 0);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int k = 0; k < DRL; ++k)
-        if (lane + 64 * k < OTX * 27) slw[r * OTX * 27 + lane + 64 * k] = dn[r * DRL + k];
-    __syncthreads();
-    if (z + 1 < z1) {
-      kload(z + 3);
-      dload(z + 1);
-    }
-    T da[27];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) { da[t] = slw[lane * 27 + t]; racc[t] += da[t]; }
-    T g[HD];
-#pragma unroll
-    for (int c = 0; c < HD; ++c) g[c] = (T)0;
-#pragma unroll
-    for (int ki = 0; ki < 3; ++ki) {
-      const T* pl = kpl + ((z + ki) % 3) * OCELLS * HD;
-#pragma unroll
-      for (int kj = 0; kj < 3; ++kj)
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          T kv[HD];
-          ldv<T, HD>(pl + ((ty + kj) * OHX + tx + kk) * HD, kv);
-#pragma unroll
-          for (int c = 0; c < HD; ++c) g[c] = tfma(da[ki * 9 + kj * 3 + kk], kv[c], g[c]);
-        }
-    }
-    if (vox) {
-      V2* o2 = reinterpret_cast<V2*>(dq + ((int64_t)bh * V + ((int64_t)z * H + y0 + ty) * W + x0 + tx) * HD);
-#pragma unroll
-      for (int c = 0; c < HD / 2; ++c) { V2 v; v.x = g[2 * c]; v.y = g[2 * c + 1]; o2[c] = v; }
-    }
-    __syncthreads();
-  }
-  if (part) {
-    T* red = slab;                       // [4][27]
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      const T r = twave_sum(racc[t]);
-      if (lane == 0) red[wv * 27 + t] = r;
-    }
-    __syncthreads();
-    if (tid < 27) {
-      const int64_t nblk = (int64_t)gridDim.x * gridDim.y, blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-      part[((int64_t)bh * nblk + blk) * 27 + tid] = ((red[tid] + red[27 + tid]) + red[54 + tid]) + red[81 + tid];
-    }
-  }
-}
-
-// d_kpad over the padded volume; the tile is in PADDED (py,px) coordinates, sources y = py - kj, x = px - kk
-template <typename T, int HD>
-__global__ __launch_bounds__(ONT, sizeof(T) == 4 ? (HD <= 6 ? 3 : 2) : 1) void qk_dk_plane_kernel(const T* __restrict__ dattn, const T* __restrict__ q,
-                                                          T* __restrict__ dkpad, int D, int H, int W, int tiles_x,
-                                                          int zlen) {
+__global__ __launch_bounds__(ONT, sizeof(T) == 4 ? 2 : 1) void qk_bwd_plane_kernel(const T* __restrict__ dattn, const T* __restrict__ q,
+                                                           const T* __restrict__ kpad, T* __restrict__ dq,
+                                                           T* __restrict__ dkpad, T* __restrict__ part, int D, int H,
+                                                           int W, int tiles_x, int zlen) {
   using V2 = typename Vec2<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char op_smem[];
   T* das = reinterpret_cast<T*>(op_smem);            // [OCELLS][27]
   T* qs = das + OCELLS * 27;                         // [OCELLS][HD]
-  constexpr int DRL = (OROW27 + ONT - 1) / ONT;      // d_attn loads per staged row and thread (4, the last one partly used)
-  const int tid = threadIdx.x, ty = tid / OTX, tx = tid - ty * OTX;
+  T* kpl = qs + OCELLS * HD;                         // [3][OCELLS][HD]
+  constexpr int DRL = (OROW27 + ONT - 1) / ONT;
+  const int tid = threadIdx.x, ty = tid / OTX, tx = tid - ty * OTX, lane = tid & 63, wv = tid >> 6;
   const int py0 = (blockIdx.x / tiles_x) * OTY, px0 = (blockIdx.x % tiles_x) * OTX;
   const int Dp = D + 2, Hp = H + 2, Wp = W + 2;
   const int pz0 = blockIdx.y * zlen, pz1 = pz0 + zlen < Dp ? pz0 + zlen : Dp;
   const int bh = blockIdx.z;
-  const int64_t HW = (int64_t)H * W;
-  // source columns of the tile: x in [px0-2, px0+OTX); the first `lo` cells (x < 0) and everything from x = W on stay zero
+  const int64_t HW = (int64_t)H * W, V = (int64_t)D * HW, kplane = (int64_t)Hp * Wp * HD;
   const int lo = px0 == 0 ? 2 : 0, xs = px0 - 2 + lo;
   const int cells = (W - xs < OHX - lo ? W - xs : OHX - lo) > 0 ? (W - xs < OHX - lo ? W - xs : OHX - lo) : 0;
+  const int klo = px0 == 0 ? 1 : 0, kxs = px0 - 1 + klo;
+  const int kcells = Wp - kxs < OHX - klo ? Wp - kxs : OHX - klo;
   const T* dbase = dattn + (int64_t)bh * D * HW * 27;
   const T* qbase = q + (int64_t)bh * D * HW * HD;
+  const T* kbase = kpad + (int64_t)bh * Dp * kplane;
   T dreg[OHY * DRL];
-  RowStage<T, HD> qst;
-  qst.init();
+  RowStage<T, HD> qst, kst;
+  qst.init(); kst.init();
   auto issue = [&](int z) {
 #pragma unroll
     for (int ly = 0; ly < OHY; ++ly) {
@@ -464,19 +372,30 @@ __global__ __launch_bounds__(ONT, sizeof(T) == 4 ? (HD <= 6 ? 3 : 2) : 1) void q
     }
     qst.load(qbase + (int64_t)z * HW * HD, py0 - 2, H, W, xs, cells);
   };
-  // cells no plane ever fills (low-side columns) must read as zero
-  for (int e = tid; e < OCELLS * 27; e += ONT) das[e] = (T)0;
-  for (int e = tid; e < OCELLS * HD; e += ONT) qs[e] = (T)0;
-  T acc[3][HD];
+  auto kload = [&](int pz) { kst.load(kbase + (int64_t)pz * kplane, py0 - 1, Hp, Wp, kxs, kcells); };
+  for (int e = tid; e < OCELLS * (27 + 4 * HD); e += ONT) das[e] = (T)0;       // das, qs and the three k slots
+  __syncthreads();
+  const int zs = pz0 - 2 > 0 ? pz0 - 2 : 0, dq_end = pz1 - 2;                   // d_q planes of this chunk: [zs, dq_end)
+  if (zs < dq_end) {
+    kload(zs);     kst.store(kpl + (zs % 3) * OCELLS * HD, klo);
+    kload(zs + 1); kst.store(kpl + ((zs + 1) % 3) * OCELLS * HD, klo);
+    kload(zs + 2);
+  }
+  T acc[3][HD], racc[27];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int c = 0; c < HD; ++c) acc[i][c] = (T)0;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) racc[t] = (T)0;
   const bool tgt = (py0 + ty < Hp) && (px0 + tx < Wp);
+  const int vy = py0 - 1 + ty, vx = px0 - 1 + tx;
+  const bool vox = vy >= 0 && vy < H && vx >= 0 && vx < W;
+  const int own = (ty + 1) * OHX + tx + 1;
   int z = pz0 - 2;
   if (z >= 0 && z < D) issue(z);
   for (; z < pz1; ++z) {
-    const bool src = z >= 0 && z < D;                 // uniform over the workgroup
+    const bool src = z >= 0 && z < D, dqa = src && z < dq_end;        // uniform over the workgroup
     if (src) {
       __syncthreads();
 #pragma unroll
@@ -487,12 +406,14 @@ __global__ __launch_bounds__(ONT, sizeof(T) == 4 ? (HD <= 6 ? 3 : 2) : 1) void q
           if (e < OROW27) das[ly * OROW27 + e] = dreg[ly * DRL + k];
         }
       qst.store(qs, lo);
+      if (dqa) kst.store(kpl + ((z + 2) % 3) * OCELLS * HD, klo);
       __syncthreads();
     }
     if (z + 1 < pz1 && z + 1 >= 0 && z + 1 < D) issue(z + 1);
+    if (dqa && z + 1 < dq_end) kload(z + 3);
     if (src) {
-#pragma unroll
-      for (int kj = 0; kj < 3; ++kj)
+#pragma unroll 1
+      for (int kj = 0; kj < 3; ++kj)               // a real loop: bounds how many LDS reads the scheduler hoists
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
           const int cell = (ty + 2 - kj) * OHX + tx + 2 - kk;
@@ -506,6 +427,33 @@ __global__ __launch_bounds__(ONT, sizeof(T) == 4 ? (HD <= 6 ? 3 : 2) : 1) void q
           }
         }
     }
+    if (dqa) {
+      T g[HD];
+#pragma unroll
+      for (int c = 0; c < HD; ++c) g[c] = (T)0;
+#pragma unroll
+      for (int t = 0; t < 27; ++t) racc[t] += das[own * 27 + t];      // cells outside the volume hold zeros
+#pragma unroll 1
+      for (int ki = 0; ki < 3; ++ki) {
+        const T* pl = kpl + ((z + ki) % 3) * OCELLS * HD;
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            const int t = ki * 9 + kj * 3 + kk;
+            const T a = das[own * 27 + t];
+            T kv[HD];
+            ldv<T, HD>(pl + ((ty + kj) * OHX + tx + kk) * HD, kv);
+#pragma unroll
+            for (int c = 0; c < HD; ++c) g[c] = tfma(a, kv[c], g[c]);
+          }
+      }
+      if (vox) {
+        V2* o2 = reinterpret_cast<V2*>(dq + ((int64_t)bh * V + ((int64_t)z * H + vy) * W + vx) * HD);
+#pragma unroll
+        for (int c = 0; c < HD / 2; ++c) { V2 v; v.x = g[2 * c]; v.y = g[2 * c + 1]; o2[c] = v; }
+      }
+    }
     if (z >= pz0 && tgt) {
       V2* o2 = reinterpret_cast<V2*>(dkpad + ((((int64_t)bh * Dp + z) * Hp + py0 + ty) * Wp + px0 + tx) * HD);
 #pragma unroll
@@ -514,10 +462,24 @@ __global__ __launch_bounds__(ONT, sizeof(T) == 4 ? (HD <= 6 ? 3 : 2) : 1) void q
 #pragma unroll
     for (int c = 0; c < HD; ++c) { acc[0][c] = acc[1][c]; acc[1][c] = acc[2][c]; acc[2][c] = (T)0; }
   }
+  if (part) {
+    __syncthreads();
+    T* red = das;                        // [4][27]
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const T r = twave_sum(racc[t]);
+      if (lane == 0) red[wv * 27 + t] = r;
+    }
+    __syncthreads();
+    if (tid < 27) {
+      const int64_t nblk = (int64_t)gridDim.x * gridDim.y, blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+      part[((int64_t)bh * nblk + blk) * 27 + tid] = ((red[tid] + red[27 + tid]) + red[54 + tid]) + red[81 + tid];
+    }
+  }
 }
 
 template <typename T, int HD> constexpr size_t op_lds_fwd() { return (size_t)(3 * OCELLS * HD + ONT * 27) * sizeof(T); }
-template <typename T, int HD> constexpr size_t op_lds_dk() { return (size_t)(OCELLS * (27 + HD)) * sizeof(T); }
+template <typename T, int HD> constexpr size_t op_lds_bwd() { return (size_t)(OCELLS * (27 + 4 * HD)) * sizeof(T); }
 inline bool op_plane_ok(int hd, int H, int W, size_t elem) {     // even small head_dim, every staged plane below 2 GiB
   return (hd == 4 || hd == 6 || hd == 8) && (uint64_t)(H + 2) * (W + 2) * 27 * elem < 0x80000000ull;
 }
@@ -535,22 +497,18 @@ inline void op_fwd_launch(const T* q, const T* kpad, const T* rpb, T* attn, int 
   hipLaunchKernelGGL((qk_fwd_plane_kernel<T, HD>), dim3(p.tiles_y * p.tiles_x, p.zchunks, B * heads), dim3(ONT), lds, s, q, kpad,
                      rpb, attn, heads, D, H, W, p.tiles_x, p.zlen);
 }
-inline int64_t op_dq_nblk(int BH, int D, int H, int W) {
-  const OpPlan p = op_plan(BH, D, H, W, OP_WGS_FWD, OP_MIN_FWD);
+inline int64_t op_dq_nblk(int BH, int D, int H, int W) {      // d_rpb partial rows per (b, head)
+  const OpPlan p = op_plan(BH, D + 2, H + 2, W + 2, OP_WGS_DK, OP_MIN_DK);
   return (int64_t)p.tiles_y * p.tiles_x * p.zchunks;
 }
 template <typename T, int HD>
 inline void op_bwd_launch(const T* d_attn, const T* q, const T* kpad, T* d_q, T* d_kpad, T* part, int B, int heads, int D, int H,
                           int W, hipStream_t s) {
-  const OpPlan p = op_plan(B * heads, D, H, W, OP_WGS_FWD, OP_MIN_FWD);
-  constexpr size_t lds = op_lds_fwd<T, HD>(), ldk = op_lds_dk<T, HD>();
-  op_allow_lds(qk_dq_plane_kernel<T, HD>, lds);
-  hipLaunchKernelGGL((qk_dq_plane_kernel<T, HD>), dim3(p.tiles_y * p.tiles_x, p.zchunks, B * heads), dim3(ONT), lds, s, d_attn,
-                     kpad, d_q, part, D, H, W, p.tiles_x, p.zlen);
   const OpPlan k = op_plan(B * heads, D + 2, H + 2, W + 2, OP_WGS_DK, OP_MIN_DK);
-  op_allow_lds(qk_dk_plane_kernel<T, HD>, ldk);
-  hipLaunchKernelGGL((qk_dk_plane_kernel<T, HD>), dim3(k.tiles_y * k.tiles_x, k.zchunks, B * heads), dim3(ONT), ldk, s, d_attn,
-                     q, d_kpad, D, H, W, k.tiles_x, k.zlen);
+  constexpr size_t lb = op_lds_bwd<T, HD>();
+  op_allow_lds(qk_bwd_plane_kernel<T, HD>, lb);
+  hipLaunchKernelGGL((qk_bwd_plane_kernel<T, HD>), dim3(k.tiles_y * k.tiles_x, k.zchunks, B * heads), dim3(ONT), lb, s, d_attn,
+                     q, kpad, d_q, d_kpad, part, D, H, W, k.tiles_x, k.zlen);
 }
 
 // float / double bodies of the operator boundary (the reference dispatches both, modet_kernel.cu:134,:364)

@@ -58,8 +58,10 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--level", type=int, default=0, help="1..5: only that level (for rocprofv3 runs); 0 = all five")
     a = ap.parse_args()
-    rows = run(a.iters, torch.float32 if a.dtype == "f32" else torch.float64)
+    rows = run(a.iters, torch.float32 if a.dtype == "f32" else torch.float64,
+               LEVELS if a.level == 0 else LEVELS[a.level - 1:a.level])
     for r in rows:
         print("%-16s heads %d  fwd %.3f ms (%.0f GB/s)  bwd %.3f ms (%.0f GB/s)" % (
             "x".join(map(str, r["shape"])), r["heads"], r["fwd_ms"], r["fwd_GBps"], r["bwd_ms"], r["bwd_GBps"]))
