@@ -190,6 +190,12 @@ def operator_only(args, rank, local, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t)
     l1 = rows[0]
+    traffic = None
+    try:                                             # per-launch HBM bytes of the same kernel from the rocprofv3 --pmc passes
+        with open(os.path.join(ROOT, "profiles", "r02f_pmc_traffic_operator.json")) as f:
+            traffic = json.load(f)["families"]["qk_bwd_plane_kernel"]["hbm_bytes_per_launch_corrected"]
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0:
         print(json.dumps({
             "metric": "volume-pairs/sec through modetqkrpb_cu fwd+bwd (5 levels of 160x192x160)", "value": world * 1e3 / ms,
@@ -197,7 +203,7 @@ def operator_only(args, rank, local, world):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "modetqkrpb_cu operator only, head_dim 6, heads 8/4/2/1/1, batch 1/GPU, median of per-call HIP events"},
             "roofline": {"bound": "hbm", "kernel": "qk_bwd_plane_kernel<float,6> @160x192x160", "achieved": l1["bwd_GBps"],
-                         "peak": 8000.0, "unit": "GB/s", "frac": l1["bwd_GBps"] / 8000.0, "traffic": None},
+                         "peak": 8000.0, "unit": "GB/s", "frac": l1["bwd_GBps"] / 8000.0, "traffic": traffic},
             "levels": rows}), flush=True)
     if world > 1:
         dist.barrier()
