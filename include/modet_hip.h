@@ -130,6 +130,32 @@ int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y
                                 void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
                                 modet_stream_t stream);
 
+/* Weight packing hoisted out of the step.  Every fp32 conv launch (forward, statistics, lazily normalised, data gradient)
+ * starts with a 4 us launch that packs its weights into the MFMA operand layout; a training step has 38 of them and
+ * the weights only change once per step.  Protocol:
+ *   modet_conv3d_prepack_record(1); <one forward+backward>; n = modet_conv3d_prepack_record(0);   -- learn the jobs
+ *   every later step: modet_conv3d_prepack_begin(arena, modet_conv3d_prepack_arena_bytes(), stream)  -- ONE launch
+ *                     <forward+backward: launches whose (weights pointer, geometry) was recorded skip their packing>
+ *                     modet_conv3d_prepack_end();
+ * The caller guarantees the recorded weight tensors stay where they are and do not change between _begin and _end, and
+ * keeps `arena` alive until _end.  Launches that were not recorded pack as usual.  Process-wide, mutex-guarded. */
+int modet_conv3d_prepack_record(int on);
+size_t modet_conv3d_prepack_arena_bytes(void);
+int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t stream);
+int modet_conv3d_prepack_end(void);
+
+/* Deferred weight-gradient reductions.  A backward pass launches ~20 weight-gradient kernels, each followed by a tiny
+ * reduction of its per-workgroup partial tiles (5-9 us apiece, all launch latency).  modet_conv3d_bwd_weight_defer is
+ * modet_conv3d_bwd_weight (y_act == NULL) / modet_conv3d_bwd_weight_act (y_act != NULL) without that reduction: it only
+ * writes the partial tiles into `ws` and queues the reduction; modet_conv3d_wgrad_defer_flush runs every queued
+ * reduction in ONE launch on `stream` (same arithmetic, same fixed order: bit-identical results) and empties the
+ * queue.  Until the flush the caller keeps every `ws`, d_w and d_bias it passed alive and untouched.  The queue is
+ * process-wide (backward runs on the autograd thread), mutex-guarded. */
+int modet_conv3d_bwd_weight_defer(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias,
+                                  void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                                  modet_stream_t stream);
+int modet_conv3d_wgrad_defer_flush(modet_stream_t stream);
+
 
 /* InstanceNorm3d(affine=False, eps, biased variance) + LeakyReLU(0.1) (ConvInsBlock, models.py:135-151).
  * x,y (B,V,C) channels-last with V = D*H*W; mean,rstd (B*C) are outputs of fwd / inputs of bwd. */

@@ -41,6 +41,12 @@ SIGNATURES = {
     "modet_conv3d_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
     "modet_conv3d_bwd_weight_act": (I, [P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
+    "modet_conv3d_prepack_record": (I, [I]),
+    "modet_conv3d_prepack_arena_bytes": (SZ, []),
+    "modet_conv3d_prepack_begin": (I, [P, SZ, P]),
+    "modet_conv3d_prepack_end": (I, []),
+    "modet_conv3d_bwd_weight_defer": (I, [P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
+    "modet_conv3d_wgrad_defer_flush": (I, [P]),
     "modet_instnorm_ws_bytes": (SZ, [I, I64, I]),
     "modet_instnorm_lrelu_fwd": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_fwd_stats": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 namespace {
 
@@ -46,6 +47,34 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int n = i % CoutP, t = i / CoutP;
     const int c = t % CinP, tapP = t / CinP;
+    const int dx = tapP % 3, dyp = (tapP / 3) % (P + 2), dz = tapP / (3 * (P + 2));
+    const int p = P > 1 ? n / CoP : 0, co = P > 1 ? n % CoP : n;
+    const int dy = dyp - p;
+    float v = 0.f;
+    if (c < Cin && co < Cout && dy >= 0 && dy <= 2) {
+      const int tap = (dz * 3 + dy) * 3 + dx;
+      v = mode == 0 ? w[((int64_t)co * Cin + c) * 27 + tap] : w[((int64_t)c * Cout + co) * 27 + 26 - tap];
+    }
+    wpk[i] = v;
+  }
+}
+
+// The same packing for many weight tensors in one launch (modet_conv3d_prepack_*): the jobs travel by value in the
+// kernel arguments, blockIdx.y = job.
+constexpr int PACK_MAX_JOBS = 48;
+struct PackJob { const float* w; float* wpk; int Cin, Cout, CinP, CoutP, mode, P, pad_; };
+struct PackTable { PackJob job[PACK_MAX_JOBS]; int n; };
+__global__ void pack_weights_many_kernel(const PackTable t) {
+  const PackJob& J = t.job[blockIdx.y];
+  const float* __restrict__ w = J.w;
+  float* __restrict__ wpk = J.wpk;
+  const int Cin = J.Cin, Cout = J.Cout, CinP = J.CinP, CoutP = J.CoutP, mode = J.mode, P = J.P;
+  const int ntap = 9 * (P + 2);
+  const int total = ntap * CinP * CoutP;
+  const int CoP = P > 1 ? 16 / P : CoutP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i % CoutP, tt = i / CoutP;
+    const int c = tt % CinP, tapP = tt / CinP;
     const int dx = tapP % 3, dyp = (tapP / 3) % (P + 2), dz = tapP / (3 * (P + 2));
     const int p = P > 1 ? n / CoP : 0, co = P > 1 ? n % CoP : n;
     const int dy = dyp - p;
@@ -715,12 +744,11 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_kernel(const float* __restr
 //   MODE 0: tiles of conv3d_wgrad_kernel     part[(bx*gy + by)*ng + grp][mrow][col]
 //   MODE 1: tiles of conv3d_wgrad_np_kernel  part[bx*ng + grp][mrow][(q, co)]        (gy == 1)
 template <int MODE>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           float* __restrict__ db, int Cin, int Cout, int gx, int gy,
-                                                           int n_ci_tiles, int cit, int ng) {
-  __shared__ double sm[3][64];
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw,
+                                                  float* __restrict__ db, int Cin, int Cout, int gx, int gy,
+                                                  int n_ci_tiles, int cit, int ng, int blk, double (*sm)[64]) {
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int quarter = blockIdx.x & 3, tl = blockIdx.x >> 2;       // tl = by*ng + grp
+  const int quarter = blk & 3, tl = blk >> 2;                     // tl = by*ng + grp
   const int by = tl / ng, grp = tl - by * ng;
   const float* pp = part + (int64_t)tl * 256 + quarter * 64 + lane;
   const int64_t st = (int64_t)gy * ng * 256;
@@ -762,6 +790,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int dxi = t == 1 ? 2 : (q == 1 ? 0 : 1);
     dw[((int64_t)co * Cin + ci) * 27 + combo * 3 + dxi] = (float)v;
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           float* __restrict__ db, int Cin, int Cout, int gx, int gy,
+                                                           int n_ci_tiles, int cit, int ng) {
+  __shared__ double sm[3][64];
+  wgrad_reduce_body<MODE>(part, dw, db, Cin, Cout, gx, gy, n_ci_tiles, cit, ng, blockIdx.x, sm);
+}
+
+// Deferred form (modet_conv3d_bwd_weight_defer + modet_conv3d_wgrad_defer_flush): the reductions of ALL weight-gradient launches of a backward
+// pass in one launch.  A step has 20 of them, 5-9 us each as separate launches of 8-560 workgroups -- almost all of it
+// launch + drain latency.  The job table travels by value in the kernel arguments (no device table to keep alive,
+// capturable); workgroup -> job by a scalar search over the block prefix.
+constexpr int REDUCE_MAX_JOBS = 32;
+struct ReduceJob {
+  const float* part; float* dw; float* db;
+  int Cin, Cout, gx, gy, n_ci, cit, ng, mode;
+};
+struct ReduceTable {
+  ReduceJob job[REDUCE_MAX_JOBS];
+  int first[REDUCE_MAX_JOBS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const ReduceTable t) {
+  __shared__ double sm[3][64];
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.x >= t.first[j + 1]) ++j;
+  const ReduceJob& J = t.job[j];
+  const int blk = blockIdx.x - t.first[j];
+  if (J.mode == 0) wgrad_reduce_body<0>(J.part, J.dw, J.db, J.Cin, J.Cout, J.gx, J.gy, J.n_ci, J.cit, J.ng, blk, sm);
+  else wgrad_reduce_body<1>(J.part, J.dw, J.db, J.Cin, J.Cout, J.gx, J.gy, J.n_ci, J.cit, J.ng, blk, sm);
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad, N-packed
@@ -1197,6 +1257,38 @@ inline size_t fwd_ws_elems(int Cin, int Cout) {
   return plain > packed ? plain : packed;
 }
 
+// ---- weight packing hoisted out of the step (modet_conv3d_prepack_*).  While RECORDING, every conv launch notes its
+// packing job (weights pointer, mode, padded geometry); _begin packs all recorded jobs in one launch into the caller's
+// arena and, until _end, a conv launch whose job is in the table uses the arena copy and skips its own packing launch.
+struct PackKey {
+  const float* w; int Cin, Cout, CinP, CoutP, mode, P;
+  bool operator==(const PackKey& o) const {
+    return w == o.w && Cin == o.Cin && Cout == o.Cout && CinP == o.CinP && CoutP == o.CoutP && mode == o.mode && P == o.P;
+  }
+};
+static std::mutex g_pack_mu;
+static bool g_pack_recording = false, g_pack_active = false;
+static std::vector<PackKey> g_pack_jobs;          // recorded, in launch order
+static std::vector<size_t> g_pack_off;            // float offset of each job's packed weights inside the arena
+static float* g_pack_arena = nullptr;
+inline size_t pack_job_elems(const PackKey& k) { return ((size_t)9 * (k.P + 2) * k.CinP * k.CoutP + 63) / 64 * 64; }
+
+// returns the pre-packed weights for this launch, or null (and records the job when recording)
+static const float* prepacked_or_record(const PackKey& k) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (g_pack_active) {
+    for (size_t i = 0; i < g_pack_jobs.size(); ++i)
+      if (g_pack_jobs[i] == k) return g_pack_arena + g_pack_off[i];
+    return nullptr;
+  }
+  if (g_pack_recording) {
+    bool seen = false;
+    for (const PackKey& j : g_pack_jobs) seen = seen || j == k;
+    if (!seen) g_pack_jobs.push_back(k);
+  }
+  return nullptr;
+}
+
 // query_gx != null: only report the persistent grid's x size (the statistics layout depends on it), launch nothing
 int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
                 int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr, int* query_gx = nullptr,
@@ -1205,8 +1297,12 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 9 * (p.P + 2) * CinP * CoutP;
   if (!query_gx) {
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
-                       wpk, Cin, Cout, CinP, CoutP, pack_mode, p.P);
+    const float* pre = prepacked_or_record(PackKey{w, Cin, Cout, CinP, CoutP, pack_mode, p.P});
+    if (pre)
+      wpk = const_cast<float*>(pre);
+    else
+      hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
+                         wpk, Cin, Cout, CinP, CoutP, pack_mode, p.P);
     if (stats) {
       // the statistics buffer starts with the [B][Cout] shift header; the partial rows follow it
       hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, s, x, w, bias, inorm.mean, inorm.rstd,
@@ -1347,6 +1443,57 @@ int modet_debug_conv_timing(long long* buf) {       // not in the header: tuning
 
 int modet_conv3d_uses_bf16x3(void) { return use_split(4, 4) ? 1 : 0; }
 
+int modet_conv3d_prepack_record(int on) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (on) { g_pack_jobs.clear(); g_pack_off.clear(); g_pack_active = false; }
+  g_pack_recording = on != 0;
+  return (int)g_pack_jobs.size();
+}
+
+size_t modet_conv3d_prepack_arena_bytes(void) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  size_t n = 0;
+  for (const PackKey& k : g_pack_jobs) n += pack_job_elems(k);
+  return n * sizeof(float);
+}
+
+int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t stream) {
+  std::vector<PackKey> jobs;
+  {
+    std::lock_guard<std::mutex> lk(g_pack_mu);
+    if (g_pack_recording) return MODET_ERR_UNSUPPORTED;         // stop recording first
+    if (g_pack_jobs.empty()) { g_pack_active = false; return MODET_OK; }
+    if (arena == nullptr) return MODET_ERR_NULL;
+    g_pack_off.assign(g_pack_jobs.size(), 0);
+    size_t n = 0;
+    for (size_t i = 0; i < g_pack_jobs.size(); ++i) { g_pack_off[i] = n; n += pack_job_elems(g_pack_jobs[i]); }
+    if (arena_bytes < n * sizeof(float)) return MODET_ERR_WORKSPACE;
+    g_pack_arena = (float*)arena;
+    g_pack_active = true;
+    jobs = g_pack_jobs;
+  }
+  for (size_t i0 = 0; i0 < jobs.size(); i0 += PACK_MAX_JOBS) {
+    PackTable t;
+    const int n = (int)(jobs.size() - i0 < (size_t)PACK_MAX_JOBS ? jobs.size() - i0 : (size_t)PACK_MAX_JOBS);
+    int most = 1;
+    for (int i = 0; i < n; ++i) {
+      const PackKey& k = jobs[i0 + i];
+      t.job[i] = PackJob{k.w, g_pack_arena + g_pack_off[i0 + i], k.Cin, k.Cout, k.CinP, k.CoutP, k.mode, k.P, 0};
+      const int blocks = cdiv(9 * (k.P + 2) * k.CinP * k.CoutP, 256);
+      most = blocks > most ? blocks : most;
+    }
+    t.n = n;
+    hipLaunchKernelGGL(pack_weights_many_kernel, dim3(most > 64 ? 64 : most, n), dim3(256), 0, (hipStream_t)stream, t);
+  }
+  return modet_launch_status();
+}
+
+int modet_conv3d_prepack_end(void) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  g_pack_active = false;
+  return MODET_OK;
+}
+
 size_t modet_conv3d_ws_bytes(int Cin, int Cout) {
   const int m = Cin > Cout ? Cin : Cout;       // bwd_data swaps the roles
   const size_t a = fwd_ws_elems(m, m) * sizeof(float), b = modetx_split_ws_bytes(Cin, Cout);
@@ -1450,11 +1597,60 @@ size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int
 }
 
 static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
-                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
+                                bool defer = false);
+
+// ---- deferred reductions: modet_conv3d_bwd_weight*_defer only produce the partial tiles (the workspace must stay
+// untouched until the flush) and queue the reduction; modet_conv3d_wgrad_defer_flush runs everything queued at once.
+// Process-wide queue, mutex-guarded: the autograd engine calls backward from its own thread.
+static std::mutex g_defer_mu;
+static std::vector<ReduceJob> g_defer_jobs;
+static std::vector<int> g_defer_blocks;
+
+static void reduce_or_defer(const ReduceJob& j, int blocks, hipStream_t s, bool defer) {
+  if (defer) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    g_defer_jobs.push_back(j);
+    g_defer_blocks.push_back(blocks);
+    return;
+  }
+  if (j.mode == 0)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, j.part, j.dw, j.db, j.Cin, j.Cout, j.gx, j.gy,
+                       j.n_ci, j.cit, j.ng);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, j.part, j.dw, j.db, j.Cin, j.Cout, j.gx, j.gy,
+                       j.n_ci, j.cit, j.ng);
+}
+
+int modet_conv3d_wgrad_defer_flush(modet_stream_t stream) {
+  std::vector<ReduceJob> jobs;
+  std::vector<int> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    jobs.swap(g_defer_jobs);
+    blocks.swap(g_defer_blocks);
+  }
+  for (size_t i0 = 0; i0 < jobs.size(); i0 += REDUCE_MAX_JOBS) {
+    ReduceTable t;
+    const int n = (int)(jobs.size() - i0 < (size_t)REDUCE_MAX_JOBS ? jobs.size() - i0 : (size_t)REDUCE_MAX_JOBS);
+    int total = 0;
+    for (int i = 0; i < n; ++i) { t.job[i] = jobs[i0 + i]; t.first[i] = total; total += blocks[i0 + i]; }
+    for (int i = n; i <= REDUCE_MAX_JOBS; ++i) t.first[i] = total;
+    t.n = n;
+    hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, t);
+  }
+  return modet_launch_status();
+}
 
 int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes,
                             int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
   return conv_bwd_weight_impl(x, d_y, nullptr, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream);
+}
+
+int modet_conv3d_bwd_weight_defer(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
+                                  size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+  if (y_act && !(Cin == 1 && Cout == 4)) return MODET_ERR_UNSUPPORTED;
+  return conv_bwd_weight_impl(x, d_y, y_act, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, true);
 }
 
 int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias,
@@ -1466,7 +1662,8 @@ int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y
 }
 
 static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
-                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
+                                bool defer) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (Cout > NTHR) return MODET_ERR_UNSUPPORTED;
@@ -1478,8 +1675,7 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
     const int nblk = ntiles < C1_MFMA_BLOCKS ? ntiles : C1_MFMA_BLOCKS;
     hipLaunchKernelGGL(conv_c1_wgrad_mfma_kernel, dim3(nblk), dim3(NTHR), 0, s, x, d_y, y_act, (float*)ws, D, H, W, tx, ty, tz,
                        ntiles);
-    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(2 * 4), dim3(256), 0, s, (const float*)ws, d_w, d_bias, 1, 4, nblk * 4, 1,
-                       1, 1, 2);
+    reduce_or_defer(ReduceJob{(const float*)ws, d_w, d_bias, 1, 4, nblk * 4, 1, 1, 1, 2, 0}, 2 * 4, s, defer);
     return modet_launch_status();
   }
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
@@ -1491,8 +1687,7 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
     if (p.tz == 4) { if (rowld) NP_LAUNCH(4, true); else NP_LAUNCH(4, false); }
     else { if (rowld) NP_LAUNCH(2, true); else NP_LAUNCH(2, false); }
 #undef NP_LAUNCH
-    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(p.ng * 4), dim3(256), 0, s, (const float*)part, d_w, d_bias, Cin, Cout,
-                       p.gx, 1, 1, p.cit, p.ng);
+    reduce_or_defer(ReduceJob{(const float*)part, d_w, d_bias, Cin, Cout, p.gx, 1, 1, p.cit, p.ng, 1}, p.ng * 4, s, defer);
     return modet_launch_status();
   }
   dim3 grid(p.gx, p.gy);
@@ -1502,8 +1697,7 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
   else if (p.cit == 8) { if (p.tz == 4) WG_LAUNCH(8, 4); else WG_LAUNCH(8, 2); }
   else WG_LAUNCH(16, 2);
 #undef WG_LAUNCH
-  hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(p.gy * p.ng * 4), dim3(256), 0, s, (const float*)part, d_w, d_bias, Cin,
-                     Cout, p.gx, p.gy, p.n_ci, p.cit, p.ng);
+  reduce_or_defer(ReduceJob{(const float*)part, d_w, d_bias, Cin, Cout, p.gx, p.gy, p.n_ci, p.cit, p.ng, 0}, p.gy * p.ng * 4, s, defer);
   return modet_launch_status();
 }
 

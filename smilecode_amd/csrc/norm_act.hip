@@ -10,7 +10,7 @@ namespace {
 constexpr int BLK = 256;
 // voxels per partial-sum workgroup: 32 passes of the 256/(C/4) voxels one pass covers (keeps the serial
 // loop short at the coarse, wide-channel levels)
-static inline int in_chunk(int C) { return (BLK / (C >> 2)) * 32; }
+static inline int in_chunk(int C) { return C >= 4 ? (BLK / (C >> 2)) * 32 : BLK * 32; }   // C % 4 != 0 is refused by the callers
 
 // MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat), g = dy * lrelu'(xhat)
 template <int MODE>
@@ -307,7 +307,7 @@ __device__ __forceinline__ void store8(void* base, int64_t i8, const float (&f)[
 }
 
 // voxels per partial-sum workgroup: 16 passes (twice the workgroups of the fp32 kernel per byte: a pass moves half the bytes)
-static inline int in_chunk8(int C) { return (BLK / (C >> 3)) * 16; }
+static inline int in_chunk8(int C) { return C >= 8 ? (BLK / (C >> 3)) * 16 : BLK * 16; }   // C % 8 != 0 is refused by the callers
 
 template <bool OUT_BF>
 __global__ __launch_bounds__(BLK) void in_apply_bf16_kernel(const void* __restrict__ x, void* __restrict__ y,

@@ -3,6 +3,8 @@
 poly learning-rate schedule, batch of volume pairs per rank, RCCL gradient all-reduce when >1 rank."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -30,6 +32,7 @@ class Trainer:
         self.vmax = torch.zeros_like(self.fp.flat)
         self.step = 0
         self._graph = self._static_in = self._static_out = self._graph_key = None
+        self.batch_small_launches = os.environ.get("MODET_STEP_BATCHING", "1") != "0"
         self.lr_last = lr
         self.sim = NCC_vxm()
         self.reg = Grad3d(penalty="l2")
@@ -47,11 +50,24 @@ class Trainer:
     # ---------------------------------------------------------------- hipGraph replay of forward + backward
     def _fwd_bwd(self, moving, fixed):
         self.fp.zero_grad()
-        with ops.trace_range("forward+loss"):
-            loss, sim, reg = self.loss(moving, fixed)
-        with ops.trace_range("backward"):
-            loss.backward()
-            self.fp.gather_grads()
+        if not self.batch_small_launches:               # MODET_STEP_BATCHING=0: every conv packs / reduces on its own (A/B)
+            with ops.trace_range("forward+loss"):
+                loss, sim, reg = self.loss(moving, fixed)
+            with ops.trace_range("backward"):
+                loss.backward()
+                self.fp.gather_grads()
+            return loss.detach(), sim.detach(), reg.detach()
+        if getattr(self, "_prepack", None) is None:
+            self._prepack = ops.PrepackedConvWeights()
+        # the parameters are constant from here to the end of backward: pack all conv weights in one launch up front
+        with self._prepack.step((tuple(moving.shape), moving.device, torch.is_grad_enabled())):
+            with ops.trace_range("forward+loss"):
+                loss, sim, reg = self.loss(moving, fixed)
+            with ops.trace_range("backward"):
+                # the ~20 per-layer partial-tile reductions as one launch, written straight into the flat gradient buffer
+                with ops.deferred_wgrad_reductions(self.fp.grad_destinations()) as scope:
+                    loss.backward()
+                self.fp.gather_grads(scope.written)
         return loss.detach(), sim.detach(), reg.detach()
 
     def capture(self, moving, fixed, warmup=2):

@@ -220,18 +220,120 @@ def conv3d_backward_data(dy, w, Cin):
     return dx
 
 
-def conv3d_backward_weight(x, dy, want_bias, y_act=None):
+class PrepackedConvWeights:
+    """The per-launch weight packing of the fp32 convs hoisted into one launch per step (include/modet_hip.h,
+    modet_conv3d_prepack_*).  ``with pp.step(): forward; backward`` -- the first use (and any use after another owner
+    recorded) runs the pass normally while the library records its packing jobs; later passes start with ONE launch
+    that packs every recorded weight tensor and the conv launches skip their own.  The owner guarantees that the
+    weights are not modified inside the scope and live at the same addresses from one pass to the next (FlatParams
+    views do).  The job table is process-wide: ``_owner`` tells whose recording it currently holds."""
+    _owner = None
+
+    def __init__(self):
+        self.arena = None
+        self.key = None
+
+    class _Scope:
+        def __init__(self, pp, key):
+            self.pp, self.key = pp, key
+
+        def __enter__(self):
+            L, pp = _L(), self.pp
+            self.recording = not (PrepackedConvWeights._owner is pp and pp.key == self.key and pp.arena is not None)
+            if self.recording:
+                L.modet_conv3d_prepack_record(1)
+                PrepackedConvWeights._owner, pp.key, pp.arena = pp, self.key, None
+            else:
+                _lib.check(L.modet_conv3d_prepack_begin(_p(pp.arena), pp.arena.numel() * 4, _stream()),
+                           "modet_conv3d_prepack_begin")
+            return self
+
+        def __exit__(self, *exc):
+            L, pp = _L(), self.pp
+            if self.recording:
+                L.modet_conv3d_prepack_record(0)
+                if exc[0] is None:
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                    pp.arena = torch.empty(L.modet_conv3d_prepack_arena_bytes() // 4 + 64, dtype=torch.float32, device=dev)
+                else:
+                    PrepackedConvWeights._owner = None
+            else:
+                L.modet_conv3d_prepack_end()
+            return False
+
+    def step(self, key=None):
+        return PrepackedConvWeights._Scope(self, key)
+
+
+class deferred_wgrad_reductions:
+    """``with ops.deferred_wgrad_reductions(dst) as scope: loss.backward()`` -- the ~20 tiny per-layer reductions of the
+    weight-gradient partial tiles run as ONE launch when the scope closes (include/modet_hip.h,
+    modet_conv3d_bwd_weight_defer / modet_conv3d_wgrad_defer_flush).
+
+    ``dst`` maps ``parameter.data_ptr()`` to the tensor that parameter's gradient must be written to (FlatParams: a view
+    of the flat gradient buffer).  A conv whose weight (and bias) have a destination writes there -- after the flush --
+    and returns no gradient to autograd, so nothing depends on how autograd hands tensors to ``.grad``; the pointers
+    written are in ``scope.written``.  A conv without a destination, or a second use of the same weight inside one scope,
+    takes the immediate path.  Scopes do not nest."""
+    _active = None
+
+    def __init__(self, dst):
+        self.dst = dst
+        self.written = set()
+        self._keep = []
+
+    def __enter__(self):
+        if deferred_wgrad_reductions._active is not None:
+            raise RuntimeError("deferred_wgrad_reductions scopes do not nest")
+        deferred_wgrad_reductions._active = self
+        return self
+
+    def __exit__(self, *exc):
+        deferred_wgrad_reductions._active = None
+        rc = _L().modet_conv3d_wgrad_defer_flush(_stream())      # always empties the queue, also on an exception
+        self._keep = []
+        if exc[0] is None:
+            _lib.check(rc, "modet_conv3d_wgrad_defer_flush")
+        return False
+
+    def destinations(self, w, b, want_bias):
+        """(d_w, d_bias) destinations for this call, or None -> immediate path"""
+        dw = self.dst.get(w.data_ptr()) if w is not None else None
+        if dw is None or dw.shape != w.shape or w.data_ptr() in self.written:
+            return None
+        db = None
+        if want_bias:
+            db = self.dst.get(b.data_ptr()) if b is not None else None
+            if db is None or db.shape != b.shape or b.data_ptr() in self.written:
+                return None
+        return dw, db
+
+
+def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None):
     """d_w, d_bias; with y_act (ConvBlock 1 -> 4 only) dy is the gradient w.r.t. LeakyReLU(conv) and the activation's
-    derivative is applied while loading it"""
+    derivative is applied while loading it.  Inside a ``deferred_wgrad_reductions`` scope that knows destinations for the
+    parameters ``w`` / ``b``, the gradients go straight there at the scope's flush and (None, None) is returned."""
     _chk(x, dy)
     B, D, H, W, Cin = x.shape
     Cout = dy.shape[-1]
-    dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     L = _L()
     nb = L.modet_conv3d_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)
     ws = _ws(nb, x)
     n = float(B) * D * H * W
+    scope = deferred_wgrad_reductions._active
+    dst = scope.destinations(w, b, want_bias) if scope is not None else None
+    if dst is not None:
+        dw, db = dst
+        with _Guard(x, f"conv_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+            _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
+                                                       Cout, _stream()), "modet_conv3d_bwd_weight_defer")
+        scope._keep.append(ws)                                # the partial tiles must survive until the flush
+        scope.written.add(w.data_ptr())
+        if db is not None:
+            scope.written.add(b.data_ptr())
+        return None, None
+    dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     with _Guard(x, f"conv_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         if y_act is not None:
             _lib.check(L.modet_conv3d_bwd_weight_act(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
@@ -249,16 +351,16 @@ class _Conv3d(Function):
         y = conv3d_forward(x, w, b, act)
         ctx.act = bool(act)
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x, w, y if act else None)
+        ctx.save_for_backward(x, w, y if act else None, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, b = ctx.saved_tensors
         dy = dy.contiguous()
         if ctx.act and not ctx.needs_input_grad[0] and x.shape[-1] == 1 and w.shape[0] == 4:
             # first encoder block: no d_x, and the weight-gradient kernel folds LeakyReLU' into its d_y load
-            dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, y_act=y)
+            dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, y_act=y, w=w, b=b)
             return None, dw, db, None
         if ctx.act:
             g = torch.empty_like(dy)
@@ -266,7 +368,7 @@ class _Conv3d(Function):
                 _lib.check(_L().modet_lrelu_bwd(_p(dy), _p(y), _p(g), dy.numel(), _stream()), "modet_lrelu_bwd")
             dy = g
         dx = conv3d_backward_data(dy, w, x.shape[-1]) if ctx.needs_input_grad[0] else None
-        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias)
+        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b)
         return dx, dw, db, None
 
 
@@ -289,16 +391,16 @@ class _Conv3dStats(Function):
             _lib.check(L.modet_conv3d_fwd_stats(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
                                                 Cout, _stream()), "modet_conv3d_fwd_stats")
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats):
-        x, w = ctx.saved_tensors
+        x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
         dx = conv3d_backward_data(dy, w, x.shape[-1]) if ctx.needs_input_grad[0] else None
-        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias)
+        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b)
         return dx, dw, db
 
 

@@ -78,10 +78,21 @@ class FlatParams:
         for p in self.params:
             p.grad = None
 
-    def gather_grads(self):
-        """pack every parameter gradient into the flat buffer (one fused multi-tensor copy)"""
+    def grad_destinations(self):
+        """parameter.data_ptr() -> that parameter's view of the flat gradient buffer (ops.deferred_wgrad_reductions)"""
+        if getattr(self, "_dst", None) is None:
+            self._dst = {p.data_ptr(): self.grad[off:off + k].view(p.shape) for p, (off, k) in zip(self.params, self.offsets)}
+        return self._dst
+
+    def gather_grads(self, written=()):
+        """pack every parameter gradient into the flat buffer (one fused multi-tensor copy); parameters whose pointer is
+        in ``written`` already have theirs there (written directly by the deferred weight-gradient reductions)"""
         views, srcs, missing = [], [], []
         for p, (off, k) in zip(self.params, self.offsets):
+            if p.data_ptr() in written:
+                if p.grad is not None:            # a further use of the parameter went through autograd: add it on top
+                    self.grad[off:off + k].view(p.shape).add_(p.grad)
+                continue
             v = self.grad[off:off + k].view(p.shape)
             if p.grad is None:
                 missing.append(v)

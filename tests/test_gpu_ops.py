@@ -366,6 +366,98 @@ def test_conv_vs_oracle(ops, cin, cout, shape):
     assert_close(np64(db), rb.numpy(), atol=wtol, rtol=2e-4, what="conv dbias")
 
 
+def test_prepacked_conv_weights_follow_the_weights(ops):
+    """ops.PrepackedConvWeights: pass 1 records the packing jobs (forward + data-gradient form of every layer), later
+    passes pack them all in one launch from the CURRENT weights and the conv launches use that copy -- outputs and data
+    gradients must be bit-identical to the unscoped calls, also after the weights were updated in place, for the plain,
+    row-packed (Cout <= 8), statistics and multi-chunk configurations."""
+    from smilecode_amd import _lib
+    gen = torch.Generator().manual_seed(9)
+    cfgs = [(4, 8, (9, 24, 37)), (8, 8, (21, 40, 41)), (8, 4, (6, 9, 20)), (16, 16, (5, 9, 20)), (16, 32, (4, 6, 18)),
+            (32, 32, (4, 6, 9)), (12, 2, (6, 6, 18)), (64, 128, (2, 3, 10))]
+    layers = []
+    for cin, cout, shape in cfgs:
+        x = torch.randn((2,) + shape + (cin,), generator=gen).cuda().requires_grad_(True)
+        w = (torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(cin * 27)).cuda().requires_grad_(True)
+        b = (0.1 * torch.randn(cout, generator=gen)).cuda().requires_grad_(True)
+        gy = torch.randn((2,) + shape + (cout,), generator=gen).cuda()
+        layers.append((x, w, b, gy))
+
+    def run():
+        out = []
+        for i, (x, w, b, gy) in enumerate(layers):
+            y = ops.conv3d_instnorm_lrelu(x, w, b) if i % 2 else ops.conv3d(x, w, b, False)
+            (dx,) = torch.autograd.grad(y, [x], gy)
+            out.append((y.detach().clone(), dx.clone()))
+        return out
+
+    pp = ops.PrepackedConvWeights()
+    with pp.step("shape-a"):
+        first = run()                                        # recording pass (packs per launch)
+    assert pp.arena is not None and _lib.load().modet_conv3d_prepack_arena_bytes() > 0
+    for a, b in zip(first, run()):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with torch.no_grad():
+        for _, w, _, _ in layers:
+            w.mul_(1.5).add_(0.01)                           # an optimizer step: same storage, new values
+    want = run()                                             # unscoped: packs per launch from the new weights
+    with pp.step("shape-a"):
+        got = run()                                          # one packing launch, then no per-launch packing
+    for a, b in zip(want, got):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert not torch.equal(first[0][0], got[0][0])
+    other = ops.PrepackedConvWeights()                       # a second owner takes the table over; the first re-records
+    with other.step("x"):
+        run()
+    with pp.step("shape-a"):
+        again = run()
+    for a, b in zip(want, again):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_deferred_wgrad_reductions_bit_identical(ops):
+    """ops.deferred_wgrad_reductions: all weight-gradient reductions of a backward pass as one launch, written to the
+    destinations the scope was given.  40 layers (two batches of the 32-job table) covering the three partial-tile
+    layouts -- conv3d_wgrad_kernel (Cin 4/8/16 M packing), conv3d_wgrad_np_kernel (Cin, Cout <= 8) and the first 1->4
+    layer with LeakyReLU' folded in -- must give exactly the bits of the per-layer reductions, with and without a bias."""
+    cfgs = [(1, 4, (9, 17, 33)), (4, 8, (9, 24, 37)), (8, 8, (21, 40, 41)), (8, 4, (6, 9, 20)), (16, 16, (5, 9, 20)),
+            (16, 32, (4, 6, 18)), (12, 2, (6, 6, 18)), (24, 48, (3, 4, 5)), (6, 12, (8, 6, 16)), (64, 128, (2, 3, 10))] * 4
+    gen = torch.Generator().manual_seed(5)
+    ins, dst = [], {}
+    for i, (cin, cout, shape) in enumerate(cfgs):
+        x = torch.randn((2,) + shape + (cin,), generator=gen).cuda()
+        dy = torch.randn((2,) + shape + (cout,), generator=gen).cuda()
+        ya = torch.randn((2,) + shape + (cout,), generator=gen).cuda() if cin == 1 else None
+        w, b = torch.zeros((cout, cin, 3, 3, 3), device="cuda"), torch.zeros((cout,), device="cuda")   # the "parameters"
+        dst[w.data_ptr()] = torch.full_like(w, float("nan"))
+        dst[b.data_ptr()] = torch.full_like(b, float("nan"))
+        ins.append((x, dy, i % 3 != 0, ya, w, b))
+    ref = [ops.conv3d_backward_weight(x, dy, wb, y_act=ya) for x, dy, wb, ya, _, _ in ins]
+    with ops.deferred_wgrad_reductions(dst) as scope:
+        got = [ops.conv3d_backward_weight(x, dy, wb, y_act=ya, w=w, b=b) for x, dy, wb, ya, w, b in ins]
+        junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]    # allocator churn inside the scope
+        del junk
+        # a second use of a weight inside the scope takes the immediate path and returns its gradient
+        x, dy, wb, ya, w, b = ins[2]
+        w2, b2 = ops.conv3d_backward_weight(x, dy, True, w=w, b=b)
+        # so does a parameter the scope has no destination for
+        w3, _ = ops.conv3d_backward_weight(x, dy, False, w=torch.zeros_like(w), b=None)
+    assert all(g == (None, None) for g in got)
+    for (rw, rb), (x, dy, wb, ya, w, b) in zip(ref, ins):
+        assert torch.equal(rw, dst[w.data_ptr()]) and w.data_ptr() in scope.written
+        if wb:
+            assert torch.equal(rb, dst[b.data_ptr()]) and b.data_ptr() in scope.written
+        else:
+            assert bool(torch.isnan(dst[b.data_ptr()]).all()) and b.data_ptr() not in scope.written
+    assert torch.equal(w2, ref[2][0]) and torch.equal(w3, ref[2][0])
+    with pytest.raises(RuntimeError, match="do not nest"):
+        with ops.deferred_wgrad_reductions(dst):
+            with ops.deferred_wgrad_reductions(dst):
+                pass
+    rw, rb = ops.conv3d_backward_weight(*ins[1][:3])             # no scope: immediate
+    assert torch.equal(rw, ref[1][0])
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(4, 8, (9, 24, 37)), (8, 8, (33, 40, 48)), (8, 16, (6, 8, 16)),
                                             (16, 16, (5, 9, 20)), (12, 4, (7, 6, 18)), (32, 32, (4, 6, 9))])
 def test_conv_instnorm_fused_vs_oracle(ops, cin, cout, shape):

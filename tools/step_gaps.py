@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""Per-step timeline occupancy from a rocprofv3 kernel trace: steps are delimited by adam_kernel launches.
+
+    python tools/step_gaps.py kernel_trace.csv
+
+For every step: span (first start .. last end), busy (sum of kernel durations), launches, idle = span - busy, and the
+share of launches shorter than 12 us.  Used to tell whether the ~200 small launches of a step cost their duration only
+(hipGraph replay: gaps ~0) or their duration plus a dispatch gap (eager)."""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+cuts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel") or "adam_kernel" in r["Kernel_Name"]]
+print("# %d dispatches, %d optimizer steps" % (len(rows), len(cuts)))
+for a, b in zip(cuts[:-1], cuts[1:]):
+    seg = rows[a + 1:b + 1]
+    s0, e1 = int(seg[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in seg)
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg]
+    small = [d for d in dur if d < 12000]
+    gaps = sorted(max(0, int(seg[i + 1]["Start_Timestamp"]) - int(seg[i]["End_Timestamp"])) for i in range(len(seg) - 1))
+    print("step: launches %4d  span %7.3f ms  busy %7.3f ms  idle %6.3f ms  small(<12us) %3d launches %6.3f ms  median gap %5d ns  p90 gap %6d ns"
+          % (len(seg), (e1 - s0) / 1e6, sum(dur) / 1e6, (e1 - s0 - sum(dur)) / 1e6, len(small), sum(small) / 1e6,
+             gaps[len(gaps) // 2], gaps[int(len(gaps) * 0.9)]))
