@@ -469,7 +469,7 @@ def main():
                          "measured_over": ("%d eager steps right after the timed region (the timed region replays a hipGraph, "
                                            "which cannot carry per-kernel events)" % roof_steps) if graphed else "the timed region",
                          "note": "all launches of this kernel symbol in the K timed steps; algorithmic work summed per "
-                                 "launch shape (DESIGN.md section 4); each bracket also contains the ~4 us weight-pack launch"
+                                 "launch shape (DESIGN.md section 4); the weights are packed once per step by one separate launch (modet_conv3d_prepack_*), outside these brackets"
                                  if dominant.startswith("conv3d_mfma") else "all launches of this kernel in the K timed steps"})
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc runs
             if os.path.exists(pmc):

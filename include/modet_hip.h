@@ -189,6 +189,15 @@ int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const 
                       float* d_x, float* d_Wt, float* d_bias, float* d_gamma, float* d_beta,
                       void* ws, size_t ws_bytes, int64_t N, int Cin, int dim, float eps, modet_stream_t stream);
 
+/* The same layer applied to two inputs (the fixed and the moving feature map of a level share one ProjectionLayer,
+ * models.py:371-372): both data gradients and the parameter gradients of BOTH uses, summed in one fixed-order fp64
+ * reduction.  _ws_bytes returns 0 when the shape is not covered (use two modet_proj_ln_bwd calls and add). */
+size_t modet_proj_ln_bwd_pair_ws_bytes(int64_t N, int Cin, int dim);
+int modet_proj_ln_bwd_pair(const float* x1, const float* d_y1, float* d_x1, const float* x2, const float* d_y2, float* d_x2,
+                           const float* Wt, const float* bias, const float* gamma, float* d_Wt, float* d_bias,
+                           float* d_gamma, float* d_beta, void* ws, size_t ws_bytes, int64_t N, int Cin, int dim,
+                           float eps, modet_stream_t stream);
+
 /* SpatialTransformer (models.py:25-67; utils.py:30-83 for mode 1):
  *   out[b,p,c] = sample(src[b,:,c], p + flow[b,p,:]), zero padding, voxel coordinates
  *   (the reference's normalise -> grid_sample(align_corners=True) round trip is the identity).

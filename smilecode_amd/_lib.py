@@ -58,6 +58,8 @@ SIGNATURES = {
     "modet_proj_ln_fwd": (I, [P, P, P, P, P, P, I64, I, I, F, P]),
     "modet_proj_ln_bwd_ws_bytes": (SZ, [I64, I, I]),
     "modet_proj_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
+    "modet_proj_ln_bwd_pair_ws_bytes": (SZ, [I64, I, I]),
+    "modet_proj_ln_bwd_pair": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
     "modet_warp_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "modet_warp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "modet_upsample2_fwd": (I, [P, P, I, I, I, I, I, F, P]),

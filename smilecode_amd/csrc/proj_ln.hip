@@ -567,6 +567,48 @@ size_t modet_proj_ln_bwd_ws_bytes(int64_t N, int Cin, int dim) {
   return fl * sizeof(float);
 }
 
+// The layer applied to TWO inputs with the same parameters (ModeT projects the fixed and the moving feature map of a level
+// with one ProjectionLayer, models.py:371-372): both data gradients, and the parameter gradients of both uses summed by
+// ONE fixed-order fp64 column sum over the partial rows of the two backward launches -- instead of two reductions and
+// four element-wise additions of their results.
+size_t modet_proj_ln_bwd_pair_ws_bytes(int64_t N, int Cin, int dim) {
+  if (!group_of(Cin, dim)) return 0;                  // only the grouped kernels (every level of the model)
+  return 2 * modet_proj_ln_bwd_ws_bytes(N, Cin, dim);
+}
+
+int modet_proj_ln_bwd_pair(const float* x1, const float* d_y1, float* d_x1, const float* x2, const float* d_y2, float* d_x2,
+                           const float* Wt, const float* bias, const float* gamma, float* d_Wt, float* d_bias,
+                           float* d_gamma, float* d_beta, void* ws, size_t ws_bytes, int64_t N, int Cin, int dim, float eps,
+                           modet_stream_t stream) {
+  MODET_CHECK_PTR(x1); MODET_CHECK_PTR(d_y1); MODET_CHECK_PTR(d_x1); MODET_CHECK_PTR(x2); MODET_CHECK_PTR(d_y2);
+  MODET_CHECK_PTR(d_x2); MODET_CHECK_PTR(Wt); MODET_CHECK_PTR(bias); MODET_CHECK_PTR(gamma); MODET_CHECK_PTR(d_Wt);
+  MODET_CHECK_PTR(d_bias); MODET_CHECK_PTR(d_gamma); MODET_CHECK_PTR(d_beta); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(N > 0 && Cin > 0 && dim > 0);
+  const int G = group_of(Cin, dim);
+  if (Cin % 4 != 0 || Cin > 128 || !G) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_proj_ln_bwd_pair_ws_bytes(N, Cin, dim)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int gg = group_grid(N, G), row = 3 * dim + dim * Cin;
+  float* gpart = (float*)ws;
+  for (int u = 0; u < 2; ++u) {
+    const float* x = u ? x2 : x1;
+    const float* d_y = u ? d_y2 : d_y1;
+    float* d_x = u ? d_x2 : d_x1;
+    float* part = gpart + (size_t)u * gg * row;
+#define LAUNCH_G(D_, C_, G_) hipLaunchKernelGGL((proj_ln_bwd_g_kernel<D_, C_, G_>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, \
+                                                d_y, d_x, part, N, eps)
+    if (G == 1 && Cin == 8) LAUNCH_G(6, 8, 1);
+    else if (G == 1) LAUNCH_G(6, 16, 1);
+    else if (G == 4) LAUNCH_G(12, 32, 4);
+    else if (G == 8) LAUNCH_G(24, 64, 8);
+    else LAUNCH_G(48, 128, 16);
+#undef LAUNCH_G
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(row), dim3(64), 0, s, (const float*)gpart, 2 * gg, row, d_gamma, dim, d_beta, dim,
+                     d_bias, dim, d_Wt, dim * Cin);
+  return modet_launch_status();
+}
+
 int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const float* gamma, const float* d_y,
                       float* d_x, float* d_Wt, float* d_bias, float* d_gamma, float* d_beta, void* ws, size_t ws_bytes,
                       int64_t N, int Cin, int dim, float eps, modet_stream_t stream) {

@@ -196,6 +196,11 @@ class ProjectionLayer(nn.Module):
     def forward(self, feat):
         return ops.proj_ln(feat, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, 1e-5)
 
+    def forward_pair(self, fixed_feat, moving_feat):
+        """(q, k) = (self(fixed_feat), self(moving_feat)): one backward reduction for the shared parameters"""
+        return ops.proj_ln_pair(fixed_feat, moving_feat, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias,
+                                1e-5)
+
 
 class CWM(nn.Module):
     """competitive weighting module (reference models.py:243-275); channels-last."""
@@ -340,31 +345,31 @@ class ModeT(nn.Module):
         ST = self.transformer
 
         with ops.trace_range("level5"):
-            q5, k5 = self.projblock5(Fx[4]), self.projblock5(M[4])
+            q5, k5 = self.projblock5.forward_pair(Fx[4], M[4])
             flow = self.cwm5(self.mdt5(q5, k5))
 
         with ops.trace_range("level4"):
             M4 = ST[3].forward_cl(M[3], flow)
-            q4, k4 = self.projblock4(Fx[3]), self.projblock4(M4)
+            q4, k4 = self.projblock4.forward_pair(Fx[3], M4)
             w = self.cwm4(self.mdt4(q4, k4))
             flow = ST[2].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
         with ops.trace_range("level3"):
             M3 = ST[2].forward_cl(M[2], flow)
-            q3, k3 = self.projblock3(Fx[2]), self.projblock3(M3)
+            q3, k3 = self.projblock3.forward_pair(Fx[2], M3)
             w = self.cwm3(self.mdt3(q3, k3))
             flow = ST[1].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
         with ops.trace_range("level2"):
             M2 = ST[1].forward_cl(M[1], flow)
-            q2, k2 = self.projblock2(Fx[1]), self.projblock2(M2)
+            q2, k2 = self.projblock2.forward_pair(Fx[1], M2)
             w = self.mdt2(q2, k2)
             # w comes straight from the attention (expected offset in [-1,1]^3): bounded-flow backward, no atomics
             flow = ops.upsample2(ST[1].forward_cl(flow, w, add_flow=True, flow_bound=1), 2.0)
 
         with ops.trace_range("level1"):
             M1 = ST[0].forward_cl(M[0], flow)
-            q1, k1 = self.projblock1(Fx[0]), self.projblock1(M1)
+            q1, k1 = self.projblock1.forward_pair(Fx[0], M1)
             w = self.mdt1(q1, k1)
             flow = ST[0].forward_cl(flow, w, add_flow=True, flow_bound=1)
             y_moved = ST[0].forward_cl(mov_cl, flow)

@@ -638,6 +638,55 @@ class _ProjLN(Function):
         return dx, dW, db, dg, dbeta, None
 
 
+class _ProjLNPair(Function):
+    """The projection layer applied to two inputs of one shape with the same parameters; the backward sums the
+    parameter gradients of both uses in one reduction (modet_proj_ln_bwd_pair) instead of autograd adding two results."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, Wt, b, gamma, beta, eps):
+        _chk(x1, x2, Wt, b, gamma, beta)
+        Cin = x1.shape[-1]
+        dim = Wt.shape[0]
+        N = x1.numel() // Cin
+        L = _L()
+        ys = []
+        for x in (x1, x2):
+            y = torch.empty(x.shape[:-1] + (dim,), dtype=torch.float32, device=x.device)
+            with _Guard(x, f"proj_ln_fwd[{Cin}->{dim}]", N * (2.0 * Cin * dim + 8.0 * dim), 4.0 * N * (Cin + dim)):
+                _lib.check(L.modet_proj_ln_fwd(_p(x), _p(Wt), _p(b), _p(gamma), _p(beta), _p(y), N, Cin, dim, eps, _stream()),
+                           "modet_proj_ln_fwd")
+            ys.append(y)
+        ctx.save_for_backward(x1, x2, Wt, b, gamma)
+        ctx.eps = eps
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x1, x2, Wt, b, gamma = ctx.saved_tensors
+        dy1, dy2 = dy1.contiguous(), dy2.contiguous()
+        Cin = x1.shape[-1]
+        dim = Wt.shape[0]
+        N = x1.numel() // Cin
+        dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+        dW, db, dg, dbeta = torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma), torch.empty_like(gamma)
+        L = _L()
+        nb = L.modet_proj_ln_bwd_pair_ws_bytes(N, Cin, dim)
+        ws = _ws(nb, x1)
+        with _Guard(x1, f"proj_ln_bwd[{Cin}->{dim}]", 2 * N * (6.0 * Cin * dim + 20.0 * dim), 8.0 * N * (2 * Cin + dim)):
+            _lib.check(L.modet_proj_ln_bwd_pair(_p(x1), _p(dy1), _p(dx1), _p(x2), _p(dy2), _p(dx2), _p(Wt), _p(b), _p(gamma),
+                                                _p(dW), _p(db), _p(dg), _p(dbeta), _p(ws), nb, N, Cin, dim, ctx.eps,
+                                                _stream()), "modet_proj_ln_bwd_pair")
+        return dx1, dx2, dW, db, dg, dbeta, None
+
+
+def proj_ln_pair(x1, x2, Wt, b, gamma, beta, eps=1e-5):
+    """(proj_ln(x1), proj_ln(x2)) with shared parameters -- ModeT's q / k projections of a level (models.py:371-372)"""
+    if (x1.shape == x2.shape and torch.is_grad_enabled() and x1.requires_grad and x2.requires_grad and
+            _L().modet_proj_ln_bwd_pair_ws_bytes(x1.numel() // x1.shape[-1], x1.shape[-1], Wt.shape[0]) > 0):
+        return _ProjLNPair.apply(x1, x2, Wt, b, gamma, beta, eps)
+    return _ProjLN.apply(x1, Wt, b, gamma, beta, eps), _ProjLN.apply(x2, Wt, b, gamma, beta, eps)
+
+
 def proj_ln(x, Wt, b, gamma, beta, eps=1e-5):
     """Linear + LayerNorm on channels-last voxels.  reference: ProjectionLayer, models.py:230-241"""
     return _ProjLN.apply(x, Wt, b, gamma, beta, eps)

@@ -317,6 +317,40 @@ def test_projection_vs_oracle_large(ops, orc, cin, dim, n):
         assert_close(np64(a), b.numpy(), atol=3e-3, rtol=2e-4, what=f"proj {nme} (sum over {n} voxels)")
 
 
+@pytest.mark.parametrize("cin,dim,n", [(8, 6, 70001), (16, 6, 5003), (32, 12, 9001), (64, 24, 1531), (128, 48, 1203),
+                                       (24, 12, 777)])
+def test_projection_pair_vs_oracle(ops, orc, cin, dim, n):
+    """ops.proj_ln_pair (the layer applied to the fixed and the moving features of a level): outputs and data gradients as
+    two single applications, parameter gradients of both uses summed in one reduction -- against the fp64 oracle of
+    proj(x1) and proj(x2) with shared parameters; (24, 12) is not covered by the pair kernel and takes two single calls."""
+    gen = torch.Generator().manual_seed(13)
+    x1 = torch.randn((1, cin, 1, 1, n), generator=gen).double().requires_grad_(True)
+    x2 = torch.randn((1, cin, 1, 1, n), generator=gen).double().requires_grad_(True)
+    p = {"p.proj.weight": 0.3 * torch.randn((dim, cin), generator=gen).double(),
+         "p.proj.bias": 0.1 * torch.randn(dim, generator=gen).double(),
+         "p.norm.weight": 1 + 0.1 * torch.randn(dim, generator=gen).double(),
+         "p.norm.bias": 0.1 * torch.randn(dim, generator=gen).double()}
+    for t in p.values():
+        t.requires_grad_(True)
+    r1, r2 = orc.projection(p, "p", x1), orc.projection(p, "p", x2)
+    g1, g2 = torch.randn(r1.shape, generator=gen).double(), torch.randn(r1.shape, generator=gen).double()
+    rg = torch.autograd.grad([r1, r2], [x1, x2] + list(p.values()), [g1, g2])
+    xd1, xd2 = cl(x1.detach().numpy()).requires_grad_(True), cl(x2.detach().numpy()).requires_grad_(True)
+    pd = [t.detach().float().cuda().requires_grad_(True) for t in p.values()]
+    y1, y2 = ops.proj_ln_pair(xd1, xd2, *pd)
+    assert_close(np64(y1), r1.detach().numpy(), what="proj out 1")
+    assert_close(np64(y2), r2.detach().numpy(), what="proj out 2")
+    gd = torch.autograd.grad([y1, y2], [xd1, xd2] + pd, [g1.float().cuda(), g2.float().cuda()])
+    assert_close(ncdhw(gd[0]), rg[0].numpy(), atol=5e-5, what="proj dx1")
+    assert_close(ncdhw(gd[1]), rg[1].numpy(), atol=5e-5, what="proj dx2")
+    for a, b, nme in zip(gd[2:], rg[2:], ("dW", "db", "dgamma", "dbeta")):
+        assert_close(np64(a), b.numpy(), atol=4e-3, rtol=2e-4, what=f"proj pair {nme} (sum over 2x{n} voxels)")
+    # without gradients the pair is two plain applications
+    with torch.no_grad():
+        z1, z2 = ops.proj_ln_pair(xd1, xd2, *pd)
+    assert torch.equal(z1, y1) and torch.equal(z2, y2)
+
+
 # ------------------------------------------------------------------------------------------------ conv / norm / pool
 @pytest.mark.parametrize("tag", ["c0", "c1", "c2", "c3"])
 def test_conv_block_golden(ops, tag):

@@ -3,4 +3,4 @@
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_g -o tr -- python /root/repo/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extra --graph ${1:-on} > /tmp/bench_g.json 2>/tmp/bench_g.err
 cut -c1-260 /tmp/bench_g.json
-python /root/repo/tools/step_gaps.py $(find /tmp/prof_g -name "*kernel_trace.csv" | head -1)
+python /root/repo/tools/step_gaps.py $(find /tmp/prof_g -name "*kernel_trace.csv" | head -1) ${2:-} | tail -${3:-60}

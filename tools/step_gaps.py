@@ -22,3 +22,20 @@ for a, b in zip(cuts[:-1], cuts[1:]):
     print("step: launches %4d  span %7.3f ms  busy %7.3f ms  idle %6.3f ms  small(<12us) %3d launches %6.3f ms  median gap %5d ns  p90 gap %6d ns"
           % (len(seg), (e1 - s0) / 1e6, sum(dur) / 1e6, (e1 - s0 - sum(dur)) / 1e6, len(small), sum(small) / 1e6,
              gaps[len(gaps) // 2], gaps[int(len(gaps) * 0.9)]))
+
+if len(sys.argv) > 2 and sys.argv[2] == "--census" and len(cuts) >= 2:
+    import collections
+    import re
+    a, b = cuts[-2], cuts[-1]
+    seg = rows[a + 1:b + 1]
+    cnt, tot = collections.Counter(), collections.Counter()
+    for r in seg:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        n = re.sub(r"^void ", "", n)[:70]
+        if d < 12000:
+            cnt[n] += 1
+            tot[n] += d
+    print("# launches shorter than 12 us in the last step: %d, %.3f ms" % (sum(cnt.values()), sum(tot.values()) / 1e6))
+    for n, c in cnt.most_common(40):
+        print("%4d x %6.1f us  %s" % (c, tot[n] / c / 1e3, n))
