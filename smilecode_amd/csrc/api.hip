@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 200; /* 0.2.0 */ }
+int modet_hip_version(void) { return 210; /* 0.2.1: operator fp64 + plane kernels, prepack, deferred reductions, projection pair */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {
