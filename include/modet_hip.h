@@ -218,6 +218,11 @@ int modet_warp_bwd(const float* src, const float* flow, const float* d_out, floa
  * x (B,d,h,w,C) -> y (B,2d,2h,2w,C).  Backward is the exact transpose in gather form (no atomics). */
 int modet_upsample2_fwd(const float* x, float* y, int B, int d, int h, int w, int C, float scale, modet_stream_t stream);
 int modet_upsample2_bwd(const float* d_y, float* d_x, int B, int d, int h, int w, int C, float scale, modet_stream_t stream);
+/* the same gradient as three 1-D passes (z, y, x) through a workspace, for the large levels; _ws_bytes returns 0 where the
+ * one-launch gather above is the better choice (small volumes) */
+size_t modet_upsample2_bwd_sep_ws_bytes(int B, int d, int h, int w, int C);
+int modet_upsample2_bwd_sep(const float* d_y, float* d_x, void* ws, size_t ws_bytes, int B, int d, int h, int w, int C,
+                            float scale, modet_stream_t stream);
 
 /* layout changes at the module boundary: (B,C,V) <-> (B,V,C) */
 int modet_ncdhw_to_cl(const float* x, float* y, int B, int C, int64_t V, modet_stream_t stream);

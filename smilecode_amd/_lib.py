@@ -64,6 +64,8 @@ SIGNATURES = {
     "modet_warp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "modet_upsample2_fwd": (I, [P, P, I, I, I, I, I, F, P]),
     "modet_upsample2_bwd": (I, [P, P, I, I, I, I, I, F, P]),
+    "modet_upsample2_bwd_sep_ws_bytes": (SZ, [I, I, I, I, I]),
+    "modet_upsample2_bwd_sep": (I, [P, P, P, SZ, I, I, I, I, I, F, P]),
     "modet_ncdhw_to_cl": (I, [P, P, I, I, I64, P]),
     "modet_cl_to_ncdhw": (I, [P, P, I, I, I64, P]),
     "modet_cwm_tail_fwd": (I, [P, P, P, I64, I, P]),

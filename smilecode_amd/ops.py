@@ -827,9 +827,16 @@ class _Upsample2(Function):
         dy = dy.contiguous()
         B, d, h, w, C = ctx.shape
         dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        L = _L()
+        nb = L.modet_upsample2_bwd_sep_ws_bytes(B, d, h, w, C)       # > 0: large level, three 1-D passes
+        ws = _ws(nb, dy) if nb else None
         with _Guard(dy, f"upsample2_bwd[C{C}]", 16.0 * dy.numel(), 4.0 * (dx.numel() + dy.numel())):
-            _lib.check(_L().modet_upsample2_bwd(_p(dy), _p(dx), B, d, h, w, C, ctx.scale, _stream()),
-                       "modet_upsample2_bwd")
+            if nb:
+                _lib.check(L.modet_upsample2_bwd_sep(_p(dy), _p(dx), _p(ws), nb, B, d, h, w, C, ctx.scale, _stream()),
+                           "modet_upsample2_bwd_sep")
+            else:
+                _lib.check(L.modet_upsample2_bwd(_p(dy), _p(dx), B, d, h, w, C, ctx.scale, _stream()),
+                           "modet_upsample2_bwd")
         return dx, None
 
 

@@ -576,6 +576,30 @@ def test_upsample_golden(ops):
         assert_close(ncdhw(torch.autograd.grad(yd, xd, cl(gy.numpy()))[0]), rx.numpy(), atol=5e-5, what="upsample dx")
 
 
+@pytest.mark.parametrize("C,shape,B", [(3, (33, 40, 52), 1), (6, (16, 41, 50), 2), (1, (41, 40, 41), 1)])
+def test_upsample_backward_separable(ops, C, shape, B):
+    """large levels take the three-pass (z, y, x) form of the upsample gradient: against ATen-CPU fp64 and against the
+    one-launch gather it replaces (same weights, different summation order: 1e-5)."""
+    from smilecode_amd import _lib
+    from smilecode_amd.ops import _p, _stream
+    d, h, w = shape
+    L = _lib.load()
+    assert L.modet_upsample2_bwd_sep_ws_bytes(B, d, h, w, C) > 0 and L.modet_upsample2_bwd_sep_ws_bytes(1, 8, 8, 8, C) == 0
+    gen = torch.Generator().manual_seed(C + d)
+    xx = torch.randn((B, C) + shape, generator=gen).double().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(xx, scale_factor=2, mode="trilinear", align_corners=True) * 2.0
+    gy = torch.randn(ref.shape, generator=gen).double()
+    rx = torch.autograd.grad(ref, xx, gy)[0]
+    xd = cl(xx.detach().numpy()).requires_grad_(True)
+    yd = ops.upsample2(xd, 2.0)
+    gyd = cl(gy.numpy())
+    dx = torch.autograd.grad(yd, xd, gyd)[0]
+    assert_close(ncdhw(dx), rx.numpy(), atol=5e-5, what="upsample dx (separable)")
+    direct = torch.empty_like(dx)
+    _lib.check(L.modet_upsample2_bwd(_p(gyd), _p(direct), B, d, h, w, C, 2.0, _stream()), "modet_upsample2_bwd")
+    assert float((direct - dx).abs().max()) <= 1e-5 * max(1.0, float(direct.abs().max()))
+
+
 @pytest.mark.parametrize("tag,heads", [("w3", 2), ("w5", 8)])
 def test_cwm_golden(tag, heads):
     from smilecode_amd.models import CWM
