@@ -190,6 +190,27 @@ def operator_only(args, rank, local, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t)
     l1 = rows[0]
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # the plain-C restatement of the CUDA operator (oracle/modet_ref.c: ref_modet_fw / ref_modet_bw, fp64, one thread)
+        # on a bounded sample -- the level-1 shape, 4 915 200 of the step's 5 768 400 voxel-heads -- scaled to the whole step
+        import numpy as np
+        from oracle import cref
+        rng = np.random.default_rng(0)
+        D, H, W = 160, 192, 160
+        q = rng.standard_normal((1, 1, D, H, W, 6))
+        kp = np.zeros((1, 1, D + 2, H + 2, W + 2, 6))
+        kp[:, :, 1:-1, 1:-1, 1:-1] = rng.standard_normal((1, 1, D, H, W, 6))
+        rpb = rng.standard_normal((1, 3, 3, 3))
+        ga = rng.standard_normal((1, 1, D, H, W, 27))
+        t0 = time.perf_counter()
+        cref.modet_fw(q, kp, rpb)
+        cref.modet_bw(ga, q, kp, True)
+        dt = time.perf_counter() - t0
+        vh_step = sum(r["shape"][0] * r["shape"][1] * r["shape"][2] * r["heads"] for r in rows)
+        cpu = {"value": 1.0 / (dt * vh_step / (D * H * W)), "unit": "volume-pairs/sec", "cores": 1, "kind": "port",
+               "sample": "modet_fw + modet_bw of oracle/modet_ref.c (plain C, fp64) at 160x192x160, 1 head: %.2f s, scaled by voxel-heads"
+                         % dt}
     traffic = None
     try:                                             # per-launch HBM bytes of the same kernel from the rocprofv3 --pmc passes
         with open(os.path.join(ROOT, "profiles", "r02f_pmc_traffic_operator.json")) as f:
@@ -204,7 +225,7 @@ def operator_only(args, rank, local, world):
             "config": {"workload": "modetqkrpb_cu operator only, head_dim 6, heads 8/4/2/1/1, batch 1/GPU, median of per-call HIP events"},
             "roofline": {"bound": "hbm", "kernel": "qk_bwd_plane_kernel<float,6> @160x192x160", "achieved": l1["bwd_GBps"],
                          "peak": 8000.0, "unit": "GB/s", "frac": l1["bwd_GBps"] / 8000.0, "traffic": traffic},
-            "levels": rows}), flush=True)
+            "cpu_baseline": cpu, "levels": rows}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
