@@ -9,12 +9,15 @@
  *
  * Conventions
  *  - plain C, no torch types: raw DEVICE pointers, sizes, an explicit hipStream_t (as void*).
- *  - fp32 everywhere.  Activations are channels-last "(B,D,H,W,C)" unless a comment says
+ *  - fp32 unless the name says otherwise (*_bf16: bf16 activations, fp32 accumulate; *_f64: the operator boundary in
+ *    double).  Activations are channels-last "(B,D,H,W,C)" unless a comment says
  *    otherwise; (D,H,W) are the reference's (H,W,T) = the three spatial axes in memory order.
  *  - caller allocates every output and workspace; the library never allocates, frees or retains
  *    device memory and is re-entrant (the autograd engine calls the backward entry points from
- *    another thread).  Its only process-wide state is a mutex-guarded memo of
- *    per-kernel occupancy constants (filled on first use, never changed afterwards).
+ *    another thread).  Its process-wide state: a mutex-guarded memo of
+ *    per-kernel occupancy constants (filled on first use, never changed afterwards), and the two OPT-IN tables of the
+ *    step-batching entry points -- the packing jobs recorded by modet_conv3d_prepack_* and the reductions queued by
+ *    modet_conv3d_bwd_weight_defer (both mutex-guarded; pointers only, the caller owns every buffer they name).
  *  - every entry point only enqueues stream work (kernels, hipMemsetAsync): a sequence of calls
  *    can be captured into a hipGraph once each kernel has been launched at least once.
  *  - all launches are asynchronous on `stream`; nothing synchronises.
