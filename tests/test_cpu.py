@@ -381,6 +381,41 @@ def test_trainer_state_dict_is_torch_adam_compatible():
         tr2.load_state_dict({"step": 1, "lr": 1e-4})                       # round 1's stub format is rejected loudly
 
 
+def test_flat_params_gather_with_directly_written_gradients():
+    """FlatParams.gather_grads(written): parameters whose gradient was written straight into the flat buffer (the
+    deferred weight-gradient reductions) are left alone, a further autograd contribution to such a parameter is added
+    on top, the others are copied, and parameters without any gradient are zeroed."""
+    import torch.nn as nn
+    from smilecode_amd.parallel import FlatParams
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Parameter(torch.arange(6.0).reshape(2, 3))
+            self.b = nn.Parameter(torch.ones(4))
+            self.c = nn.Parameter(torch.full((5,), 2.0))
+            self.d = nn.Parameter(torch.zeros(3))
+
+    m = M()
+    fp = FlatParams(m)
+    dst = fp.grad_destinations()
+    assert set(dst) == {p.data_ptr() for p in fp.params} and dst[m.a.data_ptr()].shape == m.a.shape
+    assert dst[m.b.data_ptr()].data_ptr() == fp.grad[6:10].data_ptr()          # views of the flat buffer, in order
+    fp.grad.fill_(-7.0)                                                        # stale values from the previous step
+    fp.zero_grad()
+    dst[m.a.data_ptr()].copy_(torch.full((2, 3), 10.0))                        # written directly
+    dst[m.b.data_ptr()].copy_(torch.full((4,), 20.0))                          # written directly ...
+    m.b.grad = torch.full((4,), 1.0)                                           # ... plus a second use through autograd
+    m.c.grad = torch.full((5,), 3.0)                                           # ordinary autograd gradient
+    fp.gather_grads({m.a.data_ptr(), m.b.data_ptr()})
+    assert torch.equal(fp.grad, torch.cat([torch.full((6,), 10.0), torch.full((4,), 21.0), torch.full((5,), 3.0),
+                                           torch.zeros(3)]))
+    fp.zero_grad()
+    m.a.grad = torch.ones(2, 3)
+    fp.gather_grads()                                                          # no direct writes: everything as before
+    assert torch.equal(fp.grad[:6], torch.ones(6)) and float(fp.grad[6:].abs().sum()) == 0.0
+
+
 def test_save_checkpoint_rotation_keeps_the_eight_best(tmp_path):
     """save_checkpoint (train.py:171-176): at most 8 files, the naturally-sorted first (lowest Dice) goes first"""
     from smilecode_amd.train import latest_checkpoint, save_checkpoint
