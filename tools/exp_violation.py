@@ -21,6 +21,9 @@ def viol():
 
 shape = (160, 192, 160)
 dev = torch.device("cuda", 0)
+hold = None
+if float(os.environ.get("HOLD_GB", "0")) > 0:      # experiment: push every later allocation to another part of the HBM
+    hold = torch.empty(int(float(os.environ["HOLD_GB"]) * (1 << 30)), dtype=torch.uint8, device=dev)
 model = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).to(dev)
 models.load_numpy_weights(model, synth.make_weights(24))
 tr = Trainer(model)
@@ -37,7 +40,7 @@ for _ in range(400):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / 400 * 1e3
 b = viol()
-print("step %.3f ms" % ms)
+print("step %.3f ms  (hold %s GB)" % (ms, os.environ.get("HOLD_GB", "0")))
 la, lb = a.splitlines(), b.splitlines()
 for x, y in zip(la, lb):
     if x != y:
