@@ -291,6 +291,10 @@ int modet_conv3d_bf16_bwd_data(const void* d_y, const float* w, void* d_x, int d
 size_t modet_conv3d_bf16_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modet_conv3d_bf16_bwd_weight(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
                                  size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+/* modet_conv3d_bf16_bwd_weight without its two reduction launches: they are queued and run by
+ * modet_conv3d_wgrad_defer_flush together with the fp32 ones (same contract as modet_conv3d_bwd_weight_defer). */
+int modet_conv3d_bf16_bwd_weight_defer(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
+                                       size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
 /* InstanceNorm3d + LeakyReLU(0.1) on a bf16 raw conv output x: forward from the conv's statistics buffer (y fp32 | bf16,
  * mean / rstd (B*C) fp32 out); backward d_x (bf16) from d_y (fp32 | bf16), x, mean, rstd. */
 size_t modet_instnorm_bf16_ws_bytes(int B, int64_t V, int C);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "modet_conv3d_bf16_bwd_data": (I, [P, P, P, I, P, SZ, I, I, I, I, I, I, P]),
     "modet_conv3d_bf16_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_bf16_bwd_weight": (I, [P, I, P, P, P, P, SZ, I, I, I, I, I, I, P]),
+    "modet_conv3d_bf16_bwd_weight_defer": (I, [P, I, P, P, P, P, SZ, I, I, I, I, I, I, P]),
     "modet_instnorm_bf16_ws_bytes": (SZ, [I, I64, I]),
     "modet_instnorm_lrelu_fwd_stats_bf16": (I, [P, P, I, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_bwd_bf16": (I, [P, I, P, P, P, P, P, SZ, I, I64, I, P]),

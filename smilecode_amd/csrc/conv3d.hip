@@ -1423,6 +1423,12 @@ inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
 // tests pass with it, but as measured in round 2 (profiles/r02d_split_vs_exact.txt) it wins 1.2-1.4x only at pyramid levels
 // 2-3, ties at level 1 (those kernels are bound by staging the fp32 tile, not by the matrix pipe) and loses at levels
 // 4-5, so the train step does not move (12.37 vs 12.46 ms) and the default stays the exact-f32 MFMA kernels of this file.
+void modetx_bf16_prepack_record(int on);
+size_t modetx_bf16_prepack_bytes();
+int modetx_bf16_prepack_count();
+void modetx_bf16_prepack_begin(void* arena, hipStream_t stream);
+void modetx_bf16_prepack_end();
+void modetx_bf16_defer_flush(hipStream_t stream);
 bool modetx_split_eligible(int Cin, int Cout);
 size_t modetx_split_ws_bytes(int Cin, int Cout);
 size_t modetx_split_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
@@ -1444,30 +1450,36 @@ int modet_debug_conv_timing(long long* buf) {       // not in the header: tuning
 int modet_conv3d_uses_bf16x3(void) { return use_split(4, 4) ? 1 : 0; }
 
 int modet_conv3d_prepack_record(int on) {
+  modetx_bf16_prepack_record(on);                       // the bf16 convs keep their own job list (conv3d_bf16.hip)
   std::lock_guard<std::mutex> lk(g_pack_mu);
   if (on) { g_pack_jobs.clear(); g_pack_off.clear(); g_pack_active = false; }
   g_pack_recording = on != 0;
-  return (int)g_pack_jobs.size();
+  return (int)g_pack_jobs.size() + modetx_bf16_prepack_count();
 }
 
-size_t modet_conv3d_prepack_arena_bytes(void) {
+static size_t prepack_f32_bytes() {
   std::lock_guard<std::mutex> lk(g_pack_mu);
   size_t n = 0;
   for (const PackKey& k : g_pack_jobs) n += pack_job_elems(k);
   return n * sizeof(float);
 }
 
+size_t modet_conv3d_prepack_arena_bytes(void) { return prepack_f32_bytes() + modetx_bf16_prepack_bytes(); }
+
 int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t stream) {
   std::vector<PackKey> jobs;
+  const size_t f32_bytes = prepack_f32_bytes(), b16_bytes = modetx_bf16_prepack_bytes();
+  if (f32_bytes + b16_bytes == 0) return MODET_OK;
+  if (arena == nullptr) return MODET_ERR_NULL;
+  if (arena_bytes < f32_bytes + b16_bytes) return MODET_ERR_WORKSPACE;
+  modetx_bf16_prepack_begin((char*)arena + f32_bytes, (hipStream_t)stream);      // bf16 jobs follow the fp32 ones
   {
     std::lock_guard<std::mutex> lk(g_pack_mu);
     if (g_pack_recording) return MODET_ERR_UNSUPPORTED;         // stop recording first
-    if (g_pack_jobs.empty()) { g_pack_active = false; return MODET_OK; }
-    if (arena == nullptr) return MODET_ERR_NULL;
+    if (g_pack_jobs.empty()) { g_pack_active = false; return modet_launch_status(); }
     g_pack_off.assign(g_pack_jobs.size(), 0);
     size_t n = 0;
     for (size_t i = 0; i < g_pack_jobs.size(); ++i) { g_pack_off[i] = n; n += pack_job_elems(g_pack_jobs[i]); }
-    if (arena_bytes < n * sizeof(float)) return MODET_ERR_WORKSPACE;
     g_pack_arena = (float*)arena;
     g_pack_active = true;
     jobs = g_pack_jobs;
@@ -1489,6 +1501,7 @@ int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t s
 }
 
 int modet_conv3d_prepack_end(void) {
+  modetx_bf16_prepack_end();
   std::lock_guard<std::mutex> lk(g_pack_mu);
   g_pack_active = false;
   return MODET_OK;
@@ -1623,6 +1636,7 @@ static void reduce_or_defer(const ReduceJob& j, int blocks, hipStream_t s, bool 
 }
 
 int modet_conv3d_wgrad_defer_flush(modet_stream_t stream) {
+  modetx_bf16_defer_flush((hipStream_t)stream);           // the queue of modet_conv3d_bf16_bwd_weight_defer
   std::vector<ReduceJob> jobs;
   std::vector<int> blocks;
   {

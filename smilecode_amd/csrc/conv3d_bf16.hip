@@ -17,6 +17,8 @@
 // staging the halo'd tile; 3-5 workgroups per CU overlap each other's phases).
 // dgrad is the same kernel on flipped + transposed weights.
 #include "common.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -71,6 +73,66 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned s
       wpk[i] = h; wpk[(size_t)total + i] = m; wpk[(size_t)2 * total + i] = l;
     }
   }
+}
+
+// The same packing for many weight tensors in one launch (modet_conv3d_prepack_*, see conv3d.hip): jobs by value.
+constexpr int PACKB_MAX_JOBS = 40;
+struct PackBJob { const float* w; unsigned short* wpk; int Cin, Cout, CoutP, CK, nstage, ksteps, mode, npiece; };
+struct PackBTable { PackBJob job[PACKB_MAX_JOBS]; int n; };
+__global__ void pack_weights_bf16_many_kernel(const PackBTable t) {
+  const PackBJob& J = t.job[blockIdx.y];
+  const float* __restrict__ w = J.w;
+  unsigned short* __restrict__ wpk = J.wpk;
+  const int Cin = J.Cin, Cout = J.Cout, CoutP = J.CoutP, CK = J.CK, ksteps = J.ksteps, mode = J.mode;
+  const int total = J.nstage * ksteps * CoutP * 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 31;
+    int tt = i >> 5;
+    const int n = tt % CoutP; tt /= CoutP;
+    const int step = tt % ksteps, stage = tt / ksteps;
+    const int kp = step * 32 + j;
+    const int tap = kp / CK, c = stage * CK + kp % CK;
+    float v = 0.f;
+    if (tap < 27 && c < Cin && n < Cout)
+      v = mode == 0 ? w[((int64_t)n * Cin + c) * 27 + tap] : w[((int64_t)c * Cout + n) * 27 + 26 - tap];
+    if (J.npiece == 1) {
+      wpk[i] = to_bf16(v);
+    } else {
+      unsigned short h, m, l;
+      split3(v, h, m, l);
+      wpk[i] = h; wpk[(size_t)total + i] = m; wpk[(size_t)2 * total + i] = l;
+    }
+  }
+}
+
+struct PackBKey {
+  const float* w; int Cin, Cout, CoutP, CK, nstage, ksteps, mode, npiece;
+  bool operator==(const PackBKey& o) const {
+    return w == o.w && Cin == o.Cin && Cout == o.Cout && CoutP == o.CoutP && CK == o.CK && nstage == o.nstage &&
+           ksteps == o.ksteps && mode == o.mode && npiece == o.npiece;
+  }
+};
+std::mutex g_packb_mu;
+bool g_packb_recording = false, g_packb_active = false;
+std::vector<PackBKey> g_packb_jobs;
+std::vector<size_t> g_packb_off;                    // ushort offset of each job inside the bf16 part of the arena
+unsigned short* g_packb_arena = nullptr;
+inline size_t packb_elems(const PackBKey& k) {
+  return ((size_t)k.nstage * k.ksteps * k.CoutP * 32 * k.npiece + 127) / 128 * 128;
+}
+const unsigned short* prepacked_bf16_or_record(const PackBKey& k) {
+  std::lock_guard<std::mutex> lk(g_packb_mu);
+  if (g_packb_active) {
+    for (size_t i = 0; i < g_packb_jobs.size(); ++i)
+      if (g_packb_jobs[i] == k) return g_packb_arena + g_packb_off[i];
+    return nullptr;
+  }
+  if (g_packb_recording) {
+    bool seen = false;
+    for (const PackBKey& j : g_packb_jobs) seen = seen || j == k;
+    if (!seen) g_packb_jobs.push_back(k);
+  }
+  return nullptr;
 }
 
 // shift K of the fused statistics (see conv_shift_kernel in conv3d.hip): the conv output at voxel (1,1,1), any summation order
@@ -526,11 +588,10 @@ __global__ __launch_bounds__(NTHR) void conv3d_bf16_wgrad_kernel(const void* __r
 // stage 1 of the partial reduction: red[j] = sum_g part[g][j] over the gx workgroup partials, j over gy * RED_FL floats.
 // 1024 threads = 64 consecutive j x 16 g-lanes: coalesced 256-byte rows, fixed assignment and fixed order (fp64):
 // deterministic.  (One thread per output element walking 512 partials 28 KB apart took longer than the MFMA kernel.)
-__global__ __launch_bounds__(1024) void wgrad_bf16_colsum_kernel(const float* __restrict__ part, float* __restrict__ red,
-                                                                 int gx, int64_t row_fl) {
-  __shared__ double sm[16][64];
+__device__ __forceinline__ void wgrad_bf16_colsum_body(const float* __restrict__ part, float* __restrict__ red, int gx,
+                                                       int64_t row_fl, int blk, double (*sm)[64]) {
   const int o = threadIdx.x & 63, gl = threadIdx.x >> 6;
-  const int64_t j = (int64_t)blockIdx.x * 64 + o;
+  const int64_t j = (int64_t)blk * 64 + o;
   double a = 0.0;
   if (j < row_fl)
     for (int g = gl; g < gx; g += 16) a += (double)part[(int64_t)g * row_fl + j];
@@ -543,13 +604,18 @@ __global__ __launch_bounds__(1024) void wgrad_bf16_colsum_kernel(const float* __
     red[j] = (float)t;
   }
 }
+__global__ __launch_bounds__(1024) void wgrad_bf16_colsum_kernel(const float* __restrict__ part, float* __restrict__ red,
+                                                                 int gx, int64_t row_fl) {
+  __shared__ double sm[16][64];
+  wgrad_bf16_colsum_body(part, red, gx, row_fl, blockIdx.x, sm);
+}
 
 // stage 2: d_w[co][ci][tap] / d_bias[co] gathered out of the reduced fragment-layout buffer (call with gx = 1).
-__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                float* __restrict__ dbias, int Cin, int Cout, int CIB, int U,
-                                                                int NTB, int gx, int gy, int n_coblk) {
+__device__ __forceinline__ void wgrad_bf16_reduce_body(const float* __restrict__ part, float* __restrict__ dw,
+                                                       float* __restrict__ dbias, int Cin, int Cout, int CIB, int U, int NTB,
+                                                       int gx, int gy, int n_coblk, int blk) {
   const int nW = Cout * Cin * 27;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blk * 256 + threadIdx.x;
   if (i >= nW + Cout) return;
   const int SLOTS = U * 3 + 1, RED_FL = SLOTS * NTB * 256;
   const int GPB = CIB == 16 ? 9 : (CIB == 8 ? 5 : 3);
@@ -576,6 +642,36 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
   if (i < nW) dw[i] = (float)a;
   else if (dbias) dbias[co] = (float)a;
 }
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                float* __restrict__ dbias, int Cin, int Cout, int CIB, int U,
+                                                                int NTB, int gx, int gy, int n_coblk) {
+  wgrad_bf16_reduce_body(part, dw, dbias, Cin, Cout, CIB, U, NTB, gx, gy, n_coblk, blockIdx.x);
+}
+
+// Deferred form (modet_conv3d_bf16_bwd_weight_defer + modet_conv3d_wgrad_defer_flush): both stages of every queued
+// weight gradient in two launches instead of two per layer; job tables by value in the kernel arguments.
+constexpr int BRED_MAX_JOBS = 24;
+struct BRedJob {
+  const float* part; float* red; float* dw; float* dbias;
+  int64_t row_fl;
+  int gx, Cin, Cout, cib, u, ntb, gy, n_coblk;
+};
+struct BRedTable { BRedJob job[BRED_MAX_JOBS]; int first[BRED_MAX_JOBS + 1]; int n; };
+__global__ __launch_bounds__(1024) void wgrad_bf16_colsum_many_kernel(const BRedTable t) {
+  __shared__ double sm[16][64];
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.x >= t.first[j + 1]) ++j;
+  const BRedJob& J = t.job[j];
+  wgrad_bf16_colsum_body(J.part, J.red, J.gx, J.row_fl, blockIdx.x - t.first[j], sm);
+}
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_many_kernel(const BRedTable t) {
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.x >= t.first[j + 1]) ++j;
+  const BRedJob& J = t.job[j];
+  wgrad_bf16_reduce_body(J.red, J.dw, J.dbias, J.Cin, J.Cout, J.cib, J.u, J.ntb, 1, J.gy, J.n_coblk, blockIdx.x - t.first[j]);
+}
+std::mutex g_bdefer_mu;
+std::vector<BRedJob> g_bdefer_jobs;
 
 struct WgBf16Plan { int cib, u, ntb, tz, ty, n_chunk, n_coblk, gy, gx, ntiles, tiles_x, tiles_y, tiles_z, red_fl; };
 inline WgBf16Plan plan_wgrad_bf16(int B, int D, int H, int W, int Cin, int Cout) {
@@ -628,8 +724,11 @@ int launch_bf16(const void* x, const float* w, const float* bias, void* y, void*
   const Bf16Plan p = plan_bf16(V, Cin, Cout);
   unsigned short* wpk = (unsigned short*)ws;
   const int total = p.nstage * p.ksteps * p.coutp * 32;
-  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w, wpk,
-                     Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 1);
+  if (const unsigned short* pre = prepacked_bf16_or_record(PackBKey{w, Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 1}))
+    wpk = const_cast<unsigned short*>(pre);
+  else
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w, wpk,
+                       Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 1);
   const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
   const dim3 grid(tiles_x * tiles_y * tiles_z, p.coutp / (p.nt * 16), B);
   float* shift = nullptr;
@@ -682,8 +781,11 @@ int launch_split(const float* x, const float* w, const float* bias, float* y, vo
   const Bf16Plan p = plan_split(V, Cin, Cout);
   unsigned short* wpk = (unsigned short*)ws;
   const int total = p.nstage * p.ksteps * p.coutp * 32;
-  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w, wpk,
-                     Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 3);
+  if (const unsigned short* pre = prepacked_bf16_or_record(PackBKey{w, Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 3}))
+    wpk = const_cast<unsigned short*>(pre);
+  else
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w, wpk,
+                       Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 3);
   const int tiles_x = cdiv(W, TX), tiles_y = cdiv(H, p.ty), tiles_z = cdiv(D, p.tz);
   const dim3 grid(tiles_x * tiles_y * tiles_z, p.coutp / (p.nt * 16), B);
   float* shift = nullptr;
@@ -729,6 +831,75 @@ int modetx_split_conv(const float* x, const float* w, const float* bias, float* 
                       int Cin, int Cout, int mode, hipStream_t s) {
   return stats ? launch_split<true>(x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, mode, s)
                : launch_split<false>(x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, mode, s);
+}
+
+// ---- bf16 side of modet_conv3d_wgrad_defer_flush (conv3d.hip calls it)
+void modetx_bf16_defer_flush(hipStream_t stream) {
+  std::vector<BRedJob> jobs;
+  {
+    std::lock_guard<std::mutex> lk(g_bdefer_mu);
+    jobs.swap(g_bdefer_jobs);
+  }
+  for (size_t i0 = 0; i0 < jobs.size(); i0 += BRED_MAX_JOBS) {
+    BRedTable t;
+    const int n = (int)(jobs.size() - i0 < (size_t)BRED_MAX_JOBS ? jobs.size() - i0 : (size_t)BRED_MAX_JOBS);
+    t.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) { t.job[i] = jobs[i0 + i]; t.first[i] = total; total += (int)cdiv64(t.job[i].row_fl, 64); }
+    for (int i = n; i <= BRED_MAX_JOBS; ++i) t.first[i] = total;
+    hipLaunchKernelGGL(wgrad_bf16_colsum_many_kernel, dim3(total), dim3(1024), 0, stream, t);
+    total = 0;
+    for (int i = 0; i < n; ++i) { t.first[i] = total; total += cdiv(t.job[i].Cout * t.job[i].Cin * 27 + t.job[i].Cout, 256); }
+    for (int i = n; i <= BRED_MAX_JOBS; ++i) t.first[i] = total;
+    hipLaunchKernelGGL(wgrad_bf16_reduce_many_kernel, dim3(total), dim3(256), 0, stream, t);
+  }
+}
+
+// ---- bf16 side of modet_conv3d_prepack_* (conv3d.hip owns the entry points; the bf16 jobs follow the fp32 jobs in the arena)
+void modetx_bf16_prepack_record(int on) {
+  std::lock_guard<std::mutex> lk(g_packb_mu);
+  if (on) { g_packb_jobs.clear(); g_packb_off.clear(); g_packb_active = false; }
+  g_packb_recording = on != 0;
+}
+size_t modetx_bf16_prepack_bytes() {
+  std::lock_guard<std::mutex> lk(g_packb_mu);
+  size_t n = 0;
+  for (const PackBKey& k : g_packb_jobs) n += packb_elems(k);
+  return n * sizeof(unsigned short);
+}
+int modetx_bf16_prepack_count() {
+  std::lock_guard<std::mutex> lk(g_packb_mu);
+  return (int)g_packb_jobs.size();
+}
+void modetx_bf16_prepack_begin(void* arena, hipStream_t stream) {
+  std::vector<PackBKey> jobs;
+  {
+    std::lock_guard<std::mutex> lk(g_packb_mu);
+    if (g_packb_jobs.empty()) { g_packb_active = false; return; }
+    g_packb_off.assign(g_packb_jobs.size(), 0);
+    size_t n = 0;
+    for (size_t i = 0; i < g_packb_jobs.size(); ++i) { g_packb_off[i] = n; n += packb_elems(g_packb_jobs[i]); }
+    g_packb_arena = (unsigned short*)arena;
+    g_packb_active = true;
+    jobs = g_packb_jobs;
+  }
+  for (size_t i0 = 0; i0 < jobs.size(); i0 += PACKB_MAX_JOBS) {
+    PackBTable t;
+    const int n = (int)(jobs.size() - i0 < (size_t)PACKB_MAX_JOBS ? jobs.size() - i0 : (size_t)PACKB_MAX_JOBS);
+    int most = 1;
+    for (int i = 0; i < n; ++i) {
+      const PackBKey& k = jobs[i0 + i];
+      t.job[i] = PackBJob{k.w, g_packb_arena + g_packb_off[i0 + i], k.Cin, k.Cout, k.CoutP, k.CK, k.nstage, k.ksteps, k.mode, k.npiece};
+      const int blocks = cdiv(k.nstage * k.ksteps * k.CoutP * 32, 256);
+      most = blocks > most ? blocks : most;
+    }
+    t.n = n;
+    hipLaunchKernelGGL(pack_weights_bf16_many_kernel, dim3(most > 64 ? 64 : most, n), dim3(256), 0, stream, t);
+  }
+}
+void modetx_bf16_prepack_end() {
+  std::lock_guard<std::mutex> lk(g_packb_mu);
+  g_packb_active = false;
 }
 
 extern "C" {
@@ -779,8 +950,21 @@ size_t modet_conv3d_bf16_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin
   return ((size_t)p.gx + 1) * p.gy * p.red_fl * sizeof(float);        // workgroup partials + their column sums
 }
 
+static int bf16_bwd_weight_impl(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
+                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream, bool defer);
+
 int modet_conv3d_bf16_bwd_weight(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
                                  size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+  return bf16_bwd_weight_impl(x, x_bf16, d_y, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, false);
+}
+int modet_conv3d_bf16_bwd_weight_defer(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
+                                       size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+  return bf16_bwd_weight_impl(x, x_bf16, d_y, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, true);
+}
+
+static int bf16_bwd_weight_impl(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
+                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
+                                bool defer) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (Cout % 8 != 0 || (x_bf16 ? Cin % 8 != 0 : Cin % 4 != 0)) return MODET_ERR_UNSUPPORTED;
@@ -809,6 +993,11 @@ int modet_conv3d_bf16_bwd_weight(const void* x, int x_bf16, const void* d_y, flo
   const int nout = Cout * Cin * 27 + Cout;
   const int64_t row_fl = (int64_t)p.gy * p.red_fl;
   float* red = (float*)ws + (size_t)p.gx * row_fl;
+  if (defer) {
+    std::lock_guard<std::mutex> lk(g_bdefer_mu);
+    g_bdefer_jobs.push_back(BRedJob{(const float*)ws, red, d_w, d_bias, row_fl, p.gx, Cin, Cout, p.cib, p.u, p.ntb, p.gy, p.n_coblk});
+    return modet_launch_status();
+  }
   hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, (const float*)ws, red, p.gx, row_fl);
   hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, s, (const float*)red, d_w, d_bias, Cin, Cout,
                      p.cib, p.u, p.ntb, 1, p.gy, p.n_coblk);

@@ -1114,18 +1114,30 @@ def conv3d_bf16_backward_data(dy, w, Cin, dx_bf16):
     return dx
 
 
-def conv3d_bf16_backward_weight(x, dy):
-    """d_w, d_bias (fp32) from x (fp32 | bf16) and d_y (bf16)"""
+def conv3d_bf16_backward_weight(x, dy, w=None, b=None):
+    """d_w, d_bias (fp32) from x (fp32 | bf16) and d_y (bf16); inside a ``deferred_wgrad_reductions`` scope with
+    destinations for the parameters ``w`` / ``b`` the gradients go there at the flush and (None, None) is returned"""
     _chk16(x, dy)
     L = _L()
     if hasattr(L, "modet_conv3d_bf16_bwd_weight"):
         B, D, H, W, Cin = x.shape
         Cout = dy.shape[-1]
-        dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
-        db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
         nb = L.modet_conv3d_bf16_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)
         ws = _ws(nb, x)
         n = float(B) * D * H * W
+        scope = deferred_wgrad_reductions._active
+        dst = scope.destinations(w, b, True) if (scope is not None and hasattr(L, "modet_conv3d_bf16_bwd_weight_defer")) else None
+        if dst is not None:
+            dw, db = dst
+            with _Guard(x, f"conv_bf16_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
+                _lib.check(L.modet_conv3d_bf16_bwd_weight_defer(_p(x), _isbf(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W,
+                                                                Cin, Cout, _stream()), "modet_conv3d_bf16_bwd_weight_defer")
+            scope._keep.append(ws)
+            scope.written.add(w.data_ptr())
+            scope.written.add(b.data_ptr())
+            return None, None
+        dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+        db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
         with _Guard(x, f"conv_bf16_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
             _lib.check(L.modet_conv3d_bf16_bwd_weight(_p(x), _isbf(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
                                                       _stream()), "modet_conv3d_bf16_bwd_weight")
@@ -1140,16 +1152,16 @@ class _Conv3dBF16(Function):
     @staticmethod
     def forward(ctx, x, w, b):
         y, stats = conv3d_bf16_forward(x, w, b, True)
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats):
-        x, w = ctx.saved_tensors
+        x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
         dx = conv3d_bf16_backward_data(dy, w, x.shape[-1], x.dtype == torch.bfloat16) if ctx.needs_input_grad[0] else None
-        dw, db = conv3d_bf16_backward_weight(x, dy)
+        dw, db = conv3d_bf16_backward_weight(x, dy, w, b)
         return dx, dw, db
 
 

@@ -70,6 +70,55 @@ def test_conv_bf16_fwd_dgrad_wgrad_vs_exact_on_rounded_operands(B, D, H, W, Cin,
     assert torch.equal(dw, dw2) and torch.equal(db, db2), "weight gradient must be run-to-run deterministic"
 
 
+def test_bf16_step_batching_is_bit_identical():
+    """The step-level batching scopes on the bf16 convs: every layer's weight packing in one launch
+    (ops.PrepackedConvWeights, bf16 jobs behind the fp32 ones in the arena) and every weight-gradient reduction in two
+    (ops.deferred_wgrad_reductions) must give the bits of the per-layer launches, also after the weights moved."""
+    from smilecode_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    layers, dst = [], {}
+    for (B, D, H, W, Cin, Cout, inbf) in CASES[:10]:
+        x = torch.randn((B, D, H, W, Cin), generator=gen).cuda()
+        if inbf:
+            x = x.bfloat16()
+        w = (torch.randn((Cout, Cin, 3, 3, 3), generator=gen) / np.sqrt(Cin * 27)).cuda()
+        b = (0.1 * torch.randn(Cout, generator=gen)).cuda()
+        dy = torch.randn((B, D, H, W, Cout), generator=gen).cuda().bfloat16()
+        dst[w.data_ptr()] = torch.full_like(w, float("nan"))
+        dst[b.data_ptr()] = torch.full_like(b, float("nan"))
+        layers.append((x, w, b, dy, inbf))
+
+    def run(scope=None):
+        out = []
+        for x, w, b, dy, inbf in layers:
+            y, st = ops.conv3d_bf16_forward(x, w, b, True)
+            dx = ops.conv3d_bf16_backward_data(dy, w, x.shape[-1], inbf)
+            g = ops.conv3d_bf16_backward_weight(x, dy, w, b)
+            out.append((y.clone(), st.clone(), dx.clone(), g))
+        return out
+
+    ref = run()
+    pp = ops.PrepackedConvWeights()
+    with pp.step("k"):
+        run()                                                  # records
+    with pp.step("k"):
+        with ops.deferred_wgrad_reductions(dst) as scope:
+            got = run()
+    for (ry, rs, rdx, (rw, rb)), (gy, gs, gdx, g), (x, w, b, dy, inbf) in zip(ref, got, layers):
+        live = rs.numel() - x.shape[0] * 64 * 2 * w.shape[0]       # the buffer ends in a 64-row scratch tail per sample
+        assert torch.equal(ry, gy) and torch.equal(rs[:live], gs[:live]) and torch.equal(rdx, gdx)
+        assert g == (None, None) and w.data_ptr() in scope.written
+        assert torch.equal(rw, dst[w.data_ptr()]) and torch.equal(rb, dst[b.data_ptr()])
+    for _, w, _, _, _ in layers:
+        w.mul_(1.25)
+    ref2 = run()
+    with pp.step("k"):
+        got2 = run()
+    for a, c in zip(ref2, got2):
+        assert torch.equal(a[0], c[0]) and torch.equal(a[2], c[2]) and torch.equal(a[3][0], c[3][0])
+    assert not torch.equal(ref[0][0], ref2[0][0])
+
+
 @pytest.mark.parametrize("C,dybf", [(8, True), (8, False), (16, True), (64, False), (128, True)])
 def test_instnorm_bf16_forward_backward(C, dybf):
     """InstanceNorm + LeakyReLU on a bf16 raw tensor: vs fp64 autograd on the SAME (bf16-valued) tensor"""
