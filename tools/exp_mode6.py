@@ -30,7 +30,9 @@ def sampler():
         p = re.search(r"SOCKET_POWER: (\d+) W", out)
         thr = re.search(r"THROTTLE_STATUS: (\S+)", out)
         act = re.search(r"UMC_ACTIVITY: (\d+)", out)
-        samples.append((gfx, int(p.group(1)) if p else -1, thr.group(1) if thr else "?", int(act.group(1)) if act else -1))
+        busy = re.search(r"GFX_BUSY_INST:\s*\n\s*XCP_0: \[([^\]]*)\]", out)
+        samples.append((gfx, int(p.group(1)) if p else -1, thr.group(1) if thr else "?", int(act.group(1)) if act else -1,
+                        busy.group(1) if busy else "?"))
         time.sleep(0.2)
 
 
@@ -53,3 +55,4 @@ print("step %.3f ms  samples %d  mean GFX clk %.0f MHz (min %d max %d)  power %.
     ms, len(mid), sum(clk) / len(clk), min(min(s[0]) for s in mid), max(max(s[0]) for s in mid),
     sum(s[1] for s in mid) / len(mid), set(s[2] for s in mid), set(s[3] for s in mid)))
 print("  e.g.", mid[len(mid) // 2])
+print("  UMC activity samples:", [x[3] for x in mid])
