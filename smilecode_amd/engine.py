@@ -43,8 +43,12 @@ class Trainer:
 
     def loss(self, moving, fixed):
         y_moved, flow = self.model(moving, fixed)
-        sim = self.sim(fixed, y_moved) * self.weights[0]
-        reg = self.reg(flow, fixed) * self.weights[1]
+        sim = self.sim(fixed, y_moved)
+        reg = self.reg(flow, fixed)
+        if self.weights[0] != 1.0:          # train.py:127-129 multiplies by weights [1, 1]: x * 1.0 == x, and each scalar
+            sim = sim * self.weights[0]     # multiplication is a 4 us launch forward and another one backward
+        if self.weights[1] != 1.0:
+            reg = reg * self.weights[1]
         return sim + reg, sim, reg
 
     # ---------------------------------------------------------------- hipGraph replay of forward + backward
