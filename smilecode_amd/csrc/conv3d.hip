@@ -1468,6 +1468,10 @@ size_t modet_conv3d_prepack_arena_bytes(void) { return prepack_f32_bytes() + mod
 
 int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t stream) {
   std::vector<PackKey> jobs;
+  {
+    std::lock_guard<std::mutex> lk(g_pack_mu);
+    if (g_pack_recording) return MODET_ERR_UNSUPPORTED;         // stop recording first
+  }
   const size_t f32_bytes = prepack_f32_bytes(), b16_bytes = modetx_bf16_prepack_bytes();
   if (f32_bytes + b16_bytes == 0) return MODET_OK;
   if (arena == nullptr) return MODET_ERR_NULL;
@@ -1475,7 +1479,6 @@ int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t s
   modetx_bf16_prepack_begin((char*)arena + f32_bytes, (hipStream_t)stream);      // bf16 jobs follow the fp32 ones
   {
     std::lock_guard<std::mutex> lk(g_pack_mu);
-    if (g_pack_recording) return MODET_ERR_UNSUPPORTED;         // stop recording first
     if (g_pack_jobs.empty()) { g_pack_active = false; return modet_launch_status(); }
     g_pack_off.assign(g_pack_jobs.size(), 0);
     size_t n = 0;
