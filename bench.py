@@ -384,21 +384,22 @@ def main():
         t_eager = quick()
         try:
             trainer.capture(mov, fix)
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
             graphed = True
         except Exception as e:
             trainer.release_graph()
             if args.graph == "on":
                 raise
             log(f"[bench] hipGraph capture failed ({e!r}); timing the eager path")
-        if world > 1:                       # every rank must take the same path
-            flag = torch.tensor([1 if graphed else 0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if world > 1:                       # every rank must take the same path -- agreed on BEFORE any further step: a
+            flag = torch.tensor([1 if graphed else 0], device=dev)     # step holds a 4 MB gradient all-reduce, and a rank
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # that skipped it would pair this flag with it
             if graphed and int(flag.item()) == 0:
                 trainer.release_graph()
                 graphed = False
+        if graphed:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
         if graphed and args.graph == "auto":
             t_graph = quick()
             if t_graph > 1.05 * t_eager:     # never let the replay cost throughput (same decision on every rank: both are maxima)

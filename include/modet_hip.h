@@ -14,10 +14,10 @@
  *    otherwise; (D,H,W) are the reference's (H,W,T) = the three spatial axes in memory order.
  *  - caller allocates every output and workspace; the library never allocates, frees or retains
  *    device memory and is re-entrant (the autograd engine calls the backward entry points from
- *    another thread).  Its process-wide state: a mutex-guarded memo of
- *    per-kernel occupancy constants (filled on first use, never changed afterwards), and the two OPT-IN tables of the
- *    step-batching entry points -- the packing jobs recorded by modet_conv3d_prepack_* and the reductions queued by
- *    modet_conv3d_bwd_weight_defer (both mutex-guarded; pointers only, the caller owns every buffer they name).
+ *    another thread).  Its only process-wide state is a mutex-guarded memo of per-kernel occupancy
+ *    constants (filled on first use, never changed afterwards).  The step-batching entry points (recorded weight-packing
+ *    jobs, queued weight-gradient reductions) keep their tables in a CALLER-OWNED context, modet_step_ctx_t: host
+ *    memory only, one per trainer / stream of work, passed explicitly; NULL = "no batching" wherever it is optional.
  *  - every entry point only enqueues stream work (kernels, hipMemsetAsync): a sequence of calls
  *    can be captured into a hipGraph once each kernel has been launched at least once.
  *  - all launches are asynchronous on `stream`; nothing synchronises.
@@ -37,6 +37,15 @@ extern "C" {
 #endif
 
 typedef void* modet_stream_t; /* hipStream_t */
+
+/* Caller-owned context of the step-batching entry points (modet_conv3d_prepack_*, modet_conv3d_*_defer,
+ * modet_conv3d_wgrad_defer_flush).  Host memory only: job descriptions (pointers + geometry), no device memory, no
+ * stream.  Calls on ONE context may come from two threads (forward thread, autograd thread; guarded inside); different
+ * contexts never interact, so two trainers in one process -- two threads, two devices, a training and an evaluation
+ * model -- each use their own. */
+typedef struct modet_step_ctx modet_step_ctx_t;
+int modet_step_ctx_create(modet_step_ctx_t** out);
+int modet_step_ctx_destroy(modet_step_ctx_t* ctx);   /* NULL is a no-op; nothing queued may still be in flight */
 
 enum {
   MODET_OK = 0,
@@ -100,8 +109,10 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
  * (default: exact-f32 MFMA, bitwise an fmaf chain). */
 int modet_conv3d_uses_bf16x3(void);
 size_t modet_conv3d_ws_bytes(int Cin, int Cout);
+/* `step` (every conv entry point that packs weights): NULL, or the context whose recorded packing jobs apply, see
+ * modet_conv3d_prepack_* below. */
 int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
-                     int B, int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream);
+                     int B, int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream, modet_step_ctx_t* step);
 /* Forward + fused InstanceNorm statistics (ConvInsBlock, models.py:135-151): the staged epilogue also emits
  * per-(sample, workgroup) partial sums (sum, sum of squares) of the output.  modet_conv3d_stats_bytes() == 0 means this
  * (Cin, Cout) cannot fuse them (use modet_conv3d_fwd + modet_instnorm_lrelu_fwd).  Consume with
@@ -110,17 +121,17 @@ size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 size_t modet_conv3d_normin_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);   /* stats of modet_conv3d_fwd_normin */
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                            float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                           modet_stream_t stream);
+                           modet_stream_t stream, modet_step_ctx_t* step);
 /* Forward whose input is the RAW output of the previous ConvInsBlock: LeakyReLU((x_raw - in_mean) * in_rstd) is applied
  * while the input tile is staged (zero padding stays zero), so the normalised tensor is never written
  * (ConvInsBlock -> ConvInsBlock chains, models.py:186-219; used when no gradient is needed: inference).  in_mean / in_rstd: (B*Cin) from modet_instnorm_stats.
  * stats (+stats_bytes) may be NULL (0): no fused output statistics.  Cin % 4 == 0. */
 int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* w,
                             const float* bias, float* y, void* ws, size_t ws_bytes, float* stats, size_t stats_bytes, int B,
-                            int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+                            int D, int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step);
 /* d_x = conv(d_y, flipped/transposed w) */
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes,
-                          int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+                          int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step);
 /* d_w (Cout,Cin,3,3,3), d_bias (Cout) or NULL; deterministic two-stage reduction */
 size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes,
@@ -136,28 +147,29 @@ int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y
 /* Weight packing hoisted out of the step.  Every fp32 conv launch (forward, statistics, lazily normalised, data gradient)
  * starts with a 4 us launch that packs its weights into the MFMA operand layout; a training step has 38 of them and
  * the weights only change once per step.  Protocol:
- *   modet_conv3d_prepack_record(1); <one forward+backward>; n = modet_conv3d_prepack_record(0);   -- learn the jobs
- *   every later step: modet_conv3d_prepack_begin(arena, modet_conv3d_prepack_arena_bytes(), stream)  -- ONE launch
- *                     <forward+backward: launches whose (weights pointer, geometry) was recorded skip their packing>
- *                     modet_conv3d_prepack_end();
+ *   modet_conv3d_prepack_record(ctx, 1); <one forward+backward, every conv call given ctx>;
+ *   n = modet_conv3d_prepack_record(ctx, 0);                                                          -- learn the jobs
+ *   every later step: modet_conv3d_prepack_begin(ctx, arena, modet_conv3d_prepack_arena_bytes(ctx), stream) -- ONE launch
+ *                     <forward+backward: launches given ctx whose (weights pointer, geometry) was recorded skip theirs>
+ *                     modet_conv3d_prepack_end(ctx);
  * The caller guarantees the recorded weight tensors stay where they are and do not change between _begin and _end, and
- * keeps `arena` alive until _end.  Launches that were not recorded pack as usual.  Process-wide, mutex-guarded. */
-int modet_conv3d_prepack_record(int on);
-size_t modet_conv3d_prepack_arena_bytes(void);
-int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t stream);
-int modet_conv3d_prepack_end(void);
+ * keeps `arena` alive until _end (and for as long as a captured hipGraph of the step may be replayed).  Launches that
+ * were not recorded, or are given another / no context, pack as usual. */
+int modet_conv3d_prepack_record(modet_step_ctx_t* ctx, int on);
+size_t modet_conv3d_prepack_arena_bytes(modet_step_ctx_t* ctx);
+int modet_conv3d_prepack_begin(modet_step_ctx_t* ctx, void* arena, size_t arena_bytes, modet_stream_t stream);
+int modet_conv3d_prepack_end(modet_step_ctx_t* ctx);
 
 /* Deferred weight-gradient reductions.  A backward pass launches ~20 weight-gradient kernels, each followed by a tiny
  * reduction of its per-workgroup partial tiles (5-9 us apiece, all launch latency).  modet_conv3d_bwd_weight_defer is
  * modet_conv3d_bwd_weight (y_act == NULL) / modet_conv3d_bwd_weight_act (y_act != NULL) without that reduction: it only
- * writes the partial tiles into `ws` and queues the reduction; modet_conv3d_wgrad_defer_flush runs every queued
- * reduction in ONE launch on `stream` (same arithmetic, same fixed order: bit-identical results) and empties the
- * queue.  Until the flush the caller keeps every `ws`, d_w and d_bias it passed alive and untouched.  The queue is
- * process-wide (backward runs on the autograd thread), mutex-guarded. */
+ * writes the partial tiles into `ws` and queues the reduction in `step`; modet_conv3d_wgrad_defer_flush(step, ..) runs
+ * every reduction queued there in ONE launch on `stream` (same arithmetic, same fixed order: bit-identical results)
+ * and empties the queue.  Until the flush the caller keeps every `ws`, d_w and d_bias it passed alive and untouched. */
 int modet_conv3d_bwd_weight_defer(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias,
                                   void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                                  modet_stream_t stream);
-int modet_conv3d_wgrad_defer_flush(modet_stream_t stream);
+                                  modet_stream_t stream, modet_step_ctx_t* step);
+int modet_conv3d_wgrad_defer_flush(modet_step_ctx_t* step, modet_stream_t stream);
 
 
 /* InstanceNorm3d(affine=False, eps, biased variance) + LeakyReLU(0.1) (ConvInsBlock, models.py:135-151).
@@ -285,16 +297,17 @@ size_t modet_conv3d_bf16_ws_bytes(int Cin, int Cout);
 size_t modet_conv3d_bf16_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modet_conv3d_bf16_fwd(const void* x, int x_bf16, const float* w, const float* bias, void* y, void* ws, size_t ws_bytes,
                           float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                          modet_stream_t stream);
+                          modet_stream_t stream, modet_step_ctx_t* step);
 int modet_conv3d_bf16_bwd_data(const void* d_y, const float* w, void* d_x, int dx_bf16, void* ws, size_t ws_bytes,
-                               int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+                               int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step);
 size_t modet_conv3d_bf16_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modet_conv3d_bf16_bwd_weight(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
                                  size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
 /* modet_conv3d_bf16_bwd_weight without its two reduction launches: they are queued and run by
  * modet_conv3d_wgrad_defer_flush together with the fp32 ones (same contract as modet_conv3d_bwd_weight_defer). */
 int modet_conv3d_bf16_bwd_weight_defer(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
-                                       size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream);
+                                       size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
+                                       modet_step_ctx_t* step);
 /* InstanceNorm3d + LeakyReLU(0.1) on a bf16 raw conv output x: forward from the conv's statistics buffer (y fp32 | bf16,
  * mean / rstd (B*C) fp32 out); backward d_x (bf16) from d_y (fp32 | bf16), x, mean, rstd. */
 size_t modet_instnorm_bf16_ws_bytes(int B, int64_t V, int C);

@@ -32,21 +32,23 @@ SIGNATURES = {
     "modet_na_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, F, P]),
     "modet_conv3d_uses_bf16x3": (I, []),
     "modet_conv3d_ws_bytes": (SZ, [I, I]),
-    "modet_conv3d_fwd": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P]),
+    "modet_conv3d_fwd": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P, P]),
     "modet_conv3d_stats_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_normin_stats_bytes": (SZ, [I, I, I, I, I, I]),
-    "modet_conv3d_fwd_stats": (I, [P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P]),
-    "modet_conv3d_fwd_normin": (I, [P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P]),
-    "modet_conv3d_bwd_data": (I, [P, P, P, P, SZ, I, I, I, I, I, I, P]),
+    "modet_conv3d_fwd_stats": (I, [P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
+    "modet_conv3d_fwd_normin": (I, [P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
+    "modet_conv3d_bwd_data": (I, [P, P, P, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_bwd_weight": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
     "modet_conv3d_bwd_weight_act": (I, [P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
-    "modet_conv3d_prepack_record": (I, [I]),
-    "modet_conv3d_prepack_arena_bytes": (SZ, []),
-    "modet_conv3d_prepack_begin": (I, [P, SZ, P]),
-    "modet_conv3d_prepack_end": (I, []),
-    "modet_conv3d_bwd_weight_defer": (I, [P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
-    "modet_conv3d_wgrad_defer_flush": (I, [P]),
+    "modet_step_ctx_create": (I, [C.POINTER(P)]),
+    "modet_step_ctx_destroy": (I, [P]),
+    "modet_conv3d_prepack_record": (I, [P, I]),
+    "modet_conv3d_prepack_arena_bytes": (SZ, [P]),
+    "modet_conv3d_prepack_begin": (I, [P, P, SZ, P]),
+    "modet_conv3d_prepack_end": (I, [P]),
+    "modet_conv3d_bwd_weight_defer": (I, [P, P, P, P, P, P, SZ, I, I, I, I, I, I, P, P]),
+    "modet_conv3d_wgrad_defer_flush": (I, [P, P]),
     "modet_instnorm_ws_bytes": (SZ, [I, I64, I]),
     "modet_instnorm_lrelu_fwd": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_fwd_stats": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
@@ -83,11 +85,11 @@ SIGNATURES = {
     "modet_jacdet_nonpos_count": (I, [P, P, P, I, I, I, I, P]),
     "modet_conv3d_bf16_ws_bytes": (SZ, [I, I]),
     "modet_conv3d_bf16_stats_bytes": (SZ, [I, I, I, I, I, I]),
-    "modet_conv3d_bf16_fwd": (I, [P, I, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P]),
-    "modet_conv3d_bf16_bwd_data": (I, [P, P, P, I, P, SZ, I, I, I, I, I, I, P]),
+    "modet_conv3d_bf16_fwd": (I, [P, I, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
+    "modet_conv3d_bf16_bwd_data": (I, [P, P, P, I, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_bf16_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_bf16_bwd_weight": (I, [P, I, P, P, P, P, SZ, I, I, I, I, I, I, P]),
-    "modet_conv3d_bf16_bwd_weight_defer": (I, [P, I, P, P, P, P, SZ, I, I, I, I, I, I, P]),
+    "modet_conv3d_bf16_bwd_weight_defer": (I, [P, I, P, P, P, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_instnorm_bf16_ws_bytes": (SZ, [I, I64, I]),
     "modet_instnorm_lrelu_fwd_stats_bf16": (I, [P, P, I, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_bwd_bf16": (I, [P, I, P, P, P, P, P, SZ, I, I64, I, P]),

@@ -40,7 +40,8 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "modet_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "modet_hip.h"))
     jobs = []
     objs = []
     for src in SOURCES:

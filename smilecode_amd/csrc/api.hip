@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 210; /* 0.2.1: operator fp64 + plane kernels, prepack, deferred reductions, projection pair */ }
+int modet_hip_version(void) { return 300; /* 0.3.0: caller-owned step context (modet_step_ctx_t) for the step-batching entry points */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {

@@ -11,8 +11,10 @@
 //   Cin<=8 packs two taps into the 16 M rows.  Workgroups walk tiles persistently, partial d_w goes to a
 //   workspace and is summed in fixed order in fp64 (deterministic, no atomics).
 #include "common.h"
+#include "step_ctx.h"
 #include <cstdlib>
 #include <mutex>
+#include <new>
 #include <unordered_map>
 #include <vector>
 
@@ -805,10 +807,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // launch + drain latency.  The job table travels by value in the kernel arguments (no device table to keep alive,
 // capturable); workgroup -> job by a scalar search over the block prefix.
 constexpr int REDUCE_MAX_JOBS = 32;
-struct ReduceJob {
-  const float* part; float* dw; float* db;
-  int Cin, Cout, gx, gy, n_ci, cit, ng, mode;
-};
 struct ReduceTable {
   ReduceJob job[REDUCE_MAX_JOBS];
   int first[REDUCE_MAX_JOBS + 1];
@@ -1257,47 +1255,39 @@ inline size_t fwd_ws_elems(int Cin, int Cout) {
   return plain > packed ? plain : packed;
 }
 
-// ---- weight packing hoisted out of the step (modet_conv3d_prepack_*).  While RECORDING, every conv launch notes its
-// packing job (weights pointer, mode, padded geometry); _begin packs all recorded jobs in one launch into the caller's
-// arena and, until _end, a conv launch whose job is in the table uses the arena copy and skips its own packing launch.
-struct PackKey {
-  const float* w; int Cin, Cout, CinP, CoutP, mode, P;
-  bool operator==(const PackKey& o) const {
-    return w == o.w && Cin == o.Cin && Cout == o.Cout && CinP == o.CinP && CoutP == o.CoutP && mode == o.mode && P == o.P;
-  }
-};
-static std::mutex g_pack_mu;
-static bool g_pack_recording = false, g_pack_active = false;
-static std::vector<PackKey> g_pack_jobs;          // recorded, in launch order
-static std::vector<size_t> g_pack_off;            // float offset of each job's packed weights inside the arena
-static float* g_pack_arena = nullptr;
+// ---- weight packing hoisted out of the step (modet_conv3d_prepack_*, state in the caller's modet_step_ctx).  While
+// RECORDING, every conv launch that is given the context notes its packing job (weights pointer, mode, padded geometry);
+// _begin packs all recorded jobs in one launch into the caller's arena and, until _end, a conv launch whose job is in the
+// table uses the arena copy and skips its own packing launch.
 inline size_t pack_job_elems(const PackKey& k) { return ((size_t)9 * (k.P + 2) * k.CinP * k.CoutP + 63) / 64 * 64; }
 
-// returns the pre-packed weights for this launch, or null (and records the job when recording)
-static const float* prepacked_or_record(const PackKey& k) {
-  std::lock_guard<std::mutex> lk(g_pack_mu);
-  if (g_pack_active) {
-    for (size_t i = 0; i < g_pack_jobs.size(); ++i)
-      if (g_pack_jobs[i] == k) return g_pack_arena + g_pack_off[i];
+// returns the pre-packed weights for this launch, or null (and records the job when the context is recording)
+static const float* prepacked_or_record(modet_step_ctx* c, const PackKey& k) {
+  if (!c) return nullptr;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->active) {
+    for (size_t i = 0; i < c->jobs.size(); ++i)
+      if (c->jobs[i] == k) return c->arena + c->off[i];
     return nullptr;
   }
-  if (g_pack_recording) {
+  if (c->recording) {
     bool seen = false;
-    for (const PackKey& j : g_pack_jobs) seen = seen || j == k;
-    if (!seen) g_pack_jobs.push_back(k);
+    for (const PackKey& j : c->jobs) seen = seen || j == k;
+    if (!seen) c->jobs.push_back(k);
   }
   return nullptr;
 }
 
 // query_gx != null: only report the persistent grid's x size (the statistics layout depends on it), launch nothing
-int conv_launch(const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D, int H, int W,
-                int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr, int* query_gx = nullptr,
-                ConvIn inorm = ConvIn{nullptr, nullptr, 0, nullptr}, bool query_xf = false, bool query_st = false) {
+int conv_launch(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D,
+                int H, int W, int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr,
+                int* query_gx = nullptr, ConvIn inorm = ConvIn{nullptr, nullptr, 0, nullptr}, bool query_xf = false,
+                bool query_st = false) {
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 9 * (p.P + 2) * CinP * CoutP;
   if (!query_gx) {
-    const float* pre = prepacked_or_record(PackKey{w, Cin, Cout, CinP, CoutP, pack_mode, p.P});
+    const float* pre = prepacked_or_record(step, PackKey{w, Cin, Cout, CinP, CoutP, pack_mode, p.P});
     if (pre)
       wpk = const_cast<float*>(pre);
     else
@@ -1381,7 +1371,7 @@ int conv_launch(const float* x, const float* w, const float* bias, float* y, flo
 // hence in residency); the statistics buffer is sized by the larger one (conv_stats_rows)
 inline int conv_grid_x(int B, int D, int H, int W, int Cin, int Cout, bool xf) {
   int gx = 0;
-  conv_launch(nullptr, nullptr, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, nullptr, nullptr, &gx,
+  conv_launch(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, nullptr, nullptr, &gx,
               ConvIn{nullptr, nullptr, 0, nullptr}, xf, !xf);
   return gx;
 }
@@ -1423,17 +1413,14 @@ inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
 // tests pass with it, but as measured in round 2 (profiles/r02d_split_vs_exact.txt) it wins 1.2-1.4x only at pyramid levels
 // 2-3, ties at level 1 (those kernels are bound by staging the fp32 tile, not by the matrix pipe) and loses at levels
 // 4-5, so the train step does not move (12.37 vs 12.46 ms) and the default stays the exact-f32 MFMA kernels of this file.
-void modetx_bf16_prepack_record(int on);
-size_t modetx_bf16_prepack_bytes();
-int modetx_bf16_prepack_count();
-void modetx_bf16_prepack_begin(void* arena, hipStream_t stream);
-void modetx_bf16_prepack_end();
-void modetx_bf16_defer_flush(hipStream_t stream);
+size_t modetx_bf16_prepack_bytes(modet_step_ctx* c);
+void modetx_bf16_prepack_begin(modet_step_ctx* c, void* arena, hipStream_t stream);
+void modetx_bf16_defer_flush(modet_step_ctx* c, hipStream_t stream);
 bool modetx_split_eligible(int Cin, int Cout);
 size_t modetx_split_ws_bytes(int Cin, int Cout);
 size_t modetx_split_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
-int modetx_split_conv(const float* x, const float* w, const float* bias, float* y, void* ws, float* stats, int B, int D, int H,
-                      int W, int Cin, int Cout, int mode, hipStream_t s);
+int modetx_split_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
+                      int B, int D, int H, int W, int Cin, int Cout, int mode, hipStream_t s);
 static bool use_split(int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_SPLIT"); return e && e[0] == '1'; }();
   return on && modetx_split_eligible(Cin, Cout);
@@ -1449,43 +1436,58 @@ int modet_debug_conv_timing(long long* buf) {       // not in the header: tuning
 
 int modet_conv3d_uses_bf16x3(void) { return use_split(4, 4) ? 1 : 0; }
 
-int modet_conv3d_prepack_record(int on) {
-  modetx_bf16_prepack_record(on);                       // the bf16 convs keep their own job list (conv3d_bf16.hip)
-  std::lock_guard<std::mutex> lk(g_pack_mu);
-  if (on) { g_pack_jobs.clear(); g_pack_off.clear(); g_pack_active = false; }
-  g_pack_recording = on != 0;
-  return (int)g_pack_jobs.size() + modetx_bf16_prepack_count();
+int modet_step_ctx_create(modet_step_ctx_t** out) {
+  MODET_CHECK_PTR(out);
+  *out = new (std::nothrow) modet_step_ctx();
+  return *out ? MODET_OK : MODET_ERR_WORKSPACE;
 }
 
-static size_t prepack_f32_bytes() {
-  std::lock_guard<std::mutex> lk(g_pack_mu);
+int modet_step_ctx_destroy(modet_step_ctx_t* ctx) {
+  delete ctx;
+  return MODET_OK;
+}
+
+int modet_conv3d_prepack_record(modet_step_ctx_t* c, int on) {
+  MODET_CHECK_PTR(c);
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (on) { c->jobs.clear(); c->off.clear(); c->bjobs.clear(); c->boff.clear(); c->active = false; }
+  c->recording = on != 0;
+  return (int)(c->jobs.size() + c->bjobs.size());
+}
+
+static size_t prepack_f32_bytes(modet_step_ctx* c) {
+  std::lock_guard<std::mutex> lk(c->mu);
   size_t n = 0;
-  for (const PackKey& k : g_pack_jobs) n += pack_job_elems(k);
+  for (const PackKey& k : c->jobs) n += pack_job_elems(k);
   return n * sizeof(float);
 }
 
-size_t modet_conv3d_prepack_arena_bytes(void) { return prepack_f32_bytes() + modetx_bf16_prepack_bytes(); }
+size_t modet_conv3d_prepack_arena_bytes(modet_step_ctx_t* c) {
+  return c ? prepack_f32_bytes(c) + modetx_bf16_prepack_bytes(c) : 0;
+}
 
-int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t stream) {
+int modet_conv3d_prepack_begin(modet_step_ctx_t* c, void* arena, size_t arena_bytes, modet_stream_t stream) {
+  MODET_CHECK_PTR(c);
   std::vector<PackKey> jobs;
+  std::vector<size_t> off;
   {
-    std::lock_guard<std::mutex> lk(g_pack_mu);
-    if (g_pack_recording) return MODET_ERR_UNSUPPORTED;         // stop recording first
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->recording) return MODET_ERR_UNSUPPORTED;         // stop recording first
   }
-  const size_t f32_bytes = prepack_f32_bytes(), b16_bytes = modetx_bf16_prepack_bytes();
+  const size_t f32_bytes = prepack_f32_bytes(c), b16_bytes = modetx_bf16_prepack_bytes(c);
   if (f32_bytes + b16_bytes == 0) return MODET_OK;
   if (arena == nullptr) return MODET_ERR_NULL;
   if (arena_bytes < f32_bytes + b16_bytes) return MODET_ERR_WORKSPACE;
-  modetx_bf16_prepack_begin((char*)arena + f32_bytes, (hipStream_t)stream);      // bf16 jobs follow the fp32 ones
+  modetx_bf16_prepack_begin(c, (char*)arena + f32_bytes, (hipStream_t)stream);      // 16-bit jobs follow the fp32 ones
   {
-    std::lock_guard<std::mutex> lk(g_pack_mu);
-    if (g_pack_jobs.empty()) { g_pack_active = false; return modet_launch_status(); }
-    g_pack_off.assign(g_pack_jobs.size(), 0);
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->off.assign(c->jobs.size(), 0);
     size_t n = 0;
-    for (size_t i = 0; i < g_pack_jobs.size(); ++i) { g_pack_off[i] = n; n += pack_job_elems(g_pack_jobs[i]); }
-    g_pack_arena = (float*)arena;
-    g_pack_active = true;
-    jobs = g_pack_jobs;
+    for (size_t i = 0; i < c->jobs.size(); ++i) { c->off[i] = n; n += pack_job_elems(c->jobs[i]); }
+    c->arena = (float*)arena;
+    c->active = true;
+    jobs = c->jobs;                                         // the launch tables are built from copies taken under the lock
+    off = c->off;
   }
   for (size_t i0 = 0; i0 < jobs.size(); i0 += PACK_MAX_JOBS) {
     PackTable t;
@@ -1493,7 +1495,7 @@ int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t s
     int most = 1;
     for (int i = 0; i < n; ++i) {
       const PackKey& k = jobs[i0 + i];
-      t.job[i] = PackJob{k.w, g_pack_arena + g_pack_off[i0 + i], k.Cin, k.Cout, k.CinP, k.CoutP, k.mode, k.P, 0};
+      t.job[i] = PackJob{k.w, (float*)arena + off[i0 + i], k.Cin, k.Cout, k.CinP, k.CoutP, k.mode, k.P, 0};
       const int blocks = cdiv(9 * (k.P + 2) * k.CinP * k.CoutP, 256);
       most = blocks > most ? blocks : most;
     }
@@ -1503,10 +1505,10 @@ int modet_conv3d_prepack_begin(void* arena, size_t arena_bytes, modet_stream_t s
   return modet_launch_status();
 }
 
-int modet_conv3d_prepack_end(void) {
-  modetx_bf16_prepack_end();
-  std::lock_guard<std::mutex> lk(g_pack_mu);
-  g_pack_active = false;
+int modet_conv3d_prepack_end(modet_step_ctx_t* c) {
+  MODET_CHECK_PTR(c);
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->active = false;
   return MODET_OK;
 }
 
@@ -1517,7 +1519,7 @@ size_t modet_conv3d_ws_bytes(int Cin, int Cout) {
 }
 
 int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
-                     int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream) {
+                     int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream, modet_step_ctx_t* step) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
@@ -1530,9 +1532,9 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
   }
   if (!act && use_split(Cin, Cout)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
-    return modetx_split_conv(x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
+    return modetx_split_conv(step, x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
   }
-  return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
+  return conv_launch(step, x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
 }
 
 // InstanceNorm statistics are fused into the conv epilogue (staged or direct-store) for every Cout the model
@@ -1560,7 +1562,7 @@ size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
 
 int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                            float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                           modet_stream_t stream) {
+                           modet_stream_t stream, modet_step_ctx_t* step) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws); MODET_CHECK_PTR(stats);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
@@ -1568,15 +1570,15 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
   if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   if (use_split(Cin, Cout)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
-    return modetx_split_conv(x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
+    return modetx_split_conv(step, x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
   }
-  return conv_launch(x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
+  return conv_launch(step, x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
                      ConvIn{nullptr, nullptr, conv_stats_rows(B, D, H, W, Cin, Cout), nullptr});
 }
 
 int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* w,
                             const float* bias, float* y, void* ws, size_t ws_bytes, float* stats, size_t stats_bytes, int B,
-                            int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+                            int D, int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step) {
   MODET_CHECK_PTR(x_raw); MODET_CHECK_PTR(in_mean); MODET_CHECK_PTR(in_rstd); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y);
   MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
@@ -1586,21 +1588,21 @@ int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const floa
     if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
     if (stats_bytes < modet_conv3d_normin_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   }
-  return conv_launch(x_raw, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
+  return conv_launch(step, x_raw, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
                      ConvIn{in_mean, in_rstd, stats ? conv_stats_rows(B, D, H, W, Cin, Cout) : 0, nullptr});
 }
 
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,
-                          int W, int Cin, int Cout, modet_stream_t stream) {
+                          int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step) {
   MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(w); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (ws_bytes < fwd_ws_elems(Cout, Cin) * sizeof(float)) return MODET_ERR_WORKSPACE;
   // a convolution of d_y (Cout channels) producing Cin channels
   if (use_split(Cout, Cin)) {
     if (ws_bytes < modetx_split_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
-    return modetx_split_conv(d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, (hipStream_t)stream);
+    return modetx_split_conv(step, d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, (hipStream_t)stream);
   }
-  return conv_launch(d_y, w, nullptr, d_x, (float*)ws, B, D, H, W, Cout, Cin, 0, 1, (hipStream_t)stream);
+  return conv_launch(step, d_y, w, nullptr, d_x, (float*)ws, B, D, H, W, Cout, Cin, 0, 1, (hipStream_t)stream);
 }
 
 size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
@@ -1614,20 +1616,17 @@ size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int
 
 static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
                                 size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
-                                bool defer = false);
+                                modet_step_ctx* defer = nullptr);
 
 // ---- deferred reductions: modet_conv3d_bwd_weight*_defer only produce the partial tiles (the workspace must stay
-// untouched until the flush) and queue the reduction; modet_conv3d_wgrad_defer_flush runs everything queued at once.
-// Process-wide queue, mutex-guarded: the autograd engine calls backward from its own thread.
-static std::mutex g_defer_mu;
-static std::vector<ReduceJob> g_defer_jobs;
-static std::vector<int> g_defer_blocks;
-
-static void reduce_or_defer(const ReduceJob& j, int blocks, hipStream_t s, bool defer) {
+// untouched until the flush) and queue the reduction in the caller's step context; modet_conv3d_wgrad_defer_flush runs
+// everything queued there at once.  The context's mutex covers the queue: the autograd engine calls backward from its
+// own thread.
+static void reduce_or_defer(const ReduceJob& j, int blocks, hipStream_t s, modet_step_ctx* defer) {
   if (defer) {
-    std::lock_guard<std::mutex> lk(g_defer_mu);
-    g_defer_jobs.push_back(j);
-    g_defer_blocks.push_back(blocks);
+    std::lock_guard<std::mutex> lk(defer->mu);
+    defer->rjobs.push_back(j);
+    defer->rblocks.push_back(blocks);
     return;
   }
   if (j.mode == 0)
@@ -1638,14 +1637,15 @@ static void reduce_or_defer(const ReduceJob& j, int blocks, hipStream_t s, bool 
                        j.n_ci, j.cit, j.ng);
 }
 
-int modet_conv3d_wgrad_defer_flush(modet_stream_t stream) {
-  modetx_bf16_defer_flush((hipStream_t)stream);           // the queue of modet_conv3d_bf16_bwd_weight_defer
+int modet_conv3d_wgrad_defer_flush(modet_step_ctx_t* c, modet_stream_t stream) {
+  MODET_CHECK_PTR(c);
+  modetx_bf16_defer_flush(c, (hipStream_t)stream);        // the queue of modet_conv3d_bf16_bwd_weight_defer
   std::vector<ReduceJob> jobs;
   std::vector<int> blocks;
   {
-    std::lock_guard<std::mutex> lk(g_defer_mu);
-    jobs.swap(g_defer_jobs);
-    blocks.swap(g_defer_blocks);
+    std::lock_guard<std::mutex> lk(c->mu);
+    jobs.swap(c->rjobs);
+    blocks.swap(c->rblocks);
   }
   for (size_t i0 = 0; i0 < jobs.size(); i0 += REDUCE_MAX_JOBS) {
     ReduceTable t;
@@ -1665,9 +1665,11 @@ int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float*
 }
 
 int modet_conv3d_bwd_weight_defer(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
-                                  size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
+                                  size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
+                                  modet_step_ctx_t* step) {
+  MODET_CHECK_PTR(step);
   if (y_act && !(Cin == 1 && Cout == 4)) return MODET_ERR_UNSUPPORTED;
-  return conv_bwd_weight_impl(x, d_y, y_act, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, true);
+  return conv_bwd_weight_impl(x, d_y, y_act, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, step);
 }
 
 int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias,
@@ -1680,7 +1682,7 @@ int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y
 
 static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
                                 size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
-                                bool defer) {
+                                modet_step_ctx* defer) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (Cout > NTHR) return MODET_ERR_UNSUPPORTED;

@@ -17,6 +17,7 @@
 // staging the halo'd tile; 3-5 workgroups per CU overlap each other's phases).
 // dgrad is the same kernel on flipped + transposed weights.
 #include "common.h"
+#include "step_ctx.h"
 #include <mutex>
 #include <vector>
 
@@ -105,32 +106,21 @@ __global__ void pack_weights_bf16_many_kernel(const PackBTable t) {
   }
 }
 
-struct PackBKey {
-  const float* w; int Cin, Cout, CoutP, CK, nstage, ksteps, mode, npiece;
-  bool operator==(const PackBKey& o) const {
-    return w == o.w && Cin == o.Cin && Cout == o.Cout && CoutP == o.CoutP && CK == o.CK && nstage == o.nstage &&
-           ksteps == o.ksteps && mode == o.mode && npiece == o.npiece;
-  }
-};
-std::mutex g_packb_mu;
-bool g_packb_recording = false, g_packb_active = false;
-std::vector<PackBKey> g_packb_jobs;
-std::vector<size_t> g_packb_off;                    // ushort offset of each job inside the bf16 part of the arena
-unsigned short* g_packb_arena = nullptr;
 inline size_t packb_elems(const PackBKey& k) {
   return ((size_t)k.nstage * k.ksteps * k.CoutP * 32 * k.npiece + 127) / 128 * 128;
 }
-const unsigned short* prepacked_bf16_or_record(const PackBKey& k) {
-  std::lock_guard<std::mutex> lk(g_packb_mu);
-  if (g_packb_active) {
-    for (size_t i = 0; i < g_packb_jobs.size(); ++i)
-      if (g_packb_jobs[i] == k) return g_packb_arena + g_packb_off[i];
+const unsigned short* prepacked_bf16_or_record(modet_step_ctx* c, const PackBKey& k) {
+  if (!c) return nullptr;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->active) {
+    for (size_t i = 0; i < c->bjobs.size(); ++i)
+      if (c->bjobs[i] == k) return c->barena + c->boff[i];
     return nullptr;
   }
-  if (g_packb_recording) {
+  if (c->recording) {
     bool seen = false;
-    for (const PackBKey& j : g_packb_jobs) seen = seen || j == k;
-    if (!seen) g_packb_jobs.push_back(k);
+    for (const PackBKey& j : c->bjobs) seen = seen || j == k;
+    if (!seen) c->bjobs.push_back(k);
   }
   return nullptr;
 }
@@ -651,11 +641,6 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
 // Deferred form (modet_conv3d_bf16_bwd_weight_defer + modet_conv3d_wgrad_defer_flush): both stages of every queued
 // weight gradient in two launches instead of two per layer; job tables by value in the kernel arguments.
 constexpr int BRED_MAX_JOBS = 24;
-struct BRedJob {
-  const float* part; float* red; float* dw; float* dbias;
-  int64_t row_fl;
-  int gx, Cin, Cout, cib, u, ntb, gy, n_coblk;
-};
 struct BRedTable { BRedJob job[BRED_MAX_JOBS]; int first[BRED_MAX_JOBS + 1]; int n; };
 __global__ __launch_bounds__(1024) void wgrad_bf16_colsum_many_kernel(const BRedTable t) {
   __shared__ double sm[16][64];
@@ -670,8 +655,6 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_many_kernel(const BRedT
   const BRedJob& J = t.job[j];
   wgrad_bf16_reduce_body(J.red, J.dw, J.dbias, J.Cin, J.Cout, J.cib, J.u, J.ntb, 1, J.gy, J.n_coblk, blockIdx.x - t.first[j]);
 }
-std::mutex g_bdefer_mu;
-std::vector<BRedJob> g_bdefer_jobs;
 
 struct WgBf16Plan { int cib, u, ntb, tz, ty, n_chunk, n_coblk, gy, gx, ntiles, tiles_x, tiles_y, tiles_z, red_fl; };
 inline WgBf16Plan plan_wgrad_bf16(int B, int D, int H, int W, int Cin, int Cout) {
@@ -718,13 +701,13 @@ inline size_t bf16_wpk_elems(int Cin, int Cout) {
 }
 
 template <bool IN_BF16, bool OUT_BF16, bool STATS>
-int launch_bf16(const void* x, const float* w, const float* bias, void* y, void* ws, float* stats, int B, int D, int H, int W,
-                int Cin, int Cout, int mode, hipStream_t s) {
+int launch_bf16(modet_step_ctx* step, const void* x, const float* w, const float* bias, void* y, void* ws, float* stats, int B,
+                int D, int H, int W, int Cin, int Cout, int mode, hipStream_t s) {
   const int64_t V = (int64_t)D * H * W;
   const Bf16Plan p = plan_bf16(V, Cin, Cout);
   unsigned short* wpk = (unsigned short*)ws;
   const int total = p.nstage * p.ksteps * p.coutp * 32;
-  if (const unsigned short* pre = prepacked_bf16_or_record(PackBKey{w, Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 1}))
+  if (const unsigned short* pre = prepacked_bf16_or_record(step, PackBKey{w, Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 1, 0}))
     wpk = const_cast<unsigned short*>(pre);
   else
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w, wpk,
@@ -775,13 +758,13 @@ inline Bf16Plan plan_split(int64_t V, int Cin, int Cout) {
 }
 
 template <bool STATS>
-int launch_split(const float* x, const float* w, const float* bias, float* y, void* ws, float* stats, int B, int D, int H, int W,
-                 int Cin, int Cout, int mode, hipStream_t s) {
+int launch_split(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats, int B,
+                 int D, int H, int W, int Cin, int Cout, int mode, hipStream_t s) {
   const int64_t V = (int64_t)D * H * W;
   const Bf16Plan p = plan_split(V, Cin, Cout);
   unsigned short* wpk = (unsigned short*)ws;
   const int total = p.nstage * p.ksteps * p.coutp * 32;
-  if (const unsigned short* pre = prepacked_bf16_or_record(PackBKey{w, Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 3}))
+  if (const unsigned short* pre = prepacked_bf16_or_record(step, PackBKey{w, Cin, Cout, p.coutp, p.ck, p.nstage, p.ksteps, mode, 3, 0}))
     wpk = const_cast<unsigned short*>(pre);
   else
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w, wpk,
@@ -827,18 +810,18 @@ size_t modetx_split_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   const size_t tiles = (size_t)cdiv(W, TX) * cdiv(H, p.ty) * cdiv(D, p.tz);
   return ((size_t)B * Cout + (size_t)B * tiles * Cout * 2) * sizeof(float);
 }
-int modetx_split_conv(const float* x, const float* w, const float* bias, float* y, void* ws, float* stats, int B, int D, int H, int W,
-                      int Cin, int Cout, int mode, hipStream_t s) {
-  return stats ? launch_split<true>(x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, mode, s)
-               : launch_split<false>(x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, mode, s);
+int modetx_split_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
+                      int B, int D, int H, int W, int Cin, int Cout, int mode, hipStream_t s) {
+  return stats ? launch_split<true>(step, x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, mode, s)
+               : launch_split<false>(step, x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, mode, s);
 }
 
 // ---- bf16 side of modet_conv3d_wgrad_defer_flush (conv3d.hip calls it)
-void modetx_bf16_defer_flush(hipStream_t stream) {
+void modetx_bf16_defer_flush(modet_step_ctx* c, hipStream_t stream) {
   std::vector<BRedJob> jobs;
   {
-    std::lock_guard<std::mutex> lk(g_bdefer_mu);
-    jobs.swap(g_bdefer_jobs);
+    std::lock_guard<std::mutex> lk(c->mu);
+    jobs.swap(c->brjobs);
   }
   for (size_t i0 = 0; i0 < jobs.size(); i0 += BRED_MAX_JOBS) {
     BRedTable t;
@@ -855,33 +838,25 @@ void modetx_bf16_defer_flush(hipStream_t stream) {
   }
 }
 
-// ---- bf16 side of modet_conv3d_prepack_* (conv3d.hip owns the entry points; the bf16 jobs follow the fp32 jobs in the arena)
-void modetx_bf16_prepack_record(int on) {
-  std::lock_guard<std::mutex> lk(g_packb_mu);
-  if (on) { g_packb_jobs.clear(); g_packb_off.clear(); g_packb_active = false; }
-  g_packb_recording = on != 0;
-}
-size_t modetx_bf16_prepack_bytes() {
-  std::lock_guard<std::mutex> lk(g_packb_mu);
+// ---- 16-bit side of modet_conv3d_prepack_* (conv3d.hip owns the entry points; these jobs follow the fp32 jobs in the arena)
+size_t modetx_bf16_prepack_bytes(modet_step_ctx* c) {
+  std::lock_guard<std::mutex> lk(c->mu);
   size_t n = 0;
-  for (const PackBKey& k : g_packb_jobs) n += packb_elems(k);
+  for (const PackBKey& k : c->bjobs) n += packb_elems(k);
   return n * sizeof(unsigned short);
 }
-int modetx_bf16_prepack_count() {
-  std::lock_guard<std::mutex> lk(g_packb_mu);
-  return (int)g_packb_jobs.size();
-}
-void modetx_bf16_prepack_begin(void* arena, hipStream_t stream) {
+void modetx_bf16_prepack_begin(modet_step_ctx* c, void* arena, hipStream_t stream) {
   std::vector<PackBKey> jobs;
+  std::vector<size_t> off;
   {
-    std::lock_guard<std::mutex> lk(g_packb_mu);
-    if (g_packb_jobs.empty()) { g_packb_active = false; return; }
-    g_packb_off.assign(g_packb_jobs.size(), 0);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->bjobs.empty()) return;
+    c->boff.assign(c->bjobs.size(), 0);
     size_t n = 0;
-    for (size_t i = 0; i < g_packb_jobs.size(); ++i) { g_packb_off[i] = n; n += packb_elems(g_packb_jobs[i]); }
-    g_packb_arena = (unsigned short*)arena;
-    g_packb_active = true;
-    jobs = g_packb_jobs;
+    for (size_t i = 0; i < c->bjobs.size(); ++i) { c->boff[i] = n; n += packb_elems(c->bjobs[i]); }
+    c->barena = (unsigned short*)arena;
+    jobs = c->bjobs;
+    off = c->boff;
   }
   for (size_t i0 = 0; i0 < jobs.size(); i0 += PACKB_MAX_JOBS) {
     PackBTable t;
@@ -889,17 +864,13 @@ void modetx_bf16_prepack_begin(void* arena, hipStream_t stream) {
     int most = 1;
     for (int i = 0; i < n; ++i) {
       const PackBKey& k = jobs[i0 + i];
-      t.job[i] = PackBJob{k.w, g_packb_arena + g_packb_off[i0 + i], k.Cin, k.Cout, k.CoutP, k.CK, k.nstage, k.ksteps, k.mode, k.npiece};
+      t.job[i] = PackBJob{k.w, (unsigned short*)arena + off[i0 + i], k.Cin, k.Cout, k.CoutP, k.CK, k.nstage, k.ksteps, k.mode, k.npiece};
       const int blocks = cdiv(k.nstage * k.ksteps * k.CoutP * 32, 256);
       most = blocks > most ? blocks : most;
     }
     t.n = n;
     hipLaunchKernelGGL(pack_weights_bf16_many_kernel, dim3(most > 64 ? 64 : most, n), dim3(256), 0, stream, t);
   }
-}
-void modetx_bf16_prepack_end() {
-  std::lock_guard<std::mutex> lk(g_packb_mu);
-  g_packb_active = false;
 }
 
 extern "C" {
@@ -918,7 +889,7 @@ size_t modet_conv3d_bf16_stats_bytes(int B, int D, int H, int W, int Cin, int Co
 
 int modet_conv3d_bf16_fwd(const void* x, int x_bf16, const float* w, const float* bias, void* y, void* ws, size_t ws_bytes,
                           float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                          modet_stream_t stream) {
+                          modet_stream_t stream, modet_step_ctx_t* step) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && B <= 65535);
   if (Cout % 8 != 0 || (x_bf16 ? Cin % 8 != 0 : Cin % 4 != 0)) return MODET_ERR_UNSUPPORTED;
@@ -926,23 +897,23 @@ int modet_conv3d_bf16_fwd(const void* x, int x_bf16, const float* w, const float
   hipStream_t s = (hipStream_t)stream;
   if (stats) {
     if (stats_bytes < modet_conv3d_bf16_stats_bytes(B, D, H, W, Cin, Cout) || stats_bytes == 0) return MODET_ERR_WORKSPACE;
-    return x_bf16 ? launch_bf16<true, true, true>(x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, s)
-                  : launch_bf16<false, true, true>(x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, s);
+    return x_bf16 ? launch_bf16<true, true, true>(step, x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, s)
+                  : launch_bf16<false, true, true>(step, x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, s);
   }
-  return x_bf16 ? launch_bf16<true, true, false>(x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, s)
-                : launch_bf16<false, true, false>(x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, s);
+  return x_bf16 ? launch_bf16<true, true, false>(step, x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, s)
+                : launch_bf16<false, true, false>(step, x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, s);
 }
 
 int modet_conv3d_bf16_bwd_data(const void* d_y, const float* w, void* d_x, int dx_bf16, void* ws, size_t ws_bytes, int B, int D,
-                               int H, int W, int Cin, int Cout, modet_stream_t stream) {
+                               int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step) {
   MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(w); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && B <= 65535);
   if (Cout % 8 != 0 || (dx_bf16 ? Cin % 8 != 0 : Cin % 4 != 0)) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < bf16_wpk_elems(Cout, Cin) * sizeof(unsigned short)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   // a convolution of d_y (Cout channels, bf16) producing Cin channels
-  return dx_bf16 ? launch_bf16<true, true, false>(d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, s)
-                 : launch_bf16<true, false, false>(d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, s);
+  return dx_bf16 ? launch_bf16<true, true, false>(step, d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, s)
+                 : launch_bf16<true, false, false>(step, d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, s);
 }
 
 size_t modet_conv3d_bf16_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
@@ -951,20 +922,23 @@ size_t modet_conv3d_bf16_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin
 }
 
 static int bf16_bwd_weight_impl(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
-                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream, bool defer);
+                                size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
+                                modet_step_ctx* defer);
 
 int modet_conv3d_bf16_bwd_weight(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
                                  size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
-  return bf16_bwd_weight_impl(x, x_bf16, d_y, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, false);
+  return bf16_bwd_weight_impl(x, x_bf16, d_y, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, nullptr);
 }
 int modet_conv3d_bf16_bwd_weight_defer(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
-                                       size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream) {
-  return bf16_bwd_weight_impl(x, x_bf16, d_y, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, true);
+                                       size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
+                                       modet_step_ctx_t* step) {
+  MODET_CHECK_PTR(step);
+  return bf16_bwd_weight_impl(x, x_bf16, d_y, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, step);
 }
 
 static int bf16_bwd_weight_impl(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
                                 size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
-                                bool defer) {
+                                modet_step_ctx* defer) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (Cout % 8 != 0 || (x_bf16 ? Cin % 8 != 0 : Cin % 4 != 0)) return MODET_ERR_UNSUPPORTED;
@@ -994,8 +968,8 @@ static int bf16_bwd_weight_impl(const void* x, int x_bf16, const void* d_y, floa
   const int64_t row_fl = (int64_t)p.gy * p.red_fl;
   float* red = (float*)ws + (size_t)p.gx * row_fl;
   if (defer) {
-    std::lock_guard<std::mutex> lk(g_bdefer_mu);
-    g_bdefer_jobs.push_back(BRedJob{(const float*)ws, red, d_w, d_bias, row_fl, p.gx, Cin, Cout, p.cib, p.u, p.ntb, p.gy, p.n_coblk});
+    std::lock_guard<std::mutex> lk(defer->mu);
+    defer->brjobs.push_back(BRedJob{(const float*)ws, red, d_w, d_bias, row_fl, p.gx, Cin, Cout, p.cib, p.u, p.ntb, p.gy, p.n_coblk});
     return modet_launch_status();
   }
   hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, (const float*)ws, red, p.gx, row_fl);

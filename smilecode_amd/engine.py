@@ -32,6 +32,7 @@ class Trainer:
         self.vmax = torch.zeros_like(self.fp.flat)
         self.step = 0
         self._graph = self._static_in = self._static_out = self._graph_key = None
+        self._steps = {}                    # (shape, device, grad mode) -> ops.StepContext
         self.batch_small_launches = os.environ.get("MODET_STEP_BATCHING", "1") != "0"
         self.lr_last = lr
         self.sim = NCC_vxm()
@@ -61,15 +62,20 @@ class Trainer:
                 loss.backward()
                 self.fp.gather_grads()
             return loss.detach(), sim.detach(), reg.detach()
-        if getattr(self, "_prepack", None) is None:
-            self._prepack = ops.PrepackedConvWeights()
+        # one caller-owned step context per computation this trainer has run (shape, device, grad mode): its recorded
+        # packing jobs and its packed-weights arena stay valid for as long as the trainer lives, so a captured graph of
+        # shape A keeps working however many other shapes run eagerly in between
+        key = (tuple(moving.shape), moving.device, torch.is_grad_enabled())
+        sc = self._steps.get(key)
+        if sc is None:
+            sc = self._steps[key] = ops.StepContext()
         # the parameters are constant from here to the end of backward: pack all conv weights in one launch up front
-        with self._prepack.step((tuple(moving.shape), moving.device, torch.is_grad_enabled())):
+        with sc.prepacked():
             with ops.trace_range("forward+loss"):
                 loss, sim, reg = self.loss(moving, fixed)
             with ops.trace_range("backward"):
                 # the ~20 per-layer partial-tile reductions as one launch, written straight into the flat gradient buffer
-                with ops.deferred_wgrad_reductions(self.fp.grad_destinations()) as scope:
+                with sc.deferred(self.fp.grad_destinations()) as scope:
                     loss.backward()
                 self.fp.gather_grads(scope.written)
         return loss.detach(), sim.detach(), reg.detach()
@@ -88,7 +94,9 @@ class Trainer:
         side = torch.cuda.Stream(device=moving.device)
         side.wait_stream(torch.cuda.current_stream(moving.device))
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):
+            # with step batching the first pass of a shape only RECORDS the packing jobs: a second pass must launch the
+            # batched packing kernels (and read the arena) once before they can be captured
+            for _ in range(max(warmup, 2 if self.batch_small_launches else 1)):
                 self._fwd_bwd(*self._static_in)
         torch.cuda.current_stream(moving.device).wait_stream(side)
         torch.cuda.synchronize(moving.device)
@@ -181,8 +189,8 @@ class Trainer:
         if steps:
             self.step = steps.pop()
         g = sd["param_groups"][0]
-        self.betas, self.eps = tuple(g.get("betas", self.betas)), g.get("eps", self.eps)
-        self.lr_last = g.get("lr", self.lr_last)
+        self.betas, self.eps = tuple(float(v) for v in g.get("betas", self.betas)), float(g.get("eps", self.eps))
+        self.lr_last = float(g.get("lr", self.lr_last))     # the reference stores a numpy.float64 here (train.py:166-168)
 
     @torch.no_grad()
     def infer(self, moving, fixed):

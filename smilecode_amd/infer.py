@@ -30,7 +30,9 @@ def main(argv=None):
     model = ModeT(img_size, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1)
     if args.model_dir:
         files = sorted(os.listdir(args.model_dir), key=_natkey)
-        best = torch.load(os.path.join(args.model_dir, files[args.model_idx]), map_location="cpu")["state_dict"]
+        # weights_only=False: checkpoints written by the reference's train.py carry numpy scalars (see train.py here)
+        best = torch.load(os.path.join(args.model_dir, files[args.model_idx]), map_location="cpu",
+                          weights_only=False)["state_dict"]
         print("Best model: {}".format(files[args.model_idx]))
         model.load_state_dict(best)
     model.cuda().eval()

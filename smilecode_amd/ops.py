@@ -8,6 +8,8 @@ There is no eager / CPU fallback: a missing library or a non-GPU tensor raises.
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 from torch.autograd import Function
 
@@ -149,8 +151,9 @@ class trace_range:
 
 
 # ------------------------------------------------------------------------------------------------ raw calls
-def conv3d_forward(x, w, b, act):
+def conv3d_forward(x, w, b, act, step=None):
     _chk(x, w, b)
+    step = step if step is not None else current_step()
     B, D, H, W, Cin = x.shape
     Cout = w.shape[0]
     if tuple(w.shape) != (Cout, Cin, 3, 3, 3):
@@ -162,7 +165,7 @@ def conv3d_forward(x, w, b, act):
     n = float(B) * D * H * W
     with _Guard(x, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         _lib.check(L.modet_conv3d_fwd(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, B, D, H, W, Cin, Cout, int(act),
-                                      _stream()), "modet_conv3d_fwd")
+                                      _stream(), _h(step)), "modet_conv3d_fwd")
     return y
 
 
@@ -187,10 +190,11 @@ def instnorm_stats(x_raw, stats=None, eps=1e-5):
     return mean, rstd
 
 
-def conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats=True):
+def conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats=True, step=None):
     """conv3d(LeakyReLU((x_raw - mean) * rstd), w, b) with the normalisation applied while the input tile is staged;
     returns (y, stats or None)"""
     _chk(x_raw, w, b)
+    step = step if step is not None else current_step()
     B, D, H, W, Cin = x_raw.shape
     Cout = w.shape[0]
     L = _L()
@@ -202,12 +206,13 @@ def conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats=True):
     n = float(B) * D * H * W
     with _Guard(x_raw, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         _lib.check(L.modet_conv3d_fwd_normin(_p(x_raw), _p(mean), _p(rstd), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb,
-                                             B, D, H, W, Cin, Cout, _stream()), "modet_conv3d_fwd_normin")
+                                             B, D, H, W, Cin, Cout, _stream(), _h(step)), "modet_conv3d_fwd_normin")
     return y, stats
 
 
-def conv3d_backward_data(dy, w, Cin):
+def conv3d_backward_data(dy, w, Cin, step=None):
     _chk(dy, w)
+    step = step if step is not None else current_step()
     B, D, H, W, Cout = dy.shape
     dx = torch.empty((B, D, H, W, Cin), dtype=torch.float32, device=dy.device)
     L = _L()
@@ -215,89 +220,121 @@ def conv3d_backward_data(dy, w, Cin):
     ws = _ws(nb, dy)
     n = float(B) * D * H * W
     with _Guard(dy, f"conv_dgrad[{Cout}->{Cin}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
-        _lib.check(L.modet_conv3d_bwd_data(_p(dy), _p(w), _p(dx), _p(ws), nb, B, D, H, W, Cin, Cout, _stream()),
+        _lib.check(L.modet_conv3d_bwd_data(_p(dy), _p(w), _p(dx), _p(ws), nb, B, D, H, W, Cin, Cout, _stream(), _h(step)),
                    "modet_conv3d_bwd_data")
     return dx
 
 
-class PrepackedConvWeights:
-    """The per-launch weight packing of the fp32 convs hoisted into one launch per step (include/modet_hip.h,
-    modet_conv3d_prepack_*).  ``with pp.step(): forward; backward`` -- the first use (and any use after another owner
-    recorded) runs the pass normally while the library records its packing jobs; later passes start with ONE launch
-    that packs every recorded weight tensor and the conv launches skip their own.  The owner guarantees that the
-    weights are not modified inside the scope and live at the same addresses from one pass to the next (FlatParams
-    views do).  The job table is process-wide: ``_owner`` tells whose recording it currently holds."""
-    _owner = None
+class StepContext:
+    """Caller-owned state of the step-level launch batching (include/modet_hip.h, modet_step_ctx_t): the recorded
+    weight-packing jobs of ONE forward+backward computation (one input shape / grad mode) and the weight-gradient
+    reductions its backward pass queues.  Nothing is process-wide: every Trainer keeps its own contexts (one per shape it
+    has seen), so two trainers in one process -- two threads, two devices, a training and an evaluation model -- never see
+    each other's jobs.
+
+      with sc.prepacked():                       # first use records the packing jobs while running normally; later uses
+          forward                                # start with ONE launch that packs every recorded weight tensor and the
+          with sc.deferred(dst) as scope:        # conv launches skip theirs
+              backward                           # ~20 partial-tile reductions -> one launch at scope exit, written to dst
+
+    The scopes bind the context to the calling thread; every conv op picks it up in its forward and hands it to its own
+    backward (which runs on the autograd thread), so no op ever consults a global.  The owner guarantees that the weights
+    are not modified inside ``prepacked()`` and live at the same addresses from one pass to the next (FlatParams views
+    do).  The packed-weights arena lives as long as the context -- a captured hipGraph that bakes its address in stays
+    valid however many other shapes the trainer runs eagerly in between."""
 
     def __init__(self):
-        self.arena = None
-        self.key = None
-
-    class _Scope:
-        def __init__(self, pp, key):
-            self.pp, self.key = pp, key
-
-        def __enter__(self):
-            L, pp = _L(), self.pp
-            self.recording = not (PrepackedConvWeights._owner is pp and pp.key == self.key and pp.arena is not None)
-            if self.recording:
-                L.modet_conv3d_prepack_record(1)
-                PrepackedConvWeights._owner, pp.key, pp.arena = pp, self.key, None
-            else:
-                _lib.check(L.modet_conv3d_prepack_begin(_p(pp.arena), pp.arena.numel() * 4, _stream()),
-                           "modet_conv3d_prepack_begin")
-            return self
-
-        def __exit__(self, *exc):
-            L, pp = _L(), self.pp
-            if self.recording:
-                L.modet_conv3d_prepack_record(0)
-                if exc[0] is None:
-                    dev = torch.device("cuda", torch.cuda.current_device())
-                    pp.arena = torch.empty(L.modet_conv3d_prepack_arena_bytes() // 4 + 64, dtype=torch.float32, device=dev)
-                else:
-                    PrepackedConvWeights._owner = None
-            else:
-                L.modet_conv3d_prepack_end()
-            return False
-
-    def step(self, key=None):
-        return PrepackedConvWeights._Scope(self, key)
-
-
-class deferred_wgrad_reductions:
-    """``with ops.deferred_wgrad_reductions(dst) as scope: loss.backward()`` -- the ~20 tiny per-layer reductions of the
-    weight-gradient partial tiles run as ONE launch when the scope closes (include/modet_hip.h,
-    modet_conv3d_bwd_weight_defer / modet_conv3d_wgrad_defer_flush).
-
-    ``dst`` maps ``parameter.data_ptr()`` to the tensor that parameter's gradient must be written to (FlatParams: a view
-    of the flat gradient buffer).  A conv whose weight (and bias) have a destination writes there -- after the flush --
-    and returns no gradient to autograd, so nothing depends on how autograd hands tensors to ``.grad``; the pointers
-    written are in ``scope.written``.  A conv without a destination, or a second use of the same weight inside one scope,
-    takes the immediate path.  Scopes do not nest."""
-    _active = None
-
-    def __init__(self, dst):
-        self.dst = dst
+        import ctypes
+        h = ctypes.c_void_p()
+        _lib.check(_L().modet_step_ctx_create(ctypes.byref(h)), "modet_step_ctx_create")
+        self.handle = h
+        self.arena = None            # packed weights of every recorded conv launch (fp32 jobs, then the 16-bit ones)
+        self.recorded = False
+        self.dst = None              # parameter.data_ptr() -> gradient destination, while a deferred() scope is open
         self.written = set()
         self._keep = []
 
-    def __enter__(self):
-        if deferred_wgrad_reductions._active is not None:
-            raise RuntimeError("deferred_wgrad_reductions scopes do not nest")
-        deferred_wgrad_reductions._active = self
-        return self
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h is not None and _lib._lib is not None:
+            _lib._lib.modet_step_ctx_destroy(h)
 
-    def __exit__(self, *exc):
-        deferred_wgrad_reductions._active = None
-        rc = _L().modet_conv3d_wgrad_defer_flush(_stream())      # always empties the queue, also on an exception
-        self._keep = []
-        if exc[0] is None:
-            _lib.check(rc, "modet_conv3d_wgrad_defer_flush")
-        return False
+    class _Bind:
+        def __init__(self, sc):
+            self.sc = sc
+
+        def __enter__(self):
+            self.prev = getattr(_TLS, "step", None)
+            _TLS.step = self.sc
+            return self
+
+        def __exit__(self, *exc):
+            _TLS.step = self.prev
+            return False
+
+    class _Prepacked(_Bind):
+        def __enter__(self):
+            sc, L = self.sc, _L()
+            self.recording = not sc.recorded
+            if self.recording:
+                L.modet_conv3d_prepack_record(sc.handle, 1)
+            else:
+                _lib.check(L.modet_conv3d_prepack_begin(sc.handle, _p(sc.arena), sc.arena.numel() * 4, _stream()),
+                           "modet_conv3d_prepack_begin")
+            return super().__enter__()
+
+        def __exit__(self, *exc):
+            sc, L = self.sc, _L()
+            super().__exit__(*exc)
+            if self.recording:
+                L.modet_conv3d_prepack_record(sc.handle, 0)
+                if exc[0] is None:
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                    sc.arena = torch.empty(L.modet_conv3d_prepack_arena_bytes(sc.handle) // 4 + 64, dtype=torch.float32,
+                                           device=dev)
+                    sc.recorded = True
+            else:
+                L.modet_conv3d_prepack_end(sc.handle)
+            return False
+
+    class _Deferred(_Bind):
+        def __init__(self, sc, dst):
+            super().__init__(sc)
+            self.dst = dst
+            self.written = set()
+
+        def __enter__(self):
+            sc = self.sc
+            if sc.dst is not None:
+                raise RuntimeError("StepContext.deferred scopes do not nest")
+            sc.dst, sc.written, sc._keep = self.dst, self.written, []
+            return super().__enter__()
+
+        def __exit__(self, *exc):
+            sc = self.sc
+            super().__exit__(*exc)
+            sc.dst = None
+            rc = _L().modet_conv3d_wgrad_defer_flush(sc.handle, _stream())    # always empties the queue, also on an exception
+            sc._keep = []
+            if exc[0] is None:
+                _lib.check(rc, "modet_conv3d_wgrad_defer_flush")
+            return False
+
+    def prepacked(self):
+        return StepContext._Prepacked(self)
+
+    def deferred(self, dst):
+        """``dst`` maps ``parameter.data_ptr()`` to the tensor that parameter's gradient must be written to (FlatParams: a
+        view of the flat gradient buffer).  A conv whose weight (and bias) have a destination writes there -- after the
+        flush -- and returns no gradient to autograd, so nothing depends on how autograd hands tensors to ``.grad``; the
+        pointers written are in ``scope.written``.  A conv without a destination, or a second use of the same weight inside
+        one scope, takes the immediate path."""
+        return StepContext._Deferred(self, dst)
 
     def destinations(self, w, b, want_bias):
         """(d_w, d_bias) destinations for this call, or None -> immediate path"""
+        if self.dst is None:
+            return None
         dw = self.dst.get(w.data_ptr()) if w is not None else None
         if dw is None or dw.shape != w.shape or w.data_ptr() in self.written:
             return None
@@ -309,10 +346,23 @@ class deferred_wgrad_reductions:
         return dw, db
 
 
-def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None):
+_TLS = threading.local()
+
+
+def current_step():
+    """the StepContext bound to this thread by an open ``prepacked()`` / ``deferred()`` scope, or None"""
+    return getattr(_TLS, "step", None)
+
+
+def _h(step):
+    return None if step is None else step.handle
+
+
+def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=None):
     """d_w, d_bias; with y_act (ConvBlock 1 -> 4 only) dy is the gradient w.r.t. LeakyReLU(conv) and the activation's
-    derivative is applied while loading it.  Inside a ``deferred_wgrad_reductions`` scope that knows destinations for the
-    parameters ``w`` / ``b``, the gradients go straight there at the scope's flush and (None, None) is returned."""
+    derivative is applied while loading it.  With a StepContext (given, or bound to this thread) whose ``deferred()`` scope
+    knows destinations for the parameters ``w`` / ``b``, the gradients go straight there at the scope's flush and
+    (None, None) is returned."""
     _chk(x, dy)
     B, D, H, W, Cin = x.shape
     Cout = dy.shape[-1]
@@ -320,13 +370,13 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None):
     nb = L.modet_conv3d_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)
     ws = _ws(nb, x)
     n = float(B) * D * H * W
-    scope = deferred_wgrad_reductions._active
+    scope = step if step is not None else current_step()
     dst = scope.destinations(w, b, want_bias) if scope is not None else None
     if dst is not None:
         dw, db = dst
         with _Guard(x, f"conv_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
             _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
-                                                       Cout, _stream()), "modet_conv3d_bwd_weight_defer")
+                                                       Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
         scope._keep.append(ws)                                # the partial tiles must survive until the flush
         scope.written.add(w.data_ptr())
         if db is not None:
@@ -348,7 +398,8 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None):
 class _Conv3d(Function):
     @staticmethod
     def forward(ctx, x, w, b, act):
-        y = conv3d_forward(x, w, b, act)
+        ctx.step = current_step()
+        y = conv3d_forward(x, w, b, act, ctx.step)
         ctx.act = bool(act)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act else None, b)
@@ -360,15 +411,15 @@ class _Conv3d(Function):
         dy = dy.contiguous()
         if ctx.act and not ctx.needs_input_grad[0] and x.shape[-1] == 1 and w.shape[0] == 4:
             # first encoder block: no d_x, and the weight-gradient kernel folds LeakyReLU' into its d_y load
-            dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, y_act=y, w=w, b=b)
+            dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, y_act=y, w=w, b=b, step=ctx.step)
             return None, dw, db, None
         if ctx.act:
             g = torch.empty_like(dy)
             with _Guard(dy, "lrelu_bwd", dy.numel(), 12.0 * dy.numel()):
                 _lib.check(_L().modet_lrelu_bwd(_p(dy), _p(y), _p(g), dy.numel(), _stream()), "modet_lrelu_bwd")
             dy = g
-        dx = conv3d_backward_data(dy, w, x.shape[-1]) if ctx.needs_input_grad[0] else None
-        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b)
+        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step) if ctx.needs_input_grad[0] else None
+        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step)
         return dx, dw, db, None
 
 
@@ -378,6 +429,7 @@ class _Conv3dStats(Function):
     @staticmethod
     def forward(ctx, x, w, b):
         _chk(x, w, b)
+        ctx.step = current_step()
         B, D, H, W, Cin = x.shape
         Cout = w.shape[0]
         L = _L()
@@ -389,7 +441,7 @@ class _Conv3dStats(Function):
         n = float(B) * D * H * W
         with _Guard(x, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
             _lib.check(L.modet_conv3d_fwd_stats(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
-                                                Cout, _stream()), "modet_conv3d_fwd_stats")
+                                                Cout, _stream(), _h(ctx.step)), "modet_conv3d_fwd_stats")
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(stats)
@@ -399,8 +451,8 @@ class _Conv3dStats(Function):
     def backward(ctx, dy, _dstats):
         x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = conv3d_backward_data(dy, w, x.shape[-1]) if ctx.needs_input_grad[0] else None
-        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b)
+        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step) if ctx.needs_input_grad[0] else None
+        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step)
         return dx, dw, db
 
 
@@ -1078,10 +1130,11 @@ def cast_bf16(x, to_bf16):
     return y
 
 
-def conv3d_bf16_forward(x, w, b, want_stats=True):
+def conv3d_bf16_forward(x, w, b, want_stats=True, step=None):
     """y (bf16) = conv3d(x (fp32 | bf16), w) + b on the bf16 matrix pipe, fp32 accumulate; (y, stats | None)"""
     _chk16(x)
     _chk(w, b)
+    step = step if step is not None else current_step()
     B, D, H, W, Cin = x.shape
     Cout = w.shape[0]
     if tuple(w.shape) != (Cout, Cin, 3, 3, 3):
@@ -1095,13 +1148,14 @@ def conv3d_bf16_forward(x, w, b, want_stats=True):
     n = float(B) * D * H * W
     with _Guard(x, f"conv_bf16_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
         _lib.check(L.modet_conv3d_bf16_fwd(_p(x), _isbf(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin, Cout,
-                                           _stream()), "modet_conv3d_bf16_fwd")
+                                           _stream(), _h(step)), "modet_conv3d_bf16_fwd")
     return y, stats
 
 
-def conv3d_bf16_backward_data(dy, w, Cin, dx_bf16):
+def conv3d_bf16_backward_data(dy, w, Cin, dx_bf16, step=None):
     _chk16(dy)
     _chk(w)
+    step = step if step is not None else current_step()
     B, D, H, W, Cout = dy.shape
     dx = torch.empty((B, D, H, W, Cin), dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=dy.device)
     L = _L()
@@ -1109,13 +1163,13 @@ def conv3d_bf16_backward_data(dy, w, Cin, dx_bf16):
     ws = _ws(nb, dy)
     n = float(B) * D * H * W
     with _Guard(dy, f"conv_bf16_dgrad[{Cout}->{Cin}]", 54.0 * Cin * Cout * n, n * (2.0 * Cout + (2.0 if dx_bf16 else 4.0) * Cin)):
-        _lib.check(L.modet_conv3d_bf16_bwd_data(_p(dy), _p(w), _p(dx), int(dx_bf16), _p(ws), nb, B, D, H, W, Cin, Cout, _stream()),
-                   "modet_conv3d_bf16_bwd_data")
+        _lib.check(L.modet_conv3d_bf16_bwd_data(_p(dy), _p(w), _p(dx), int(dx_bf16), _p(ws), nb, B, D, H, W, Cin, Cout, _stream(),
+                                                _h(step)), "modet_conv3d_bf16_bwd_data")
     return dx
 
 
-def conv3d_bf16_backward_weight(x, dy, w=None, b=None):
-    """d_w, d_bias (fp32) from x (fp32 | bf16) and d_y (bf16); inside a ``deferred_wgrad_reductions`` scope with
+def conv3d_bf16_backward_weight(x, dy, w=None, b=None, step=None):
+    """d_w, d_bias (fp32) from x (fp32 | bf16) and d_y (bf16); with a StepContext whose ``deferred()`` scope has
     destinations for the parameters ``w`` / ``b`` the gradients go there at the flush and (None, None) is returned"""
     _chk16(x, dy)
     L = _L()
@@ -1125,13 +1179,14 @@ def conv3d_bf16_backward_weight(x, dy, w=None, b=None):
         nb = L.modet_conv3d_bf16_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)
         ws = _ws(nb, x)
         n = float(B) * D * H * W
-        scope = deferred_wgrad_reductions._active
+        scope = step if step is not None else current_step()
         dst = scope.destinations(w, b, True) if (scope is not None and hasattr(L, "modet_conv3d_bf16_bwd_weight_defer")) else None
         if dst is not None:
             dw, db = dst
             with _Guard(x, f"conv_bf16_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
                 _lib.check(L.modet_conv3d_bf16_bwd_weight_defer(_p(x), _isbf(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W,
-                                                                Cin, Cout, _stream()), "modet_conv3d_bf16_bwd_weight_defer")
+                                                                Cin, Cout, _stream(), _h(scope)),
+                           "modet_conv3d_bf16_bwd_weight_defer")
             scope._keep.append(ws)
             scope.written.add(w.data_ptr())
             scope.written.add(b.data_ptr())
@@ -1151,7 +1206,8 @@ class _Conv3dBF16(Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        y, stats = conv3d_bf16_forward(x, w, b, True)
+        ctx.step = current_step()
+        y, stats = conv3d_bf16_forward(x, w, b, True, ctx.step)
         ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(stats)
         return y, stats
@@ -1160,8 +1216,8 @@ class _Conv3dBF16(Function):
     def backward(ctx, dy, _dstats):
         x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = conv3d_bf16_backward_data(dy, w, x.shape[-1], x.dtype == torch.bfloat16) if ctx.needs_input_grad[0] else None
-        dw, db = conv3d_bf16_backward_weight(x, dy, w, b)
+        dx = conv3d_bf16_backward_data(dy, w, x.shape[-1], x.dtype == torch.bfloat16, ctx.step) if ctx.needs_input_grad[0] else None
+        dw, db = conv3d_bf16_backward_weight(x, dy, w, b, ctx.step)
         return dx, dw, db
 
 

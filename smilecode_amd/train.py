@@ -108,7 +108,9 @@ def main(argv=None):
     resume = None
     if args.cont_training:
         ck = latest_checkpoint(exp_dir)
-        resume = torch.load(ck, map_location="cpu")
+        # a checkpoint the reference wrote holds numpy scalars (param_groups[0]['lr'] = round(INIT_LR * np.power(..), 8),
+        # train.py:166-168), which torch >= 2.6's default weights_only=True unpickler rejects: these are the user's own files
+        resume = torch.load(ck, map_location="cpu", weights_only=False)
         model.load_state_dict(resume["state_dict"])
         if rank == 0:
             print(ck)
@@ -118,7 +120,8 @@ def main(argv=None):
         # the reference saves optimizer.state_dict() but never loads it back (train.py:80-85): a resumed run restarts
         # Adam's moments from zero.  We restore them, so save -> resume -> next step is identical to never stopping.
         trainer.load_state_dict(resume["optimizer"])
-        best_dsc = resume.get("best_dsc", 0)
+    if resume is not None:
+        best_dsc = float(resume.get("best_dsc", 0))         # with or without the optimizer state
 
     if args.synthetic:
         train_set = data.SyntheticPairs(img_size, args.synthetic, 24)
@@ -143,6 +146,7 @@ def main(argv=None):
             else:
                 yield tuple(t[None].cuda() for t in val_set[i])
 
+    graph_failed = False
     for epoch in range(args.epoch_start, args.max_epoch):
         if rank == 0:
             print("Training Starts")
@@ -153,8 +157,19 @@ def main(argv=None):
         n_iter = len(mine) if not args.max_iters else min(len(mine), args.max_iters)
         for idx in range(1, n_iter + 1):
             x, y = train_pair(mine[idx - 1])
-            if not args.no_graph and trainer._graph is None:
-                trainer.capture(x, y)               # forward+backward as one hipGraph from here on (engine.Trainer.capture)
+            if not args.no_graph and trainer._graph is None and not graph_failed:
+                try:
+                    trainer.capture(x, y)           # forward+backward as one hipGraph from here on (engine.Trainer.capture)
+                except RuntimeError as e:           # keep training eagerly (every rank takes the same branch below)
+                    trainer.release_graph()
+                    graph_failed = True
+                    print(f"rank {rank}: hipGraph capture failed, continuing eagerly: {e}", file=sys.stderr)
+                if world > 1:                       # all ranks replay or none does: the eager all-reduce pairs up either way,
+                    ok = torch.tensor([0 if graph_failed else 1], device="cuda")          # but keep the modes aligned
+                    torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+                    if int(ok.item()) == 0 and not graph_failed:
+                        trainer.release_graph()
+                        graph_failed = True
             loss, sim, reg = trainer.train_step(x, y, epoch=epoch)      # lr = poly_lr(epoch) inside (train.py:117)
             if rank == 0:
                 lv = loss.item()                                        # one host sync per iteration, as train.py:130

@@ -381,6 +381,38 @@ def test_trainer_state_dict_is_torch_adam_compatible():
         tr2.load_state_dict({"step": 1, "lr": 1e-4})                       # round 1's stub format is rejected loudly
 
 
+def test_resume_from_a_checkpoint_the_reference_wrote(tmp_path):
+    """the reference's train.py stores ``param_groups[0]['lr'] = round(INIT_LR * np.power(..), 8)`` -- a
+    numpy.float64 (train.py:117,:166-168) -- in the optimizer state it saves (train.py:158-163).  torch >= 2.6 refuses to
+    unpickle that with its default weights_only=True; smilecode_amd.train / infer load with weights_only=False and the
+    Trainer casts the scalars."""
+    import inspect
+    from smilecode_amd import infer, train
+    from smilecode_amd.engine import Trainer
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0, amsgrad=True)
+    for p in net.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()
+    lr = round(1e-4 * np.power(1 - 3 / 30, 0.9), 8)                       # adjust_learning_rate, train.py:166-168
+    assert type(lr).__module__ == "numpy"
+    for g in opt.param_groups:
+        g["lr"] = lr
+    path = str(tmp_path / "dsc0.612.pth.tar")
+    torch.save({"epoch": 4, "state_dict": net.state_dict(), "best_dsc": np.float64(0.612), "optimizer": opt.state_dict()}, path)
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu")                              # the failure the advisor reproduced
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    tr = Trainer(torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3)))
+    tr.load_state_dict(ck["optimizer"])
+    assert tr.step == 1 and type(tr.lr_last) is float and abs(tr.lr_last - float(lr)) < 1e-15
+    assert type(tr.state_dict()["param_groups"][0]["lr"]) is float        # what we save loads under weights_only=True
+    for mod in (train, infer):
+        src = inspect.getsource(mod.main)
+        assert "torch.load(" in src and src.count("weights_only=False") >= src.count("torch.load(")
+
+
 def test_flat_params_gather_with_directly_written_gradients():
     """FlatParams.gather_grads(written): parameters whose gradient was written straight into the flat buffer (the
     deferred weight-gradient reductions) are left alone, a further autograd contribution to such a parameter is added

@@ -72,8 +72,8 @@ def test_conv_bf16_fwd_dgrad_wgrad_vs_exact_on_rounded_operands(B, D, H, W, Cin,
 
 def test_bf16_step_batching_is_bit_identical():
     """The step-level batching scopes on the bf16 convs: every layer's weight packing in one launch
-    (ops.PrepackedConvWeights, bf16 jobs behind the fp32 ones in the arena) and every weight-gradient reduction in two
-    (ops.deferred_wgrad_reductions) must give the bits of the per-layer launches, also after the weights moved."""
+    (ops.StepContext.prepacked(), bf16 jobs behind the fp32 ones in the arena) and every weight-gradient reduction in two
+    (StepContext.deferred()) must give the bits of the per-layer launches, also after the weights moved."""
     from smilecode_amd import ops
     gen = torch.Generator().manual_seed(21)
     layers, dst = [], {}
@@ -98,11 +98,11 @@ def test_bf16_step_batching_is_bit_identical():
         return out
 
     ref = run()
-    pp = ops.PrepackedConvWeights()
-    with pp.step("k"):
+    pp = ops.StepContext()
+    with pp.prepacked():
         run()                                                  # records
-    with pp.step("k"):
-        with ops.deferred_wgrad_reductions(dst) as scope:
+    with pp.prepacked():
+        with pp.deferred(dst) as scope:
             got = run()
     for (ry, rs, rdx, (rw, rb)), (gy, gs, gdx, g), (x, w, b, dy, inbf) in zip(ref, got, layers):
         live = rs.numel() - x.shape[0] * 64 * 2 * w.shape[0]       # the buffer ends in a 64-row scratch tail per sample
@@ -112,7 +112,7 @@ def test_bf16_step_batching_is_bit_identical():
     for _, w, _, _, _ in layers:
         w.mul_(1.25)
     ref2 = run()
-    with pp.step("k"):
+    with pp.prepacked():
         got2 = run()
     for a, c in zip(ref2, got2):
         assert torch.equal(a[0], c[0]) and torch.equal(a[2], c[2]) and torch.equal(a[3][0], c[3][0])

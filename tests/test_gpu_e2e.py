@@ -3,7 +3,6 @@ the reference's golden vectors (fp64) and the CPU oracle.  Tolerances follow SUR
 the reference's OWN fp32 run deviates from its fp64 run by 4e-5..9e-5 voxels on these fixtures
 (tests/golden/REPORT.txt), we accept max|flow err| <= 2e-3 voxels, y_moved <= 5e-5... (measured values
 are written to gpurun_out/parity_report.json)."""
-import json
 import os
 
 import numpy as np
@@ -11,17 +10,10 @@ import pytest
 import torch
 
 from tests.util import assert_close, gold, np64
+from tests.util import note as _note
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = {}
-
-
-def _note(key, val):
-    REPORT[key] = float(val)
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
-        json.dump(REPORT, f, indent=1, sort_keys=True)
 
 
 def _model(shape, scale, cls="ModeT"):
@@ -414,6 +406,87 @@ def test_hip_graph_step_equals_eager_step():
     torch.cuda.synchronize()
     _note("graph.host_enqueue_ms_per_step", host)
     assert host < 1.0, f"graph replay should cost the host well under 1 ms per step, took {host:.2f}"
+
+
+def test_graph_survives_an_eager_step_of_another_shape():
+    """the captured graph bakes in the address of the packed-weights arena.  An eager step of ANOTHER shape on
+    the same Trainer (train_step's key-mismatch fallback) must leave that arena alone: replaying the first shape
+    afterwards still gives the eager gradients (each shape has its own ops.StepContext, alive as long as the Trainer)."""
+    from smilecode_amd.engine import Trainer
+    sa, sb = (32, 48, 32), (32, 32, 48)
+    mov, fix = _pair(sa)
+    mb, fb = _pair(sb)
+    ref = Trainer(_model(sa, 1.0))
+    t = Trainer(_model(sa, 1.0)).capture(mov, fix)
+    arena = [sc.arena.data_ptr() for sc in t._steps.values()]
+    assert len(arena) == 1
+    l_ref = ref._fwd_bwd(mov, fix)
+    g_ref = ref.fp.grad.clone()
+    # an eager pass at another shape (same parameters: the encoder is fully convolutional), twice: record + batched
+    for _ in range(2):
+        lb = t._fwd_bwd(mb, fb)
+        assert torch.isfinite(lb[0])
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(4)]    # anything freed would be re-used now
+    assert len(t._steps) == 2 and arena[0] in [sc.arena.data_ptr() for sc in t._steps.values()]
+    t._static_in[0].copy_(mov); t._static_in[1].copy_(fix)
+    t._graph.replay()
+    torch.cuda.synchronize()
+    del junk
+    assert abs(float(t._static_out[0]) - float(l_ref[0])) < 1e-6
+    gerr = float((t.fp.grad - g_ref).abs().max() / g_ref.abs().max())
+    _note("graph.grad_relerr_after_shape_switch", gerr)
+    assert gerr < 1e-4, gerr
+
+
+def test_two_trainers_on_two_threads_equal_running_alone():
+    """SURVEY 8(b) "re-entrant, no global mutable state" / VERDICT r2 item 7: the step-batching tables live in caller-owned
+    contexts (modet_step_ctx_t), so two Trainers stepping concurrently from two threads of one process -- different
+    weights, different inputs, own streams -- produce the gradients they produce alone."""
+    import threading
+    from smilecode_amd import models, synth
+    from smilecode_amd.engine import Trainer
+    shape = (32, 48, 32)
+
+    def make(seed):
+        m = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).cuda()
+        models.load_numpy_weights(m, synth.make_weights(seed))
+        mov, fix = synth.make_pair(shape, seed)
+        return Trainer(m), torch.from_numpy(mov).cuda(), torch.from_numpy(fix).cuda()
+
+    alone = []
+    for seed in (24, 77):
+        t, mov, fix = make(seed)
+        for _ in range(2):                                   # recording pass, then the batched pass
+            t._fwd_bwd(mov, fix)
+        alone.append(t.fp.grad.clone())
+    assert not torch.allclose(alone[0], alone[1])
+    pairs = [make(24), make(77)]
+    torch.cuda.synchronize()
+    errs, barrier = [None, None], threading.Barrier(2)
+
+    def work(i):
+        try:
+            t, mov, fix = pairs[i]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for k in range(4):
+                    barrier.wait(timeout=120)                # both threads inside a step at the same time, every time
+                    t._fwd_bwd(mov, fix)
+            st.synchronize()
+            errs[i] = float((t.fp.grad - alone[i]).abs().max() / alone[i].abs().max())
+        except Exception as e:                               # noqa: BLE001
+            errs[i] = e
+            barrier.abort()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(300)
+    for e in errs:
+        assert isinstance(e, float), e
+        assert e < 1e-4, errs                                # the feature-warp scatter's float atomics: run-to-run ~1e-6
+    _note("two_trainers_two_threads.grad_relerr", max(errs))
 
 
 def test_reference_train_loop_call_order(tmp_path):

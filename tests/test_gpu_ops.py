@@ -401,7 +401,7 @@ def test_conv_vs_oracle(ops, cin, cout, shape):
 
 
 def test_prepacked_conv_weights_follow_the_weights(ops):
-    """ops.PrepackedConvWeights: pass 1 records the packing jobs (forward + data-gradient form of every layer), later
+    """ops.StepContext.prepacked(): pass 1 records the packing jobs (forward + data-gradient form of every layer), later
     passes pack them all in one launch from the CURRENT weights and the conv launches use that copy -- outputs and data
     gradients must be bit-identical to the unscoped calls, also after the weights were updated in place, for the plain,
     row-packed (Cout <= 8), statistics and multi-chunk configurations."""
@@ -425,32 +425,38 @@ def test_prepacked_conv_weights_follow_the_weights(ops):
             out.append((y.detach().clone(), dx.clone()))
         return out
 
-    pp = ops.PrepackedConvWeights()
-    with pp.step("shape-a"):
+    pp = ops.StepContext()
+    with pp.prepacked():
         first = run()                                        # recording pass (packs per launch)
-    assert pp.arena is not None and _lib.load().modet_conv3d_prepack_arena_bytes() > 0
+    assert pp.arena is not None and _lib.load().modet_conv3d_prepack_arena_bytes(pp.handle) > 0
     for a, b in zip(first, run()):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     with torch.no_grad():
         for _, w, _, _ in layers:
             w.mul_(1.5).add_(0.01)                           # an optimizer step: same storage, new values
     want = run()                                             # unscoped: packs per launch from the new weights
-    with pp.step("shape-a"):
+    with pp.prepacked():
         got = run()                                          # one packing launch, then no per-launch packing
     for a, b in zip(want, got):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert not torch.equal(first[0][0], got[0][0])
-    other = ops.PrepackedConvWeights()                       # a second owner takes the table over; the first re-records
-    with other.step("x"):
+    other = ops.StepContext()                                # a second context (another trainer) records its own table
+    with other.prepacked():                                  # and leaves the first one's alone: no re-recording
         run()
-    with pp.step("shape-a"):
+    arena_before = pp.arena.data_ptr()
+    with pp.prepacked():
+        with other.prepacked():                              # interleaved scopes of two contexts on one thread
+            inner = run()
         again = run()
-    for a, b in zip(want, again):
+    assert pp.arena.data_ptr() == arena_before and pp.recorded and other.recorded
+    for a, b, c in zip(want, again, inner):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    assert ops.current_step() is None
 
 
 def test_deferred_wgrad_reductions_bit_identical(ops):
-    """ops.deferred_wgrad_reductions: all weight-gradient reductions of a backward pass as one launch, written to the
+    """ops.StepContext.deferred(): all weight-gradient reductions of a backward pass as one launch, written to the
     destinations the scope was given.  40 layers (two batches of the 32-job table) covering the three partial-tile
     layouts -- conv3d_wgrad_kernel (Cin 4/8/16 M packing), conv3d_wgrad_np_kernel (Cin, Cout <= 8) and the first 1->4
     layer with LeakyReLU' folded in -- must give exactly the bits of the per-layer reductions, with and without a bias."""
@@ -467,7 +473,8 @@ def test_deferred_wgrad_reductions_bit_identical(ops):
         dst[b.data_ptr()] = torch.full_like(b, float("nan"))
         ins.append((x, dy, i % 3 != 0, ya, w, b))
     ref = [ops.conv3d_backward_weight(x, dy, wb, y_act=ya) for x, dy, wb, ya, _, _ in ins]
-    with ops.deferred_wgrad_reductions(dst) as scope:
+    sc = ops.StepContext()
+    with sc.deferred(dst) as scope:
         got = [ops.conv3d_backward_weight(x, dy, wb, y_act=ya, w=w, b=b) for x, dy, wb, ya, w, b in ins]
         junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]    # allocator churn inside the scope
         del junk
@@ -485,9 +492,10 @@ def test_deferred_wgrad_reductions_bit_identical(ops):
             assert bool(torch.isnan(dst[b.data_ptr()]).all()) and b.data_ptr() not in scope.written
     assert torch.equal(w2, ref[2][0]) and torch.equal(w3, ref[2][0])
     with pytest.raises(RuntimeError, match="do not nest"):
-        with ops.deferred_wgrad_reductions(dst):
-            with ops.deferred_wgrad_reductions(dst):
+        with sc.deferred(dst):
+            with sc.deferred(dst):
                 pass
+    assert sc.dst is None and ops.current_step() is None         # the outer scope unwound cleanly
     rw, rb = ops.conv3d_backward_weight(*ins[1][:3])             # no scope: immediate
     assert torch.equal(rw, ref[1][0])
 

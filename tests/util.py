@@ -1,4 +1,5 @@
 """helpers shared by the parity tests"""
+import json
 import os
 
 import numpy as np
@@ -46,3 +47,22 @@ def assert_close(got, want, atol=2e-5, rtol=2e-5, what=""):
         raise AssertionError(f"{what}: {bad.sum()}/{bad.size} elements off; worst at {i}: got {got[i]!r} want {want[i]!r} "
                              f"(|err| {err[i]:.3e}, max|want| {np.abs(want).max():.3e})")
     return float(err.max())
+
+
+_REPORT_PATH = os.path.join(os.path.dirname(GOLD.rstrip("/")), "..", "gpurun_out", "parity_report.json")
+
+
+def note(key, val):
+    """record a measured parity number in gpurun_out/parity_report.json; the file is MERGED (keys of other test
+    modules / earlier subsets of the same call survive), so whichever subset ran last does not erase the rest"""
+    path = os.path.normpath(_REPORT_PATH)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    rep = {}
+    if os.path.exists(path):
+        try:
+            rep = json.load(open(path))
+        except (OSError, ValueError):
+            rep = {}
+    rep[key] = float(val)
+    with open(path, "w") as f:
+        json.dump(rep, f, indent=1, sort_keys=True)
