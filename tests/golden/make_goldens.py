@@ -214,6 +214,7 @@ def op_warp():
 
 def op_misc():
     g = np.random.default_rng(103)
+    torch.manual_seed(103)      # the reference modules below draw their default init from torch's global generator
     out = {}
     # projection
     for tag, cin, dim, shape in (("p1", 8, 6, (3, 4, 5)), ("p5", 128, 48, (2, 3, 2)), ("p3", 32, 12, (3, 3, 4))):
