@@ -256,6 +256,41 @@ def cpu_cfg1():
     return out
 
 
+def cfg5_leg(dev, steps):
+    """BASELINE.json configs[4] on this one GPU: Mindboggle-sized 160x192x224 volumes, bf16 storage / fp32 accumulate,
+    2 pairs per GPU, full train step replayed as a hipGraph (the N-GPU form adds the overlapped all-reduce).  A side leg of
+    the default line so that the driver's single command records it next to the fp32 headline."""
+    from smilecode_amd import models, synth
+    from smilecode_amd.engine import Trainer
+    shape, batch = (160, 192, 224), 2
+    model = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1, act_dtype=torch.bfloat16).to(dev)
+    models.load_numpy_weights(model, synth.make_weights(24))
+    tr = Trainer(model)
+    mov, fix = (torch.from_numpy(a).to(dev) for a in synth.make_pair(shape, 24, batch))
+    graphed = True
+    try:
+        tr.capture(mov, fix)
+    except Exception as e:                                       # noqa: BLE001 -- the leg must not take the headline down
+        tr.release_graph()
+        graphed = False
+        log(f"[bench] cfg5 leg: hipGraph capture failed ({e!r}); eager steps")
+    for _ in range(3):
+        tr.train_step(mov, fix, epoch=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.train_step(mov, fix, epoch=0)[0]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"value": batch / dt, "unit": "volume-pairs/sec", "ms_per_step": dt * 1e3, "steps": steps, "dtype": "bf16",
+           "hip_graph": graphed, "loss_after": float(loss),
+           "workload": "ModeT 160x192x224 bf16 storage / fp32 accumulate (ConvInsBlock chains), batch=2/GPU, full train step "
+                       "NCC+Grad3d fwd+bwd+Adam-amsgrad, 1 GPU (the 8-GPU form of configs[4] adds the overlapped all-reduce)"}
+    del tr, model, mov, fix
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -464,6 +499,11 @@ def main():
         tf = (time.perf_counter() - t0) / args.steps
         extra["cfg2_forward_warp"] = {"value": args.batch / tf, "unit": "volume-pairs/sec", "ms_per_step": tf * 1e3,
                                       "workload": "ModeT LPBA %dx%dx%d fp32, batch=%d, forward+warp, no grad" % (*shape, args.batch)}
+        if shape == (160, 192, 160) and args.dtype == "f32" and args.batch == 1:
+            try:
+                extra["cfg5_bf16_160x192x224_b2"] = cfg5_leg(dev, max(5, min(args.steps, 20)))
+            except Exception as e:                                     # noqa: BLE001
+                extra["cfg5_bf16_160x192x224_b2"] = {"value": None, "workload": f"failed: {e!r}"}
         if not args.no_cpu_baseline:
             try:
                 extra["cfg1_cpu_forward_64"] = cpu_cfg1()

@@ -224,8 +224,12 @@ class CWM(nn.Module):
 class ModeTransformer(nn.Module):
     """3x3x3 neighbourhood attention whose values are the 27 offsets (reference models.py:278-334)."""
 
-    def __init__(self, dim, num_heads, kernel_size=3, qk_scale=None, use_rpb=True, buffer_flavour="grid"):
+    def __init__(self, dim, num_heads, kernel_size=3, qk_scale=None, use_rpb=True, buffer_flavour="grid",
+                 fused=True):
+        """``fused=False``: the reference ModeT-cu decomposition -- layout prep, the operator ``modetqkrpb_cu`` (logits),
+        softmax, ``attn @ v`` (ModeT-cu/models.py:300-316) -- instead of the single fused kernel; same result."""
         super().__init__()
+        self.fused = fused
         if kernel_size != 3:
             raise RuntimeError("ModeTransformer does not support kernel size %d" % kernel_size)
         self.num_heads = num_heads
@@ -251,11 +255,30 @@ class ModeTransformer(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, q, k):
+        if not self.fused:
+            return self.forward_operator(q, k)
         if self.use_rpb:
             rpb = self.rpb
         else:
             rpb = torch.zeros(self.num_heads, 3, 3, 3, dtype=q.dtype, device=q.device)
         return ops.neighbourhood_attention(q, k, rpb, self.num_heads, self.scale)
+
+    def forward_operator(self, q, k):
+        """ModeT-cu/models.py:300-316 statement for statement on channels-last q, k (B,D,H,W,C): the operator boundary
+        ``modetqkrpb_cu`` (functional.py -> modet_qk_fwd / modet_qk_bwd) sees exactly the tensors the reference hands its
+        CUDA extension -- pre-scaled (B,heads,D,H,W,d) queries, zero-padded (B,heads,D+2,H+2,W+2,d) keys -- and the
+        softmax / ``@ v`` / layout steps around it are the reference's own ATen calls.  Returns (B,D,H,W,heads*3)."""
+        from .functional import modetqkrpb_cu
+        B, D, H, W, C = q.shape
+        h, d = self.num_heads, C // self.num_heads
+        qh = q.reshape(B, D, H, W, h, d).permute(0, 4, 1, 2, 3, 5) * self.scale
+        kk = torch.nn.functional.pad(k.permute(0, 4, 1, 2, 3), (1, 1, 1, 1, 1, 1))
+        kk = kk.reshape(B, h, d, D + 2, H + 2, W + 2).permute(0, 1, 3, 4, 5, 2)
+        attn = modetqkrpb_cu(qh, kk, self.rpb if self.use_rpb else None)
+        attn = attn.softmax(dim=-1)
+        v = self.v if self.buffer_flavour == "v" else self.grid.reshape(27, 3)
+        x = attn @ v                                              # (B,heads,D,H,W,3)
+        return x.permute(0, 2, 3, 4, 1, 5).reshape(B, D, H, W, h * 3)      # channel = head*3 + axis (models.py:314)
 
 
 class CoTr(nn.Module):
@@ -299,11 +322,15 @@ class ModeT(nn.Module):
     _flavour = "grid"
 
     def __init__(self, inshape=(160, 192, 160), in_channel=1, channels=4, head_dim=6, num_heads=[8, 4, 2, 1, 1],
-                 scale=None, legacy_grid_buffers=False, act_dtype=torch.float32):
+                 scale=None, legacy_grid_buffers=False, act_dtype=torch.float32, fused_attention=True):
         """``act_dtype=torch.bfloat16`` (not in the reference, BASELINE.json configs[4]): the encoder's ConvInsBlock chains
         store their activations in bf16 and run on the bf16 matrix pipe with fp32 accumulation; parameters, statistics,
-        level features, flows, losses and the optimizer stay fp32, so checkpoints are unchanged."""
+        level features, flows, losses and the optimizer stay fp32, so checkpoints are unchanged.
+        ``fused_attention=False``: every ModeTransformer runs the reference ModeT-cu decomposition through the operator
+        boundary ``modetqkrpb_cu`` (see ModeTransformer.forward_operator); every level dim must then be >= 3, as the
+        reference's CHECK_3DFEATMAP demands (utils.h:10)."""
         super().__init__()
+        self.fused_attention = fused_attention
         if act_dtype not in (torch.float32, torch.bfloat16):
             raise RuntimeError("ModeT: act_dtype must be torch.float32 or torch.bfloat16")
         self.act_dtype = act_dtype
@@ -315,19 +342,20 @@ class ModeT(nn.Module):
         self.inshape = tuple(inshape)
         c = channels
         fl = self._flavour
+        mk = dict(qk_scale=scale, buffer_flavour=fl, fused=fused_attention)
         self.encoder = Encoder(in_channel=in_channel, first_out_channel=c, bf16=act_dtype == torch.bfloat16)
         self.projblock1 = ProjectionLayer(2 * c, dim=head_dim * num_heads[4])
-        self.mdt1 = ModeTransformer(head_dim * num_heads[4], num_heads[4], qk_scale=scale, buffer_flavour=fl)
+        self.mdt1 = ModeTransformer(head_dim * num_heads[4], num_heads[4], **mk)
         self.projblock2 = ProjectionLayer(4 * c, dim=head_dim * num_heads[3])
-        self.mdt2 = ModeTransformer(head_dim * num_heads[3], num_heads[3], qk_scale=scale, buffer_flavour=fl)
+        self.mdt2 = ModeTransformer(head_dim * num_heads[3], num_heads[3], **mk)
         self.projblock3 = ProjectionLayer(8 * c, dim=head_dim * num_heads[2])
-        self.mdt3 = ModeTransformer(head_dim * num_heads[2], num_heads[2], qk_scale=scale, buffer_flavour=fl)
+        self.mdt3 = ModeTransformer(head_dim * num_heads[2], num_heads[2], **mk)
         self.cwm3 = CWM(3 * num_heads[2], 3 * num_heads[2] * 2)
         self.projblock4 = ProjectionLayer(16 * c, dim=head_dim * num_heads[1])
-        self.mdt4 = ModeTransformer(head_dim * num_heads[1], num_heads[1], qk_scale=scale, buffer_flavour=fl)
+        self.mdt4 = ModeTransformer(head_dim * num_heads[1], num_heads[1], **mk)
         self.cwm4 = CWM(3 * num_heads[1], 3 * num_heads[1] * 2)
         self.projblock5 = ProjectionLayer(32 * c, dim=head_dim * num_heads[0])
-        self.mdt5 = ModeTransformer(head_dim * num_heads[0], num_heads[0], qk_scale=scale, buffer_flavour=fl)
+        self.mdt5 = ModeTransformer(head_dim * num_heads[0], num_heads[0], **mk)
         self.cwm5 = CWM(3 * num_heads[0], 3 * num_heads[0] * 2)
         self.transformer = nn.ModuleList(
             [SpatialTransformer([s // 2 ** i for s in inshape], legacy_grid_buffers=legacy_grid_buffers)
@@ -382,8 +410,9 @@ class ModeT_cu(ModeT):
     _flavour = "v"
 
     def __init__(self, inshape=(160, 192, 160), in_channel=1, channels=4, head_dim=6, num_heads=[8, 4, 2, 1, 1],
-                 scale=1, legacy_grid_buffers=False, act_dtype=torch.float32):
-        super().__init__(inshape, in_channel, channels, head_dim, num_heads, scale, legacy_grid_buffers, act_dtype)
+                 scale=1, legacy_grid_buffers=False, act_dtype=torch.float32, fused_attention=True):
+        super().__init__(inshape, in_channel, channels, head_dim, num_heads, scale, legacy_grid_buffers, act_dtype,
+                         fused_attention)
 
 
 def load_numpy_weights(model: nn.Module, weights) -> None:

@@ -222,6 +222,135 @@ def test_bf16_train_steps_track_fp32_and_checkpoints_stay_fp32():
     assert b[-1] < b[0] - 0.1
 
 
+CFG5_SHAPE = (160, 192, 224)
+
+
+@pytest.fixture(scope="module")
+def cfg5_oracle():
+    """fp64 CPU oracle of the reference path at BASELINE.json configs[4]'s shape (160x192x224), computed ONCE for the
+    tests below: the two samples of the batch are independent (InstanceNorm is per sample, no BatchNorm), so sample 0
+    runs forward + backward (its loss and every parameter gradient), sample 1 forward only -- one fp64 autograd tape in
+    host memory at a time.  ~4 min of host CPU on the GPU box."""
+    from oracle import modet_torch as orc
+    from smilecode_amd import synth
+    w = synth.make_weights(24)
+    mov_np, fix_np = synth.make_pair(CFG5_SHAPE, 24, 2)
+    p64 = {n: torch.from_numpy(v).double().requires_grad_(True) for n, v in w.items()}
+    l0, s0, r0, _, f0 = orc.train_loss(p64, torch.from_numpy(mov_np[:1]).double(), torch.from_numpy(fix_np[:1]).double(),
+                                       (8, 4, 2, 1, 1), 6, 1.0)
+    g0 = dict(zip(p64, torch.autograd.grad(l0, list(p64.values()))))
+    f0 = f0.detach()
+    with torch.no_grad():
+        _, f1 = orc.modet_forward({n: v.detach() for n, v in p64.items()}, torch.from_numpy(mov_np[1:]).double(),
+                                  torch.from_numpy(fix_np[1:]).double(), (8, 4, 2, 1, 1), 6, 1.0)
+    lab_m = torch.from_numpy(synth.make_labels(CFG5_SHAPE, 24))[None, None]
+    lab_f = torch.from_numpy(synth.make_labels(CFG5_SHAPE, 25))[None, None]
+    dice0 = orc.dice_voi(orc.warp(lab_m.float(), f0.float(), "nearest").long(), lab_f.long())
+    return {"w": w, "mov": mov_np, "fix": fix_np, "flow": torch.cat([f0, f1]), "loss0": float(l0), "sim0": float(s0),
+            "reg0": float(r0), "grad0": {n: g.detach() for n, g in g0.items()}, "lab_m": lab_m, "lab_f": lab_f, "dice0": dice0}
+
+
+def _cfg5_model(dtype, w):
+    from smilecode_amd import models
+    m = models.ModeT(CFG5_SHAPE, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1, act_dtype=dtype).cuda()
+    models.load_numpy_weights(m, w)
+    return m
+
+
+def _loss_and_grads(m, mov, fix):
+    from smilecode_amd import losses
+    for prm in m.parameters():
+        prm.grad = None
+    y, flow = m(mov, fix)
+    sim, reg = losses.NCC_vxm()(fix, y), losses.Grad3d(penalty="l2")(flow, fix)
+    (sim + reg).backward()
+    return float(sim.detach()), float(reg.detach()), flow.detach(), {n: prm.grad.clone() for n, prm in m.named_parameters()}
+
+
+def test_cfg5_shape_fp32_parity_vs_fp64_oracle(cfg5_oracle):
+    """VERDICT r2 next-1a, fp32 half: at 160x192x224 with 2 pairs per GPU the HIP path holds the tolerances stated for every
+    other size -- flow <= 2e-3 voxels against the fp64 oracle on BOTH samples, loss terms to 2e-5 / 2e-6 and every
+    parameter gradient <= 2e-2 of its tensor's max on sample 0 (the oracle's autograd ran there) -- and the batch-2
+    gradient is the mean of the two single-sample gradients (the loss is a mean over the batch; that linearity pins the
+    batch-2 step the bench times without a second fp64 tape)."""
+    from tests.util import note
+    o = cfg5_oracle
+    m = _cfg5_model(torch.float32, o["w"])
+    mov, fix = torch.from_numpy(o["mov"]).cuda(), torch.from_numpy(o["fix"]).cuda()
+    s0, r0, fl0, g0 = _loss_and_grads(m, mov[:1], fix[:1])
+    assert abs(s0 - o["sim0"]) < 2e-5 and abs(r0 - o["reg0"]) < 2e-6, (s0, o["sim0"], r0, o["reg0"])
+    worst, worst_name = 0.0, ""
+    for n, ref in o["grad0"].items():
+        gmax = float(ref.abs().max())
+        err = float((g0[n].double().cpu() - ref).abs().max())
+        if gmax < 1e-8:                                     # conv bias under InstanceNorm: analytically zero
+            assert err < 1e-5, (n, err)
+            continue
+        if err / gmax > worst:
+            worst, worst_name = err / gmax, n
+    note("cfg5_f32[160x192x224].grad_worst_rel_to_max", worst)
+    assert worst <= 2e-2, f"worst gradient error {worst:.3e} of max|g| in {worst_name}"
+    s1, r1, fl1, g1 = _loss_and_grads(m, mov[1:], fix[1:])
+    sb, rb, flb, gb = _loss_and_grads(m, mov, fix)
+    e = float((flb.double().cpu() - o["flow"]).abs().max())
+    note("cfg5_f32[160x192x224,B=2].flow_maxerr_voxels_vs_fp64", e)
+    note("cfg5_f32[160x192x224,B=2].flow_absmax", float(o["flow"].abs().max()))
+    assert e <= 2e-3, e
+    # a sample's flow does not depend on its batch (the fused statistics are summed in another grouping: fp32 noise only)
+    indep = max(float((flb[:1] - fl0).abs().max()), float((flb[1:] - fl1).abs().max()))
+    note("cfg5_f32[160x192x224,B=2].flow_maxdiff_batch2_vs_single", indep)
+    assert indep < 1e-3, indep
+    assert abs(sb - 0.5 * (s0 + s1)) < 5e-6 and abs(rb - 0.5 * (r0 + r1)) < 5e-7
+    lin = 0.0
+    for n in gb:
+        want = 0.5 * (g0[n] + g1[n])
+        gmax = float(want.abs().max())
+        if gmax < 1e-8:
+            continue
+        lin = max(lin, float((gb[n] - want).abs().max()) / gmax)
+    note("cfg5_f32[160x192x224,B=2].grad_batch_linearity_relerr", lin)
+    assert lin < 1e-3, lin                                  # fp32 summation order + the warp scatter's atomics
+
+
+def test_cfg5_shape_bf16_flow_and_dice_vs_fp64_oracle(cfg5_oracle):
+    """VERDICT r2 next-1a, bf16 half (BASELINE.json configs[4] = bf16 storage, 160x192x224, 2 pairs per GPU): against the
+    fp64 oracle of the reference path, on both samples: flow rms <= 0.1 voxel and 99.9 % of the voxels within 0.75 (the
+    bounds stated and measured at the small shapes; ~2x what this shape measures), the first loss
+    within 5e-3 -- and north_star's Dice statement: |Dice(bf16 HIP flow) - Dice(fp64 oracle flow)| <= 1e-3 through the
+    fused label-warp / Dice tail on the synthetic 54-label maps."""
+    from smilecode_amd.utils import warp_labels_and_dice
+    from tests.util import note
+    o = cfg5_oracle
+    m = _cfg5_model(torch.bfloat16, o["w"])
+    mov, fix = torch.from_numpy(o["mov"]).cuda(), torch.from_numpy(o["fix"]).cuda()
+    sb, rb, flow, gb = _loss_and_grads(m, mov, fix)
+    assert all(bool(torch.isfinite(g).all()) for g in gb.values())
+    ef = flow.double().cpu() - o["flow"]
+    rms = float(ef.pow(2).mean().sqrt())
+    p999 = float(ef.abs().flatten().kthvalue(int(0.999 * ef.numel())).values)
+    note("cfg5_bf16[160x192x224,B=2].flow_rms_voxels_vs_fp64", rms)
+    note("cfg5_bf16[160x192x224,B=2].flow_p999_voxels_vs_fp64", p999)
+    note("cfg5_bf16[160x192x224,B=2].flow_maxerr_voxels_vs_fp64", float(ef.abs().max()))
+    s0, r0, fl0, g0 = _loss_and_grads(m, mov[:1], fix[:1])
+    note("cfg5_bf16[160x192x224].loss_abs_err", abs(s0 + r0 - o["loss0"]))
+    gv, rv = [], []
+    for n, ref in o["grad0"].items():
+        if float(ref.abs().max()) < 1e-8:
+            continue
+        gv.append(g0[n].double().cpu().reshape(-1)); rv.append(ref.reshape(-1))
+    gv, rv = torch.cat(gv), torch.cat(rv)
+    rel, cos = float((gv - rv).norm() / rv.norm()), float(F.cosine_similarity(gv, rv, 0))
+    note("cfg5_bf16[160x192x224].grad_rel_l2", rel)
+    note("cfg5_bf16[160x192x224].grad_cos", cos)
+    _, dice = warp_labels_and_dice(o["lab_m"].cuda(), flow[:1], o["lab_f"].cuda())
+    note("cfg5_bf16[160x192x224].dice_hip", dice)
+    note("cfg5_bf16[160x192x224].dice_fp64_oracle", o["dice0"])
+    assert rms <= 0.1 and p999 <= 0.75, (rms, p999)
+    assert abs(s0 + r0 - o["loss0"]) <= 5e-3
+    assert cos >= 0.98 and rel <= 0.2, (cos, rel)
+    assert abs(dice - o["dice0"]) <= 1e-3, f"Dice {dice:.5f} (bf16 HIP) vs {o['dice0']:.5f} (fp64 oracle)"
+
+
 def test_cfg5_shape_160x192x224_batch2_bf16_train_step():
     """BASELINE.json configs[4] on one GPU: Mindboggle-sized 160x192x224 volumes, 2 pairs per GPU, bf16 storage: the train
     step runs (hipGraph-replayed, as the bench times it), stays finite, matches the fp32 path's first loss to the stated

@@ -46,6 +46,56 @@ def test_forward_golden(tag, scale):
     _note(f"fwd[{tag}].flow_absmax", float(g["flow_absmax"]))
 
 
+@pytest.mark.parametrize("shape,B", [((48, 64, 48), 1), ((48, 48, 64), 2)])
+def test_modet_cu_through_the_operator_boundary(shape, B):
+    """VERDICT r2 missing-2: ``ModeT_cu(fused_attention=False)`` runs every level's attention the way the reference's
+    ModeT-cu does -- layout prep -> ``modetqkrpb_cu`` -> softmax -> ``@ v`` (ModeT-cu/models.py:300-316) -- so the
+    operator kernels (qk_*_plane_kernel) see the model's real q / k / d_attn at every pyramid level (heads 8/4/2/1/1).
+    Flow, loss and every parameter gradient must equal the fused-kernel model's and the fp64 oracle's."""
+    from oracle import modet_torch as orc
+    from smilecode_amd import losses, models, synth
+    w = synth.make_weights(24)
+    res = {}
+    mov_np, fix_np = synth.make_pair(shape, 24, B)
+    mov, fix = torch.from_numpy(mov_np).cuda(), torch.from_numpy(fix_np).cuda()
+    for fused in (True, False):
+        m = models.ModeT_cu(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1, fused_attention=fused).cuda()
+        models.load_numpy_weights(m, w)
+        y, flow = m(mov, fix)
+        loss = losses.NCC_vxm()(fix, y) + losses.Grad3d(penalty="l2")(flow, fix)
+        loss.backward()
+        res[fused] = (flow.detach(), float(loss), {n: p.grad.clone() for n, p in m.named_parameters()})
+    ef = float((res[True][0] - res[False][0]).abs().max())
+    assert ef < 2e-4 and abs(res[True][1] - res[False][1]) < 1e-6, (ef, res[True][1], res[False][1])
+    p64 = {n: torch.from_numpy(v).double().requires_grad_(True) for n, v in w.items()}
+    l64, _, _, _, f64 = orc.train_loss(p64, torch.from_numpy(mov_np).double(), torch.from_numpy(fix_np).double(),
+                                       (8, 4, 2, 1, 1), 6, 1.0)
+    g64 = dict(zip(p64, torch.autograd.grad(l64, list(p64.values()))))
+    eo = float((res[False][0].double().cpu() - f64.detach()).abs().max())
+    assert eo <= 2e-3 and abs(res[False][1] - float(l64)) < 2e-5, (eo, res[False][1], float(l64))
+    worst = 0.0
+    for n, ref in g64.items():
+        gmax = float(ref.abs().max())
+        if gmax < 1e-8:
+            continue
+        worst = max(worst, float((res[False][2][n].double().cpu() - ref).abs().max()) / gmax)
+    assert worst <= 2e-2, worst
+    _note(f"modet_cu_operator[{'x'.join(map(str, shape))},B={B}].flow_maxerr_vs_fp64", eo)
+    _note(f"modet_cu_operator[{'x'.join(map(str, shape))},B={B}].flow_maxdiff_vs_fused", ef)
+    _note(f"modet_cu_operator[{'x'.join(map(str, shape))},B={B}].grad_worst_rel_to_max", worst)
+
+
+def test_modet_cu_operator_path_rejects_levels_below_the_window():
+    """CHECK_3DFEATMAP (ModeT-cu/modet/include/utils.h:10): with 32x48x32 the coarsest level is 2x3x2 < 3x3x3 and the
+    reference's extension raises; so does ours (the fused kernel handles it, as the pure-PyTorch ModeT does)."""
+    from smilecode_amd import models
+    shape = (32, 48, 32)
+    m = models.ModeT_cu(shape, fused_attention=False).cuda()
+    mov, fix = _pair(shape)
+    with pytest.raises(RuntimeError, match="greater than or equal to kernel size"):
+        m(mov, fix)
+
+
 def test_modet_cu_same_network_and_state_dict_roundtrip():
     from smilecode_amd import models
     shape = (32, 48, 32)

@@ -72,6 +72,38 @@ def test_qk_reference_contract(tag):
     assert_close(np64(a2), g[f"{tag}.logits"] - g[f"{tag}.rpb"].reshape(1, heads, 1, 1, 1, 27), what="qk no-bias")
 
 
+def test_qk_operator_full_size_vs_c_oracle():
+    """the operator boundary at the level-1 shape it is benchmarked at (160x192x160, 1 head, d = 6)
+    against oracle/modet_ref.c (the plain-C fp64 restatement of modet_fw / modet_bw, modet_kernel.cu:17-317): ALL 132.7 M
+    logits, d_q, the padded d_k including its ring, and d_rpb (a sum over 4.9 M voxels per tap)."""
+    from oracle import cref
+    from smilecode_amd.functional import modet_bw, modet_fw
+    D, H, W, d = 160, 192, 160, 6
+    g = torch.Generator().manual_seed(160)
+    q = torch.randn((1, 1, D, H, W, d), generator=g)
+    kp = torch.zeros((1, 1, D + 2, H + 2, W + 2, d))
+    kp[:, :, 1:-1, 1:-1, 1:-1] = torch.randn((1, 1, D, H, W, d), generator=g)
+    rpb = torch.randn((1, 3, 3, 3), generator=g)
+    ga = torch.randn((1, 1, D, H, W, 27), generator=g)
+    attn = modet_fw(q.cuda(), kp.cuda(), rpb.cuda())
+    dq, dk, dr = modet_bw(ga.cuda(), q.cuda(), kp.cuda(), True)
+    torch.cuda.synchronize()
+    ref = cref.modet_fw(q.numpy(), kp.numpy(), rpb.numpy())
+    e = assert_close(attn.cpu().numpy(), ref, atol=2e-5, rtol=2e-5, what="full-size logits")
+    del ref, attn
+    rq, rk, rr = cref.modet_bw(ga.numpy(), q.numpy(), kp.numpy(), True)
+    eq = assert_close(dq.cpu().numpy(), rq, atol=2e-5, rtol=2e-5, what="full-size d_q")
+    ek = assert_close(dk.cpu().numpy(), rk, atol=2e-5, rtol=2e-5, what="full-size d_kpad")
+    # d_rpb[t] sums 4.9 M products of O(1): |sum| ~ sqrt(V) = 2e3; fp32 partial rows + fp64 stages
+    er = float(np.abs(dr.double().cpu().numpy() - rr).max() / np.abs(rr).max())
+    assert er < 1e-5, er
+    from tests.util import note
+    note("operator[160x192x160].logits_maxerr", e)
+    note("operator[160x192x160].dq_maxerr", eq)
+    note("operator[160x192x160].dkpad_maxerr", ek)
+    note("operator[160x192x160].drpb_relerr", er)
+
+
 @pytest.mark.parametrize("shape,heads,d", [((5, 6, 7), 2, 6), ((3, 3, 3), 1, 4), ((9, 17, 33), 3, 8)])
 def test_qk_reference_contract_double(shape, heads, d):
     """The operator dispatches double like the reference (AT_DISPATCH_FLOATING_TYPES, modet_kernel.cu:134,:364):
