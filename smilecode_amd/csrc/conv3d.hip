@@ -1421,6 +1421,18 @@ size_t modetx_split_ws_bytes(int Cin, int Cout);
 size_t modetx_split_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_split_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                       int B, int D, int H, int W, int Cin, int Cout, int mode, hipStream_t s);
+// bf16x3 z-marching kernels of the few-channel full-resolution layers (conv3d_x3.hip): the default for the shapes they
+// cover; MODET_CONV_X3=0 selects the exact-f32 MFMA kernels of this file for every shape (A/B switch)
+bool modetx_x3_eligible(int B, int D, int H, int W, int Cin, int Cout);
+size_t modetx_x3_ws_bytes(int Cin, int Cout);
+size_t modetx_x3_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
+                   const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int act, int mode,
+                   hipStream_t s);
+static bool use_x3(int B, int D, int H, int W, int Cin, int Cout) {
+  static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
+  return on && modetx_x3_eligible(B, D, H, W, Cin, Cout);
+}
 static bool use_split(int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_SPLIT"); return e && e[0] == '1'; }();
   return on && modetx_split_eligible(Cin, Cout);
@@ -1514,8 +1526,10 @@ int modet_conv3d_prepack_end(modet_step_ctx_t* c) {
 
 size_t modet_conv3d_ws_bytes(int Cin, int Cout) {
   const int m = Cin > Cout ? Cin : Cout;       // bwd_data swaps the roles
-  const size_t a = fwd_ws_elems(m, m) * sizeof(float), b = modetx_split_ws_bytes(Cin, Cout);
-  return a > b ? a : b;
+  size_t a = fwd_ws_elems(m, m) * sizeof(float);
+  const size_t b = modetx_split_ws_bytes(Cin, Cout), c = modetx_x3_ws_bytes(Cin, Cout);
+  a = a > b ? a : b;
+  return a > c ? a : c;
 }
 
 int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
@@ -1529,6 +1543,10 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
     if (Cout == 4) hipLaunchKernelGGL(conv_c1_fwd_kernel<4>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, x, w, bias, y, D, H, W, total, act);
     else hipLaunchKernelGGL(conv_c1_fwd_kernel<8>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, x, w, bias, y, D, H, W, total, act);
     return modet_launch_status();
+  }
+  if (use_x3(B, D, H, W, Cin, Cout)) {
+    if (ws_bytes < modetx_x3_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
+    return modetx_x3_conv(step, x, w, bias, y, ws, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
   }
   if (!act && use_split(Cin, Cout)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
@@ -1549,11 +1567,13 @@ static int conv_stats_rows(int B, int D, int H, int W, int Cin, int Cout) {
 
 size_t modet_conv3d_normin_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
+  if (use_x3(B, D, H, W, Cin, Cout)) return modetx_x3_stats_bytes(B, D, H, W, Cin, Cout);
   return ((size_t)B * Cout + (size_t)B * conv_stats_rows(B, D, H, W, Cin, Cout) * Cout * 2) * sizeof(float);
 }
 
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
+  if (use_x3(B, D, H, W, Cin, Cout)) return modetx_x3_stats_bytes(B, D, H, W, Cin, Cout);    // one row per workgroup
   if (use_split(Cin, Cout)) return modetx_split_stats_bytes(B, D, H, W, Cin, Cout);     // one row per output tile
   // [sample][Cout] shift header, then [sample][workgroup][Cout][2] partial sums of (y - shift), (y - shift)^2; reduced by
   // modet_instnorm_lrelu_fwd_stats / modet_instnorm_stats
@@ -1568,6 +1588,12 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
   if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
   if (stats_bytes < modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
+  if (use_x3(B, D, H, W, Cin, Cout)) {
+    if (ws_bytes < modetx_x3_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
+    hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                       (const float*)nullptr, (const float*)nullptr, stats, B, D, H, W, Cin, Cout);
+    return modetx_x3_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream);
+  }
   if (use_split(Cin, Cout)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     return modetx_split_conv(step, x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
@@ -1588,6 +1614,13 @@ int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const floa
     if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
     if (stats_bytes < modet_conv3d_normin_stats_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
   }
+  if (use_x3(B, D, H, W, Cin, Cout)) {
+    if (ws_bytes < modetx_x3_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
+    if (stats)
+      hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x_raw, w, bias, in_mean,
+                         in_rstd, stats, B, D, H, W, Cin, Cout);
+    return modetx_x3_conv(step, x_raw, w, bias, y, ws, stats, in_mean, in_rstd, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream);
+  }
   return conv_launch(step, x_raw, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
                      ConvIn{in_mean, in_rstd, stats ? conv_stats_rows(B, D, H, W, Cin, Cout) : 0, nullptr});
 }
@@ -1598,6 +1631,10 @@ int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (ws_bytes < fwd_ws_elems(Cout, Cin) * sizeof(float)) return MODET_ERR_WORKSPACE;
   // a convolution of d_y (Cout channels) producing Cin channels
+  if (use_x3(B, D, H, W, Cout, Cin)) {
+    if (ws_bytes < modetx_x3_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
+    return modetx_x3_conv(step, d_y, w, nullptr, d_x, ws, nullptr, nullptr, nullptr, B, D, H, W, Cout, Cin, 0, 1, (hipStream_t)stream);
+  }
   if (use_split(Cout, Cin)) {
     if (ws_bytes < modetx_split_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
     return modetx_split_conv(step, d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, (hipStream_t)stream);

@@ -839,6 +839,7 @@ void modetx_bf16_defer_flush(modet_step_ctx* c, hipStream_t stream) {
 }
 
 // ---- 16-bit side of modet_conv3d_prepack_* (conv3d.hip owns the entry points; these jobs follow the fp32 jobs in the arena)
+void modetx_x3_prepack_begin(modet_step_ctx* c, hipStream_t stream);          // conv3d_x3.hip: its jobs have layout >= 2
 size_t modetx_bf16_prepack_bytes(modet_step_ctx* c) {
   std::lock_guard<std::mutex> lk(c->mu);
   size_t n = 0;
@@ -855,8 +856,8 @@ void modetx_bf16_prepack_begin(modet_step_ctx* c, void* arena, hipStream_t strea
     size_t n = 0;
     for (size_t i = 0; i < c->bjobs.size(); ++i) { c->boff[i] = n; n += packb_elems(c->bjobs[i]); }
     c->barena = (unsigned short*)arena;
-    jobs = c->bjobs;
-    off = c->boff;
+    for (size_t i = 0; i < c->bjobs.size(); ++i)
+      if (c->bjobs[i].layout < 2) { jobs.push_back(c->bjobs[i]); off.push_back(c->boff[i]); }
   }
   for (size_t i0 = 0; i0 < jobs.size(); i0 += PACKB_MAX_JOBS) {
     PackBTable t;
@@ -871,6 +872,7 @@ void modetx_bf16_prepack_begin(modet_step_ctx* c, void* arena, hipStream_t strea
     t.n = n;
     hipLaunchKernelGGL(pack_weights_bf16_many_kernel, dim3(most > 64 ? 64 : most, n), dim3(256), 0, stream, t);
   }
+  modetx_x3_prepack_begin(c, stream);
 }
 
 extern "C" {

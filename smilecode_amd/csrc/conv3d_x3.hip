@@ -1,0 +1,615 @@
+// 3x3x3 / stride 1 / zero-pad 1 convolution of the FEW-CHANNEL, FULL-RESOLUTION layers (pyramid levels 1-2: Cin, Cout <= 16)
+// in fp32 accuracy on gfx950's bf16 matrix pipe ("bf16x3"), as a z-marching kernel.
+//   reference call sites: nn.Conv3d in ConvBlock / ConvInsBlock, ModeT/models.py:127,:144 (arithmetic lives in ATen/MIOpen
+//   there; these layers are 43 % of the forward FLOPs of the path, SURVEY.md section 7 "hard parts").
+//
+// Arithmetic.  Every fp32 operand is split into three bf16 pieces, x = hi + mid + lo exactly to 2^-24 (8 significand bits
+// each, the remainders x - hi and (x - hi) - mid are exact in fp32); a product a*b is evaluated as the six piece products
+// of total order <= 2, each EXACT in the fp32 accumulator of v_mfma_f32_16x16x32_bf16; the three dropped terms are
+// <= 3 * 2^-24 |a b| -- the class of the single rounding of an fp32 FMA.  Six bf16 MFMAs (16 cycles each per SIMD) replace
+// eight passes of the exact-f32 MFMA (32 cycles each): 2.7x less matrix-pipe time, and a third of the matrix-pipe power
+// (the exact-f32 kernels run this chip into its package power limit, DESIGN.md "two speeds").
+//
+// Structure.  The exact-f32 kernel (conv3d.hip) stages a 4x8x16 tile with a one-voxel halo: 2.1x the tile's voxels pass
+// through the split/LDS path and L2 (measured 1.9x the algorithmic HBM traffic).  Here a workgroup owns a (TY x 16) column
+// of (y, x) and MARCHES ALONG z over a chunk of planes.  Each input plane is loaded from HBM once per column (halo 1.27x),
+// split once, written to LDS once, and consumed once: its k-steps (the 3 x (P+2) taps of the plane x channels) feed the
+// THREE output planes it contributes to (dz = 0, 1, 2), whose accumulators rotate through registers -- so one set of
+// LDS operand reads serves 18 MFMAs, the weights (three pieces of 3 dz x NS k-steps) live in registers or LDS for the
+// whole march, and LDS holds just two planes (double buffer), not a halo'd 3-D tile.  Software pipeline per plane:
+// MFMAs on plane p | split + LDS write of plane p+1 (already in registers) | barrier | global loads of plane p+2.
+// ROW PACKING (P = 2, Cout <= 8): the 16 MFMA rows are (row p in {0,1}) x (8 couts); the taps of a plane become (dyp in 0..3,
+// dx): 12 taps x 8 channels = 3 k-steps with no padding (the exact-f32 kernel pays 25 % zero work for the same trick).
+// dgrad is the same kernel on flipped / transposed weights.
+#include "common.h"
+#include "step_ctx.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NTHR = 256;
+constexpr int TX = 16, HX = TX + 2;
+
+__device__ __forceinline__ unsigned short to_bf16(float a) {               // round to nearest even
+  const __bf16 x = (__bf16)a;
+  return __builtin_bit_cast(unsigned short, x);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+  hi = to_bf16(x);
+  const float r1 = x - bf16_to_f32(hi);
+  mid = to_bf16(r1);
+  const float r2 = r1 - bf16_to_f32(mid);
+  lo = to_bf16(r2);
+}
+#ifndef X3_VARIANT
+#define X3_VARIANT 0
+#endif
+__device__ __forceinline__ unsigned pk_bf16(float u, float v) {             // v_cvt_pk_bf16_f32: two roundings to nearest even
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  const bf16x2 t = __builtin_convertvector((f32x2){u, v}, bf16x2);
+  return __builtin_bit_cast(unsigned, t);
+}
+// two floats -> the packed bf16 pairs of their three pieces (v_cvt_pk_bf16_f32 + two masks per piece)
+__device__ __forceinline__ void split3_pk(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  auto pk = [](float u, float v) -> unsigned {
+    const bf16x2 t = __builtin_convertvector((f32x2){u, v}, bf16x2);
+    return __builtin_bit_cast(unsigned, t);
+  };
+  hi = pk(a, b);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+  mid = pk(ra, rb);
+  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
+  lo = pk(sa, sb);
+}
+
+// Global traffic goes through buffer descriptors of ONE plane (wave-uniform base, 32-bit per-lane byte offset): an offset at
+// or past num_records loads 0 / drops the store -- the zero padding of the halo, the ragged tile edges and "no plane here"
+// (num_records = 0) all without a branch or a select, and with an instruction count the s_waitcnt pass can reason about.
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+constexpr unsigned X3_OOB = 0x80000000u;             // planes are < 2 GiB (checked on the host)
+__device__ __forceinline__ BufRsrc plane_rsrc(const float* base, unsigned bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                     (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(u), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+// geometry shared by the kernel and the weight packing
+template <int CIN, int P>
+struct X3Geo {
+  static constexpr int NTAP = 3 * (P + 2);                                 // taps of ONE input plane: (dyp, dx)
+  static constexpr int NCH = CIN == 4 ? (NTAP + 1) / 2 : NTAP * (CIN / 8); // 8-wide k chunks per plane
+  static constexpr int NS = (NCH + 3) / 4;                                 // k-steps (4 chunks = 32 k each)
+  static constexpr int CoP = 16 / P;                                       // cout slots per packed row
+};
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// wpk[((dz * NS + s) * 3 + piece) * 64 + lane] = 8 bf16: the MFMA A fragment (row m = lane & 15, k chunk c = 4 s + (lane >> 4)).
+//   chunk -> (tap, channels):  CIN 8: tap = c, channels 0..7;  CIN 16: tap = c / 2, channels 8 (c & 1) ..+7;
+//                              CIN 4: element j < 4: tap 2c, channel j;  j >= 4: tap 2c + 1, channel j - 4.
+//   tap = dyp * 3 + dx;  row m = p * CoP + co holds W((dz, dyp - p, dx); channel -> co) when 0 <= dyp - p <= 2, else 0.
+//   mode 0 (forward): w[co][ch][tap27]   w: (Cout, Cin, 27);   mode 1 (dgrad): w[ch][co][26 - tap27]   w: (Co = ch, Ci = co, 27)
+struct X3PackJob { const float* w; unsigned short* wpk; int Cin, Cout, cin_t, P, mode, pad_; };
+constexpr int X3PACK_MAX_JOBS = 40;
+struct X3PackTable { X3PackJob job[X3PACK_MAX_JOBS]; int n; };
+
+__device__ __forceinline__ void x3_pack_body(const X3PackJob& J, int i0, int stride) {
+  const int CIN = J.cin_t, P = J.P;
+  const int NTAP = 3 * (P + 2), NCH = CIN == 4 ? (NTAP + 1) / 2 : NTAP * (CIN / 8), NS = (NCH + 3) / 4, CoP = 16 / P;
+  const int per_piece = 64 * 8, total = 3 * NS * per_piece;               // per (dz, s): 3 pieces x 512 elements
+  for (int i = i0; i < total; i += stride) {
+    const int j = i & 7, lane = (i >> 3) & 63;
+    const int s = (i >> 9) % NS, dz = (i >> 9) / NS;
+    const int m = lane & 15, c = s * 4 + (lane >> 4);
+    int tap, ch;
+    if (CIN == 8) { tap = c; ch = j; }
+    else if (CIN == 16) { tap = c >> 1; ch = (c & 1) * 8 + j; }
+    else { tap = 2 * c + (j >> 2); ch = j & 3; }
+    const int p = m / CoP, co = m % CoP;
+    const int dyp = tap / 3, dx = tap % 3, dy = dyp - p;
+    float v = 0.f;
+    if (tap < NTAP && dy >= 0 && dy <= 2 && co < J.Cout && ch < J.Cin) {
+      const int t27 = (dz * 3 + dy) * 3 + dx;
+      v = J.mode == 0 ? J.w[((int64_t)co * J.Cin + ch) * 27 + t27] : J.w[((int64_t)ch * J.Cout + co) * 27 + 26 - t27];
+    }
+    unsigned short h, md, l;
+    split3(v, h, md, l);
+    unsigned short* o = J.wpk + ((size_t)((dz * NS + s) * 3) * 64 + lane) * 8 + j;
+    o[0] = h; o[per_piece] = md; o[2 * per_piece] = l;
+  }
+}
+__global__ void x3_pack_kernel(const X3PackJob J) { x3_pack_body(J, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
+__global__ void x3_pack_many_kernel(const X3PackTable t) {
+  x3_pack_body(t.job[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+inline int x3_ns(int cin_t, int P) {
+  const int ntap = 3 * (P + 2), nch = cin_t == 4 ? (ntap + 1) / 2 : ntap * (cin_t / 8);
+  return (nch + 3) / 4;
+}
+inline size_t x3_wpk_elems(int cin_t, int P) { return (size_t)3 * x3_ns(cin_t, P) * 3 * 64 * 8; }   // bf16 elements
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+struct X3Args {
+  const float* x; const uint4* wpk; const float* bias; float* y;
+  const float* in_mean; const float* in_rstd;          // NORM: x is a raw ConvInsBlock output, LeakyReLU((x - mean) * rstd) on load
+  float* stats_rows; const float* shift;               // STATS: [b][item][Cout][2] sums of (y - K), (y - K)^2;  K = shift[b][Cout]
+  int D, H, W, Cin, Cout, tiles_x, tiles_y, nchunk, ZC, nitems, act;
+  long long* dbg;                                      // MODET_TUNING builds: per-(workgroup, wave) cycle sums per phase
+};
+#ifdef MODET_TUNING
+__device__ long long* g_x3_dbg = nullptr;
+#define X3_T(i) { const long long now_ = clock64(); dsum[i] += now_ - tprev; tprev = now_; }
+#else
+#define X3_T(i)
+#endif
+
+template <int CIN, int P, int TY, bool WLDS, bool NORM, bool STATS>
+__global__ __launch_bounds__(NTHR, 2) void conv_x3_kernel(const X3Args a) {
+  using G = X3Geo<CIN, P>;
+  constexpr int NS = G::NS, NTAP = G::NTAP;
+  constexpr int HY = TY + 2, UNITS = TY / P, R = UNITS / 4;
+  // one piece's plane [hy][hx][CIN] bf16 + 16 bytes that absorb the LDS writes of staging slots past the plane's end
+  constexpr int PLANE_D = HY * HX * CIN * 2, PLANE_B = PLANE_D + 16, SLOT_B = 3 * PLANE_B;
+  constexpr int Q = CIN / 4, NITEM = HY * HX * Q, NIT = (NITEM + NTHR - 1) / NTHR;
+  constexpr int WL_B = WLDS ? 3 * NS * 3 * 1024 : 16;
+  static_assert(UNITS % 4 == 0, "row groups split over 4 waves");
+  static_assert(NTHR % Q == 0, "a thread's staging items share one channel group");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLOT_B];
+  __shared__ __attribute__((aligned(16))) unsigned char wl[WL_B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  // XCD-aware item order: workgroups land on XCD blockIdx % 8; give each XCD a contiguous range of items so that
+  // columns sharing halo rows / planes share an L2
+  const int per_xcd = (a.nitems + 7) >> 3;
+  int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (item >= a.nitems) return;
+  const int item_id = item;
+  const int tx = item % a.tiles_x; item /= a.tiles_x;
+  const int ty = item % a.tiles_y; item /= a.tiles_y;
+  const int zc = item % a.nchunk;
+  const int b = item / a.nchunk;
+  const int x0 = tx * TX, y0 = ty * TY, zs = zc * a.ZC;
+  const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int nz = (zs + a.ZC <= D ? a.ZC : D - zs);                         // output planes of this item
+
+  // ---- weights: A fragments of every (dz, k-step, piece), in registers (or LDS) for the whole march
+  uint4 wreg[WLDS ? 1 : 3][WLDS ? 1 : NS][WLDS ? 1 : 3];
+  if constexpr (WLDS) {
+    for (int i = tid; i < 3 * NS * 3 * 64; i += NTHR) reinterpret_cast<uint4*>(wl)[i] = a.wpk[i];
+  } else {
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wreg[dz][s][pc] = a.wpk[((dz * NS + s) * 3 + pc) * 64 + lane];
+  }
+
+  // ---- staging map: item i = tid + j * NTHR of the halo'd plane [hy][hx][Q channel groups]
+  unsigned goff[NIT];                                                      // byte offset inside the input plane, or out of bounds
+  int loff[NIT];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int i = tid + j * NTHR;
+    const bool on = i < NITEM;
+    const int v = on ? i / Q : 0, c4 = on ? i - v * Q : 0;
+    const int hy = v / HX, hx = v - hy * HX;
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const bool ok = on && yy >= 0 && yy < H && xx >= 0 && xx < W && c4 * 4 < Cin;
+    goff[j] = ok ? (unsigned)(((yy * W + xx) * Cin + c4 * 4) * 4) : X3_OOB;
+    loff[j] = on ? (v * CIN + c4 * 4) * 2 : PLANE_D;                       // slots past the plane's end write the pad
+    okmask |= (ok ? 1u : 0u) << j;
+  }
+  float4 nm = make_float4(0.f, 0.f, 0.f, 0.f), nr = make_float4(1.f, 1.f, 1.f, 1.f);
+  if constexpr (NORM) {
+    const int cg = (tid % Q) * 4;
+    if (cg < Cin) {
+      nm = *reinterpret_cast<const float4*>(a.in_mean + b * Cin + cg);
+      nr = *reinterpret_cast<const float4*>(a.in_rstd + b * Cin + cg);
+    }
+  }
+  const float* xb = a.x + (int64_t)b * D * H * W * Cin;
+  const unsigned in_plane_bytes = (unsigned)H * W * Cin * 4, out_plane_bytes = (unsigned)H * W * Cout * 4;
+  // XSETS register sets, plane q lives in set q % XSETS.  One set = the plane is loaded one iteration before it is split
+  // (measured: the split then waits ~1 % of a wave's cycles for its loads; a second iteration of distance bought nothing
+  // and its 24 registers are worth more to the MFMA loop's operand prefetch)
+  constexpr int XSETS = 1;
+  float4 xr[XSETS][NIT];
+  bool xr_live[XSETS] = {};                                                // the set holds an in-volume plane
+  auto load_plane = [&](auto set_c, int z) {
+    constexpr int S = decltype(set_c)::value;
+    xr_live[S] = z >= 0 && z < D;
+    const BufRsrc rs = plane_rsrc(xb + (int64_t)(xr_live[S] ? z : 0) * H * W * Cin, xr_live[S] ? in_plane_bytes : 0u);
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) xr[S][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[j], 0, 0));
+  };
+  auto store_plane = [&](auto set_c, int slot) {
+    constexpr int S = decltype(set_c)::value;
+    unsigned char* sl = lds + slot * SLOT_B;
+    // all NIT items stage by stage (2 NIT independent dependency chains side by side: the split is a chain of seven
+    // dependent VALU operations per value pair, one item after the other leaves the VALU waiting on itself)
+    float2 v[NIT][2];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      float4 t = xr[S][j];
+      if constexpr (NORM) {                                                // zero padding stays zero (selects, no branch)
+        const bool on = xr_live[S] && ((okmask >> j) & 1u);
+        t.x = on ? lrelu((t.x - nm.x) * nr.x) : 0.f; t.y = on ? lrelu((t.y - nm.y) * nr.y) : 0.f;
+        t.z = on ? lrelu((t.z - nm.z) * nr.z) : 0.f; t.w = on ? lrelu((t.w - nm.w) * nr.w) : 0.f;
+      }
+      v[j][0] = make_float2(t.x, t.y); v[j][1] = make_float2(t.z, t.w);
+    }
+    unsigned hi[NIT][2], mid[NIT][2], lo[NIT][2];
+#if X3_VARIANT & 2
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) hi[j][h] = pk_bf16(v[j][h].x, v[j][h].y);
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        v[j][h].x -= __uint_as_float(hi[j][h] << 16); v[j][h].y -= __uint_as_float(hi[j][h] & 0xffff0000u);
+      }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) mid[j][h] = pk_bf16(v[j][h].x, v[j][h].y);
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        v[j][h].x -= __uint_as_float(mid[j][h] << 16); v[j][h].y -= __uint_as_float(mid[j][h] & 0xffff0000u);
+      }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) lo[j][h] = pk_bf16(v[j][h].x, v[j][h].y);
+#else
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) split3_pk(v[j][h].x, v[j][h].y, hi[j][h], mid[j][h], lo[j][h]);
+#endif
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      *reinterpret_cast<uint2*>(sl + loff[j]) = make_uint2(hi[j][0], hi[j][1]);
+      *reinterpret_cast<uint2*>(sl + PLANE_B + loff[j]) = make_uint2(mid[j][0], mid[j][1]);
+      *reinterpret_cast<uint2*>(sl + 2 * PLANE_B + loff[j]) = make_uint2(lo[j][0], lo[j][1]);
+    }
+  };
+
+  // ---- operand addresses: B fragment = 8 k values of voxel (row group r, x = li): chunk c = 4 s + lk
+  int coffA[NS], coffB[CIN == 4 ? NS : 1];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int c = s * 4 + lk;
+    if (CIN == 4) {
+      int t0 = 2 * c, t1 = 2 * c + 1;
+      if (t0 >= NTAP) t0 = 0;                                              // padded k: finite data times zero weights
+      if (t1 >= NTAP) t1 = 0;
+      coffA[s] = ((t0 / 3) * HX + t0 % 3) * CIN * 2;
+      coffB[s] = ((t1 / 3) * HX + t1 % 3) * CIN * 2;
+    } else {
+      int tap = CIN == 16 ? c >> 1 : c;
+      const int ch0 = CIN == 16 ? (c & 1) * 8 : 0;
+      if (tap >= NTAP) tap = 0;
+      coffA[s] = (((tap / 3) * HX + tap % 3) * CIN + ch0) * 2;
+    }
+  }
+  int xoff[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) xoff[r] = ((P * (wave * R + r)) * HX + li) * CIN * 2;
+
+  f32x4 acc[3][R];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[q][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- epilogue constants: this lane holds 4 consecutive couts co0.. of voxel (row, x0 + li) of each row group
+  const int co0 = P == 2 ? (lk & 1) * 4 : lk * 4;
+  const bool co_ok = co0 < Cout;
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (co_ok && a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + co0);
+  if (STATS && co_ok) k4 = *reinterpret_cast<const float4*>(a.shift + b * Cout + co0);
+  float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+  float* yb = a.y + (int64_t)b * D * H * W * Cout;
+  unsigned soff[R];                                                        // byte offset of this lane's float4 in an output plane
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int u = wave * R + r;
+    const int row = y0 + (P == 2 ? 2 * u + (lk >> 1) : u);
+    soff[r] = (co_ok && x0 + li < W && row < H) ? (unsigned)(((row * W + x0 + li) * Cout + co0) * 4) : X3_OOB;
+  }
+
+  auto frag = [&](const unsigned char* sl, int pc, int r, int s) -> bf16x8 {
+    const unsigned char* base = sl + pc * PLANE_B + xoff[r];
+    if constexpr (CIN == 4) {
+      const uint2 lo = *reinterpret_cast<const uint2*>(base + coffA[s]);
+      const uint2 hi = *reinterpret_cast<const uint2*>(base + coffB[s]);
+      return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    } else {
+      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + coffA[s]));
+    }
+  };
+  auto wfrag = [&](int dz, int s, int pc) -> bf16x8 {
+    if constexpr (WLDS) return __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(wl)[((dz * NS + s) * 3 + pc) * 64 + lane]);
+    else return __builtin_bit_cast(bf16x8, wreg[dz][s][pc]);
+  };
+#define X3_MM(ACC, WP, XP) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[WP], xf[XP], ACC, 0, 0, 0)
+  // one input plane (LDS slot) into the three output planes it touches; C = q % 3: dz -> accumulator (C - dz) mod 3
+  auto compute = [&](auto cc, int slot, bool a0, bool a1, bool a2) {
+    constexpr int C = decltype(cc)::value;
+    constexpr int S0 = C, S1 = (C + 2) % 3, S2 = (C + 1) % 3;
+    const unsigned char* sl = lds + slot * SLOT_B;
+    if (a0 && a1 && a2) {
+      // (k-step, row group) units in order; the three B fragments of unit u+1 are read from LDS before the 18 MFMAs of unit u
+      bf16x8 xq[2][3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) xq[0][pc] = frag(sl, pc, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NS * R; ++u) {
+        const int s = u / R, r = u % R;
+        if (u + 1 < NS * R) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) xq[(u + 1) & 1][pc] = frag(sl, pc, (u + 1) % R, (u + 1) / R);
+        }
+        // keep the reads up here: left alone the scheduler sinks them to their first use to save registers and every
+        // unit then starts with an exposed LDS round trip (seen in the ISA: ds_read, s_waitcnt lgkmcnt(0), v_mfma)
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 w0[3], w1[3], w2[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) { w0[pc] = wfrag(0, s, pc); w1[pc] = wfrag(1, s, pc); w2[pc] = wfrag(2, s, pc); }
+        const bf16x8* xf = xq[u & 1];
+        // small terms first; the three accumulators alternate so that back-to-back MFMAs are independent
+#define X3_ALL(WP, XP) { bf16x8* w = w0; X3_MM(acc[S0][r], WP, XP); } { bf16x8* w = w1; X3_MM(acc[S1][r], WP, XP); } { bf16x8* w = w2; X3_MM(acc[S2][r], WP, XP); }
+        X3_ALL(2, 0) X3_ALL(0, 2) X3_ALL(1, 1) X3_ALL(1, 0) X3_ALL(0, 1) X3_ALL(0, 0)
+#undef X3_ALL
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          bf16x8 xf[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) xf[pc] = frag(sl, pc, r, s);
+#define X3_ONE(DZ, SL) { bf16x8 w[3]; for (int pc = 0; pc < 3; ++pc) w[pc] = wfrag(DZ, s, pc); \
+            X3_MM(acc[SL][r], 2, 0); X3_MM(acc[SL][r], 0, 2); X3_MM(acc[SL][r], 1, 1); X3_MM(acc[SL][r], 1, 0); X3_MM(acc[SL][r], 0, 1); X3_MM(acc[SL][r], 0, 0); }
+          if (a0) X3_ONE(0, S0)
+          if (a1) X3_ONE(1, S1)
+          if (a2) X3_ONE(2, S2)
+#undef X3_ONE
+        }
+      }
+    }
+  };
+#undef X3_MM
+  // output plane z is complete, its accumulator is SL: + bias, statistics, activation, one 16-byte store per row group.
+  // live = false (no finished plane yet): the same instructions run against an empty descriptor and store nothing.
+  auto flush = [&](auto sl_c, int z, bool live) {
+    constexpr int SL = decltype(sl_c)::value;
+    const BufRsrc rs = plane_rsrc(yb + (int64_t)(live ? z : 0) * H * W * Cout, live ? out_plane_bytes : 0u);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const f32x4 v = acc[SL][r];
+      acc[SL][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float o[4] = {v[0] + b4.x, v[1] + b4.y, v[2] + b4.z, v[3] + b4.w};
+      if (STATS) {
+        const bool on = live && soff[r] != X3_OOB;
+        const float e0 = on ? o[0] - k4.x : 0.f, e1 = on ? o[1] - k4.y : 0.f, e2 = on ? o[2] - k4.z : 0.f, e3 = on ? o[3] - k4.w : 0.f;
+        sx[0] += e0; sx[1] += e1; sx[2] += e2; sx[3] += e3;
+        sq[0] = fmaf(e0, e0, sq[0]); sq[1] = fmaf(e1, e1, sq[1]); sq[2] = fmaf(e2, e2, sq[2]); sq[3] = fmaf(e3, e3, sq[3]);
+      }
+      if (a.act) { o[0] = lrelu(o[0]); o[1] = lrelu(o[1]); o[2] = lrelu(o[2]); o[3] = lrelu(o[3]); }
+      const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rs, (int)soff[r], 0, 0);
+    }
+  };
+
+  // ---- the march: q-th input plane = zs - 1 + q, q = 0 .. nz + 1.  One iteration:
+  //   split + LDS write of plane q+1 (registers loaded two iterations ago) | stores of output plane q-3 (final since the
+  //   previous iteration) | global loads of plane q+3 | MFMAs of plane q | barrier.
+  // Every memory op younger than the loads the split waits for is counted by the compiler (straight-line buffer ops, no
+  // divergent branches), so the wait is an exact vmcnt(n), never a drain of this iteration's stores.
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  const int nq = nz + 2;
+  load_plane(I0{}, zs - 1);
+  if (WLDS) __syncthreads();
+  store_plane(I0{}, 0);
+  load_plane(I0{}, zs);
+  __syncthreads();
+#ifdef MODET_TUNING
+  long long dsum[6] = {0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+#endif
+  // The loop runs whole groups of three iterations (the accumulator / register-set rotation is compile-time) with
+  // IDENTICAL memory-op structure -- [wait][R stores][NIT loads] -- in every iteration, also the padded ones past the last
+  // plane (empty descriptors, no MFMAs): the s_waitcnt pass then derives an exact vmcnt(n) for the split's wait.
+  auto body = [&](auto cc, int q) {
+    constexpr int C = decltype(cc)::value;
+#if X3_VARIANT & 1
+    __builtin_amdgcn_s_setprio(2);                                         // staging / epilogue VALU ahead of the partner wave's MFMAs
+#endif
+#ifdef MODET_TUNING
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                        // the split's loads (and two of the next set): wait time alone
+    X3_T(5)
+#endif
+    if (q + 1 < nq) store_plane(I0{}, (q + 1) & 1);
+    X3_T(2)
+    flush(cc, zs + q - 3, q >= 3 && q <= nq);                              // slot C: output q-3, about to be re-used for output q
+    X3_T(1)
+    // plane q+2 into the registers the split just emptied; past the last plane: an empty descriptor (zeros, no traffic)
+    load_plane(I0{}, q + 2 < nq ? zs + q + 1 : -1);
+    X3_T(4)
+#if X3_VARIANT & 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    compute(cc, q & 1, q <= nz - 1, q >= 1 && q <= nz, q >= 2 && q <= nz + 1);
+    X3_T(0)
+    __syncthreads();
+    X3_T(3)
+  };
+  for (int q = 0; q <= nq; q += 3) {                                       // iteration nq only flushes the last output plane
+    body(I0{}, q);
+    body(I1{}, q + 1);
+    body(I2{}, q + 2);
+  }
+
+#ifdef MODET_TUNING
+  if (g_x3_dbg && lane == 0) {
+    long long* o = g_x3_dbg + ((int64_t)blockIdx.x * 4 + wave) * 6;
+    for (int i = 0; i < 6; ++i) o[i] = dsum[i];
+  }
+#endif
+  if constexpr (STATS) {
+    // lanes sharing a channel group: all li, and for P == 2 both rows (lk >> 1); then the 4 waves through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { sx[j] += __shfl_xor(sx[j], o, 64); sq[j] += __shfl_xor(sq[j], o, 64); }
+      if (P == 2) { sx[j] += __shfl_xor(sx[j], 32, 64); sq[j] += __shfl_xor(sq[j], 32, 64); }
+    }
+    __syncthreads();                                                       // every wave is done with the plane buffers
+    float* sred = reinterpret_cast<float*>(lds);                           // [wave][16 channels][2]
+    if (li == 0 && (P == 1 || lk < 2)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sred[(wave * 16 + co0 + j) * 2] = sx[j]; sred[(wave * 16 + co0 + j) * 2 + 1] = sq[j]; }
+    }
+    __syncthreads();
+    if (tid < 2 * Cout) {
+      float t = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) t += sred[w4 * 32 + tid];
+      const int rows_per_b = a.tiles_x * a.tiles_y * a.nchunk;
+      a.stats_rows[((int64_t)b * rows_per_b + (item_id - b * rows_per_b)) * Cout * 2 + tid] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct X3Plan { int cin_t, P, ty, wlds, tiles_x, tiles_y, nchunk, zc, nitems; };
+
+inline bool x3_shape_ok(int Cin, int Cout) { return Cin % 4 == 0 && Cin >= 4 && Cin <= 8 && Cout % 4 == 0 && Cout >= 4 && Cout <= 16; }
+
+inline X3Plan x3_plan(int B, int D, int H, int W, int Cin, int Cout) {
+  X3Plan p;
+  p.cin_t = Cin <= 4 ? 4 : (Cin <= 8 ? 8 : 16);
+  p.P = Cout <= 8 ? 2 : 1;
+  p.ty = p.P == 2 ? 16 : 8;            // 16 rows = 8 packed row pairs, or 8 plain rows: two row groups per wave either way
+  p.wlds = p.cin_t == 16;
+  p.tiles_x = cdiv(W, TX);
+  p.tiles_y = cdiv(H, p.ty);
+  // z chunks: enough workgroups to fill 256 CUs x 2 several times over (the dispatcher balances them), but chunks long
+  // enough that the two extra halo planes and the pipeline prologue stay small
+  const int cols = B * p.tiles_x * p.tiles_y;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int n = 1; n <= D; ++n) {
+    const int zc = cdiv(D, n);
+    if (zc < 4 && n > 1) break;
+    const int64_t items = (int64_t)cols * cdiv(D, zc);
+    const int64_t rounds = (items + 511) / 512;
+    const double cost = (double)rounds * (zc + 2.5);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = n; }
+  }
+  p.zc = cdiv(D, best);
+  p.nchunk = cdiv(D, p.zc);
+  p.nitems = cols * p.nchunk;
+  return p;
+}
+
+template <bool NORM, bool STATS>
+int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s) {
+  X3Args a = a0;
+  unsigned short* wpk = (unsigned short*)ws;
+  const PackBKey key{w, a.Cin, a.Cout, 16, p.cin_t, 3, x3_ns(p.cin_t, p.P), mode, 3, 1 + p.P};   // nstage = the 3 dz
+  const unsigned short* pre = nullptr;
+  if (step) {
+    std::lock_guard<std::mutex> lk(step->mu);
+    if (step->active) {
+      for (size_t i = 0; i < step->bjobs.size(); ++i)
+        if (step->bjobs[i] == key) { pre = step->barena + step->boff[i]; break; }
+    } else if (step->recording) {
+      bool seen = false;
+      for (const PackBKey& j : step->bjobs) seen = seen || j == key;
+      if (!seen) step->bjobs.push_back(key);
+    }
+  }
+  if (pre) wpk = const_cast<unsigned short*>(pre);
+  else hipLaunchKernelGGL(x3_pack_kernel, dim3(8), dim3(256), 0, s, X3PackJob{w, wpk, a.Cin, a.Cout, p.cin_t, p.P, mode, 0});
+  a.wpk = (const uint4*)wpk;
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.nchunk = p.nchunk; a.ZC = p.zc; a.nitems = p.nitems;
+  const dim3 grid(((p.nitems + 7) / 8) * 8);
+#define X3_L(CIN_, P_, TY_, WL_) hipLaunchKernelGGL((conv_x3_kernel<CIN_, P_, TY_, WL_, NORM, STATS>), grid, dim3(NTHR), 0, s, a)
+  if (p.cin_t == 4) { if (p.P == 2) X3_L(4, 2, 16, false); else X3_L(4, 1, 8, false); }
+  else { if (p.P == 2) X3_L(8, 2, 16, false); else X3_L(8, 1, 8, false); }
+#undef X3_L
+  return modet_launch_status();
+}
+
+}  // namespace
+
+#ifdef MODET_TUNING
+extern "C" int modet_debug_x3_timing(long long* buf) {       // not in the header: tuning builds only
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x3_dbg), &buf, sizeof(buf));
+}
+#endif
+
+// ---- internal interface for conv3d.hip (C++ linkage, not part of the ABI): the fp32 entry points route eligible shapes here
+bool modetx_x3_eligible(int B, int D, int H, int W, int Cin, int Cout) {
+  return x3_shape_ok(Cin, Cout) && (int64_t)D * H * W >= 4096 && B <= 65535;
+}
+size_t modetx_x3_ws_bytes(int Cin, int Cout) { return x3_wpk_elems(16, 1) * sizeof(unsigned short); }
+size_t modetx_x3_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  const X3Plan p = x3_plan(B, D, H, W, Cin, Cout);
+  return ((size_t)B * Cout + (size_t)p.nitems * Cout * 2) * sizeof(float);
+}
+// stats != null: stats = [B][Cout] shift header (filled by the caller's shift kernel) followed by the partial rows
+int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
+                   const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int act, int mode,
+                   hipStream_t s) {
+  const X3Plan p = x3_plan(B, D, H, W, Cin, Cout);
+  X3Args a{};
+  a.x = x; a.bias = bias; a.y = y; a.in_mean = in_mean; a.in_rstd = in_rstd;
+  a.shift = stats; a.stats_rows = stats ? stats + (size_t)B * Cout : nullptr;
+  a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
+  if (in_mean) return stats ? x3_launch<true, true>(step, a, w, ws, B, mode, p, s) : x3_launch<true, false>(step, a, w, ws, B, mode, p, s);
+  return stats ? x3_launch<false, true>(step, a, w, ws, B, mode, p, s) : x3_launch<false, false>(step, a, w, ws, B, mode, p, s);
+}
+// the recorded 16-bit packing jobs with layout >= 2 belong to this file (conv3d_bf16.hip's prepack launch skips them)
+void modetx_x3_prepack_begin(modet_step_ctx* c, hipStream_t stream) {
+  std::vector<PackBKey> jobs;
+  std::vector<size_t> off;
+  unsigned short* arena;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    jobs = c->bjobs; off = c->boff; arena = c->barena;
+  }
+  X3PackTable t;
+  t.n = 0;
+  auto go = [&]() {
+    if (t.n) hipLaunchKernelGGL(x3_pack_many_kernel, dim3(8, t.n), dim3(256), 0, stream, t);
+    t.n = 0;
+  };
+  for (size_t i = 0; i < jobs.size(); ++i) {
+    const PackBKey& k = jobs[i];
+    if (k.layout < 2) continue;
+    t.job[t.n++] = X3PackJob{k.w, arena + off[i], k.Cin, k.Cout, k.CK, k.layout - 1, k.mode, 0};
+    if (t.n == X3PACK_MAX_JOBS) go();
+  }
+  go();
+}

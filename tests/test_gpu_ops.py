@@ -432,6 +432,45 @@ def test_conv_vs_oracle(ops, cin, cout, shape):
     assert_close(np64(db), rb.numpy(), atol=wtol, rtol=2e-4, what="conv dbias")
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(4, 8, (21, 40, 41)), (8, 8, (23, 33, 35)), (8, 4, (17, 16, 50)),
+                                            (8, 16, (19, 24, 30)), (8, 12, (16, 16, 16)), (4, 4, (9, 30, 31))])
+def test_conv_x3_march_vs_fp64(ops, cin, cout, shape):
+    """csrc/conv3d_x3.hip: the z-marching bf16x3 kernels of the few-channel layers (volumes >= 4096 voxels, Cin 4/8, Cout
+    4..16) hold the fp32 kernels' tolerances against ATen-CPU fp64 -- forward (bias, fused LeakyReLU), the fused
+    InstanceNorm statistics (through the normalised output), the lazily normalised input (NORM) and the data gradient,
+    on shapes ragged against the 16x16 columns and the z chunks, batch 2."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(cin * 977 + cout)
+    x = torch.randn((2, cin) + shape, generator=gen).double()
+    x[:, :, :, : shape[1] // 3] = 0.25                                   # a constant region, like a skull-stripped background
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(cin * 27)).double()
+    b = (0.1 * torch.randn(cout, generator=gen)).double()
+    ref = F.conv3d(x, w, b, padding=1)
+    xd, wd, bd = cl(x.numpy()), w.float().cuda(), b.float().cuda()
+    assert_close(ncdhw(ops.conv3d_forward(xd, wd, bd, False)), ref.numpy(), what="x3 fwd")
+    assert_close(ncdhw(ops.conv3d_forward(xd, wd, bd, True)), F.leaky_relu(ref, 0.1).numpy(), what="x3 fwd + LeakyReLU")
+    # fused statistics -> InstanceNorm + LeakyReLU of the raw output
+    y = ops.conv3d_instnorm_lrelu(xd, wd, bd)
+    refn = F.leaky_relu(F.instance_norm(ref, eps=1e-5), 0.1)
+    assert_close(ncdhw(y), refn.numpy(), atol=5e-5, rtol=5e-5, what="x3 fwd + fused InstanceNorm statistics")
+    # data gradient (the same kernel on flipped / transposed weights)
+    gy = torch.randn(ref.shape, generator=gen).double()
+    rx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
+    assert_close(ncdhw(ops.conv3d_backward_data(cl(gy.numpy()), wd, cin)), rx.numpy(), atol=5e-5, what="x3 dgrad")
+    # lazily normalised input: conv(LeakyReLU(InstanceNorm(x_raw))) without materialising the normalised tensor
+    with torch.no_grad():
+        mean, rstd = ops.instnorm_stats(xd)
+        z, zst = ops.conv3d_forward_normin(xd, mean, rstd, wd, bd, True)
+    xin = F.leaky_relu(F.instance_norm(x, eps=1e-5), 0.1)
+    refz = F.conv3d(xin, w, b, padding=1)
+    assert_close(ncdhw(z), refz.numpy(), atol=1e-4, rtol=5e-5, what="x3 fwd, normalised on load")
+    zn = ops._InstNormLReLU.apply(z, 1e-5, zst)
+    assert_close(ncdhw(zn), F.leaky_relu(F.instance_norm(refz, eps=1e-5), 0.1).numpy(), atol=1e-4, rtol=5e-5,
+                 what="x3 normin + statistics")
+    # run-to-run deterministic (no atomics)
+    assert torch.equal(ops.conv3d_forward(xd, wd, bd, False), ops.conv3d_forward(xd, wd, bd, False))
+
+
 def test_prepacked_conv_weights_follow_the_weights(ops):
     """ops.StepContext.prepacked(): pass 1 records the packing jobs (forward + data-gradient form of every layer), later
     passes pack them all in one launch from the CURRENT weights and the conv launches use that copy -- outputs and data

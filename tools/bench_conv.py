@@ -1,0 +1,60 @@
+"""Conv kernels of the full-resolution layers on their own: forward, data gradient, weight gradient at the level-1 / level-2
+shapes of one ModeT train step (encoder batch = moving + fixed = 2), median HIP-event time per call.
+
+    MODET_CONV_X3=0 python tools/bench_conv.py      # exact-f32 MFMA kernels
+    MODET_CONV_X3=1 python tools/bench_conv.py      # bf16x3 z-marching kernels (default)
+"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smilecode_amd import ops  # noqa: E402
+
+L1, L2 = (160, 192, 160), (80, 96, 80)
+LAYERS = [(4, 8, L1), (8, 8, L1), (8, 16, L2), (16, 16, L2)]
+
+
+def timed(fn, iters=15):
+    for _ in range(3):
+        fn()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    rows = []
+    for cin, cout, shape in LAYERS:
+        g = torch.Generator(device="cuda").manual_seed(cin * 100 + cout)
+        x = torch.randn((2,) + shape + (cin,), device="cuda", generator=g)
+        dy = torch.randn((2,) + shape + (cout,), device="cuda", generator=g)
+        w = torch.randn((cout, cin, 3, 3, 3), device="cuda", generator=g) / (27 * cin) ** 0.5
+        b = torch.randn((cout,), device="cuda", generator=g)
+        n = 2.0 * shape[0] * shape[1] * shape[2]
+        fl = 54.0 * cin * cout * n
+        r = {"layer": f"{cin}->{cout}", "shape": list(shape)}
+        r["fwd_ms"] = timed(lambda: ops.conv3d_forward(x, w, b, False))
+        r["fwd_stats_ms"] = timed(lambda: ops._Conv3dStats.apply(x, w, b))
+        r["dgrad_ms"] = timed(lambda: ops.conv3d_backward_data(dy, w, cin))
+        r["wgrad_ms"] = timed(lambda: ops.conv3d_backward_weight(x, dy, True))
+        for k in ("fwd", "fwd_stats", "dgrad", "wgrad"):
+            r[k + "_TF"] = fl / r[k + "_ms"] / 1e9
+        rows.append(r)
+        print("%-8s %-14s fwd %.3f ms (%5.1f TF)  fwd+stats %.3f  dgrad %.3f (%5.1f TF)  wgrad %.3f (%5.1f TF)" % (
+            r["layer"], "x".join(map(str, shape)), r["fwd_ms"], r["fwd_TF"], r["fwd_stats_ms"], r["dgrad_ms"], r["dgrad_TF"],
+            r["wgrad_ms"], r["wgrad_TF"]), flush=True)
+        del x, dy
+        torch.cuda.empty_cache()
+    if len(sys.argv) > 1:
+        json.dump(rows, open(sys.argv[1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
