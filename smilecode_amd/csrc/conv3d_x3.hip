@@ -150,8 +150,11 @@ __device__ long long* g_x3_dbg = nullptr;
 #define X3_T(i)
 #endif
 
+// CIN 4 / 8: two workgroups per CU (<= 256 registers; the partner's MFMAs cover this wave's staging).  CIN 16: the weights
+// alone are 180 registers (3 dz x 5 k-steps x 3 pieces), so ONE workgroup per CU with the whole register file; a plane then
+// carries 360 MFMAs per wave against ~150 staging instructions, which a single wave per SIMD absorbs.
 template <int CIN, int P, int TY, bool WLDS, bool NORM, bool STATS>
-__global__ __launch_bounds__(NTHR, 2) void conv_x3_kernel(const X3Args a) {
+__global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const X3Args a) {
   using G = X3Geo<CIN, P>;
   constexpr int NS = G::NS, NTAP = G::NTAP;
   constexpr int HY = TY + 2, UNITS = TY / P, R = UNITS / 4;
@@ -503,14 +506,17 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_kernel(const X3Args a) {
 // ------------------------------------------------------------------------------------------------ host side
 struct X3Plan { int cin_t, P, ty, wlds, tiles_x, tiles_y, nchunk, zc, nitems; };
 
-inline bool x3_shape_ok(int Cin, int Cout) { return Cin % 4 == 0 && Cin >= 4 && Cin <= 8 && Cout % 4 == 0 && Cout >= 4 && Cout <= 16; }
+inline bool x3_shape_ok(int Cin, int Cout) { return Cin % 4 == 0 && Cin >= 4 && Cin <= 16 && Cout % 4 == 0 && Cout >= 4 && Cout <= 16; }
 
 inline X3Plan x3_plan(int B, int D, int H, int W, int Cin, int Cout) {
   X3Plan p;
   p.cin_t = Cin <= 4 ? 4 : (Cin <= 8 ? 8 : 16);
-  p.P = Cout <= 8 ? 2 : 1;
-  p.ty = p.P == 2 ? 16 : 8;            // 16 rows = 8 packed row pairs, or 8 plain rows: two row groups per wave either way
-  p.wlds = p.cin_t == 16;
+  // CIN 16 runs unpacked (P = 1) also for Cout <= 8: its packed form needs 6 k-steps = 216 weight registers
+  p.P = (Cout <= 8 && p.cin_t < 16) ? 2 : 1;
+  // 16 rows = 8 packed row pairs, or 8 plain rows: two row groups per wave; CIN 16: 16 plain rows, four per wave
+  p.ty = (p.P == 2 || p.cin_t == 16) ? 16 : 8;
+  p.wlds = 0;
+  const int slots = p.cin_t == 16 ? 256 : 512;                             // resident workgroups
   p.tiles_x = cdiv(W, TX);
   p.tiles_y = cdiv(H, p.ty);
   // z chunks: enough workgroups to fill 256 CUs x 2 several times over (the dispatcher balances them), but chunks long
@@ -522,7 +528,7 @@ inline X3Plan x3_plan(int B, int D, int H, int W, int Cin, int Cout) {
     const int zc = cdiv(D, n);
     if (zc < 4 && n > 1) break;
     const int64_t items = (int64_t)cols * cdiv(D, zc);
-    const int64_t rounds = (items + 511) / 512;
+    const int64_t rounds = (items + slots - 1) / slots;
     const double cost = (double)rounds * (zc + 2.5);
     if (cost < best_cost - 1e-9) { best_cost = cost; best = n; }
   }
@@ -556,7 +562,8 @@ int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, 
   const dim3 grid(((p.nitems + 7) / 8) * 8);
 #define X3_L(CIN_, P_, TY_, WL_) hipLaunchKernelGGL((conv_x3_kernel<CIN_, P_, TY_, WL_, NORM, STATS>), grid, dim3(NTHR), 0, s, a)
   if (p.cin_t == 4) { if (p.P == 2) X3_L(4, 2, 16, false); else X3_L(4, 1, 8, false); }
-  else { if (p.P == 2) X3_L(8, 2, 16, false); else X3_L(8, 1, 8, false); }
+  else if (p.cin_t == 8) { if (p.P == 2) X3_L(8, 2, 16, false); else X3_L(8, 1, 8, false); }
+  else X3_L(16, 1, 16, false);
 #undef X3_L
   return modet_launch_status();
 }

@@ -433,7 +433,8 @@ def test_conv_vs_oracle(ops, cin, cout, shape):
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(4, 8, (21, 40, 41)), (8, 8, (23, 33, 35)), (8, 4, (17, 16, 50)),
-                                            (8, 16, (19, 24, 30)), (8, 12, (16, 16, 16)), (4, 4, (9, 30, 31))])
+                                            (8, 16, (19, 24, 30)), (8, 12, (16, 16, 16)), (4, 4, (9, 30, 31)),
+                                            (16, 16, (19, 24, 30)), (16, 8, (17, 18, 20)), (12, 12, (16, 20, 18))])
 def test_conv_x3_march_vs_fp64(ops, cin, cout, shape):
     """csrc/conv3d_x3.hip: the z-marching bf16x3 kernels of the few-channel layers (volumes >= 4096 voxels, Cin 4/8, Cout
     4..16) hold the fp32 kernels' tolerances against ATen-CPU fp64 -- forward (bias, fused LeakyReLU), the fused
