@@ -1429,9 +1429,17 @@ size_t modetx_x3_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                    const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int act, int mode,
                    hipStream_t s);
+bool modetx_x3_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout);
+size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
+                    int W, int Cin, int Cout, hipStream_t s);
 static bool use_x3(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
   return on && modetx_x3_eligible(B, D, H, W, Cin, Cout);
+}
+static bool use_x3_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
+  static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
+  return on && modetx_x3_wgrad_eligible(B, D, H, W, Cin, Cout);
 }
 static bool use_split(int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_SPLIT"); return e && e[0] == '1'; }();
@@ -1648,7 +1656,12 @@ size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int
   const int gx = p.gy >= 1024 ? 1 : 1024 / p.gy;
   const size_t fl = (size_t)gx * p.gy * p.ng * 256;
   const size_t c1 = (size_t)C1_MFMA_BLOCKS * 4 * 2 * 256;       // per-wave partial tiles of conv_c1_wgrad_mfma_kernel
-  return (fl > c1 ? fl : c1) * sizeof(float);
+  size_t n = (fl > c1 ? fl : c1) * sizeof(float);
+  if (use_x3_wgrad(B, D, H, W, Cin, Cout)) {
+    const size_t x3 = modetx_x3_wgrad_ws_bytes(B, D, H, W, Cin, Cout);
+    n = n > x3 ? n : x3;
+  }
+  return n;
 }
 
 static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
@@ -1734,6 +1747,8 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
     reduce_or_defer(ReduceJob{(const float*)ws, d_w, d_bias, 1, 4, nblk * 4, 1, 1, 1, 2, 0}, 2 * 4, s, defer);
     return modet_launch_status();
   }
+  if (!y_act && use_x3_wgrad(B, D, H, W, Cin, Cout))
+    return modetx_x3_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s);
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
   float* part = (float*)ws;
   if (p.np) {

@@ -603,10 +603,34 @@ __global__ __launch_bounds__(1024) void wgrad_bf16_colsum_kernel(const float* __
 // stage 2: d_w[co][ci][tap] / d_bias[co] gathered out of the reduced fragment-layout buffer (call with gx = 1).
 __device__ __forceinline__ void wgrad_bf16_reduce_body(const float* __restrict__ part, float* __restrict__ dw,
                                                        float* __restrict__ dbias, int Cin, int Cout, int CIB, int U, int NTB,
-                                                       int gx, int gy, int n_coblk, int blk) {
+                                                       int gx, int gy, int n_coblk, int blk, int layout = 0) {
   const int nW = Cout * Cin * 27;
   const int i = blk * 256 + threadIdx.x;
   if (i >= nW + Cout) return;
+  if (layout == 1) {
+    // N-packed tiles of conv_x3_wgrad_kernel (Cout <= 8): column n = q * 8 + co multiplies d_y shifted by q voxels in x, row
+    // tile t in {0,1} is x shifted by t: (t, q) = (0,1), (0,0), (1,0) are the taps dx = 0, 1, 2; (1,1) is not a tap
+    const int RED_FL = (U * 2 + 1) * 256;
+    int co, slot, m, q = 0;
+    if (i < nW) {
+      const int tap = i % 27, ci = (i / 27) % Cin;
+      co = i / (27 * Cin);
+      const int combo = tap / 3, dx = tap % 3;
+      const int gl = CIB == 8 ? combo / 2 : combo / 4;
+      m = CIB == 8 ? (combo % 2) * 8 + ci : (combo % 4) * 4 + ci;
+      slot = gl * 2 + (dx == 2 ? 1 : 0);
+      q = dx == 0 ? 1 : 0;
+    } else {
+      co = i - nW; slot = U * 2; m = 0;
+    }
+    const int n = q * 8 + co, lane = (m / 4) * 16 + n, reg = m % 4;
+    const size_t off = (size_t)slot * 256 + lane * 4 + reg;
+    double a = 0.0;
+    for (int g = 0; g < gx; ++g) a += (double)part[(size_t)g * RED_FL + off];
+    if (i < nW) dw[i] = (float)a;
+    else if (dbias) dbias[co] = (float)a;
+    return;
+  }
   const int SLOTS = U * 3 + 1, RED_FL = SLOTS * NTB * 256;
   const int GPB = CIB == 16 ? 9 : (CIB == 8 ? 5 : 3);
   int co, slot, m, chunk;
@@ -634,8 +658,8 @@ __device__ __forceinline__ void wgrad_bf16_reduce_body(const float* __restrict__
 }
 __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                 float* __restrict__ dbias, int Cin, int Cout, int CIB, int U,
-                                                                int NTB, int gx, int gy, int n_coblk) {
-  wgrad_bf16_reduce_body(part, dw, dbias, Cin, Cout, CIB, U, NTB, gx, gy, n_coblk, blockIdx.x);
+                                                                int NTB, int gx, int gy, int n_coblk, int layout) {
+  wgrad_bf16_reduce_body(part, dw, dbias, Cin, Cout, CIB, U, NTB, gx, gy, n_coblk, blockIdx.x, layout);
 }
 
 // Deferred form (modet_conv3d_bf16_bwd_weight_defer + modet_conv3d_wgrad_defer_flush): both stages of every queued
@@ -653,7 +677,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_many_kernel(const BRedT
   int j = 0;
   while (j + 1 < t.n && (int)blockIdx.x >= t.first[j + 1]) ++j;
   const BRedJob& J = t.job[j];
-  wgrad_bf16_reduce_body(J.red, J.dw, J.dbias, J.Cin, J.Cout, J.cib, J.u, J.ntb, 1, J.gy, J.n_coblk, blockIdx.x - t.first[j]);
+  wgrad_bf16_reduce_body(J.red, J.dw, J.dbias, J.Cin, J.Cout, J.cib, J.u, J.ntb, 1, J.gy, J.n_coblk, blockIdx.x - t.first[j], J.layout);
 }
 
 struct WgBf16Plan { int cib, u, ntb, tz, ty, n_chunk, n_coblk, gy, gx, ntiles, tiles_x, tiles_y, tiles_z, red_fl; };
@@ -816,6 +840,23 @@ int modetx_split_conv(modet_step_ctx* step, const float* x, const float* w, cons
                : launch_split<false>(step, x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, mode, s);
 }
 
+// ---- conv3d_x3.hip's weight-gradient kernel writes this file's partial layout (fragment-major tiles, slot = group * 3 + dx,
+// bias slot last): its two reduction stages run here, immediately or queued in the caller's step context
+int modetx_wgrad_partials_reduce(modet_step_ctx* defer, const float* part, float* red, float* dw, float* db, int gx, int Cin,
+                                 int Cout, int cib, int u, int layout, hipStream_t s) {
+  const int red_fl = (u * (layout == 1 ? 2 : 3) + 1) * 256;     // ntb = 1, gy = 1, n_coblk = 1
+  const int64_t row_fl = red_fl;
+  if (defer) {
+    std::lock_guard<std::mutex> lk(defer->mu);
+    defer->brjobs.push_back(BRedJob{part, red, dw, db, row_fl, gx, Cin, Cout, cib, u, 1, 1, 1, layout});
+    return modet_launch_status();
+  }
+  hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, part, red, gx, row_fl);
+  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(cdiv(Cout * Cin * 27 + Cout, 256)), dim3(256), 0, s, (const float*)red, dw, db,
+                     Cin, Cout, cib, u, 1, 1, 1, 1, layout);
+  return modet_launch_status();
+}
+
 // ---- bf16 side of modet_conv3d_wgrad_defer_flush (conv3d.hip calls it)
 void modetx_bf16_defer_flush(modet_step_ctx* c, hipStream_t stream) {
   std::vector<BRedJob> jobs;
@@ -971,12 +1012,12 @@ static int bf16_bwd_weight_impl(const void* x, int x_bf16, const void* d_y, floa
   float* red = (float*)ws + (size_t)p.gx * row_fl;
   if (defer) {
     std::lock_guard<std::mutex> lk(defer->mu);
-    defer->brjobs.push_back(BRedJob{(const float*)ws, red, d_w, d_bias, row_fl, p.gx, Cin, Cout, p.cib, p.u, p.ntb, p.gy, p.n_coblk});
+    defer->brjobs.push_back(BRedJob{(const float*)ws, red, d_w, d_bias, row_fl, p.gx, Cin, Cout, p.cib, p.u, p.ntb, p.gy, p.n_coblk, 0});
     return modet_launch_status();
   }
   hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, (const float*)ws, red, p.gx, row_fl);
   hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, s, (const float*)red, d_w, d_bias, Cin, Cout,
-                     p.cib, p.u, p.ntb, 1, p.gy, p.n_coblk);
+                     p.cib, p.u, p.ntb, 1, p.gy, p.n_coblk, 0);
   return modet_launch_status();
 }
 

@@ -570,6 +570,257 @@ int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, 
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// d_w[co][ci][tap] = sum_v d_y[v][co] * x[v + off(tap)][ci]  as  D[m][n] += A[m][k] B[k][n]  with  k = 32 voxels along W,
+// m = (tap, ci) in tiles of 16 rows, n = cout -- the mapping of conv3d_bf16_wgrad_kernel (conv3d_bf16.hip): both operands need
+// 8 CONSECUTIVE VOXELS of one channel per lane, so planes are staged channel-planar (two x-adjacent voxels per ds_write_b32),
+// and the three x taps of a (dz, dy, ci) row come from one set of aligned reads by funnel shifts.  Here in fp32 accuracy
+// (x and d_y split into three bf16 pieces each, six piece products per tile) and as a z-MARCH: a workgroup owns a 4 x 32
+// column (y, x) and walks a chunk of planes; every x plane (one-voxel halo in y and x) is loaded, split and transposed
+// ONCE and stays in a 4-slot LDS ring while the three d_y planes that touch it pass by, d_y planes are double-buffered.
+// Workgroups are persistent over (column, z chunk) items and keep their fp32 accumulators (all 27 taps x Cin x 16 couts +
+// the bias row) in registers across all of them; the four waves are summed through LDS at the end and ONE partial per
+// workgroup goes to the fixed-order fp64 reduction shared with the bf16 path (deterministic, no atomics).
+constexpr int WTX = 32, WHXP = 48, WTY = 4, WHY = WTY + 2;
+struct X3WArgs {
+  const float* x; const float* dy; float* part;
+  int D, H, W, Cin, Cout, tiles_x, tiles_y, nchunk, ZC, nitems;
+};
+
+// NP (Cout <= 8, "N-packed"): the 16 N columns are (q in {0,1}) x 8 couts, column block q = 1 multiplies d_y shifted one
+// voxel in +x; with A row tiles t in {0,1} = x shifted by t voxels, D[t][q] = sum_u x[u + t - q] d_y[u] is the weight
+// gradient of tap dx = t - q: (0,1), (0,0), (1,0) are dx = -1, 0, +1 and (1,1) is not a tap -- two row tiles per group
+// instead of three, a third fewer MFMAs.  The q = 1 columns see the segment shifted by +1: what they miss over a whole row
+// (u = 0, tap dx = -1) multiplies the zero padding x[-1], so nothing is lost; d_y rows carry one extra voxel.
+template <int CIB, int NCO, bool NP>
+__global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a) {
+  static_assert(!NP || NCO == 8, "N packing: 2 x 8 couts");
+  constexpr int U = CIB == 8 ? 5 : 3;                            // tap groups: 2 (dz,dy) combos x 8 channels, or 4 x 4
+  constexpr int NT = NP ? 2 : 3;                                 // row tiles per group
+  constexpr int PX = WHY * WHXP + 8;                             // elements of one channel's plane (+8: spreads the planes over the banks)
+  constexpr int XPIECE = CIB * PX, XSLOT = 3 * XPIECE;
+  constexpr int DROW = NP ? 40 : WTX;                            // d_y row: 32 voxels (+1 for the shifted columns, padded to 16 bytes)
+  constexpr int DPAIRS = NP ? 17 : 16;
+  constexpr int PD = WTY * DROW + 8, DPIECE = NCO * PD, DSLOT = 3 * DPIECE;
+  constexpr int RED_FL = (U * NT + 1) * 256;
+  constexpr int LDS_EL = 4 * XSLOT + 2 * DSLOT;
+  static_assert(LDS_EL * 2 >= RED_FL * 4, "the cross-wave reduction re-uses the plane buffers");
+  __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_EL];
+  unsigned short* xs = lds;
+  unsigned short* dys = lds + 4 * XSLOT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+
+  // per-lane A row of each group: channel and (dz, dy) combination
+  const int myci = CIB == 8 ? (li & 7) : (li & 3);
+  int adz[U], aoff[U];                                           // dz of the row's combination; element offset inside an x slot (piece 0)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int combo = CIB == 8 ? 2 * u + (li >> 3) : 4 * u + (li >> 2);
+    if (combo > 8) combo = 8;                                    // dummy rows: finite data, never written out
+    adz[u] = combo / 3;
+    aoff[u] = myci * PX + (combo % 3) * WHXP + 8 * lk;
+  }
+  const int bco = NP ? (li & 7) : (li < NCO ? li : li - NCO);    // N columns past the staged couts repeat valid planes (never read back)
+  const bool bq = NP && (li >> 3);                               // this lane's column takes d_y shifted by one voxel
+  const int boff = bco * PD + 8 * lk;
+
+  f32x4 acc[U][NT], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int d = 0; d < NT; ++d) acc[u][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned one2 = li == 0 ? 0x3f803f80u : 0u;              // bf16 (1, 1): row 0 of the bias tile
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2));
+
+  // ---- staging maps (constant over the march): x item = (halo row hy, voxel pair, 4-channel group), d_y item = (row, pair, group)
+  constexpr int QX = CIB / 4, NXI = WHY * 18 * QX, QD = NCO / 4, NDI = WTY * DPAIRS * QD;
+  static_assert(NXI <= NTHR && NDI <= NTHR, "one staging item of each kind per thread");
+  const bool xon = tid < NXI, don = tid < NDI;
+  const int xc4 = tid % QX, xpr = (tid / QX) % 18, xhy = tid / (QX * 18);
+  const int dc4 = tid % QD, dpr = (tid / QD) % DPAIRS, drow = tid / (QD * DPAIRS);
+  const int xl = (xc4 * 4) * PX + xhy * WHXP + 2 * (xpr + 3);   // element of channel xc4*4, piece 0, inside an x slot
+  const int dl = (dc4 * 4) * PD + drow * DROW + 2 * dpr;
+  const unsigned in_plane_bytes = (unsigned)H * W * Cin * 4, dy_plane_bytes = (unsigned)H * W * Cout * 4;
+
+  unsigned gx0 = X3_OOB, gx1 = X3_OOB, gd0 = X3_OOB, gd1 = X3_OOB;
+  const float* xb = a.x;
+  const float* db_ = a.dy;
+  struct Pair { float4 v0, v1; };                                // the two voxels of a thread's x pair / d_y pair
+  auto load_x = [&](int z) -> Pair {
+    const bool live = z >= 0 && z < D;
+    const BufRsrc rs = plane_rsrc(xb + (int64_t)(live ? z : 0) * H * W * Cin, live ? in_plane_bytes : 0u);
+    Pair p;
+    p.v0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gx0, 0, 0));
+    p.v1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gx1, 0, 0));
+    return p;
+  };
+  auto load_dy = [&](int z, int ze) -> Pair {
+    const bool live = z < ze;
+    const BufRsrc rs = plane_rsrc(db_ + (int64_t)(live ? z : 0) * H * W * Cout, live ? dy_plane_bytes : 0u);
+    Pair p;
+    p.v0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gd0, 0, 0));
+    p.v1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gd1, 0, 0));
+    return p;
+  };
+  // split a voxel pair's 4 channels into three packed pieces each and write them into the channel planes
+  auto put = [&](unsigned short* base, int piece_el, int plane_el, const Pair& pr) {
+    const float p0[4] = {pr.v0.x, pr.v0.y, pr.v0.z, pr.v0.w}, p1[4] = {pr.v1.x, pr.v1.y, pr.v1.z, pr.v1.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned h, m, l;
+      split3_pk(p0[c], p1[c], h, m, l);
+      unsigned* d = reinterpret_cast<unsigned*>(base + c * plane_el);
+      d[0] = h; d[piece_el / 2] = m; d[piece_el] = l;            // piece stride in 32-bit words: piece_el / 2
+    }
+  };
+  auto store_x = [&](int slot, const Pair& pr) { if (xon) put(xs + slot * XSLOT + xl, XPIECE, PX, pr); };
+  auto store_dy = [&](int slot, const Pair& pr) { if (don) put(dys + slot * DSLOT + dl, DPIECE, PD, pr); };
+
+  // ---- one d_y plane (slot ds) against the three x planes around it: x plane of tap dz sits in ring slot (q + dz) & 3
+  auto compute = [&](int q, int ds) {
+    const int row = wave;                                        // WTY = 4 rows, one k-step per wave and plane
+    const unsigned short* db = dys + ds * DSLOT + boff + row * DROW;
+    bf16x8 b[3];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      const uint4 qq = *reinterpret_cast<const uint4*>(db + pc * DPIECE);
+      if constexpr (NP) {
+        const unsigned r0 = *reinterpret_cast<const unsigned*>(db + pc * DPIECE + 8);
+        const unsigned s0 = __builtin_amdgcn_alignbit(qq.y, qq.x, 16), s1 = __builtin_amdgcn_alignbit(qq.z, qq.y, 16),
+                       s2 = __builtin_amdgcn_alignbit(qq.w, qq.z, 16), s3 = __builtin_amdgcn_alignbit(r0, qq.w, 16);
+        b[pc] = __builtin_bit_cast(bf16x8, make_uint4(bq ? s0 : qq.x, bq ? s1 : qq.y, bq ? s2 : qq.z, bq ? s3 : qq.w));
+      } else {
+        b[pc] = __builtin_bit_cast(bf16x8, qq);
+      }
+    }
+    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[2], accb, 0, 0, 0);
+    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[1], accb, 0, 0, 0);
+    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[0], accb, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned short* pa = xs + ((q + adz[u]) & 3) * XSLOT + aoff[u] + row * WHXP;
+      bf16x8 f[3][NT];                                           // [piece][row tile]
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const unsigned short* pp = pa + pc * XPIECE;
+        const uint4 qq = *reinterpret_cast<const uint4*>(pp + 8);
+        const unsigned r0 = *reinterpret_cast<const unsigned*>(pp + 16);
+        const unsigned a1 = __builtin_amdgcn_alignbit(qq.y, qq.x, 16), a2 = __builtin_amdgcn_alignbit(qq.z, qq.y, 16),
+                       a3 = __builtin_amdgcn_alignbit(qq.w, qq.z, 16), a4 = __builtin_amdgcn_alignbit(r0, qq.w, 16);
+        if constexpr (NP) {
+          f[pc][0] = __builtin_bit_cast(bf16x8, qq);                              // x[v]
+          f[pc][1] = __builtin_bit_cast(bf16x8, make_uint4(a1, a2, a3, a4));      // x[v + 1]
+        } else {
+          const unsigned p3 = *reinterpret_cast<const unsigned*>(pp + 6);
+          const unsigned a0 = __builtin_amdgcn_alignbit(qq.x, p3, 16);
+          f[pc][0] = __builtin_bit_cast(bf16x8, make_uint4(a0, a1, a2, a3));      // dx = 0: x[v - 1]
+          f[pc][1] = __builtin_bit_cast(bf16x8, qq);
+          f[pc][NT - 1] = __builtin_bit_cast(bf16x8, make_uint4(a1, a2, a3, a4));
+        }
+      }
+      // six piece products, small terms first; the row-tile accumulators alternate (independent back-to-back MFMAs)
+#define X3W(AP, BP)                                                                                      \
+      _Pragma("unroll") for (int d = 0; d < NT; ++d)                                                      \
+        acc[u][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[AP][d], b[BP], acc[u][d], 0, 0, 0);
+      X3W(2, 0) X3W(0, 2) X3W(1, 1) X3W(1, 0) X3W(0, 1) X3W(0, 0)
+#undef X3W
+    }
+  };
+
+  for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+    int t = item;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; t /= a.tiles_y;
+    const int zc = t % a.nchunk;
+    const int b = t / a.nchunk;
+    const int x0 = tx * WTX, y0 = ty * WTY, zs = zc * a.ZC;
+    const int ze = zs + a.ZC < D ? zs + a.ZC : D;
+    xb = a.x + (int64_t)b * D * H * W * Cin;
+    db_ = a.dy + (int64_t)b * D * H * W * Cout;
+    {
+      const int yy = y0 - 1 + xhy, xx = x0 - 8 + 2 * (xpr + 3);
+      const bool rok = xon && yy >= 0 && yy < H && xc4 * 4 < Cin;
+      gx0 = (rok && xx >= 0 && xx < W) ? (unsigned)(((yy * W + xx) * Cin + xc4 * 4) * 4) : X3_OOB;
+      gx1 = (rok && xx + 1 >= 0 && xx + 1 < W) ? (unsigned)(((yy * W + xx + 1) * Cin + xc4 * 4) * 4) : X3_OOB;
+      const int dyy = y0 + drow, dxx = x0 + 2 * dpr;
+      const bool dok = don && dyy < H && dc4 * 4 < Cout;
+      gd0 = (dok && dxx < W) ? (unsigned)(((dyy * W + dxx) * Cout + dc4 * 4) * 4) : X3_OOB;
+      gd1 = (dok && dxx + 1 < W) ? (unsigned)(((dyy * W + dxx + 1) * Cout + dc4 * 4) * 4) : X3_OOB;
+    }
+    __syncthreads();                                             // every wave is done with the previous item's planes
+    // prologue: x planes zs-1, zs, zs+1 -> ring slots 0, 1, 2; d_y plane zs -> slot 0 (all four loads in flight together);
+    // then registers <- x plane zs+2, d_y plane zs+1
+    Pair xr, dr;
+    {
+      const Pair p0 = load_x(zs - 1), p1 = load_x(zs), p2 = load_x(zs + 1), pd = load_dy(zs, ze);
+      xr = load_x(zs + 2);
+      dr = load_dy(zs + 1, ze);
+      store_x(0, p0); store_x(1, p1); store_x(2, p2); store_dy(0, pd);
+    }
+    __syncthreads();
+    const int nz = ze - zs;
+    for (int q = 0; q < nz; ++q) {                               // d_y plane zs + q; x planes zs + q - 1 .. zs + q + 1 in slots q .. q+2
+      // the planes loaded one iteration ago: x plane zs+q+2 -> the slot x plane zs+q-2 left, d_y plane zs+q+1 -> the other buffer
+      store_x((q + 3) & 3, xr);
+      store_dy((q + 1) & 1, dr);
+      xr = load_x(zs + q + 3);
+      dr = load_dy(zs + q + 2, ze);
+      compute(q, q & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- sum the 4 waves through LDS (fixed order), one partial per workgroup
+  float* red = reinterpret_cast<float*>(lds);
+  for (int w4 = 0; w4 < 4; ++w4) {
+    __syncthreads();
+    if (wave == w4) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int d = 0; d < NT; ++d) {
+          float4* slot = reinterpret_cast<float4*>(red + (u * NT + d) * 256) + lane;
+          float4 v = make_float4(acc[u][d][0], acc[u][d][1], acc[u][d][2], acc[u][d][3]);
+          if (w4 > 0) { const float4 o = *slot; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          *slot = v;
+        }
+      float4* slot = reinterpret_cast<float4*>(red + U * NT * 256) + lane;
+      float4 v = make_float4(accb[0], accb[1], accb[2], accb[3]);
+      if (w4 > 0) { const float4 o = *slot; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      *slot = v;
+    }
+  }
+  __syncthreads();
+  float* out = a.part + (size_t)blockIdx.x * RED_FL;
+  for (int i = tid; i < RED_FL; i += NTHR) out[i] = red[i];
+}
+
+struct X3WPlan { int cib, nco, u, np, gx, tiles_x, tiles_y, nchunk, zc, nitems, red_fl; };
+inline X3WPlan x3w_plan(int B, int D, int H, int W, int Cin, int Cout) {
+  X3WPlan p;
+  p.cib = Cin <= 4 ? 4 : 8;
+  p.nco = Cout <= 8 ? 8 : 16;
+  p.u = p.cib == 8 ? 5 : 3;
+  p.np = Cout <= 8;
+  p.red_fl = (p.u * (p.np ? 2 : 3) + 1) * 256;
+  p.tiles_x = cdiv(W, WTX);
+  p.tiles_y = cdiv(H, WTY);
+  const int cols = B * p.tiles_x * p.tiles_y;
+  const int slots = (p.cib == 8 && p.nco == 16) ? 256 : 512;      // resident workgroups (LDS: two per CU, one for 8 x 16)
+  // chunks of >= 8 planes (3 planes of prologue each), about eight items per workgroup to even out the tail
+  int n = (int)((8LL * slots + cols - 1) / cols);
+  const int maxn = D / 8 > 0 ? D / 8 : 1;
+  n = n < 1 ? 1 : (n > maxn ? maxn : n);
+  p.zc = cdiv(D, n);
+  p.nchunk = cdiv(D, p.zc);
+  p.nitems = cols * p.nchunk;
+  p.gx = p.nitems < slots ? p.nitems : slots;
+  return p;
+}
+
 #ifdef MODET_TUNING
 extern "C" int modet_debug_x3_timing(long long* buf) {       // not in the header: tuning builds only
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x3_dbg), &buf, sizeof(buf));
@@ -597,6 +848,32 @@ int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const f
   if (in_mean) return stats ? x3_launch<true, true>(step, a, w, ws, B, mode, p, s) : x3_launch<true, false>(step, a, w, ws, B, mode, p, s);
   return stats ? x3_launch<false, true>(step, a, w, ws, B, mode, p, s) : x3_launch<false, false>(step, a, w, ws, B, mode, p, s);
 }
+// ---- weight gradient
+int modetx_wgrad_partials_reduce(modet_step_ctx* defer, const float* part, float* red, float* dw, float* db, int gx, int Cin,
+                                 int Cout, int cib, int u, int layout, hipStream_t s);      // conv3d_bf16.hip
+bool modetx_x3_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout) {
+  return Cin % 4 == 0 && Cin >= 4 && Cin <= 8 && Cout % 4 == 0 && Cout >= 4 && Cout <= 16 && (int64_t)B * D * H * W >= 200000 &&
+         (int64_t)H * W * 16 * 4 < 0x7fffffffLL;
+}
+size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout);
+  return ((size_t)512 + 1) * p.red_fl * sizeof(float);           // workgroup partials + their column sums
+}
+int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
+                    int W, int Cin, int Cout, hipStream_t s) {
+  const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout);
+  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems};
+  if (p.cib == 4) {
+    if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 8, true>), dim3(p.gx), dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 16, false>), dim3(p.gx), dim3(NTHR), 0, s, a);
+  } else {
+    if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 8, true>), dim3(p.gx), dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 16, false>), dim3(p.gx), dim3(NTHR), 0, s, a);
+  }
+  float* red = (float*)ws + (size_t)p.gx * p.red_fl;
+  return modetx_wgrad_partials_reduce(defer, (const float*)ws, red, dw, db, p.gx, Cin, Cout, p.cib, p.u, p.np ? 1 : 0, s);
+}
+
 // the recorded 16-bit packing jobs with layout >= 2 belong to this file (conv3d_bf16.hip's prepack launch skips them)
 void modetx_x3_prepack_begin(modet_step_ctx* c, hipStream_t stream) {
   std::vector<PackBKey> jobs;

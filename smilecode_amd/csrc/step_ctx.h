@@ -36,6 +36,8 @@ struct BRedJob {
   const float* part; float* red; float* dw; float* dbias;
   int64_t row_fl;
   int gx, Cin, Cout, cib, u, ntb, gy, n_coblk;
+  int layout;   // 0: slot = group * 3 + dx, n = cout (conv3d_bf16_wgrad_kernel, conv_x3_wgrad_kernel<.., NP = false>)
+                // 1: slot = group * 2 + t, n = q * 8 + cout (conv_x3_wgrad_kernel<.., NP = true>: d_y shifted by q voxels)
 };
 
 struct modet_step_ctx {

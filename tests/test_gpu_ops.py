@@ -472,6 +472,27 @@ def test_conv_x3_march_vs_fp64(ops, cin, cout, shape):
     assert torch.equal(ops.conv3d_forward(xd, wd, bd, False), ops.conv3d_forward(xd, wd, bd, False))
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(8, 8, (40, 50, 52)), (4, 8, (37, 46, 63)), (8, 16, (33, 42, 75)), (8, 4, (40, 41, 66))])
+def test_conv_x3_weight_gradient_vs_fp64(ops, cin, cout, shape):
+    """csrc/conv3d_x3.hip, weight gradient: the z-marching bf16x3 kernel (Cin 4/8, Cout <= 16, >= 200 k voxels) against
+    ATen-CPU fp64, tile-ragged in every axis, batch 2; deterministic run to run.  d_w / d_bias sum n = 2*prod(shape)
+    products of O(1) in fp32 accumulators: the absolute tolerance grows like sqrt(n), as for the exact-f32 kernels."""
+    gen = torch.Generator().manual_seed(cin * 31 + cout)
+    x = torch.randn((2, cin) + shape, generator=gen).double()
+    gy = torch.randn((2, cout) + shape, generator=gen).double()
+    rw = torch.nn.grad.conv3d_weight(x, (cout, cin, 3, 3, 3), gy, padding=1)
+    rb = gy.sum((0, 2, 3, 4))
+    xd, gd = cl(x.numpy()), cl(gy.numpy())
+    dw, db = ops.conv3d_backward_weight(xd, gd, True)
+    wtol = 5e-4 * max(1.0, (2 * np.prod(shape) / 2e4) ** 0.5)
+    assert_close(np64(dw), rw.numpy(), atol=wtol, rtol=2e-4, what="x3 wgrad")
+    assert_close(np64(db), rb.numpy(), atol=wtol, rtol=2e-4, what="x3 dbias")
+    dw2, db2 = ops.conv3d_backward_weight(xd, gd, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "weight gradient must be run-to-run deterministic"
+    dw3, _ = ops.conv3d_backward_weight(xd, gd, False)
+    assert torch.equal(dw, dw3)
+
+
 def test_prepacked_conv_weights_follow_the_weights(ops):
     """ops.StepContext.prepacked(): pass 1 records the packing jobs (forward + data-gradient form of every layer), later
     passes pack them all in one launch from the CURRENT weights and the conv launches use that copy -- outputs and data
