@@ -60,7 +60,6 @@ class Trainer:
                 loss, sim, reg = self.loss(moving, fixed)
             with ops.trace_range("backward"):
                 loss.backward()
-                ops.join_pending()
                 self.fp.gather_grads()
             return loss.detach(), sim.detach(), reg.detach()
         # one caller-owned step context per computation this trainer has run (shape, device, grad mode): its recorded
@@ -78,7 +77,6 @@ class Trainer:
                 # the ~20 per-layer partial-tile reductions as one launch, written straight into the flat gradient buffer
                 with sc.deferred(self.fp.grad_destinations()) as scope:
                     loss.backward()
-                ops.join_pending()              # side-stream producers nobody consumed (none in ModeT: a safety net)
                 self.fp.gather_grads(scope.written)
         return loss.detach(), sim.detach(), reg.detach()
 
@@ -133,7 +131,6 @@ class Trainer:
             self.buckets.begin()
             with ops.trace_range("backward+allreduce"):
                 loss.backward()
-                ops.join_pending()
                 scale = self.buckets.finish()
             loss, sim, reg = loss.detach(), sim.detach(), reg.detach()
         else:

@@ -35,7 +35,6 @@ class _SplitBatch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ga, gb):
-        ops.wait_pending(ga, gb)                # the moving half may come from a feature warp's side-stream scatter
         B = ctx.B
         ref = ga if ga is not None else gb
         out = torch.empty((2 * B,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device)
@@ -77,8 +76,8 @@ class SpatialTransformer(nn.Module):
                        0 if self.mode == "bilinear" else 1, False)
         return ops.to_ncdhw(out)
 
-    def forward_cl(self, src_cl, flow_cl, add_flow=False, flow_bound=0, side_dsrc=False):
-        return ops.warp(src_cl, flow_cl, 0 if self.mode == "bilinear" else 1, add_flow, flow_bound, side_dsrc)
+    def forward_cl(self, src_cl, flow_cl, add_flow=False, flow_bound=0):
+        return ops.warp(src_cl, flow_cl, 0 if self.mode == "bilinear" else 1, add_flow, flow_bound)
 
 
 class _Conv3dParams(nn.Module):
@@ -378,26 +377,26 @@ class ModeT(nn.Module):
             flow = self.cwm5(self.mdt5(q5, k5))
 
         with ops.trace_range("level4"):
-            M4 = ST[3].forward_cl(M[3], flow, side_dsrc=True)    # d(M[3]) is consumed by the encoder's backward only
+            M4 = ST[3].forward_cl(M[3], flow)
             q4, k4 = self.projblock4.forward_pair(Fx[3], M4)
             w = self.cwm4(self.mdt4(q4, k4))
             flow = ST[2].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
         with ops.trace_range("level3"):
-            M3 = ST[2].forward_cl(M[2], flow, side_dsrc=True)
+            M3 = ST[2].forward_cl(M[2], flow)
             q3, k3 = self.projblock3.forward_pair(Fx[2], M3)
             w = self.cwm3(self.mdt3(q3, k3))
             flow = ST[1].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
         with ops.trace_range("level2"):
-            M2 = ST[1].forward_cl(M[1], flow, side_dsrc=True)
+            M2 = ST[1].forward_cl(M[1], flow)
             q2, k2 = self.projblock2.forward_pair(Fx[1], M2)
             w = self.mdt2(q2, k2)
             # w comes straight from the attention (expected offset in [-1,1]^3): bounded-flow backward, no atomics
             flow = ops.upsample2(ST[1].forward_cl(flow, w, add_flow=True, flow_bound=1), 2.0)
 
         with ops.trace_range("level1"):
-            M1 = ST[0].forward_cl(M[0], flow, side_dsrc=True)
+            M1 = ST[0].forward_cl(M[0], flow)
             q1, k1 = self.projblock1.forward_pair(Fx[0], M1)
             w = self.mdt1(q1, k1)
             flow = ST[0].forward_cl(flow, w, add_flow=True, flow_bound=1)

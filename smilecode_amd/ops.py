@@ -598,7 +598,6 @@ class _PoolTee(Function):
 
     @staticmethod
     def backward(ctx, gy, gx):
-        wait_pending(gx)
         B, D, H, W, C = ctx.shape
         if gy is None:
             return gx
@@ -633,7 +632,6 @@ class _PoolTeeSplit(Function):
 
     @staticmethod
     def backward(ctx, gy, ga, gb):
-        wait_pending(ga, gb)                    # a half's gradient may still be in flight on the side stream (feature warps)
         B, D, H, W, C = ctx.shape
         Bh = ctx.Bh
         dx = torch.empty(ctx.shape, dtype=torch.float32, device=(gy if gy is not None else ga if ga is not None else gb).device)
@@ -826,51 +824,10 @@ def neighbourhood_attention(q, k, rpb, heads, scale):
     return _NA.apply(q, k, rpb.contiguous(), heads, scale)
 
 
-# ---- the feature warps' d_src on a side stream ------------------------------------------------------------------------
-# The backward of a FEATURE warp (C > 3: the moving image's encoder features) has two halves of very different nature: d_flow
-# is a gather the rest of the backward pass waits for (it carries the gradient down the pyramid), d_src is a float-atomic
-# scatter (1.0 ms at level 1, bound by the L2 atomic unit, not by CUs or HBM) whose result is not needed before the encoder's
-# own backward at the very end.  So d_src runs on a side stream next to the pyramid heads and the coarse encoder levels
-# (MFMA- and HBM-bound kernels: they share the chip well with an atomic-bound one); its consumer joins.  Inside a hipGraph
-# capture the fork / join become parallel graph branches.  MODET_WARP_SIDE=0 keeps everything on one stream (A/B switch).
-_SIDE_STREAMS = {}
-_PENDING = {}                  # data_ptr of a tensor being produced on the side stream -> (ready event, tensors it reads)
-
-
-def _side_stream(device):
-    st = _SIDE_STREAMS.get(device.index)
-    if st is None:
-        st = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
-    return st
-
-
-def wait_pending(*tensors):
-    """make the current stream wait for tensors a side stream is still writing (no-op for anything else)"""
-    for t in tensors:
-        if t is None:
-            continue
-        e = _PENDING.pop(t.data_ptr(), None)
-        if e is not None:
-            torch.cuda.current_stream(t.device).wait_event(e[0])
-
-
-def join_pending():
-    """join every outstanding side-stream producer (end of backward: nothing may outlive the step)"""
-    for key in list(_PENDING):
-        ev, keep = _PENDING.pop(key)
-        torch.cuda.current_stream(keep[0].device).wait_event(ev)
-
-
-def _warp_side_enabled():
-    import os
-    return os.environ.get("MODET_WARP_SIDE", "1") != "0"
-
-
 class _Warp(Function):
     @staticmethod
-    def forward(ctx, src, flow, mode, add_flow, flow_bound=0, side_dsrc=False):
+    def forward(ctx, src, flow, mode, add_flow, flow_bound=0):
         _chk(src, flow)
-        ctx.side_dsrc = bool(side_dsrc)
         B, D, H, W, C = src.shape
         if tuple(flow.shape) != (B, D, H, W, 3):
             raise RuntimeError(f"warp: flow {tuple(flow.shape)} does not match src {tuple(src.shape)}")
@@ -893,38 +850,16 @@ class _Warp(Function):
         dsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
         dflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
         n = float(B) * D * H * W
-        L = _L()
-        if ctx.side_dsrc and dsrc is not None and dflow is not None and _warp_side_enabled():
-            main = torch.cuda.current_stream(src.device)
-            side = _side_stream(src.device)
-            with _Guard(src, f"warp_bwd[C{C}]", n * (30.0 * C + 40.0), 4.0 * n * (2 * C + 6)):
-                _lib.check(L.modet_warp_bwd(_p(src), _p(flow), _p(dout), None, _p(dflow), B, D, H, W, C, ctx.add_flow, 0,
-                                            _stream()), "modet_warp_bwd")
-            fork = torch.cuda.Event()
-            fork.record(main)                                   # d_out (and everything before it) is ready
-            side.wait_event(fork)
-            with torch.cuda.stream(side):
-                with _Guard(src, f"warp_bwd_dsrc[C{C}]", n * 30.0 * C, 4.0 * n * 2 * C):
-                    _lib.check(L.modet_warp_bwd(_p(src), _p(flow), _p(dout), _p(dsrc), None, B, D, H, W, C, ctx.add_flow, 0,
-                                                _stream()), "modet_warp_bwd")
-                done = torch.cuda.Event()
-                done.record(side)
-            # the consumer of d_src (the encoder's backward) joins; the inputs stay referenced until then, so the caching
-            # allocator cannot hand their memory to a main-stream kernel while the side stream still reads it
-            _PENDING[dsrc.data_ptr()] = (done, (src, flow, dout, dsrc))
-            return dsrc, dflow, None, None, None, None
         with _Guard(src, f"warp_bwd[C{C}]", n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6)):
-            _lib.check(L.modet_warp_bwd(_p(src), _p(flow), _p(dout), _p(dsrc), _p(dflow), B, D, H, W, C,
-                                        ctx.add_flow, ctx.flow_bound if C == 3 else 0, _stream()), "modet_warp_bwd")
-        return dsrc, dflow, None, None, None, None
+            _lib.check(_L().modet_warp_bwd(_p(src), _p(flow), _p(dout), _p(dsrc), _p(dflow), B, D, H, W, C,
+                                           ctx.add_flow, ctx.flow_bound if C == 3 else 0, _stream()), "modet_warp_bwd")
+        return dsrc, dflow, None, None, None
 
 
-def warp(src, flow, mode=0, add_flow=False, flow_bound=0, side_dsrc=False):
+def warp(src, flow, mode=0, add_flow=False, flow_bound=0):
     """SpatialTransformer on channels-last tensors; add_flow -> warp(src,flow)+flow.  reference: models.py:25-67.
-    flow_bound=1 promises |flow| <= 1 voxel (attention outputs): the backward then gathers d_src without atomics.
-    side_dsrc=True: the backward may compute d_src on a side stream; the CALLER guarantees that whatever consumes d_src
-    calls ``ops.wait_pending`` on it first (ModeT: the encoder's pool_tee_split / _SplitBatch backward do)."""
-    return _Warp.apply(src, flow, mode, add_flow, flow_bound, side_dsrc)
+    flow_bound=1 promises |flow| <= 1 voxel (attention outputs): the backward then gathers d_src without atomics."""
+    return _Warp.apply(src, flow, mode, add_flow, flow_bound)
 
 
 class _Upsample2(Function):
