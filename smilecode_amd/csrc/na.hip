@@ -8,6 +8,7 @@
 //    (ModeT-cu/modet/modet_kernel.cu:17-381), for callers shaped like ModeT-cu/functional.py.
 #include "common.h"
 #include "drpb_reduce.h"
+#include <cstdlib>
 
 namespace {
 
@@ -293,6 +294,243 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------ backward, z-marching
+// The same single-pass arithmetic as na_bwd_kernel for the LARGE levels (pyramid levels 1-2: 0.6-4.9 M voxels, where a
+// 4x4x16 tile stages 2.5x its own voxels -- 13 scalar / 8-byte loads per halo voxel -- and nothing overlaps the staging).
+// A workgroup owns an 8 x 32 column of (y, x), one thread per voxel, and MARCHES along z over a chunk of planes: the
+// (k, scale*q, d_out, u, lse) records of a plane (+1 halo in y and x: 1.33x) are loaded ONCE, through per-plane buffer
+// descriptors (out-of-volume voxels read zeros: no bounds tests, no selects), into registers while the previous plane is
+// being computed, then written into a 3-slot LDS ring; plane z needs slots z-1, z, z+1 in both roles.  The d_rpb partial
+// sums stay in registers for the whole chunk: one row per workgroup.
+constexpr int MY = 8, MX = 32, MHY = MY + 2, MHX = MX + 2, MHV = MHY * MHX;       // 340 halo'd voxels per plane
+constexpr int MSLOT = MHV * (2 * HD + AUX);                                       // floats per ring slot
+using NaBuf = __amdgpu_buffer_rsrc_t;
+constexpr unsigned NA_OOB = 0x80000000u;
+__device__ __forceinline__ NaBuf na_rsrc(const float* base, unsigned bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                     (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(u), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+struct NaMarchArgs {
+  const float* q; const float* k; const float* rpb; const float* out; const float* lse; const float* dout;
+  float* dq; float* dk; float* drpb_part;
+  int D, H, W, heads, tiles_x, tiles_y, nchunk, ZC;
+  float scale;
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void na_bwd_march_kernel(const NaMarchArgs a) {
+  // ring slot: k[MHV][6] | q'[MHV][6] | (g0, g1, g2, u)[MHV] | lse'[MHV]   with q' = scale * log2(e) * q, lse' = log2(e) * lse:
+  // the logits are kept in the base-2 domain (p = exp2(logit' - lse'): no multiply in front of v_exp_f32), d_k divides the
+  // factor out again at the end
+  __shared__ __attribute__((aligned(16))) float ring[3 * MSLOT];
+  __shared__ float red[27 * (NTHREADS / 64)];
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int D = a.D, H = a.H, W = a.W, heads = a.heads;
+  const int C = heads * HD, C3 = heads * 3;
+  int t = blockIdx.x;
+  const int x0 = (t % a.tiles_x) * MX; t /= a.tiles_x;
+  const int y0 = (t % a.tiles_y) * MY;
+  const int zs = (t / a.tiles_y) * a.ZC;
+  const int ze = zs + a.ZC < D ? zs + a.ZC : D;
+  // the 27 biases of this head: wave-uniform, read through the scalar unit (they stay in SGPRs, no LDS traffic)
+  float rp[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) rp[i] = a.rpb[h * 27 + i];  // (unscaled: the log2(e) rides on the fma that subtracts lse')
+  const int64_t V = (int64_t)D * H * W, HW = (int64_t)H * W;
+  const float* qb = a.q + (int64_t)b * V * C + h * HD;
+  const float* kb = a.k + (int64_t)b * V * C + h * HD;
+  const float* gb = a.dout + (int64_t)b * V * C3 + h * 3;
+  const float* ob = a.out + (int64_t)b * V * C3 + h * 3;
+  const float* lb = a.lse + (int64_t)b * V * heads + h;
+  const unsigned qbytes = (unsigned)(HW * C * 4), gbytes = (unsigned)(HW * C3 * 4), lbytes = (unsigned)(HW * heads * 4);
+  const float qmul = a.scale * LOG2E;
+
+  // staging items: halo voxel v = tid (and v = 256 + tid for the first MHV - 256 threads)
+  constexpr int NIT = (MHV + NTHREADS - 1) / NTHREADS;
+  unsigned oq[NIT], og[NIT], ol[NIT];
+  int sl_[NIT];
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int v = threadIdx.x + j * NTHREADS;
+    const bool on = v < MHV;
+    const int hy = on ? v / MHX : 0, hx = on ? v - hy * MHX : 0;
+    const int y = y0 + hy - 1, x = x0 + hx - 1;
+    const bool ok = on && y >= 0 && y < H && x >= 0 && x < W;
+    const unsigned n = (unsigned)(y * W + x);
+    oq[j] = ok ? n * (unsigned)(C * 4) : NA_OOB;
+    og[j] = ok ? n * (unsigned)(C3 * 4) : NA_OOB;
+    ol[j] = ok ? n * (unsigned)(heads * 4) : NA_OOB;
+    sl_[j] = on ? v : -1;
+  }
+  float2 rk[NIT][3], rq[NIT][3];
+  float rg[NIT][3], ro[NIT][3], rl[NIT];
+  auto load_plane = [&](int z) {
+    const bool live = z >= 0 && z < D;
+    const int64_t zo = live ? z : 0;
+    const NaBuf bq = na_rsrc(qb + zo * HW * C, live ? qbytes : 0u), bk = na_rsrc(kb + zo * HW * C, live ? qbytes : 0u);
+    const NaBuf bg = na_rsrc(gb + zo * HW * C3, live ? gbytes : 0u), bo = na_rsrc(ob + zo * HW * C3, live ? gbytes : 0u);
+    const NaBuf bl = na_rsrc(lb + zo * HW * heads, live ? lbytes : 0u);
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        rk[j][c] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(bk, (int)(oq[j] + c * 8), 0, 0));
+        rq[j][c] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(bq, (int)(oq[j] + c * 8), 0, 0));
+        rg[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bg, (int)(og[j] + c * 4), 0, 0));
+        ro[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bo, (int)(og[j] + c * 4), 0, 0));
+      }
+      rl[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bl, (int)ol[j], 0, 0));
+    }
+  };
+  auto store_plane = [&](int slot) {
+    float* kt = ring + slot * MSLOT;
+    float* qt = kt + MHV * HD;
+    float* gu = qt + MHV * HD;
+    float* ls = gu + MHV * 4;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      if (sl_[j] < 0) continue;
+      const int v = sl_[j];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        *reinterpret_cast<float2*>(kt + v * HD + c * 2) = rk[j][c];
+        *reinterpret_cast<float2*>(qt + v * HD + c * 2) = make_float2(rq[j][c].x * qmul, rq[j][c].y * qmul);
+      }
+      *reinterpret_cast<float4*>(gu + v * 4) =
+          make_float4(rg[j][0], rg[j][1], rg[j][2], rg[j][0] * ro[j][0] + rg[j][1] * ro[j][1] + rg[j][2] * ro[j][2]);
+      ls[v] = rl[j] * LOG2E;
+    }
+  };
+
+  const int tx = threadIdx.x % MX, ty = threadIdx.x / MX;
+  const int y = y0 + ty, x = x0 + tx;
+  const bool live = y < H && x < W;
+  const int hc = (ty + 1) * MHX + tx + 1;                   // this voxel inside a halo'd plane
+  float dlv[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) dlv[i] = 0.f;
+
+  // prologue: planes zs-1, zs, zs+1 -> slots 0, 1, 2; registers <- plane zs+2
+  load_plane(zs - 1); store_plane(0);
+  load_plane(zs); store_plane(1);
+  load_plane(zs + 1); store_plane(2);
+  load_plane(zs + 2);
+  __syncthreads();
+  for (int z = zs, i = 0; z < ze; ++z, ++i) {
+    const int s0 = i % 3, s1 = (i + 1) % 3, s2 = (i + 2) % 3;          // slots of planes z-1, z, z+1
+    if (live) {
+      const int sof[3] = {s0 * MSLOT, s1 * MSLOT, s2 * MSLOT};
+      const float* kc = ring + sof[1];
+      const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+      // ---- query role: this voxel's 27 logits against the keys around it
+      float qs[HD], dqa[HD];
+      load6(kc + MHV * HD + hc * HD, qs);                   // scale * log2(e) * q
+#pragma unroll
+      for (int c = 0; c < HD; ++c) dqa[c] = 0.f;
+      const float4 gc = *reinterpret_cast<const float4*>(kc + 2 * MHV * HD + hc * 4);
+      const float l = kc[2 * MHV * HD + MHV * 4 + hc];
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki) {
+        const float* kt = ring + sof[ki];
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            const int tt = ki * 9 + kj * 3 + kk;
+            float kv[HD];
+            load6(kt + (hc + (kj - 1) * MHX + (kk - 1)) * HD, kv);
+            float lg = fmaf(rp[tt], LOG2E, -l);
+#pragma unroll
+            for (int c = 0; c < HD; ++c) lg = fmaf(qs[c], kv[c], lg);
+            const float gt = (float)(ki - 1) * gc.x + (float)(kj - 1) * gc.y + (float)(kk - 1) * gc.z;
+            const float d = __builtin_amdgcn_exp2f(lg) * (gt - gc.w);
+            dlv[tt] += d;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) dqa[c] = fmaf(d, kv[c], dqa[c]);
+          }
+      }
+      float* dqp = a.dq + n * C + h * HD;
+#pragma unroll
+      for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dqp + c) = make_float2(dqa[c] * a.scale, dqa[c + 1] * a.scale);
+      // ---- key role: for each tap the query voxel m = n - off(t) sees this voxel's key under that tap.  No bounds test: a
+      // halo voxel outside the volume was staged with d_out = u = 0, its dlogit is p * (0 - 0) = 0 (p finite: lse = 0)
+      float kn[HD], dka[HD];
+      load6(kc + hc * HD, kn);
+#pragma unroll
+      for (int c = 0; c < HD; ++c) dka[c] = 0.f;
+#pragma unroll
+      for (int ki = 0; ki < 3; ++ki) {
+        const float* qt = ring + sof[2 - ki] + MHV * HD;   // plane z + (1 - ki)
+        const float* gu = qt + MHV * HD;
+        const float* ls = gu + MHV * 4;
+#pragma unroll
+        for (int kj = 0; kj < 3; ++kj)
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            const int lm = hc + (1 - kj) * MHX + (1 - kk);
+            float qv[HD];
+            load6(qt + lm * HD, qv);
+            float lg = fmaf(rp[ki * 9 + kj * 3 + kk], LOG2E, -ls[lm]);
+#pragma unroll
+            for (int c = 0; c < HD; ++c) lg = fmaf(qv[c], kn[c], lg);
+            const float4 gm = *reinterpret_cast<const float4*>(gu + lm * 4);
+            const float gt = (float)(ki - 1) * gm.x + (float)(kj - 1) * gm.y + (float)(kk - 1) * gm.z;
+            const float d = __builtin_amdgcn_exp2f(lg) * (gt - gm.w);
+#pragma unroll
+            for (int c = 0; c < HD; ++c) dka[c] = fmaf(d, qv[c], dka[c]);
+          }
+      }
+      float* dkp = a.dk + n * C + h * HD;
+      constexpr float ILOG2E = 0.6931471805599453f;          // q' carries log2(e): d_k = sum d * scale * q
+#pragma unroll
+      for (int c = 0; c < HD; c += 2) *reinterpret_cast<float2*>(dkp + c) = make_float2(dka[c] * ILOG2E, dka[c + 1] * ILOG2E);
+    }
+    __syncthreads();                                        // every thread is done with plane z-1 (slot s0)
+    store_plane(s0);                                        // plane z+2 takes its place
+    __syncthreads();
+    load_plane(z + 3);                                      // in flight during the next plane's arithmetic
+  }
+  // d_rpb: wave sums of the 27 accumulated dlogits (butterfly reduce-scatter), then the waves through LDS
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    const float r = wave_reduce_scatter32(dlv, lane);
+    if ((lane & 1) == 0 && (lane >> 1) < 27) red[wv * 27 + (lane >> 1)] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    float s = 0.f;
+    for (int w = 0; w < NTHREADS / 64; ++w) s += red[w * 27 + threadIdx.x];
+    const int64_t blk = ((int64_t)b * gridDim.y + h) * gridDim.x + blockIdx.x;
+    a.drpb_part[blk * 27 + threadIdx.x] = s;
+  }
+}
+
+struct NaMarchPlan { int tiles_x, tiles_y, nchunk, zc; bool on; };
+inline NaMarchPlan na_march_plan(int B, int D, int H, int W, int heads, int hd) {
+  NaMarchPlan p;
+  p.tiles_x = cdiv(W, MX); p.tiles_y = cdiv(H, MY);
+  // the large levels only (the small ones are latency-bound either way and the 4x4x16 tiles give them more workgroups),
+  // planes below 2 GiB per tensor (32-bit descriptor offsets)
+  p.on = hd == HD && (int64_t)D * H * W >= 1500000 && (int64_t)H * W * heads * HD * 4 < 0x7fffffffLL;
+  const int cols = B * heads * p.tiles_x * p.tiles_y;
+  // z chunks of >= 8 planes, about WANT workgroups in all: the kernel is latency-bound (two waves per SIMD), many short
+  // workgroups that the dispatcher interleaves beat few long ones although every chunk pays three planes of prologue
+  // (measured at level 1: 1560 workgroups of 13 planes 0.37 ms, 480 of 40 planes 0.40 ms)
+  int want = 2000;
+#ifdef MODET_TUNING
+  if (const char* e = getenv("MODET_NA_WGS")) want = atoi(e);
+  if (const char* e = getenv("MODET_NA_MARCH")) p.on = p.on && e[0] != '0';
+#endif
+  int best = (want + cols - 1) / cols;
+  const int maxn = D / 8 > 0 ? D / 8 : 1;
+  best = best < 1 ? 1 : (best > maxn ? maxn : best);
+  p.zc = cdiv(D, best);
+  p.nchunk = cdiv(D, p.zc);
+  return p;
+}
+
 // ------------------------------------------------------------------------------------------ any head_dim % 8 == 0
 // The same two kernels for head dimensions other than ModeT's 6 (8 ... 128): e.g. Im2Grid's CoTr
 // ("Baseline methods/Im2Grid/models.py":276-322) is this attention with one head over all C channels, no bias, no
@@ -542,7 +780,7 @@ int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, f
 }
 
 size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads) {
-  const TileGeom g = geom(D, H, W);
+  const TileGeom g = geom(D, H, W);                      // (at least as many rows as the z-marching kernel's workgroups)
   size_t fl = (size_t)B * heads * g.tiles_x * g.tiles_y * g.tiles_z * 27;
   fl += fl & 1;                                        // keep the fp64 scratch that follows 8-byte aligned
   return fl * sizeof(float) + drpb_scratch_bytes(B, heads);
@@ -557,6 +795,16 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
   if (hd != HD && !gen_hd_ok(hd)) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_na_bwd_ws_bytes(B, D, H, W, heads)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  const NaMarchPlan mp = na_march_plan(B, D, H, W, heads, hd);
+  if (mp.on) {
+    const int64_t nblk = (int64_t)mp.tiles_x * mp.tiles_y * mp.nchunk;
+    NaMarchArgs a{q, k, rpb, out, lse, d_out, d_q, d_k, (float*)ws, D, H, W, heads, mp.tiles_x, mp.tiles_y, mp.nchunk, mp.zc, scale};
+    hipLaunchKernelGGL(na_bwd_march_kernel, dim3((unsigned)nblk, heads, B), dim3(NTHREADS), 0, s, a);
+    size_t fl = (size_t)B * heads * nblk * 27;
+    fl += fl & 1;
+    drpb_reduce((float*)ws, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
+    return modet_launch_status();
+  }
   const TileGeom g = geom(D, H, W);
   const int64_t nblk = (int64_t)g.tiles_x * g.tiles_y * g.tiles_z;
   float* part = (float*)ws;

@@ -190,6 +190,30 @@ def test_na_fused_vs_oracle_ragged(ops, orc, shape, heads):
     assert_close(np64(dr), rr.numpy(), atol=2e-4, what="na drpb")
 
 
+@pytest.mark.parametrize("shape,heads,B", [((97, 122, 131), 1, 1), ((100, 101, 150), 2, 2)])
+def test_na_backward_z_march_vs_oracle(ops, orc, shape, heads, B):
+    """na_bwd_march_kernel (volumes >= 1.5 M voxels: pyramid level 1): plane ring, buffer-descriptor halo, chunked z --
+    ragged against the 8 x 32 columns and the z chunks, 1 and 2 heads, batch 1 and 2; d_q, d_k and the d_rpb partial rows
+    (accumulated in registers over a whole chunk) against fp64 autograd of the oracle; deterministic run to run."""
+    gen = torch.Generator().manual_seed(11)
+    C = heads * 6
+    q = torch.randn((B,) + shape + (C,), generator=gen).double().requires_grad_(True)
+    k = torch.randn((B,) + shape + (C,), generator=gen).double().requires_grad_(True)
+    rpb = (0.5 * torch.randn((heads, 3, 3, 3), generator=gen)).double().requires_grad_(True)
+    ref = orc.mode_transformer(q, k, rpb, heads, 0.7)
+    gy = torch.randn(ref.shape, generator=gen).double()
+    rq, rk, rr = torch.autograd.grad(ref, [q, k, rpb], gy)
+    qd, kd, rd = (t.detach().float().cuda().requires_grad_(True) for t in (q, k, rpb))
+    out = ops.neighbourhood_attention(qd, kd, rd, heads, 0.7)
+    gyd = gy.permute(0, 2, 3, 4, 1).float().contiguous().cuda()
+    dq, dk, dr = torch.autograd.grad(out, [qd, kd, rd], gyd, retain_graph=True)
+    assert_close(np64(dq), rq.numpy(), what="na dq (z-march)")
+    assert_close(np64(dk), rk.numpy(), what="na dk (z-march)")
+    assert float(np.abs(np64(dr) - rr.numpy()).max()) <= 2e-5 * float(rr.abs().max()) + 2e-4, "na drpb (z-march)"
+    dq2, dk2, dr2 = torch.autograd.grad(out, [qd, kd, rd], gyd)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dr, dr2), "no atomics: bit-identical re-run"
+
+
 # ------------------------------------------------------------------------------------------------ warp
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_warp_golden(ops, tag):
