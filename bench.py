@@ -38,20 +38,48 @@ def log(*a):
 
 
 def family(tag):
-    """launch tag -> kernel family (= the kernel symbol rocprof reports)"""
-    if tag.startswith("conv_fwd[1->") :
+    """launch tag -> kernel family (= the kernel symbol rocprof reports, template arguments stripped).  The conv tags carry
+    the family the library picked for that shape (ops._conv_tag): @x3 = z-marching bf16x3, @split = tiled bf16x3."""
+    base = tag.split("[")[0]
+    if tag.startswith("conv_fwd[1->"):
         return "conv_c1_fwd_kernel"
     if tag.startswith("conv_wgrad[1->"):
-        return "conv_c1_wgrad_kernel"
-    if tag.startswith("conv_bf16_fwd") or tag.startswith("conv_bf16_dgrad"):
+        return "conv_c1_wgrad_mfma_kernel"
+    if base in ("conv_bf16_fwd", "conv_bf16_dgrad"):
         return "conv3d_bf16_kernel"
-    if tag.startswith("conv_bf16_wgrad"):
+    if base == "conv_bf16_wgrad":
         return "conv3d_bf16_wgrad_kernel"
-    if tag.startswith("conv_fwd") or tag.startswith("conv_dgrad"):
-        return "conv3d_mfma_kernel"
-    if tag.startswith("conv_wgrad"):
-        return "conv3d_wgrad_kernel"
-    return tag.split("[")[0]
+    if base in ("conv_fwd", "conv_dgrad"):
+        return "conv_x3_kernel" if tag.endswith("@x3") else ("conv3d_bf16_kernel<SP=3>" if tag.endswith("@split") else "conv3d_mfma_kernel")
+    if base == "conv_wgrad":
+        return "conv_x3_wgrad_kernel" if tag.endswith("@x3") else "conv3d_wgrad_kernel"
+    if base == "warp_bwd":
+        return "warp_bwd_kernel"
+    if base == "warp_bwd_gather3":
+        return "warp_bwd_gather3_tiled_kernel"
+    return base
+
+
+# fp32-accurate matrix work on the bf16 pipe costs six bf16 MFMAs per fp32 product (csrc/conv3d_x3.hip): its ceiling in
+# algorithmic (fp32) FLOP/s is the dense bf16 peak / 6
+PEAK_MFMA_BF16_TFLOPS = 2500.0
+MFMA_F32_FAMILIES = ("conv3d_mfma_kernel", "conv3d_wgrad_kernel", "conv_c1_wgrad_mfma_kernel")
+MFMA_X3_FAMILIES = ("conv_x3_kernel", "conv_x3_wgrad_kernel", "conv3d_bf16_kernel<SP=3>")
+
+
+def roof_of(fam, flops, nbytes, sec):
+    """roofline object of one kernel family from its algorithmic work and summed duration"""
+    if fam in MFMA_F32_FAMILIES:
+        ach = flops / sec / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS}
+    if fam in MFMA_X3_FAMILIES:
+        ach, peak = flops / sec / 1e12, PEAK_MFMA_BF16_TFLOPS / 6.0
+        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "peak_note": "fp32-accurate FLOPs on the bf16 pipe: dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per "
+                             "fp32 product; against the exact-f32 MFMA peak (157.3) the same number is frac_of_f32_mfma_peak",
+                "frac_of_f32_mfma_peak": ach / PEAK_MFMA_F32_TFLOPS}
+    ach = nbytes / sec / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
 
 
 def cpu_baseline(shape, workload, budget_s=40.0):
@@ -518,27 +546,30 @@ def main():
                 for f in d:
                     d[f] += v[f]
             sec = d["ms"] * 1e-3
-            if dominant.startswith("conv3d"):
-                ach = d["flops"] / sec / 1e12
-                roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None}
-            else:
-                ach = d["bytes"] / sec / 1e9
-                roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": ach / PEAK_HBM_GBS, "traffic": None}
+            roof = roof_of(dominant, d["flops"], d["bytes"], sec)
+            roof["traffic"] = None
             roof.update({"kernel": dominant, "launches": d["calls"], "launches_per_step": d["calls"] / roof_steps,
                          "avg_launch_ms": d["ms"] / d["calls"], "share_of_step": d["ms"] / ((dt_eager or dt) * 1e3),
                          "measured_over": ("%d eager steps right after the timed region (the timed region replays a hipGraph, "
                                            "which cannot carry per-kernel events)" % roof_steps) if graphed else "the timed region",
                          "note": "all launches of this kernel symbol in the K timed steps; algorithmic work summed per "
-                                 "launch shape (DESIGN.md section 4); the weights are packed once per step by one separate launch (modet_conv3d_prepack_*), outside these brackets"
-                                 if dominant.startswith("conv3d_mfma") else "all launches of this kernel in the K timed steps"})
+                                 "launch shape (DESIGN.md section 4)" + ("; warp_bwd_kernel is bound by the L2 float-atomic "
+                                 "unit (its d_src scatter), not by HBM: DESIGN.md section 4" if dominant == "warp_bwd_kernel" else "")})
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc runs
             if os.path.exists(pmc):
                 try:
-                    roof["traffic"] = json.load(open(pmc)).get(dominant)
+                    pj = json.load(open(pmc))
+                    roof["traffic"] = pj.get(dominant, pj.get("families", {}).get(dominant, {}).get("hbm_bytes_per_launch_corrected"))
                 except Exception:
                     pass
+        # the same object for the six largest families of the profiled warm-up steps (median of those steps)
+        tot_ms = sum(v["ms"] for v in fams.values()) or 1.0
+        roof_top = []
+        for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])[:6]:
+            r = roof_of(k, v["flops"], v["bytes"], v["ms"] * 1e-3)
+            r.pop("peak_note", None)
+            r.update({"kernel": k, "ms_per_step": v["ms"], "launches_per_step": v["calls"], "share_of_kernel_time": v["ms"] / tot_ms})
+            roof_top.append(r)
         out = {
             "metric": "volume-pairs/sec (%dx%dx%d) %s" % (*shape, "fwd+bwd" if args.workload == "train" else "fwd+warp"),
             "value": pairs / dt, "unit": "volume-pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -549,7 +580,7 @@ def main():
                 if args.workload == "train" else "forward+warp")),
                 "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}",
                 "allreduce": "3 buckets from backward hooks, overlapped" if args.overlap else "one flat all-reduce after backward"},
-            "roofline": roof, "host_enqueue_ms_per_step": host_graph_ms if graphed else host_ms,
+            "roofline": roof, "roofline_top": roof_top, "host_enqueue_ms_per_step": host_graph_ms if graphed else host_ms,
             "hip_graph": graphed, "eager": {"host_enqueue_ms_per_step": host_ms,
                                             "ms_per_step": dt_eager / roof_steps * 1e3 if dt_eager else None},
             # proof of the N-rank run: what torch.distributed itself reports, and the step's one collective timed alone

@@ -104,10 +104,15 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
  * as an fp32 MFMA implicit GEMM.  x (B,D,H,W,Cin), y (B,D,H,W,Cout) channels-last;
  * w in the reference's parameter layout (Cout,Cin,3,3,3); bias (Cout) or NULL.
  * act: 0 = none, 1 = LeakyReLU(0.1) fused (ConvBlock, models.py:119-133). */
-/* 1 if the fp32 conv entry points run the opt-in "bf16x3" fp32 emulation (env MODET_CONV_SPLIT=1 at first use: fp32
- * tensors, every product as six exact bf16 piece products on the bf16 matrix pipe, error <= 3 * 2^-24 |a b|), else 0
- * (default: exact-f32 MFMA, bitwise an fmaf chain). */
-int modet_conv3d_uses_bf16x3(void);
+/* Which kernel family the fp32 conv entry points run for this launch shape (chosen per shape);
+ * pass: 0 = forward (Cin -> Cout), 1 = data gradient of that layer, 2 = its weight gradient:
+ *   0 = exact-f32 MFMA implicit GEMM (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain)            conv3d.hip
+ *   1 = "bf16x3" fp32 emulation, tiled: fp32 tensors, every operand split into three bf16 pieces, every product as six
+ *       exact piece products on the bf16 matrix pipe, error <= 3 * 2^-24 |a b|                  conv3d_bf16.hip (SP = 3)
+ *   2 = the same arithmetic as a z-marching kernel for the few-channel full-resolution layers   conv3d_x3.hip
+ * Families 1 and 2 produce the fused InstanceNorm statistics (modet_conv3d_fwd_stats) at no cost for every Cout.
+ * Env (read at first use): MODET_CONV_X3=0 disables family 2, MODET_CONV_SPLIT=0 / 1 disables / forces family 1. */
+int modet_conv3d_kernel_family(int B, int D, int H, int W, int Cin, int Cout, int pass);
 size_t modet_conv3d_ws_bytes(int Cin, int Cout);
 /* `step` (every conv entry point that packs weights): NULL, or the context whose recorded packing jobs apply, see
  * modet_conv3d_prepack_* below. */

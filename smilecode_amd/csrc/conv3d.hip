@@ -1441,9 +1441,15 @@ static bool use_x3_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
   return on && modetx_x3_wgrad_eligible(B, D, H, W, Cin, Cout);
 }
-static bool use_split(int Cin, int Cout) {
-  static const bool on = [] { const char* e = getenv("MODET_CONV_SPLIT"); return e && e[0] == '1'; }();
-  return on && modetx_split_eligible(Cin, Cout);
+// The tiled bf16x3 kernels of conv3d_bf16.hip (SP = 3): default for the MID levels of the pyramid -- Cin >= 16 channels at
+// 16 k .. 1 M voxels (levels 3-4: 16->32 / 32->32 forward 0.077 / 0.131 -> 0.054 / 0.086 ms, 64->64 0.080 -> 0.067); the
+// few-channel full-resolution layers take conv3d_x3.hip, level 5 (2.4 k voxels) stays on the exact-f32 kernels.
+// MODET_CONV_SPLIT=1 forces them for every eligible shape, =0 switches them off.
+static bool use_split(int Cin, int Cout, int64_t nvox = -1) {
+  static const int mode = [] { const char* e = getenv("MODET_CONV_SPLIT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  if (!modetx_split_eligible(Cin, Cout) || mode == 0) return false;
+  if (mode == 1) return true;
+  return nvox >= 16000 && Cin >= 16 && Cin % 16 == 0 && Cout >= 16;
 }
 
 extern "C" {
@@ -1454,7 +1460,13 @@ int modet_debug_conv_timing(long long* buf) {       // not in the header: tuning
 }
 #endif
 
-int modet_conv3d_uses_bf16x3(void) { return use_split(4, 4) ? 1 : 0; }
+int modet_conv3d_kernel_family(int B, int D, int H, int W, int Cin, int Cout, int pass) {
+  if (Cin == 1) return 0;
+  if (pass == 2) return use_x3_wgrad(B, D, H, W, Cin, Cout) ? 2 : 0;
+  const int ci = pass == 1 ? Cout : Cin, co = pass == 1 ? Cin : Cout;      // the data gradient convolves d_y (Cout channels)
+  if (use_x3(B, D, H, W, ci, co)) return 2;
+  return use_split(ci, co, (int64_t)B * D * H * W) ? 1 : 0;
+}
 
 int modet_step_ctx_create(modet_step_ctx_t** out) {
   MODET_CHECK_PTR(out);
@@ -1556,7 +1568,7 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
     if (ws_bytes < modetx_x3_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     return modetx_x3_conv(step, x, w, bias, y, ws, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
   }
-  if (!act && use_split(Cin, Cout)) {
+  if (!act && use_split(Cin, Cout, (int64_t)B * D * H * W)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     return modetx_split_conv(step, x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
   }
@@ -1582,7 +1594,7 @@ size_t modet_conv3d_normin_stats_bytes(int B, int D, int H, int W, int Cin, int 
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
   if (use_x3(B, D, H, W, Cin, Cout)) return modetx_x3_stats_bytes(B, D, H, W, Cin, Cout);    // one row per workgroup
-  if (use_split(Cin, Cout)) return modetx_split_stats_bytes(B, D, H, W, Cin, Cout);     // one row per output tile
+  if (use_split(Cin, Cout, (int64_t)B * D * H * W)) return modetx_split_stats_bytes(B, D, H, W, Cin, Cout);     // one row per output tile
   // [sample][Cout] shift header, then [sample][workgroup][Cout][2] partial sums of (y - shift), (y - shift)^2; reduced by
   // modet_instnorm_lrelu_fwd_stats / modet_instnorm_stats
   return ((size_t)B * Cout + (size_t)B * conv_stats_rows(B, D, H, W, Cin, Cout) * Cout * 2) * sizeof(float);
@@ -1602,7 +1614,7 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
                        (const float*)nullptr, (const float*)nullptr, stats, B, D, H, W, Cin, Cout);
     return modetx_x3_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream);
   }
-  if (use_split(Cin, Cout)) {
+  if (use_split(Cin, Cout, (int64_t)B * D * H * W)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     return modetx_split_conv(step, x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
   }
@@ -1643,7 +1655,7 @@ int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws
     if (ws_bytes < modetx_x3_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
     return modetx_x3_conv(step, d_y, w, nullptr, d_x, ws, nullptr, nullptr, nullptr, B, D, H, W, Cout, Cin, 0, 1, (hipStream_t)stream);
   }
-  if (use_split(Cout, Cin)) {
+  if (use_split(Cout, Cin, (int64_t)B * D * H * W)) {
     if (ws_bytes < modetx_split_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
     return modetx_split_conv(step, d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, (hipStream_t)stream);
   }

@@ -150,6 +150,25 @@ class trace_range:
         _ROCTX.pop()
 
 
+_FAM_CACHE = {}
+_FAM_SUFFIX = ("", "@split", "@x3")
+
+
+def _conv_tag(kind, x_shape, Cin, Cout):
+    """KernelTimer tag of a conv launch: 'conv_fwd[8->8]@x3' names the kernel family that runs this shape (exact-f32
+    MFMA: no suffix; tiled bf16x3: @split; z-marching bf16x3: @x3) -- only evaluated while a timer is installed"""
+    if _TIMER is None:
+        return None
+    key = (kind, tuple(x_shape[:4]), Cin, Cout)
+    t = _FAM_CACHE.get(key)
+    if t is None:
+        B, D, H, W = x_shape[:4]
+        fam = _L().modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind])
+        arrow = f"{Cout}->{Cin}" if kind == "dgrad" else f"{Cin}->{Cout}"
+        t = _FAM_CACHE[key] = f"conv_{kind}[{arrow}]{_FAM_SUFFIX[fam]}"
+    return t
+
+
 # ------------------------------------------------------------------------------------------------ raw calls
 def conv3d_forward(x, w, b, act, step=None):
     _chk(x, w, b)
@@ -163,7 +182,7 @@ def conv3d_forward(x, w, b, act, step=None):
     nb = L.modet_conv3d_ws_bytes(Cin, Cout)
     ws = _ws(nb, x)
     n = float(B) * D * H * W
-    with _Guard(x, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+    with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         _lib.check(L.modet_conv3d_fwd(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, B, D, H, W, Cin, Cout, int(act),
                                       _stream(), _h(step)), "modet_conv3d_fwd")
     return y
@@ -204,7 +223,7 @@ def conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats=True, step=None):
     sb = L.modet_conv3d_normin_stats_bytes(B, D, H, W, Cin, Cout) if want_stats else 0
     stats = torch.empty(sb // 4, dtype=torch.float32, device=x_raw.device) if sb > 0 else None
     n = float(B) * D * H * W
-    with _Guard(x_raw, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+    with _Guard(x_raw, _conv_tag("fwd", x_raw.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         _lib.check(L.modet_conv3d_fwd_normin(_p(x_raw), _p(mean), _p(rstd), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb,
                                              B, D, H, W, Cin, Cout, _stream(), _h(step)), "modet_conv3d_fwd_normin")
     return y, stats
@@ -219,7 +238,7 @@ def conv3d_backward_data(dy, w, Cin, step=None):
     nb = L.modet_conv3d_ws_bytes(Cin, Cout)
     ws = _ws(nb, dy)
     n = float(B) * D * H * W
-    with _Guard(dy, f"conv_dgrad[{Cout}->{Cin}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+    with _Guard(dy, _conv_tag("dgrad", dy.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         _lib.check(L.modet_conv3d_bwd_data(_p(dy), _p(w), _p(dx), _p(ws), nb, B, D, H, W, Cin, Cout, _stream(), _h(step)),
                    "modet_conv3d_bwd_data")
     return dx
@@ -374,7 +393,7 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
     dst = scope.destinations(w, b, want_bias) if scope is not None else None
     if dst is not None:
         dw, db = dst
-        with _Guard(x, f"conv_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+        with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
             _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
                                                        Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
         scope._keep.append(ws)                                # the partial tiles must survive until the flush
@@ -384,7 +403,7 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
         return None, None
     dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
-    with _Guard(x, f"conv_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+    with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         if y_act is not None:
             _lib.check(L.modet_conv3d_bwd_weight_act(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
                                                      Cout, _stream()), "modet_conv3d_bwd_weight_act")
@@ -439,7 +458,7 @@ class _Conv3dStats(Function):
         sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)
         stats = torch.empty(sb // 4, dtype=torch.float32, device=x.device)
         n = float(B) * D * H * W
-        with _Guard(x, f"conv_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+        with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
             _lib.check(L.modet_conv3d_fwd_stats(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
                                                 Cout, _stream(), _h(ctx.step)), "modet_conv3d_fwd_stats")
         ctx.has_bias = b is not None
@@ -465,7 +484,7 @@ def _fuse_stats(x, w):
     L = _L()
     if L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout) == 0:
         return False
-    if L.modet_conv3d_uses_bf16x3():        # opt-in fp32 emulation kernels carry the statistics for every shape at no cost
+    if L.modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 0) != 0:  # the bf16x3 kernels carry the statistics at no cost
         return True
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
     return Cout in (4, 8, 16) or not needs_grad
@@ -850,7 +869,8 @@ class _Warp(Function):
         dsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
         dflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
         n = float(B) * D * H * W
-        with _Guard(src, f"warp_bwd[C{C}]", n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6)):
+        tag = "warp_bwd_gather3[C3]" if (C == 3 and ctx.flow_bound) else f"warp_bwd[C{C}]"     # the kernel that runs
+        with _Guard(src, tag, n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6)):
             _lib.check(_L().modet_warp_bwd(_p(src), _p(flow), _p(dout), _p(dsrc), _p(dflow), B, D, H, W, C,
                                            ctx.add_flow, ctx.flow_bound if C == 3 else 0, _stream()), "modet_warp_bwd")
         return dsrc, dflow, None, None, None

@@ -13,8 +13,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smilecode_amd import ops  # noqa: E402
 
-L1, L2 = (160, 192, 160), (80, 96, 80)
+L1, L2, L3, L4 = (160, 192, 160), (80, 96, 80), (40, 48, 40), (20, 24, 20)
 LAYERS = [(4, 8, L1), (8, 8, L1), (8, 16, L2), (16, 16, L2)]
+if os.environ.get("BENCH_CONV_LEVELS") == "34":
+    LAYERS = [(16, 32, L3), (32, 32, L3), (32, 64, L4), (64, 64, L4)]
 
 
 def timed(fn, iters=15):

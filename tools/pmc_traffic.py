@@ -44,9 +44,8 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes o
                "MI355X_MICROARCH.md (gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads); averaged over all launches of "
                "the kernel symbol in a step",
        "families": fams}
-for k in ("conv3d_mfma_kernel", "conv3d_wgrad_kernel", "warp_bwd_kernel"):      # bench.py reads the dominant family here
-    if k in fams:
-        out[k] = fams[k]["hbm_bytes_per_launch_corrected"]
+for k in fams:                                   # bench.py reads the dominant family's per-launch bytes from the top level
+    out[k] = fams[k]["hbm_bytes_per_launch_corrected"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 if len(sys.argv) > 4:
     with open(sys.argv[4], "w") as f:
