@@ -13,7 +13,7 @@ acc = defaultdict(lambda: defaultdict(list))
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         k = r["Kernel_Name"]
-        if "conv3d" not in k and "conv_c1" not in k:
+        if "conv3d" not in k and "conv_c1" not in k and "conv_x3" not in k:
             continue
         k = re.sub(r"\(anonymous namespace\)::", "", k)
         k = re.sub(r"^void ", "", k)
