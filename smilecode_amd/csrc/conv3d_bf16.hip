@@ -821,6 +821,12 @@ inline int bf16_tiles_per_sample(int D, int H, int W, int Cin, int Cout) {
   return cdiv(W, TX) * cdiv(H, p.ty) * cdiv(D, p.tz);
 }
 
+// MODET_CONV_X3 = 0 keeps the tiled kernels (A/B measurements); otherwise the z-marching kernel takes the few-channel layers
+inline bool x3_on() {
+  static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 }  // namespace
 
 // ---- internal interface for conv3d.hip (C++ linkage, not part of the ABI): the fp32 entry points route eligible shapes here
@@ -881,6 +887,10 @@ void modetx_bf16_defer_flush(modet_step_ctx* c, hipStream_t stream) {
 
 // ---- 16-bit side of modet_conv3d_prepack_* (conv3d.hip owns the entry points; these jobs follow the fp32 jobs in the arena)
 void modetx_x3_prepack_begin(modet_step_ctx* c, hipStream_t stream);          // conv3d_x3.hip: its jobs have layout >= 2
+bool modetx_x3_bf16_eligible(int B, int D, int H, int W, int Cin, int Cout, int x_bf16);
+int modetx_x3_bf16_rows_per_sample(int B, int D, int H, int W, int Cin, int Cout);
+int modetx_x3_bf16_conv(modet_step_ctx* step, const void* x, int x_bf16, const float* w, const float* bias, void* y, int y_bf16,
+                        void* ws, float* stats, int B, int D, int H, int W, int Cin, int Cout, int mode, hipStream_t s);
 size_t modetx_bf16_prepack_bytes(modet_step_ctx* c) {
   std::lock_guard<std::mutex> lk(c->mu);
   size_t n = 0;
@@ -927,7 +937,10 @@ size_t modet_conv3d_bf16_stats_bytes(int B, int D, int H, int W, int Cin, int Co
   if (Cout % 4 != 0 || Cout > 128) return 0;
   // [sample][Cout] shift header, one row [Cout][2] per (sample, output tile), and a tail of 64 rows per sample for the
   // first stage of modet_instnorm_lrelu_fwd_stats_bf16's reduction
-  return ((size_t)B * Cout + (size_t)B * (bf16_tiles_per_sample(D, H, W, Cin, Cout) + 64) * Cout * 2) * sizeof(float);
+  // the row count of the kernel with FEWER rows would do for either input type; fp32 and bf16 inputs share a plan anyway
+  const int rows = (x3_on() && modetx_x3_bf16_eligible(B, D, H, W, Cin, Cout, Cin % 8 == 0)) ? modetx_x3_bf16_rows_per_sample(B, D, H, W, Cin, Cout)
+                                                                                         : bf16_tiles_per_sample(D, H, W, Cin, Cout);
+  return ((size_t)B * Cout + (size_t)B * (rows + 64) * Cout * 2) * sizeof(float);
 }
 
 int modet_conv3d_bf16_fwd(const void* x, int x_bf16, const float* w, const float* bias, void* y, void* ws, size_t ws_bytes,
@@ -938,8 +951,15 @@ int modet_conv3d_bf16_fwd(const void* x, int x_bf16, const float* w, const float
   if (Cout % 8 != 0 || (x_bf16 ? Cin % 8 != 0 : Cin % 4 != 0)) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < bf16_wpk_elems(Cin, Cout) * sizeof(unsigned short)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  if (stats && (stats_bytes < modet_conv3d_bf16_stats_bytes(B, D, H, W, Cin, Cout) || stats_bytes == 0)) return MODET_ERR_WORKSPACE;
+  if (x3_on() && modetx_x3_bf16_eligible(B, D, H, W, Cin, Cout, x_bf16)) {
+    if (stats) {
+      if (x_bf16) hipLaunchKernelGGL(conv_shift_bf16_kernel<true>, dim3(cdiv(B * Cout, 4)), dim3(256), 0, s, x, w, bias, stats, B, D, H, W, Cin, Cout);
+      else hipLaunchKernelGGL(conv_shift_bf16_kernel<false>, dim3(cdiv(B * Cout, 4)), dim3(256), 0, s, x, w, bias, stats, B, D, H, W, Cin, Cout);
+    }
+    return modetx_x3_bf16_conv(step, x, x_bf16, w, bias, y, 1, ws, stats, B, D, H, W, Cin, Cout, 0, s);
+  }
   if (stats) {
-    if (stats_bytes < modet_conv3d_bf16_stats_bytes(B, D, H, W, Cin, Cout) || stats_bytes == 0) return MODET_ERR_WORKSPACE;
     return x_bf16 ? launch_bf16<true, true, true>(step, x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, s)
                   : launch_bf16<false, true, true>(step, x, w, bias, y, ws, stats, B, D, H, W, Cin, Cout, 0, s);
   }
@@ -955,6 +975,8 @@ int modet_conv3d_bf16_bwd_data(const void* d_y, const float* w, void* d_x, int d
   if (ws_bytes < bf16_wpk_elems(Cout, Cin) * sizeof(unsigned short)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   // a convolution of d_y (Cout channels, bf16) producing Cin channels
+  if (x3_on() && modetx_x3_bf16_eligible(B, D, H, W, Cout, Cin, 1))
+    return modetx_x3_bf16_conv(step, d_y, 1, w, nullptr, d_x, dx_bf16, ws, nullptr, B, D, H, W, Cout, Cin, 1, s);
   return dx_bf16 ? launch_bf16<true, true, false>(step, d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, s)
                  : launch_bf16<true, false, false>(step, d_y, w, nullptr, d_x, ws, nullptr, B, D, H, W, Cout, Cin, 1, s);
 }

@@ -72,6 +72,7 @@ __device__ __forceinline__ void split3_pk(float a, float b, unsigned& hi, unsign
 // or past num_records loads 0 / drops the store -- the zero padding of the halo, the ragged tile edges and "no plane here"
 // (num_records = 0) all without a branch or a select, and with an instruction count the s_waitcnt pass can reason about.
 using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+using u32x2 = unsigned __attribute__((ext_vector_type(2)));
 using BufRsrc = __amdgpu_buffer_rsrc_t;
 constexpr unsigned X3_OOB = 0x80000000u;             // planes are < 2 GiB (checked on the host)
 __device__ __forceinline__ BufRsrc plane_rsrc(const float* base, unsigned bytes) {
@@ -91,12 +92,12 @@ struct X3Geo {
 };
 
 // ------------------------------------------------------------------------------------------------ weight packing
-// wpk[((dz * NS + s) * 3 + piece) * 64 + lane] = 8 bf16: the MFMA A fragment (row m = lane & 15, k chunk c = 4 s + (lane >> 4)).
+// wpk[((dz * NS + s) * npiece + piece) * 64 + lane] = 8 bf16: the MFMA A fragment (row m = lane & 15, k chunk c = 4 s + (lane >> 4)).
 //   chunk -> (tap, channels):  CIN 8: tap = c, channels 0..7;  CIN 16: tap = c / 2, channels 8 (c & 1) ..+7;
 //                              CIN 4: element j < 4: tap 2c, channel j;  j >= 4: tap 2c + 1, channel j - 4.
 //   tap = dyp * 3 + dx;  row m = p * CoP + co holds W((dz, dyp - p, dx); channel -> co) when 0 <= dyp - p <= 2, else 0.
 //   mode 0 (forward): w[co][ch][tap27]   w: (Cout, Cin, 27);   mode 1 (dgrad): w[ch][co][26 - tap27]   w: (Co = ch, Ci = co, 27)
-struct X3PackJob { const float* w; unsigned short* wpk; int Cin, Cout, cin_t, P, mode, pad_; };
+struct X3PackJob { const float* w; unsigned short* wpk; int Cin, Cout, cin_t, P, mode, npiece; };   // npiece 3 (fp32 emulation) | 1 (bf16)
 constexpr int X3PACK_MAX_JOBS = 40;
 struct X3PackTable { X3PackJob job[X3PACK_MAX_JOBS]; int n; };
 
@@ -121,8 +122,9 @@ __device__ __forceinline__ void x3_pack_body(const X3PackJob& J, int i0, int str
     }
     unsigned short h, md, l;
     split3(v, h, md, l);
-    unsigned short* o = J.wpk + ((size_t)((dz * NS + s) * 3) * 64 + lane) * 8 + j;
-    o[0] = h; o[per_piece] = md; o[2 * per_piece] = l;
+    unsigned short* o = J.wpk + ((size_t)((dz * NS + s) * J.npiece) * 64 + lane) * 8 + j;
+    o[0] = h;                                                             // npiece 1: the weight rounded to bf16
+    if (J.npiece == 3) { o[per_piece] = md; o[2 * per_piece] = l; }
   }
 }
 __global__ void x3_pack_kernel(const X3PackJob J) { x3_pack_body(J, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
@@ -133,11 +135,11 @@ inline int x3_ns(int cin_t, int P) {
   const int ntap = 3 * (P + 2), nch = cin_t == 4 ? (ntap + 1) / 2 : ntap * (cin_t / 8);
   return (nch + 3) / 4;
 }
-inline size_t x3_wpk_elems(int cin_t, int P) { return (size_t)3 * x3_ns(cin_t, P) * 3 * 64 * 8; }   // bf16 elements
+inline size_t x3_wpk_elems(int cin_t, int P, int npiece = 3) { return (size_t)3 * x3_ns(cin_t, P) * npiece * 64 * 8; }   // bf16 elements
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
 struct X3Args {
-  const float* x; const uint4* wpk; const float* bias; float* y;
+  const void* x; const uint4* wpk; const float* bias; void* y;           // x, y: fp32, or bf16 in the storage variants
   const float* in_mean; const float* in_rstd;          // NORM: x is a raw ConvInsBlock output, LeakyReLU((x - mean) * rstd) on load
   float* stats_rows; const float* shift;               // STATS: [b][item][Cout][2] sums of (y - K), (y - K)^2;  K = shift[b][Cout]
   int D, H, W, Cin, Cout, tiles_x, tiles_y, nchunk, ZC, nitems, act;
@@ -153,17 +155,24 @@ __device__ long long* g_x3_dbg = nullptr;
 // CIN 4 / 8: two workgroups per CU (<= 256 registers; the partner's MFMAs cover this wave's staging).  CIN 16: the weights
 // alone are 180 registers (3 dz x 5 k-steps x 3 pieces), so ONE workgroup per CU with the whole register file; a plane then
 // carries 360 MFMAs per wave against ~150 staging instructions, which a single wave per SIMD absorbs.
-template <int CIN, int P, int TY, bool WLDS, bool NORM, bool STATS>
-__global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const X3Args a) {
+// NPC = 1 (BASELINE.json configs[4], bf16 STORAGE / fp32 accumulate): one bf16 piece per operand -- the contract of conv3d_bf16.hip
+// (exact arithmetic on the bf16-rounded operands, one rounding of the output) in this kernel's structure.  IN16: x is bf16 in
+// HBM (a staging item = 8 channels = 16 bytes goes to LDS untouched), else fp32 rounded while staged; OUT16: y is stored as bf16.
+// A plane then carries 18 MFMAs per wave instead of 108: the kernel is HBM-bound (8->8: 32 bytes per voxel).
+template <int CIN, int P, int TY, bool WLDS, bool NORM, bool STATS, int NPC = 3, bool IN16 = false, bool OUT16 = false>
+__global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (CIN == 16 ? 1 : 2)) void conv_x3_kernel(const X3Args a) {
   using G = X3Geo<CIN, P>;
   constexpr int NS = G::NS, NTAP = G::NTAP;
   constexpr int HY = TY + 2, UNITS = TY / P, R = UNITS / 4;
   // one piece's plane [hy][hx][CIN] bf16 + 16 bytes that absorb the LDS writes of staging slots past the plane's end
-  constexpr int PLANE_D = HY * HX * CIN * 2, PLANE_B = PLANE_D + 16, SLOT_B = 3 * PLANE_B;
-  constexpr int Q = CIN / 4, NITEM = HY * HX * Q, NIT = (NITEM + NTHR - 1) / NTHR;
-  constexpr int WL_B = WLDS ? 3 * NS * 3 * 1024 : 16;
+  constexpr int PLANE_D = HY * HX * CIN * 2, PLANE_B = PLANE_D + 16, SLOT_B = NPC * PLANE_B;
+  constexpr int EPI = IN16 ? 8 : 4;                                        // channels per 16-byte staging item
+  constexpr int Q = CIN / EPI, NITEM = HY * HX * Q, NIT = (NITEM + NTHR - 1) / NTHR;
+  constexpr int WL_B = WLDS ? 3 * NS * NPC * 1024 : 16;
   static_assert(UNITS % 4 == 0, "row groups split over 4 waves");
-  static_assert(NTHR % Q == 0, "a thread's staging items share one channel group");
+  static_assert(Q >= 1 && NTHR % Q == 0, "a thread's staging items share one channel group");
+  static_assert(NPC == 3 || !NORM, "the lazily normalised input exists for the fp32 form only");
+  static_assert(NPC == 1 || (!IN16 && !OUT16), "bf16 tensors belong to the one-piece form");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLOT_B];
   __shared__ __attribute__((aligned(16))) unsigned char wl[WL_B];
 
@@ -184,16 +193,16 @@ __global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const 
   const int nz = (zs + a.ZC <= D ? a.ZC : D - zs);                         // output planes of this item
 
   // ---- weights: A fragments of every (dz, k-step, piece), in registers (or LDS) for the whole march
-  uint4 wreg[WLDS ? 1 : 3][WLDS ? 1 : NS][WLDS ? 1 : 3];
+  uint4 wreg[WLDS ? 1 : 3][WLDS ? 1 : NS][WLDS ? 1 : NPC];
   if constexpr (WLDS) {
-    for (int i = tid; i < 3 * NS * 3 * 64; i += NTHR) reinterpret_cast<uint4*>(wl)[i] = a.wpk[i];
+    for (int i = tid; i < 3 * NS * NPC * 64; i += NTHR) reinterpret_cast<uint4*>(wl)[i] = a.wpk[i];
   } else {
 #pragma unroll
     for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) wreg[dz][s][pc] = a.wpk[((dz * NS + s) * 3 + pc) * 64 + lane];
+        for (int pc = 0; pc < NPC; ++pc) wreg[dz][s][pc] = a.wpk[((dz * NS + s) * NPC + pc) * 64 + lane];
   }
 
   // ---- staging map: item i = tid + j * NTHR of the halo'd plane [hy][hx][Q channel groups]
@@ -207,9 +216,9 @@ __global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const 
     const int v = on ? i / Q : 0, c4 = on ? i - v * Q : 0;
     const int hy = v / HX, hx = v - hy * HX;
     const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-    const bool ok = on && yy >= 0 && yy < H && xx >= 0 && xx < W && c4 * 4 < Cin;
-    goff[j] = ok ? (unsigned)(((yy * W + xx) * Cin + c4 * 4) * 4) : X3_OOB;
-    loff[j] = on ? (v * CIN + c4 * 4) * 2 : PLANE_D;                       // slots past the plane's end write the pad
+    const bool ok = on && yy >= 0 && yy < H && xx >= 0 && xx < W && c4 * EPI < Cin;
+    goff[j] = ok ? (unsigned)(((yy * W + xx) * Cin + c4 * EPI) * (IN16 ? 2 : 4)) : X3_OOB;
+    loff[j] = on ? (v * CIN + c4 * EPI) * 2 : PLANE_D;                     // slots past the plane's end write the pad
     okmask |= (ok ? 1u : 0u) << j;
   }
   float4 nm = make_float4(0.f, 0.f, 0.f, 0.f), nr = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -220,8 +229,9 @@ __global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const 
       nr = *reinterpret_cast<const float4*>(a.in_rstd + b * Cin + cg);
     }
   }
-  const float* xb = a.x + (int64_t)b * D * H * W * Cin;
-  const unsigned in_plane_bytes = (unsigned)H * W * Cin * 4, out_plane_bytes = (unsigned)H * W * Cout * 4;
+  constexpr int ISZ = IN16 ? 2 : 4, OSZ = OUT16 ? 2 : 4;
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + (int64_t)b * D * H * W * Cin * ISZ;
+  const unsigned in_plane_bytes = (unsigned)H * W * Cin * ISZ, out_plane_bytes = (unsigned)H * W * Cout * OSZ;
   // XSETS register sets, plane q lives in set q % XSETS.  One set = the plane is loaded one iteration before it is split
   // (measured: the split then waits ~1 % of a wave's cycles for its loads; a second iteration of distance bought nothing
   // and its 24 registers are worth more to the MFMA loop's operand prefetch)
@@ -231,13 +241,23 @@ __global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const 
   auto load_plane = [&](auto set_c, int z) {
     constexpr int S = decltype(set_c)::value;
     xr_live[S] = z >= 0 && z < D;
-    const BufRsrc rs = plane_rsrc(xb + (int64_t)(xr_live[S] ? z : 0) * H * W * Cin, xr_live[S] ? in_plane_bytes : 0u);
+    const BufRsrc rs = plane_rsrc(reinterpret_cast<const float*>(xb + (int64_t)(xr_live[S] ? z : 0) * in_plane_bytes),
+                                  xr_live[S] ? in_plane_bytes : 0u);
 #pragma unroll
     for (int j = 0; j < NIT; ++j) xr[S][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)goff[j], 0, 0));
   };
   auto store_plane = [&](auto set_c, int slot) {
     constexpr int S = decltype(set_c)::value;
     unsigned char* sl = lds + slot * SLOT_B;
+    if constexpr (NPC == 1) {
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const float4 t = xr[S][j];
+        if constexpr (IN16) *reinterpret_cast<uint4*>(sl + loff[j]) = __builtin_bit_cast(uint4, t);     // 8 bf16, untouched
+        else *reinterpret_cast<uint2*>(sl + loff[j]) = make_uint2(pk_bf16(t.x, t.y), pk_bf16(t.z, t.w));
+      }
+      return;
+    }
     // all NIT items stage by stage (2 NIT independent dependency chains side by side: the split is a chain of seven
     // dependent VALU operations per value pair, one item after the other leaves the VALU waiting on itself)
     float2 v[NIT][2];
@@ -326,13 +346,13 @@ __global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const 
   if (co_ok && a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + co0);
   if (STATS && co_ok) k4 = *reinterpret_cast<const float4*>(a.shift + b * Cout + co0);
   float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-  float* yb = a.y + (int64_t)b * D * H * W * Cout;
-  unsigned soff[R];                                                        // byte offset of this lane's float4 in an output plane
+  unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + (int64_t)b * D * H * W * Cout * OSZ;
+  unsigned soff[R];                                                        // byte offset of this lane's 4 couts in an output plane
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int u = wave * R + r;
     const int row = y0 + (P == 2 ? 2 * u + (lk >> 1) : u);
-    soff[r] = (co_ok && x0 + li < W && row < H) ? (unsigned)(((row * W + x0 + li) * Cout + co0) * 4) : X3_OOB;
+    soff[r] = (co_ok && x0 + li < W && row < H) ? (unsigned)(((row * W + x0 + li) * Cout + co0) * OSZ) : X3_OOB;
   }
 
   auto frag = [&](const unsigned char* sl, int pc, int r, int s) -> bf16x8 {
@@ -346,7 +366,7 @@ __global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const 
     }
   };
   auto wfrag = [&](int dz, int s, int pc) -> bf16x8 {
-    if constexpr (WLDS) return __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(wl)[((dz * NS + s) * 3 + pc) * 64 + lane]);
+    if constexpr (WLDS) return __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(wl)[((dz * NS + s) * NPC + pc) * 64 + lane]);
     else return __builtin_bit_cast(bf16x8, wreg[dz][s][pc]);
   };
 #define X3_MM(ACC, WP, XP) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[WP], xf[XP], ACC, 0, 0, 0)
@@ -355,7 +375,21 @@ __global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const 
     constexpr int C = decltype(cc)::value;
     constexpr int S0 = C, S1 = (C + 2) % 3, S2 = (C + 1) % 3;
     const unsigned char* sl = lds + slot * SLOT_B;
-    if (a0 && a1 && a2) {
+    if constexpr (NPC == 1) {
+      // one product per (dz, k-step, row group); the B fragment of unit u+1 is read before the MFMAs of unit u
+      bf16x8 xq[2];
+      xq[0] = frag(sl, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NS * R; ++u) {
+        const int s = u / R, r = u % R;
+        if (u + 1 < NS * R) xq[(u + 1) & 1] = frag(sl, 0, (u + 1) % R, (u + 1) / R);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 xf = xq[u & 1];
+        if (a0) acc[S0][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(0, s, 0), xf, acc[S0][r], 0, 0, 0);
+        if (a1) acc[S1][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(1, s, 0), xf, acc[S1][r], 0, 0, 0);
+        if (a2) acc[S2][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(2, s, 0), xf, acc[S2][r], 0, 0, 0);
+      }
+    } else if (a0 && a1 && a2) {
       // (k-step, row group) units in order; the three B fragments of unit u+1 are read from LDS before the 18 MFMAs of unit u
       bf16x8 xq[2][3];
 #pragma unroll
@@ -403,7 +437,7 @@ __global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const 
   // live = false (no finished plane yet): the same instructions run against an empty descriptor and store nothing.
   auto flush = [&](auto sl_c, int z, bool live) {
     constexpr int SL = decltype(sl_c)::value;
-    const BufRsrc rs = plane_rsrc(yb + (int64_t)(live ? z : 0) * H * W * Cout, live ? out_plane_bytes : 0u);
+    const BufRsrc rs = plane_rsrc(reinterpret_cast<const float*>(yb + (int64_t)(live ? z : 0) * out_plane_bytes), live ? out_plane_bytes : 0u);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const f32x4 v = acc[SL][r];
@@ -416,8 +450,13 @@ __global__ __launch_bounds__(NTHR, CIN == 16 ? 1 : 2) void conv_x3_kernel(const 
         sq[0] = fmaf(e0, e0, sq[0]); sq[1] = fmaf(e1, e1, sq[1]); sq[2] = fmaf(e2, e2, sq[2]); sq[3] = fmaf(e3, e3, sq[3]);
       }
       if (a.act) { o[0] = lrelu(o[0]); o[1] = lrelu(o[1]); o[2] = lrelu(o[2]); o[3] = lrelu(o[3]); }
-      const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rs, (int)soff[r], 0, 0);
+      if constexpr (OUT16) {                                               // statistics above: of the fp32 values, as conv3d_bf16.hip
+        const u32x2 o2 = {pk_bf16(o[0], o[1]), pk_bf16(o[2], o[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(o2, rs, (int)soff[r], 0, 0);
+      } else {
+        const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rs, (int)soff[r], 0, 0);
+      }
     }
   };
 
@@ -508,15 +547,15 @@ struct X3Plan { int cin_t, P, ty, wlds, tiles_x, tiles_y, nchunk, zc, nitems; };
 
 inline bool x3_shape_ok(int Cin, int Cout) { return Cin % 4 == 0 && Cin >= 4 && Cin <= 16 && Cout % 4 == 0 && Cout >= 4 && Cout <= 16; }
 
-inline X3Plan x3_plan(int B, int D, int H, int W, int Cin, int Cout) {
+inline X3Plan x3_plan(int B, int D, int H, int W, int Cin, int Cout, int npc = 3) {
   X3Plan p;
   p.cin_t = Cin <= 4 ? 4 : (Cin <= 8 ? 8 : 16);
-  // CIN 16 runs unpacked (P = 1) also for Cout <= 8: its packed form needs 6 k-steps = 216 weight registers
-  p.P = (Cout <= 8 && p.cin_t < 16) ? 2 : 1;
-  // 16 rows = 8 packed row pairs, or 8 plain rows: two row groups per wave; CIN 16: 16 plain rows, four per wave
-  p.ty = (p.P == 2 || p.cin_t == 16) ? 16 : 8;
+  // CIN 16 runs unpacked (P = 1) also for Cout <= 8: its packed form needs 6 k-steps = 216 weight registers (one piece: 18)
+  p.P = (Cout <= 8 && (p.cin_t < 16 || npc == 1)) ? 2 : 1;
+  // 16 rows = 8 packed row pairs, or 8 plain rows: two row groups per wave; CIN 16 / one piece: 16 plain rows, four per wave
+  p.ty = (p.P == 2 || p.cin_t == 16 || npc == 1) ? 16 : 8;
   p.wlds = 0;
-  const int slots = p.cin_t == 16 ? 256 : 512;                             // resident workgroups
+  const int slots = npc == 1 ? ((p.P == 2 && p.cin_t < 16) ? 768 : 512) : (p.cin_t == 16 ? 256 : 512);       // resident workgroups
   p.tiles_x = cdiv(W, TX);
   p.tiles_y = cdiv(H, p.ty);
   // z chunks: enough workgroups to fill 256 CUs x 2 several times over (the dispatcher balances them), but chunks long
@@ -538,11 +577,11 @@ inline X3Plan x3_plan(int B, int D, int H, int W, int Cin, int Cout) {
   return p;
 }
 
-template <bool NORM, bool STATS>
-int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s) {
-  X3Args a = a0;
+// packed weights of this launch: the step context's arena (prepacked) or `ws` (packed here)
+inline const uint4* x3_weights(modet_step_ctx* step, const float* w, void* ws, int Cin, int Cout, int mode, int npc, const X3Plan& p,
+                               hipStream_t s) {
   unsigned short* wpk = (unsigned short*)ws;
-  const PackBKey key{w, a.Cin, a.Cout, 16, p.cin_t, 3, x3_ns(p.cin_t, p.P), mode, 3, 1 + p.P};   // nstage = the 3 dz
+  const PackBKey key{w, Cin, Cout, 16, p.cin_t, 3, x3_ns(p.cin_t, p.P), mode, npc, 1 + p.P};   // nstage = the 3 dz
   const unsigned short* pre = nullptr;
   if (step) {
     std::lock_guard<std::mutex> lk(step->mu);
@@ -556,14 +595,36 @@ int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, 
     }
   }
   if (pre) wpk = const_cast<unsigned short*>(pre);
-  else hipLaunchKernelGGL(x3_pack_kernel, dim3(8), dim3(256), 0, s, X3PackJob{w, wpk, a.Cin, a.Cout, p.cin_t, p.P, mode, 0});
-  a.wpk = (const uint4*)wpk;
+  else hipLaunchKernelGGL(x3_pack_kernel, dim3(8), dim3(256), 0, s, X3PackJob{w, wpk, Cin, Cout, p.cin_t, p.P, mode, npc});
+  return (const uint4*)wpk;
+}
+
+template <bool NORM, bool STATS>
+int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s) {
+  X3Args a = a0;
+  a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, 3, p, s);
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.nchunk = p.nchunk; a.ZC = p.zc; a.nitems = p.nitems;
   const dim3 grid(((p.nitems + 7) / 8) * 8);
 #define X3_L(CIN_, P_, TY_, WL_) hipLaunchKernelGGL((conv_x3_kernel<CIN_, P_, TY_, WL_, NORM, STATS>), grid, dim3(NTHR), 0, s, a)
   if (p.cin_t == 4) { if (p.P == 2) X3_L(4, 2, 16, false); else X3_L(4, 1, 8, false); }
   else if (p.cin_t == 8) { if (p.P == 2) X3_L(8, 2, 16, false); else X3_L(8, 1, 8, false); }
   else X3_L(16, 1, 16, false);
+#undef X3_L
+  return modet_launch_status();
+}
+
+// bf16 storage (one piece): x fp32 | bf16, y fp32 | bf16 (never both fp32: that is the fp32 path above)
+template <bool IN16, bool OUT16, bool STATS>
+int x3_launch16(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s) {
+  X3Args a = a0;
+  a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, 1, p, s);
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.nchunk = p.nchunk; a.ZC = p.zc; a.nitems = p.nitems;
+  const dim3 grid(((p.nitems + 7) / 8) * 8);
+#define X3_L(CIN_, P_) hipLaunchKernelGGL((conv_x3_kernel<CIN_, P_, 16, false, false, STATS, 1, IN16, OUT16>), grid, dim3(NTHR), 0, s, a)
+  if (p.cin_t == 4) {
+    if constexpr (!IN16) { if (p.P == 2) X3_L(4, 2); else X3_L(4, 1); } else return MODET_ERR_UNSUPPORTED;
+  } else if (p.cin_t == 8) { if (p.P == 2) X3_L(8, 2); else X3_L(8, 1); }
+  else { if (p.P == 2) X3_L(16, 2); else X3_L(16, 1); }
 #undef X3_L
   return modet_launch_status();
 }
@@ -627,6 +688,9 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a)
   const bool bq = NP && (li >> 3);                               // this lane's column takes d_y shifted by one voxel
   const int boff = bco * PD + 8 * lk;
 
+#ifdef MODET_TUNING
+  long long dsum[6] = {0, 0, 0, 0, 0, 0};
+#endif
   f32x4 acc[U][NT], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < U; ++u)
@@ -699,23 +763,38 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a)
     accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[2], accb, 0, 0, 0);
     accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[1], accb, 0, 0, 0);
     accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[0], accb, 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
+    // raw operand words of a group (per piece: the aligned 16-byte block and its neighbours) are read one group AHEAD of
+    // the MFMAs that use them, fenced: left alone the scheduler sinks each read to its first use and every group starts
+    // with an exposed LDS round trip
+    struct Raw { uint4 qq; unsigned r0, p3; };
+    auto rd = [&](int u, Raw (&w)[3]) {
       const unsigned short* pa = xs + ((q + adz[u]) & 3) * XSLOT + aoff[u] + row * WHXP;
-      bf16x8 f[3][NT];                                           // [piece][row tile]
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) {
         const unsigned short* pp = pa + pc * XPIECE;
-        const uint4 qq = *reinterpret_cast<const uint4*>(pp + 8);
-        const unsigned r0 = *reinterpret_cast<const unsigned*>(pp + 16);
+        w[pc].qq = *reinterpret_cast<const uint4*>(pp + 8);
+        w[pc].r0 = *reinterpret_cast<const unsigned*>(pp + 16);
+        w[pc].p3 = NP ? 0u : *reinterpret_cast<const unsigned*>(pp + 6);
+      }
+    };
+    Raw raw[2][3];
+    rd(0, raw[0]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u + 1 < U) rd(u + 1, raw[(u + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 f[3][NT];                                           // [piece][row tile]
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const uint4 qq = raw[u & 1][pc].qq;
+        const unsigned r0 = raw[u & 1][pc].r0;
         const unsigned a1 = __builtin_amdgcn_alignbit(qq.y, qq.x, 16), a2 = __builtin_amdgcn_alignbit(qq.z, qq.y, 16),
                        a3 = __builtin_amdgcn_alignbit(qq.w, qq.z, 16), a4 = __builtin_amdgcn_alignbit(r0, qq.w, 16);
         if constexpr (NP) {
           f[pc][0] = __builtin_bit_cast(bf16x8, qq);                              // x[v]
           f[pc][1] = __builtin_bit_cast(bf16x8, make_uint4(a1, a2, a3, a4));      // x[v + 1]
         } else {
-          const unsigned p3 = *reinterpret_cast<const unsigned*>(pp + 6);
-          const unsigned a0 = __builtin_amdgcn_alignbit(qq.x, p3, 16);
+          const unsigned a0 = __builtin_amdgcn_alignbit(qq.x, raw[u & 1][pc].p3, 16);
           f[pc][0] = __builtin_bit_cast(bf16x8, make_uint4(a0, a1, a2, a3));      // dx = 0: x[v - 1]
           f[pc][1] = __builtin_bit_cast(bf16x8, qq);
           f[pc][NT - 1] = __builtin_bit_cast(bf16x8, make_uint4(a1, a2, a3, a4));
@@ -727,6 +806,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a)
         acc[u][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[AP][d], b[BP], acc[u][d], 0, 0, 0);
       X3W(2, 0) X3W(0, 2) X3W(1, 1) X3W(1, 0) X3W(0, 1) X3W(0, 0)
 #undef X3W
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -752,26 +832,52 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a)
     }
     __syncthreads();                                             // every wave is done with the previous item's planes
     // prologue: x planes zs-1, zs, zs+1 -> ring slots 0, 1, 2; d_y plane zs -> slot 0 (all four loads in flight together);
-    // then registers <- x plane zs+2, d_y plane zs+1
-    Pair xr, dr;
+    // then two register sets: A <- (x plane zs+2, d_y plane zs+1), B <- (x plane zs+3, d_y plane zs+2).  A plane is loaded
+    // TWO iterations before it is split: one iteration here is ~65 MFMAs per wave (a 4-row plane), shorter than an HBM
+    // round trip under load, and the split would wait for its loads every plane (41 % of wave cycles parked, PMC)
+    Pair xa, da, xb2, db2;
     {
       const Pair p0 = load_x(zs - 1), p1 = load_x(zs), p2 = load_x(zs + 1), pd = load_dy(zs, ze);
-      xr = load_x(zs + 2);
-      dr = load_dy(zs + 1, ze);
+      xa = load_x(zs + 2); da = load_dy(zs + 1, ze);
+      xb2 = load_x(zs + 3); db2 = load_dy(zs + 2, ze);
       store_x(0, p0); store_x(1, p1); store_x(2, p2); store_dy(0, pd);
     }
     __syncthreads();
     const int nz = ze - zs;
-    for (int q = 0; q < nz; ++q) {                               // d_y plane zs + q; x planes zs + q - 1 .. zs + q + 1 in slots q .. q+2
-      // the planes loaded one iteration ago: x plane zs+q+2 -> the slot x plane zs+q-2 left, d_y plane zs+q+1 -> the other buffer
-      store_x((q + 3) & 3, xr);
-      store_dy((q + 1) & 1, dr);
-      xr = load_x(zs + q + 3);
-      dr = load_dy(zs + q + 2, ze);
+    // d_y plane zs + q with x planes zs + q - 1 .. zs + q + 1 in slots q .. q+2.  Two iterations per trip (register sets A, B);
+    // an odd chunk runs one padded iteration: its d_y plane is past the chunk, loaded as zeros, and adds nothing
+#ifdef MODET_TUNING
+    long long tprev = clock64();
+#endif
+    for (int q = 0; q < nz; q += 2) {
+      store_x((q + 3) & 3, xa);                                  // x plane zs+q+2 -> the slot x plane zs+q-2 left
+      store_dy((q + 1) & 1, da);                                 // d_y plane zs+q+1 -> the other buffer
+      X3_T(2)
+      xa = load_x(zs + q + 4);
+      da = load_dy(zs + q + 3, ze);
+      X3_T(4)
       compute(q, q & 1);
+      X3_T(0)
       __syncthreads();
+      X3_T(3)
+      store_x((q + 4) & 3, xb2);
+      store_dy((q + 2) & 1, db2);
+      X3_T(2)
+      xb2 = load_x(zs + q + 5);
+      db2 = load_dy(zs + q + 4, ze);
+      X3_T(4)
+      compute(q + 1, (q + 1) & 1);
+      X3_T(0)
+      __syncthreads();
+      X3_T(3)
     }
   }
+#ifdef MODET_TUNING
+  if (g_x3_dbg && lane == 0) {
+    long long* o = g_x3_dbg + ((int64_t)blockIdx.x * 4 + wave) * 6;
+    for (int i = 0; i < 6; ++i) o[i] = dsum[i];
+  }
+#endif
 
   // ---- sum the 4 waves through LDS (fixed order), one partial per workgroup
   float* red = reinterpret_cast<float*>(lds);
@@ -848,6 +954,28 @@ int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const f
   if (in_mean) return stats ? x3_launch<true, true>(step, a, w, ws, B, mode, p, s) : x3_launch<true, false>(step, a, w, ws, B, mode, p, s);
   return stats ? x3_launch<false, true>(step, a, w, ws, B, mode, p, s) : x3_launch<false, false>(step, a, w, ws, B, mode, p, s);
 }
+// ---- bf16 storage (conv3d_bf16.hip routes the full-resolution layers here): x fp32 | bf16, y fp32 | bf16, one bf16 piece
+bool modetx_x3_bf16_eligible(int B, int D, int H, int W, int Cin, int Cout, int x_bf16) {
+  return x3_shape_ok(Cin, Cout) && (x_bf16 ? Cin % 8 == 0 : true) && (int64_t)D * H * W >= 4096 && B <= 65535 &&
+         (int64_t)H * W * 16 * 4 < 0x7fffffffLL;
+}
+int modetx_x3_bf16_rows_per_sample(int B, int D, int H, int W, int Cin, int Cout) {
+  const X3Plan p = x3_plan(B, D, H, W, Cin, Cout, 1);
+  return p.nitems / B;
+}
+// stats != null: [B][Cout] shift header (filled by the caller) followed by one row [Cout][2] per (sample, workgroup item)
+int modetx_x3_bf16_conv(modet_step_ctx* step, const void* x, int x_bf16, const float* w, const float* bias, void* y, int y_bf16,
+                        void* ws, float* stats, int B, int D, int H, int W, int Cin, int Cout, int mode, hipStream_t s) {
+  const X3Plan p = x3_plan(B, D, H, W, Cin, Cout, 1);
+  X3Args a{};
+  a.x = x; a.bias = bias; a.y = y;
+  a.shift = stats; a.stats_rows = stats ? stats + (size_t)B * Cout : nullptr;
+  a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = 0;
+  if (!x_bf16 && !y_bf16) return MODET_ERR_UNSUPPORTED;
+  if (!y_bf16) return stats ? MODET_ERR_UNSUPPORTED : x3_launch16<true, false, false>(step, a, w, ws, B, mode, p, s);
+  if (x_bf16) return stats ? x3_launch16<true, true, true>(step, a, w, ws, B, mode, p, s) : x3_launch16<true, true, false>(step, a, w, ws, B, mode, p, s);
+  return stats ? x3_launch16<false, true, true>(step, a, w, ws, B, mode, p, s) : x3_launch16<false, true, false>(step, a, w, ws, B, mode, p, s);
+}
 // ---- weight gradient
 int modetx_wgrad_partials_reduce(modet_step_ctx* defer, const float* part, float* red, float* dw, float* db, int gx, int Cin,
                                  int Cout, int cib, int u, int layout, hipStream_t s);      // conv3d_bf16.hip
@@ -892,7 +1020,7 @@ void modetx_x3_prepack_begin(modet_step_ctx* c, hipStream_t stream) {
   for (size_t i = 0; i < jobs.size(); ++i) {
     const PackBKey& k = jobs[i];
     if (k.layout < 2) continue;
-    t.job[t.n++] = X3PackJob{k.w, arena + off[i], k.Cin, k.Cout, k.CK, k.layout - 1, k.mode, 0};
+    t.job[t.n++] = X3PackJob{k.w, arena + off[i], k.Cin, k.Cout, k.CK, k.layout - 1, k.mode, k.npiece};
     if (t.n == X3PACK_MAX_JOBS) go();
   }
   go();

@@ -28,7 +28,10 @@ def ncdhw(t):
 
 CASES = [(2, 20, 24, 28, 4, 8, False), (2, 20, 24, 28, 8, 8, True), (1, 17, 12, 40, 8, 16, False), (2, 16, 16, 16, 16, 16, True),
          (1, 9, 12, 10, 16, 32, False), (1, 33, 17, 40, 32, 32, True), (1, 9, 12, 10, 32, 64, False), (1, 5, 6, 7, 64, 64, True),
-         (1, 9, 12, 10, 64, 128, False), (2, 10, 12, 14, 128, 128, True), (1, 1, 2, 1, 64, 128, False)]
+         (1, 9, 12, 10, 64, 128, False), (2, 10, 12, 14, 128, 128, True), (1, 1, 2, 1, 64, 128, False),
+         # the z-marching kernel's forms (conv3d_x3.hip, one bf16 piece): ragged tiles, z chunks, every (channels, packing, dtype)
+         (1, 37, 45, 50, 8, 8, False), (1, 40, 33, 70, 16, 8, True), (2, 21, 19, 35, 8, 16, True), (1, 23, 30, 18, 4, 16, False),
+         (1, 64, 96, 112, 8, 8, True), (1, 30, 20, 33, 16, 16, False)]
 
 
 @pytest.mark.parametrize("B,D,H,W,Cin,Cout,inbf", CASES)

@@ -13,7 +13,8 @@ x = torch.randn(B, D, H, W, Cin, device="cuda")
 w = torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.1
 b = torch.randn(Cout, device="cuda")
 dy = torch.randn(B, D, H, W, Cout, device="cuda")
-fn = (lambda: ops.conv3d_forward(x, w, b, False)) if what == "fwd" else (lambda: ops.conv3d_backward_data(dy, w, Cin))
+fn = {"fwd": lambda: ops.conv3d_forward(x, w, b, False), "dgrad": lambda: ops.conv3d_backward_data(dy, w, Cin),
+      "wgrad": lambda: ops.conv3d_backward_weight(x, dy, True)}[what]
 for _ in range(3): fn()
 L = _lib.load()
 buf = torch.zeros(16384 * 4 * 6, dtype=torch.int64, device="cuda")

@@ -11,6 +11,6 @@ done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/x3t/obj/*.o -o /tmp/x3t/libmodet_tuning.so
 cd $R
-for cfg in "fwd 8 8" "dgrad 8 8" "fwd 4 8" "dgrad 4 8" "fwd 8 16 2"; do
+for cfg in "fwd 8 8" "fwd 4 8" "wgrad 8 8" "wgrad 4 8"; do
   MODET_HIP_LIB=/tmp/x3t/libmodet_tuning.so python tools/exp_x3_phases.py $cfg
 done
