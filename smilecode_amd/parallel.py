@@ -101,8 +101,8 @@ class FlatParams:
                 srcs.append(p.grad)
         if views:
             torch._foreach_copy_(views, srcs)
-        for v in missing:
-            v.zero_()
+        if missing:                           # parameters no loss term reaches: one multi-tensor launch, not one fill each
+            torch._foreach_zero_(missing)
 
     def allreduce_grads(self, group=None):
         """sum over ranks (in place); returns the factor the optimizer must apply (1/world)"""
