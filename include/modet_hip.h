@@ -254,11 +254,15 @@ int modet_cwm_tail_fwd(const float* x, const float* logits, float* out, int64_t 
 int modet_cwm_tail_bwd(const float* x, const float* logits, const float* d_out, float* d_x, float* d_logits,
                        int64_t N, int heads, modet_stream_t stream);
 
-/* NCC_vxm(win=9) (losses.py:34-94): loss[0] = -mean(cc); d_J (same shape as J) = d loss / d J or NULL.
- * I = y_true, J = y_pred, (B,D,H,W) single channel.  Separable zero-padded box sums. */
+/* NCC_vxm (losses.py:34-94): loss[0] = -mean(cc); d_J (same shape as J) = d loss / d J or NULL.
+ * I = y_true, J = y_pred, (B,D,H,W) single channel.  Separable zero-padded box sums, one z-marching kernel per direction.
+ * modet_ncc_fwd_bwd: the default window win = [9, 9, 9] (what train.py:103 constructs);  _win: cubic windows
+ * win x win x win, win in {3, 5, 7, 9} (losses.py:52 `self.win`; padding floor(win / 2) as losses.py:57). */
 size_t modet_ncc_ws_bytes(int B, int D, int H, int W);
 int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes,
                       int B, int D, int H, int W, modet_stream_t stream);
+int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes,
+                          int B, int D, int H, int W, int win, modet_stream_t stream);
 /* Grad3d (losses.py:6-31) on a planar flow (B,3,D,H,W): loss[0], d_flow (NULL to skip).
  * penalty = 1 ('l1', |forward differences|, the class default) or 2 ('l2', squared; what train.py:104 uses). */
 size_t modet_grad3d_ws_bytes(int B, int D, int H, int W);

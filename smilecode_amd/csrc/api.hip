@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 300; /* 0.3.0: caller-owned step context (modet_step_ctx_t) for the step-batching entry points */ }
+int modet_hip_version(void) { return 301; /* 0.3.1: + modet_ncc_fwd_bwd_win (NCC windows 3 / 5 / 7 / 9) */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {

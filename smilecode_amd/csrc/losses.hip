@@ -1,8 +1,13 @@
 // NCC_vxm(win=9) and Grad3d('l2') forward + gradient (reference ModeT/losses.py:34-94, :6-31).
 //
-// The reference evaluates five dense 9x9x9 all-ones conv3d (729 taps each, ~36 GFLOP at 160x192x160); the box
-// filter is separable, so here each is a fused W+H pass over LDS tiles and a D pass with register windows over
-// (B,D,H,W) volumes: HBM-bound streams.  The backward uses that the zero-padded box sum S is self-adjoint:
+// The reference evaluates five dense 9x9x9 all-ones conv3d (729 taps each, ~36 GFLOP at 160x192x160).  The box filter is
+// separable; here each direction is ONE z-marching kernel (ncc_march_kernel): a workgroup owns a 24 x 32 (y, x) tile,
+// every thread keeps the last WIN planes of its 5 halo voxels in REGISTERS (the z box sum of the five products is
+// register arithmetic, each input plane is loaded once per chunk), then the W and H box sums run over two small LDS
+// arrays and the pointwise tail (cc + the backward coefficients, resp. the final gradient formula) finishes the plane:
+// forward reads I, J and writes three coefficient volumes, backward reads those + I, J and writes d_J -- no five-volume
+// intermediates (round 2: four passes, 31 N floats of traffic, 0.21 ms; now 2 launches + the scalar finalize).
+// The backward uses that the zero-padded box sum S is self-adjoint:
 //   d(-mean cc)/dJ = g * ( S(cB) + 2 J S(cD) + I S(cE) ),  g = -1/N,
 //   cE = d cc/d IJ_sum, cD = d cc/d J2_sum, cB = d cc/d J_sum  (pointwise in the five sums).
 // Scalar losses are reduced in two deterministic stages (workgroup partials -> fixed-order fp64 sum).
@@ -23,178 +28,264 @@ __device__ __forceinline__ void decode(int64_t i, const Dims d, int& z, int& y, 
   z = (int)((t / d.H) % d.D);
 }
 
-// W and H box passes in one kernel over 32x32 tiles of a z-slice staged in LDS (+4 halo each side, zeros outside the
-// volume): rows are box-summed along W into a second LDS array, then columns along H.  PROD: the inputs are I and J and
-// the five box-summed quantities {I, J, I*I, J*J, I*J} are formed on the fly (forward); otherwise NARR stacked volumes
-// are filtered as they are (the three coefficient volumes of the backward).  Replaces two full HBM passes
-// (a W pass and an H pass) by one.
-constexpr int HW_T = 32, HW_H = HW_T + 2 * PAD, HW_LD = HW_H + 1;
-template <int NARR, bool PROD>
-__global__ __launch_bounds__(BLK) void box_hw_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
-                                                     float* __restrict__ out, Dims d, int64_t N, int tiles_w) {
-  constexpr int NIN = PROD ? 2 : NARR;
-  __shared__ float raw[NIN][HW_H * HW_LD];
-  __shared__ float tmp[NARR][HW_H * HW_T];
-  const int x0 = (blockIdx.x % tiles_w) * HW_T, y0 = (blockIdx.x / tiles_w) * HW_T;
-  const int z = blockIdx.y, b = blockIdx.z;
-  const int64_t slice = ((int64_t)b * d.D + z) * d.H * d.W;
-  for (int i = threadIdx.x; i < HW_H * HW_H; i += BLK) {
-    const int r = i / HW_H, c = i - r * HW_H;
-    const int y = y0 + r - PAD, x = x0 + c - PAD;
-    const bool ok = y >= 0 && y < d.H && x >= 0 && x < d.W;
-    const int64_t o = slice + (int64_t)y * d.W + x;
-    if (PROD) {
-      raw[0][r * HW_LD + c] = ok ? in0[o] : 0.f;
-      raw[1][r * HW_LD + c] = ok ? in1[o] : 0.f;
-    } else {
+// ------------------------------------------------------------------------------------------------ z-marching form
+// FWD: in0 = I, in1 = J (NIN = 2); the five window sums {I, J, I^2, J^2, I J} -> cc (loss partial per workgroup) and the
+//      coefficient volumes coef = {cB, cD, cE}.   BWD: in0 = coef (three stacked volumes, NIN = 3) -> S(cB), S(cD), S(cE)
+//      -> d_J = g (S(cB) + 2 J S(cD) + I S(cE)).   Each window sum is the plain WIN^3-term sum (z, then x, then y), no
+//      running differences.  Zero padding = predicated loads.
+constexpr int MT_Y = 24, MT_X = 32;
+#ifndef NCC_VARIANT
+#define NCC_VARIANT 0          // tuning builds (tools/variants.sh): 1 no W / H passes, 2 no loads after the prologue, 4 no z sums
+#endif
+// NOUT consecutive W_-term window sums of v[0 .. NOUT + W_ - 2]: the values common to all windows are added once (purely
+// additive: another association of the same terms, no running differences).  T = float or a float pair (v_pk_add_f32).
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int W_, int NOUT, typename T>
+__device__ __forceinline__ void window_sums(const T (&v)[NOUT + W_ - 1], T (&o)[NOUT]) {
+  if constexpr (W_ >= NOUT) {
+    T core = v[NOUT - 1];
 #pragma unroll
-      for (int v = 0; v < NARR; ++v) raw[v][r * HW_LD + c] = ok ? in0[(int64_t)v * N + o] : 0.f;
+    for (int k = NOUT; k < W_; ++k) core += v[k];
+#pragma unroll
+    for (int m = 0; m < NOUT; ++m) {
+      T a = core;
+#pragma unroll
+      for (int k = m; k < NOUT - 1; ++k) a += v[k];
+#pragma unroll
+      for (int k = W_; k < W_ + m; ++k) a += v[k];
+      o[m] = a;
     }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < HW_H * HW_T; i += BLK) {          // W pass: (halo row r, output column c)
-    const int r = i / HW_T, c = i - r * HW_T;
-    if (PROD) {
-      float a = 0.f, bb = 0.f, cc = 0.f, e = 0.f, f = 0.f;
+  } else {                                       // windows shorter than the run: no common core
 #pragma unroll
-      for (int k = 0; k < WIN; ++k) {
-        const float iv = raw[0][r * HW_LD + c + k], jv = raw[1][r * HW_LD + c + k];
-        a += iv; bb += jv; cc = fmaf(iv, iv, cc); e = fmaf(jv, jv, e); f = fmaf(iv, jv, f);
-      }
-      tmp[0][i] = a; tmp[1][i] = bb; tmp[2][i] = cc; tmp[3][i] = e; tmp[4][i] = f;
-    } else {
+    for (int m = 0; m < NOUT; ++m) {
+      T a = v[m];
 #pragma unroll
-      for (int v = 0; v < NARR; ++v) {
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < WIN; ++k) a += raw[v][r * HW_LD + c + k];
-        tmp[v][i] = a;
-      }
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < HW_T * HW_T; i += BLK) {          // H pass + store
-    const int r = i / HW_T, c = i - r * HW_T;
-    const int y = y0 + r, x = x0 + c;
-    if (y >= d.H || x >= d.W) continue;
-    const int64_t o = slice + (int64_t)y * d.W + x;
-#pragma unroll
-    for (int v = 0; v < NARR; ++v) {
-      float a = 0.f;
-#pragma unroll
-      for (int k = 0; k < WIN; ++k) a += tmp[v][(r + k) * HW_T + c];
-      out[(int64_t)v * N + o] = a;
+      for (int k = 1; k < W_; ++k) a += v[m + k];
+      o[m] = a;
     }
   }
 }
 
-
-// 9-tap pass along D (axis 0) or H (axis 1) over `nvol` stacked volumes: each thread produces SEG consecutive
-// outputs along the axis from a (SEG+8)-value register window (lanes run along W, so every load is coalesced):
-// 24 loads per 16 outputs instead of 144, each output still the plain 9-term sum.
-constexpr int SEG = 16;
-template <int AXIS>
-__device__ __forceinline__ void seg_decode(int64_t t, const Dims d, int& z, int& y, int& x, int& b) {
-  x = (int)(t % d.W); t /= d.W;
-  if (AXIS == 0) {
-    y = (int)(t % d.H); t /= d.H;
-    const int nseg = (d.D + SEG - 1) / SEG;
-    z = (int)(t % nseg) * SEG; b = (int)(t / nseg);
-  } else {
-    const int nseg = (d.H + SEG - 1) / SEG;
-    y = (int)(t % nseg) * SEG; t /= nseg;
-    z = (int)(t % d.D); b = (int)(t / d.D);
-  }
-}
-template <int AXIS>
-__device__ __forceinline__ void seg_window(const float* __restrict__ vol, const Dims d, int b, int z, int y, int x,
-                                           float (&win)[SEG + 2 * PAD]) {
-  const int len = AXIS == 0 ? d.D : d.H, p0 = AXIS == 0 ? z : y;
-  const int64_t stride = AXIS == 0 ? (int64_t)d.H * d.W : d.W;
-  const float* base = vol + (((int64_t)b * d.D + (AXIS == 0 ? 0 : z)) * d.H + (AXIS == 0 ? y : 0)) * d.W + x;
-#pragma unroll
-  for (int i = 0; i < SEG + 2 * PAD; ++i) {
-    const int p = p0 + i - PAD;
-    win[i] = (p >= 0 && p < len) ? base[(int64_t)p * stride] : 0.f;
-  }
-}
-__device__ __forceinline__ float win_sum(const float (&win)[SEG + 2 * PAD], int i) {
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < WIN; ++k) s += win[i + k];
-  return s;
-}
-
-
-// last forward pass (along D) fused with cc and the three backward coefficients; arithmetic in the
-// reference's own (expanded) order, losses.py:85-91
-__global__ __launch_bounds__(BLK) void ncc_pass_d_fwd_kernel(const float* __restrict__ T, float* __restrict__ coef,
-                                                             float* __restrict__ part, Dims d, int64_t N,
-                                                             int64_t nthreads) {
+// The kernels are VALU-issue bound (measured with compile-time variants: the loads are a tenth of the time), so the
+// quantities travel in PAIRS through registers and LDS and every sum is a packed fp32 instruction (v_pk_add_f32 /
+// v_pk_fma_f32: two lanes' worth of work per issue):  FWD: (I, J) -> pairs (sum I, sum J), (sum I^2, sum J^2) + the single
+// sum I J;  BWD: pair (cB, cD) + the single cE.
+template <int W_, bool FWD>
+__global__ __launch_bounds__(BLK, 2) void ncc_march_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                           const float* __restrict__ Ivol, const float* __restrict__ Jvol,
+                                                           float* __restrict__ out, float* __restrict__ part, Dims d,
+                                                           int64_t N, int tiles_x, int tiles_y, int nchunk, int zc,
+                                                           float g) {
+  constexpr int P = W_ / 2, HY = MT_Y + 2 * P, HXW = MT_X + 2 * P, NVOX = HY * HXW;
+  constexpr int NIN = FWD ? 2 : 3, NPQ = FWD ? 2 : 1;           // inputs; pairs of summed quantities (+ one single)
+  constexpr int NV = (NVOX + BLK - 1) / BLK;                     // halo voxels per thread
+  constexpr int RPT = MT_Y / (BLK / MT_X);                       // output rows per thread in the H pass (3)
+  constexpr float WINSZ_ = (float)(W_ * W_ * W_);
+  __shared__ __attribute__((aligned(16))) f2 zsP[NPQ][HY * HXW + 2];                // + a dummy slot
+  __shared__ __attribute__((aligned(16))) float zsS[HY * HXW + 4];
+  __shared__ __attribute__((aligned(16))) f2 twP[NPQ][HY * MT_X];
+  __shared__ __attribute__((aligned(16))) float twS[HY * MT_X];
   __shared__ float red[BLK / 64];
-  const int64_t stride = (int64_t)d.H * d.W;
-  float lsum = 0.f;
-  for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < nthreads; t += (int64_t)gridDim.x * BLK) {
-    int z, y, x, b;
-    seg_decode<0>(t, d, z, y, x, b);
-    const int64_t o0 = (((int64_t)b * d.D + z) * d.H + y) * d.W + x;
-    float s[5][SEG];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int x0 = (t % tiles_x) * MT_X; t /= tiles_x;
+  const int y0 = (t % tiles_y) * MT_Y; t /= tiles_y;
+  const int zs0 = (t % nchunk) * zc;
+  const int b = t / nchunk;
+  const int ze = zs0 + zc < d.D ? zs0 + zc : d.D;
+  const int64_t plane = (int64_t)d.H * d.W;
+  const float* src[NIN];
+  src[0] = in0 + (int64_t)b * d.D * plane;
+  if constexpr (FWD) src[1] = in1 + (int64_t)b * d.D * plane;
+  else { src[1] = in0 + N + (int64_t)b * d.D * plane; src[2] = in0 + 2 * N + (int64_t)b * d.D * plane; }
+
+  // this thread's halo voxels: byte offset inside a plane (out of range for the zero padding) and LDS slot (a dummy
+  // slot past the tile for the few threads beyond the halo tile's end): every load is a buffer load through a
+  // descriptor of ONE plane -- out-of-range offsets and planes outside the volume (num_records = 0) read 0 -- so a
+  // plane's loads are issued back to back, with no branch and no select
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned goff[NV];
+  int lidx[NV];
 #pragma unroll
-    for (int v = 0; v < 5; ++v) {
-      float win[SEG + 2 * PAD];
-      seg_window<0>(T + (int64_t)v * N, d, b, z, y, x, win);
+  for (int j = 0; j < NV; ++j) {
+    const int i = tid + j * BLK;
+    const int hy = i / HXW, hx = i - hy * HXW;
+    const int y = y0 + hy - P, x = x0 + hx - P;
+    const bool ok = i < NVOX && y >= 0 && y < d.H && x >= 0 && x < d.W;
+    goff[j] = ok ? (unsigned)(y * d.W + x) * 4u : OOB;
+    lidx[j] = i < NVOX ? i : NVOX;
+  }
+  const unsigned plane_bytes = (unsigned)plane * 4u;
+  // the last W_ planes of this thread's halo voxels: inputs 0 and 1 as a pair, input 2 (BWD) on its own
+  f2 ringP[NV][W_], nxtP[NV];
+  float ringS[FWD ? 1 : NV][W_], nxtS[FWD ? 1 : NV];
+  auto load_plane = [&](int z, f2 (&dp)[NV], float (&ds)[FWD ? 1 : NV]) {
+    const bool zin = z >= 0 && z < d.D;
 #pragma unroll
-      for (int i = 0; i < SEG; ++i) s[v][i] = win_sum(win, i);
+    for (int v = 0; v < NIN; ++v) {
+      const uint64_t a = reinterpret_cast<uint64_t>(src[v] + (int64_t)(zin ? z : 0) * plane);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<void*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                                  (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a)),
+          0, (int)(zin ? plane_bytes : 0u), 0x00020000);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const float val = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)goff[j], 0, 0));
+        if (v == 0) dp[j].x = val;
+        else if (v == 1) dp[j].y = val;
+        else ds[FWD ? 0 : j] = val;
+      }
     }
+  };
+  // The window sums do not care which ring slot is the oldest plane, only the REPLACEMENT does: slot (z - zs0) % W_ is
+  // overwritten through a wave-uniform switch (a handful of register moves), nothing is shifted.
+  // prologue: planes zs0 - P .. zs0 + P - 1 into ring slots 1 .. W_-1 (slot 0 is filled by the first iteration)
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-      if (z + i >= d.D) continue;
-      const float I_sum = s[0][i], J_sum = s[1][i], I2_sum = s[2][i], J2_sum = s[3][i], IJ_sum = s[4][i];
-      const float u_I = I_sum / WINSZ, u_J = J_sum / WINSZ;
-      const float cross = IJ_sum - u_J * I_sum - u_I * J_sum + u_I * u_J * WINSZ;
-      const float I_var = I2_sum - 2.f * u_I * I_sum + u_I * u_I * WINSZ;
-      const float J_var = J2_sum - 2.f * u_J * J_sum + u_J * u_J * WINSZ;
-      const float den = I_var * J_var + 1e-5f;
-      const float cc = cross * cross / den;
-      lsum += cc;
-      if (coef) {
-        const float cE = 2.f * cross / den;
-        const float cD = -cc * I_var / den;
-        const float cB = -(cE * I_sum + 2.f * cD * J_sum) / WINSZ;
-        const int64_t o = o0 + (int64_t)i * stride;
-        coef[o] = cB; coef[N + o] = cD; coef[2 * N + o] = cE;
+  for (int k = 1; k < W_; ++k) {
+    f2 tp[NV];
+    float ts[FWD ? 1 : NV];
+    load_plane(zs0 - P + k - 1, tp, ts);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      ringP[j][k] = tp[j];
+      if constexpr (!FWD) ringS[j][k] = ts[j];
+    }
+  }
+  load_plane(zs0 + P, nxtP, nxtS);
+
+  float lsum = 0.f;
+  int slot = 0;
+  for (int z = zs0; z < ze; ++z) {
+    // ring <- planes z - P .. z + P: the newest one replaces the oldest
+#pragma unroll
+    for (int k = 0; k < W_; ++k) {
+      if (slot == k) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          ringP[j][k] = nxtP[j];
+          if constexpr (!FWD) ringS[j][k] = nxtS[j];
+        }
+      }
+    }
+    slot = slot + 1 == W_ ? 0 : slot + 1;
+#if !(NCC_VARIANT & 2)
+    if (z + 1 < ze) load_plane(z + 1 + P, nxtP, nxtS);           // in flight during this plane's arithmetic
+#endif
+    // ---- z box sums of this thread's halo voxels -> LDS
+#pragma unroll
+    for (int j = 0; j < ((NCC_VARIANT & 4) ? 1 : NV); ++j) {
+      f2 ab = {0.f, 0.f};
+      if constexpr (FWD) {
+        f2 ce = {0.f, 0.f};
+        float f = 0.f;
+#pragma unroll
+        for (int k = 0; k < W_; ++k) {
+          const f2 ij = ringP[j][k];
+          ab += ij;                                              // (sum I, sum J)
+          ce = __builtin_elementwise_fma(ij, ij, ce);            // (sum I^2, sum J^2)
+          f = fmaf(ij.x, ij.y, f);                               // sum I J
+        }
+        zsP[0][lidx[j]] = ab; zsP[NPQ - 1][lidx[j]] = ce; zsS[lidx[j]] = f;
+      } else {
+        float c = 0.f;
+#pragma unroll
+        for (int k = 0; k < W_; ++k) { ab += ringP[j][k]; c += ringS[j][k]; }
+        zsP[0][lidx[j]] = ab; zsS[lidx[j]] = c;
+      }
+    }
+    __syncthreads();
+    // ---- W pass: (halo row r, 4 consecutive outputs) from a register window of 4 + W_ - 1 values
+#if !(NCC_VARIANT & 1)
+    {
+      const int r = tid >> 3, c0 = (tid & 7) * 4;
+      if (r < HY) {
+#pragma unroll
+        for (int q = 0; q < NPQ; ++q) {
+          f2 v[4 + W_ - 1], o[4];
+#pragma unroll
+          for (int k = 0; k < 4 + W_ - 1; ++k) v[k] = zsP[q][r * HXW + c0 + k];
+          window_sums<W_, 4>(v, o);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) twP[q][r * MT_X + c0 + m] = o[m];
+        }
+        float v[4 + W_ - 1], o[4];
+#pragma unroll
+        for (int k = 0; k < 4 + W_ - 1; ++k) v[k] = zsS[r * HXW + c0 + k];
+        window_sums<W_, 4>(v, o);
+        *reinterpret_cast<float4*>(&twS[r * MT_X + c0]) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+#endif
+    __syncthreads();
+    // ---- H pass + pointwise tail: column x, RPT consecutive output rows
+    {
+      const int x = tid & (MT_X - 1), r0 = (tid / MT_X) * RPT;
+      f2 sp[NPQ][RPT];
+      float ss[RPT];
+#pragma unroll
+      for (int q = 0; q < NPQ; ++q) {
+        f2 v[RPT + W_ - 1];
+#pragma unroll
+        for (int k = 0; k < RPT + W_ - 1; ++k) v[k] = twP[q][(r0 + k) * MT_X + x];
+        window_sums<W_, RPT>(v, sp[q]);
+      }
+      {
+        float v[RPT + W_ - 1];
+#pragma unroll
+        for (int k = 0; k < RPT + W_ - 1; ++k) v[k] = twS[(r0 + k) * MT_X + x];
+        window_sums<W_, RPT>(v, ss);
+      }
+#pragma unroll
+      for (int m = 0; m < RPT; ++m) {
+        const int y = y0 + r0 + m, xg = x0 + x;
+        if (y >= d.H || xg >= d.W) continue;
+        const int64_t o = ((int64_t)b * d.D + z) * plane + (int64_t)y * d.W + xg;
+        if constexpr (FWD) {
+          // the reference's own (expanded) order, losses.py:85-91
+          const float I_sum = sp[0][m].x, J_sum = sp[0][m].y, I2_sum = sp[NPQ - 1][m].x, J2_sum = sp[NPQ - 1][m].y, IJ_sum = ss[m];
+          // (six IEEE divisions per voxel were a third of this kernel's instructions: the window size divides as a
+          // multiplication by its rounded reciprocal, 1 / den is one v_rcp_f32 (1 ulp) shared by cc, cE and cD)
+          constexpr float RW = 1.f / WINSZ_;
+          const float u_I = I_sum * RW, u_J = J_sum * RW;
+          const float cross = IJ_sum - u_J * I_sum - u_I * J_sum + u_I * u_J * WINSZ_;
+          const float I_var = I2_sum - 2.f * u_I * I_sum + u_I * u_I * WINSZ_;
+          const float J_var = J2_sum - 2.f * u_J * J_sum + u_J * u_J * WINSZ_;
+          const float rden = __builtin_amdgcn_rcpf(I_var * J_var + 1e-5f);
+          const float cc = cross * cross * rden;
+          lsum += cc;
+          if (out) {
+            const float cE = 2.f * cross * rden;
+            const float cD = -cc * I_var * rden;
+            const float cB = -(cE * I_sum + 2.f * cD * J_sum) * RW;
+            out[o] = cB; out[N + o] = cD; out[2 * N + o] = cE;
+          }
+        } else {
+          out[o] = g * (sp[0][m].x + 2.f * Jvol[o] * sp[0][m].y + Ivol[o] * ss[m]);
+        }
       }
     }
   }
-  const float r = block_sum(lsum, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = r;
-}
-
-// last backward pass (along D) fused with the final combine
-__global__ __launch_bounds__(BLK) void ncc_pass_d_bwd_kernel(const float* __restrict__ T, const float* __restrict__ I,
-                                                             const float* __restrict__ J, float* __restrict__ dJ,
-                                                             Dims d, int64_t N, float g, int64_t nthreads) {
-  const int64_t stride = (int64_t)d.H * d.W;
-  for (int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x; t < nthreads; t += (int64_t)gridDim.x * BLK) {
-    int z, y, x, b;
-    seg_decode<0>(t, d, z, y, x, b);
-    const int64_t o0 = (((int64_t)b * d.D + z) * d.H + y) * d.W + x;
-    float s[3][SEG];
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      float win[SEG + 2 * PAD];
-      seg_window<0>(T + (int64_t)v * N, d, b, z, y, x, win);
-#pragma unroll
-      for (int i = 0; i < SEG; ++i) s[v][i] = win_sum(win, i);
-    }
-#pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-      if (z + i >= d.D) continue;
-      const int64_t o = o0 + (int64_t)i * stride;
-      dJ[o] = g * (s[0][i] + 2.f * J[o] * s[1][i] + I[o] * s[2][i]);
-    }
+  if constexpr (FWD) {
+    const float r = block_sum(lsum, red);
+    if (tid == 0) part[blockIdx.x] = r;
   }
 }
+
+struct MarchPlan { int tiles_x, tiles_y, nchunk, zc, grid; };
+inline MarchPlan march_plan(int B, int D, int H, int W, int win) {
+  MarchPlan p;
+  p.tiles_x = cdiv(W, MT_X); p.tiles_y = cdiv(H, MT_Y);
+  // z chunks: every chunk re-reads win - 1 planes, so as long as the chip allows (>= ~3 workgroups per CU)
+  const int cols = B * p.tiles_x * p.tiles_y;
+  int n = cdiv(768, cols);
+  if (n < 1) n = 1;
+  int zc = cdiv(D, n);
+  if (zc < win) zc = win < D ? win : D;
+  p.zc = zc; p.nchunk = cdiv(D, zc);
+  p.grid = cols * p.nchunk;
+  return p;
+}
+
 
 // loss[0] = scale * sum(part[0..n))  (fp64, fixed order); optionally adds into loss (accumulate != 0)
 __global__ void scalar_finalize_kernel(const float* __restrict__ part, int n, double scale, float* __restrict__ loss) {
@@ -250,37 +341,44 @@ extern "C" {
 
 size_t modet_ncc_ws_bytes(int B, int D, int H, int W) {
   const int64_t N = (int64_t)B * D * H * W;
-  return ((size_t)10 * N + 2048) * sizeof(float);
+  // the three coefficient volumes of the backward + one loss partial per workgroup of the forward kernel
+  return ((size_t)3 * N + (size_t)march_plan(B, D, H, W, 3).grid + 64) * sizeof(float);
+}
+
+int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B, int D,
+                          int H, int W, int win, modet_stream_t stream) {
+  MODET_CHECK_PTR(I); MODET_CHECK_PTR(J); MODET_CHECK_PTR(loss); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0);
+  if (win != 3 && win != 5 && win != 7 && win != 9) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_ncc_ws_bytes(B, D, H, W)) return MODET_ERR_WORKSPACE;
+  if ((int64_t)D * H * W >= (1ll << 31)) return MODET_ERR_DIM;
+  hipStream_t s = (hipStream_t)stream;
+  const Dims d{B, D, H, W};
+  const int64_t N = (int64_t)B * D * H * W;
+  float* coef = (float*)ws;
+  float* part = coef + 3 * N;
+  const MarchPlan p = march_plan(B, D, H, W, win);
+#define NCC_GO(W_)                                                                                                          \
+  do {                                                                                                                     \
+    hipLaunchKernelGGL((ncc_march_kernel<W_, true>), dim3(p.grid), dim3(BLK), 0, s, I, J, (const float*)nullptr,          \
+                       (const float*)nullptr, d_J ? coef : (float*)nullptr, part, d, N, p.tiles_x, p.tiles_y, p.nchunk, p.zc, 0.f); \
+    hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(BLK), 0, s, (const float*)part, p.grid, -1.0 / (double)N, loss); \
+    if (d_J)                                                                                                               \
+      hipLaunchKernelGGL((ncc_march_kernel<W_, false>), dim3(p.grid), dim3(BLK), 0, s, (const float*)coef,                \
+                         (const float*)nullptr, I, J, d_J, (float*)nullptr, d, N, p.tiles_x, p.tiles_y, p.nchunk, p.zc,    \
+                         -1.f / (float)N);                                                                                 \
+  } while (0)
+  if (win == 9) NCC_GO(9);
+  else if (win == 7) NCC_GO(7);
+  else if (win == 5) NCC_GO(5);
+  else NCC_GO(3);
+#undef NCC_GO
+  return modet_launch_status();
 }
 
 int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B, int D,
                       int H, int W, modet_stream_t stream) {
-  MODET_CHECK_PTR(I); MODET_CHECK_PTR(J); MODET_CHECK_PTR(loss); MODET_CHECK_PTR(ws);
-  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0);
-  if (ws_bytes < modet_ncc_ws_bytes(B, D, H, W)) return MODET_ERR_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
-  const Dims d{B, D, H, W};
-  const int64_t N = (int64_t)B * D * H * W;
-  float* T1 = (float*)ws;
-  float* T2 = T1 + 5 * N;
-  float* part = T2 + 5 * N;
-  const int64_t nth_d = (int64_t)B * cdiv(D, SEG) * H * W;
-  int rg = flat_grid(nth_d, BLK);
-  if (rg > 2048) rg = 2048;
-  // forward: W+H box sums of the five products (one kernel) -> D pass fused with cc and the loss partials
-  const int tw = cdiv(W, HW_T), th = cdiv(H, HW_T);
-  const dim3 hwgrid(tw * th, D, B);
-  hipLaunchKernelGGL((box_hw_kernel<5, true>), hwgrid, dim3(BLK), 0, s, I, J, T2, d, N, tw);
-  hipLaunchKernelGGL(ncc_pass_d_fwd_kernel, dim3(rg), dim3(BLK), 0, s, (const float*)T2, d_J ? T1 : nullptr, part, d, N, nth_d);
-  hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(BLK), 0, s, (const float*)part, rg, -1.0 / (double)N, loss);
-  if (d_J) {
-    // backward: the box sum is self-adjoint: W+H on the three coefficient volumes, D pass fused with the final formula
-    hipLaunchKernelGGL((box_hw_kernel<3, false>), hwgrid, dim3(BLK), 0, s, (const float*)T1, (const float*)nullptr, T2, d, N,
-                       tw);
-    hipLaunchKernelGGL(ncc_pass_d_bwd_kernel, dim3(flat_grid(nth_d, BLK)), dim3(BLK), 0, s, (const float*)T2, I, J, d_J, d, N,
-                       -1.f / (float)N, nth_d);
-  }
-  return modet_launch_status();
+  return modet_ncc_fwd_bwd_win(I, J, loss, d_J, ws, ws_bytes, B, D, H, W, 9, stream);
 }
 
 size_t modet_grad3d_ws_bytes(int, int, int, int) { return 2048 * sizeof(float); }

@@ -25,13 +25,17 @@ class Grad3d(torch.nn.Module):
 
 
 class NCC_vxm(torch.nn.Module):
-    """local (9^3 window) normalized cross correlation loss (reference losses.py:34-94)."""
+    """local normalized cross correlation loss over win^3 windows (reference losses.py:34-94); ``win`` = None (the
+    reference's default [9, 9, 9], what train.py:103 uses) or a cubic window [w, w, w] with w in {3, 5, 7, 9}.  The
+    reference pads every axis by floor(win[0] / 2) (losses.py:57), so only cubic odd windows keep the volume's shape there."""
 
     def __init__(self, win=None):
         super().__init__()
-        if win is not None and list(win) != [9, 9, 9]:
-            raise RuntimeError("NCC_vxm: only the default 9x9x9 window is implemented on the HIP path")
+        w = [9, 9, 9] if win is None else [int(v) for v in win]
+        if len(w) != 3 or w[0] != w[1] or w[0] != w[2] or w[0] not in (3, 5, 7, 9):
+            raise RuntimeError(f"NCC_vxm: cubic windows of 3, 5, 7 or 9 voxels are implemented on the HIP path, got {win}")
         self.win = win
+        self._w = w[0]
 
     def forward(self, y_true, y_pred):
-        return ops.ncc_loss(y_true.contiguous(), y_pred.contiguous())
+        return ops.ncc_loss(y_true.contiguous(), y_pred.contiguous(), self._w)

@@ -1001,8 +1001,8 @@ def _scale_by(x, s):
     return y
 
 
-def _ncc_launch(I, J, want_grad):
-    """modet_ncc_fwd_bwd(I, J): (loss (1,), d loss / d J or None)"""
+def _ncc_launch(I, J, want_grad, win=9):
+    """modet_ncc_fwd_bwd_win(I, J): (loss (1,), d loss / d J or None)"""
     B, _, D, H, W = I.shape
     loss = torch.empty(1, dtype=torch.float32, device=I.device)
     dJ = torch.empty_like(J) if want_grad else None
@@ -1011,7 +1011,8 @@ def _ncc_launch(I, J, want_grad):
     ws = _ws(nb, I)
     nv = float(I.numel())               # reads I,J once, writes d_J once
     with _Guard(I, "ncc_fwd_bwd", 400.0 * nv, 12.0 * nv):
-        _lib.check(L.modet_ncc_fwd_bwd(_p(I), _p(J), _p(loss), _p(dJ), _p(ws), nb, B, D, H, W, _stream()), "modet_ncc_fwd_bwd")
+        _lib.check(L.modet_ncc_fwd_bwd_win(_p(I), _p(J), _p(loss), _p(dJ), _p(ws), nb, B, D, H, W, int(win), _stream()),
+                   "modet_ncc_fwd_bwd_win")
     return loss, dJ
 
 
@@ -1021,18 +1022,18 @@ class _NCC(Function):
     ``loss_function(output[n], y)`` = NCC_vxm.forward(y_true=y_moved, y_pred=fixed))."""
 
     @staticmethod
-    def forward(ctx, y_true, y_pred):
+    def forward(ctx, y_true, y_pred, win=9):
         _chk(y_true, y_pred)
         if y_true.shape != y_pred.shape or y_true.dim() != 5 or y_true.shape[1] != 1:
             raise RuntimeError("NCC: expects two (B,1,D,H,W) volumes")
         need_t, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         d_t = d_p = None
         if need_t and not need_p:
-            loss, d_t = _ncc_launch(y_pred, y_true, True)
+            loss, d_t = _ncc_launch(y_pred, y_true, True, win)
         else:
-            loss, d_p = _ncc_launch(y_true, y_pred, need_p)
+            loss, d_p = _ncc_launch(y_true, y_pred, need_p, win)
             if need_t:
-                _, d_t = _ncc_launch(y_pred, y_true, True)
+                _, d_t = _ncc_launch(y_pred, y_true, True, win)
         ctx.save_for_backward(d_t, d_p)
         return loss.reshape(())
 
@@ -1040,12 +1041,12 @@ class _NCC(Function):
     def backward(ctx, g):
         d_t, d_p = ctx.saved_tensors
         g = g.contiguous().reshape(1)
-        return (None if d_t is None else _scale_by(d_t, g)), (None if d_p is None else _scale_by(d_p, g))
+        return (None if d_t is None else _scale_by(d_t, g)), (None if d_p is None else _scale_by(d_p, g)), None
 
 
-def ncc_loss(y_true, y_pred):
-    """NCC_vxm(win=9): -mean(cc).  reference: losses.py:34-94"""
-    return _NCC.apply(y_true, y_pred)
+def ncc_loss(y_true, y_pred, win=9):
+    """NCC_vxm: -mean(cc) over win^3 windows (win 3 / 5 / 7 / 9; default 9).  reference: losses.py:34-94"""
+    return _NCC.apply(y_true, y_pred, int(win))
 
 
 class _Grad3d(Function):

@@ -91,6 +91,25 @@ lo = orc.ncc_loss(a2, b)
 (gao,) = torch.autograd.grad(lo, a2)
 REPORT.append(f"ncc first-arg: |oracle-ref| value {abs(float(lo) - float(lv)):.3e}, grad {float((gao - ga).abs().max()):.3e}")
 
+# ---------------------------------------------------------------- NCC_vxm(win=[w, w, w]) for the other cubic windows (losses.py:52-57)
+torch.Tensor.to = _cpu_to
+torch.ones = lambda *a, **k: _ones(*a, **{**k, "dtype": torch.float64})
+try:
+    for w in (3, 5, 7):
+        mov, fix = synth.make_pair((13, 27, 35), 50 + w)         # ragged against the kernel's 24 x 32 tiles
+        a = torch.from_numpy(mov).double().requires_grad_(True)
+        b = torch.from_numpy(fix).double().requires_grad_(True)
+        lv = ref_losses.NCC_vxm(win=[w, w, w])(a, b)
+        ga, gb = torch.autograd.grad(lv, [a, b])
+        out[f"nccw{w}.a"], out[f"nccw{w}.b"], out[f"nccw{w}.val"] = mov, fix, np.array(float(lv))
+        out[f"nccw{w}.da"], out[f"nccw{w}.db"] = ga.numpy(), gb.numpy()
+        a2 = torch.from_numpy(mov).double().requires_grad_(True)
+        lo = orc.ncc_loss(a2, b.detach(), win=w)
+        (gao,) = torch.autograd.grad(lo, a2)
+        REPORT.append(f"ncc win {w}: |oracle-ref| value {abs(float(lo) - float(lv)):.3e}, grad {float((gao - ga).abs().max()):.3e}")
+finally:
+    torch.Tensor.to, torch.ones = _to, _ones
+
 np.savez_compressed(os.path.join(HERE, "op_eval.npz"), **out)
 with open(os.path.join(HERE, "REPORT_eval.txt"), "w") as f:
     f.write("\n".join(REPORT) + "\n")

@@ -522,6 +522,13 @@ def test_oracle_eval_goldens(orc):
     l = orc.ncc_loss(a, T(g["ncc1.b"]))
     assert abs(float(l) - float(g["ncc1.val"])) < 1e-12
     assert_close(torch.autograd.grad(l, a)[0].numpy(), g["ncc1.da"], atol=1e-15, rtol=1e-9, what="ncc d y_true")
+    for w in (3, 5, 7):                                     # NCC_vxm(win=[w, w, w]), from the reference's own class
+        a, b = T(g[f"nccw{w}.a"]).requires_grad_(True), T(g[f"nccw{w}.b"]).requires_grad_(True)
+        l = orc.ncc_loss(a, b, win=w)
+        assert abs(float(l) - float(g[f"nccw{w}.val"])) < 1e-12
+        da, db = torch.autograd.grad(l, [a, b])
+        assert_close(da.numpy(), g[f"nccw{w}.da"], atol=1e-15, rtol=1e-9, what=f"ncc win {w} d y_true")
+        assert_close(db.numpy(), g[f"nccw{w}.db"], atol=1e-15, rtol=1e-9, what=f"ncc win {w} d y_pred")
 
 
 # ------------------------------------------------------------------------------------------------ C oracle pins

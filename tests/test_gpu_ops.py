@@ -780,6 +780,43 @@ def test_ncc_first_argument_gradient_golden(ops):
     assert_close(np64(db), g2["ncc.db"], atol=2e-6, rtol=2e-3, what="ncc d y_pred (both)")
 
 
+@pytest.mark.parametrize("w", [3, 5, 7])
+def test_ncc_other_windows_golden(ops, w):
+    """NCC_vxm(win=[w, w, w]) (losses.py:52-57), goldens from the reference's own class on a volume ragged against the
+    kernel's tiles; windows the HIP path does not implement are refused loudly, not approximated"""
+    from smilecode_amd import losses
+    g = gold("op_eval.npz")
+    a, b = cu(g[f"nccw{w}.a"]).requires_grad_(True), cu(g[f"nccw{w}.b"]).requires_grad_(True)
+    l = losses.NCC_vxm(win=[w, w, w])(a, b)
+    assert_close(np64(l), g[f"nccw{w}.val"], atol=2e-5, what="ncc value")
+    da, db = torch.autograd.grad(l, [a, b])
+    assert_close(np64(da), g[f"nccw{w}.da"], atol=2e-6, rtol=2e-3, what="ncc d y_true")
+    assert_close(np64(db), g[f"nccw{w}.db"], atol=2e-6, rtol=2e-3, what="ncc d y_pred")
+    for bad in ([4, 4, 4], [9, 9, 5], [11, 11, 11], [9, 9]):
+        with pytest.raises(RuntimeError):
+            losses.NCC_vxm(win=bad)
+
+
+@pytest.mark.parametrize("shape,B", [((37, 50, 70), 2), ((9, 24, 32), 1), ((4, 5, 6), 1), ((70, 49, 33), 1)])
+def test_ncc_z_march_vs_oracle(ops, orc, shape, B):
+    """the z-marching NCC kernels on shapes that exercise several z chunks per column, ragged tiles in y and x, and
+    volumes smaller than the 9-voxel window, against the fp64 oracle (value, both gradients)"""
+    gen = torch.Generator().manual_seed(shape[0] * 7 + B)
+    base = torch.rand((B, 1) + shape, generator=gen).double()
+    a = (base + 0.3 * torch.rand((B, 1) + shape, generator=gen).double()).requires_grad_(True)
+    b = (base + 0.3 * torch.rand((B, 1) + shape, generator=gen).double()).requires_grad_(True)
+    lr = orc.ncc_loss(a, b)
+    ra, rb = torch.autograd.grad(lr, [a, b])
+    ad, bd = a.detach().float().cuda().requires_grad_(True), b.detach().float().cuda().requires_grad_(True)
+    l = ops.ncc_loss(ad, bd)
+    da, db = torch.autograd.grad(l, [ad, bd])
+    assert_close(np64(l), float(lr), atol=2e-5, what="ncc value")
+    assert_close(np64(da), ra.numpy(), atol=2e-6 / B, rtol=2e-3, what="ncc d y_true")
+    assert_close(np64(db), rb.numpy(), atol=2e-6 / B, rtol=2e-3, what="ncc d y_pred")
+    l2 = ops.ncc_loss(ad, bd)
+    assert torch.equal(l, l2), "deterministic two-stage loss reduction"
+
+
 def test_grad3d_l1_golden(ops):
     """Grad3d's class default penalty (losses.py:11), golden from the reference's own Grad3d('l1')"""
     from smilecode_amd import losses
