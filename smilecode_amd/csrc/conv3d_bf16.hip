@@ -891,6 +891,10 @@ bool modetx_x3_bf16_eligible(int B, int D, int H, int W, int Cin, int Cout, int 
 int modetx_x3_bf16_rows_per_sample(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_bf16_conv(modet_step_ctx* step, const void* x, int x_bf16, const float* w, const float* bias, void* y, int y_bf16,
                         void* ws, float* stats, int B, int D, int H, int W, int Cin, int Cout, int mode, hipStream_t s);
+bool modetx_x3_bf16_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout, int x_bf16);
+size_t modetx_x3_bf16_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modetx_x3_bf16_wgrad(modet_step_ctx* defer, const void* x, int x_bf16, const void* dy, float* dw, float* db, void* ws, int B,
+                         int D, int H, int W, int Cin, int Cout, hipStream_t s);
 size_t modetx_bf16_prepack_bytes(modet_step_ctx* c) {
   std::lock_guard<std::mutex> lk(c->mu);
   size_t n = 0;
@@ -983,7 +987,12 @@ int modet_conv3d_bf16_bwd_data(const void* d_y, const float* w, void* d_x, int d
 
 size_t modet_conv3d_bf16_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   const WgBf16Plan p = plan_wgrad_bf16(B, D, H, W, Cin, Cout);
-  return ((size_t)p.gx + 1) * p.gy * p.red_fl * sizeof(float);        // workgroup partials + their column sums
+  size_t need = ((size_t)p.gx + 1) * p.gy * p.red_fl * sizeof(float);        // workgroup partials + their column sums
+  if (x3_on() && modetx_x3_bf16_wgrad_eligible(B, D, H, W, Cin, Cout, 0)) {
+    const size_t x3 = modetx_x3_bf16_wgrad_ws_bytes(B, D, H, W, Cin, Cout);
+    need = x3 > need ? x3 : need;
+  }
+  return need;
 }
 
 static int bf16_bwd_weight_impl(const void* x, int x_bf16, const void* d_y, float* d_w, float* d_bias, void* ws,
@@ -1010,8 +1019,11 @@ static int bf16_bwd_weight_impl(const void* x, int x_bf16, const void* d_y, floa
   if (Cin > 8 && Cin % 16 != 0) return MODET_ERR_UNSUPPORTED;            // channel blocks of 16 beyond Cin = 8
   if (Cin == 4 && x_bf16) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_conv3d_bf16_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
-  const WgBf16Plan p = plan_wgrad_bf16(B, D, H, W, Cin, Cout);
   hipStream_t s = (hipStream_t)stream;
+  // the few-channel full-resolution layers: z-marching kernel (conv3d_x3.hip), one bf16 piece per operand
+  if (x3_on() && modetx_x3_bf16_wgrad_eligible(B, D, H, W, Cin, Cout, x_bf16))
+    return modetx_x3_bf16_wgrad(defer, x, x_bf16, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s);
+  const WgBf16Plan p = plan_wgrad_bf16(B, D, H, W, Cin, Cout);
   const dim3 grid(p.gx, p.gy);
 #define WG_BF(CIB_, U_, NTB_, TZ_, TY_)                                                                                     \
   do {                                                                                                                     \

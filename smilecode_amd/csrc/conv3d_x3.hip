@@ -644,7 +644,7 @@ int x3_launch16(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws
 // workgroup goes to the fixed-order fp64 reduction shared with the bf16 path (deterministic, no atomics).
 constexpr int WTX = 32, WHXP = 48, WTY = 4, WHY = WTY + 2;
 struct X3WArgs {
-  const float* x; const float* dy; float* part;
+  const void* x; const void* dy; float* part;                    // fp32; bf16 in the one-piece (storage) form
   int D, H, W, Cin, Cout, tiles_x, tiles_y, nchunk, ZC, nitems;
 };
 
@@ -653,19 +653,23 @@ struct X3WArgs {
 // gradient of tap dx = t - q: (0,1), (0,0), (1,0) are dx = -1, 0, +1 and (1,1) is not a tap -- two row tiles per group
 // instead of three, a third fewer MFMAs.  The q = 1 columns see the segment shifted by +1: what they miss over a whole row
 // (u = 0, tap dx = -1) multiplies the zero padding x[-1], so nothing is lost; d_y rows carry one extra voxel.
-template <int CIB, int NCO, bool NP>
-__global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a) {
+// NPC = 1 (BASELINE.json configs[4], bf16 storage): d_y is bf16 in HBM, x is bf16 (X16) or fp32 rounded while staged; one
+// piece per operand, one MFMA per tile instead of six, no split -- conv3d_bf16_wgrad_kernel's contract in this structure.
+template <int CIB, int NCO, bool NP, int NPC = 3, bool X16 = false>
+__global__ __launch_bounds__(NTHR, NPC == 1 ? 3 : 2) void conv_x3_wgrad_kernel(const X3WArgs a) {
   static_assert(!NP || NCO == 8, "N packing: 2 x 8 couts");
+  static_assert(NPC == 3 || NPC == 1, "three pieces (fp32 accuracy) or one (bf16 storage)");
+  static_assert(NPC == 1 || !X16, "bf16 x belongs to the one-piece form");
+  constexpr bool D16 = NPC == 1;                                 // d_y is bf16 in HBM
   constexpr int U = CIB == 8 ? 5 : 3;                            // tap groups: 2 (dz,dy) combos x 8 channels, or 4 x 4
   constexpr int NT = NP ? 2 : 3;                                 // row tiles per group
   constexpr int PX = WHY * WHXP + 8;                             // elements of one channel's plane (+8: spreads the planes over the banks)
-  constexpr int XPIECE = CIB * PX, XSLOT = 3 * XPIECE;
+  constexpr int XPIECE = CIB * PX, XSLOT = NPC * XPIECE;
   constexpr int DROW = NP ? 40 : WTX;                            // d_y row: 32 voxels (+1 for the shifted columns, padded to 16 bytes)
   constexpr int DPAIRS = NP ? 17 : 16;
-  constexpr int PD = WTY * DROW + 8, DPIECE = NCO * PD, DSLOT = 3 * DPIECE;
+  constexpr int PD = WTY * DROW + 8, DPIECE = NCO * PD, DSLOT = NPC * DPIECE;
   constexpr int RED_FL = (U * NT + 1) * 256;
-  constexpr int LDS_EL = 4 * XSLOT + 2 * DSLOT;
-  static_assert(LDS_EL * 2 >= RED_FL * 4, "the cross-wave reduction re-uses the plane buffers");
+  constexpr int LDS_EL = (4 * XSLOT + 2 * DSLOT) * 2 >= RED_FL * 4 ? 4 * XSLOT + 2 * DSLOT : RED_FL * 2;   // (the cross-wave reduction re-uses the plane buffers)
   __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_EL];
   unsigned short* xs = lds;
   unsigned short* dys = lds + 4 * XSLOT;
@@ -707,49 +711,76 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a)
   const int dc4 = tid % QD, dpr = (tid / QD) % DPAIRS, drow = tid / (QD * DPAIRS);
   const int xl = (xc4 * 4) * PX + xhy * WHXP + 2 * (xpr + 3);   // element of channel xc4*4, piece 0, inside an x slot
   const int dl = (dc4 * 4) * PD + drow * DROW + 2 * dpr;
-  const unsigned in_plane_bytes = (unsigned)H * W * Cin * 4, dy_plane_bytes = (unsigned)H * W * Cout * 4;
+  constexpr int XSZ = X16 ? 2 : 4, DSZ = D16 ? 2 : 4;            // bytes per element in HBM
+  const unsigned in_plane_bytes = (unsigned)H * W * Cin * XSZ, dy_plane_bytes = (unsigned)H * W * Cout * DSZ;
 
   unsigned gx0 = X3_OOB, gx1 = X3_OOB, gd0 = X3_OOB, gd1 = X3_OOB;
-  const float* xb = a.x;
-  const float* db_ = a.dy;
-  struct Pair { float4 v0, v1; };                                // the two voxels of a thread's x pair / d_y pair
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
+  const unsigned char* db_ = reinterpret_cast<const unsigned char*>(a.dy);
+  struct Pair { float4 v0, v1; };                                // the two voxels of a thread's x pair / d_y pair (4 channels each;
+                                                                 // bf16 tensors: 8 bytes per voxel in .x, .y)
+  auto ld4 = [&](const BufRsrc rs, unsigned off, bool is16) -> float4 {
+    if (is16) {
+      const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+      return make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), 0.f, 0.f);
+    }
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+  };
   auto load_x = [&](int z) -> Pair {
     const bool live = z >= 0 && z < D;
-    const BufRsrc rs = plane_rsrc(xb + (int64_t)(live ? z : 0) * H * W * Cin, live ? in_plane_bytes : 0u);
+    const BufRsrc rs = plane_rsrc(reinterpret_cast<const float*>(xb + (int64_t)(live ? z : 0) * in_plane_bytes), live ? in_plane_bytes : 0u);
     Pair p;
-    p.v0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gx0, 0, 0));
-    p.v1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gx1, 0, 0));
+    p.v0 = ld4(rs, gx0, X16);
+    p.v1 = ld4(rs, gx1, X16);
     return p;
   };
   auto load_dy = [&](int z, int ze) -> Pair {
     const bool live = z < ze;
-    const BufRsrc rs = plane_rsrc(db_ + (int64_t)(live ? z : 0) * H * W * Cout, live ? dy_plane_bytes : 0u);
+    const BufRsrc rs = plane_rsrc(reinterpret_cast<const float*>(db_ + (int64_t)(live ? z : 0) * dy_plane_bytes), live ? dy_plane_bytes : 0u);
     Pair p;
-    p.v0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gd0, 0, 0));
-    p.v1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gd1, 0, 0));
+    p.v0 = ld4(rs, gd0, D16);
+    p.v1 = ld4(rs, gd1, D16);
     return p;
   };
-  // split a voxel pair's 4 channels into three packed pieces each and write them into the channel planes
-  auto put = [&](unsigned short* base, int piece_el, int plane_el, const Pair& pr) {
-    const float p0[4] = {pr.v0.x, pr.v0.y, pr.v0.z, pr.v0.w}, p1[4] = {pr.v1.x, pr.v1.y, pr.v1.z, pr.v1.w};
+  // a voxel pair's 4 channels -> packed (voxel, voxel + 1) words in the channel planes: split into three pieces each
+  // (fp32 accuracy), or one bf16 piece (rounded here if the tensor is fp32, re-paired if it already is bf16)
+  auto put = [&](unsigned short* base, int piece_el, int plane_el, const Pair& pr, bool is16) {
+    if constexpr (NPC == 1) {
+      unsigned w[4];
+      if (is16) {
+        const unsigned a0 = __float_as_uint(pr.v0.x), a1 = __float_as_uint(pr.v0.y);     // voxel 0: (c0 | c1 << 16), (c2 | c3 << 16)
+        const unsigned b0 = __float_as_uint(pr.v1.x), b1 = __float_as_uint(pr.v1.y);     // voxel 1
+        w[0] = __builtin_amdgcn_perm(b0, a0, 0x05040100u);      // (a0.lo, b0.lo)
+        w[1] = __builtin_amdgcn_perm(b0, a0, 0x07060302u);      // (a0.hi, b0.hi)
+        w[2] = __builtin_amdgcn_perm(b1, a1, 0x05040100u);
+        w[3] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+      } else {
+        w[0] = pk_bf16(pr.v0.x, pr.v1.x); w[1] = pk_bf16(pr.v0.y, pr.v1.y);
+        w[2] = pk_bf16(pr.v0.z, pr.v1.z); w[3] = pk_bf16(pr.v0.w, pr.v1.w);
+      }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      unsigned h, m, l;
-      split3_pk(p0[c], p1[c], h, m, l);
-      unsigned* d = reinterpret_cast<unsigned*>(base + c * plane_el);
-      d[0] = h; d[piece_el / 2] = m; d[piece_el] = l;            // piece stride in 32-bit words: piece_el / 2
+      for (int c = 0; c < 4; ++c) *reinterpret_cast<unsigned*>(base + c * plane_el) = w[c];
+    } else {
+      const float p0[4] = {pr.v0.x, pr.v0.y, pr.v0.z, pr.v0.w}, p1[4] = {pr.v1.x, pr.v1.y, pr.v1.z, pr.v1.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsigned h, m, l;
+        split3_pk(p0[c], p1[c], h, m, l);
+        unsigned* d = reinterpret_cast<unsigned*>(base + c * plane_el);
+        d[0] = h; d[piece_el / 2] = m; d[piece_el] = l;          // piece stride in 32-bit words: piece_el / 2
+      }
     }
   };
-  auto store_x = [&](int slot, const Pair& pr) { if (xon) put(xs + slot * XSLOT + xl, XPIECE, PX, pr); };
-  auto store_dy = [&](int slot, const Pair& pr) { if (don) put(dys + slot * DSLOT + dl, DPIECE, PD, pr); };
+  auto store_x = [&](int slot, const Pair& pr) { if (xon) put(xs + slot * XSLOT + xl, XPIECE, PX, pr, X16); };
+  auto store_dy = [&](int slot, const Pair& pr) { if (don) put(dys + slot * DSLOT + dl, DPIECE, PD, pr, D16); };
 
   // ---- one d_y plane (slot ds) against the three x planes around it: x plane of tap dz sits in ring slot (q + dz) & 3
   auto compute = [&](int q, int ds) {
     const int row = wave;                                        // WTY = 4 rows, one k-step per wave and plane
     const unsigned short* db = dys + ds * DSLOT + boff + row * DROW;
-    bf16x8 b[3];
+    bf16x8 b[NPC];
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+    for (int pc = 0; pc < NPC; ++pc) {
       const uint4 qq = *reinterpret_cast<const uint4*>(db + pc * DPIECE);
       if constexpr (NP) {
         const unsigned r0 = *reinterpret_cast<const unsigned*>(db + pc * DPIECE + 8);
@@ -760,32 +791,31 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a)
         b[pc] = __builtin_bit_cast(bf16x8, qq);
       }
     }
-    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[2], accb, 0, 0, 0);
-    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[1], accb, 0, 0, 0);
-    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[0], accb, 0, 0, 0);
+#pragma unroll
+    for (int pc = NPC - 1; pc >= 0; --pc) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[pc], accb, 0, 0, 0);
     // raw operand words of a group (per piece: the aligned 16-byte block and its neighbours) are read one group AHEAD of
     // the MFMAs that use them, fenced: left alone the scheduler sinks each read to its first use and every group starts
     // with an exposed LDS round trip
     struct Raw { uint4 qq; unsigned r0, p3; };
-    auto rd = [&](int u, Raw (&w)[3]) {
+    auto rd = [&](int u, Raw (&w)[NPC]) {
       const unsigned short* pa = xs + ((q + adz[u]) & 3) * XSLOT + aoff[u] + row * WHXP;
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
+      for (int pc = 0; pc < NPC; ++pc) {
         const unsigned short* pp = pa + pc * XPIECE;
         w[pc].qq = *reinterpret_cast<const uint4*>(pp + 8);
         w[pc].r0 = *reinterpret_cast<const unsigned*>(pp + 16);
         w[pc].p3 = NP ? 0u : *reinterpret_cast<const unsigned*>(pp + 6);
       }
     };
-    Raw raw[2][3];
+    Raw raw[2][NPC];
     rd(0, raw[0]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (u + 1 < U) rd(u + 1, raw[(u + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-      bf16x8 f[3][NT];                                           // [piece][row tile]
+      bf16x8 f[NPC][NT];                                         // [piece][row tile]
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
+      for (int pc = 0; pc < NPC; ++pc) {
         const uint4 qq = raw[u & 1][pc].qq;
         const unsigned r0 = raw[u & 1][pc].r0;
         const unsigned a1 = __builtin_amdgcn_alignbit(qq.y, qq.x, 16), a2 = __builtin_amdgcn_alignbit(qq.z, qq.y, 16),
@@ -804,7 +834,8 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a)
 #define X3W(AP, BP)                                                                                      \
       _Pragma("unroll") for (int d = 0; d < NT; ++d)                                                      \
         acc[u][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[AP][d], b[BP], acc[u][d], 0, 0, 0);
-      X3W(2, 0) X3W(0, 2) X3W(1, 1) X3W(1, 0) X3W(0, 1) X3W(0, 0)
+      if constexpr (NPC == 3) { X3W(2, 0) X3W(0, 2) X3W(1, 1) X3W(1, 0) X3W(0, 1) }
+      X3W(0, 0)
 #undef X3W
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -818,17 +849,17 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a)
     const int b = t / a.nchunk;
     const int x0 = tx * WTX, y0 = ty * WTY, zs = zc * a.ZC;
     const int ze = zs + a.ZC < D ? zs + a.ZC : D;
-    xb = a.x + (int64_t)b * D * H * W * Cin;
-    db_ = a.dy + (int64_t)b * D * H * W * Cout;
+    xb = reinterpret_cast<const unsigned char*>(a.x) + (int64_t)b * D * in_plane_bytes;
+    db_ = reinterpret_cast<const unsigned char*>(a.dy) + (int64_t)b * D * dy_plane_bytes;
     {
       const int yy = y0 - 1 + xhy, xx = x0 - 8 + 2 * (xpr + 3);
       const bool rok = xon && yy >= 0 && yy < H && xc4 * 4 < Cin;
-      gx0 = (rok && xx >= 0 && xx < W) ? (unsigned)(((yy * W + xx) * Cin + xc4 * 4) * 4) : X3_OOB;
-      gx1 = (rok && xx + 1 >= 0 && xx + 1 < W) ? (unsigned)(((yy * W + xx + 1) * Cin + xc4 * 4) * 4) : X3_OOB;
+      gx0 = (rok && xx >= 0 && xx < W) ? (unsigned)(((yy * W + xx) * Cin + xc4 * 4) * XSZ) : X3_OOB;
+      gx1 = (rok && xx + 1 >= 0 && xx + 1 < W) ? (unsigned)(((yy * W + xx + 1) * Cin + xc4 * 4) * XSZ) : X3_OOB;
       const int dyy = y0 + drow, dxx = x0 + 2 * dpr;
       const bool dok = don && dyy < H && dc4 * 4 < Cout;
-      gd0 = (dok && dxx < W) ? (unsigned)(((dyy * W + dxx) * Cout + dc4 * 4) * 4) : X3_OOB;
-      gd1 = (dok && dxx + 1 < W) ? (unsigned)(((dyy * W + dxx + 1) * Cout + dc4 * 4) * 4) : X3_OOB;
+      gd0 = (dok && dxx < W) ? (unsigned)(((dyy * W + dxx) * Cout + dc4 * 4) * DSZ) : X3_OOB;
+      gd1 = (dok && dxx + 1 < W) ? (unsigned)(((dyy * W + dxx + 1) * Cout + dc4 * 4) * DSZ) : X3_OOB;
     }
     __syncthreads();                                             // every wave is done with the previous item's planes
     // prologue: x planes zs-1, zs, zs+1 -> ring slots 0, 1, 2; d_y plane zs -> slot 0 (all four loads in flight together);
@@ -905,7 +936,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_x3_wgrad_kernel(const X3WArgs a)
 }
 
 struct X3WPlan { int cib, nco, u, np, gx, tiles_x, tiles_y, nchunk, zc, nitems, red_fl; };
-inline X3WPlan x3w_plan(int B, int D, int H, int W, int Cin, int Cout) {
+inline X3WPlan x3w_plan(int B, int D, int H, int W, int Cin, int Cout, int npc = 3) {
   X3WPlan p;
   p.cib = Cin <= 4 ? 4 : 8;
   p.nco = Cout <= 8 ? 8 : 16;
@@ -915,7 +946,7 @@ inline X3WPlan x3w_plan(int B, int D, int H, int W, int Cin, int Cout) {
   p.tiles_x = cdiv(W, WTX);
   p.tiles_y = cdiv(H, WTY);
   const int cols = B * p.tiles_x * p.tiles_y;
-  const int slots = (p.cib == 8 && p.nco == 16) ? 256 : 512;      // resident workgroups (LDS: two per CU, one for 8 x 16)
+  const int slots = npc == 1 ? 768 : ((p.cib == 8 && p.nco == 16) ? 256 : 512);   // resident workgroups (LDS: two per CU, one for 8 x 16)
   // chunks of >= 8 planes (3 planes of prologue each), about eight items per workgroup to even out the tail
   int n = (int)((8LL * slots + cols - 1) / cols);
   const int maxn = D / 8 > 0 ? D / 8 : 1;
@@ -998,6 +1029,35 @@ int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, floa
     if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 8, true>), dim3(p.gx), dim3(NTHR), 0, s, a);
     else hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 16, false>), dim3(p.gx), dim3(NTHR), 0, s, a);
   }
+  float* red = (float*)ws + (size_t)p.gx * p.red_fl;
+  return modetx_wgrad_partials_reduce(defer, (const float*)ws, red, dw, db, p.gx, Cin, Cout, p.cib, p.u, p.np ? 1 : 0, s);
+}
+
+// bf16 storage: x fp32 | bf16 (Cin 8), d_y bf16; same partial layout and reduction as the fp32 form
+// Cin = 8 only: with one piece a plane of the 4 x 32 column is 6-10 MFMAs per wave, and for Cin = 4 the per-plane barrier
+// and LDS round trip outweigh them (measured 4->8 at 160x192x224, B = 2: 0.327 ms against the tiled kernel's 0.261)
+bool modetx_x3_bf16_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout, int x_bf16) {
+  (void)x_bf16;
+  return modetx_x3_wgrad_eligible(B, D, H, W, Cin, Cout) && Cin == 8 && Cout == 8;      // (8->16 at level 2: 0.143 vs 0.101 ms)
+}
+size_t modetx_x3_bf16_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout, 1);
+  return ((size_t)768 + 1) * p.red_fl * sizeof(float);
+}
+int modetx_x3_bf16_wgrad(modet_step_ctx* defer, const void* x, int x_bf16, const void* dy, float* dw, float* db, void* ws, int B,
+                         int D, int H, int W, int Cin, int Cout, hipStream_t s) {
+  const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout, 1);
+  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems};
+#define X3W_L(CIB_, NCO_, NP_, X16_) hipLaunchKernelGGL((conv_x3_wgrad_kernel<CIB_, NCO_, NP_, 1, X16_>), dim3(p.gx), dim3(NTHR), 0, s, a)
+  if (p.cib == 4) {
+    if (x_bf16) return MODET_ERR_UNSUPPORTED;
+    if (p.np) X3W_L(4, 8, true, false); else X3W_L(4, 16, false, false);
+  } else if (x_bf16) {
+    if (p.np) X3W_L(8, 8, true, true); else X3W_L(8, 16, false, true);
+  } else {
+    if (p.np) X3W_L(8, 8, true, false); else X3W_L(8, 16, false, false);
+  }
+#undef X3W_L
   float* red = (float*)ws + (size_t)p.gx * p.red_fl;
   return modetx_wgrad_partials_reduce(defer, (const float*)ws, red, dw, db, p.gx, Cin, Cout, p.cib, p.u, p.np ? 1 : 0, s);
 }

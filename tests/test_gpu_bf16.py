@@ -31,7 +31,9 @@ CASES = [(2, 20, 24, 28, 4, 8, False), (2, 20, 24, 28, 8, 8, True), (1, 17, 12, 
          (1, 9, 12, 10, 64, 128, False), (2, 10, 12, 14, 128, 128, True), (1, 1, 2, 1, 64, 128, False),
          # the z-marching kernel's forms (conv3d_x3.hip, one bf16 piece): ragged tiles, z chunks, every (channels, packing, dtype)
          (1, 37, 45, 50, 8, 8, False), (1, 40, 33, 70, 16, 8, True), (2, 21, 19, 35, 8, 16, True), (1, 23, 30, 18, 4, 16, False),
-         (1, 64, 96, 112, 8, 8, True), (1, 30, 20, 33, 16, 16, False)]
+         (1, 64, 96, 112, 8, 8, True), (1, 30, 20, 33, 16, 16, False),
+         # ... and its weight gradient (>= 200 000 voxels): N-packed / plain columns, bf16 / fp32 x, ragged rows and chunks
+         (2, 40, 50, 64, 8, 16, True), (1, 50, 61, 70, 4, 8, False), (1, 48, 52, 90, 8, 8, False), (1, 41, 70, 75, 4, 16, False)]
 
 
 @pytest.mark.parametrize("B,D,H,W,Cin,Cout,inbf", CASES)
