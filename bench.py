@@ -45,10 +45,10 @@ def family(tag):
         return "conv_c1_fwd_kernel"
     if tag.startswith("conv_wgrad[1->"):
         return "conv_c1_wgrad_mfma_kernel"
-    if base in ("conv_bf16_fwd", "conv_bf16_dgrad"):
-        return "conv3d_bf16_kernel"
+    if base in ("conv_bf16_fwd", "conv_bf16_dgrad"):        # one bf16 piece: HBM-bound, priced against the HBM roofline
+        return "conv_x3_kernel<NPC=1>" if tag.endswith("@x3") else "conv3d_bf16_kernel"
     if base == "conv_bf16_wgrad":
-        return "conv3d_bf16_wgrad_kernel"
+        return "conv_x3_wgrad_kernel<NPC=1>" if tag.endswith("@x3") else "conv3d_bf16_wgrad_kernel"
     if base in ("conv_fwd", "conv_dgrad"):
         return "conv_x3_kernel" if tag.endswith("@x3") else ("conv3d_bf16_kernel<SP=3>" if tag.endswith("@split") else "conv3d_mfma_kernel")
     if base == "conv_wgrad":

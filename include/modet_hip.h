@@ -302,6 +302,10 @@ int modet_jacdet_nonpos_count(const float* flow, int64_t* counts, double* det_ou
  *             (consumed by modet_instnorm_lrelu_fwd_stats_bf16).  Cout % 8 == 0; Cin % 8 == 0 (bf16 x) or % 4 == 0 (fp32 x).
  *   bwd_data: d_x (fp32 | bf16) from d_y (bf16).
  *   bwd_weight: d_w, d_bias (fp32) from x (fp32 | bf16) and d_y (bf16). */
+/* which kernel the bf16 entry points run for this launch shape (pass as modet_conv3d_kernel_family): 1 = tiled
+ * (conv3d_bf16_kernel / conv3d_bf16_wgrad_kernel), 2 = z-marching with one bf16 piece (conv_x3_kernel<.., NPC = 1>,
+ * conv_x3_wgrad_kernel<.., NPC = 1>): the few-channel full-resolution layers, HBM-bound */
+int modet_conv3d_bf16_kernel_family(int B, int D, int H, int W, int Cin, int Cout, int pass, int x_bf16);
 size_t modet_conv3d_bf16_ws_bytes(int Cin, int Cout);
 size_t modet_conv3d_bf16_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modet_conv3d_bf16_fwd(const void* x, int x_bf16, const float* w, const float* bias, void* y, void* ws, size_t ws_bytes,

@@ -86,6 +86,7 @@ SIGNATURES = {
     "modet_jacdet_nonpos_count": (I, [P, P, P, I, I, I, I, P]),
     "modet_conv3d_bf16_ws_bytes": (SZ, [I, I]),
     "modet_conv3d_bf16_stats_bytes": (SZ, [I, I, I, I, I, I]),
+    "modet_conv3d_bf16_kernel_family": (I, [I, I, I, I, I, I, I, I]),
     "modet_conv3d_bf16_fwd": (I, [P, I, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_bf16_bwd_data": (I, [P, P, P, I, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_bf16_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I, I]),

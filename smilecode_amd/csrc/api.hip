@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 301; /* 0.3.1: + modet_ncc_fwd_bwd_win (NCC windows 3 / 5 / 7 / 9) */ }
+int modet_hip_version(void) { return 301; /* 0.3.1: + modet_ncc_fwd_bwd_win (NCC windows 3 / 5 / 7 / 9), modet_conv3d_bf16_kernel_family */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {

@@ -932,6 +932,13 @@ void modetx_bf16_prepack_begin(modet_step_ctx* c, void* arena, hipStream_t strea
 
 extern "C" {
 
+int modet_conv3d_bf16_kernel_family(int B, int D, int H, int W, int Cin, int Cout, int pass, int x_bf16) {
+  if (!x3_on()) return 1;
+  if (pass == 0) return modetx_x3_bf16_eligible(B, D, H, W, Cin, Cout, x_bf16) ? 2 : 1;
+  if (pass == 1) return modetx_x3_bf16_eligible(B, D, H, W, Cout, Cin, 1) ? 2 : 1;
+  return modetx_x3_bf16_wgrad_eligible(B, D, H, W, Cin, Cout, x_bf16) ? 2 : 1;
+}
+
 size_t modet_conv3d_bf16_ws_bytes(int Cin, int Cout) {
   const int m = Cin > Cout ? Cin : Cout;
   return bf16_wpk_elems(m, m) * sizeof(unsigned short);

@@ -169,6 +169,20 @@ def _conv_tag(kind, x_shape, Cin, Cout):
     return t
 
 
+def _conv16_tag(kind, x_shape, Cin, Cout, x_bf16):
+    """the same for the bf16-storage entry points: 'conv_bf16_fwd[8->8]@x3' = the one-piece z-marching kernel"""
+    if _TIMER is None:
+        return None
+    key = ("b16" + kind, tuple(x_shape[:4]), Cin, Cout, bool(x_bf16))
+    t = _FAM_CACHE.get(key)
+    if t is None:
+        B, D, H, W = x_shape[:4]
+        fam = _L().modet_conv3d_bf16_kernel_family(B, D, H, W, Cin, Cout, {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind], int(x_bf16))
+        arrow = f"{Cout}->{Cin}" if kind == "dgrad" else f"{Cin}->{Cout}"
+        t = _FAM_CACHE[key] = f"conv_bf16_{kind}[{arrow}]" + ("@x3" if fam == 2 else "")
+    return t
+
+
 # ------------------------------------------------------------------------------------------------ raw calls
 def conv3d_forward(x, w, b, act, step=None):
     _chk(x, w, b)
@@ -1167,7 +1181,7 @@ def conv3d_bf16_forward(x, w, b, want_stats=True, step=None):
     sb = L.modet_conv3d_bf16_stats_bytes(B, D, H, W, Cin, Cout) if want_stats else 0
     stats = torch.empty(sb // 4, dtype=torch.float32, device=x.device) if sb > 0 else None
     n = float(B) * D * H * W
-    with _Guard(x, f"conv_bf16_fwd[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
+    with _Guard(x, _conv16_tag("fwd", x.shape, Cin, Cout, _isbf(x)), 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
         _lib.check(L.modet_conv3d_bf16_fwd(_p(x), _isbf(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin, Cout,
                                            _stream(), _h(step)), "modet_conv3d_bf16_fwd")
     return y, stats
@@ -1183,7 +1197,7 @@ def conv3d_bf16_backward_data(dy, w, Cin, dx_bf16, step=None):
     nb = L.modet_conv3d_bf16_ws_bytes(Cin, Cout)
     ws = _ws(nb, dy)
     n = float(B) * D * H * W
-    with _Guard(dy, f"conv_bf16_dgrad[{Cout}->{Cin}]", 54.0 * Cin * Cout * n, n * (2.0 * Cout + (2.0 if dx_bf16 else 4.0) * Cin)):
+    with _Guard(dy, _conv16_tag("dgrad", dy.shape, Cin, Cout, True), 54.0 * Cin * Cout * n, n * (2.0 * Cout + (2.0 if dx_bf16 else 4.0) * Cin)):
         _lib.check(L.modet_conv3d_bf16_bwd_data(_p(dy), _p(w), _p(dx), int(dx_bf16), _p(ws), nb, B, D, H, W, Cin, Cout, _stream(),
                                                 _h(step)), "modet_conv3d_bf16_bwd_data")
     return dx
@@ -1204,7 +1218,7 @@ def conv3d_bf16_backward_weight(x, dy, w=None, b=None, step=None):
         dst = scope.destinations(w, b, True) if (scope is not None and hasattr(L, "modet_conv3d_bf16_bwd_weight_defer")) else None
         if dst is not None:
             dw, db = dst
-            with _Guard(x, f"conv_bf16_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
+            with _Guard(x, _conv16_tag("wgrad", x.shape, Cin, Cout, _isbf(x)), 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
                 _lib.check(L.modet_conv3d_bf16_bwd_weight_defer(_p(x), _isbf(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W,
                                                                 Cin, Cout, _stream(), _h(scope)),
                            "modet_conv3d_bf16_bwd_weight_defer")
@@ -1214,7 +1228,7 @@ def conv3d_bf16_backward_weight(x, dy, w=None, b=None, step=None):
             return None, None
         dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
         db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
-        with _Guard(x, f"conv_bf16_wgrad[{Cin}->{Cout}]", 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
+        with _Guard(x, _conv16_tag("wgrad", x.shape, Cin, Cout, _isbf(x)), 54.0 * Cin * Cout * n, n * ((2.0 if _isbf(x) else 4.0) * Cin + 2.0 * Cout)):
             _lib.check(L.modet_conv3d_bf16_bwd_weight(_p(x), _isbf(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
                                                       _stream()), "modet_conv3d_bf16_bwd_weight")
         return dw, db
