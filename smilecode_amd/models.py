@@ -334,9 +334,11 @@ class ModeT(nn.Module):
         if act_dtype not in (torch.float32, torch.bfloat16):
             raise RuntimeError("ModeT: act_dtype must be torch.float32 or torch.bfloat16")
         self.act_dtype = act_dtype
-        for s in inshape:
-            if s % 16 != 0:
-                raise RuntimeError("ModeT: every input dimension must be a multiple of 16 (four 2x poolings)")
+        # like the reference's constructor (models.py:338-375) any inshape is accepted here; shapes that four 2x poolings
+        # do not divide fail in forward(), where the reference fails too (its x2-upsampled flow no longer matches the
+        # next level's grid: "The size of tensor a must match the size of tensor b")
+        if len(tuple(inshape)) != 3 or any(int(v) < 1 for v in inshape):
+            raise RuntimeError("ModeT: inshape = (D, H, W)")
         self.channels = channels
         self.step = 7
         self.inshape = tuple(inshape)
@@ -364,6 +366,9 @@ class ModeT(nn.Module):
     def forward(self, moving, fixed):
         if moving.shape != fixed.shape or moving.dim() != 5:
             raise RuntimeError("ModeT.forward expects two (B,C,D,H,W) volumes of the same shape")
+        if any(int(v) % 16 != 0 for v in moving.shape[2:]):
+            raise RuntimeError(f"ModeT.forward: every spatial dimension must be a multiple of 16 (four 2x poolings, then x2 "
+                               f"upsampling back: the level sizes would not match), got {tuple(moving.shape[2:])}")
         B = moving.shape[0]
         mov_cl = ops.to_channels_last(moving.contiguous())
         fix_cl = ops.to_channels_last(fixed.contiguous())

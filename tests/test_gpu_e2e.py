@@ -97,6 +97,16 @@ def test_modet_cu_operator_path_rejects_levels_below_the_window():
         m(mov, fix)
 
 
+def test_inshape_not_divisible_by_16_fails_in_forward_like_the_reference():
+    """the reference's constructor accepts any inshape (models.py:338-375) and its forward raises a RuntimeError when the
+    x2-upsampled flow no longer matches the next level; same here: construction succeeds, forward raises"""
+    from smilecode_amd import models
+    m = models.ModeT((40, 48, 40)).cuda()
+    mov, fix = _pair((40, 48, 40))
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        m(mov, fix)
+
+
 def test_modet_cu_same_network_and_state_dict_roundtrip():
     from smilecode_amd import models
     shape = (32, 48, 32)
