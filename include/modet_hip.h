@@ -137,6 +137,16 @@ int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const floa
 /* d_x = conv(d_y, flipped/transposed w) */
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes,
                           int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step);
+/* Data gradient of a conv whose INPUT was y = LeakyReLU(InstanceNorm(x_raw)) (ConvInsBlock -> conv, models.py:186-219): d_x
+ * is the gradient w.r.t. y, and the kernel's epilogue also forms the first pass of that InstanceNorm's backward over it --
+ * rows [B][workgroup][Cin][2] of (sum g, sum g*xhat), g = d_x * lrelu'(xhat), xhat = (x_raw - mean) * rstd -- so
+ * modet_instnorm_lrelu_bwd_rows can go straight to its apply pass (saves reading d_x and x_raw once more: 8 B/element).
+ * modet_conv3d_bwd_data_instats_bytes() == 0: this shape does not run the kernel family that carries the epilogue (family 2):
+ * use modet_conv3d_bwd_data + modet_instnorm_lrelu_bwd.  x_raw (B,D,H,W,Cin); mean / rstd (B*Cin). */
+size_t modet_conv3d_bwd_data_instats_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modet_conv3d_bwd_data_instats(const float* d_y, const float* w, float* d_x, const float* x_raw, const float* mean,
+                                  const float* rstd, float* rows, size_t rows_bytes, void* ws, size_t ws_bytes,
+                                  int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step);
 /* d_w (Cout,Cin,3,3,3), d_bias (Cout) or NULL; deterministic two-stage reduction */
 size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes,
@@ -192,6 +202,11 @@ int modet_instnorm_stats(const float* x, float* mean, float* rstd, const float* 
                          size_t ws_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream);
 int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
                              void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream);
+/* the same with the statistics pass already done by modet_conv3d_bwd_data_instats (rows, rows_bytes as returned there);
+ * ws_bytes >= 2 * B * C * 4 */
+int modet_instnorm_lrelu_bwd_rows(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
+                                  const float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B, int64_t V, int C,
+                                  modet_stream_t stream);
 /* d_x = d_y * (y > 0 ? 1 : 0.1): backward of the LeakyReLU fused into modet_conv3d_fwd(act=1) */
 int modet_lrelu_bwd(const float* d_y, const float* y, float* d_x, int64_t n, modet_stream_t stream);
 /* AvgPool3d(2) (models.py:201,:207,:213,:219); D,H,W are the INPUT dims (even). */

@@ -53,6 +53,9 @@ SIGNATURES = {
     "modet_instnorm_lrelu_fwd": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_fwd_stats": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_stats": (I, [P, P, P, P, SZ, P, SZ, I, I64, I, F, P]),
+    "modet_conv3d_bwd_data_instats_bytes": (SZ, [I, I, I, I, I, I]),
+    "modet_conv3d_bwd_data_instats": (I, [P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
+    "modet_instnorm_lrelu_bwd_rows": (I, [P, P, P, P, P, P, SZ, P, SZ, I, I64, I, P]),
     "modet_instnorm_lrelu_bwd": (I, [P, P, P, P, P, P, SZ, I, I64, I, P]),
     "modet_lrelu_bwd": (I, [P, P, P, I64, P]),
     "modet_avgpool2_fwd": (I, [P, P, I, I, I, I, I, P]),

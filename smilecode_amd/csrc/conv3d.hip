@@ -1532,6 +1532,9 @@ size_t modetx_x3_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                    const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int act, int mode,
                    hipStream_t s);
+size_t modetx_x3_bst_rows_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modetx_x3_dgrad_bst(modet_step_ctx* step, const float* dy, const float* w, float* dx, const float* xraw, const float* mean,
+                        const float* rstd, float* rows, void* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t s);
 bool modetx_x3_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout);
 size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
@@ -1756,6 +1759,24 @@ int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const floa
   }
   return conv_launch(step, x_raw, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
                      ConvIn{in_mean, in_rstd, stats ? conv_stats_rows(B, D, H, W, Cin, Cout) : 0, nullptr});
+}
+
+size_t modet_conv3d_bwd_data_instats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  if (B > 32 || Cin % 4 != 0 || !use_x3(B, D, H, W, Cout, Cin)) return 0;
+  return modetx_x3_bst_rows_bytes(B, D, H, W, Cin, Cout);
+}
+
+int modet_conv3d_bwd_data_instats(const float* d_y, const float* w, float* d_x, const float* x_raw, const float* mean,
+                                  const float* rstd, float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B, int D,
+                                  int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step) {
+  MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(w); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
+  MODET_CHECK_PTR(x_raw); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(rows);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  const size_t need = modet_conv3d_bwd_data_instats_bytes(B, D, H, W, Cin, Cout);
+  if (need == 0) return MODET_ERR_UNSUPPORTED;
+  if (rows_bytes < need) return MODET_ERR_WORKSPACE;
+  if (ws_bytes < fwd_ws_elems(Cout, Cin) * sizeof(float) || ws_bytes < modetx_x3_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
+  return modetx_x3_dgrad_bst(step, d_y, w, d_x, x_raw, mean, rstd, rows, ws, B, D, H, W, Cin, Cout, (hipStream_t)stream);
 }
 
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,

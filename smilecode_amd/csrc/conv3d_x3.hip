@@ -141,7 +141,9 @@ inline size_t x3_wpk_elems(int cin_t, int P, int npiece = 3) { return (size_t)3 
 struct X3Args {
   const void* x; const uint4* wpk; const float* bias; void* y;           // x, y: fp32, or bf16 in the storage variants
   const float* in_mean; const float* in_rstd;          // NORM: x is a raw ConvInsBlock output, LeakyReLU((x - mean) * rstd) on load
-  float* stats_rows; const float* shift;               // STATS: [b][item][Cout][2] sums of (y - K), (y - K)^2;  K = shift[b][Cout]
+  float* stats_rows; const float* shift;               // STATS 1: [b][item][Cout][2] sums of (y - K), (y - K)^2;  K = shift[b][Cout]
+  const float* xraw; const float* bmean; const float* brstd;   // STATS 2 (dgrad whose output is the gradient w.r.t. LeakyReLU(
+                                                       // InstanceNorm(xraw))): rows of sum g, sum g*xhat, g = y * lrelu'(xhat)
   int D, H, W, Cin, Cout, tiles_x, tiles_y, nchunk, ZC, nitems, act;
   long long* dbg;                                      // MODET_TUNING builds: per-(workgroup, wave) cycle sums per phase
 };
@@ -159,7 +161,7 @@ __device__ long long* g_x3_dbg = nullptr;
 // (exact arithmetic on the bf16-rounded operands, one rounding of the output) in this kernel's structure.  IN16: x is bf16 in
 // HBM (a staging item = 8 channels = 16 bytes goes to LDS untouched), else fp32 rounded while staged; OUT16: y is stored as bf16.
 // A plane then carries 18 MFMAs per wave instead of 108: the kernel is HBM-bound (8->8: 32 bytes per voxel).
-template <int CIN, int P, int TY, bool WLDS, bool NORM, bool STATS, int NPC = 3, bool IN16 = false, bool OUT16 = false>
+template <int CIN, int P, int TY, bool WLDS, bool NORM, int STATS, int NPC = 3, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (CIN == 16 ? 1 : 2)) void conv_x3_kernel(const X3Args a) {
   using G = X3Geo<CIN, P>;
   constexpr int NS = G::NS, NTAP = G::NTAP;
@@ -168,7 +170,11 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   constexpr int PLANE_D = HY * HX * CIN * 2, PLANE_B = PLANE_D + 16, SLOT_B = NPC * PLANE_B;
   constexpr int EPI = IN16 ? 8 : 4;                                        // channels per 16-byte staging item
   constexpr int Q = CIN / EPI, NITEM = HY * HX * Q, NIT = (NITEM + NTHR - 1) / NTHR;
-  constexpr int WL_B = WLDS ? 3 * NS * NPC * 1024 : 16;
+  // STATS 2 (8 / 16 input channels): the LOW piece of the weights lives in LDS, the other two in registers -- its A
+  // fragments are read once per (plane, k-step) and feed the last MFMAs of the unit; frees 36 registers for the statistics
+  constexpr bool WLO = STATS == 2 && NPC == 3 && CIN >= 8 && !WLDS;
+  constexpr int NPR = WLO ? 2 : NPC;                                       // pieces kept in registers
+  constexpr int WL_B = WLDS ? 3 * NS * NPC * 1024 : (WLO ? 3 * NS * 1024 : 16);
   static_assert(UNITS % 4 == 0, "row groups split over 4 waves");
   static_assert(Q >= 1 && NTHR % Q == 0, "a thread's staging items share one channel group");
   static_assert(NPC == 3 || !NORM, "the lazily normalised input exists for the fp32 form only");
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   const int nz = (zs + a.ZC <= D ? a.ZC : D - zs);                         // output planes of this item
 
   // ---- weights: A fragments of every (dz, k-step, piece), in registers (or LDS) for the whole march
-  uint4 wreg[WLDS ? 1 : 3][WLDS ? 1 : NS][WLDS ? 1 : NPC];
+  uint4 wreg[WLDS ? 1 : 3][WLDS ? 1 : NS][WLDS ? 1 : NPR];
   if constexpr (WLDS) {
     for (int i = tid; i < 3 * NS * NPC * 64; i += NTHR) reinterpret_cast<uint4*>(wl)[i] = a.wpk[i];
   } else {
@@ -202,7 +208,10 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int pc = 0; pc < NPC; ++pc) wreg[dz][s][pc] = a.wpk[((dz * NS + s) * NPC + pc) * 64 + lane];
+        for (int pc = 0; pc < NPR; ++pc) wreg[dz][s][pc] = a.wpk[((dz * NS + s) * NPC + pc) * 64 + lane];
+    if constexpr (WLO) {
+      for (int i = tid; i < 3 * NS * 64; i += NTHR) reinterpret_cast<uint4*>(wl)[i] = a.wpk[((i >> 6) * NPC + 2) * 64 + (i & 63)];
+    }
   }
 
   // ---- staging map: item i = tid + j * NTHR of the halo'd plane [hy][hx][Q channel groups]
@@ -344,7 +353,22 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   const bool co_ok = co0 < Cout;
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (co_ok && a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + co0);
-  if (STATS && co_ok) k4 = *reinterpret_cast<const float4*>(a.shift + b * Cout + co0);
+  if (STATS == 1 && co_ok) k4 = *reinterpret_cast<const float4*>(a.shift + b * Cout + co0);
+  // STATS 2: InstanceNorm-backward statistics of this launch's OUTPUT (a data gradient) against the raw tensor the norm
+  // was applied to (same shape as the output): its float4 of the NEXT plane to be flushed is loaded one iteration ahead
+  // (mean, rstd of the sample's 16 channel slots sit in LDS and are re-read by every flush: the 8->8 instantiation has no
+  // registers to spare -- with them and a second operand buffer in registers it spilled 36 and ran at half speed)
+  __shared__ __attribute__((aligned(16))) float bst_mr[STATS == 2 ? 32 : 1];
+  if constexpr (STATS == 2) {
+    if (tid < 32) {
+      const int c = tid & 15;
+      bst_mr[tid] = c < Cout ? (tid < 16 ? a.bmean[b * Cout + c] : a.brstd[b * Cout + c]) : 0.f;
+    }
+  }
+  float4 xraw_nx[STATS == 2 ? R : 1];
+#pragma unroll
+  for (int r = 0; r < (STATS == 2 ? R : 1); ++r) xraw_nx[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* xrawb = STATS == 2 ? a.xraw + (int64_t)b * D * H * W * Cout : nullptr;
   float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
   unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + (int64_t)b * D * H * W * Cout * OSZ;
   unsigned soff[R];                                                        // byte offset of this lane's 4 couts in an output plane
@@ -367,7 +391,10 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   };
   auto wfrag = [&](int dz, int s, int pc) -> bf16x8 {
     if constexpr (WLDS) return __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(wl)[((dz * NS + s) * NPC + pc) * 64 + lane]);
-    else return __builtin_bit_cast(bf16x8, wreg[dz][s][pc]);
+    else if constexpr (WLO) {
+      if (pc == 2) return __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(wl)[(dz * NS + s) * 64 + lane]);
+      return __builtin_bit_cast(bf16x8, wreg[dz][s][pc < 2 ? pc : 0]);
+    } else return __builtin_bit_cast(bf16x8, wreg[dz][s][pc]);
   };
 #define X3_MM(ACC, WP, XP) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[WP], xf[XP], ACC, 0, 0, 0)
   // one input plane (LDS slot) into the three output planes it touches; C = q % 3: dz -> accumulator (C - dz) mod 3
@@ -391,15 +418,20 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
       }
     } else if (a0 && a1 && a2) {
       // (k-step, row group) units in order; the three B fragments of unit u+1 are read from LDS before the 18 MFMAs of unit u
-      bf16x8 xq[2][3];
+      constexpr int NXQ = STATS == 2 ? 1 : 2;                  // (STATS 2: no register room for the second buffer)
+      bf16x8 xq[NXQ][3];
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) xq[0][pc] = frag(sl, pc, 0, 0);
 #pragma unroll
       for (int u = 0; u < NS * R; ++u) {
         const int s = u / R, r = u % R;
-        if (u + 1 < NS * R) {
+        if (NXQ == 1 && u > 0) {
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) xq[(u + 1) & 1][pc] = frag(sl, pc, (u + 1) % R, (u + 1) / R);
+          for (int pc = 0; pc < 3; ++pc) xq[0][pc] = frag(sl, pc, r, s);
+        }
+        if (NXQ == 2 && u + 1 < NS * R) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) xq[(u + 1) % NXQ][pc] = frag(sl, pc, (u + 1) % R, (u + 1) / R);
         }
         // keep the reads up here: left alone the scheduler sinks them to their first use to save registers and every
         // unit then starts with an exposed LDS round trip (seen in the ISA: ds_read, s_waitcnt lgkmcnt(0), v_mfma)
@@ -407,10 +439,11 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
         bf16x8 w0[3], w1[3], w2[3];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) { w0[pc] = wfrag(0, s, pc); w1[pc] = wfrag(1, s, pc); w2[pc] = wfrag(2, s, pc); }
-        const bf16x8* xf = xq[u & 1];
+        const bf16x8* xf = xq[u % NXQ];
         // small terms first; the three accumulators alternate so that back-to-back MFMAs are independent
 #define X3_ALL(WP, XP) { bf16x8* w = w0; X3_MM(acc[S0][r], WP, XP); } { bf16x8* w = w1; X3_MM(acc[S1][r], WP, XP); } { bf16x8* w = w2; X3_MM(acc[S2][r], WP, XP); }
-        X3_ALL(2, 0) X3_ALL(0, 2) X3_ALL(1, 1) X3_ALL(1, 0) X3_ALL(0, 1) X3_ALL(0, 0)
+        if constexpr (WLO) { X3_ALL(0, 2) X3_ALL(1, 1) X3_ALL(1, 0) X3_ALL(0, 1) X3_ALL(0, 0) X3_ALL(2, 0) }   // LDS-resident piece last
+        else { X3_ALL(2, 0) X3_ALL(0, 2) X3_ALL(1, 1) X3_ALL(1, 0) X3_ALL(0, 1) X3_ALL(0, 0) }
 #undef X3_ALL
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -435,7 +468,7 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
 #undef X3_MM
   // output plane z is complete, its accumulator is SL: + bias, statistics, activation, one 16-byte store per row group.
   // live = false (no finished plane yet): the same instructions run against an empty descriptor and store nothing.
-  auto flush = [&](auto sl_c, int z, bool live) {
+  auto flush = [&](auto sl_c, int z, bool live, bool next_live) {
     constexpr int SL = decltype(sl_c)::value;
     const BufRsrc rs = plane_rsrc(reinterpret_cast<const float*>(yb + (int64_t)(live ? z : 0) * out_plane_bytes), live ? out_plane_bytes : 0u);
 #pragma unroll
@@ -443,11 +476,24 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
       const f32x4 v = acc[SL][r];
       acc[SL][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
       float o[4] = {v[0] + b4.x, v[1] + b4.y, v[2] + b4.z, v[3] + b4.w};
-      if (STATS) {
+      if (STATS == 1) {
         const bool on = live && soff[r] != X3_OOB;
         const float e0 = on ? o[0] - k4.x : 0.f, e1 = on ? o[1] - k4.y : 0.f, e2 = on ? o[2] - k4.z : 0.f, e3 = on ? o[3] - k4.w : 0.f;
         sx[0] += e0; sx[1] += e1; sx[2] += e2; sx[3] += e3;
         sq[0] = fmaf(e0, e0, sq[0]); sq[1] = fmaf(e1, e1, sq[1]); sq[2] = fmaf(e2, e2, sq[2]); sq[3] = fmaf(e3, e3, sq[3]);
+      }
+      if constexpr (STATS == 2) {
+        const bool on = live && soff[r] != X3_OOB;
+        const float4 xr = xraw_nx[r];                          // loaded by the previous iteration's flush for THIS plane
+        const float4 bm4 = *reinterpret_cast<const float4*>(bst_mr + (co_ok ? co0 : 0));
+        const float4 br4 = *reinterpret_cast<const float4*>(bst_mr + 16 + (co_ok ? co0 : 0));
+        const float xv[4] = {xr.x, xr.y, xr.z, xr.w}, mv[4] = {bm4.x, bm4.y, bm4.z, bm4.w}, rv[4] = {br4.x, br4.y, br4.z, br4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[j] - mv[j]) * rv[j];
+          const float gg = on ? o[j] * (xh > 0.f ? 1.f : LRELU_SLOPE) : 0.f;
+          sx[j] += gg; sq[j] = fmaf(gg, xh, sq[j]);
+        }
       }
       if (a.act) { o[0] = lrelu(o[0]); o[1] = lrelu(o[1]); o[2] = lrelu(o[2]); o[3] = lrelu(o[3]); }
       if constexpr (OUT16) {                                               // statistics above: of the fp32 values, as conv3d_bf16.hip
@@ -457,6 +503,11 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
         const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rs, (int)soff[r], 0, 0);
       }
+    }
+    if constexpr (STATS == 2) {                                          // the raw tensor's values for the next plane to be flushed
+      const BufRsrc rx = plane_rsrc(xrawb + (int64_t)(next_live ? z + 1 : 0) * H * W * Cout, next_live ? out_plane_bytes : 0u);
+#pragma unroll
+      for (int r = 0; r < R; ++r) xraw_nx[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)soff[r], 0, 0));
     }
   };
 
@@ -470,7 +521,7 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   using I2 = std::integral_constant<int, 2>;
   const int nq = nz + 2;
   load_plane(I0{}, zs - 1);
-  if (WLDS) __syncthreads();
+  if (WLDS || WLO) __syncthreads();
   store_plane(I0{}, 0);
   load_plane(I0{}, zs);
   __syncthreads();
@@ -492,7 +543,7 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
 #endif
     if (q + 1 < nq) store_plane(I0{}, (q + 1) & 1);
     X3_T(2)
-    flush(cc, zs + q - 3, q >= 3 && q <= nq);                              // slot C: output q-3, about to be re-used for output q
+    flush(cc, zs + q - 3, q >= 3 && q <= nq, q + 1 >= 3 && q + 1 <= nq);   // slot C: output q-3, about to be re-used for output q
     X3_T(1)
     // plane q+2 into the registers the split just emptied; past the last plane: an empty descriptor (zeros, no traffic)
     load_plane(I0{}, q + 2 < nq ? zs + q + 1 : -1);
@@ -517,7 +568,7 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
     for (int i = 0; i < 6; ++i) o[i] = dsum[i];
   }
 #endif
-  if constexpr (STATS) {
+  if constexpr (STATS != 0) {
     // lanes sharing a channel group: all li, and for P == 2 both rows (lk >> 1); then the 4 waves through LDS
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -609,6 +660,20 @@ int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, 
   if (p.cin_t == 4) { if (p.P == 2) X3_L(4, 2, 16, false); else X3_L(4, 1, 8, false); }
   else if (p.cin_t == 8) { if (p.P == 2) X3_L(8, 2, 16, false); else X3_L(8, 1, 8, false); }
   else X3_L(16, 1, 16, false);
+#undef X3_L
+  return modet_launch_status();
+}
+
+// data gradient + InstanceNorm-backward statistics of its output (STATS = 2)
+int x3_launch_bst(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s) {
+  X3Args a = a0;
+  a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, 3, p, s);
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.nchunk = p.nchunk; a.ZC = p.zc; a.nitems = p.nitems;
+  const dim3 grid(((p.nitems + 7) / 8) * 8);
+#define X3_L(CIN_, P_, TY_) hipLaunchKernelGGL((conv_x3_kernel<CIN_, P_, TY_, false, false, 2>), grid, dim3(NTHR), 0, s, a)
+  if (p.cin_t == 4) { if (p.P == 2) X3_L(4, 2, 16); else X3_L(4, 1, 8); }
+  else if (p.cin_t == 8) { if (p.P == 2) X3_L(8, 2, 16); else X3_L(8, 1, 8); }
+  else X3_L(16, 1, 16);
 #undef X3_L
   return modet_launch_status();
 }
@@ -984,6 +1049,21 @@ int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const f
   a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
   if (in_mean) return stats ? x3_launch<true, true>(step, a, w, ws, B, mode, p, s) : x3_launch<true, false>(step, a, w, ws, B, mode, p, s);
   return stats ? x3_launch<false, true>(step, a, w, ws, B, mode, p, s) : x3_launch<false, false>(step, a, w, ws, B, mode, p, s);
+}
+// data gradient d_x = conv^T(d_y) (Cout channels in, Cin out) whose output is the gradient w.r.t. LeakyReLU(InstanceNorm(xraw)):
+// also writes rows [B][items][Cin][2] of (sum g, sum g*xhat) -- the first pass of the InstanceNorm backward, for free
+size_t modetx_x3_bst_rows_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  const X3Plan p = x3_plan(B, D, H, W, Cout, Cin);
+  return (size_t)p.nitems * Cin * 2 * sizeof(float);
+}
+int modetx_x3_dgrad_bst(modet_step_ctx* step, const float* dy, const float* w, float* dx, const float* xraw, const float* mean,
+                        const float* rstd, float* rows, void* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t s) {
+  const X3Plan p = x3_plan(B, D, H, W, Cout, Cin);
+  X3Args a{};
+  a.x = dy; a.bias = nullptr; a.y = dx;
+  a.xraw = xraw; a.bmean = mean; a.brstd = rstd; a.stats_rows = rows;
+  a.D = D; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.act = 0;
+  return x3_launch_bst(step, a, w, ws, B, 1, p, s);
 }
 // ---- bf16 storage (conv3d_bf16.hip routes the full-resolution layers here): x fp32 | bf16, y fp32 | bf16, one bf16 piece
 bool modetx_x3_bf16_eligible(int B, int D, int H, int W, int Cin, int Cout, int x_bf16) {

@@ -136,6 +136,21 @@ __global__ __launch_bounds__(256) void in_rows_finalize_kernel(const float* __re
   }
 }
 
+// the same column sums for the InstanceNorm BACKWARD rows a data-gradient kernel left (sum g, sum g*xhat): -> means over V
+__global__ __launch_bounds__(256) void in_rows_finalize_bwd_kernel(const float* __restrict__ rows, float* __restrict__ s1,
+                                                                   float* __restrict__ s2, int64_t V, int C, int64_t rows_per_b) {
+  __shared__ double sm[256];
+  __shared__ double tot[256];
+  const int b = blockIdx.x;
+  block_colsum_256(rows + (int64_t)b * rows_per_b * 2 * C, 0, rows_per_b, 2 * C, tot, sm);
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x;
+    s1[b * C + c] = (float)(tot[2 * c] / (double)V);
+    s2[b * C + c] = (float)(tot[2 * c + 1] / (double)V);
+  }
+}
+
 // stage 1 for statistics with one row per OUTPUT TILE (bf16 convs: thousands of rows per sample): IN_SLICES workgroups per
 // sample sum a slice of the rows each (fixed order, fp64) into one row of the buffer's tail; the finalize then reads
 // IN_SLICES rows.  (One workgroup walking 9 600 rows took 71 us per level-1 layer.)
@@ -525,6 +540,29 @@ int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2,
                      d_x, V, C, total4);
+  return modet_launch_status();
+}
+
+/* InstanceNorm backward whose statistics pass already happened in the producer of d_y (modet_conv3d_bwd_data_instats):
+ * rows [B][rows_per_b][C][2] of (sum g, sum g*xhat) -> fixed-order fp64 column sums / V, then the apply pass.
+ * ws >= 2 * B * C floats. */
+int modet_instnorm_lrelu_bwd_rows(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
+                                  const float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B, int64_t V, int C,
+                                  modet_stream_t stream) {
+  MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x);
+  MODET_CHECK_PTR(rows); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
+  if (C % 4 != 0 || 2 * C > 256) return MODET_ERR_UNSUPPORTED;
+  const int64_t per = (int64_t)(rows_bytes / sizeof(float)) / ((int64_t)B * C * 2);
+  if (per < 1 || (size_t)per * B * C * 2 * sizeof(float) != rows_bytes) return MODET_ERR_DIM;
+  if (ws_bytes < (size_t)2 * B * C * sizeof(float)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* s1 = (float*)ws;
+  float* s2 = s1 + (size_t)B * C;
+  hipLaunchKernelGGL(in_rows_finalize_bwd_kernel, dim3(B), dim3(256), 0, s, rows, s1, s2, V, C, per);
+  const int64_t total4 = (int64_t)B * V * (C / 4);
+  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, (const float*)s1,
+                     (const float*)s2, d_x, V, C, total4);
   return modet_launch_status();
 }
 

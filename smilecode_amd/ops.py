@@ -8,6 +8,7 @@ There is no eager / CPU fallback: a missing library or a non-GPU tensor raises.
 """
 from __future__ import annotations
 
+import os
 import threading
 
 import torch
@@ -525,10 +526,96 @@ def lazy_instnorm_conv3d(x_raw, stats_in, w, b, eps=1e-5, want_stats=True):
     if not needs_grad and Cin % 4 == 0 and Cin > 1:
         mean, rstd = instnorm_stats(x_raw, stats_in, eps)
         return conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats)
-    y = _InstNormLReLU.apply(x_raw, eps, stats_in)
-    if not want_stats:
-        return _Conv3d.apply(y, w, b, False), None
-    return conv3d_with_stats(y, w, b)
+    return _InstNormConv.apply(x_raw, stats_in, w, b, eps, want_stats)
+
+
+# The data gradient of a conv whose input is LeakyReLU(InstanceNorm(x_raw)) can form that norm's backward statistics in
+# its own epilogue (modet_conv3d_bwd_data_instats: kernel family 2 only): the norm's backward then skips its first pass
+# over (d_y, x_raw).  False = the two ops run back to back as before (A/B switch of the parity tests).
+FUSE_IN_DGRAD = os.environ.get("MODET_FUSE_IN_DGRAD", "1") != "0"
+
+
+class _InstNormConv(Function):
+    """z = conv3d(LeakyReLU(InstanceNorm(x_raw)), w, b) as ONE autograd node (ConvInsBlock -> conv, reference
+    models.py:186-219 / :252-254), so that its backward can hand the conv's data gradient and the norm's backward
+    statistics over inside one kernel.  Returns (z, z_stats or None)."""
+
+    @staticmethod
+    def forward(ctx, x_raw, stats_in, w, b, eps, want_stats):
+        _chk(x_raw, w, b)
+        ctx.step = current_step()
+        B, C = x_raw.shape[0], x_raw.shape[-1]
+        V = x_raw.numel() // (B * C)
+        y = torch.empty_like(x_raw)
+        mean = torch.empty(B * C, dtype=torch.float32, device=x_raw.device)
+        rstd = torch.empty_like(mean)
+        L = _L()
+        with _Guard(x_raw, "instnorm_lrelu_fwd", 8.0 * x_raw.numel(), 8.0 * x_raw.numel()):
+            if stats_in is not None:
+                _lib.check(L.modet_instnorm_lrelu_fwd_stats(_p(x_raw), _p(y), _p(mean), _p(rstd), _p(stats_in),
+                                                            stats_in.numel() * 4, B, V, C, eps, _stream()),
+                           "modet_instnorm_lrelu_fwd_stats")
+            else:
+                nb = L.modet_instnorm_ws_bytes(B, V, C)
+                ws = _ws(nb, x_raw)
+                _lib.check(L.modet_instnorm_lrelu_fwd(_p(x_raw), _p(y), _p(mean), _p(rstd), _p(ws), nb, B, V, C, eps,
+                                                      _stream()), "modet_instnorm_lrelu_fwd")
+        _, D, H, W, Cin = y.shape
+        Cout = w.shape[0]
+        stats = None
+        if want_stats and _fuse_stats(y, w):
+            z = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=y.device)
+            nb = L.modet_conv3d_ws_bytes(Cin, Cout)
+            ws = _ws(nb, y)
+            sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)
+            stats = torch.empty(sb // 4, dtype=torch.float32, device=y.device)
+            n = float(B) * D * H * W
+            with _Guard(y, _conv_tag("fwd", y.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+                _lib.check(L.modet_conv3d_fwd_stats(_p(y), _p(w), _p(b), _p(z), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
+                                                    Cout, _stream(), _h(ctx.step)), "modet_conv3d_fwd_stats")
+            ctx.mark_non_differentiable(stats)
+        else:
+            z = conv3d_forward(y, w, b, False, ctx.step)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x_raw, mean, rstd, y, w, b)
+        return z, stats
+
+    @staticmethod
+    def backward(ctx, dz, _dstats):
+        x_raw, mean, rstd, y, w, b = ctx.saved_tensors
+        dz = dz.contiguous()
+        B, D, H, W, C = x_raw.shape
+        Cout = w.shape[0]
+        V = D * H * W
+        L = _L()
+        d_raw = None
+        if ctx.needs_input_grad[0]:
+            d_raw = torch.empty_like(x_raw)
+            rb = L.modet_conv3d_bwd_data_instats_bytes(B, D, H, W, C, Cout) if FUSE_IN_DGRAD else 0
+            if rb > 0:
+                d_y = torch.empty_like(x_raw)
+                rows = torch.empty(rb // 4, dtype=torch.float32, device=x_raw.device)
+                nb = L.modet_conv3d_ws_bytes(C, Cout)
+                ws = _ws(nb, dz)
+                n = float(B) * V
+                with _Guard(dz, _conv_tag("dgrad", dz.shape, C, Cout), 54.0 * C * Cout * n, 4.0 * n * (2 * C + Cout)):
+                    _lib.check(L.modet_conv3d_bwd_data_instats(_p(dz), _p(w), _p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(rows),
+                                                               rb, _p(ws), nb, B, D, H, W, C, Cout, _stream(), _h(ctx.step)),
+                               "modet_conv3d_bwd_data_instats")
+                nb2 = 2 * B * C * 4
+                ws2 = _ws(nb2, x_raw)
+                with _Guard(x_raw, "instnorm_lrelu_bwd", 7.0 * x_raw.numel(), 12.0 * x_raw.numel()):
+                    _lib.check(L.modet_instnorm_lrelu_bwd_rows(_p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(d_raw), _p(rows), rb,
+                                                               _p(ws2), nb2, B, V, C, _stream()), "modet_instnorm_lrelu_bwd_rows")
+            else:
+                d_y = conv3d_backward_data(dz, w, C, ctx.step)
+                nb = L.modet_instnorm_ws_bytes(B, V, C)
+                ws = _ws(nb, x_raw)
+                with _Guard(x_raw, "instnorm_lrelu_bwd", 14.0 * x_raw.numel(), 12.0 * x_raw.numel()):
+                    _lib.check(L.modet_instnorm_lrelu_bwd(_p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(d_raw), _p(ws), nb, B, V, C,
+                                                          _stream()), "modet_instnorm_lrelu_bwd")
+        dw, db = conv3d_backward_weight(y, dz, ctx.has_bias, w=w, b=b, step=ctx.step)
+        return d_raw, None, dw, db, None, None
 
 
 def conv3d_with_stats(x, w, b):

@@ -643,6 +643,55 @@ def test_conv_instnorm_fused_vs_oracle(ops, cin, cout, shape):
     assert_close(np64(dw), rw.numpy(), atol=5e-4, rtol=2e-4, what="fused block dw")
 
 
+@pytest.mark.parametrize("c0,c1,c2,shape,B", [(4, 8, 8, (20, 24, 28), 2), (8, 16, 16, (17, 21, 40), 1), (8, 8, 4, (33, 40, 48), 1),
+                                              (6, 12, 12, (18, 20, 35), 1), (16, 32, 32, (12, 10, 20), 2),
+                                              (8, 8, 8, (64, 96, 112), 1)])
+def test_instnorm_conv_chain_with_fused_backward_statistics(ops, c0, c1, c2, shape, B):
+    """conv -> InstanceNorm + LeakyReLU -> conv as the model runs it in training (ops.lazy_instnorm_conv3d = one autograd
+    node): the second conv's data gradient forms the norm's backward statistics in its epilogue
+    (modet_conv3d_bwd_data_instats, z-march family; the other shapes take the two-kernel form) -- against fp64 autograd,
+    and against the unfused form of the same build."""
+    gen = torch.Generator().manual_seed(c0 * 101 + c1 * 7 + c2)
+    x = torch.randn((B, c0) + shape, generator=gen).double().requires_grad_(True)
+    w1 = (torch.randn((c1, c0, 3, 3, 3), generator=gen) / np.sqrt(c0 * 27)).double().requires_grad_(True)
+    w2 = (torch.randn((c2, c1, 3, 3, 3), generator=gen) / np.sqrt(c1 * 27)).double().requires_grad_(True)
+    b2 = (0.1 * torch.randn(c2, generator=gen)).double().requires_grad_(True)
+    big = int(np.prod(shape)) > 200000
+    xd = cl(x.detach().numpy()).requires_grad_(True)
+    w1d, w2d, b2d = (t.detach().float().cuda().requires_grad_(True) for t in (w1, w2, b2))
+    gz = torch.randn((B,) + shape + (c2,), generator=gen).cuda()
+
+    def run(flag):
+        ops.FUSE_IN_DGRAD = flag
+        try:
+            raw, st = ops.conv3d_with_stats(xd, w1d, None)
+            z, _ = ops.lazy_instnorm_conv3d(raw, st, w2d, b2d)
+            return [z.detach()] + list(torch.autograd.grad(z, [xd, w1d, w2d, b2d], gz))
+        finally:
+            ops.FUSE_IN_DGRAD = True
+
+    got, plain = run(True), run(False)
+    for name, a, b in zip(("z", "dx", "dw1", "dw2", "db2"), got, plain):
+        d = float((a - b).abs().max())
+        assert d <= 2e-5 * float(b.abs().max()) + 1e-7, f"{name}: fused vs unfused backward statistics, max |d| {d}"
+    if not big:                                            # (fp64 conv autograd on the host: small shapes only)
+        raw_r = torch.nn.functional.conv3d(x, w1, None, padding=1)
+        xhat = torch.nn.functional.instance_norm(raw_r, eps=1e-5)
+        z_r = torch.nn.functional.conv3d(torch.nn.functional.leaky_relu(xhat, 0.1), w2, b2, padding=1)
+        gzr = gz.double().cpu().permute(0, 4, 1, 2, 3)
+        ref = [z_r.detach()] + list(torch.autograd.grad(z_r, [x, w1, w2, b2], gzr))
+        assert_close(ncdhw(got[0]), ref[0].numpy(), atol=1e-4, what="chain z")
+        # LeakyReLU's kink: a handful of elements within fp32 noise of 0 may take the other slope on the GPU (each moves
+        # d_x by a few 1e-3 of its max locally); compare in the mean and bound the outliers
+        ex = np.abs(ncdhw(got[1]) - ref[1].numpy())
+        assert float(ex.mean()) <= 2e-6 * float(ref[1].abs().max()) + 1e-7 and float(ex.max()) <= 5e-2 * float(ref[1].abs().max())
+        assert_close(np64(got[2]), ref[2].numpy(), atol=5e-4 * float(ref[2].abs().max()), what="chain dw1")
+        assert_close(np64(got[3]), ref[3].numpy(), atol=5e-4 * float(ref[3].abs().max()), what="chain dw2")
+    again = run(True)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b), "the fused form must be run-to-run deterministic"
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(8, 8, (33, 40, 48)), (16, 16, (9, 11, 37)), (32, 32, (12, 10, 20)),
                                             (12, 2, (7, 9, 18)), (48, 48, (5, 6, 7))])
 def test_lazy_instnorm_conv_inference(ops, cin, cout, shape):
