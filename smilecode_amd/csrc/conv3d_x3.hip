@@ -162,7 +162,7 @@ __device__ long long* g_x3_dbg = nullptr;
 // HBM (a staging item = 8 channels = 16 bytes goes to LDS untouched), else fp32 rounded while staged; OUT16: y is stored as bf16.
 // A plane then carries 18 MFMAs per wave instead of 108: the kernel is HBM-bound (8->8: 32 bytes per voxel).
 template <int CIN, int P, int TY, bool WLDS, bool NORM, int STATS, int NPC = 3, bool IN16 = false, bool OUT16 = false>
-__global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (CIN == 16 ? 1 : 2)) void conv_x3_kernel(const X3Args a) {
+__global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (CIN == 16 ? 1 : (((X3_VARIANT & 8) && CIN == 8) ? 3 : 2))) void conv_x3_kernel(const X3Args a) {
   using G = X3Geo<CIN, P>;
   constexpr int NS = G::NS, NTAP = G::NTAP;
   constexpr int HY = TY + 2, UNITS = TY / P, R = UNITS / 4;
@@ -172,9 +172,11 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   constexpr int Q = CIN / EPI, NITEM = HY * HX * Q, NIT = (NITEM + NTHR - 1) / NTHR;
   // STATS 2 (8 / 16 input channels): the LOW piece of the weights lives in LDS, the other two in registers -- its A
   // fragments are read once per (plane, k-step) and feed the last MFMAs of the unit; frees 36 registers for the statistics
-  constexpr bool WLO = STATS == 2 && NPC == 3 && CIN >= 8 && !WLDS;
-  constexpr int NPR = WLO ? 2 : NPC;                                       // pieces kept in registers
-  constexpr int WL_B = WLDS ? 3 * NS * NPC * 1024 : (WLO ? 3 * NS * 1024 : 16);
+  // (X3_VARIANT bits 4 / 8, tuning builds: the low piece / the two low pieces in LDS for every fp32 instantiation with 8+ channels)
+  constexpr int NPR = (NPC != 3 || WLDS || CIN < 8) ? NPC                  // pieces kept in registers
+                      : ((X3_VARIANT & 8) && CIN == 8) ? 1 : ((STATS == 2 || (X3_VARIANT & 4)) ? 2 : 3);
+  constexpr bool WLO = NPR < NPC;
+  constexpr int WL_B = WLDS ? 3 * NS * NPC * 1024 : (WLO ? 3 * NS * (NPC - NPR) * 1024 : 16);
   static_assert(UNITS % 4 == 0, "row groups split over 4 waves");
   static_assert(Q >= 1 && NTHR % Q == 0, "a thread's staging items share one channel group");
   static_assert(NPC == 3 || !NORM, "the lazily normalised input exists for the fp32 form only");
@@ -209,8 +211,11 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
       for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int pc = 0; pc < NPR; ++pc) wreg[dz][s][pc] = a.wpk[((dz * NS + s) * NPC + pc) * 64 + lane];
-    if constexpr (WLO) {
-      for (int i = tid; i < 3 * NS * 64; i += NTHR) reinterpret_cast<uint4*>(wl)[i] = a.wpk[((i >> 6) * NPC + 2) * 64 + (i & 63)];
+    if constexpr (WLO) {                                                   // wl[((dz*NS + s) * (NPC - NPR) + pc - NPR) * 64 + lane]
+      for (int i = tid; i < 3 * NS * (NPC - NPR) * 64; i += NTHR) {
+        const int ln = i & 63, j = i >> 6, pcl = j % (NPC - NPR), ds = j / (NPC - NPR);
+        reinterpret_cast<uint4*>(wl)[i] = a.wpk[(ds * NPC + NPR + pcl) * 64 + ln];
+      }
     }
   }
 
@@ -392,8 +397,8 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   auto wfrag = [&](int dz, int s, int pc) -> bf16x8 {
     if constexpr (WLDS) return __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(wl)[((dz * NS + s) * NPC + pc) * 64 + lane]);
     else if constexpr (WLO) {
-      if (pc == 2) return __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(wl)[(dz * NS + s) * 64 + lane]);
-      return __builtin_bit_cast(bf16x8, wreg[dz][s][pc < 2 ? pc : 0]);
+      if (pc >= NPR) return __builtin_bit_cast(bf16x8, reinterpret_cast<const uint4*>(wl)[((dz * NS + s) * (NPC - NPR) + pc - NPR) * 64 + lane]);
+      return __builtin_bit_cast(bf16x8, wreg[dz][s][pc < NPR ? pc : 0]);
     } else return __builtin_bit_cast(bf16x8, wreg[dz][s][pc]);
   };
 #define X3_MM(ACC, WP, XP) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[WP], xf[XP], ACC, 0, 0, 0)
@@ -606,7 +611,8 @@ inline X3Plan x3_plan(int B, int D, int H, int W, int Cin, int Cout, int npc = 3
   // 16 rows = 8 packed row pairs, or 8 plain rows: two row groups per wave; CIN 16 / one piece: 16 plain rows, four per wave
   p.ty = (p.P == 2 || p.cin_t == 16 || npc == 1) ? 16 : 8;
   p.wlds = 0;
-  const int slots = npc == 1 ? ((p.P == 2 && p.cin_t < 16) ? 768 : 512) : (p.cin_t == 16 ? 256 : 512);       // resident workgroups
+  const int slots = npc == 1 ? ((p.P == 2 && p.cin_t < 16) ? 768 : 512)                                      // resident workgroups
+                             : (p.cin_t == 16 ? 256 : (((X3_VARIANT & 8) && p.cin_t == 8) ? 768 : 512));
   p.tiles_x = cdiv(W, TX);
   p.tiles_y = cdiv(H, p.ty);
   // z chunks: enough workgroups to fill 256 CUs x 2 several times over (the dispatcher balances them), but chunks long
