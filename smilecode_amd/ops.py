@@ -290,8 +290,9 @@ class StepContext:
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
-        if h is not None and _lib._lib is not None:
-            _lib._lib.modet_step_ctx_destroy(h)
+        lib = getattr(_lib, "_lib", None) if _lib is not None else None     # (module globals are gone at interpreter exit)
+        if h is not None and lib is not None:
+            lib.modet_step_ctx_destroy(h)
 
     class _Bind:
         def __init__(self, sc):
