@@ -1098,17 +1098,19 @@ __global__ __launch_bounds__(NTHR) void conv_c1_march_kernel(const C1Args a) {
   const int b = blockIdx.y;
   const float* xb = a.x + (int64_t)b * D * H * W;
   float* yb = a.y + (int64_t)b * D * H * W * 4;
-  float wv[27][4], bv[4];
+  // the four couts travel as two float PAIRS: 54 v_pk_fma_f32 per voxel instead of 108 v_fma_f32 (the kernel was VALU-bound)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 wv[27][2], bv[2];
 #pragma unroll
   for (int tp = 0; tp < 27; ++tp)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float t_ = a.w[c * 27 + tp];                                           // (4, 1, 27): wave-uniform reads ...
       asm volatile("" : "+v"(t_));                                           // ... pinned into VECTOR registers: left to itself
-      wv[tp][c] = t_;                                                        // the compiler keeps 108 SGPRs and spills them
+      wv[tp][c >> 1][c & 1] = t_;                                            // the compiler keeps 108 SGPRs and spills them
     }
 #pragma unroll
-  for (int c = 0; c < 4; ++c) bv[c] = a.bias ? a.bias[c] : 0.f;
+  for (int c = 0; c < 4; ++c) bv[c >> 1][c & 1] = a.bias ? a.bias[c] : 0.f;
   // staging: halo voxel v = tid (and 256 + tid for the first C1HV - 256 threads); byte offsets inside a plane
   using Buf = __amdgpu_buffer_rsrc_t;
   auto rsrc = [](const float* base, unsigned bytes) -> Buf {
@@ -1163,15 +1165,16 @@ __global__ __launch_bounds__(NTHR) void conv_c1_march_kernel(const C1Args a) {
     __syncthreads();
     load_plane(z + 2);
     nb9(i & 1, n2);
-    float acc[4] = {bv[0], bv[1], bv[2], bv[3]};
+    f2 ac[2] = {bv[0], bv[1]};
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[c] = fmaf(n0[k], wv[k][c], acc[c]);
-        acc[c] = fmaf(n1[k], wv[9 + k][c], acc[c]);
-        acc[c] = fmaf(n2[k], wv[18 + k][c], acc[c]);
+      for (int h = 0; h < 2; ++h) {
+        ac[h] = __builtin_elementwise_fma((f2){n0[k], n0[k]}, wv[k][h], ac[h]);
+        ac[h] = __builtin_elementwise_fma((f2){n1[k], n1[k]}, wv[9 + k][h], ac[h]);
+        ac[h] = __builtin_elementwise_fma((f2){n2[k], n2[k]}, wv[18 + k][h], ac[h]);
       }
+    float acc[4] = {ac[0][0], ac[0][1], ac[1][0], ac[1][1]};
     if (a.act) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = lrelu(acc[c]);
