@@ -366,9 +366,11 @@ def main():
     mov, fix = synth.make_pair(shape, 24 + 2 * args.batch * rank, args.batch)      # per-rank pairs, weak scaling
     mov, fix = torch.from_numpy(mov).to(dev), torch.from_numpy(fix).to(dev)
 
+    last = {}
+
     def step():
         if args.workload == "train":
-            trainer.train_step(mov, fix, epoch=0)
+            last["loss"] = trainer.train_step(mov, fix, epoch=0)[0]      # device scalar, read once after the timed region
         else:
             trainer.infer(mov, fix)
 
@@ -494,6 +496,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    # A timing of a broken computation is worthless (a network that went NaN skips most of its scatter-adds and runs ~13 %
+    # faster): the loss of the last timed step and every parameter must be finite, or the run is refused
+    loss_timed = float(last["loss"]) if "loss" in last else None
+    if args.workload == "train" and not (loss_timed == loss_timed and abs(loss_timed) < 1e6
+                                         and bool(torch.isfinite(trainer.fp.flat).all())):
+        log(f"[bench] ERROR: the train step diverged inside the timed region (loss {loss_timed}); refusing to report a number")
+        sys.exit(3)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -581,6 +590,7 @@ def main():
                 "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}",
                 "allreduce": "3 buckets from backward hooks, overlapped" if args.overlap else "one flat all-reduce after backward"},
             "roofline": roof, "roofline_top": roof_top, "host_enqueue_ms_per_step": host_graph_ms if graphed else host_ms,
+            "loss_after_timed_region": loss_timed,
             "hip_graph": graphed, "eager": {"host_enqueue_ms_per_step": host_ms,
                                             "ms_per_step": dt_eager / roof_steps * 1e3 if dt_eager else None},
             # proof of the N-rank run: what torch.distributed itself reports, and the step's one collective timed alone

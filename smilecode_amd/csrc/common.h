@@ -25,6 +25,21 @@ static inline int flat_grid(int64_t n, int block) {
   return (int)g;
 }
 
+// Zero fill as a KERNEL.  hipMemsetAsync must not be used by anything that may be captured into a hipGraph: on this ROCm
+// (7.2) a captured memset node clears its buffer on the first replay only -- later replays leave garbage (tools/
+// exp_graph_memset.py: warp backward captured alone, replay 0 exact, replay 1 off by 2e27).  n_bytes % 4 == 0.
+static __global__ void modet_zero_kernel(unsigned* __restrict__ p, int64_t n_words) {
+  const int64_t n4 = n_words >> 2;
+  uint4* p4 = reinterpret_cast<uint4*>(p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    p4[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) p[(n4 << 2) + threadIdx.x] = 0u;
+}
+static inline void modet_zero_async(void* p, size_t n_bytes, hipStream_t s) {     // p 16-byte aligned (torch allocations are)
+  const int64_t words = (int64_t)(n_bytes / 4);
+  hipLaunchKernelGGL(modet_zero_kernel, dim3(flat_grid(words / 4 + 1, 256)), dim3(256), 0, s, (unsigned*)p, words);
+}
+
 #define LRELU_SLOPE 0.1f
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU_SLOPE * v; }

@@ -72,8 +72,7 @@ int modet_jacdet_nonpos_count(const float* flow, int64_t* counts, double* det_ou
   MODET_CHECK_PTR(flow); MODET_CHECK_PTR(counts);
   MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1);          // np.gradient needs at least 2 samples per axis
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(counts, 0, (size_t)B * sizeof(int64_t), s);
-  if (e != hipSuccess) return (int)e;
+  modet_zero_async(counts, (size_t)B * sizeof(int64_t), s);
   const int64_t V = (int64_t)D * H * W;
   int grid = flat_grid(V, BLK);
   if (grid > 2048) grid = 2048;

@@ -669,10 +669,7 @@ int modet_warp_bwd(const float* src, const float* flow, const float* d_out, floa
   while (G < C) G <<= 1;
   if (G > 64) return MODET_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (d_src) {
-    hipError_t e = hipMemsetAsync(d_src, 0, (size_t)B * D * H * W * C * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-  }
+  if (d_src) modet_zero_async(d_src, (size_t)B * D * H * W * C * sizeof(float), s);     // (not hipMemsetAsync: common.h)
   const int64_t total = (int64_t)B * cdiv(D, ZRUN) * H * W * G;       // one item per (z run, y, x, channel slot)
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow, D,
                      H, W, C, G, total, add_flow);
@@ -781,8 +778,7 @@ int modet_label_warp_counts(const int16_t* lab_moving, const float* flow, const 
   MODET_CHECK_DIM(D > 0 && H > 0 && W > 0 && nlabels > 0);
   if (nlabels + 1 > MAXLAB) return MODET_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(counts, 0, (size_t)3 * (nlabels + 1) * sizeof(int64_t), s);
-  if (e != hipSuccess) return (int)e;
+  modet_zero_async(counts, (size_t)3 * (nlabels + 1) * sizeof(int64_t), s);
   const int64_t V = (int64_t)D * H * W;
   int grid = flat_grid(V, BLK);
   if (grid > 1024) grid = 1024;
