@@ -8,7 +8,7 @@
 // of total order <= 2, each EXACT in the fp32 accumulator of v_mfma_f32_16x16x32_bf16; the three dropped terms are
 // <= 3 * 2^-24 |a b| -- the class of the single rounding of an fp32 FMA.  Six bf16 MFMAs (16 cycles each per SIMD) replace
 // eight passes of the exact-f32 MFMA (32 cycles each): 2.7x less matrix-pipe time, and a third of the matrix-pipe power
-// (the exact-f32 kernels run this chip into its package power limit, DESIGN.md "two speeds").
+// (the exact-f32 kernels run this chip into its package power limit: s_memtime shows ~1.5 GHz inside them on random data).
 //
 // Structure.  The exact-f32 kernel (conv3d.hip) stages a 4x8x16 tile with a one-voxel halo: 2.1x the tile's voxels pass
 // through the split/LDS path and L2 (measured 1.9x the algorithmic HBM traffic).  Here a workgroup owns a (TY x 16) column

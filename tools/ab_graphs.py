@@ -1,5 +1,5 @@
-"""Same-process A/B of two variants of the captured train step (the chip has two speed modes PER PROCESS, so two bench.py
-runs cannot be compared): captures one hipGraph per variant in one process and replays them alternately.
+"""Same-process A/B of two variants of the captured train step (replays on FIXED parameters -- no optimizer step -- so both
+variants see identical data; run-to-run noise of separate bench.py processes is ~0.5 %): captures one hipGraph per variant in one process and replays them alternately.
 
     python tools/ab_graphs.py attr:smilecode_amd.ops.SOME_FLAG=True,False     # a module attribute read at capture time
 (used for profiles/r03i_arrival_counter_experiment.txt)
