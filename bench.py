@@ -310,8 +310,11 @@ def cfg5_leg(dev, steps):
         loss = tr.train_step(mov, fix, epoch=0)[0]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    lv = float(loss)
+    if not (lv == lv and abs(lv) < 1e6 and bool(torch.isfinite(tr.fp.flat).all())):      # a diverged run times a different computation
+        raise RuntimeError(f"cfg5 leg diverged (loss {lv})")
     out = {"value": batch / dt, "unit": "volume-pairs/sec", "ms_per_step": dt * 1e3, "steps": steps, "dtype": "bf16",
-           "hip_graph": graphed, "loss_after": float(loss),
+           "hip_graph": graphed, "loss_after": lv,
            "workload": "ModeT 160x192x224 bf16 storage / fp32 accumulate (ConvInsBlock chains), batch=2/GPU, full train step "
                        "NCC+Grad3d fwd+bwd+Adam-amsgrad, 1 GPU (the 8-GPU form of configs[4] adds the overlapped all-reduce)"}
     del tr, model, mov, fix
