@@ -80,7 +80,7 @@ class Trainer:
                 self.fp.gather_grads(scope.written)
         return loss.detach(), sim.detach(), reg.detach()
 
-    def capture(self, moving, fixed, warmup=2):
+    def capture(self, moving, fixed, warmup=2, verify=True):
         """Capture forward + losses + backward + gradient packing for this input shape into ONE hipGraph
         (torch.cuda.CUDAGraph = hipGraph on ROCm).  A step is ~500 kernel launches issued from Python through ctypes and
         the autograd tape (6-7 ms of host time at 160x192x160); replaying the graph costs the host ~0.1 ms, so the GPU
@@ -88,7 +88,10 @@ class Trainer:
         outside the graph (their lr / step / 1/world arguments change per step; RCCL picks its own stream order).
         ``warmup`` eager steps of the SAME computation run first on the capture stream (every kernel must have been
         launched once: lazy code-object loading and the occupancy memo are not capturable); they do not update the
-        parameters.  Returns self."""
+        parameters.  ``verify``: the captured step is replayed TWICE and its gradients compared with the eager step's
+        before the graph is accepted (RuntimeError otherwise) -- a captured stream operation that is not a kernel may replay
+        differently from how it ran (round 3: a hipMemsetAsync node cleared its buffer on the first replay only and the step
+        was silently wrong from the second one on); two eager-sized steps, once per capture.  Returns self."""
         self.model.train()
         self._static_in = (moving.clone(), fixed.clone())
         side = torch.cuda.Stream(device=moving.device)
@@ -110,6 +113,17 @@ class Trainer:
             self._static_out = self._fwd_bwd(*self._static_in)
         self._graph = g
         self._graph_key = (tuple(moving.shape), moving.device)
+        if verify:
+            ref = self.fp.grad.clone()                      # the last warm-up pass = the eager step on these parameters
+            scale = float(ref.abs().max())
+            for rep in range(2):
+                self.fp.grad.fill_(float("nan"))
+                g.replay()
+                err = float((self.fp.grad - ref).abs().max())
+                if not (err <= 2e-2 * scale + 1e-12):        # (float atomics reorder: ~1e-6; a broken replay: NaN or 1e20)
+                    self.release_graph()
+                    raise RuntimeError(f"hipGraph replay {rep} of the train step does not reproduce the eager gradients "
+                                       f"(max |diff| {err:.3e} at gradient scale {scale:.3e}); running eagerly is the fallback")
         return self
 
     def release_graph(self):
