@@ -155,7 +155,12 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
     const bool dn_ok = (dn >= 0) && inr && pxi == xi - 1;
     float pend[4] = {0.f, 0.f, 0.f, 0.f};                    // dz=1 half of the previous voxel, index dy*2 + dx
     int pz = 0, py = 0, px = 0;
+    int64_t poff = 0;                                        // element offset of corner (pz, py, px) in a channel's volume
     bool have = false;
+    // corner addressing: ONE 64-bit multiply per voxel (the element offset of its (z0, y0, x0) corner), the other seven
+    // corners by adding wave-uniform strides -- written per corner as (((z * H + y) * W + x) * C the address arithmetic
+    // (quarter-rate v_mul_lo_u32 / v_mad_u64_u32, ~150 per voxel) was most of this kernel's instructions
+    const int64_t sXc = C, sYc = (int64_t)W * C, sZc = HW * C;
     for (int k = 0; k < ZRUN; ++k) {
       const int zi = zr * ZRUN + k;
       const bool zin = zi < D;                               // uniform over the wave except at the run tail
@@ -167,6 +172,10 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
       // contributions of this (voxel, channel) to the 8 corners, index = dz*4 + dy*2 + dx
       float cv[8];
       float gz = 0.f, gy = 0.f, gx = 0.f;
+      const int64_t off0 = (((int64_t)t.z0 * H + t.y0) * W + t.x0) * C;
+      const bool zok[2] = {t.z0 >= 0 && t.z0 < D, t.z0 + 1 >= 0 && t.z0 + 1 < D};
+      const bool yok[2] = {t.y0 >= 0 && t.y0 < H, t.y0 + 1 >= 0 && t.y0 + 1 < H};
+      const bool xok[2] = {t.x0 >= 0 && t.x0 < W, t.x0 + 1 >= 0 && t.x0 + 1 < W};
 #pragma unroll
       for (int dz = 0; dz < 2; ++dz) {
         const float wz = dz ? t.fz : 1.f - t.fz;
@@ -176,11 +185,10 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
 #pragma unroll
           for (int dx = 0; dx < 2; ++dx) {
             const float wx = dx ? t.fx : 1.f - t.fx;
-            const int zz = t.z0 + dz, yy = t.y0 + dy, xx = t.x0 + dx;
-            const bool ok = live && zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const bool ok = live && zok[dz] && yok[dy] && xok[dx];
             cv[dz * 4 + dy * 2 + dx] = ok ? wz * wy * wx * go : 0.f;
             if (dflow && ok) {
-              const float dot = sb[(((int64_t)zz * H + yy) * W + xx) * C] * go;
+              const float dot = sb[off0 + (dz ? sZc : 0) + (dy ? sYc : 0) + (dx ? sXc : 0)] * go;
               gz += (dz ? 1.f : -1.f) * wy * wx * dot;
               gy += (dy ? 1.f : -1.f) * wz * wx * dot;
               gx += (dx ? 1.f : -1.f) * wz * wy * dot;
@@ -208,16 +216,15 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (pend[q] != 0.f) atomicAdd(db + (((int64_t)pz * H + (py + (q >> 1))) * W + (px + (q & 1))) * C, pend[q]);
+              if (pend[q] != 0.f) atomicAdd(db + poff + ((q >> 1) ? sYc : 0) + ((q & 1) ? sXc : 0), pend[q]);
           }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                        // the dz=0 half is final now
-          if (cv[q] != 0.f)
-            atomicAdd(db + (((int64_t)t.z0 * H + (t.y0 + (q >> 1))) * W + (t.x0 + (q & 1))) * C, cv[q]);
+          if (cv[q] != 0.f) atomicAdd(db + off0 + ((q >> 1) ? sYc : 0) + ((q & 1) ? sXc : 0), cv[q]);
           pend[q] = cv[4 + q];
         }
-        pz = t.z0 + 1; py = t.y0; px = t.x0;
+        pz = t.z0 + 1; py = t.y0; px = t.x0; poff = off0 + sZc;
         have = zin;
       }
       if (dflow) {
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
     if (db && have) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (pend[q] != 0.f) atomicAdd(db + (((int64_t)pz * H + (py + (q >> 1))) * W + (px + (q & 1))) * C, pend[q]);
+        if (pend[q] != 0.f) atomicAdd(db + poff + ((q >> 1) ? sYc : 0) + ((q & 1) ? sXc : 0), pend[q]);
     }
   }
 }
