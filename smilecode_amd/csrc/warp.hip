@@ -76,28 +76,30 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
       if (zr >= 0.f && zr < (float)D && yr >= 0.f && yr < (float)H && xr >= 0.f && xr < (float)W)
         ldv<CPT>(sb + (((int64_t)zr * H + (int64_t)yr) * W + (int64_t)xr) * C, acc);
     } else {
+      // branch-free: the eight corner loads are issued back to back (out-of-range corners read a clamped, valid voxel
+      // with weight 0).  A load per `if (inside)` compiled to eight load -> s_waitcnt vmcnt(0) round trips in series.
       const Tri t = tri_setup(z, y, x);
+      int64_t zo[2], yo[2], xo[2];
+      float wzv[2], wyv[2], wxv[2];
 #pragma unroll
-      for (int dz = 0; dz < 2; ++dz) {
-        const int zz = t.z0 + dz;
-        const float wz = dz ? t.fz : 1.f - t.fz;
+      for (int d = 0; d < 2; ++d) {
+        const int zz = t.z0 + d, yy = t.y0 + d, xx = t.x0 + d;
+        const bool zk = zz >= 0 && zz < D, yk = yy >= 0 && yy < H, xk = xx >= 0 && xx < W;
+        zo[d] = (int64_t)(zk ? zz : 0) * H * W * C;
+        yo[d] = (int64_t)(yk ? yy : 0) * W * C;
+        xo[d] = (int64_t)(xk ? xx : 0) * C;
+        wzv[d] = zk ? (d ? t.fz : 1.f - t.fz) : 0.f;
+        wyv[d] = yk ? (d ? t.fy : 1.f - t.fy) : 0.f;
+        wxv[d] = xk ? (d ? t.fx : 1.f - t.fx) : 0.f;
+      }
+      float s[8][CPT];
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-          const int yy = t.y0 + dy;
-          const float wy = dy ? t.fy : 1.f - t.fy;
+      for (int q = 0; q < 8; ++q) ldv<CPT>(sb + zo[q >> 2] + yo[(q >> 1) & 1] + xo[q & 1], s[q]);
 #pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            const int xx = t.x0 + dx;
-            const float wx = dx ? t.fx : 1.f - t.fx;
-            if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-              float s[CPT];
-              ldv<CPT>(sb + (((int64_t)zz * H + yy) * W + xx) * C, s);
-              const float wgt = wz * wy * wx;
+      for (int q = 0; q < 8; ++q) {
+        const float wgt = wzv[q >> 2] * wyv[(q >> 1) & 1] * wxv[q & 1];
 #pragma unroll
-              for (int c = 0; c < CPT; ++c) acc[c] = fmaf(wgt, s[c], acc[c]);
-            }
-          }
-        }
+        for (int c = 0; c < CPT; ++c) acc[c] = fmaf(wgt, s[q][c], acc[c]);
       }
     }
     if (add_flow) {                            // C == 3, CPT == 3, G == 1
@@ -161,14 +163,32 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
     // corners by adding wave-uniform strides -- written per corner as (((z * H + y) * W + x) * C the address arithmetic
     // (quarter-rate v_mul_lo_u32 / v_mad_u64_u32, ~150 per voxel) was most of this kernel's instructions
     const int64_t sXc = C, sYc = (int64_t)W * C, sZc = HW * C;
+    // Every load is unconditional (clamped, always valid addresses; the predicate goes into the VALUE): a load under
+    // `if (ok)` costs its own s_waitcnt vmcnt(0) -- the first version waited for ten memory round trips in series per
+    // voxel (flow, d_out, then the eight source corners one by one).  flow and d_out of the NEXT voxel of the run are
+    // fetched while the current one is processed.
+    const int64_t nrow = b * V + (int64_t)yi * W + xi;
+    float pf0, pf1, pf2, pgo;
+    {
+      const int z0i = zr * ZRUN < D ? zr * ZRUN : D - 1;
+      const int64_t n0 = nrow + (int64_t)z0i * HW;
+      pf0 = flow[n0 * 3]; pf1 = flow[n0 * 3 + 1]; pf2 = flow[n0 * 3 + 2];
+      pgo = dout[n0 * C + cc];
+    }
     for (int k = 0; k < ZRUN; ++k) {
       const int zi = zr * ZRUN + k;
       const bool zin = zi < D;                               // uniform over the wave except at the run tail
       const bool live = livec && zin;
-      const int64_t n = b * V + (int64_t)(zin ? zi : D - 1) * HW + (int64_t)yi * W + xi;
-      const float* fp = flow + n * 3;
-      const Tri t = tri_setup((float)zi + fp[0], (float)yi + fp[1], (float)xi + fp[2]);
-      const float go = live ? dout[n * C + cc] : 0.f;
+      const int64_t n = nrow + (int64_t)(zin ? zi : D - 1) * HW;
+      const float f0 = pf0, f1 = pf1, f2 = pf2;
+      const float go = live ? pgo : 0.f;
+      {
+        const int zn = (zi + 1 < D && k + 1 < ZRUN) ? zi + 1 : (zin ? zi : D - 1);
+        const int64_t nn = nrow + (int64_t)zn * HW;
+        pf0 = flow[nn * 3]; pf1 = flow[nn * 3 + 1]; pf2 = flow[nn * 3 + 2];
+        pgo = dout[nn * C + cc];
+      }
+      const Tri t = tri_setup((float)zi + f0, (float)yi + f1, (float)xi + f2);
       // contributions of this (voxel, channel) to the 8 corners, index = dz*4 + dy*2 + dx
       float cv[8];
       float gz = 0.f, gy = 0.f, gx = 0.f;
@@ -176,6 +196,15 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
       const bool zok[2] = {t.z0 >= 0 && t.z0 < D, t.z0 + 1 >= 0 && t.z0 + 1 < D};
       const bool yok[2] = {t.y0 >= 0 && t.y0 < H, t.y0 + 1 >= 0 && t.y0 + 1 < H};
       const bool xok[2] = {t.x0 >= 0 && t.x0 < W, t.x0 + 1 >= 0 && t.x0 + 1 < W};
+      float sv[8];
+      if (dflow) {                                           // uniform
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool ok = live && zok[q >> 2] && yok[(q >> 1) & 1] && xok[q & 1];
+          const int64_t off = off0 + ((q >> 2) ? sZc : 0) + (((q >> 1) & 1) ? sYc : 0) + ((q & 1) ? sXc : 0);
+          sv[q] = sb[ok ? off : 0];
+        }
+      }
 #pragma unroll
       for (int dz = 0; dz < 2; ++dz) {
         const float wz = dz ? t.fz : 1.f - t.fz;
@@ -187,8 +216,8 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
             const float wx = dx ? t.fx : 1.f - t.fx;
             const bool ok = live && zok[dz] && yok[dy] && xok[dx];
             cv[dz * 4 + dy * 2 + dx] = ok ? wz * wy * wx * go : 0.f;
-            if (dflow && ok) {
-              const float dot = sb[off0 + (dz ? sZc : 0) + (dy ? sYc : 0) + (dx ? sXc : 0)] * go;
+            if (dflow) {
+              const float dot = ok ? sv[dz * 4 + dy * 2 + dx] * go : 0.f;     // an exact zero for the corners outside
               gz += (dz ? 1.f : -1.f) * wy * wx * dot;
               gy += (dy ? 1.f : -1.f) * wz * wx * dot;
               gx += (dx ? 1.f : -1.f) * wz * wy * dot;
@@ -270,19 +299,28 @@ __global__ __launch_bounds__(BLK) void warp_bwd_gather3_tiled_kernel(const float
   const int x0 = (t % tiles_x) * G3X; t /= tiles_x;
   const int y0 = (t % tiles_y) * G3Y;
   const int z0 = (t / tiles_y) * G3Z;
-  for (int i = threadIdx.x; i < G3HV * 3; i += BLK) {
+  // staging, branch-free: all loads of a thread are issued before the first LDS write (clamped addresses, the halo
+  // outside the volume selected to zero afterwards); with a load per `if (inside)` every item was its own round trip
+  constexpr int G3N = (G3HV * 3 + BLK - 1) / BLK;
+  float2 stg[G3N];
+#pragma unroll
+  for (int j = 0; j < G3N; ++j) {
+    const int i = min((int)threadIdx.x + j * BLK, G3HV * 3 - 1);
     const int v = i / 3, part = i - v * 3;               // part 0: flow[0..1]; 1: flow[2], d_out[0]; 2: d_out[1..2]
     const int hx = v % G3HX, r = v / G3HX;
     const int hy = r % G3HY, hz = r / G3HY;
     const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-    float2 val = make_float2(0.f, 0.f);
-    if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
-      const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
-      if (part == 0) val = make_float2(flow[n * 3], flow[n * 3 + 1]);
-      else if (part == 1) val = make_float2(flow[n * 3 + 2], dout[n * 3]);
-      else val = make_float2(dout[n * 3 + 1], dout[n * 3 + 2]);
-    }
-    *reinterpret_cast<float2*>(fg + v * 6 + part * 2) = val;
+    const bool in = z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
+    const int64_t n = (int64_t)b * V + (in ? ((int64_t)z * H + y) * W + x : 0);
+    const float* pa = part == 0 ? flow + n * 3 : (part == 1 ? flow + n * 3 + 2 : dout + n * 3 + 1);
+    const float* pb = part == 0 ? flow + n * 3 + 1 : (part == 1 ? dout + n * 3 : dout + n * 3 + 2);
+    const float va = *pa, vb = *pb;
+    stg[j] = in ? make_float2(va, vb) : make_float2(0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < G3N; ++j) {
+    const int i = threadIdx.x + j * BLK;
+    if (i < G3HV * 3) *reinterpret_cast<float2*>(fg + i * 2) = stg[j];       // fg + v * 6 + part * 2 with i = v * 3 + part
   }
   __syncthreads();
   const int tx = threadIdx.x % G3X, ty = (threadIdx.x / G3X) % G3Y, tz = threadIdx.x / (G3X * G3Y);
@@ -318,25 +356,30 @@ __global__ __launch_bounds__(BLK) void warp_bwd_gather3_tiled_kernel(const float
     const float g0 = pc[3], g1 = pc[4], g2 = pc[5];
     const float* sb = src + (int64_t)b * V * 3;
     float gz = 0.f, gy = 0.f, gx = 0.f;
+    // eight corner gathers issued back to back (clamped address + zero weight outside; see warp_fwd_kernel)
+    float sp[8][3];
+    bool okc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int zz = tr.z0 + (q >> 2), yy = tr.y0 + ((q >> 1) & 1), xx = tr.x0 + (q & 1);
+      okc[q] = zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const float* pq = sb + (okc[q] ? (((int64_t)zz * H + yy) * W + xx) * 3 : 0);
+      sp[q][0] = pq[0]; sp[q][1] = pq[1]; sp[q][2] = pq[2];
+    }
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz) {
-      const int zz = tr.z0 + dz;
       const float wz = dz ? tr.fz : 1.f - tr.fz;
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy) {
-        const int yy = tr.y0 + dy;
         const float wy = dy ? tr.fy : 1.f - tr.fy;
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-          const int xx = tr.x0 + dx;
           const float wx = dx ? tr.fx : 1.f - tr.fx;
-          if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const float* sp = sb + (((int64_t)zz * H + yy) * W + xx) * 3;
-            const float dot = sp[0] * g0 + sp[1] * g1 + sp[2] * g2;
-            gz += (dz ? 1.f : -1.f) * wy * wx * dot;
-            gy += (dy ? 1.f : -1.f) * wz * wx * dot;
-            gx += (dx ? 1.f : -1.f) * wz * wy * dot;
-          }
+          const int q = dz * 4 + dy * 2 + dx;
+          const float dot = okc[q] ? sp[q][0] * g0 + sp[q][1] * g1 + sp[q][2] * g2 : 0.f;
+          gz += (dz ? 1.f : -1.f) * wy * wx * dot;
+          gy += (dy ? 1.f : -1.f) * wz * wx * dot;
+          gx += (dx ? 1.f : -1.f) * wz * wy * dot;
         }
       }
     }
@@ -479,9 +522,11 @@ __global__ __launch_bounds__(BLK) void upsample2_bwd_rows_kernel(const float* __
   const int64_t o = blockIdx.x / n;
   int lo, hi;
   lin_range(i, r, n, lo, hi);
+  while (lo < hi && lin_wt(lo, i, r, n) == 0.f) ++lo;      // (scalar) the conservative range starts with zero weights
   float wt[9];
 #pragma unroll
   for (int a = 0; a < 9; ++a) wt[a] = lo + a <= hi ? lin_wt(lo + a, i, r, n) : 0.f;
+  const int cnt = hi - lo + 1;                         // >= 1
   const float* p = in + (o * 2 * n + lo) * inner;
   float* q = out + (int64_t)blockIdx.x * inner;
   constexpr int E = V4 ? 4 : 1;
@@ -489,8 +534,25 @@ __global__ __launch_bounds__(BLK) void upsample2_bwd_rows_kernel(const float* __
     float acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    // the first four candidates (all there are, except next to the borders) are loaded unconditionally and back to back
+    // (a missing one re-reads the last valid row with weight 0); a load per `if (wt != 0)` was a round trip each
+    float v4[4][E];
 #pragma unroll
-    for (int a = 0; a < 9; ++a) {
+    for (int a = 0; a < 4; ++a) {
+      const int aa = a < cnt ? a : cnt - 1;
+      if (V4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + aa * inner + k);
+        v4[a][0] = t.x; if (E > 1) { v4[a][1] = t.y; v4[a][2] = t.z; v4[a][3] = t.w; }
+      } else {
+        v4[a][0] = p[aa * inner + k];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = fmaf(wt[a], v4[a][e], acc[e]);
+#pragma unroll
+    for (int a = 4; a < 9; ++a) {
       if (wt[a] == 0.f) continue;                      // uniform over the workgroup
       float v[E];
       if (V4) {

@@ -480,10 +480,13 @@ class _Conv3dStats(Function):
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)        # no zeros_like(stats) fill launch for the statistics output's "gradient"
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        if dy is None:
+            return None, None, None
         x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
         dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step) if ctx.needs_input_grad[0] else None
@@ -577,12 +580,15 @@ class _InstNormConv(Function):
             ctx.mark_non_differentiable(stats)
         else:
             z = conv3d_forward(y, w, b, False, ctx.step)
+        ctx.set_materialize_grads(False)        # no zeros_like(stats) fill launch for the statistics output's "gradient"
         ctx.has_bias = b is not None
         ctx.save_for_backward(x_raw, mean, rstd, y, w, b)
         return z, stats
 
     @staticmethod
     def backward(ctx, dz, _dstats):
+        if dz is None:
+            return None, None, None, None, None, None
         x_raw, mean, rstd, y, w, b = ctx.saved_tensors
         dz = dz.contiguous()
         B, D, H, W, C = x_raw.shape
@@ -1333,10 +1339,13 @@ class _Conv3dBF16(Function):
         y, stats = conv3d_bf16_forward(x, w, b, True, ctx.step)
         ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)        # no zeros_like(stats) fill launch for the statistics output's "gradient"
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        if dy is None:
+            return None, None, None
         x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
         dx = conv3d_bf16_backward_data(dy, w, x.shape[-1], x.dtype == torch.bfloat16, ctx.step) if ctx.needs_input_grad[0] else None
