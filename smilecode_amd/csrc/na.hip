@@ -30,21 +30,46 @@ __device__ __forceinline__ void tile_origin(int tile, const TileGeom g, int& z0,
   z0 = (t2 / g.tiles_y) * TZ;
 }
 
-// stage k[b, z0-1.., y0-1.., x0-1.., head*6 + 0..5] into LDS, zeros outside the volume
-__device__ __forceinline__ void stage_k_tile(float* __restrict__ kt, const float* __restrict__ k, int64_t bbase,
-                                             int z0, int y0, int x0, int D, int H, int W, int C, int hoff) {
-  for (int idx = threadIdx.x; idx < HVOX * 3; idx += NTHREADS) {
+// stage k[b, z0-1.., y0-1.., x0-1.., head*6 + 0..5] into LDS, zeros outside the volume.  Two phases: ALL global loads of a
+// thread are issued first (clamped, always valid addresses; the halo outside the volume is selected to zero afterwards),
+// then the LDS writes.  As one loop with a load per `if (inside)` every item was its own memory round trip: eight in
+// series per tile (and nineteen in na_bwd_kernel) in front of ~10 us of work.
+constexpr int KT_IT = (HVOX * 3 + NTHREADS - 1) / NTHREADS;
+__device__ __forceinline__ void stage_k_load(float2 (&r)[KT_IT], const float* __restrict__ k, int64_t bbase, int z0, int y0,
+                                             int x0, int D, int H, int W, int C, int hoff) {
+  bool inside[KT_IT];
+#pragma unroll
+  for (int j = 0; j < KT_IT; ++j) {
+    const int idx = min((int)threadIdx.x + j * NTHREADS, HVOX * 3 - 1);
     const int v = idx / 3, part = idx - v * 3;
     const int hx = v % HX, t = v / HX;
     const int hy = t % HY, hz = t / HY;
     const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-    float2 val = make_float2(0.f, 0.f);
-    if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
-      const int64_t off = (bbase + ((int64_t)z * H + y) * W + x) * C + hoff + part * 2;
-      val = *reinterpret_cast<const float2*>(k + off);
-    }
-    *reinterpret_cast<float2*>(kt + v * HD + part * 2) = val;
+    const bool in = z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
+    const int64_t off = (bbase + (in ? ((int64_t)z * H + y) * W + x : 0)) * C + hoff + part * 2;
+    r[j] = *reinterpret_cast<const float2*>(k + off);
+    inside[j] = in;
   }
+  // the loaded values are "used" here, unconditionally and all at once: without this hipcc sinks every load back under its
+  // `inside` test (branch, load, s_waitcnt vmcnt(0), eight times in series)
+#pragma unroll
+  for (int j = 0; j < KT_IT; ++j) asm volatile("" : "+v"(r[j].x), "+v"(r[j].y));
+#pragma unroll
+  for (int j = 0; j < KT_IT; ++j)
+    if (!inside[j]) r[j] = make_float2(0.f, 0.f);
+}
+__device__ __forceinline__ void stage_k_store(float* __restrict__ kt, const float2 (&r)[KT_IT]) {
+#pragma unroll
+  for (int j = 0; j < KT_IT; ++j) {
+    const int idx = threadIdx.x + j * NTHREADS;          // = v * 3 + part, and kt + v * HD + part * 2 = kt + idx * 2
+    if (idx < HVOX * 3) *reinterpret_cast<float2*>(kt + idx * 2) = r[j];
+  }
+}
+__device__ __forceinline__ void stage_k_tile(float* __restrict__ kt, const float* __restrict__ k, int64_t bbase,
+                                             int z0, int y0, int x0, int D, int H, int W, int C, int hoff) {
+  float2 r[KT_IT];
+  stage_k_load(r, k, bbase, z0, y0, x0, D, H, W, C, hoff);
+  stage_k_store(kt, r);
 }
 
 __device__ __forceinline__ void load6(const float* __restrict__ p, float (&r)[HD]) {
@@ -183,23 +208,51 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
   int z0, y0, x0;
   tile_origin(blockIdx.x, g, z0, y0, x0);
   if (threadIdx.x < 27) rp[threadIdx.x] = rpb[h * 27 + threadIdx.x];
-  stage_k_tile(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
-  stage_k_tile(qt, q, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
-  for (int v = threadIdx.x; v < HVOX; v += NTHREADS) {
-    const int hx = v % HX, t = v / HX;
-    const int hy = t % HY, hz = t / HY;
-    const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, u = 0.f, l = 0.f;
-    if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
-      const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
+  {
+    // every global load of the three staged tiles is in flight before the first LDS write (see stage_k_load)
+    constexpr int AX_IT = (HVOX + NTHREADS - 1) / NTHREADS;
+    float2 rk[KT_IT], rq[KT_IT];
+    float ra[AX_IT][7];
+    bool ain[AX_IT];
+    stage_k_load(rk, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
+    stage_k_load(rq, q, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
+#pragma unroll
+    for (int j = 0; j < AX_IT; ++j) {
+      const int v = min((int)threadIdx.x + j * NTHREADS, HVOX - 1);
+      const int hx = v % HX, t = v / HX;
+      const int hy = t % HY, hz = t / HY;
+      const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+      const bool in = z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
+      const int64_t n = (int64_t)b * V + (in ? ((int64_t)z * H + y) * W + x : 0);
       const float* go = dout + n * (heads * 3) + h * 3;
       const float* oo = out + n * (heads * 3) + h * 3;
-      g0 = go[0]; g1 = go[1]; g2 = go[2];
-      u = g0 * oo[0] + g1 * oo[1] + g2 * oo[2];
-      l = lse[n * heads + h];
+      ra[j][0] = go[0]; ra[j][1] = go[1]; ra[j][2] = go[2];
+      ra[j][3] = oo[0]; ra[j][4] = oo[1]; ra[j][5] = oo[2];
+      ra[j][6] = lse[n * heads + h];
+      ain[j] = in;
     }
-    float* a = ax + v * AUX;
-    a[0] = g0; a[1] = g1; a[2] = g2; a[3] = u; a[4] = l;
+#pragma unroll
+    for (int j = 0; j < AX_IT; ++j)
+#pragma unroll
+      for (int e = 0; e < 7; ++e) asm volatile("" : "+v"(ra[j][e]));
+#pragma unroll
+    for (int j = 0; j < AX_IT; ++j)
+      if (!ain[j]) {
+#pragma unroll
+        for (int e = 0; e < 7; ++e) ra[j][e] = 0.f;
+      }
+    stage_k_store(kt, rk);
+    stage_k_store(qt, rq);
+#pragma unroll
+    for (int j = 0; j < AX_IT; ++j) {
+      const int v = threadIdx.x + j * NTHREADS;
+      if (v < HVOX) {
+        float* a = ax + v * AUX;
+        a[0] = ra[j][0]; a[1] = ra[j][1]; a[2] = ra[j][2];
+        a[3] = ra[j][0] * ra[j][3] + ra[j][1] * ra[j][4] + ra[j][2] * ra[j][5];
+        a[4] = ra[j][6];
+      }
+    }
   }
   __syncthreads();
   const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);

@@ -32,15 +32,12 @@ __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict
   const int64_t v0 = (int64_t)blockIdx.x * chunk;
   const int64_t v1 = v0 + chunk < V ? v0 + chunk : V;
   if (active) {
-    for (int64_t v = v0 + vl; v < v1; v += VPB) {
-      const int64_t off = ((int64_t)b * V + v) * C + g * 4;
-      const float4 xv = *reinterpret_cast<const float4*>(x + off);
+    auto acc1 = [&](const float4 xv, const float4 gv) {
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
       if (MODE == 0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { a[c] += xs[c]; q[c] = fmaf(xs[c], xs[c], q[c]); }
       } else {
-        const float4 gv = *reinterpret_cast<const float4*>(dy + off);
         const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -49,6 +46,25 @@ __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict
           a[c] += gg; q[c] = fmaf(gg, xh, q[c]);
         }
       }
+    };
+    // the loads of PU passes are issued together, the sums keep their order (bit-identical to the one-pass-per-trip loop)
+    constexpr int PU = MODE == 0 ? 4 : 2;
+    int64_t v = v0 + vl;
+    for (; v + (PU - 1) * VPB < v1; v += PU * VPB) {
+      float4 xv[PU], gv[PU];
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int64_t off = ((int64_t)b * V + v + u * VPB) * C + g * 4;
+        xv[u] = *reinterpret_cast<const float4*>(x + off);
+        gv[u] = MODE == 1 ? *reinterpret_cast<const float4*>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) acc1(xv[u], gv[u]);
+    }
+    for (; v < v1; v += VPB) {
+      const int64_t off = ((int64_t)b * V + v) * C + g * 4;
+      const float4 xv = *reinterpret_cast<const float4*>(x + off);
+      acc1(xv, MODE == 1 ? *reinterpret_cast<const float4*>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
   if ((G & (G - 1)) == 0 && G <= 64) {
@@ -168,21 +184,45 @@ __global__ __launch_bounds__(256) void in_rows_slice_kernel(const float* __restr
   if ((int)threadIdx.x < 2 * C) tail[((int64_t)b * IN_SLICES + sl) * 2 * C + threadIdx.x] = (float)tot[threadIdx.x];
 }
 
+// (channel group, sample) of float4 element i.  32-bit arithmetic whenever the tensor allows it: a 64-bit division by a
+// run-time value is a ~100-instruction software routine, and these kernels have ~10 instructions of real work per element.
+__device__ __forceinline__ void in_elem(int64_t i, int G, int64_t V, bool small, int& g, int& b) {
+  if (small) {
+    const unsigned u = (unsigned)i, q = u / (unsigned)G;
+    g = (int)(u - q * (unsigned)G);
+    b = (int)(q / (unsigned)V);
+  } else {
+    g = (int)(i % G);
+    b = (int)((i / G) / V);
+  }
+}
+constexpr int IN_ILP = 4;      // float4 elements per thread and trip, all loads issued before the first use
+
 __global__ __launch_bounds__(BLK) void in_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        int64_t V, int C, int64_t total4) {
   const int G = C >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
-    const int g = (int)(i % G);
-    const int64_t b = (i / G) / V;
-    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+  const bool small = total4 < (1ll << 31) && V < (1ll << 31);
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  auto one = [&](int64_t i, const float4 xv) {
+    int g, b;
+    in_elem(i, G, V, small, g, b);
     const float4 m = *reinterpret_cast<const float4*>(mean + b * C + g * 4);
     const float4 r = *reinterpret_cast<const float4*>(rstd + b * C + g * 4);
     float4 o;
     o.x = lrelu((xv.x - m.x) * r.x); o.y = lrelu((xv.y - m.y) * r.y);
     o.z = lrelu((xv.z - m.z) * r.z); o.w = lrelu((xv.w - m.w) * r.w);
     reinterpret_cast<float4*>(y)[i] = o;
+  };
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  for (; i + (IN_ILP - 1) * stride < total4; i += IN_ILP * stride) {
+    float4 xv[IN_ILP];
+#pragma unroll
+    for (int u = 0; u < IN_ILP; ++u) xv[u] = reinterpret_cast<const float4*>(x)[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < IN_ILP; ++u) one(i + u * stride, xv[u]);
   }
+  for (; i < total4; i += stride) one(i, reinterpret_cast<const float4*>(x)[i]);
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat))
@@ -191,23 +231,37 @@ __global__ __launch_bounds__(BLK) void in_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ s1, const float* __restrict__ s2,
                                                            float* __restrict__ dx, int64_t V, int C, int64_t total4) {
   const int G = C >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
-    const int g = (int)(i % G);
-    const int64_t b = (i / G) / V;
-    const float4 xv = reinterpret_cast<const float4*>(x)[i];
-    const float4 gv = reinterpret_cast<const float4*>(dy)[i];
+  const bool small = total4 < (1ll << 31) && V < (1ll << 31);
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  auto one = [&](int64_t i, const float4 xv, const float4 gv) {
+    int g, b;
+    in_elem(i, G, V, small, g, b);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
     float o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int bc = (int)b * C + g * 4 + c;
+      const int bc = b * C + g * 4 + c;
       const float r = rstd[bc];
       const float xh = (xs[c] - mean[bc]) * r;
       const float gg = gs[c] * (xh > 0.f ? 1.f : LRELU_SLOPE);
       o[c] = r * (gg - s1[bc] - xh * s2[bc]);
     }
     reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  };
+  constexpr int ILP = 2;       // two tensors are read: 4 float4 loads in flight per thread
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  for (; i + (ILP - 1) * stride < total4; i += ILP * stride) {
+    float4 xv[ILP], gv[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+      xv[u] = reinterpret_cast<const float4*>(x)[i + u * stride];
+      gv[u] = reinterpret_cast<const float4*>(dy)[i + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) one(i + u * stride, xv[u], gv[u]);
   }
+  for (; i < total4; i += stride)
+    one(i, reinterpret_cast<const float4*>(x)[i], reinterpret_cast<const float4*>(dy)[i]);
 }
 
 __global__ __launch_bounds__(BLK) void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
