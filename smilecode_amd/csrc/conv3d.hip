@@ -1101,14 +1101,20 @@ __global__ __launch_bounds__(NTHR) void conv_c1_march_kernel(const C1Args a) {
   // the four couts travel as two float PAIRS: 54 v_pk_fma_f32 per voxel instead of 108 v_fma_f32 (the kernel was VALU-bound)
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 wv[27][2], bv[2];
+  {
+    // (4, 1, 27): wave-uniform reads, pinned into VECTOR registers (left to itself the compiler keeps 108 SGPRs and spills
+    // them).  All 108 loads are issued before the first pin: pinned one by one, each load was followed by its own
+    // s_waitcnt vmcnt(0) -- 108 memory round trips in series at the head of every workgroup.
+    float tw[108];
 #pragma unroll
-  for (int tp = 0; tp < 27; ++tp)
+    for (int i = 0; i < 108; ++i) tw[i] = a.w[i];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float t_ = a.w[c * 27 + tp];                                           // (4, 1, 27): wave-uniform reads ...
-      asm volatile("" : "+v"(t_));                                           // ... pinned into VECTOR registers: left to itself
-      wv[tp][c >> 1][c & 1] = t_;                                            // the compiler keeps 108 SGPRs and spills them
-    }
+    for (int i = 0; i < 108; ++i) asm volatile("" : "+v"(tw[i]));
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wv[tp][c >> 1][c & 1] = tw[c * 27 + tp];
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) bv[c >> 1][c & 1] = a.bias ? a.bias[c] : 0.f;
   // staging: halo voxel v = tid (and 256 + tid for the first C1HV - 256 threads); byte offsets inside a plane

@@ -21,6 +21,15 @@ constexpr float WINSZ = 729.f;
 
 struct Dims { int B, D, H, W; };
 
+// 32-bit form: a 64-bit division by a run-time value is a ~100-instruction software routine (three of them made
+// grad3d_kernel VALU-bound: 14.7 M elements x ~350 instructions)
+__device__ __forceinline__ void decode32(unsigned i, const Dims d, int& z, int& y, int& x) {
+  const unsigned t = i / (unsigned)d.W;
+  x = (int)(i - t * (unsigned)d.W);
+  const unsigned u = t / (unsigned)d.H;
+  y = (int)(t - u * (unsigned)d.H);
+  z = (int)(u % (unsigned)d.D);
+}
 __device__ __forceinline__ void decode(int64_t i, const Dims d, int& z, int& y, int& x) {
   x = (int)(i % d.W);
   const int64_t t = i / d.W;
@@ -310,9 +319,11 @@ __global__ __launch_bounds__(BLK) void grad3d_kernel(const float* __restrict__ f
   __shared__ float red[BLK / 64];
   const int64_t sD = (int64_t)d.H * d.W, sH = d.W;
   float lsum = 0.f;
+  const bool small = N < (1ll << 31);
   for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
     int z, y, x;
-    decode(i, d, z, y, x);
+    if (small) decode32((unsigned)i, d, z, y, x);
+    else decode(i, d, z, y, x);
     const float v = f[i];
     float g = 0.f;
     // pen(t) = t^2 (l2) or |t| (l1); dpen(t) = t (the factor 2 is applied at the end) or sign(t)

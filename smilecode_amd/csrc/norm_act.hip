@@ -280,13 +280,25 @@ __global__ __launch_bounds__(BLK) void scale_kernel(const float* __restrict__ x,
 __global__ __launch_bounds__(BLK) void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int D,
                                                            int H, int W, int C, int64_t total4) {
   const int G = C >> 2, d = D / 2, h = H / 2, w = W / 2;
+  const bool small = total4 < (1ll << 31);
   for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
-    const int g = (int)(i % G);
-    int64_t t = i / G;
-    const int xo = (int)(t % w); t /= w;
-    const int yo = (int)(t % h); t /= h;
-    const int zo = (int)(t % d);
-    const int64_t b = t / d;
+    int g, xo, yo, zo;
+    int64_t b;
+    if (small) {                 // 32-bit index arithmetic (64-bit div/mod: ~100 instructions each, five per element)
+      unsigned t = (unsigned)i, q = t / (unsigned)G;
+      g = (int)(t - q * (unsigned)G); t = q;
+      q = t / (unsigned)w; xo = (int)(t - q * (unsigned)w); t = q;
+      q = t / (unsigned)h; yo = (int)(t - q * (unsigned)h); t = q;
+      q = t / (unsigned)d; zo = (int)(t - q * (unsigned)d);
+      b = q;
+    } else {
+      g = (int)(i % G);
+      int64_t t = i / G;
+      xo = (int)(t % w); t /= w;
+      yo = (int)(t % h); t /= h;
+      zo = (int)(t % d);
+      b = t / d;
+    }
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz)
@@ -309,13 +321,25 @@ __global__ __launch_bounds__(BLK) void avgpool2_bwd_kernel(const float* __restri
                                                            float* __restrict__ dx, int D, int H, int W, int C,
                                                            int64_t total4) {
   const int G = C >> 2, h = H / 2, w = W / 2, d = D / 2;
+  const bool small = total4 < (1ll << 31);
   for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
-    const int g = (int)(i % G);
-    int64_t t = i / G;
-    const int xi = (int)(t % W); t /= W;
-    const int yi = (int)(t % H); t /= H;
-    const int zi = (int)(t % D);
-    const int64_t b = t / D;
+    int g, xi, yi, zi;
+    int64_t b;
+    if (small) {
+      unsigned t = (unsigned)i, q = t / (unsigned)G;
+      g = (int)(t - q * (unsigned)G); t = q;
+      q = t / (unsigned)W; xi = (int)(t - q * (unsigned)W); t = q;
+      q = t / (unsigned)H; yi = (int)(t - q * (unsigned)H); t = q;
+      q = t / (unsigned)D; zi = (int)(t - q * (unsigned)D);
+      b = q;
+    } else {
+      g = (int)(i % G);
+      int64_t t = i / G;
+      xi = (int)(t % W); t /= W;
+      yi = (int)(t % H); t /= H;
+      zi = (int)(t % D);
+      b = t / D;
+    }
     const int64_t off = (((b * d + zi / 2) * h + yi / 2) * w + xi / 2) * C + g * 4;
     float4 v = *reinterpret_cast<const float4*>(dy + off);
     v.x *= 0.125f; v.y *= 0.125f; v.z *= 0.125f; v.w *= 0.125f;

@@ -411,13 +411,28 @@ __global__ __launch_bounds__(BLK) void upsample2_fwd_kernel(const float* __restr
   const int D = 2 * d, H = 2 * h, W = 2 * w;
   const float rz = up_ratio(d), ry = up_ratio(h), rx = up_ratio(w);
   const int64_t Vo = (int64_t)D * H * W, Vi = (int64_t)d * h * w;
+  const bool small = total < (1ll << 31) && Vo < (1ll << 31);
   for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
-    const int g = (int)(idx % G);
-    const int64_t n = idx / G;
-    const int64_t b = n / Vo, v = n - b * Vo;
-    const int xo = (int)(v % W);
-    const int64_t t2 = v / W;
-    const int yo = (int)(t2 % H), zo = (int)(t2 / H);
+    int g, xo, yo, zo;
+    int64_t n, b;
+    if (small) {               // 32-bit index arithmetic: 64-bit div/mod are ~100-instruction software routines
+      const unsigned u = (unsigned)idx, un = u / (unsigned)G;
+      g = (int)(u - un * (unsigned)G);
+      const unsigned ub = un / (unsigned)Vo, uv = un - ub * (unsigned)Vo;
+      const unsigned t2 = uv / (unsigned)W;
+      xo = (int)(uv - t2 * (unsigned)W);
+      zo = (int)(t2 / (unsigned)H);
+      yo = (int)(t2 - (unsigned)zo * (unsigned)H);
+      n = un; b = ub;
+    } else {
+      g = (int)(idx % G);
+      n = idx / G;
+      b = n / Vo;
+      const int64_t v = n - b * Vo;
+      xo = (int)(v % W);
+      const int64_t t2 = v / W;
+      yo = (int)(t2 % H); zo = (int)(t2 / H);
+    }
     const Lin lz = lin_src(zo, rz, d), ly = lin_src(yo, ry, h), lx = lin_src(xo, rx, w);
     const float* xb = x + b * Vi * C + g * CPT;
     float acc[CPT];
