@@ -204,25 +204,35 @@ __global__ __launch_bounds__(BLK) void in_apply_kernel(const float* __restrict__
   const int G = C >> 2;
   const bool small = total4 < (1ll << 31) && V < (1ll << 31);
   const int64_t stride = (int64_t)gridDim.x * BLK;
-  auto one = [&](int64_t i, const float4 xv) {
-    int g, b;
-    in_elem(i, G, V, small, g, b);
-    const float4 m = *reinterpret_cast<const float4*>(mean + b * C + g * 4);
-    const float4 r = *reinterpret_cast<const float4*>(rstd + b * C + g * 4);
+  auto one = [&](int64_t i, const float4 xv, const float4 m, const float4 r) {
     float4 o;
     o.x = lrelu((xv.x - m.x) * r.x); o.y = lrelu((xv.y - m.y) * r.y);
     o.z = lrelu((xv.z - m.z) * r.z); o.w = lrelu((xv.w - m.w) * r.w);
     reinterpret_cast<float4*>(y)[i] = o;
   };
+  auto cidx = [&](int64_t i) { int g, b; in_elem(i, G, V, small, g, b); return b * C + g * 4; };
   int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
   for (; i + (IN_ILP - 1) * stride < total4; i += IN_ILP * stride) {
-    float4 xv[IN_ILP];
+    float4 xv[IN_ILP], m[IN_ILP], r[IN_ILP];
 #pragma unroll
     for (int u = 0; u < IN_ILP; ++u) xv[u] = reinterpret_cast<const float4*>(x)[i + u * stride];
 #pragma unroll
-    for (int u = 0; u < IN_ILP; ++u) one(i + u * stride, xv[u]);
+    for (int u = 0; u < IN_ILP; ++u) {
+      const int ci = cidx(i + u * stride);
+      m[u] = *reinterpret_cast<const float4*>(mean + ci);
+      r[u] = *reinterpret_cast<const float4*>(rstd + ci);
+    }
+    // every load of the trip in flight before the first use (hipcc otherwise waits per element for its mean / rstd)
+#pragma unroll
+    for (int u = 0; u < IN_ILP; ++u) asm volatile("" : "+v"(m[u].x), "+v"(r[u].x), "+v"(xv[u].x));
+#pragma unroll
+    for (int u = 0; u < IN_ILP; ++u) one(i + u * stride, xv[u], m[u], r[u]);
   }
-  for (; i < total4; i += stride) one(i, reinterpret_cast<const float4*>(x)[i]);
+  for (; i < total4; i += stride) {
+    const int ci = cidx(i);
+    one(i, reinterpret_cast<const float4*>(x)[i], *reinterpret_cast<const float4*>(mean + ci),
+        *reinterpret_cast<const float4*>(rstd + ci));
+  }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat))
@@ -233,35 +243,49 @@ __global__ __launch_bounds__(BLK) void in_bwd_apply_kernel(const float* __restri
   const int G = C >> 2;
   const bool small = total4 < (1ll << 31) && V < (1ll << 31);
   const int64_t stride = (int64_t)gridDim.x * BLK;
-  auto one = [&](int64_t i, const float4 xv, const float4 gv) {
-    int g, b;
-    in_elem(i, G, V, small, g, b);
+  auto one = [&](int64_t i, const float4 xv, const float4 gv, const float4 m4, const float4 r4, const float4 a4,
+                 const float4 b4) {
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float ms[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
+    const float s1v[4] = {a4.x, a4.y, a4.z, a4.w}, s2v[4] = {b4.x, b4.y, b4.z, b4.w};
     float o[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int bc = b * C + g * 4 + c;
-      const float r = rstd[bc];
-      const float xh = (xs[c] - mean[bc]) * r;
+      const float r = rs[c];
+      const float xh = (xs[c] - ms[c]) * r;
       const float gg = gs[c] * (xh > 0.f ? 1.f : LRELU_SLOPE);
-      o[c] = r * (gg - s1[bc] - xh * s2[bc]);
+      o[c] = r * (gg - s1v[c] - xh * s2v[c]);
     }
     reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   };
+  auto cidx = [&](int64_t i) { int g, b; in_elem(i, G, V, small, g, b); return b * C + g * 4; };
   constexpr int ILP = 2;       // two tensors are read: 4 float4 loads in flight per thread
   int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
   for (; i + (ILP - 1) * stride < total4; i += ILP * stride) {
-    float4 xv[ILP], gv[ILP];
+    float4 xv[ILP], gv[ILP], m4[ILP], r4[ILP], a4[ILP], b4[ILP];
 #pragma unroll
     for (int u = 0; u < ILP; ++u) {
       xv[u] = reinterpret_cast<const float4*>(x)[i + u * stride];
       gv[u] = reinterpret_cast<const float4*>(dy)[i + u * stride];
     }
 #pragma unroll
-    for (int u = 0; u < ILP; ++u) one(i + u * stride, xv[u], gv[u]);
+    for (int u = 0; u < ILP; ++u) {
+      const int ci = cidx(i + u * stride);                 // 4 channels of one sample: contiguous in all four arrays
+      m4[u] = *reinterpret_cast<const float4*>(mean + ci); r4[u] = *reinterpret_cast<const float4*>(rstd + ci);
+      a4[u] = *reinterpret_cast<const float4*>(s1 + ci);   b4[u] = *reinterpret_cast<const float4*>(s2 + ci);
+    }
+#pragma unroll
+    for (int u = 0; u < ILP; ++u)
+      asm volatile("" : "+v"(xv[u].x), "+v"(gv[u].x), "+v"(m4[u].x), "+v"(r4[u].x), "+v"(a4[u].x), "+v"(b4[u].x));
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) one(i + u * stride, xv[u], gv[u], m4[u], r4[u], a4[u], b4[u]);
   }
-  for (; i < total4; i += stride)
-    one(i, reinterpret_cast<const float4*>(x)[i], reinterpret_cast<const float4*>(dy)[i]);
+  for (; i < total4; i += stride) {
+    const int ci = cidx(i);
+    one(i, reinterpret_cast<const float4*>(x)[i], reinterpret_cast<const float4*>(dy)[i],
+        *reinterpret_cast<const float4*>(mean + ci), *reinterpret_cast<const float4*>(rstd + ci),
+        *reinterpret_cast<const float4*>(s1 + ci), *reinterpret_cast<const float4*>(s2 + ci));
+  }
 }
 
 __global__ __launch_bounds__(BLK) void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -342,11 +366,11 @@ __global__ __launch_bounds__(BLK) void avgpool2_bwd_kernel(const float* __restri
     }
     const int64_t off = (((b * d + zi / 2) * h + yi / 2) * w + xi / 2) * C + g * 4;
     float4 v = *reinterpret_cast<const float4*>(dy + off);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (addend) a = reinterpret_cast<const float4*>(addend)[i];              // (uniform) both loads in flight together
+    asm volatile("" : "+v"(v.x), "+v"(a.x));
     v.x *= 0.125f; v.y *= 0.125f; v.z *= 0.125f; v.w *= 0.125f;
-    if (addend) {
-      const float4 a = reinterpret_cast<const float4*>(addend)[i];
-      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-    }
+    if (addend) { v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
     reinterpret_cast<float4*>(dx)[i] = v;
   }
 }
