@@ -754,14 +754,35 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
   const int by = tl / ng, grp = tl - by * ng;
   const float* pp = part + (int64_t)tl * 256 + quarter * 64 + lane;
   const int64_t st = (int64_t)gy * ng * 256;
-  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int bx = ph;
-  for (; bx + 28 < gx; bx += 32) {
+  // The long jobs (512-1024 partial rows, 10-28 tiles) are chains of dependent batches: sixteen rows in flight per wave,
+  // every batch fenced so that its loads are issued together (the tail too: it was one load -> wait -> add per row).
+  double a[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += (double)pp[(int64_t)(bx + 4 * u) * st];
+  for (int u = 0; u < 16; ++u) a[u] = 0.0;
+  int bx = ph;
+  for (; bx + 60 < gx; bx += 64) {
+    float r[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) r[u] = pp[(int64_t)(bx + 4 * u) * st];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(r[u]));
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] += (double)r[u];
   }
-  for (int u = 0; bx < gx; bx += 4, ++u) a[u & 7] += (double)pp[(int64_t)bx * st];
-  double v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  {
+    float r[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int b2 = bx + 4 * u;
+      r[u] = pp[(int64_t)(b2 < gx ? b2 : 0) * st];               // row 0 always exists
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(r[u]));
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] += bx + 4 * u < gx ? (double)r[u] : 0.0;
+  }
+  double v = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+             (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
   if (ph > 0) sm[ph - 1][lane] = v;
   __syncthreads();
   if (ph > 0) return;
