@@ -1240,7 +1240,9 @@ __global__ __launch_bounds__(NTHR) void conv_c1_wgrad_mfma_kernel(const float* _
   // register prefetch of the next tile (x: C1_HVOX scalars, d_y: one float4 per voxel) under the MFMA loop
   constexpr int NXS = (C1_HVOX + NTHR - 1) / NTHR, NDS = C1_ROWS * TX / NTHR;
   float xr[NXS];
-  float4 dr[NDS];
+  bool xin[NXS];
+  float4 dr[NDS], yr[NDS];
+  bool din[NDS];
   auto load_tile = [&](int tl) {
     int t = tl;
     const int x0 = (t % tiles_x) * TX; t /= tiles_x;
@@ -1252,25 +1254,21 @@ __global__ __launch_bounds__(NTHR) void conv_c1_wgrad_mfma_kernel(const float* _
       const int i = tid + k * NTHR;
       const int hx = i % HX, r = i / HX;
       const int z = z0 + r / WG_HY - 1, yy = y0 + r % WG_HY - 1, xx = x0 + hx - 1;
-      xr[k] = (i < C1_HVOX && z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
-                  ? x[vb + ((int64_t)z * H + yy) * W + xx] : 0.f;
+      xin[k] = i < C1_HVOX && z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      xr[k] = x[xin[k] ? vb + ((int64_t)z * H + yy) * W + xx : 0];          // raw; zero padding applied at the LDS write
     }
 #pragma unroll
     for (int k = 0; k < NDS; ++k) {
       const int i = tid + k * NTHR;
       const int vx = i % TX, row = i / TX;
       const int z = z0 + row / WG_TY, yy = y0 + row % WG_TY, xx = x0 + vx;
-      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (z < D && yy < H && xx < W) {
-        const int64_t o = (vb + ((int64_t)z * H + yy) * W + xx) * 4;
-        gv = *reinterpret_cast<const float4*>(dy + o);
-        if (yact) {
-          const float4 yv = *reinterpret_cast<const float4*>(yact + o);
-          gv.x *= yv.x > 0.f ? 1.f : LRELU_SLOPE; gv.y *= yv.y > 0.f ? 1.f : LRELU_SLOPE;
-          gv.z *= yv.z > 0.f ? 1.f : LRELU_SLOPE; gv.w *= yv.w > 0.f ? 1.f : LRELU_SLOPE;
-        }
-      }
-      dr[k] = gv;
+      // raw loads only (clamped address, the predicate is applied when the tile is written to LDS): forming
+      // d_y * LeakyReLU'(y) here made the PREFETCH wait for both loads in front of the MFMA loop it should hide under
+      const bool in = z < D && yy < H && xx < W;
+      const int64_t o = in ? (vb + ((int64_t)z * H + yy) * W + xx) * 4 : 0;
+      dr[k] = *reinterpret_cast<const float4*>(dy + o);
+      if (yact) yr[k] = *reinterpret_cast<const float4*>(yact + o);          // (uniform)
+      din[k] = in;
     }
   };
   int tile = blockIdx.x;
@@ -1280,10 +1278,18 @@ __global__ __launch_bounds__(NTHR) void conv_c1_wgrad_mfma_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < NXS; ++k) {
       const int i = tid + k * NTHR;
-      if (i < C1_HVOX) xs[i] = xr[k];
+      if (i < C1_HVOX) xs[i] = xin[k] ? xr[k] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < NDS; ++k) *reinterpret_cast<float4*>(dys + (tid + k * NTHR) * 4) = dr[k];
+    for (int k = 0; k < NDS; ++k) {
+      float4 gv = dr[k];
+      if (yact) {
+        gv.x *= yr[k].x > 0.f ? 1.f : LRELU_SLOPE; gv.y *= yr[k].y > 0.f ? 1.f : LRELU_SLOPE;
+        gv.z *= yr[k].z > 0.f ? 1.f : LRELU_SLOPE; gv.w *= yr[k].w > 0.f ? 1.f : LRELU_SLOPE;
+      }
+      if (!din[k]) gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(dys + (tid + k * NTHR) * 4) = gv;
+    }
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
     __builtin_amdgcn_s_setprio(1);
