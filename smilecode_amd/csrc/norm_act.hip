@@ -423,6 +423,33 @@ __device__ __forceinline__ void store8(void* base, int64_t i8, const float (&f)[
   }
 }
 
+// raw form of load8: the load(s) only, so that several elements' loads can be issued (and fenced) before the first unpack
+struct Raw8 { uint4 a, b; };
+template <bool BF>
+__device__ __forceinline__ Raw8 load8_raw(const void* base, int64_t i8) {
+  Raw8 r;
+  if (BF) { r.a = reinterpret_cast<const uint4*>(base)[i8]; r.b = make_uint4(0u, 0u, 0u, 0u); }
+  else { r.a = reinterpret_cast<const uint4*>(base)[2 * i8]; r.b = reinterpret_cast<const uint4*>(base)[2 * i8 + 1]; }
+  return r;
+}
+template <bool BF>
+__device__ __forceinline__ void raw8_fence(Raw8& r) {
+  if (BF) asm volatile("" : "+v"(r.a.x)); else asm volatile("" : "+v"(r.a.x), "+v"(r.b.x));
+}
+template <bool BF>
+__device__ __forceinline__ void unpack8(const Raw8& r, float (&f)[8]) {
+  if (BF) {
+    bf_unpack8(r.a, f);
+  } else {
+    f[0] = __uint_as_float(r.a.x); f[1] = __uint_as_float(r.a.y); f[2] = __uint_as_float(r.a.z); f[3] = __uint_as_float(r.a.w);
+    f[4] = __uint_as_float(r.b.x); f[5] = __uint_as_float(r.b.y); f[6] = __uint_as_float(r.b.z); f[7] = __uint_as_float(r.b.w);
+  }
+}
+__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
 // voxels per partial-sum workgroup: 16 passes (twice the workgroups of the fp32 kernel per byte: a pass moves half the bytes)
 static inline int in_chunk8(int C) { return C >= 8 ? (BLK / (C >> 3)) * 16 : BLK * 16; }   // C % 8 != 0 is refused by the callers
 
@@ -431,15 +458,30 @@ __global__ __launch_bounds__(BLK) void in_apply_bf16_kernel(const void* __restri
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             int64_t V, int C, int64_t total8) {
   const int G = C >> 3;
-  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total8; i += (int64_t)gridDim.x * BLK) {
-    const int g = (int)(i % G);
-    const int64_t b = (i / G) / V;
-    float xv[8], o[8];
-    load8<true>(x, i, xv);
+  const bool small = total8 < (1ll << 31) && V < (1ll << 31);
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  auto one = [&](int64_t i, const Raw8& rx) {
+    int g, b;
+    in_elem(i, G, V, small, g, b);
+    float xv[8], o[8], m[8], r[8];
+    unpack8<true>(rx, xv);
+    ld8f(mean + b * C + g * 8, m);
+    ld8f(rstd + b * C + g * 8, r);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = lrelu((xv[c] - mean[b * C + g * 8 + c]) * rstd[b * C + g * 8 + c]);
+    for (int c = 0; c < 8; ++c) o[c] = lrelu((xv[c] - m[c]) * r[c]);
     store8<OUT_BF>(y, i, o);
+  };
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  for (; i + (IN_ILP - 1) * stride < total8; i += IN_ILP * stride) {      // IN_ILP loads in flight per thread
+    Raw8 rx[IN_ILP];
+#pragma unroll
+    for (int u = 0; u < IN_ILP; ++u) rx[u] = load8_raw<true>(x, i + u * stride);
+#pragma unroll
+    for (int u = 0; u < IN_ILP; ++u) raw8_fence<true>(rx[u]);
+#pragma unroll
+    for (int u = 0; u < IN_ILP; ++u) one(i + u * stride, rx[u]);
   }
+  for (; i < total8; i += stride) one(i, load8_raw<true>(x, i));
 }
 
 // (sum g, sum g*xhat), g = dy * lrelu'(xhat); x is the bf16 raw conv output
@@ -524,22 +566,37 @@ __global__ __launch_bounds__(BLK) void in_bwd_apply_bf16_kernel(const void* __re
                                                                 const float* __restrict__ s1, const float* __restrict__ s2,
                                                                 void* __restrict__ dx, int64_t V, int C, int64_t total8) {
   const int G = C >> 3;
-  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total8; i += (int64_t)gridDim.x * BLK) {
-    const int g = (int)(i % G);
-    const int64_t b = (i / G) / V;
-    float xs[8], gs[8], o[8];
-    load8<true>(x, i, xs);
-    load8<DY_BF>(dy, i, gs);
+  const bool small = total8 < (1ll << 31) && V < (1ll << 31);
+  const int64_t stride = (int64_t)gridDim.x * BLK;
+  auto one = [&](int64_t i, const Raw8& rx, const Raw8& rg) {
+    int g, b;
+    in_elem(i, G, V, small, g, b);
+    const int bc0 = b * C + g * 8;
+    float xs[8], gs[8], o[8], m[8], rs[8], a1[8], a2[8];
+    unpack8<true>(rx, xs);
+    unpack8<DY_BF>(rg, gs);
+    ld8f(mean + bc0, m); ld8f(rstd + bc0, rs); ld8f(s1 + bc0, a1); ld8f(s2 + bc0, a2);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const int bc = (int)b * C + g * 8 + c;
-      const float r = rstd[bc];
-      const float xh = (xs[c] - mean[bc]) * r;
+      const float r = rs[c];
+      const float xh = (xs[c] - m[c]) * r;
       const float gg = gs[c] * (xh > 0.f ? 1.f : LRELU_SLOPE);
-      o[c] = r * (gg - s1[bc] - xh * s2[bc]);
+      o[c] = r * (gg - a1[c] - xh * a2[c]);
     }
     store8<true>(dx, i, o);
+  };
+  constexpr int ILP = 2;
+  int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+  for (; i + (ILP - 1) * stride < total8; i += ILP * stride) {
+    Raw8 rx[ILP], rg[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) { rx[u] = load8_raw<true>(x, i + u * stride); rg[u] = load8_raw<DY_BF>(dy, i + u * stride); }
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) { raw8_fence<true>(rx[u]); raw8_fence<DY_BF>(rg[u]); }
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) one(i + u * stride, rx[u], rg[u]);
   }
+  for (; i < total8; i += stride) one(i, load8_raw<true>(x, i), load8_raw<DY_BF>(dy, i));
 }
 
 template <bool TO_BF>
