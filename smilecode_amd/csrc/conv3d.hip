@@ -123,13 +123,33 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(const float* __restrict
   const int b = item / Cout, co = item - b * Cout;
   const int z = D > 1 ? 1 : 0, y = H > 1 ? 1 : 0, xx = W > 1 ? 1 : 0;
   float acc = 0.f;
-  for (int i = lane; i < 27 * Cin; i += 64) {
-    const int tap = i / Cin, c = i - tap * Cin;
-    const int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xq = xx + tap % 3 - 1;
-    if (zz < 0 || zz >= D || yy < 0 || yy >= H || xq < 0 || xq >= W) continue;
-    float v = x[((((int64_t)b * D + zz) * H + yy) * W + xq) * Cin + c];
-    if (in_mean) v = lrelu((v - in_mean[b * Cin + c]) * in_rstd[b * Cin + c]);
-    acc = fmaf(v, w[((int64_t)co * Cin + c) * 27 + tap], acc);
+  const int n = 27 * Cin;
+  const float* xb = x + (int64_t)b * D * H * W * Cin;
+  // four (tap, cin) items per lane and trip, their loads issued together (clamped addresses, fenced): this launch is a chain of
+  // dependent round trips in front of every statistics conv -- one load per `continue` test made it ~10 us for ~nothing
+  for (int i0 = lane; i0 < n; i0 += 256) {
+    float xv[4], wv[4], mv[4], rv[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 64 * u;
+      const int ii = i < n ? i : 0;
+      const int tap = ii / Cin, c = ii - tap * Cin;
+      const int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xq = xx + tap % 3 - 1;
+      ok[u] = i < n && zz >= 0 && zz < D && yy >= 0 && yy < H && xq >= 0 && xq < W;
+      xv[u] = xb[ok[u] ? (((int64_t)zz * H + yy) * W + xq) * Cin + c : 0];
+      wv[u] = w[((int64_t)co * Cin + c) * 27 + tap];
+      mv[u] = in_mean ? in_mean[b * Cin + c] : 0.f;
+      rv[u] = in_mean ? in_rstd[b * Cin + c] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(xv[u]), "+v"(wv[u]), "+v"(mv[u]), "+v"(rv[u]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v = xv[u];
+      if (in_mean) v = lrelu((v - mv[u]) * rv[u]);
+      if (ok[u]) acc = fmaf(v, wv[u], acc);
+    }
   }
   acc = wave_sum(acc);
   if (lane == 0) shift[item] = acc + (bias ? bias[co] : 0.f);

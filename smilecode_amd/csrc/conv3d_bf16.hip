@@ -136,13 +136,31 @@ __global__ __launch_bounds__(256) void conv_shift_bf16_kernel(const void* __rest
   const int b = item / Cout, co = item - b * Cout;
   const int z = D > 1 ? 1 : 0, y = H > 1 ? 1 : 0, xx = W > 1 ? 1 : 0;
   float acc = 0.f;
-  for (int i = lane; i < 27 * Cin; i += 64) {
-    const int tap = i / Cin, c = i - tap * Cin;
-    const int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xq = xx + tap % 3 - 1;
-    if (zz < 0 || zz >= D || yy < 0 || yy >= H || xq < 0 || xq >= W) continue;
-    const int64_t off = ((((int64_t)b * D + zz) * H + yy) * W + xq) * Cin + c;
-    const float v = IN_BF16 ? bf16_to_f32(((const unsigned short*)xv)[off]) : ((const float*)xv)[off];
-    acc = fmaf(v, w[((int64_t)co * Cin + c) * 27 + tap], acc);
+  const int n = 27 * Cin;
+  const int64_t xb = (int64_t)b * D * H * W * Cin;
+  // four (tap, cin) items per lane and trip with their loads in flight together (see conv_shift_kernel in conv3d.hip)
+  for (int i0 = lane; i0 < n; i0 += 256) {
+    unsigned xr[4];
+    float wv[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 64 * u;
+      const int ii = i < n ? i : 0;
+      const int tap = ii / Cin, c = ii - tap * Cin;
+      const int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xq = xx + tap % 3 - 1;
+      ok[u] = i < n && zz >= 0 && zz < D && yy >= 0 && yy < H && xq >= 0 && xq < W;
+      const int64_t off = xb + (ok[u] ? (((int64_t)zz * H + yy) * W + xq) * Cin + c : 0);
+      xr[u] = IN_BF16 ? (unsigned)((const unsigned short*)xv)[off] : __float_as_uint(((const float*)xv)[off]);    // raw
+      wv[u] = w[((int64_t)co * Cin + c) * 27 + tap];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(xr[u]), "+v"(wv[u]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float v = IN_BF16 ? bf16_to_f32((unsigned short)xr[u]) : __uint_as_float(xr[u]);
+      if (ok[u]) acc = fmaf(v, wv[u], acc);
+    }
   }
   acc = wave_sum(acc);
   if (lane == 0) shift[item] = acc + (bias ? bias[co] : 0.f);
