@@ -1550,6 +1550,9 @@ inline WgPlan plan_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   WgPlan p;
   p.np = Cin > 4 && Cin <= 8 && Cout <= 8;   // N-packed kernel (Cin <= 4 already fills M with 4 taps: no gain there)
   p.cit = Cin <= 4 ? 4 : (Cin <= 8 ? 8 : 16);
+  // channel counts that are not multiples of 16 (the CWM layers: 12, 24): the largest tile that divides Cin wastes no M rows
+  // (Cin = 12 as three 4-channel tiles: 21 row tiles instead of 28 with 12 of 16 rows used; Cin = 24 as three 8-channel tiles)
+  if (Cin > 8 && Cin % 16 != 0) p.cit = Cin % 8 == 0 ? 8 : (Cin % 4 == 0 ? 4 : 16);
   p.n_ci = p.np ? 1 : cdiv(Cin, p.cit);
   p.n_co = p.np ? 1 : cdiv(Cout, 16);
   p.gy = p.n_ci * p.n_co;
