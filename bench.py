@@ -39,7 +39,7 @@ def log(*a):
 
 def family(tag):
     """launch tag -> kernel family (= the kernel symbol rocprof reports, template arguments stripped).  The conv tags carry
-    the family the library picked for that shape (ops._conv_tag): @x3 = z-marching bf16x3, @split = tiled bf16x3."""
+    the family the library picked for that shape (ops._conv_tag): @x3 = z-marching bf16x3, @split = tiled bf16x3, @direct = the small-volume direct MFMA kernel."""
     base = tag.split("[")[0]
     if tag.startswith("conv_fwd[1->"):
         return "conv_c1_fwd_kernel"
@@ -50,6 +50,8 @@ def family(tag):
     if base == "conv_bf16_wgrad":
         return "conv_x3_wgrad_kernel<NPC=1>" if tag.endswith("@x3") else "conv3d_bf16_wgrad_kernel"
     if base in ("conv_fwd", "conv_dgrad"):
+        if tag.endswith("@direct"):
+            return "conv_direct_kernel"
         return "conv_x3_kernel" if tag.endswith("@x3") else ("conv3d_bf16_kernel<SP=3>" if tag.endswith("@split") else "conv3d_mfma_kernel")
     if base == "conv_wgrad":
         return "conv_x3_wgrad_kernel" if tag.endswith("@x3") else "conv3d_wgrad_kernel"
@@ -63,7 +65,7 @@ def family(tag):
 # fp32-accurate matrix work on the bf16 pipe costs six bf16 MFMAs per fp32 product (csrc/conv3d_x3.hip): its ceiling in
 # algorithmic (fp32) FLOP/s is the dense bf16 peak / 6
 PEAK_MFMA_BF16_TFLOPS = 2500.0
-MFMA_F32_FAMILIES = ("conv3d_mfma_kernel", "conv3d_wgrad_kernel", "conv_c1_wgrad_mfma_kernel")
+MFMA_F32_FAMILIES = ("conv3d_mfma_kernel", "conv3d_wgrad_kernel", "conv_c1_wgrad_mfma_kernel", "conv_direct_kernel")
 MFMA_X3_FAMILIES = ("conv_x3_kernel", "conv_x3_wgrad_kernel", "conv3d_bf16_kernel<SP=3>")
 
 

@@ -110,8 +110,12 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
  *   1 = "bf16x3" fp32 emulation, tiled: fp32 tensors, every operand split into three bf16 pieces, every product as six
  *       exact piece products on the bf16 matrix pipe, error <= 3 * 2^-24 |a b|                  conv3d_bf16.hip (SP = 3)
  *   2 = the same arithmetic as a z-marching kernel for the few-channel full-resolution layers   conv3d_x3.hip
+ *   3 = exact-f32 MFMA straight from global memory for volumes of <= 16 k voxels (pyramid level 5, the CWM layers at
+ *       level-4 resolution): one wave per 16 voxels x 16/32 output channels, no LDS (plain forward / dgrad launches only;
+ *       launches with fused statistics, a lazily normalised input or an activation run family 0)   conv3d.hip (conv_direct_kernel)
  * Families 1 and 2 produce the fused InstanceNorm statistics (modet_conv3d_fwd_stats) at no cost for every Cout.
- * Env (read at first use): MODET_CONV_X3=0 disables family 2, MODET_CONV_SPLIT=0 / 1 disables / forces family 1. */
+ * Env (read at first use): MODET_CONV_X3=0 disables family 2, MODET_CONV_SPLIT=0 / 1 disables / forces family 1,
+ * MODET_CONV_DIRECT=0 disables family 3. */
 int modet_conv3d_kernel_family(int B, int D, int H, int W, int Cin, int Cout, int pass);
 size_t modet_conv3d_ws_bytes(int Cin, int Cout);
 /* `step` (every conv entry point that packs weights): NULL, or the context whose recorded packing jobs apply, see

@@ -41,11 +41,33 @@ __host__ __device__ constexpr int pad16mod32(int n) { return ((n - 16 + 31) / 32
 // Row packing P (= 16/CoP output rows share one 16-wide MFMA N tile when Cout <= CoP = 16/P):
 //   tapP = (dz*(P+2) + dyp)*3 + dx with dyp = p + dy in [0, P+2);  column n = p*CoP + co holds
 //   W((dz, dyp-p, dx); c -> co) when 0 <= dyp-p <= 2, else 0.   P = 1 is the plain layout.
+// Layout of conv_direct_kernel (pack modes 2 / 3 = forward / dgrad, P = 1; CinP, CoutP multiples of 16):
+//   wpk[tap][cs][ct][k][n][j] = W(tap; c = cs*16 + 4k + j -> co = ct*16 + n)        (k, j in 0..3, n in 0..15)
+// i.e. one 1 KB block per (tap, 16 input channels, 16 output channels) in which lane (k, n) of a wave finds the B operands of
+// four consecutive MFMAs as ONE float4 (the K order inside a block is a permutation the A operand follows).
+__device__ __forceinline__ void pack_direct(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int CinP,
+                                            int CoutP, int dgrad) {
+  const int CS = CinP / 16, CT = CoutP / 16;
+  const int total = 27 * CinP * CoutP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 3, n = (i >> 2) & 15, k = (i >> 6) & 3;
+    int t = i >> 8;
+    const int ct = t % CT; t /= CT;
+    const int cs = t % CS, tap = t / CS;
+    const int c = cs * 16 + 4 * k + j, co = ct * 16 + n;
+    float v = 0.f;
+    if (c < Cin && co < Cout)
+      v = dgrad ? w[((int64_t)c * Cout + co) * 27 + 26 - tap] : w[((int64_t)co * Cin + c) * 27 + tap];
+    wpk[i] = v;
+  }
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cin, int Cout, int CinP,
                                     int CoutP, int mode, int P) {
   const int ntap = 9 * (P + 2);
   const int total = ntap * CinP * CoutP;
   const int CoP = P > 1 ? 16 / P : CoutP;
+  if (mode >= 2) { pack_direct(w, wpk, Cin, Cout, CinP, CoutP, mode - 2); return; }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int n = i % CoutP, t = i / CoutP;
     const int c = t % CinP, tapP = t / CinP;
@@ -74,6 +96,7 @@ __global__ void pack_weights_many_kernel(const PackTable t) {
   const int ntap = 9 * (P + 2);
   const int total = ntap * CinP * CoutP;
   const int CoP = P > 1 ? 16 / P : CoutP;
+  if (mode >= 2) { pack_direct(w, wpk, Cin, Cout, CinP, CoutP, mode - 2); return; }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int n = i % CoutP, tt = i / CoutP;
     const int c = tt % CinP, tapP = tt / CinP;
@@ -1409,7 +1432,7 @@ inline int resident_blocks(const void* fn, int nthreads) {
 
 inline size_t fwd_ws_elems(int Cin, int Cout) {
   // generous: any plan pads Cin to <= 8 and Cout to <= 64 granules; row packing uses up to 54 taps x 16 columns
-  const size_t plain = (size_t)27 * round_up(Cin, 8) * round_up(Cout, 64);
+  const size_t plain = (size_t)27 * round_up(Cin, 16) * round_up(Cout, 64);       // (16: conv_direct_kernel's channel blocks)
   const size_t packed = (size_t)54 * round_up(Cin, 8) * 16;
   return plain > packed ? plain : packed;
 }
@@ -1437,11 +1460,151 @@ static const float* prepacked_or_record(modet_step_ctx* c, const PackKey& k) {
   return nullptr;
 }
 
+// ------------------------------------------------------------------------------------------------ small volumes
+// Forward / dgrad of the coarse levels (<= 16 k voxels: encoder level 5, the CWM layers at level-4 resolution).  The tiled
+// kernel above stages 1x4x16-voxel tiles through LDS: at 10x12x10 a row of 16 holds 10 voxels, ~240 workgroups of 4 waves
+// serialise 16-32 stages behind two barriers each, and the launch runs at 24-40 TFLOP/s.  Here the whole problem sits in L2
+// (1-5 MB of activations, < 2 MB of weights), so nothing is staged at all: ONE WAVE owns 16 consecutive voxels of the flattened
+// volume (no ragged rows) x 16*NT output channels (its four waves: a quarter of the 27 taps each), and feeds v_mfma_f32_16x16x4_f32 (exact
+// fp32) straight from global memory: lane (voxel i, k) loads float4 = channels c0 + 4k .. c0 + 4k + 3 of its voxel's tap
+// neighbour (clamped address, zero by select outside the volume), lane (k, n) the matching float4 of the direct weight layout
+// (pack_direct); MFMA j of the four takes component j of both.  U channel blocks are loaded and fenced together; no LDS, no
+// barrier in the main loop, no tile geometry.
+template <int NT, int U>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int D, int H,
+                                                          int W, int Cin, int Cout, int CS, int CT, int BV) {
+  // the four waves of a workgroup split the 27 taps of ONE (voxel tile, output tile) -- K split four ways, partial tiles
+  // summed through LDS in fixed order: a single wave per tile is a chain of ~1 us load round trips with 0.25 us of MFMAs
+  // between them (measured: 50 us where the matrix pipe needs 15), four to five waves per SIMD hide it
+  __shared__ float red[3][NT][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int vt = blockIdx.x;
+  const int ct0 = blockIdx.y * NT;
+  const int v = vt * 16 + li < BV ? vt * 16 + li : BV - 1;   // rows past the end repeat the last voxel (never stored)
+  const unsigned uv = (unsigned)v, q1 = uv / (unsigned)W, q2 = q1 / (unsigned)H;
+  const int xi = (int)(uv - q1 * (unsigned)W), yi = (int)(q1 - q2 * (unsigned)H), zi = (int)(q2 % (unsigned)D);
+  const float* xv = x + (int64_t)v * Cin;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // trips = (tap of this wave, U channel blocks); the loads of trip i + 1 are issued before the MFMAs of trip i (two register
+  // sets), so a wave's chain costs max(load latency, MFMA time) per trip instead of their sum
+  const int TPT = CS / U;                                    // trips per tap (CS % U == 0 by dispatch)
+  const int ntrip = ((27 - wave + 3) / 4) * TPT;
+  auto issue = [&](int trip, float4 (&a)[U], float4 (&b)[U][NT], bool& inb) {
+    const int tap = wave + 4 * (trip / TPT), cs0 = (trip % TPT) * U;
+    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    inb = zi + dz >= 0 && zi + dz < D && yi + dy >= 0 && yi + dy < H && xi + dx >= 0 && xi + dx < W;
+    const float* xa = inb ? xv + ((int64_t)(dz * H + dy) * W + dx) * Cin : xv;
+    const float* wb = wpk + (int64_t)tap * CS * CT * 256 + lane * 4;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int coff = (cs0 + u) * 16 + 4 * lk;                    // a channel block past Cin meets zero weights: any valid address
+      coff = coff <= Cin - 4 ? coff : Cin - 4;
+      a[u] = *reinterpret_cast<const float4*>(xa + coff);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[u][t] = *reinterpret_cast<const float4*>(wb + (int64_t)((cs0 + u) * CT + ct0 + t) * 256);
+    }
+  };
+  auto consume = [&](float4 (&a)[U], float4 (&b)[U][NT], bool inb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                            // this trip's loads have landed (all of them, at once)
+      asm volatile("" : "+v"(a[u].x), "+v"(a[u].y), "+v"(a[u].z), "+v"(a[u].w));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(b[u][t].x));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!inb) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u][t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u][t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u][t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u][t].w, acc[t], 0, 0, 0);
+      }
+    }
+  };
+  float4 a0[U], b0[U][NT], a1[U], b1[U][NT];
+  bool in0 = false, in1 = false;
+  // branch-free body (a trip index past the end re-loads the last trip and is consumed with zeros): at a control-flow join
+  // the compiler's wait insertion falls back to s_waitcnt vmcnt(0), which would wait for the prefetch it just issued
+  const int last = ntrip - 1;                                // ntrip >= 6
+  issue(0, a0, b0, in0);
+  for (int trip = 0; trip < ntrip; trip += 2) {
+    issue(trip + 1 < ntrip ? trip + 1 : last, a1, b1, in1);
+    consume(a0, b0, in0);
+    issue(trip + 2 < ntrip ? trip + 2 : last, a0, b0, in0);
+    consume(a1, b1, in1 && trip + 1 < ntrip);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave - 1][t][j * 64 + lane] = acc[t][j];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int co = (ct0 + t) * 16 + li;
+    if (co >= Cout) continue;
+    const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = vt * 16 + lk * 4 + j;
+      const float sum = ((acc[t][j] + red[0][t][j * 64 + lane]) + red[1][t][j * 64 + lane]) + red[2][t][j * 64 + lane];
+      if (row < BV) y[(int64_t)row * Cout + co] = sum + bv;
+    }
+  }
+}
+
+// MODET_CONV_DIRECT=0 keeps the tiled kernels for every shape (A/B switch)
+static bool use_direct(int B, int D, int H, int W, int Cin, int Cout) {
+  static const bool on = [] { const char* e = getenv("MODET_CONV_DIRECT"); return !(e && e[0] == '0'); }();
+  const int64_t BV = (int64_t)B * D * H * W;
+  return on && BV <= 16384 && Cin >= 8 && Cin % 4 == 0 && Cout >= 4;
+}
+
+static void conv_direct_launch(const float* x, const float* wpk, const float* bias, float* y, int B, int D, int H, int W,
+                               int Cin, int Cout, hipStream_t s) {
+  const int BV = B * D * H * W;
+  const int CS = round_up(Cin, 16) / 16, CT = round_up(Cout, 16) / 16;
+  const int VT = cdiv(BV, 16);
+  // two output tiles per workgroup (half the A loads) once one tile each would put more than ~8 waves on a SIMD
+  const bool nt2 = CT % 2 == 0 && (int64_t)VT * CT > 512;
+  const dim3 grid(VT, nt2 ? CT / 2 : CT);
+#define DIRECT_LAUNCH(NT_, U_) hipLaunchKernelGGL((conv_direct_kernel<NT_, U_>), grid, dim3(256), 0, s, x, wpk, bias, y, D, H, W, Cin, Cout, CS, CT, BV)
+#define DIRECT_U(NT_)                                  \
+  do {                                                 \
+    if (CS % 4 == 0) DIRECT_LAUNCH(NT_, 4);            \
+    else if (CS % 3 == 0) DIRECT_LAUNCH(NT_, 3);       \
+    else if (CS % 2 == 0) DIRECT_LAUNCH(NT_, 2);       \
+    else DIRECT_LAUNCH(NT_, 1);                        \
+  } while (0)
+  if (nt2) DIRECT_U(2); else DIRECT_U(1);
+#undef DIRECT_U
+#undef DIRECT_LAUNCH
+}
+
 // query_gx != null: only report the persistent grid's x size (the statistics layout depends on it), launch nothing
 int conv_launch(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, float* wpk, int B, int D,
                 int H, int W, int Cin, int Cout, int act, int pack_mode, hipStream_t s, float* stats = nullptr,
                 int* query_gx = nullptr, ConvIn inorm = ConvIn{nullptr, nullptr, 0, nullptr}, bool query_xf = false,
                 bool query_st = false) {
+  if (!query_gx && !stats && !inorm.mean && !act && use_direct(B, D, H, W, Cin, Cout)) {
+    const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 16), total = 27 * CinP * CoutP;
+    const float* pre = prepacked_or_record(step, PackKey{w, Cin, Cout, CinP, CoutP, pack_mode + 2, 1});
+    if (pre)
+      wpk = const_cast<float*>(pre);
+    else
+      hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, s, w,
+                         wpk, Cin, Cout, CinP, CoutP, pack_mode + 2, 1);
+    conv_direct_launch(x, wpk, bias, y, B, D, H, W, Cin, Cout, s);
+    return modet_launch_status();
+  }
   const FwdPlan p = plan_fwd((int64_t)B * D * H * W, Cin, Cout);
   const int CinP = round_up(Cin, p.ck), CoutP = round_up(Cout, p.ncb);
   const int total = 9 * (p.P + 2) * CinP * CoutP;
@@ -1630,7 +1793,8 @@ int modet_conv3d_kernel_family(int B, int D, int H, int W, int Cin, int Cout, in
   if (pass == 2) return use_x3_wgrad(B, D, H, W, Cin, Cout) ? 2 : 0;
   const int ci = pass == 1 ? Cout : Cin, co = pass == 1 ? Cin : Cout;      // the data gradient convolves d_y (Cout channels)
   if (use_x3(B, D, H, W, ci, co)) return 2;
-  return use_split(ci, co, (int64_t)B * D * H * W) ? 1 : 0;
+  if (use_split(ci, co, (int64_t)B * D * H * W)) return 1;
+  return use_direct(B, D, H, W, ci, co) ? 3 : 0;               // 3: conv_direct_kernel (plain forward / dgrad launches only)
 }
 
 int modet_step_ctx_create(modet_step_ctx_t** out) {

@@ -152,12 +152,12 @@ class trace_range:
 
 
 _FAM_CACHE = {}
-_FAM_SUFFIX = ("", "@split", "@x3")
+_FAM_SUFFIX = ("", "@split", "@x3", "@direct")
 
 
 def _conv_tag(kind, x_shape, Cin, Cout):
     """KernelTimer tag of a conv launch: 'conv_fwd[8->8]@x3' names the kernel family that runs this shape (exact-f32
-    MFMA: no suffix; tiled bf16x3: @split; z-marching bf16x3: @x3) -- only evaluated while a timer is installed"""
+    MFMA: no suffix; tiled bf16x3: @split; z-marching bf16x3: @x3; small-volume direct MFMA: @direct) -- only evaluated while a timer is installed"""
     if _TIMER is None:
         return None
     key = (kind, tuple(x_shape[:4]), Cin, Cout)
@@ -503,7 +503,7 @@ def _fuse_stats(x, w):
     L = _L()
     if L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout) == 0:
         return False
-    if L.modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 0) != 0:  # the bf16x3 kernels carry the statistics at no cost
+    if L.modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 0) in (1, 2):  # the bf16x3 kernels carry the statistics at no cost
         return True
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
     return Cout in (4, 8, 16) or not needs_grad

@@ -19,6 +19,9 @@ L1, L2, L3, L4 = (160, 192, 160), (80, 96, 80), (40, 48, 40), (20, 24, 20)
 LAYERS = [(4, 8, L1), (8, 8, L1), (8, 16, L2), (16, 16, L2)]
 if os.environ.get("BENCH_CONV_LEVELS") == "34":
     LAYERS = [(16, 32, L3), (32, 32, L3), (32, 64, L4), (64, 64, L4)]
+if os.environ.get("BENCH_CONV_LEVELS") == "5":      # level 5 of the encoder and the CWM layers at level-4 resolution
+    L5 = (10, 12, 10)
+    LAYERS = [(64, 128, L5), (128, 128, L5), (24, 48, L4), (48, 48, L4), (48, 8, L4)]
 
 
 def timed(fn, iters=15):
