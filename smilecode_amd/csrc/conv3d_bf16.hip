@@ -601,8 +601,29 @@ __device__ __forceinline__ void wgrad_bf16_colsum_body(const float* __restrict__
   const int o = threadIdx.x & 63, gl = threadIdx.x >> 6;
   const int64_t j = (int64_t)blk * 64 + o;
   double a = 0.0;
-  if (j < row_fl)
-    for (int g = gl; g < gx; g += 16) a += (double)part[(int64_t)g * row_fl + j];
+  if (j < row_fl) {
+    // eight partial rows in flight per thread (fenced: one load -> wait -> add per row was a chain of gx / 16 round trips);
+    // the adds keep their order
+    int g = gl;
+    for (; g + 7 * 16 < gx; g += 8 * 16) {
+      float r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = part[(int64_t)(g + 16 * u) * row_fl + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(r[u]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (double)r[u];
+    }
+    {
+      float r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = part[(int64_t)(g + 16 * u < gx ? g + 16 * u : 0) * row_fl + j];     // row 0 always exists
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(r[u]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += g + 16 * u < gx ? (double)r[u] : 0.0;
+    }
+  }
   sm[gl][o] = a;
   __syncthreads();
   if (gl == 0 && j < row_fl) {

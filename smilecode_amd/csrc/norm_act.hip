@@ -504,18 +504,36 @@ __global__ __launch_bounds__(BLK) void in_partial_bf16_kernel(const void* __rest
   const int64_t v0 = (int64_t)blockIdx.x * chunk;
   const int64_t v1 = v0 + chunk < V ? v0 + chunk : V;
   if (active) {
-#pragma unroll 4
-    for (int64_t v = v0 + vl; v < v1; v += VPB) {
-      const int64_t i8 = ((int64_t)b * V + v) * G + g;
+    auto acc1 = [&](const Raw8& rx, const Raw8& rg) {
       float xs[8], gs[8];
-      load8<true>(x, i8, xs);
-      load8<DY_BF>(dy, i8, gs);
+      unpack8<true>(rx, xs);
+      unpack8<DY_BF>(rg, gs);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const float xh = (xs[c] - mu[c]) * rs[c];
         const float gg = gs[c] * (xh > 0.f ? 1.f : LRELU_SLOPE);
         a[c] += gg; q[c] = fmaf(gg, xh, q[c]);
       }
+    };
+    // the loads of PU passes are issued and fenced together, the sums keep their order (bit-identical)
+    constexpr int PU = 4;
+    int64_t v = v0 + vl;
+    for (; v + (PU - 1) * VPB < v1; v += PU * VPB) {
+      Raw8 rx[PU], rg[PU];
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int64_t i8 = ((int64_t)b * V + v + u * VPB) * G + g;
+        rx[u] = load8_raw<true>(x, i8);
+        rg[u] = load8_raw<DY_BF>(dy, i8);
+      }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) { raw8_fence<true>(rx[u]); raw8_fence<DY_BF>(rg[u]); }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) acc1(rx[u], rg[u]);
+    }
+    for (; v < v1; v += VPB) {
+      const int64_t i8 = ((int64_t)b * V + v) * G + g;
+      acc1(load8_raw<true>(x, i8), load8_raw<DY_BF>(dy, i8));
     }
   }
   if ((G & (G - 1)) == 0 && G <= 64) {                   // see in_partial_kernel: shuffle tree, then the 4 waves through LDS
