@@ -1565,6 +1565,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
 static bool use_direct(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_DIRECT"); return !(e && e[0] == '0'); }();
   const int64_t BV = (int64_t)B * D * H * W;
+  // (up to 100 k voxels -- the CWM layers at level-3 resolution -- measured: 9.655 vs 9.590 ms/step; the operands then stream from HBM)
   return on && BV <= 16384 && Cin >= 8 && Cin % 4 == 0 && Cout >= 4;
 }
 
