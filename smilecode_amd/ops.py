@@ -494,7 +494,7 @@ class _Conv3dStats(Function):
         return dx, dw, db
 
 
-def _fuse_stats(x, w):
+def _fuse_stats(x, w, needs_grad=None):
     """fuse the InstanceNorm statistics into this conv's epilogue?  The staged epilogue of the 16-wide configurations
     (Cout 4/8/16) carries them for free; in the direct-store configurations they cost the conv ~3 % and only pay off when
     no backward pass follows (measured: training +0.07 ms, inference -0.05 ms)."""
@@ -505,7 +505,8 @@ def _fuse_stats(x, w):
         return False
     if L.modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 0) in (1, 2):  # the bf16x3 kernels carry the statistics at no cost
         return True
-    needs_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+    if needs_grad is None:     # (inside an autograd.Function.forward grad mode is off: such callers pass their ctx.needs_input_grad)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
     return Cout in (4, 8, 16) or not needs_grad
 
 
@@ -567,7 +568,7 @@ class _InstNormConv(Function):
         _, D, H, W, Cin = y.shape
         Cout = w.shape[0]
         stats = None
-        if want_stats and _fuse_stats(y, w):
+        if want_stats and _fuse_stats(y, w, needs_grad=any(ctx.needs_input_grad)):
             z = torch.empty((B, D, H, W, Cout), dtype=torch.float32, device=y.device)
             nb = L.modet_conv3d_ws_bytes(Cin, Cout)
             ws = _ws(nb, y)
