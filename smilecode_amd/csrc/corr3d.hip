@@ -26,23 +26,27 @@ __global__ __launch_bounds__(BLK) void box3_kernel(const float* __restrict__ in,
     const int y = (int)(r % Ho) - e_out; r /= Ho;
     const int z = (int)(r % Do) - e_out;
     const int b = (int)(r / Do);
+    // the 27 loads are unconditional (clamped coordinates; the box outside the padded volume is selected to zero afterwards) and
+    // fenced in rows of nine: under `if (inside) continue` each one compiled to its own memory round trip, 27 in series
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int dz = -1; dz <= 1; ++dz) {
       const int zz = z + dz + e_in;
-      if (zz < 0 || zz >= Di) continue;
+      const bool zk = zz >= 0 && zz < Di;
+      float4 v[9];
+      bool ok[9];
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = y + dy + e_in;
-        if (yy < 0 || yy >= Hi) continue;
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int xx = x + dx + e_in;
-          if (xx < 0 || xx >= Wi) continue;
-          const float4 v = *reinterpret_cast<const float4*>(in + ((((int64_t)b * Di + zz) * Hi + yy) * Wi + xx) * C + g * 4);
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
+      for (int q = 0; q < 9; ++q) {
+        const int yy = y + q / 3 - 1 + e_in, xx = x + q % 3 - 1 + e_in;
+        ok[q] = zk && yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
+        const int64_t off = ok[q] ? ((((int64_t)b * Di + zz) * Hi + yy) * Wi + xx) * C : (int64_t)b * Di * Hi * Wi * C;
+        v[q] = *reinterpret_cast<const float4*>(in + off + g * 4);
       }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        if (ok[q]) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
     }
     *reinterpret_cast<float4*>(out + (int64_t)idx * 4) = acc;
   }
@@ -122,15 +126,29 @@ __global__ __launch_bounds__(BLK) void corr_bwd_pm_kernel(const float* __restric
     const int b = (int)(r / D);
     const int64_t p = ((int64_t)z * H + y) * W + x;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // nine displacements per batch, loads unconditional (clamped) and fenced together; the sum keeps its order
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      const int qz = z + 2 * (t / 9 - 1), qy = y + 2 * ((t / 3) % 3 - 1), qx = x + 2 * (t % 3 - 1);
-      if (qz >= -1 && qz <= D && qy >= -1 && qy <= H && qx >= -1 && qx <= W) {
-        const float gv = g[((int64_t)b * 27 + t) * V + p];
-        const float4 fv = *reinterpret_cast<const float4*>(
-            pfx + ((((int64_t)b * (D + 2) + qz + 1) * He + qy + 1) * We + qx + 1) * C + c4 * 4);
-        acc.x = fmaf(gv, fv.x, acc.x); acc.y = fmaf(gv, fv.y, acc.y); acc.z = fmaf(gv, fv.z, acc.z); acc.w = fmaf(gv, fv.w, acc.w);
+    for (int t0 = 0; t0 < 27; t0 += 9) {
+      float gv[9];
+      float4 fv[9];
+      bool ok[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const int t = t0 + u;
+        const int qz = z + 2 * (t / 9 - 1), qy = y + 2 * ((t / 3) % 3 - 1), qx = x + 2 * (t % 3 - 1);
+        ok[u] = qz >= -1 && qz <= D && qy >= -1 && qy <= H && qx >= -1 && qx <= W;
+        gv[u] = g[((int64_t)b * 27 + t) * V + p];
+        const int64_t off = ok[u] ? ((((int64_t)b * (D + 2) + qz + 1) * He + qy + 1) * We + qx + 1) * C : (int64_t)b * (D + 2) * He * We * C;
+        fv[u] = *reinterpret_cast<const float4*>(pfx + off + c4 * 4);
       }
+#pragma unroll
+      for (int u = 0; u < 9; ++u) asm volatile("" : "+v"(gv[u]), "+v"(fv[u].x), "+v"(fv[u].y), "+v"(fv[u].z), "+v"(fv[u].w));
+#pragma unroll
+      for (int u = 0; u < 9; ++u)
+        if (ok[u]) {
+          acc.x = fmaf(gv[u], fv[u].x, acc.x); acc.y = fmaf(gv[u], fv[u].y, acc.y);
+          acc.z = fmaf(gv[u], fv[u].z, acc.z); acc.w = fmaf(gv[u], fv[u].w, acc.w);
+        }
     }
     const float k = 1.f / 27.f;
     *reinterpret_cast<float4*>(dpm + (int64_t)idx * 4) = make_float4(acc.x * k, acc.y * k, acc.z * k, acc.w * k);
@@ -153,14 +171,27 @@ __global__ __launch_bounds__(BLK) void corr_bwd_pf_kernel(const float* __restric
     const int b = (int)(r / De);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      const int z = qz - 2 * (t / 9 - 1), y = qy - 2 * ((t / 3) % 3 - 1), x = qx - 2 * (t % 3 - 1);
-      if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
-        const int64_t p = ((int64_t)z * H + y) * W + x;
-        const float gv = g[((int64_t)b * 27 + t) * V + p];
-        const float4 av = *reinterpret_cast<const float4*>(pm + ((int64_t)b * V + p) * C + c4 * 4);
-        acc.x = fmaf(gv, av.x, acc.x); acc.y = fmaf(gv, av.y, acc.y); acc.z = fmaf(gv, av.z, acc.z); acc.w = fmaf(gv, av.w, acc.w);
+    for (int t0 = 0; t0 < 27; t0 += 9) {                  // as in corr_bwd_pm_kernel: nine fenced (g, pm) pairs per batch
+      float gv[9];
+      float4 av[9];
+      bool ok[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const int t = t0 + u;
+        const int z = qz - 2 * (t / 9 - 1), y = qy - 2 * ((t / 3) % 3 - 1), x = qx - 2 * (t % 3 - 1);
+        ok[u] = z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
+        const int64_t p = ok[u] ? ((int64_t)z * H + y) * W + x : 0;
+        gv[u] = g[((int64_t)b * 27 + t) * V + p];
+        av[u] = *reinterpret_cast<const float4*>(pm + ((int64_t)b * V + p) * C + c4 * 4);
       }
+#pragma unroll
+      for (int u = 0; u < 9; ++u) asm volatile("" : "+v"(gv[u]), "+v"(av[u].x), "+v"(av[u].y), "+v"(av[u].z), "+v"(av[u].w));
+#pragma unroll
+      for (int u = 0; u < 9; ++u)
+        if (ok[u]) {
+          acc.x = fmaf(gv[u], av[u].x, acc.x); acc.y = fmaf(gv[u], av[u].y, acc.y);
+          acc.z = fmaf(gv[u], av[u].z, acc.z); acc.w = fmaf(gv[u], av[u].w, acc.w);
+        }
     }
     const float k = 1.f / 27.f;
     *reinterpret_cast<float4*>(dpfx + (int64_t)idx * 4) = make_float4(acc.x * k, acc.y * k, acc.z * k, acc.w * k);
