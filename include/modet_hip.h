@@ -215,6 +215,12 @@ int modet_instnorm_lrelu_bwd_rows(const float* d_y, const float* x, const float*
 int modet_lrelu_bwd(const float* d_y, const float* y, float* d_x, int64_t n, modet_stream_t stream);
 /* AvgPool3d(2) (models.py:201,:207,:213,:219); D,H,W are the INPUT dims (even). */
 int modet_avgpool2_fwd(const float* x, float* y, int B, int D, int H, int W, int C, modet_stream_t stream);
+/* The apply pass of InstanceNorm + LeakyReLU (mean / rstd from modet_instnorm_stats) fused with the AvgPool3d(2) that follows
+ * the last ConvInsBlock of an encoder level (models.py:186-219): y = LeakyReLU((x - mean) * rstd) (B,D,H,W,C) and
+ * pooled = AvgPool3d(2)(y) (B,D/2,H/2,W/2,C) in one pass over x; bit-identical to modet_instnorm_lrelu_fwd* followed by
+ * modet_avgpool2_fwd.  D, H, W even, C % 4 == 0. */
+int modet_instnorm_lrelu_apply_pool(const float* x, const float* mean, const float* rstd, float* y, float* pooled, int B,
+                                    int D, int H, int W, int C, modet_stream_t stream);
 /* d_x = unpool(d_y)/8 + addend; addend (same shape as d_x, may be NULL) = gradient of the un-pooled branch */
 int modet_avgpool2_bwd(const float* d_y, const float* addend, float* d_x, int B, int D, int H, int W, int C,
                        modet_stream_t stream);

@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 301; /* 0.3.1: + modet_ncc_fwd_bwd_win (NCC windows 3 / 5 / 7 / 9), modet_conv3d_bf16_kernel_family */ }
+int modet_hip_version(void) { return 302; /* 0.3.2: + modet_instnorm_lrelu_apply_pool, conv kernel family 3 (conv_direct_kernel) */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {

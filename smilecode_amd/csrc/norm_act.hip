@@ -339,6 +339,59 @@ __global__ __launch_bounds__(BLK) void avgpool2_fwd_kernel(const float* __restri
   }
 }
 
+// InstanceNorm apply + LeakyReLU + AvgPool3d(2) in one pass (the last block of an encoder level: its output goes to the
+// level's consumers AND, pooled, to the next level): thread = (pooled voxel, 4 channels) reads its 2x2x2 raw voxels (all
+// eight loads in flight), writes the eight normalised voxels and their mean.  y and the pooled sum use the arithmetic and the
+// (dz, dy, dx) order of in_apply_kernel / avgpool2_fwd_kernel: bit-identical to the two-pass form, which re-read y (8 B/element).
+__global__ __launch_bounds__(BLK) void in_apply_pool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            float* __restrict__ pooled, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int D, int H, int W, int C,
+                                                            int64_t total4) {
+  const int G = C >> 2, d = D / 2, h = H / 2, w = W / 2;
+  const bool small = total4 < (1ll << 31);
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BLK) {
+    int g, xo, yo, zo;
+    int64_t b;
+    if (small) {
+      unsigned t = (unsigned)i, q = t / (unsigned)G;
+      g = (int)(t - q * (unsigned)G); t = q;
+      q = t / (unsigned)w; xo = (int)(t - q * (unsigned)w); t = q;
+      q = t / (unsigned)h; yo = (int)(t - q * (unsigned)h); t = q;
+      q = t / (unsigned)d; zo = (int)(t - q * (unsigned)d);
+      b = q;
+    } else {
+      g = (int)(i % G);
+      int64_t t = i / G;
+      xo = (int)(t % w); t /= w;
+      yo = (int)(t % h); t /= h;
+      zo = (int)(t % d);
+      b = t / d;
+    }
+    const float4 m = *reinterpret_cast<const float4*>(mean + b * C + g * 4);
+    const float4 r = *reinterpret_cast<const float4*>(rstd + b * C + g * 4);
+    float4 v[8];
+    int64_t off[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      off[k] = (((b * D + 2 * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1)) * C + g * 4;
+      v[k] = *reinterpret_cast<const float4*>(x + off[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float4 o;
+      o.x = lrelu((v[k].x - m.x) * r.x); o.y = lrelu((v[k].y - m.y) * r.y);
+      o.z = lrelu((v[k].z - m.z) * r.z); o.w = lrelu((v[k].w - m.w) * r.w);
+      *reinterpret_cast<float4*>(y + off[k]) = o;
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    s.x *= 0.125f; s.y *= 0.125f; s.z *= 0.125f; s.w *= 0.125f;
+    reinterpret_cast<float4*>(pooled)[i] = s;
+  }
+}
+
 // dx = upsample(dy)/8 (+ addend): the optional addend is the gradient arriving on the un-pooled branch of the same
 // tensor, so "pool backward" and autograd's "sum of the two consumers" become one pass
 __global__ __launch_bounds__(BLK) void avgpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ addend,
@@ -765,6 +818,18 @@ int modet_avgpool2_fwd(const float* x, float* y, int B, int D, int H, int W, int
   const int64_t total4 = (int64_t)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, y, D, H,
                      W, C, total4);
+  return modet_launch_status();
+}
+
+int modet_instnorm_lrelu_apply_pool(const float* x, const float* mean, const float* rstd, float* y, float* pooled, int B,
+                                    int D, int H, int W, int C, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(y); MODET_CHECK_PTR(pooled);
+  MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1 && C > 0);
+  MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
+  if (C % 4 != 0) return MODET_ERR_UNSUPPORTED;
+  const int64_t total4 = (int64_t)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(in_apply_pool_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, y, pooled, mean,
+                     rstd, D, H, W, C, total4);
   return modet_launch_status();
 }
 

@@ -114,6 +114,14 @@ class ConvInsBlock(nn.Module):
         return ops.conv3d_instnorm_lrelu(x, self.main.weight, self.main.bias)
 
 
+def _two_blocks_pool(inp, first, second, Bh):
+    """_two_blocks followed by the pool tee of the [moving; fixed] batch, fp32 path: the second block's InstanceNorm apply pass
+    also writes the pooled tensor of the next level (ops.instnorm_lrelu_pool_tee_split); returns (pooled, moving, fixed)"""
+    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias)
+    raw2, st2 = ops.lazy_instnorm_conv3d(raw, st, second.main.weight, second.main.bias)
+    return ops.instnorm_lrelu_pool_tee_split(raw2, st2, Bh)
+
+
 def _two_blocks(inp, first, second, bf16=False):
     """ConvInsBlock -> ConvInsBlock: the first block's normalised output exists only inside the second conv's kernels
     (ops.lazy_instnorm_conv3d); the second block's InstanceNorm is applied for real (its output has several consumers).
@@ -158,12 +166,23 @@ class Encoder(nn.Module):
         """x = [moving; fixed] as one batch of 2B (InstanceNorm is per sample, so this is exact); returns the per-level
         features of each half: ([M1..M5], [F1..F5])"""
         Ms, Fs = [], []
-        cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2], self.bf16)
-        for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
-            pooled, m, f = ops.pool_tee_split(cur, B)
+        if not self.bf16:
+            # fp32: the last InstanceNorm of a level writes the level's features and their pooled copy in one pass
+            pooled, m, f = _two_blocks_pool(self.conv0[0](x), self.conv0[1], self.conv0[2], B)
             Ms.append(m)
             Fs.append(f)
-            cur = _two_blocks(pooled, blk[1], blk[2], self.bf16)            # blk[0] is the AvgPool3d(2) the tee already applied
+            for blk in (self.conv1, self.conv2, self.conv3):
+                pooled, m, f = _two_blocks_pool(pooled, blk[1], blk[2], B)
+                Ms.append(m)
+                Fs.append(f)
+            cur = _two_blocks(pooled, self.conv4[1], self.conv4[2], False)
+        else:
+            cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2], self.bf16)
+            for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
+                pooled, m, f = ops.pool_tee_split(cur, B)
+                Ms.append(m)
+                Fs.append(f)
+                cur = _two_blocks(pooled, blk[1], blk[2], self.bf16)        # blk[0] is the AvgPool3d(2) the tee already applied
         m, f = _SplitBatch.apply(cur, B)
         Ms.append(m)
         Fs.append(f)

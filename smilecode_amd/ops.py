@@ -785,6 +785,72 @@ def pool_tee_split(x, Bh):
     return _PoolTeeSplit.apply(x, Bh)
 
 
+class _InstNormLReLUPoolSplit(Function):
+    """_InstNormLReLU followed by _PoolTeeSplit as ONE node: x_raw (2B,...) -> (avgpool2(y), y[:B], y[B:]) with
+    y = LeakyReLU(InstanceNorm(x_raw)).  Forward: statistics (finalize only, or one pass), then one kernel that writes y
+    and its pooled copy (modet_instnorm_lrelu_apply_pool: the separate AvgPool3d re-read y).  Backward: the two nodes'
+    backward kernels in sequence, unchanged.  Bit-identical to the two-node form."""
+
+    @staticmethod
+    def forward(ctx, x, eps, stats, Bh):
+        _chk(x)
+        B, D, H, W, C = x.shape
+        V = D * H * W
+        L = _L()
+        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        pooled = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+        with _Guard(x, "instnorm_lrelu_fwd", 9.0 * x.numel(), 8.5 * x.numel()):
+            if stats is not None:
+                _lib.check(L.modet_instnorm_stats(_p(x), _p(mean), _p(rstd), _p(stats), stats.numel() * 4, None, 0, B, V, C,
+                                                  eps, _stream()), "modet_instnorm_stats")
+            else:
+                nb = L.modet_instnorm_ws_bytes(B, V, C)
+                ws = _ws(nb, x)
+                _lib.check(L.modet_instnorm_stats(_p(x), _p(mean), _p(rstd), None, 0, _p(ws), nb, B, V, C, eps, _stream()),
+                           "modet_instnorm_stats")
+            _lib.check(L.modet_instnorm_lrelu_apply_pool(_p(x), _p(mean), _p(rstd), _p(y), _p(pooled), B, D, H, W, C,
+                                                         _stream()), "modet_instnorm_lrelu_apply_pool")
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.Bh = Bh
+        return pooled, y[:Bh], y[Bh:]
+
+    @staticmethod
+    def backward(ctx, gy, ga, gb):
+        x, mean, rstd = ctx.saved_tensors
+        B, D, H, W, C = x.shape
+        Bh = ctx.Bh
+        V = D * H * W
+        L = _L()
+        dy = torch.empty_like(x)
+        if gy is None:
+            for sl, g in ((slice(0, Bh), ga), (slice(Bh, B), gb)):
+                if g is None:
+                    dy[sl].zero_()
+                else:
+                    dy[sl].copy_(g)
+        else:
+            gy = gy.contiguous()
+            with _Guard(gy, "avgpool2_bwd", dy.numel(), 8.5 * dy.numel()):
+                for lo, hi, g in ((0, Bh, ga), (Bh, B, gb)):
+                    add = None if g is None else g.contiguous()
+                    _lib.check(L.modet_avgpool2_bwd(_p(gy[lo:hi]), _p(add), _p(dy[lo:hi]), hi - lo, D, H, W, C, _stream()),
+                               "modet_avgpool2_bwd")
+        dx = torch.empty_like(x)
+        nb = L.modet_instnorm_ws_bytes(B, V, C)
+        ws = _ws(nb, x)
+        with _Guard(x, "instnorm_lrelu_bwd", 14.0 * x.numel(), 12.0 * x.numel()):
+            _lib.check(L.modet_instnorm_lrelu_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C, _stream()),
+                       "modet_instnorm_lrelu_bwd")
+        return dx, None, None, None
+
+
+def instnorm_lrelu_pool_tee_split(x_raw, stats, Bh, eps=1e-5):
+    """(avgpool2(y), y[:Bh], y[Bh:]) for y = LeakyReLU(InstanceNorm(x_raw)); see _InstNormLReLUPoolSplit"""
+    return _InstNormLReLUPoolSplit.apply(x_raw, eps, stats, Bh)
+
+
 class _ProjLN(Function):
     @staticmethod
     def forward(ctx, x, Wt, b, gamma, beta, eps):
