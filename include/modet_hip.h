@@ -211,6 +211,13 @@ int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean
 int modet_instnorm_lrelu_bwd_rows(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
                                   const float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B, int64_t V, int C,
                                   modet_stream_t stream);
+/* modet_instnorm_lrelu_bwd for the last block of an encoder level, whose d_y = unpool(g_pooled) / 8 + [add_a ; add_b]
+ * (g_pooled (B,D/2,H/2,W/2,C): gradient of the AvgPool3d(2) output; add_a (Bh,D,H,W,C) / add_b (B-Bh,D,H,W,C): gradients of the
+ * two batch halves of y, either may be NULL): d_y is formed while it is read instead of being written by modet_avgpool2_bwd
+ * and read back twice; bit-identical to that sequence.  ws_bytes >= modet_instnorm_ws_bytes(B, D*H*W, C). */
+int modet_instnorm_lrelu_bwd_pool(const float* g_pooled, const float* add_a, const float* add_b, int Bh, const float* x,
+                                  const float* mean, const float* rstd, float* d_x, void* ws, size_t ws_bytes, int B, int D,
+                                  int H, int W, int C, modet_stream_t stream);
 /* d_x = d_y * (y > 0 ? 1 : 0.1): backward of the LeakyReLU fused into modet_conv3d_fwd(act=1) */
 int modet_lrelu_bwd(const float* d_y, const float* y, float* d_x, int64_t n, modet_stream_t stream);
 /* AvgPool3d(2) (models.py:201,:207,:213,:219); D,H,W are the INPUT dims (even). */

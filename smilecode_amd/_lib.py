@@ -60,6 +60,7 @@ SIGNATURES = {
     "modet_lrelu_bwd": (I, [P, P, P, I64, P]),
     "modet_avgpool2_fwd": (I, [P, P, I, I, I, I, I, P]),
     "modet_instnorm_lrelu_apply_pool": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "modet_instnorm_lrelu_bwd_pool": (I, [P, P, P, I, P, P, P, P, P, SZ, I, I, I, I, I, P]),
     "modet_avgpool2_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "modet_proj_ln_fwd": (I, [P, P, P, P, P, P, I64, I, I, F, P]),
     "modet_proj_ln_bwd_ws_bytes": (SZ, [I64, I, I]),

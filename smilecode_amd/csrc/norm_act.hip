@@ -12,11 +12,33 @@ constexpr int BLK = 256;
 // loop short at the coarse, wide-channel levels)
 static inline int in_chunk(int C) { return C >= 4 ? (BLK / (C >> 2)) * 32 : BLK * 32; }   // C % 4 != 0 is refused by the callers
 
-// MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat), g = dy * lrelu'(xhat)
+// d_y of a level's output block formed on the fly (MODE 2 / POOL = true below): the block's output y went to the level's
+// consumers (moving half: add_a, fixed half: add_b, either may be null) and, through AvgPool3d(2), to the next level (gy), so
+//   d_y[b][v] = gy[b][v / 2] * 0.125 + add[b][v]
+// -- the arithmetic of avgpool2_bwd_kernel, which used to write this tensor for the two passes below to read back.
+struct PoolSrc { const float* gy; const float* add_a; const float* add_b; int Bh, D, H, W; };
+__device__ __forceinline__ void pool_dy_addr(const PoolSrc& p, int b, int64_t v, int64_t V, int C, int g, const float*& pg,
+                                             const float*& pa) {
+  const unsigned uv = (unsigned)v, q1 = uv / (unsigned)p.W, q2 = q1 / (unsigned)p.H;          // (v < 2^31: checked by the host)
+  const int xi = (int)(uv - q1 * (unsigned)p.W), yi = (int)(q1 - q2 * (unsigned)p.H), zi = (int)q2;
+  const int h = p.H >> 1, w = p.W >> 1, d = p.D >> 1;
+  pg = p.gy + ((((int64_t)b * d + (zi >> 1)) * h + (yi >> 1)) * w + (xi >> 1)) * C + g * 4;
+  const float* base = b < p.Bh ? p.add_a : p.add_b;
+  pa = base ? base + ((int64_t)(b < p.Bh ? b : b - p.Bh) * V + v) * C + g * 4 : nullptr;
+}
+__device__ __forceinline__ float4 pool_dy_value(const float4 gv, const float4 av, bool has_add) {
+  float4 r = gv;
+  r.x *= 0.125f; r.y *= 0.125f; r.z *= 0.125f; r.w *= 0.125f;
+  if (has_add) { r.x += av.x; r.y += av.y; r.z += av.z; r.w += av.w; }
+  return r;
+}
+
+// MODE 0: (sum x, sum x^2)        MODE 1: (sum g, sum g*xhat), g = dy * lrelu'(xhat)        MODE 2: MODE 1 with d_y from PoolSrc
 template <int MODE>
 __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         float* __restrict__ part, int64_t V, int C, int chunk) {
+                                                         float* __restrict__ part, int64_t V, int C, int chunk,
+                                                         const PoolSrc ps = PoolSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0}) {
   __shared__ float red[BLK * 8];
   const int G = C >> 2;                        // float4 groups per voxel
   const int VPB = BLK / G;                     // voxels per pass
@@ -25,7 +47,7 @@ __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict
   const bool active = vl < VPB;
   float a[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
   float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
-  if (MODE == 1 && active) {
+  if (MODE >= 1 && active) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { mu[c] = mean[b * C + g * 4 + c]; rs[c] = rstd[b * C + g * 4 + c]; }
   }
@@ -51,20 +73,43 @@ __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict
     constexpr int PU = MODE == 0 ? 4 : 2;
     int64_t v = v0 + vl;
     for (; v + (PU - 1) * VPB < v1; v += PU * VPB) {
-      float4 xv[PU], gv[PU];
+      float4 xv[PU], gv[PU], av[PU];
+      bool ha[PU];
 #pragma unroll
       for (int u = 0; u < PU; ++u) {
         const int64_t off = ((int64_t)b * V + v + u * VPB) * C + g * 4;
         xv[u] = *reinterpret_cast<const float4*>(x + off);
-        gv[u] = MODE == 1 ? *reinterpret_cast<const float4*>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        av[u] = gv[u];
+        ha[u] = false;
+        if (MODE == 1) gv[u] = *reinterpret_cast<const float4*>(dy + off);
+        if (MODE == 2) {
+          const float *pg, *pa;
+          pool_dy_addr(ps, b, v + u * VPB, V, C, g, pg, pa);
+          gv[u] = *reinterpret_cast<const float4*>(pg);
+          ha[u] = pa != nullptr;                                     // (uniform per sample half)
+          av[u] = *reinterpret_cast<const float4*>(ha[u] ? pa : pg);
+        }
+      }
+      if (MODE == 2) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) asm volatile("" : "+v"(xv[u].x), "+v"(gv[u].x), "+v"(av[u].x));
       }
 #pragma unroll
-      for (int u = 0; u < PU; ++u) acc1(xv[u], gv[u]);
+      for (int u = 0; u < PU; ++u) acc1(xv[u], MODE == 2 ? pool_dy_value(gv[u], av[u], ha[u]) : gv[u]);
     }
     for (; v < v1; v += VPB) {
       const int64_t off = ((int64_t)b * V + v) * C + g * 4;
       const float4 xv = *reinterpret_cast<const float4*>(x + off);
-      acc1(xv, MODE == 1 ? *reinterpret_cast<const float4*>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f));
+      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == 1) gv = *reinterpret_cast<const float4*>(dy + off);
+      if (MODE == 2) {
+        const float *pg, *pa;
+        pool_dy_addr(ps, b, v, V, C, g, pg, pa);
+        const float4 g4 = *reinterpret_cast<const float4*>(pg);
+        gv = pool_dy_value(g4, pa ? *reinterpret_cast<const float4*>(pa) : g4, pa != nullptr);
+      }
+      acc1(xv, gv);
     }
   }
   if ((G & (G - 1)) == 0 && G <= 64) {
@@ -235,11 +280,13 @@ __global__ __launch_bounds__(BLK) void in_apply_kernel(const float* __restrict__
   }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g*xhat))
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat));  POOL: d_y is formed on the fly from PoolSrc (see above) instead of read
+template <bool POOL>
 __global__ __launch_bounds__(BLK) void in_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ s1, const float* __restrict__ s2,
-                                                           float* __restrict__ dx, int64_t V, int C, int64_t total4) {
+                                                           float* __restrict__ dx, int64_t V, int C, int64_t total4,
+                                                           const PoolSrc ps = PoolSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0}) {
   const int G = C >> 2;
   const bool small = total4 < (1ll << 31) && V < (1ll << 31);
   const int64_t stride = (int64_t)gridDim.x * BLK;
@@ -262,11 +309,23 @@ __global__ __launch_bounds__(BLK) void in_bwd_apply_kernel(const float* __restri
   constexpr int ILP = 2;       // two tensors are read: 4 float4 loads in flight per thread
   int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
   for (; i + (ILP - 1) * stride < total4; i += ILP * stride) {
-    float4 xv[ILP], gv[ILP], m4[ILP], r4[ILP], a4[ILP], b4[ILP];
+    float4 xv[ILP], gv[ILP], m4[ILP], r4[ILP], a4[ILP], b4[ILP], pv[ILP];
+    bool ha[ILP];
 #pragma unroll
     for (int u = 0; u < ILP; ++u) {
       xv[u] = reinterpret_cast<const float4*>(x)[i + u * stride];
-      gv[u] = reinterpret_cast<const float4*>(dy)[i + u * stride];
+      if (!POOL) {
+        gv[u] = reinterpret_cast<const float4*>(dy)[i + u * stride];
+      } else {
+        int g, b;
+        in_elem(i + u * stride, G, V, small, g, b);
+        const int64_t v = (i + u * stride) / G - (int64_t)b * V;
+        const float *pg, *pa;
+        pool_dy_addr(ps, b, v, V, C, g, pg, pa);
+        gv[u] = *reinterpret_cast<const float4*>(pg);
+        ha[u] = pa != nullptr;
+        pv[u] = *reinterpret_cast<const float4*>(ha[u] ? pa : pg);
+      }
     }
 #pragma unroll
     for (int u = 0; u < ILP; ++u) {
@@ -275,14 +334,28 @@ __global__ __launch_bounds__(BLK) void in_bwd_apply_kernel(const float* __restri
       a4[u] = *reinterpret_cast<const float4*>(s1 + ci);   b4[u] = *reinterpret_cast<const float4*>(s2 + ci);
     }
 #pragma unroll
-    for (int u = 0; u < ILP; ++u)
+    for (int u = 0; u < ILP; ++u) {
       asm volatile("" : "+v"(xv[u].x), "+v"(gv[u].x), "+v"(m4[u].x), "+v"(r4[u].x), "+v"(a4[u].x), "+v"(b4[u].x));
+      if (POOL) asm volatile("" : "+v"(pv[u].x));
+    }
 #pragma unroll
-    for (int u = 0; u < ILP; ++u) one(i + u * stride, xv[u], gv[u], m4[u], r4[u], a4[u], b4[u]);
+    for (int u = 0; u < ILP; ++u)
+      one(i + u * stride, xv[u], POOL ? pool_dy_value(gv[u], pv[u], ha[u]) : gv[u], m4[u], r4[u], a4[u], b4[u]);
   }
   for (; i < total4; i += stride) {
     const int ci = cidx(i);
-    one(i, reinterpret_cast<const float4*>(x)[i], reinterpret_cast<const float4*>(dy)[i],
+    float4 gv;
+    if (!POOL) {
+      gv = reinterpret_cast<const float4*>(dy)[i];
+    } else {
+      int g, b;
+      in_elem(i, G, V, small, g, b);
+      const float *pg, *pa;
+      pool_dy_addr(ps, b, i / G - (int64_t)b * V, V, C, g, pg, pa);
+      const float4 g4 = *reinterpret_cast<const float4*>(pg);
+      gv = pool_dy_value(g4, pa ? *reinterpret_cast<const float4*>(pa) : g4, pa != nullptr);
+    }
+    one(i, reinterpret_cast<const float4*>(x)[i], gv,
         *reinterpret_cast<const float4*>(mean + ci), *reinterpret_cast<const float4*>(rstd + ci),
         *reinterpret_cast<const float4*>(s1 + ci), *reinterpret_cast<const float4*>(s2 + ci));
   }
@@ -768,7 +841,7 @@ int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean
   hipLaunchKernelGGL(in_partial_kernel<1>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C, chunk);
   hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f);
   const int64_t total4 = (int64_t)B * V * (C / 4);
-  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2,
+  hipLaunchKernelGGL(in_bwd_apply_kernel<false>, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2,
                      d_x, V, C, total4);
   return modet_launch_status();
 }
@@ -791,8 +864,35 @@ int modet_instnorm_lrelu_bwd_rows(const float* d_y, const float* x, const float*
   float* s2 = s1 + (size_t)B * C;
   hipLaunchKernelGGL(in_rows_finalize_bwd_kernel, dim3(B), dim3(256), 0, s, rows, s1, s2, V, C, per);
   const int64_t total4 = (int64_t)B * V * (C / 4);
-  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, (const float*)s1,
+  hipLaunchKernelGGL(in_bwd_apply_kernel<false>, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, (const float*)s1,
                      (const float*)s2, d_x, V, C, total4);
+  return modet_launch_status();
+}
+
+/* InstanceNorm backward of a level's output block whose gradient is unpool(g_pooled) / 8 + [add_a ; add_b] (the block's
+ * output went to AvgPool3d(2) and, split into its two batch halves, to the level's consumers): the sum is formed while the two
+ * passes read it instead of being written by modet_avgpool2_bwd and read back twice.  Same kernels, same order of the sums. */
+int modet_instnorm_lrelu_bwd_pool(const float* g_pooled, const float* add_a, const float* add_b, int Bh, const float* x,
+                                  const float* mean, const float* rstd, float* d_x, void* ws, size_t ws_bytes, int B, int D,
+                                  int H, int W, int C, modet_stream_t stream) {
+  MODET_CHECK_PTR(g_pooled); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1 && C > 0 && Bh >= 0 && Bh <= B);
+  MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
+  const int64_t V = (int64_t)D * H * W;
+  if (C % 4 != 0 || C > 512 || V >= (1ll << 31)) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_instnorm_ws_bytes(B, V, C)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const PoolSrc ps{g_pooled, add_a, add_b, Bh, D, H, W};
+  const int chunk = in_chunk(C);
+  const int nchunk = (int)cdiv64(V, chunk);
+  float* part = (float*)ws;
+  float* s1 = part + (size_t)B * nchunk * C * 2;
+  float* s2 = s1 + (size_t)B * C;
+  hipLaunchKernelGGL(in_partial_kernel<2>, dim3(nchunk, B), dim3(BLK), 0, s, x, nullptr, mean, rstd, part, V, C, chunk, ps);
+  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f);
+  const int64_t total4 = (int64_t)B * V * (C / 4);
+  hipLaunchKernelGGL(in_bwd_apply_kernel<true>, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, nullptr, x, mean, rstd, s1, s2,
+                     d_x, V, C, total4, ps);
   return modet_launch_status();
 }
 

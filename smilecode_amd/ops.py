@@ -823,23 +823,24 @@ class _InstNormLReLUPoolSplit(Function):
         Bh = ctx.Bh
         V = D * H * W
         L = _L()
-        dy = torch.empty_like(x)
-        if gy is None:
-            for sl, g in ((slice(0, Bh), ga), (slice(Bh, B), gb)):
-                if g is None:
-                    dy[sl].zero_()
-                else:
-                    dy[sl].copy_(g)
-        else:
-            gy = gy.contiguous()
-            with _Guard(gy, "avgpool2_bwd", dy.numel(), 8.5 * dy.numel()):
-                for lo, hi, g in ((0, Bh, ga), (Bh, B, gb)):
-                    add = None if g is None else g.contiguous()
-                    _lib.check(L.modet_avgpool2_bwd(_p(gy[lo:hi]), _p(add), _p(dy[lo:hi]), hi - lo, D, H, W, C, _stream()),
-                               "modet_avgpool2_bwd")
         dx = torch.empty_like(x)
         nb = L.modet_instnorm_ws_bytes(B, V, C)
         ws = _ws(nb, x)
+        if gy is not None:
+            # d_y = unpool(gy) / 8 + [ga ; gb] is formed inside the two InstanceNorm backward passes, never written
+            gy = gy.contiguous()
+            ga = None if ga is None else ga.contiguous()
+            gb = None if gb is None else gb.contiguous()
+            with _Guard(x, "instnorm_lrelu_bwd", 15.0 * x.numel(), 12.5 * x.numel()):
+                _lib.check(L.modet_instnorm_lrelu_bwd_pool(_p(gy), _p(ga), _p(gb), Bh, _p(x), _p(mean), _p(rstd), _p(dx), _p(ws),
+                                                           nb, B, D, H, W, C, _stream()), "modet_instnorm_lrelu_bwd_pool")
+            return dx, None, None, None
+        dy = torch.empty_like(x)
+        for sl, g in ((slice(0, Bh), ga), (slice(Bh, B), gb)):
+            if g is None:
+                dy[sl].zero_()
+            else:
+                dy[sl].copy_(g)
         with _Guard(x, "instnorm_lrelu_bwd", 14.0 * x.numel(), 12.0 * x.numel()):
             _lib.check(L.modet_instnorm_lrelu_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C, _stream()),
                        "modet_instnorm_lrelu_bwd")
