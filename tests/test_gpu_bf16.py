@@ -318,7 +318,7 @@ def test_cfg5_shape_fp32_parity_vs_fp64_oracle(cfg5_oracle):
     note("cfg5_f32[160x192x224,B=2].grad_batch_linearity_relerr", lin)
     # fp32 summation order + the warp scatter's atomics + (round 3) the coarse-level forward convs: a self-consistency check
     # between fp32 runs, each within 2e-2 of the oracle.  Measured per parameter (tools/exp_linearity.py,
-    # profiles/r03r_direct_conv_accuracy.txt): <= 3.4e-4 everywhere except the two CWM5 weights behind two InstanceNorms of
+    # profiles/r03s_direct_conv_accuracy.txt): <= 3.4e-4 everywhere except the two CWM5 weights behind two InstanceNorms of
     # nearly constant maps, 8e-4 / 2.6e-3 with conv_direct_kernel (7.7e-4 worst with the tiled kernel, which is 2x LESS accurate)
     assert lin < 5e-3, lin
 
