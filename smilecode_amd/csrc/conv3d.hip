@@ -1762,6 +1762,12 @@ bool modetx_x3_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout);
 size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
                     int W, int Cin, int Cout, hipStream_t s);
+// bf16x3 weight gradient through LDS transpose reads (conv3d_wtr.hip): every layer the z-march kernel does not take
+// (Cin >= 12, and the few-channel layers below its voxel threshold); MODET_CONV_WTR=0 restores the exact-f32 kernels (A/B switch)
+bool modetx_wtr_eligible(int B, int D, int H, int W, int Cin, int Cout);
+size_t modetx_wtr_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
+                     int W, int Cin, int Cout, hipStream_t s);
 static bool use_x3(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
   return on && modetx_x3_eligible(B, D, H, W, Cin, Cout);
@@ -1769,6 +1775,10 @@ static bool use_x3(int B, int D, int H, int W, int Cin, int Cout) {
 static bool use_x3_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
   return on && modetx_x3_wgrad_eligible(B, D, H, W, Cin, Cout);
+}
+static bool use_wtr_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
+  static const bool on = [] { const char* e = getenv("MODET_CONV_WTR"); return !(e && e[0] == '0'); }();
+  return on && !use_x3_wgrad(B, D, H, W, Cin, Cout) && modetx_wtr_eligible(B, D, H, W, Cin, Cout);
 }
 // The tiled bf16x3 kernels of conv3d_bf16.hip (SP = 3): default for the MID levels of the pyramid -- Cin >= 16 channels at
 // 16 k .. 1 M voxels (levels 3-4: 16->32 / 32->32 forward 0.077 / 0.131 -> 0.054 / 0.086 ms, 64->64 0.080 -> 0.067); the
@@ -1791,7 +1801,7 @@ int modet_debug_conv_timing(long long* buf) {       // not in the header: tuning
 
 int modet_conv3d_kernel_family(int B, int D, int H, int W, int Cin, int Cout, int pass) {
   if (Cin == 1) return 0;
-  if (pass == 2) return use_x3_wgrad(B, D, H, W, Cin, Cout) ? 2 : 0;
+  if (pass == 2) return use_x3_wgrad(B, D, H, W, Cin, Cout) ? 2 : (use_wtr_wgrad(B, D, H, W, Cin, Cout) ? 4 : 0);
   const int ci = pass == 1 ? Cout : Cin, co = pass == 1 ? Cin : Cout;      // the data gradient convolves d_y (Cout channels)
   if (use_x3(B, D, H, W, ci, co)) return 2;
   if (use_split(ci, co, (int64_t)B * D * H * W)) return 1;
@@ -2031,6 +2041,10 @@ size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int
     const size_t x3 = modetx_x3_wgrad_ws_bytes(B, D, H, W, Cin, Cout);
     n = n > x3 ? n : x3;
   }
+  if (use_wtr_wgrad(B, D, H, W, Cin, Cout)) {
+    const size_t w3 = modetx_wtr_ws_bytes(B, D, H, W, Cin, Cout);
+    n = n > w3 ? n : w3;
+  }
   return n;
 }
 
@@ -2119,6 +2133,8 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
   }
   if (!y_act && use_x3_wgrad(B, D, H, W, Cin, Cout))
     return modetx_x3_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s);
+  if (!y_act && use_wtr_wgrad(B, D, H, W, Cin, Cout))
+    return modetx_wtr_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s);
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
   float* part = (float*)ws;
   if (p.np) {

@@ -670,6 +670,29 @@ __device__ __forceinline__ void wgrad_bf16_reduce_body(const float* __restrict__
     else if (dbias) dbias[co] = (float)a;
     return;
   }
+  if (layout == 2) {
+    // conv_wgrad_tr_kernel (conv3d_wtr.hip): CIB = NQ quads per channel block, U = MT real M tiles (+ 1 bias slot), NTB = NT;
+    // M tile mt holds the chunks q = 4 mt .. 4 mt + 3 of the list q = tap * NQ + quad, row = 4 (q & 3) + channel % 4
+    const int NQ = CIB, MT = U, NT = NTB;
+    const int RED_FL = (MT + 1) * NT * 256;
+    int co, by_ci = 0, mt, c = 0, e = 0;
+    if (i < nW) {
+      const int tap = i % 27, ci = (i / 27) % Cin;
+      co = i / (27 * Cin);
+      by_ci = ci / (4 * NQ);
+      const int q = tap * NQ + (ci % (4 * NQ)) / 4;
+      mt = q >> 2; c = q & 3; e = ci & 3;
+    } else {
+      co = i - nW; mt = MT;
+    }
+    const int cob = co / (16 * NT), nt = (co / 16) % NT, j = co % 16;
+    const size_t off = (size_t)(by_ci * n_coblk + cob) * RED_FL + (size_t)(mt * NT + nt) * 256 + (c * 16 + j) * 4 + e;
+    double a = 0.0;
+    for (int g = 0; g < gx; ++g) a += (double)part[(size_t)g * gy * RED_FL + off];
+    if (i < nW) dw[i] = (float)a;
+    else if (dbias) dbias[co] = (float)a;
+    return;
+  }
   const int SLOTS = U * 3 + 1, RED_FL = SLOTS * NTB * 256;
   const int GPB = CIB == 16 ? 9 : (CIB == 8 ? 5 : 3);
   int co, slot, m, chunk;
@@ -899,6 +922,21 @@ int modetx_wgrad_partials_reduce(modet_step_ctx* defer, const float* part, float
   hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, part, red, gx, row_fl);
   hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(cdiv(Cout * Cin * 27 + Cout, 256)), dim3(256), 0, s, (const float*)red, dw, db,
                      Cin, Cout, cib, u, 1, 1, 1, 1, layout);
+  return modet_launch_status();
+}
+
+// ---- conv3d_wtr.hip's partial layout (layout 2): gy = (channel blocks) x (cout blocks) partial sets per workgroup row
+int modetx_wgrad_partials_reduce2(modet_step_ctx* defer, const float* part, float* red, float* dw, float* db, int gx, int gy,
+                                  int Cin, int Cout, int nq, int mt, int nt, int n_coblk, hipStream_t s) {
+  const int64_t row_fl = (int64_t)gy * (mt + 1) * nt * 256;
+  if (defer) {
+    std::lock_guard<std::mutex> lk(defer->mu);
+    defer->brjobs.push_back(BRedJob{part, red, dw, db, row_fl, gx, Cin, Cout, nq, mt, nt, gy, n_coblk, 2});
+    return modet_launch_status();
+  }
+  hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, part, red, gx, row_fl);
+  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(cdiv(Cout * Cin * 27 + Cout, 256)), dim3(256), 0, s, (const float*)red, dw, db,
+                     Cin, Cout, nq, mt, nt, 1, gy, n_coblk, 2);
   return modet_launch_status();
 }
 

@@ -38,6 +38,7 @@ struct BRedJob {
   int gx, Cin, Cout, cib, u, ntb, gy, n_coblk;
   int layout;   // 0: slot = group * 3 + dx, n = cout (conv3d_bf16_wgrad_kernel, conv_x3_wgrad_kernel<.., NP = false>)
                 // 1: slot = group * 2 + t, n = q * 8 + cout (conv_x3_wgrad_kernel<.., NP = true>: d_y shifted by q voxels)
+                // 2: conv_wgrad_tr_kernel (conv3d_wtr.hip): cib = NQ, u = MT, ntb = NT; M tile = 4 chunks of q = tap * NQ + quad
 };
 
 struct modet_step_ctx {

@@ -152,7 +152,7 @@ class trace_range:
 
 
 _FAM_CACHE = {}
-_FAM_SUFFIX = ("", "@split", "@x3", "@direct")
+_FAM_SUFFIX = ("", "@split", "@x3", "@direct", "@tr")
 
 
 def _conv_tag(kind, x_shape, Cin, Cout):
