@@ -1774,7 +1774,9 @@ static bool use_x3(int B, int D, int H, int W, int Cin, int Cout) {
 }
 static bool use_x3_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
-  return on && modetx_x3_wgrad_eligible(B, D, H, W, Cin, Cout);
+  static const bool wtr_first = [] { const char* e = getenv("MODET_CONV_WTR"); return e && e[0] == '2'; }();   // experiment: tr kernel everywhere
+  // Cout = 16 (8 -> 16 at level 2) runs 1.7x faster on the transpose-read kernel (102 -> 60 us): the march keeps Cout <= 8
+  return on && !wtr_first && Cout <= 8 && modetx_x3_wgrad_eligible(B, D, H, W, Cin, Cout);
 }
 static bool use_wtr_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = [] { const char* e = getenv("MODET_CONV_WTR"); return !(e && e[0] == '0'); }();

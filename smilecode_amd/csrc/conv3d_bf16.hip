@@ -671,8 +671,9 @@ __device__ __forceinline__ void wgrad_bf16_reduce_body(const float* __restrict__
     return;
   }
   if (layout == 2) {
-    // conv_wgrad_tr_kernel (conv3d_wtr.hip): CIB = NQ quads per channel block, U = MT real M tiles (+ 1 bias slot), NTB = NT;
-    // M tile mt holds the chunks q = 4 mt .. 4 mt + 3 of the list q = tap * NQ + quad, row = 4 (q & 3) + channel % 4
+    // conv_wgrad_tr_kernel (conv3d_wtr.hip): CIB = NQ quads per channel block, U = MT = 3 NF real M tiles (+ 1 bias slot),
+    // NTB = NT; M tile mt = 3 f + dx, family f holds the chunks q = 4 f .. 4 f + 3 of the list q = (dz, dy) * NQ + quad,
+    // row = 4 (q & 3) + channel % 4
     const int NQ = CIB, MT = U, NT = NTB;
     const int RED_FL = (MT + 1) * NT * 256;
     int co, by_ci = 0, mt, c = 0, e = 0;
@@ -680,8 +681,8 @@ __device__ __forceinline__ void wgrad_bf16_reduce_body(const float* __restrict__
       const int tap = i % 27, ci = (i / 27) % Cin;
       co = i / (27 * Cin);
       by_ci = ci / (4 * NQ);
-      const int q = tap * NQ + (ci % (4 * NQ)) / 4;
-      mt = q >> 2; c = q & 3; e = ci & 3;
+      const int q = (tap / 3) * NQ + (ci % (4 * NQ)) / 4;
+      mt = (q >> 2) * 3 + tap % 3; c = q & 3; e = ci & 3;
     } else {
       co = i - nW; mt = MT;
     }

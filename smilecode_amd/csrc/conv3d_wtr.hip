@@ -9,24 +9,27 @@
 // The contraction index is the VOXEL, but channels-last tensors hold consecutive CHANNELS of one voxel: both MFMA operands
 // want "8 consecutive k of one row/column per lane", i.e. a transposed image.  The earlier kernels (conv3d.hip
 // conv3d_wgrad_kernel: exact-f32 MFMA; conv3d_bf16.hip / conv3d_x3.hip: channel-planar LDS planes written voxel pair by
-// voxel pair, x taps by funnel shifts) pay for that transposition in the staging pass.  Here the LDS image is the tensor's
-// own layout -- [voxel][16 channels] bf16 rows of 32 bytes, one image per bf16 piece -- written with plain 8-byte stores,
-// and ds_read_b64_tr_b16 transposes on the way out: within a 16-lane group, lane 4j + c supplies the address of 4 bf16
-// (row j = which k, chunk c = which 4 channels) and lane t receives {row 0..3} of column t (chunk t >> 2, element t & 3)
-// (probed on the chip: tools/micro/tr16_probe.hip).  Because every lane supplies its OWN address,
-//   * a chunk may point at any (tap, channel quad): the 16 rows of an M tile are 4 consecutive entries of the list
-//     q = tap * NQ + quad, so channel counts 12, 24, 48 (NQ = 3 quads per block) and 6 (2 quads) fill M tiles with no padding
-//     (the exact-f32 kernel runs Cin = 12 as three 4-channel tiles and 12 -> 2 at 9.5 TFLOP/s);
-//   * a tap is only an address offset: no shifted copies, no alignbit.
-// k-step = 32 voxels = 4 (y) x 8 (x) of the 2 x 8 x 8 voxel tile: read r in {0,1} of lane group kg covers row 4 yq + 2 r +
-// (kg >> 1), x = 4 (kg & 1) + j, so a 32-lane half reads 8 consecutive voxels = 256 contiguous bytes (conflict-free), and A
-// and B use the same k order.  x3 arithmetic: operands hi + mid + lo (exact to 2^-24), six piece products of order <= 2,
-// small terms first, fp32 accumulate.
+// voxel pair) pay for that transposition in the staging pass.  Here the LDS image is the tensor's own layout -- [voxel][16
+// channels] bf16 rows of 32 bytes, one image per bf16 piece -- written with plain 8-byte stores, and ds_read_b64_tr_b16
+// transposes on the way out: within a 16-lane group, lane 4j + c supplies the address of 4 bf16 (row j = which k, chunk c =
+// which 4 channels) and lane t receives {row 0..3} of column t (chunk t >> 2, element t & 3) (probed on the chip:
+// tools/micro/tr16_probe.hip).  Every lane supplies its OWN address, so a chunk may point at any (dz, dy, channel quad): the
+// 16 rows of an M tile are 4 consecutive entries of the list q = (dz, dy) * NQ + quad, and channel counts 12, 24, 48 (NQ = 3
+// quads per block) or 6 (2 quads) fill M tiles without padding (the exact-f32 kernel runs 12 -> 2 at 9.5 TFLOP/s).
+//
+// k-step = 32 voxels = 4 rows (lane group kg) x 8 x of the 2 x 8 x 8 voxel tile; a lane's 8 k values are 8 consecutive x.
+// The three x taps of a (dz, dy) come from ONE set of reads: three 4-voxel blocks = slots x - 1 .. x + 10 of the halo'd row
+// give the fragments of dx = 0 (registers 0..3), dx = 2 (registers 1..4) and dx = 1 (four v_alignbit) -- 9 transpose reads
+// per 18 MFMAs (a first version read every tap separately: 1 read per MFMA, LDS-bound at 0.4 of the matrix pipe's rate).
+// Row pitch 12 voxel slots (384 B) for x and an x ^ 4 (y & 1) swizzle for d_y put the two rows a 32-lane half reads on
+// disjoint bank halves.  x3 arithmetic: operands hi + mid + lo (exact to 2^-24), six piece products of order <= 2, small
+// terms first, fp32 accumulate; the three taps of a family alternate accumulators (no dependent MFMA chains).
 //
 // Work split.  Workgroup = (voxel tiles [persistent over gridDim.x], channel block of NQ quads, cout block of NT x 16).
-// Its four waves own DISJOINT M tiles (mt = wave + 4 mi), so nothing is summed across waves: every wave stores its own
-// accumulators as fragment-major partial tiles, which the two-stage fp64 reduction of conv3d_bf16.hip (layout 2) sums over
-// the workgroups in fixed order (deterministic).  The bias gradient rides in the first free M-tile slot (A = ones).
+// Wave w owns k-step w of every tile (NT = 2: N tile w & 1, k-steps 2 (w >> 1) and + 1) and ALL M tiles: 27 (+ bias) x 4
+// accumulator registers; at the end of the workgroup's life the waves are summed through LDS in fixed order and ONE
+// fragment-major partial goes to memory, which the two-stage fp64 reduction of conv3d_bf16.hip (layout 2) sums over the
+// workgroups (deterministic).  The bias gradient is one more accumulator (A = ones).
 #include "common.h"
 #include "step_ctx.h"
 
@@ -42,8 +45,10 @@ using BufRsrc = __amdgpu_buffer_rsrc_t;
 constexpr int NTHR = 256;
 constexpr int TZ = 2, TY = 8, TX = 8, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
 constexpr int HVOX = HZ * HY * HX, VOX = TZ * TY * TX;
-constexpr int ROWB = 32;                               // bytes of one voxel row of a 16-channel bf16 image
-constexpr int XPL = HVOX * ROWB, DPL = VOX * ROWB;     // one piece of the x tile / one (piece, N tile) of the d_y tile
+constexpr int ROWB = 32;                               // bytes of one voxel slot of a 16-channel bf16 image
+constexpr int XP = 12;                                 // slots per halo'd x row (10 used: pitch 384 B = odd multiple of 128 B)
+constexpr int XPL = HZ * HY * XP * ROWB;               // one piece of the x tile
+constexpr int DPL = VOX * ROWB;                        // one (piece, N tile) of the d_y tile (x swizzled by 4 (y & 1))
 constexpr unsigned WTR_OOB = 0x80000000u;              // tensors are < 2 GiB (checked on the host): this offset reads 0
 
 __device__ __forceinline__ BufRsrc tensor_rsrc(const float* base, unsigned bytes) {
@@ -66,222 +71,284 @@ __device__ __forceinline__ void split3_pk(float a, float b, unsigned& hi, unsign
   const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
   lo = pk(sa, sb);
 }
-__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lds, int off0, int off1) {
+__device__ __forceinline__ uint2 tr_read(const unsigned char* lds, int off) {
   typedef __attribute__((address_space(3))) v4s* lptr;
-  const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off0));
-  const v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off1));
-  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off)));
 }
+__device__ __forceinline__ bf16x8 frag(unsigned a, unsigned b, unsigned c, unsigned d) {
+  const u32x4 v = {a, b, c, d};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+#ifdef MODET_TUNING
+__device__ long long* g_wtr_dbg = nullptr;
+#endif
 
 struct WtrArgs {
   const float* x; const float* dy; float* part;
   int B, D, H, W, Cin, Cout, tiles_x, tiles_y, tiles_z, ntiles, n_coblk;
 };
 
-template <int NQ, int NT>
 #ifndef WTR_VARIANT
-#define WTR_VARIANT 2
+#define WTR_VARIANT 8
 #endif
-// WTR_VARIANT bit 0: two workgroups per CU for NT = 1 too (256 registers); bit 1: no register prefetch of the next tile
-__global__ __launch_bounds__(NTHR, (NT == 1 && !(WTR_VARIANT & 1)) ? 3 : 2) void conv_wgrad_tr_kernel(const WtrArgs a) {
-  constexpr int MT = (27 * NQ + 3) / 4;                // M tiles holding real (tap, quad) chunks; slot MT = bias tile
-  constexpr int MT_W = (MT + 1 + 3) / 4;               // M-tile slots per wave
-  constexpr int BIAS_W = MT % 4, BIAS_MI = MT / 4;
+// WTR_VARIANT bit 1: no register prefetch of the next tile's global loads; bit 2: no operand prefetch of the next family
+template <int NQ, int NT, bool VEC>
+__global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrArgs a) {
+  constexpr int NF = (9 * NQ + 3) / 4;                 // families: 4 chunks of the list q = (dz, dy) * NQ + quad
+  constexpr int MT = 3 * NF;                           // M tiles = (family, dx); slot MT = bias
+  constexpr int KS = NT;                               // k-steps per wave and tile
   constexpr int XS_BYTES = 3 * XPL, DS_BYTES = 3 * NT * DPL;
-  constexpr int NXI = (HVOX * NQ + NTHR - 1) / NTHR;   // 16-byte x items per thread and tile
-  constexpr int NDI = (VOX * NT * 4) / NTHR;           // 16-byte d_y items per thread and tile
-  __shared__ __attribute__((aligned(16))) unsigned char lds[XS_BYTES + DS_BYTES];
+  constexpr int RED_FL = (MT + 1) * NT * 256;
+  constexpr int LDS_BYTES = XS_BYTES + DS_BYTES > RED_FL * 4 ? XS_BYTES + DS_BYTES : RED_FL * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
+#ifdef MODET_TUNING
+  const long long t_entry = __builtin_readcyclecounter();
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = lane >> 4, S = lane & 15, sj = S >> 2, sc = S & 3;
-  const int xl = 4 * (kg & 1) + sj, yl = kg >> 1;
+  const int nw = NT == 2 ? (wave & 1) : 0;             // this wave's N tile
+  const int s_first = NT == 2 ? 2 * (wave >> 1) : wave;                 // its first k-step: z = s >> 1, rows 4 (s & 1) + kg
   const int cib = blockIdx.y / a.n_coblk, cob = blockIdx.y - cib * a.n_coblk;
   const int ci0 = cib * 4 * NQ, co0 = cob * 16 * NT;
   const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
 
-  int aoff[MT_W];
+  // supplier addresses: lane 4j + c of a group supplies slot x-block + j of chunk c
+  int aoff[NF];
 #pragma unroll
-  for (int mi = 0; mi < MT_W; ++mi) {
-    int q = (wave + 4 * mi) * 4 + sc;
-    if (q >= 27 * NQ) q = 0;                           // dummy chunks: finite data, never reduced
-    const int tap = q / NQ, quad = q - tap * NQ;
-    const int dz = tap / 9, dyy = (tap / 3) % 3, dx = tap % 3;
-    aoff[mi] = ((dz * HY + dyy + yl) * HX + dx + xl) * ROWB + quad * 8;
+  for (int f = 0; f < NF; ++f) {
+    int q = 4 * f + sc;
+    if (q >= 9 * NQ) q = 0;                            // dummy chunks: finite data, never reduced
+    const int zy = q / NQ, quad = q - zy * NQ;
+    aoff[f] = ((zy / 3) * HY + zy % 3) * XP * ROWB + quad * 8;
   }
-  const int boff = XS_BYTES + (yl * TX + xl) * ROWB + sc * 8;
-  const bool bias_wave = wave == BIAS_W;
-  const unsigned one2 = S == 0 ? 0x3f803f80u : 0u;     // A = ones: row 0 (lane & 15 == 0) of the bias tile, hi piece
+  const int abase = (((s_first >> 1) * HY + 4 * (s_first & 1) + kg) * XP + sj) * ROWB;
+  const int yrow = 4 * (s_first & 1) + kg;             // (NT = 2: the second k-step is 4 rows further, same parity)
+  const int bslot = ((s_first >> 1) * TY + yrow) * TX;
+  const int bsw = (kg & 1) << 2;
+  const int boff0 = XS_BYTES + nw * DPL + (bslot + (sj ^ bsw)) * ROWB + sc * 8;           // x = 0..3
+  const int boff1 = XS_BYTES + nw * DPL + (bslot + ((4 + sj) ^ bsw)) * ROWB + sc * 8;     // x = 4..7
+  const unsigned one2 = S == 0 ? 0x3f803f80u : 0u;     // A = ones (hi piece): row 0 of the bias tile
 
-  f32x4 acc[MT_W][NT];
+  f32x4 acc[NF][3], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int mi = 0; mi < MT_W; ++mi)
+  for (int f = 0; f < NF; ++f)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[mi][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < 3; ++d) acc[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const BufRsrc rx = tensor_rsrc(a.x, (unsigned)((int64_t)a.B * D * H * W * Cin * 4));
   const BufRsrc rd = tensor_rsrc(a.dy, (unsigned)((int64_t)a.B * D * H * W * Cout * 4));
-  const bool xvec = (Cin & 3) == 0, dvec = (Cout & 3) == 0;
 
-  u32x4 xr[NXI], dr[NDI];
+  // ---- staging roles (tile-invariant): the halo'd x tile is 40 rows (hz, hy) of IPR = 10 NQ 16-byte items; a pass covers RP
+  // whole rows (RP | 10 or 10 | RP, so a pass's (hz, hy) are compile-time + per-thread constants: no divisions per item)
+  constexpr int IPR = HX * NQ, RP = NQ >= 3 ? 5 : (NQ == 2 ? 10 : 20), NPASS = HZ * HY / RP;
+  const int r_t = tid / IPR, i_t = tid - r_t * IPR;
+  const bool x_act = r_t < RP;
+  const int hx_t = i_t / NQ, qd_t = i_t - hx_t * NQ;
+  const int hzo_t = RP == 20 ? r_t / HY : 0, hy_t = RP == 20 ? r_t - hzo_t * HY : r_t;
+  const int cx_t = ci0 + qd_t * 4;
+  const int xlds_t = ((hzo_t * HY + hy_t) * XP + hx_t) * ROWB + qd_t * 8;
+  // d_y tile: 128 voxels x 4 NT items, a pass = 256 / (4 NT) voxels
+  constexpr int DVP = NTHR / (4 * NT), NDP = VOX / DVP;
+  const int dr_t = tid % (4 * NT), dv_t = tid / (4 * NT);
+  const int cd_t = co0 + dr_t * 4;
+  const int dlds_t = XS_BYTES + (dr_t >> 2) * DPL + (dr_t & 3) * 8;
+
+  u32x4 xr[NPASS], dr[NDP];
   auto load_tile = [&](int tl) {
     int t = tl;
     const int x0 = (t % a.tiles_x) * TX; t /= a.tiles_x;
     const int y0 = (t % a.tiles_y) * TY; t /= a.tiles_y;
     const int z0 = (t % a.tiles_z) * TZ;
     const int vb = (t / a.tiles_z) * D;                // sample * D
+    const int xx = x0 - 1 + hx_t;
+    const bool xok = x_act && xx >= 0 && xx < W && cx_t < Cin;
+    const unsigned xterm = ((unsigned)xx * (unsigned)Cin + (unsigned)cx_t) * 4u;
+    const unsigned rowb = (unsigned)(W * Cin) * 4u;
 #pragma unroll
-    for (int i = 0; i < NXI; ++i) {
-      const int idx = tid + i * NTHR;
-      const int hv = idx / NQ, qd = idx - hv * NQ;
-      const int hx = hv % HX, t2 = hv / HX;
-      const int hy = t2 % HY, hz = t2 / HY;
-      const int z = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
-      const int c = ci0 + qd * 4;
-      const bool ok = idx < HVOX * NQ && z >= 0 && z < D && yy >= 0 && yy < H && xx >= 0 && xx < W && c < Cin;
-      const unsigned off = ((unsigned)(((vb + z) * H + yy) * W + xx) * (unsigned)Cin + (unsigned)c) * 4u;
-      if (xvec) {
+    for (int i = 0; i < NPASS; ++i) {
+      const int row0 = i * RP;                         // compile-time: first row of the pass
+      const int z = z0 - 1 + row0 / HY + hzo_t, yy = y0 - 1 + row0 % HY + hy_t;
+      const bool ok = xok && z >= 0 && z < D && yy >= 0 && yy < H;
+      const unsigned off = (unsigned)((vb + z) * H + yy) * rowb + xterm;
+      if (VEC) {
         xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : WTR_OOB, 0, 0);
       } else {
         u32x4 v;
         v[0] = __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? off : WTR_OOB, 0, 0);
-        v[1] = __builtin_amdgcn_raw_buffer_load_b32(rx, ok && c + 1 < Cin ? off + 4 : WTR_OOB, 0, 0);
-        v[2] = __builtin_amdgcn_raw_buffer_load_b32(rx, ok && c + 2 < Cin ? off + 8 : WTR_OOB, 0, 0);
-        v[3] = __builtin_amdgcn_raw_buffer_load_b32(rx, ok && c + 3 < Cin ? off + 12 : WTR_OOB, 0, 0);
+        v[1] = __builtin_amdgcn_raw_buffer_load_b32(rx, ok && cx_t + 1 < Cin ? off + 4 : WTR_OOB, 0, 0);
+        v[2] = __builtin_amdgcn_raw_buffer_load_b32(rx, ok && cx_t + 2 < Cin ? off + 8 : WTR_OOB, 0, 0);
+        v[3] = __builtin_amdgcn_raw_buffer_load_b32(rx, ok && cx_t + 3 < Cin ? off + 12 : WTR_OOB, 0, 0);
         xr[i] = v;
       }
     }
+    const unsigned rowd = (unsigned)(W * Cout) * 4u;
 #pragma unroll
-    for (int i = 0; i < NDI; ++i) {
-      const int idx = tid + i * NTHR;
-      const int v = idx / (NT * 4), r = idx - v * (NT * 4);      // voxel of the tile, (N tile, quad)
-      const int xx = x0 + (v & 7), yy = y0 + ((v >> 3) & 7), z = z0 + (v >> 6);
-      const int c = co0 + r * 4;
-      const bool ok = z < D && yy < H && xx < W && c < Cout;
-      const unsigned off = ((unsigned)(((vb + z) * H + yy) * W + xx) * (unsigned)Cout + (unsigned)c) * 4u;
-      if (dvec) {
+    for (int i = 0; i < NDP; ++i) {
+      const int v = i * DVP + dv_t;                    // voxel of the tile: z = v >> 6, y = (v >> 3) & 7, x = v & 7
+      const int xd = x0 + (v & 7), yy = y0 + ((v >> 3) & 7), z = z0 + (v >> 6);
+      const bool ok = z < D && yy < H && xd < W && cd_t < Cout;
+      const unsigned off = (unsigned)((vb + z) * H + yy) * rowd + ((unsigned)xd * (unsigned)Cout + (unsigned)cd_t) * 4u;
+      if (VEC) {
         dr[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? off : WTR_OOB, 0, 0);
       } else {
         u32x4 w4;
         w4[0] = __builtin_amdgcn_raw_buffer_load_b32(rd, ok ? off : WTR_OOB, 0, 0);
-        w4[1] = __builtin_amdgcn_raw_buffer_load_b32(rd, ok && c + 1 < Cout ? off + 4 : WTR_OOB, 0, 0);
-        w4[2] = __builtin_amdgcn_raw_buffer_load_b32(rd, ok && c + 2 < Cout ? off + 8 : WTR_OOB, 0, 0);
-        w4[3] = __builtin_amdgcn_raw_buffer_load_b32(rd, ok && c + 3 < Cout ? off + 12 : WTR_OOB, 0, 0);
+        w4[1] = __builtin_amdgcn_raw_buffer_load_b32(rd, ok && cd_t + 1 < Cout ? off + 4 : WTR_OOB, 0, 0);
+        w4[2] = __builtin_amdgcn_raw_buffer_load_b32(rd, ok && cd_t + 2 < Cout ? off + 8 : WTR_OOB, 0, 0);
+        w4[3] = __builtin_amdgcn_raw_buffer_load_b32(rd, ok && cd_t + 3 < Cout ? off + 12 : WTR_OOB, 0, 0);
         dr[i] = w4;
       }
     }
   };
   auto write_tile = [&]() {
+    if (x_act) {
 #pragma unroll
-    for (int i = 0; i < NXI; ++i) {
-      const int idx = tid + i * NTHR;
-      if (idx < HVOX * NQ) {
-        const int hv = idx / NQ, qd = idx - hv * NQ;
+      for (int i = 0; i < NPASS; ++i) {
         unsigned h0, m0, l0, h1, m1, l1;
         split3_pk(__uint_as_float(xr[i][0]), __uint_as_float(xr[i][1]), h0, m0, l0);
         split3_pk(__uint_as_float(xr[i][2]), __uint_as_float(xr[i][3]), h1, m1, l1);
-        unsigned char* dst = lds + hv * ROWB + qd * 8;
+        unsigned char* dst = lds + xlds_t + i * RP * XP * ROWB;
         *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(dst + XPL) = make_uint2(m0, m1);
         *reinterpret_cast<uint2*>(dst + 2 * XPL) = make_uint2(l0, l1);
       }
     }
 #pragma unroll
-    for (int i = 0; i < NDI; ++i) {
-      const int idx = tid + i * NTHR;
-      const int v = idx / (NT * 4), r = idx - v * (NT * 4);
-      const int n = r >> 2, qd = r & 3;
+    for (int i = 0; i < NDP; ++i) {
+      const int v = i * DVP + dv_t;
+      const int slot = (v & ~7) | ((v & 7) ^ (((v >> 3) & 1) << 2));          // x ^ 4 (y & 1)
       unsigned h0, m0, l0, h1, m1, l1;
       split3_pk(__uint_as_float(dr[i][0]), __uint_as_float(dr[i][1]), h0, m0, l0);
       split3_pk(__uint_as_float(dr[i][2]), __uint_as_float(dr[i][3]), h1, m1, l1);
-      unsigned char* dst = lds + XS_BYTES + n * DPL + v * ROWB + qd * 8;
+      unsigned char* dst = lds + dlds_t + slot * ROWB;
       *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(dst + NT * DPL) = make_uint2(m0, m1);
       *reinterpret_cast<uint2*>(dst + 2 * NT * DPL) = make_uint2(l0, l1);
     }
   };
 
+#ifdef MODET_TUNING
+  long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tq0, tq1;      // cycles in: load issue | barrier 1 | split + LDS write (incl. the wait for the loads) | barrier 2 | MFMA phase
+#define TPH(k) do { tq1 = __builtin_readcyclecounter(); tph[k] += tq1 - tq0; tq0 = tq1; } while (0)
+#else
+#define TPH(k) do { } while (0)
+#endif
   int tile = blockIdx.x;
   if (!(WTR_VARIANT & 2) && tile < a.ntiles) load_tile(tile);
+#ifdef MODET_TUNING
+  tq0 = __builtin_readcyclecounter();
+  tph[5] = tq0 - t_entry;
+#endif
   for (; tile < a.ntiles; tile += gridDim.x) {
     if (WTR_VARIANT & 2) load_tile(tile);
+    TPH(0);
     __syncthreads();                                   // every wave is done with the previous tile's images
+    TPH(1);
+    if (WTR_VARIANT & 8) __builtin_amdgcn_s_setprio(2);     // staging is VALU work beside the other workgroup's MFMA phase
     write_tile();
+    TPH(2);
     __syncthreads();
+    TPH(3);
     if (!(WTR_VARIANT & 2) && tile + (int)gridDim.x < a.ntiles) load_tile(tile + gridDim.x);
-    // ---- MFMA phase, software-pipelined by hand (left alone, hipcc emits read x 6 -> lgkmcnt(0) -> six MFMAs chained on one
-    // accumulator).  Unit u = (k-step s = u / MT_W, M-tile slot mi = u % MT_W); units run in PAIRS so that consecutive MFMAs
-    // alternate between two accumulators, and the operand reads of pair P + 1 (and the d_y fragments of a k-step the next
-    // pair enters) are issued before the MFMAs of pair P.
-    constexpr int NU = 4 * MT_W, G = NT == 1 ? 2 : 1, NP = NU / G;    // NT = 2: the two N tiles already alternate accumulators
-    static_assert(NU % G == 0, "units come in groups");
-    auto load_a = [&](int u, bf16x8 (&af)[3]) {
-      const int s = u / MT_W, mi = u - s * MT_W;
-      const int sx = ((s >> 1) * HY * HX + (s & 1) * 4 * HX) * ROWB;      // k-step s: z = s >> 1, rows 4 (s & 1) ..
-#pragma unroll
-      for (int p = 0; p < 3; ++p) af[p] = tr_pair(lds, aoff[mi] + p * XPL + sx, aoff[mi] + p * XPL + sx + 2 * HX * ROWB);
-    };
-    auto load_b = [&](int s, bf16x8 (&bf)[3][NT]) {
-      const int sd = s * 32 * ROWB;
+    if (WTR_VARIANT & 8) __builtin_amdgcn_s_setprio(0);
+    TPH(0);
+    // ---- MFMA phase.  Unit = (k-step ks, family f): 9 transpose reads -> fragments of dx = 0, 1, 2 -> 18 MFMAs on three
+    // accumulators; the reads of the next unit are issued before the MFMAs of this one (left alone, hipcc emits
+    // read -> lgkmcnt(0) -> MFMA chains).
+    auto load_raw = [&](int u, uint2 (&R)[3][3]) {
+      const int ks = u / NF, f = u - ks * NF;
+      const int o = abase + aoff[f] + ks * 4 * XP * ROWB;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          bf[p][n] = tr_pair(lds, boff + (p * NT + n) * DPL + sd, boff + (p * NT + n) * DPL + sd + 2 * TX * ROWB);
+        for (int b = 0; b < 3; ++b) R[p][b] = tr_read(lds, o + p * XPL + b * 4 * ROWB);
     };
-    bf16x8 ac[G][3], an[G][3], bb[2][3][NT];
-    load_b(0, bb[0]);
+    uint2 Rc[3][3], Rn[3][3];
+    bf16x8 bq[3];
+    load_raw(0, Rc);
 #pragma unroll
-    for (int g = 0; g < G; ++g) load_a(g, ac[g]);
+    for (int u = 0; u < KS * NF; ++u) {
+      const int ks = u / NF, f = u - ks * NF;
+      if (f == 0) {
 #pragma unroll
-    for (int P = 0; P < NP; ++P) {
-      const int ul = G * P + G - 1, sl = ul / MT_W;                      // last unit of this group and its k-step
-      if (P + 1 < NP) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const int sn = (G * (P + 1) + g) / MT_W;
-          if (sn > sl && (g == 0 || (G * (P + 1) + g - 1) / MT_W == sl)) load_b(sn, bb[sn & 1]);   // a k-step the next group enters
+        for (int p = 0; p < 3; ++p) {
+          const uint2 lo = tr_read(lds, boff0 + p * NT * DPL + ks * 4 * TX * ROWB), hi = tr_read(lds, boff1 + p * NT * DPL + ks * 4 * TX * ROWB);
+          bq[p] = frag(lo.x, lo.y, hi.x, hi.y);
         }
-#pragma unroll
-        for (int g = 0; g < G; ++g) load_a(G * (P + 1) + g, an[g]);
       }
+      if (!(WTR_VARIANT & 4) && u + 1 < KS * NF) load_raw(u + 1, Rn);
       __builtin_amdgcn_sched_barrier(0);
+      if (f == 0) {                                    // d_bias: ones x d_y (the mid / lo pieces of "ones" are zero)
+        const bf16x8 on = frag(one2, one2, one2, one2);
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(on, bq[2], accb, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(on, bq[1], accb, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(on, bq[0], accb, 0, 0, 0);
+      }
+      bf16x8 d0[3], d1[3], d2[3];
 #pragma unroll
-      for (int g = 0; g < G; ++g)
-        if ((G * P + g) % MT_W == BIAS_MI) {           // the bias tile lives in exactly one (wave, mi) slot
-          const u32x4 o4 = {one2, one2, one2, one2}, z4 = {0u, 0u, 0u, 0u};
-          ac[g][0] = bias_wave ? __builtin_bit_cast(bf16x8, o4) : ac[g][0];
-          ac[g][1] = bias_wave ? __builtin_bit_cast(bf16x8, z4) : ac[g][1];
-          ac[g][2] = bias_wave ? __builtin_bit_cast(bf16x8, z4) : ac[g][2];
-        }
-#define MMG(PA, PB)                                                                                                        \
-      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                                       \
-        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                                    \
-          const int u = G * P + g, su = u / MT_W, mu = u - su * MT_W;                                                      \
-          acc[mu][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[g][PA], bb[su & 1][PB][n], acc[mu][n], 0, 0, 0);         \
-        }
-      MMG(2, 0) MMG(0, 2) MMG(1, 1) MMG(1, 0) MMG(0, 1) MMG(0, 0)
-#undef MMG
+      for (int p = 0; p < 3; ++p) {
+        const unsigned r0 = Rc[p][0].x, r1 = Rc[p][0].y, r2 = Rc[p][1].x, r3 = Rc[p][1].y, r4 = Rc[p][2].x;
+        d0[p] = frag(r0, r1, r2, r3);
+        d2[p] = frag(r1, r2, r3, r4);
+        d1[p] = frag(__builtin_amdgcn_alignbit(r1, r0, 16), __builtin_amdgcn_alignbit(r2, r1, 16),
+                     __builtin_amdgcn_alignbit(r3, r2, 16), __builtin_amdgcn_alignbit(r4, r3, 16));
+      }
+#define MM3(PA, PB)                                                                                   \
+      acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0[PA], bq[PB], acc[f][0], 0, 0, 0);       \
+      acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1[PA], bq[PB], acc[f][1], 0, 0, 0);       \
+      acc[f][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d2[PA], bq[PB], acc[f][2], 0, 0, 0);
+      MM3(2, 0) MM3(0, 2) MM3(1, 1) MM3(1, 0) MM3(0, 1) MM3(0, 0)
+#undef MM3
       __builtin_amdgcn_sched_barrier(0);
-      if (P + 1 < NP) {
+      if (u + 1 < KS * NF) {
+        if (WTR_VARIANT & 4) load_raw(u + 1, Rc);
+        else {
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+          for (int p = 0; p < 3; ++p)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) ac[g][p] = an[g][p];
+            for (int b = 0; b < 3; ++b) Rc[p][b] = Rn[p][b];
+        }
       }
     }
+    TPH(4);
   }
-  // fragment-major partial tiles: part[bx][by][mt <= MT][n][lane * 4 + reg]
-  float* out = a.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)((MT + 1) * NT * 256);
+  // ---- sum the waves that share an N tile through LDS in fixed order; ONE fragment-major partial per workgroup:
+  // part[bx][by][mt <= MT][n][lane * 4 + reg]
+  float* red = reinterpret_cast<float*>(lds);
+  constexpr int ROUNDS = 4 / NT;
+#pragma unroll 1
+  for (int r = 0; r < ROUNDS; ++r) {
+    __syncthreads();
+    if ((NT == 2 ? (wave >> 1) : wave) == r) {
 #pragma unroll
-  for (int mi = 0; mi < MT_W; ++mi) {
-    const int mt = wave + 4 * mi;
-    if (mt > MT) continue;
+      for (int f = 0; f < NF; ++f)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-      *reinterpret_cast<float4*>(out + (size_t)(mt * NT + n) * 256 + lane * 4) =
-          make_float4(acc[mi][n][0], acc[mi][n][1], acc[mi][n][2], acc[mi][n][3]);
+        for (int d = 0; d < 3; ++d) {
+          float4* slot = reinterpret_cast<float4*>(red + ((f * 3 + d) * NT + nw) * 256) + lane;
+          float4 v = make_float4(acc[f][d][0], acc[f][d][1], acc[f][d][2], acc[f][d][3]);
+          if (r > 0) { const float4 o = *slot; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          *slot = v;
+        }
+      float4* slot = reinterpret_cast<float4*>(red + (MT * NT + nw) * 256) + lane;
+      float4 v = make_float4(accb[0], accb[1], accb[2], accb[3]);
+      if (r > 0) { const float4 o = *slot; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      *slot = v;
+    }
   }
+  __syncthreads();
+  float* out = a.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)RED_FL;
+  for (int i = tid * 4; i < RED_FL; i += NTHR * 4) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(red + i);
+#ifdef MODET_TUNING
+  TPH(6);
+  if (g_wtr_dbg && lane == 0) {
+    long long* o = g_wtr_dbg + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    for (int i = 0; i < 7; ++i) o[i] = tph[i];
+    o[7] = t_entry;
+  }
+#endif
 }
 
 struct WtrPlan { int nq, nt, n_cib, n_coblk, gy, gx, tiles_x, tiles_y, tiles_z, ntiles, mt, red_fl; };
@@ -295,28 +362,35 @@ inline WtrPlan wtr_plan(int B, int D, int H, int W, int Cin, int Cout) {
   p.gy = p.n_cib * p.n_coblk;
   p.tiles_x = cdiv(W, TX); p.tiles_y = cdiv(H, TY); p.tiles_z = cdiv(D, TZ);
   p.ntiles = B * p.tiles_x * p.tiles_y * p.tiles_z;
-  const int slots = p.nt == 1 ? 768 : 512;             // resident workgroups (LDS: 50 / 62 KB)
+  const int slots = 512;                               // resident workgroups (LDS 58 / 71 KB, <= 256 registers: two per CU)
   int gx = slots / p.gy;
   if (gx < 1) gx = 1;
   if (gx > p.ntiles) gx = p.ntiles;
   p.gx = gx;
-  p.mt = (27 * p.nq + 3) / 4;
+  p.mt = 3 * ((9 * p.nq + 3) / 4);
   p.red_fl = (p.mt + 1) * p.nt * 256;
   return p;
 }
 
 }  // namespace
 
+#ifdef MODET_TUNING
+extern "C" int modet_debug_wtr_timing(long long* buf) {       // not in the header: tuning builds only
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wtr_dbg), &buf, sizeof(buf));
+}
+#endif
+
 // ---- internal interface for conv3d.hip (C++ linkage, not part of the ABI)
 int modetx_wgrad_partials_reduce2(modet_step_ctx* defer, const float* part, float* red, float* dw, float* db, int gx, int gy,
                                   int Cin, int Cout, int nq, int mt, int nt, int n_coblk, hipStream_t s);      // conv3d_bf16.hip
 bool modetx_wtr_eligible(int B, int D, int H, int W, int Cin, int Cout) {
   const int64_t n = (int64_t)B * D * H * W;
-  return Cin >= 4 && n * (Cin > Cout ? Cin : Cout) * 4 < 0x7fffffffLL && Cout <= 256 && Cin <= 1024;
+  const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
+  return Cin >= 4 && n * (Cin > Cout ? Cin : Cout) * 4 < 0x7fffffffLL && Cout <= 256 && Cin <= 1024 && (vec || Cout <= 16);
 }
 size_t modetx_wtr_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   const WtrPlan p = wtr_plan(B, D, H, W, Cin, Cout);
-  const int gx = p.gy >= 768 ? 1 : 768 / p.gy;         // upper bound of the plan's gx
+  const int gx = p.gy >= 512 ? 1 : 512 / p.gy;         // upper bound of the plan's gx
   return ((size_t)gx + 1) * p.gy * p.red_fl * sizeof(float);      // workgroup partials + their column sums
 }
 int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
@@ -324,9 +398,12 @@ int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, flo
   const WtrPlan p = wtr_plan(B, D, H, W, Cin, Cout);
   WtrArgs a{x, dy, (float*)ws, B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles, p.n_coblk};
   const dim3 grid(p.gx, p.gy);
-#define WTR_L(NQ_, NT_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<NQ_, NT_>), grid, dim3(NTHR), 0, s, a)
-#define WTR_Q(NT_) do { if (p.nq == 4) WTR_L(4, NT_); else if (p.nq == 3) WTR_L(3, NT_); else if (p.nq == 2) WTR_L(2, NT_); else WTR_L(1, NT_); } while (0)
-  if (p.nt == 1) WTR_Q(1); else WTR_Q(2);
+  const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
+#define WTR_L(NQ_, NT_, V_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<NQ_, NT_, V_>), grid, dim3(NTHR), 0, s, a)
+#define WTR_Q(NT_, V_) do { if (p.nq == 4) WTR_L(4, NT_, V_); else if (p.nq == 3) WTR_L(3, NT_, V_); else if (p.nq == 2) WTR_L(2, NT_, V_); else WTR_L(1, NT_, V_); } while (0)
+  if (p.nt == 2) WTR_Q(2, true);                       // (eligibility: the odd channel counts only come with Cout <= 16)
+  else if (vec) WTR_Q(1, true);
+  else WTR_Q(1, false);
 #undef WTR_Q
 #undef WTR_L
   float* red = (float*)ws + (size_t)p.gx * p.gy * p.red_fl;

@@ -20,6 +20,9 @@ L2, L3, L4, L5 = (80, 96, 80), (40, 48, 40), (20, 24, 20), (10, 12, 10)
 STEP_LAYERS = [(16, 16, L2, 2), (16, 32, L3, 2), (32, 32, L3, 2), (32, 64, L4, 2), (64, 64, L4, 2), (64, 128, L5, 2), (128, 128, L5, 2),
                (6, 12, L2, 1), (12, 12, L2, 1), (12, 2, L2, 1), (12, 24, L3, 1), (24, 24, L3, 1), (24, 4, L3, 1),
                (24, 48, L4, 1), (48, 48, L4, 1), (48, 8, L4, 1), (8, 16, L2, 2)]
+if os.environ.get("EXP_WTR_L1"):
+    L1 = (160, 192, 160)
+    STEP_LAYERS = [(4, 8, L1, 2), (8, 8, L1, 2), (8, 16, L2, 2)]
 
 
 def timed(fn, iters=15):
