@@ -39,7 +39,7 @@ def log(*a):
 
 def family(tag):
     """launch tag -> kernel family (= the kernel symbol rocprof reports, template arguments stripped).  The conv tags carry
-    the family the library picked for that shape (ops._conv_tag): @x3 = z-marching bf16x3, @split = tiled bf16x3, @direct = the small-volume direct MFMA kernel."""
+    the family the library picked for that shape (ops._conv_tag): @x3 = z-marching bf16x3, @split = tiled bf16x3, @direct = the small-volume direct MFMA kernel, @tr = the transpose-read bf16x3 weight gradient."""
     base = tag.split("[")[0]
     if tag.startswith("conv_fwd[1->"):
         return "conv_c1_fwd_kernel"
@@ -54,7 +54,7 @@ def family(tag):
             return "conv_direct_kernel"
         return "conv_x3_kernel" if tag.endswith("@x3") else ("conv3d_bf16_kernel<SP=3>" if tag.endswith("@split") else "conv3d_mfma_kernel")
     if base == "conv_wgrad":
-        return "conv_x3_wgrad_kernel" if tag.endswith("@x3") else "conv3d_wgrad_kernel"
+        return "conv_x3_wgrad_kernel" if tag.endswith("@x3") else ("conv_wgrad_tr_kernel" if tag.endswith("@tr") else "conv3d_wgrad_kernel")
     if base == "warp_bwd":
         return "warp_bwd_kernel"
     if base == "warp_bwd_gather3":
@@ -66,7 +66,19 @@ def family(tag):
 # algorithmic (fp32) FLOP/s is the dense bf16 peak / 6
 PEAK_MFMA_BF16_TFLOPS = 2500.0
 MFMA_F32_FAMILIES = ("conv3d_mfma_kernel", "conv3d_wgrad_kernel", "conv_c1_wgrad_mfma_kernel", "conv_direct_kernel")
-MFMA_X3_FAMILIES = ("conv_x3_kernel", "conv_x3_wgrad_kernel", "conv3d_bf16_kernel<SP=3>")
+MFMA_X3_FAMILIES = ("conv_x3_kernel", "conv_x3_wgrad_kernel", "conv_wgrad_tr_kernel", "conv3d_bf16_kernel<SP=3>")
+
+
+def csrc_sha16():
+    """fingerprint of the kernel sources (same function as tools/pmc_traffic.py)"""
+    import hashlib
+    root = os.path.join(ROOT, "smilecode_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(root)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(root, fn), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def roof_of(fam, flops, nbytes, sec):
@@ -569,11 +581,19 @@ def main():
                          "note": "all launches of this kernel symbol in the K timed steps; algorithmic work summed per "
                                  "launch shape (DESIGN.md section 4)" + ("; warp_bwd_kernel is bound by the L2 float-atomic "
                                  "unit (its d_src scatter), not by HBM: DESIGN.md section 4" if dominant == "warp_bwd_kernel" else "")})
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc runs
+            # per-launch HBM bytes from the rocprofv3 --pmc passes of tools/refresh_profiles.sh: quoted only while the profile
+            # was taken on THESE kernel sources (fingerprint of smilecode_amd/csrc), otherwise null + the reason
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
                     pj = json.load(open(pmc))
-                    roof["traffic"] = pj.get(dominant, pj.get("families", {}).get(dominant, {}).get("hbm_bytes_per_launch_corrected"))
+                    have, now = pj.get("csrc_sha16"), csrc_sha16()
+                    if have == now:
+                        roof["traffic"] = pj.get(dominant, pj.get("families", {}).get(dominant, {}).get("hbm_bytes_per_launch_corrected"))
+                        roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE), csrc %s" % now
+                    else:
+                        roof["traffic_source"] = ("profiles/pmc_traffic.json is stale: taken on csrc %s, this build is %s "
+                                                  "(re-run tools/refresh_profiles.sh)" % (have, now))
                 except Exception:
                     pass
         # the same object for the six largest families of the profiled warm-up steps (median of those steps)

@@ -114,9 +114,18 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
  *       level-4 resolution): one wave per 16 voxels x 16/32 output channels, no LDS (plain forward / dgrad launches only;
  *       launches with fused statistics, a lazily normalised input or an activation run family 0)   conv3d.hip (conv_direct_kernel)
  * Families 1 and 2 produce the fused InstanceNorm statistics (modet_conv3d_fwd_stats) at no cost for every Cout.
- * Env (read at first use): MODET_CONV_X3=0 disables family 2, MODET_CONV_SPLIT=0 / 1 disables / forces family 1,
- * MODET_CONV_DIRECT=0 disables family 3. */
+ *   4 = (weight gradient only) bf16x3 through LDS transpose reads, ds_read_b64_tr_b16: every layer with Cin >= 12 or an
+ *       odd channel count, and Cout = 16                                                           conv3d_wtr.hip
+ * Families 1 and 2 produce the fused InstanceNorm statistics (modet_conv3d_fwd_stats) at no cost for every Cout.
+ * The choice is a function of the arguments alone: the product library reads NO environment variable.  The A/B switches
+ * MODET_CONV_X3=0 (no family 2), MODET_CONV_SPLIT=0 / 1 (no / forced family 1), MODET_CONV_DIRECT=0 (no family 3),
+ * MODET_CONV_WTR=0 (no family 4) exist only in tuning builds of the library (-DMODET_TUNING, tools/build_variant.sh).
+ * `variant` tells what the launch fuses, because that changes the routing: 0 = plain (modet_conv3d_fwd with act = 0,
+ * modet_conv3d_fwd_stats, _bwd_data, _bwd_weight), 1 = fused LeakyReLU (modet_conv3d_fwd with act = 1: never family 1 or 3),
+ * 2 = lazily normalised input (modet_conv3d_fwd_normin: family 2 or 0), 3 = fused statistics (modet_conv3d_fwd_stats:
+ * never family 3).  modet_conv3d_kernel_family == variant 0. */
 int modet_conv3d_kernel_family(int B, int D, int H, int W, int Cin, int Cout, int pass);
+int modet_conv3d_kernel_family_v(int B, int D, int H, int W, int Cin, int Cout, int pass, int variant);
 size_t modet_conv3d_ws_bytes(int Cin, int Cout);
 /* `step` (every conv entry point that packs weights): NULL, or the context whose recorded packing jobs apply, see
  * modet_conv3d_prepack_* below. */

@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 302; /* 0.3.2: + modet_instnorm_lrelu_apply_pool, conv kernel family 3 (conv_direct_kernel) */ }
+int modet_hip_version(void) { return 400; /* 0.4.0: + modet_conv3d_kernel_family_v, conv kernel family 4 (conv_wgrad_tr_kernel); no environment reads in product builds */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/modet_hip.h"
 
@@ -12,6 +13,19 @@
 static inline int modet_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MODET_OK : (int)e;
+}
+
+// A/B switches of the kernel dispatch exist in TUNING builds only (-DMODET_TUNING: `MODET_TUNING=1 python -m smilecode_amd.build`
+// or tools/build_variant.sh): the product library reads no environment variable, so its behaviour -- which kernel family a
+// shape runs, hence its rounding -- is a function of the arguments alone.  Returns the variable's first character, or 0.
+static inline char modet_tuning_env(const char* name) {
+#ifdef MODET_TUNING
+  const char* e = getenv(name);
+  return e ? e[0] : 0;
+#else
+  (void)name;
+  return 0;
+#endif
 }
 
 __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1563,7 +1563,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
 
 // MODET_CONV_DIRECT=0 keeps the tiled kernels for every shape (A/B switch)
 static bool use_direct(int B, int D, int H, int W, int Cin, int Cout) {
-  static const bool on = [] { const char* e = getenv("MODET_CONV_DIRECT"); return !(e && e[0] == '0'); }();
+  static const bool on = modet_tuning_env("MODET_CONV_DIRECT") != '0';
   const int64_t BV = (int64_t)B * D * H * W;
   // (up to 100 k voxels -- the CWM layers at level-3 resolution -- measured: 9.655 vs 9.590 ms/step; the operands then stream from HBM)
   return on && BV <= 16384 && Cin >= 8 && Cin % 4 == 0 && Cout >= 4;
@@ -1769,17 +1769,17 @@ size_t modetx_wtr_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
                      int W, int Cin, int Cout, hipStream_t s);
 static bool use_x3(int B, int D, int H, int W, int Cin, int Cout) {
-  static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
+  static const bool on = modet_tuning_env("MODET_CONV_X3") != '0';
   return on && modetx_x3_eligible(B, D, H, W, Cin, Cout);
 }
 static bool use_x3_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
-  static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
-  static const bool wtr_first = [] { const char* e = getenv("MODET_CONV_WTR"); return e && e[0] == '2'; }();   // experiment: tr kernel everywhere
+  static const bool on = modet_tuning_env("MODET_CONV_X3") != '0';
+  static const bool wtr_first = modet_tuning_env("MODET_CONV_WTR") == '2';      // experiment: the transpose-read kernel everywhere
   // Cout = 16 (8 -> 16 at level 2) runs 1.7x faster on the transpose-read kernel (102 -> 60 us): the march keeps Cout <= 8
   return on && !wtr_first && Cout <= 8 && modetx_x3_wgrad_eligible(B, D, H, W, Cin, Cout);
 }
 static bool use_wtr_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
-  static const bool on = [] { const char* e = getenv("MODET_CONV_WTR"); return !(e && e[0] == '0'); }();
+  static const bool on = modet_tuning_env("MODET_CONV_WTR") != '0';
   return on && !use_x3_wgrad(B, D, H, W, Cin, Cout) && modetx_wtr_eligible(B, D, H, W, Cin, Cout);
 }
 // The tiled bf16x3 kernels of conv3d_bf16.hip (SP = 3): default for the MID levels of the pyramid -- Cin >= 16 channels at
@@ -1787,7 +1787,7 @@ static bool use_wtr_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
 // few-channel full-resolution layers take conv3d_x3.hip, level 5 (2.4 k voxels) stays on the exact-f32 kernels.
 // MODET_CONV_SPLIT=1 forces them for every eligible shape, =0 switches them off.
 static bool use_split(int Cin, int Cout, int64_t nvox = -1) {
-  static const int mode = [] { const char* e = getenv("MODET_CONV_SPLIT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  static const int mode = [] { const char e = modet_tuning_env("MODET_CONV_SPLIT"); return e ? (e == '1' ? 1 : 0) : -1; }();
   if (!modetx_split_eligible(Cin, Cout) || mode == 0) return false;
   if (mode == 1) return true;
   return nvox >= 16000 && Cin >= 16 && Cin % 16 == 0 && Cout >= 16;
@@ -1801,13 +1801,18 @@ int modet_debug_conv_timing(long long* buf) {       // not in the header: tuning
 }
 #endif
 
-int modet_conv3d_kernel_family(int B, int D, int H, int W, int Cin, int Cout, int pass) {
+int modet_conv3d_kernel_family_v(int B, int D, int H, int W, int Cin, int Cout, int pass, int variant) {
   if (Cin == 1) return 0;
   if (pass == 2) return use_x3_wgrad(B, D, H, W, Cin, Cout) ? 2 : (use_wtr_wgrad(B, D, H, W, Cin, Cout) ? 4 : 0);
   const int ci = pass == 1 ? Cout : Cin, co = pass == 1 ? Cin : Cout;      // the data gradient convolves d_y (Cout channels)
   if (use_x3(B, D, H, W, ci, co)) return 2;
+  if (variant == 1 || variant == 2) return 0;                  // fused activation / normalised input: exact-f32 tiles otherwise
   if (use_split(ci, co, (int64_t)B * D * H * W)) return 1;
+  if (variant == 3) return 0;                                  // fused statistics: never the direct kernel
   return use_direct(B, D, H, W, ci, co) ? 3 : 0;               // 3: conv_direct_kernel (plain forward / dgrad launches only)
+}
+int modet_conv3d_kernel_family(int B, int D, int H, int W, int Cin, int Cout, int pass) {
+  return modet_conv3d_kernel_family_v(B, D, H, W, Cin, Cout, pass, 0);
 }
 
 int modet_step_ctx_create(modet_step_ctx_t** out) {

@@ -886,7 +886,7 @@ inline int bf16_tiles_per_sample(int D, int H, int W, int Cin, int Cout) {
 
 // MODET_CONV_X3 = 0 keeps the tiled kernels (A/B measurements); otherwise the z-marching kernel takes the few-channel layers
 inline bool x3_on() {
-  static const bool on = [] { const char* e = getenv("MODET_CONV_X3"); return !(e && e[0] == '0'); }();
+  static const bool on = modet_tuning_env("MODET_CONV_X3") != '0';
   return on;
 }
 

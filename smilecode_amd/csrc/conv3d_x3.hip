@@ -1037,7 +1037,8 @@ extern "C" int modet_debug_x3_timing(long long* buf) {       // not in the heade
 
 // ---- internal interface for conv3d.hip (C++ linkage, not part of the ABI): the fp32 entry points route eligible shapes here
 bool modetx_x3_eligible(int B, int D, int H, int W, int Cin, int Cout) {
-  return x3_shape_ok(Cin, Cout) && (int64_t)D * H * W >= 4096 && B <= 65535;
+  // per-lane byte offsets inside one plane are 32-bit and 0x80000000 is the out-of-bounds sentinel: planes stay < 2 GiB
+  return x3_shape_ok(Cin, Cout) && (int64_t)D * H * W >= 4096 && B <= 65535 && (int64_t)H * W * 16 * 4 < 0x7fffffffLL;
 }
 size_t modetx_x3_ws_bytes(int Cin, int Cout) { return x3_wpk_elems(16, 1) * sizeof(unsigned short); }
 size_t modetx_x3_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {

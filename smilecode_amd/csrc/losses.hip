@@ -368,6 +368,7 @@ int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_
   if (win != 3 && win != 5 && win != 7 && win != 9) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_ncc_ws_bytes(B, D, H, W)) return MODET_ERR_WORKSPACE;
   if ((int64_t)D * H * W >= (1ll << 31)) return MODET_ERR_DIM;
+  if ((int64_t)H * W * 4 >= (1ll << 31)) return MODET_ERR_DIM;      // 32-bit byte offsets inside a plane (buffer loads, OOB sentinel)
   hipStream_t s = (hipStream_t)stream;
   const Dims d{B, D, H, W};
   const int64_t N = (int64_t)B * D * H * W;

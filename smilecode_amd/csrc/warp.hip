@@ -76,21 +76,25 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
       if (zr >= 0.f && zr < (float)D && yr >= 0.f && yr < (float)H && xr >= 0.f && xr < (float)W)
         ldv<CPT>(sb + (((int64_t)zr * H + (int64_t)yr) * W + (int64_t)xr) * C, acc);
     } else {
-      // branch-free: the eight corner loads are issued back to back (out-of-range corners read a clamped, valid voxel
-      // with weight 0).  A load per `if (inside)` compiled to eight load -> s_waitcnt vmcnt(0) round trips in series.
+      // branch-free: the eight corner loads are issued back to back (out-of-range corners read a clamped, valid voxel and
+      // the VALUE is replaced by 0 afterwards -- as grid_sample's zeros padding and the backward kernels do, so an Inf / NaN
+      // border voxel cannot leak in through 0 * Inf).  A load per `if (inside)` compiled to eight load -> s_waitcnt vmcnt(0)
+      // round trips in series.
       const Tri t = tri_setup(z, y, x);
       int64_t zo[2], yo[2], xo[2];
       float wzv[2], wyv[2], wxv[2];
+      bool zkv[2], ykv[2], xkv[2];
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         const int zz = t.z0 + d, yy = t.y0 + d, xx = t.x0 + d;
         const bool zk = zz >= 0 && zz < D, yk = yy >= 0 && yy < H, xk = xx >= 0 && xx < W;
+        zkv[d] = zk; ykv[d] = yk; xkv[d] = xk;
         zo[d] = (int64_t)(zk ? zz : 0) * H * W * C;
         yo[d] = (int64_t)(yk ? yy : 0) * W * C;
         xo[d] = (int64_t)(xk ? xx : 0) * C;
-        wzv[d] = zk ? (d ? t.fz : 1.f - t.fz) : 0.f;
-        wyv[d] = yk ? (d ? t.fy : 1.f - t.fy) : 0.f;
-        wxv[d] = xk ? (d ? t.fx : 1.f - t.fx) : 0.f;
+        wzv[d] = d ? t.fz : 1.f - t.fz;
+        wyv[d] = d ? t.fy : 1.f - t.fy;
+        wxv[d] = d ? t.fx : 1.f - t.fx;
       }
       float s[8][CPT];
 #pragma unroll
@@ -98,8 +102,9 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const float wgt = wzv[q >> 2] * wyv[(q >> 1) & 1] * wxv[q & 1];
+        const bool ok = zkv[q >> 2] && ykv[(q >> 1) & 1] && xkv[q & 1];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) acc[c] = fmaf(wgt, s[q][c], acc[c]);
+        for (int c = 0; c < CPT; ++c) acc[c] = fmaf(wgt, ok ? s[q][c] : 0.f, acc[c]);
       }
     }
     if (add_flow) {                            // C == 3, CPT == 3, G == 1

@@ -155,16 +155,18 @@ _FAM_CACHE = {}
 _FAM_SUFFIX = ("", "@split", "@x3", "@direct", "@tr")
 
 
-def _conv_tag(kind, x_shape, Cin, Cout):
+def _conv_tag(kind, x_shape, Cin, Cout, variant=0):
     """KernelTimer tag of a conv launch: 'conv_fwd[8->8]@x3' names the kernel family that runs this shape (exact-f32
-    MFMA: no suffix; tiled bf16x3: @split; z-marching bf16x3: @x3; small-volume direct MFMA: @direct) -- only evaluated while a timer is installed"""
+    MFMA: no suffix; tiled bf16x3: @split; z-marching bf16x3: @x3; small-volume direct MFMA: @direct; transpose-read weight
+    gradient: @tr) -- only evaluated while a timer is installed.  ``variant`` = what the launch fuses (it changes the routing,
+    include/modet_hip.h modet_conv3d_kernel_family_v): 0 plain, 1 LeakyReLU, 2 normalised input, 3 statistics."""
     if _TIMER is None:
         return None
-    key = (kind, tuple(x_shape[:4]), Cin, Cout)
+    key = (kind, tuple(x_shape[:4]), Cin, Cout, variant)
     t = _FAM_CACHE.get(key)
     if t is None:
         B, D, H, W = x_shape[:4]
-        fam = _L().modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind])
+        fam = _L().modet_conv3d_kernel_family_v(B, D, H, W, Cin, Cout, {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind], variant)
         arrow = f"{Cout}->{Cin}" if kind == "dgrad" else f"{Cin}->{Cout}"
         t = _FAM_CACHE[key] = f"conv_{kind}[{arrow}]{_FAM_SUFFIX[fam]}"
     return t
@@ -197,7 +199,7 @@ def conv3d_forward(x, w, b, act, step=None):
     nb = L.modet_conv3d_ws_bytes(Cin, Cout)
     ws = _ws(nb, x)
     n = float(B) * D * H * W
-    with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+    with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout, 1 if act else 0), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         _lib.check(L.modet_conv3d_fwd(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, B, D, H, W, Cin, Cout, int(act),
                                       _stream(), _h(step)), "modet_conv3d_fwd")
     return y
@@ -238,7 +240,7 @@ def conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats=True, step=None):
     sb = L.modet_conv3d_normin_stats_bytes(B, D, H, W, Cin, Cout) if want_stats else 0
     stats = torch.empty(sb // 4, dtype=torch.float32, device=x_raw.device) if sb > 0 else None
     n = float(B) * D * H * W
-    with _Guard(x_raw, _conv_tag("fwd", x_raw.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+    with _Guard(x_raw, _conv_tag("fwd", x_raw.shape, Cin, Cout, 2), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         _lib.check(L.modet_conv3d_fwd_normin(_p(x_raw), _p(mean), _p(rstd), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb,
                                              B, D, H, W, Cin, Cout, _stream(), _h(step)), "modet_conv3d_fwd_normin")
     return y, stats
@@ -474,7 +476,7 @@ class _Conv3dStats(Function):
         sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)
         stats = torch.empty(sb // 4, dtype=torch.float32, device=x.device)
         n = float(B) * D * H * W
-        with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+        with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout, 3), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
             _lib.check(L.modet_conv3d_fwd_stats(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
                                                 Cout, _stream(), _h(ctx.step)), "modet_conv3d_fwd_stats")
         ctx.has_bias = b is not None
@@ -575,7 +577,7 @@ class _InstNormConv(Function):
             sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)
             stats = torch.empty(sb // 4, dtype=torch.float32, device=y.device)
             n = float(B) * D * H * W
-            with _Guard(y, _conv_tag("fwd", y.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+            with _Guard(y, _conv_tag("fwd", y.shape, Cin, Cout, 3), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
                 _lib.check(L.modet_conv3d_fwd_stats(_p(y), _p(w), _p(b), _p(z), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
                                                     Cout, _stream(), _h(ctx.step)), "modet_conv3d_fwd_stats")
             ctx.mark_non_differentiable(stats)
@@ -814,10 +816,13 @@ class _InstNormLReLUPoolSplit(Function):
                                                          _stream()), "modet_instnorm_lrelu_apply_pool")
         ctx.save_for_backward(x, mean, rstd)
         ctx.Bh = Bh
+        ctx.set_materialize_grads(False)        # an unused output arrives as None (no zeros fill launch); handled below
         return pooled, y[:Bh], y[Bh:]
 
     @staticmethod
     def backward(ctx, gy, ga, gb):
+        if not ctx.needs_input_grad[0] or (gy is None and ga is None and gb is None):
+            return None, None, None, None
         x, mean, rstd = ctx.saved_tensors
         B, D, H, W, C = x.shape
         Bh = ctx.Bh

@@ -78,6 +78,13 @@ class FlatParams:
         for p in self.params:
             p.grad = None
 
+    def segment_index(self):
+        """int64 tensor (numel): element of the flat buffers -> index of its parameter in ``params``"""
+        if getattr(self, "_seg", None) is None:
+            sizes = torch.tensor([k for _, k in self.offsets], device=self.flat.device)
+            self._seg = torch.repeat_interleave(torch.arange(len(self.offsets), device=self.flat.device), sizes)
+        return self._seg
+
     def grad_destinations(self):
         """parameter.data_ptr() -> that parameter's view of the flat gradient buffer (ops.deferred_wgrad_reductions)"""
         if getattr(self, "_dst", None) is None:

@@ -233,28 +233,18 @@ CFG5_SHAPE = (160, 192, 224)
 
 
 @pytest.fixture(scope="module")
-def cfg5_oracle():
-    """fp64 CPU oracle of the reference path at BASELINE.json configs[4]'s shape (160x192x224), computed ONCE for the
-    tests below: the two samples of the batch are independent (InstanceNorm is per sample, no BatchNorm), so sample 0
-    runs forward + backward (its loss and every parameter gradient), sample 1 forward only -- one fp64 autograd tape in
-    host memory at a time.  ~4 min of host CPU on the GPU box."""
-    from oracle import modet_torch as orc
+def cfg5_oracle(oracle_job):
+    """fp64 CPU oracle of the reference path at BASELINE.json configs[4]'s shape (160x192x224), computed ONCE
+    (tests/oracle_jobs.py `cfg5`, a background process started at collection time beside the GPU tests): the two samples of
+    the batch are independent (InstanceNorm is per sample, no BatchNorm), so sample 0 runs forward + backward (its loss and
+    every parameter gradient), sample 1 forward only -- one fp64 autograd tape in host memory at a time.  ~4 min of host CPU."""
     from smilecode_amd import synth
-    w = synth.make_weights(24)
-    mov_np, fix_np = synth.make_pair(CFG5_SHAPE, 24, 2)
-    p64 = {n: torch.from_numpy(v).double().requires_grad_(True) for n, v in w.items()}
-    l0, s0, r0, _, f0 = orc.train_loss(p64, torch.from_numpy(mov_np[:1]).double(), torch.from_numpy(fix_np[:1]).double(),
-                                       (8, 4, 2, 1, 1), 6, 1.0)
-    g0 = dict(zip(p64, torch.autograd.grad(l0, list(p64.values()))))
-    f0 = f0.detach()
-    with torch.no_grad():
-        _, f1 = orc.modet_forward({n: v.detach() for n, v in p64.items()}, torch.from_numpy(mov_np[1:]).double(),
-                                  torch.from_numpy(fix_np[1:]).double(), (8, 4, 2, 1, 1), 6, 1.0)
-    lab_m = torch.from_numpy(synth.make_labels(CFG5_SHAPE, 24))[None, None]
-    lab_f = torch.from_numpy(synth.make_labels(CFG5_SHAPE, 25))[None, None]
-    dice0 = orc.dice_voi(orc.warp(lab_m.float(), f0.float(), "nearest").long(), lab_f.long())
-    return {"w": w, "mov": mov_np, "fix": fix_np, "flow": torch.cat([f0, f1]), "loss0": float(l0), "sim0": float(s0),
-            "reg0": float(r0), "grad0": {n: g.detach() for n, g in g0.items()}, "lab_m": lab_m, "lab_f": lab_f, "dice0": dice0}
+    o = dict(oracle_job("cfg5"))
+    o["w"] = synth.make_weights(24)
+    o["mov"], o["fix"] = synth.make_pair(CFG5_SHAPE, 24, 2)
+    o["lab_m"] = torch.from_numpy(synth.make_labels(CFG5_SHAPE, 24))[None, None]
+    o["lab_f"] = torch.from_numpy(synth.make_labels(CFG5_SHAPE, 25))[None, None]
+    return o
 
 
 def _cfg5_model(dtype, w):

@@ -266,10 +266,11 @@ def test_full_size_train_step_runs_and_is_sane():
     _note("train[160x192x160].loss3", float(l1))
 
 
-def test_full_size_dice_parity_vs_oracle():
+def test_full_size_dice_parity_vs_oracle(oracle_job):
     """north-star parity statement: Dice on (synthetic 54-label) LPBA-shaped labels matches the reference path to
     +-0.001 at 160x192x160.  Reference path = CPU oracle forward (fp32, same op sequence as ModeT/models.py) ->
-    nearest label warp -> dice_val_VOI arithmetic (utils.py:86-106); ours = HIP forward -> fused GPU eval tail."""
+    nearest label warp -> dice_val_VOI arithmetic (utils.py:86-106); ours = HIP forward -> fused GPU eval tail.
+    The oracle's full-size runs (fp32 and fp64 flow) come from tests/oracle_jobs.py, computed once beside the GPU tests."""
     from oracle import modet_torch as orc
     from smilecode_amd import synth
     from smilecode_amd.utils import warp_labels_and_dice
@@ -288,14 +289,10 @@ def test_full_size_dice_parity_vs_oracle():
     d_same = orc.dice_voi(w_ref.long(), lab_f.long())
     assert abs(d_same - dice_gpu) < 1e-4
     # (2) the oracle's own forward (CPU fp32) -> its flow -> its Dice
-    p = {n: torch.from_numpy(v) for n, v in synth.make_weights(24).items()}
-    with torch.no_grad():
-        _, f_ref = orc.modet_forward(p, mov.cpu(), fix.cpu(), (8, 4, 2, 1, 1), 6, 1.0)
+    o = oracle_job("full160")
+    f_ref, f64 = o["flow32"], o["flow64"]
     d_ref = orc.dice_voi(orc.warp(lab_m.float(), f_ref, "nearest").long(), lab_f.long())
     # fp64 oracle: separates our error from the fp32 CPU path's own (both are fp32 noise on |flow| up to ~17)
-    with torch.no_grad():
-        _, f64 = orc.modet_forward({n: v.double() for n, v in p.items()}, mov.double().cpu(), fix.double().cpu(),
-                                   (8, 4, 2, 1, 1), 6, 1.0)
     e_hip = float((flow.double().cpu() - f64).abs().max())
     e_cpu32 = float((f_ref.double() - f64).abs().max())
     _note("fwd[160x192x160].flow_maxerr_voxels_hip_vs_fp64", e_hip)
@@ -309,20 +306,16 @@ def test_full_size_dice_parity_vs_oracle():
     assert abs(d_ref - dice_gpu) <= 1e-3, f"Dice {dice_gpu:.5f} vs reference path {d_ref:.5f}"
 
 
-def test_full_size_gradient_parity_vs_oracle():
+def test_full_size_gradient_parity_vs_oracle(oracle_job):
     """BASELINE size 160x192x160: loss and EVERY parameter gradient of one train step against the fp64 CPU oracle's
     autograd (ModeT/train.py:122-131 on ModeT/models.py:377-412), same tolerance as the small shapes: worst error per
     tensor <= 2e-2 of that tensor's max |g| (biases in front of an InstanceNorm have an analytically zero gradient and
     are compared absolutely)."""
-    from oracle import modet_torch as orc
     from smilecode_amd import losses, synth
     shape = (160, 192, 160)
-    w = synth.make_weights(24)
+    o = oracle_job("full160")
+    g64, loss64, sim64, reg64 = o["grad"], o["loss"], o["sim"], o["reg"]
     mov_np, fix_np = synth.make_pair(shape, 24)
-    p64 = {n: torch.from_numpy(v).double().requires_grad_(True) for n, v in w.items()}
-    loss64, sim64, reg64, _, _ = orc.train_loss(p64, torch.from_numpy(mov_np).double(), torch.from_numpy(fix_np).double(),
-                                                (8, 4, 2, 1, 1), 6, 1.0)
-    g64 = dict(zip(p64, torch.autograd.grad(loss64, list(p64.values()))))
     model = _model(shape, 1.0)
     mov, fix = torch.from_numpy(mov_np).cuda(), torch.from_numpy(fix_np).cuda()
     y, flow = model(mov, fix)

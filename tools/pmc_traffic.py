@@ -9,10 +9,24 @@ Counters are KB; per MI355X_MICROARCH.md (HBM / rocprofv3 section) gfx950's FETC
 reads, so hbm_bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024.  Values are means over all launches of a kernel symbol
 (template arguments stripped), i.e. per launch like bench.py's roofline.achieved."""
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+
+def csrc_sha16():
+    """fingerprint of the kernel sources this profile was taken on (bench.py recomputes it: a profile older than the kernels
+    is reported as stale instead of being quoted as roofline.traffic; the GPU box has no .git, so a commit id is not available there)"""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "smilecode_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(root)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(root, fn), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def family(name):
@@ -43,6 +57,7 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes o
                "step, 160x192x160, B=1); counters are KB; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per "
                "MI355X_MICROARCH.md (gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads); averaged over all launches of "
                "the kernel symbol in a step",
+       "csrc_sha16": csrc_sha16(),
        "families": fams}
 for k in fams:                                   # bench.py reads the dominant family's per-launch bytes from the top level
     out[k] = fams[k]["hbm_bytes_per_launch_corrected"]
