@@ -284,6 +284,182 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
   }
 }
 
+// Second form of the same backward with a THIRD merge (y), for tensors below 2^31 elements (32-bit offsets): a thread owns
+// one (x, channel lane) and walks a PATCH of ZR planes x YR rows, z outer (run-time loop), y inner (unrolled).  Contributions
+// travel in two kinds of carries, each tagged with the LINEAR element offset of the cell it belongs to:
+//   * inner (y) carry: the four (dz, dx) values of the voxel's dy = 1 level, merged into the next voxel of the run when that
+//     one's base cell is exactly this offset (otherwise flushed);
+//   * outer (z) carry: per position of the y run, the two (dx) values of the (dz = 1, dy = 0) level (already holding what the
+//     y merge put there), consumed by the voxel at the same position of the NEXT plane when its base cell matches.
+// Equality of linear offsets is sufficient: a carried value is non-zero only for a cell inside the volume, and a value is only
+// ever added to something that is then written at that same linear offset.  On a smooth flow every run of YR voxels issues
+// YR + 1 atomics for its dz = 0 level (+ one outer flush per patch): ~1.4 per (voxel, channel) against 2.25 with the x / z
+// merges of warp_bwd_kernel.  Same arithmetic per contribution; the order of the float adds differs (as between any two runs
+// of the atomic form).
+constexpr int WB_NONE = -2147483647 - 1;
+#ifndef WB2_ZR
+#define WB2_ZR 8
+#endif
+#ifndef WB2_YR
+#define WB2_YR 4
+#endif
+template <int ZR, int YR>
+__global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                        const float* __restrict__ dout, float* __restrict__ dsrc,
+                                                        float* __restrict__ dflow, int D, int H, int W, int C, int G,
+                                                        unsigned total, int add_flow) {
+  // total = B * ceil(D/ZR) * ceil(H/YR) * W * G items (one per patch column)
+  const int V = D * H * W;
+  const unsigned nzr = (unsigned)((D + ZR - 1) / ZR), nyr = (unsigned)((H + YR - 1) / YR);
+  const unsigned total_pad = (total + BLK - 1) / BLK * BLK;       // keep whole waves alive for the shuffles
+  const int lane = threadIdx.x & 63;
+  const int sX = C, sY = W * C, sZ = H * W * C;
+  for (unsigned idx = blockIdx.x * BLK + threadIdx.x; idx < total_pad; idx += gridDim.x * BLK) {
+    const bool inr = idx < total;
+    const unsigned id = inr ? idx : total - 1;
+    const int c = (int)(id % (unsigned)G);
+    const bool livec = inr && c < C;
+    unsigned r = id / (unsigned)G;
+    const int xi = (int)(r % (unsigned)W); r /= (unsigned)W;
+    const int yr = (int)(r % nyr); r /= nyr;
+    const int zr = (int)(r % nzr);
+    const int b = (int)(r / nzr);
+    const int cc = livec ? c : 0;
+    const float* sb = src + (int64_t)b * V * C + cc;
+    float* db = dsrc ? dsrc + (int64_t)b * V * C + cc : nullptr;
+    const int up = lane + G, dn = lane - G;
+    const int nxi = __shfl(xi, up, 64), pxi = __shfl(xi, dn, 64);
+    const bool up_ok = (up < 64) && (idx + G < total) && nxi == xi + 1;
+    const bool dn_ok = (dn >= 0) && inr && pxi == xi - 1;
+    float OC[YR + 1][2];                               // outer carry: (dz = 1, dy = 0) level per position of the y run, [dx]
+    int OCoff[YR + 1];
+#pragma unroll
+    for (int k = 0; k <= YR; ++k) { OC[k][0] = 0.f; OC[k][1] = 0.f; OCoff[k] = WB_NONE; }
+    auto flush2 = [&](int off, float v0, float v1) {
+      if (v0 != 0.f) atomicAdd(db + off, v0);
+      if (v1 != 0.f) atomicAdd(db + off + sX, v1);
+    };
+    const int y0p = yr * YR;
+#pragma unroll 1
+    for (int j = 0; j < ZR; ++j) {
+      const int zi = zr * ZR + j;
+      const bool zin = zi < D;
+      const int zc = zin ? zi : D - 1;
+      float IC[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // inner carry: [dz][dx] of the previous voxel's dy = 1 level
+      int ICoff = WB_NONE;
+      float ON[YR + 1][2];
+      int ONoff[YR + 1];
+      const int nplane = b * V + zc * H * W + xi;
+      // all loads of the run up front (flow, d_out of its YR voxels): independent of each other
+      float f0v[YR], f1v[YR], f2v[YR], gov[YR];
+#pragma unroll
+      for (int k = 0; k < YR; ++k) {
+        const int yk = y0p + k < H ? y0p + k : H - 1;
+        const int n = nplane + yk * W;
+        f0v[k] = flow[(int64_t)n * 3]; f1v[k] = flow[(int64_t)n * 3 + 1]; f2v[k] = flow[(int64_t)n * 3 + 2];
+        gov[k] = dout[(int64_t)n * C + cc];
+      }
+#pragma unroll
+      for (int k = 0; k < YR; ++k) {
+        const int yi = y0p + k;
+        const bool yin = yi < H;
+        const int yc = yin ? yi : H - 1;
+        const bool live = livec && zin && yin;
+        const int n = nplane + yc * W;
+        const float go = live ? gov[k] : 0.f;
+        const Tri t = tri_setup((float)zc + f0v[k], (float)yc + f1v[k], (float)xi + f2v[k]);
+        float cv[8];                                   // index dz*4 + dy*2 + dx
+        float gz = 0.f, gy = 0.f, gx = 0.f;
+        const int off0 = ((t.z0 * H + t.y0) * W + t.x0) * C;     // (wild flows: tri_setup clamps to [-2, 1e9]; such cells are never valid)
+        const bool zok[2] = {t.z0 >= 0 && t.z0 < D, t.z0 + 1 >= 0 && t.z0 + 1 < D};
+        const bool yok[2] = {t.y0 >= 0 && t.y0 < H, t.y0 + 1 >= 0 && t.y0 + 1 < H};
+        const bool xok[2] = {t.x0 >= 0 && t.x0 < W, t.x0 + 1 >= 0 && t.x0 + 1 < W};
+        float sv[8];
+        if (dflow) {                                   // uniform
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const bool ok = live && zok[q >> 2] && yok[(q >> 1) & 1] && xok[q & 1];
+            const int off = off0 + ((q >> 2) ? sZ : 0) + (((q >> 1) & 1) ? sY : 0) + ((q & 1) ? sX : 0);
+            sv[q] = sb[ok ? off : 0];
+          }
+        }
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz) {
+          const float wz = dz ? t.fz : 1.f - t.fz;
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const float wy = dy ? t.fy : 1.f - t.fy;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const float wx = dx ? t.fx : 1.f - t.fx;
+              const bool ok = live && zok[dz] && yok[dy] && xok[dx];
+              cv[dz * 4 + dy * 2 + dx] = ok ? wz * wy * wx * go : 0.f;
+              if (dflow) {
+                const float dot = ok ? sv[dz * 4 + dy * 2 + dx] * go : 0.f;
+                gz += (dz ? 1.f : -1.f) * wy * wx * dot;
+                gy += (dy ? 1.f : -1.f) * wz * wx * dot;
+                gx += (dx ? 1.f : -1.f) * wz * wy * dot;
+              }
+            }
+          }
+        }
+        if (db) {
+          // ---- x merge (as warp_bwd_kernel)
+          const int nz0 = __shfl(t.z0, up, 64), ny0 = __shfl(t.y0, up, 64), nx0 = __shfl(t.x0, up, 64);
+          const bool give = up_ok && zin && yin && nz0 == t.z0 && ny0 == t.y0 && nx0 == t.x0 + 1;
+          const int pz0 = __shfl(t.z0, dn, 64), py0 = __shfl(t.y0, dn, 64), px0 = __shfl(t.x0, dn, 64);
+          const bool take = dn_ok && zin && yin && pz0 == t.z0 && py0 == t.y0 && px0 == t.x0 - 1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                // q = dz*2 + dy
+            const float from_prev = __shfl(cv[q * 2 + 1], dn, 64);
+            if (take) cv[q * 2] += from_prev;
+            if (give) cv[q * 2 + 1] = 0.f;
+          }
+          // ---- z merge: the carry of this run position from the previous plane, (dz = 0, dy = 0) of this voxel
+          if (OCoff[k] == off0) { cv[0] += OC[k][0]; cv[1] += OC[k][1]; }
+          else flush2(OCoff[k], OC[k][0], OC[k][1]);
+          if (k == YR - 1) {                           // the run's last carry meets the last voxel's (dz = 0, dy = 1)
+            if (OCoff[YR] == off0 + sY) { cv[2] += OC[YR][0]; cv[3] += OC[YR][1]; }
+            else flush2(OCoff[YR], OC[YR][0], OC[YR][1]);
+          }
+          // ---- y merge: the previous voxel's dy = 1 level
+          if (ICoff == off0) { cv[0] += IC[0][0]; cv[1] += IC[0][1]; cv[4] += IC[1][0]; cv[5] += IC[1][1]; }
+          else { flush2(ICoff, IC[0][0], IC[0][1]); flush2(ICoff + sZ, IC[1][0], IC[1][1]); }
+          // ---- (dz = 0, dy = 0) is final; (dz = 1, dy = 0) waits for the next plane; dy = 1 for the next voxel of the run
+          flush2(off0, cv[0], cv[1]);
+          ON[k][0] = cv[4]; ON[k][1] = cv[5]; ONoff[k] = off0 + sZ;
+          IC[0][0] = cv[2]; IC[0][1] = cv[3]; IC[1][0] = cv[6]; IC[1][1] = cv[7];
+          ICoff = off0 + sY;
+        }
+        if (dflow) {
+          if (add_flow && live) {                      // C == 3: d(out_c)/d(flow_c) has the identity term
+            gz += c == 0 ? go : 0.f; gy += c == 1 ? go : 0.f; gx += c == 2 ? go : 0.f;
+          }
+          for (int o = 1; o < G; o <<= 1) {
+            gz += __shfl_xor(gz, o, 64);
+            gy += __shfl_xor(gy, o, 64);
+            gx += __shfl_xor(gx, o, 64);
+          }
+          if (inr && zin && yin && c == 0) {
+            float* dfp = dflow + (int64_t)n * 3;
+            dfp[0] = gz; dfp[1] = gy; dfp[2] = gx;
+          }
+        }
+      }
+      if (db) {                                        // run end: the last voxel's dy = 1 level
+        flush2(ICoff, IC[0][0], IC[0][1]);
+        ON[YR][0] = IC[1][0]; ON[YR][1] = IC[1][1]; ONoff[YR] = ICoff == WB_NONE ? WB_NONE : ICoff + sZ;
+#pragma unroll
+        for (int k = 0; k <= YR; ++k) { OC[k][0] = ON[k][0]; OC[k][1] = ON[k][1]; OCoff[k] = ONoff[k]; }
+      }
+    }
+    if (db) {
+#pragma unroll
+      for (int k = 0; k <= YR; ++k) flush2(OCoff[k], OC[k][0], OC[k][1]);
+    }
+  }
+}
+
 // Bounded-flow backward (|flow| <= 1, C == 3: the flow compositions with an attention output).  A sample point
 // p + flow[p] lies within one voxel of p, so source voxel s only receives from the 27 voxels p = s + d, d in {-1,0,1}^3,
 // with weight prod_a max(0, 1 - |p_a + flow_a[p] - s_a|) (the trilinear hat: (1-f) at floor, f at floor+1).
@@ -759,6 +935,14 @@ int modet_warp_bwd(const float* src, const float* flow, const float* d_out, floa
   if (G > 64) return MODET_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (d_src) modet_zero_async(d_src, (size_t)B * D * H * W * C * sizeof(float), s);     // (not hipMemsetAsync: common.h)
+  // patch form (x, z AND y merges): 32-bit offsets, enough patch columns to fill the chip
+  const int64_t total2 = (int64_t)B * cdiv(D, WB2_ZR) * cdiv(H, WB2_YR) * W * G;
+  const char wb2 = modet_tuning_env("MODET_WARP_BWD2");
+  if (d_src && wb2 != '0' && (int64_t)B * D * H * W * C * 3 < 0x7fffffffLL && total2 < 0x7fffffffLL && total2 >= 256 * 256) {
+    hipLaunchKernelGGL((warp_bwd2_kernel<WB2_ZR, WB2_YR>), dim3(flat_grid(total2, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src,
+                       d_flow, D, H, W, C, G, (unsigned)total2, add_flow);
+    return modet_launch_status();
+  }
   const int64_t total = (int64_t)B * cdiv(D, ZRUN) * H * W * G;       // one item per (z run, y, x, channel slot)
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow, D,
                      H, W, C, G, total, add_flow);
