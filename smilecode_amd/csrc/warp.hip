@@ -297,23 +297,45 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
 // merges of warp_bwd_kernel.  Same arithmetic per contribution; the order of the float adds differs (as between any two runs
 // of the atomic form).
 constexpr int WB_NONE = -2147483647 - 1;
+constexpr unsigned WB_OOB = 0x80000000u;               // buffer offset past any tensor here (< 2 GiB, checked on the host)
 #ifndef WB2_ZR
 #define WB2_ZR 8
 #endif
 #ifndef WB2_YR
 #define WB2_YR 4
 #endif
+#ifdef MODET_TUNING
+__device__ unsigned long long* g_wb_dbg = nullptr;
+#endif
+using WbRsrc = __amdgpu_buffer_rsrc_t;
+using wb_u32x3 = unsigned __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ WbRsrc wb_rsrc(const void* base, unsigned bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                     (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(u), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// Instruction diet of the first patch kernel (~750 instructions per voxel, 0.86 ms at level 1 whatever the patch shape: issue
+// bound, not atomic bound): every tensor through a buffer descriptor with a 32-bit byte offset (no 64-bit address pairs; an
+// offset past the tensor reads 0 / drops the atomic, so "this lane has nothing to add" is an offset select, not a branch),
+// 24-bit integer multiplies (full rate; v_mul_lo_u32 is quarter rate), per-axis validity as -1 / 0 masks folded into the
+// weights, flow as ONE 12-byte load, the x neighbour test on ONE shuffled value (the cell's byte offset: equal offsets = same
+// cell, see above), d_flow sums as (upper - lower) differences.
 template <int ZR, int YR>
 __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                         const float* __restrict__ dout, float* __restrict__ dsrc,
-                                                        float* __restrict__ dflow, int D, int H, int W, int C, int G,
+                                                        float* __restrict__ dflow, int B, int D, int H, int W, int C, int G,
                                                         unsigned total, int add_flow) {
   // total = B * ceil(D/ZR) * ceil(H/YR) * W * G items (one per patch column)
   const int V = D * H * W;
   const unsigned nzr = (unsigned)((D + ZR - 1) / ZR), nyr = (unsigned)((H + YR - 1) / YR);
   const unsigned total_pad = (total + BLK - 1) / BLK * BLK;       // keep whole waves alive for the shuffles
   const int lane = threadIdx.x & 63;
-  const int sX = C, sY = W * C, sZ = H * W * C;
+  const int sX = C * 4, sY = W * C * 4, sZ = H * W * C * 4;       // byte strides of a channel's volume
+  const unsigned tbytes = (unsigned)B * (unsigned)V * (unsigned)C * 4u, fbytes = (unsigned)B * (unsigned)V * 12u;
+  const WbRsrc r_src = wb_rsrc(src, tbytes), r_flow = wb_rsrc(flow, fbytes), r_do = wb_rsrc(dout, tbytes);
+  const WbRsrc r_ds = wb_rsrc(dsrc, dsrc ? tbytes : 0u), r_df = wb_rsrc(dflow, dflow ? fbytes : 0u);
+  const bool want_src = dsrc != nullptr, want_flow = dflow != nullptr;
   for (unsigned idx = blockIdx.x * BLK + threadIdx.x; idx < total_pad; idx += gridDim.x * BLK) {
     const bool inr = idx < total;
     const unsigned id = inr ? idx : total - 1;
@@ -325,8 +347,7 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
     const int zr = (int)(r % nzr);
     const int b = (int)(r / nzr);
     const int cc = livec ? c : 0;
-    const float* sb = src + (int64_t)b * V * C + cc;
-    float* db = dsrc ? dsrc + (int64_t)b * V * C + cc : nullptr;
+    const int cb = (b * V * C + cc) * 4;               // byte offset of (sample, channel) inside src / d_src / d_out
     const int up = lane + G, dn = lane - G;
     const int nxi = __shfl(xi, up, 64), pxi = __shfl(xi, dn, 64);
     const bool up_ok = (up < 64) && (idx + G < total) && nxi == xi + 1;
@@ -335,9 +356,18 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
     int OCoff[YR + 1];
 #pragma unroll
     for (int k = 0; k <= YR; ++k) { OC[k][0] = 0.f; OC[k][1] = 0.f; OCoff[k] = WB_NONE; }
-    auto flush2 = [&](int off, float v0, float v1) {
-      if (v0 != 0.f) atomicAdd(db + off, v0);
-      if (v1 != 0.f) atomicAdd(db + off + sX, v1);
+    auto atom = [&](int off, float v) {                // branch-free: nothing to add = an out-of-range offset
+#ifdef MODET_TUNING
+      if (g_wb_dbg) {                                  // census: atomic instructions issued, lanes that add something
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(v != 0.f);
+        if (lane == 0) { atomicAdd(g_wb_dbg, 1ull); atomicAdd(g_wb_dbg + 1, (unsigned long long)__builtin_popcountll(m)); }
+      }
+#endif
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r_ds, v != 0.f ? (unsigned)off : WB_OOB, 0, 0);
+    };
+    auto flush2 = [&](int off, float v0, float v1) {   // (for the rarely taken paths: skipped when no lane has anything)
+      if (v0 != 0.f) atom(off, v0);
+      if (v1 != 0.f) atom(off + sX, v1);
     };
     const int y0p = yr * YR;
 #pragma unroll 1
@@ -349,15 +379,16 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
       int ICoff = WB_NONE;
       float ON[YR + 1][2];
       int ONoff[YR + 1];
-      const int nplane = b * V + zc * H * W + xi;
+      const int nplane = b * V + __mul24(zc, H * W) + xi;
       // all loads of the run up front (flow, d_out of its YR voxels): independent of each other
-      float f0v[YR], f1v[YR], f2v[YR], gov[YR];
+      wb_u32x3 fv[YR];
+      float gov[YR];
 #pragma unroll
       for (int k = 0; k < YR; ++k) {
         const int yk = y0p + k < H ? y0p + k : H - 1;
-        const int n = nplane + yk * W;
-        f0v[k] = flow[(int64_t)n * 3]; f1v[k] = flow[(int64_t)n * 3 + 1]; f2v[k] = flow[(int64_t)n * 3 + 2];
-        gov[k] = dout[(int64_t)n * C + cc];
+        const int n = nplane + __mul24(yk, W);
+        fv[k] = __builtin_amdgcn_raw_buffer_load_b96(r_flow, (unsigned)n * 12u, 0, 0);
+        gov[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_do, (unsigned)n * (unsigned)sX + (unsigned)cc * 4u, 0, 0));
       }
 #pragma unroll
       for (int k = 0; k < YR; ++k) {
@@ -365,55 +396,61 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
         const bool yin = yi < H;
         const int yc = yin ? yi : H - 1;
         const bool live = livec && zin && yin;
-        const int n = nplane + yc * W;
+        const int n = nplane + __mul24(yc, W);
         const float go = live ? gov[k] : 0.f;
-        const Tri t = tri_setup((float)zc + f0v[k], (float)yc + f1v[k], (float)xi + f2v[k]);
+        // ---- footprint: floor, fraction, base cell clamped to [-2, dim] (anything outside [-1, dim - 1] has no valid corner)
+        const float z = (float)zc + __uint_as_float(fv[k][0]), y = (float)yc + __uint_as_float(fv[k][1]), x = (float)xi + __uint_as_float(fv[k][2]);
+        const float zf = floorf(z), yf = floorf(y), xf = floorf(x);
+        const float fz = z - zf, fy = y - yf, fx = x - xf;
+        const int z0 = (int)fminf(fmaxf(zf, -2.f), (float)D), y0 = (int)fminf(fmaxf(yf, -2.f), (float)H), x0 = (int)fminf(fmaxf(xf, -2.f), (float)W);
+        const int off0 = __mul24(__mul24(__mul24(z0, H) + y0, W) + x0, sX) + cb;      // byte offset of the (z0, y0, x0) cell
+        // per-axis validity as all-ones / zero masks, folded into the weights
+        const int mz0 = (unsigned)z0 < (unsigned)D ? -1 : 0, mz1 = (unsigned)(z0 + 1) < (unsigned)D ? -1 : 0;
+        const int my0 = (unsigned)y0 < (unsigned)H ? -1 : 0, my1 = (unsigned)(y0 + 1) < (unsigned)H ? -1 : 0;
+        const int mx0 = (unsigned)x0 < (unsigned)W ? -1 : 0, mx1 = (unsigned)(x0 + 1) < (unsigned)W ? -1 : 0;
+        auto msk = [](float v, int m) { return __uint_as_float(__float_as_uint(v) & (unsigned)m); };
+        const float wz[2] = {msk(1.f - fz, mz0), msk(fz, mz1)};
+        const float wy[2] = {msk(1.f - fy, my0), msk(fy, my1)};
+        const float wx[2] = {msk(1.f - fx, mx0), msk(fx, mx1)};
+        const float pyx[4] = {wy[0] * wx[0], wy[0] * wx[1], wy[1] * wx[0], wy[1] * wx[1]};     // [dy*2 + dx]
         float cv[8];                                   // index dz*4 + dy*2 + dx
+        {
+          const float g0 = wz[0] * go, g1 = wz[1] * go;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { cv[q] = g0 * pyx[q]; cv[4 + q] = g1 * pyx[q]; }
+        }
         float gz = 0.f, gy = 0.f, gx = 0.f;
-        const int off0 = ((t.z0 * H + t.y0) * W + t.x0) * C;     // (wild flows: tri_setup clamps to [-2, 1e9]; such cells are never valid)
-        const bool zok[2] = {t.z0 >= 0 && t.z0 < D, t.z0 + 1 >= 0 && t.z0 + 1 < D};
-        const bool yok[2] = {t.y0 >= 0 && t.y0 < H, t.y0 + 1 >= 0 && t.y0 + 1 < H};
-        const bool xok[2] = {t.x0 >= 0 && t.x0 < W, t.x0 + 1 >= 0 && t.x0 + 1 < W};
-        float sv[8];
-        if (dflow) {                                   // uniform
+        if (want_flow) {                               // uniform
+          float dot[8];
+          const int mzy[4] = {mz0 & my0, mz0 & my1, mz1 & my0, mz1 & my1};
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const bool ok = live && zok[q >> 2] && yok[(q >> 1) & 1] && xok[q & 1];
+          for (int q = 0; q < 8; ++q) {                // an offset outside the tensor reads 0; an aliased one is masked
             const int off = off0 + ((q >> 2) ? sZ : 0) + (((q >> 1) & 1) ? sY : 0) + ((q & 1) ? sX : 0);
-            sv[q] = sb[ok ? off : 0];
+            const float sv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_src, (unsigned)off, 0, 0));
+            dot[q] = msk(sv, mzy[q >> 1] & ((q & 1) ? mx1 : mx0)) * go;
           }
-        }
 #pragma unroll
-        for (int dz = 0; dz < 2; ++dz) {
-          const float wz = dz ? t.fz : 1.f - t.fz;
+          for (int q = 0; q < 4; ++q) gz = fmaf(pyx[q], dot[4 + q] - dot[q], gz);
+          const float wzx[4] = {wz[0] * wx[0], wz[0] * wx[1], wz[1] * wx[0], wz[1] * wx[1]};     // [dz*2 + dx]
+          const float wzy[4] = {wz[0] * wy[0], wz[0] * wy[1], wz[1] * wy[0], wz[1] * wy[1]};     // [dz*2 + dy]
 #pragma unroll
-          for (int dy = 0; dy < 2; ++dy) {
-            const float wy = dy ? t.fy : 1.f - t.fy;
+          for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-              const float wx = dx ? t.fx : 1.f - t.fx;
-              const bool ok = live && zok[dz] && yok[dy] && xok[dx];
-              cv[dz * 4 + dy * 2 + dx] = ok ? wz * wy * wx * go : 0.f;
-              if (dflow) {
-                const float dot = ok ? sv[dz * 4 + dy * 2 + dx] * go : 0.f;
-                gz += (dz ? 1.f : -1.f) * wy * wx * dot;
-                gy += (dy ? 1.f : -1.f) * wz * wx * dot;
-                gx += (dx ? 1.f : -1.f) * wz * wy * dot;
-              }
+            for (int d = 0; d < 2; ++d) {
+              gy = fmaf(wzx[dz * 2 + d], dot[dz * 4 + 2 + d] - dot[dz * 4 + d], gy);          // d = dx
+              gx = fmaf(wzy[dz * 2 + d], dot[dz * 4 + d * 2 + 1] - dot[dz * 4 + d * 2], gx);  // d = dy
             }
-          }
         }
-        if (db) {
-          // ---- x merge (as warp_bwd_kernel)
-          const int nz0 = __shfl(t.z0, up, 64), ny0 = __shfl(t.y0, up, 64), nx0 = __shfl(t.x0, up, 64);
-          const bool give = up_ok && zin && yin && nz0 == t.z0 && ny0 == t.y0 && nx0 == t.x0 + 1;
-          const int pz0 = __shfl(t.z0, dn, 64), py0 = __shfl(t.y0, dn, 64), px0 = __shfl(t.x0, dn, 64);
-          const bool take = dn_ok && zin && yin && pz0 == t.z0 && py0 == t.y0 && px0 == t.x0 - 1;
+        if (want_src) {
+          // ---- x merge: the neighbour one voxel up in x takes this voxel's dx = 1 corners when its base cell is this one + 1
+          const int nup = __shfl(off0, up, 64), ndn = __shfl(off0, dn, 64);
+          const bool give = up_ok && zin && yin && nup == off0 + sX;
+          const bool take = dn_ok && zin && yin && ndn + sX == off0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {                // q = dz*2 + dy
             const float from_prev = __shfl(cv[q * 2 + 1], dn, 64);
-            if (take) cv[q * 2] += from_prev;
-            if (give) cv[q * 2 + 1] = 0.f;
+            cv[q * 2] += take ? from_prev : 0.f;
+            cv[q * 2 + 1] = give ? 0.f : cv[q * 2 + 1];
           }
           // ---- z merge: the carry of this run position from the previous plane, (dz = 0, dy = 0) of this voxel
           if (OCoff[k] == off0) { cv[0] += OC[k][0]; cv[1] += OC[k][1]; }
@@ -426,12 +463,13 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
           if (ICoff == off0) { cv[0] += IC[0][0]; cv[1] += IC[0][1]; cv[4] += IC[1][0]; cv[5] += IC[1][1]; }
           else { flush2(ICoff, IC[0][0], IC[0][1]); flush2(ICoff + sZ, IC[1][0], IC[1][1]); }
           // ---- (dz = 0, dy = 0) is final; (dz = 1, dy = 0) waits for the next plane; dy = 1 for the next voxel of the run
-          flush2(off0, cv[0], cv[1]);
+          atom(off0, cv[0]);
+          if (__builtin_amdgcn_ballot_w64(cv[1] != 0.f)) atom(off0 + sX, cv[1]);     // (only where the x neighbour did not take it)
           ON[k][0] = cv[4]; ON[k][1] = cv[5]; ONoff[k] = off0 + sZ;
           IC[0][0] = cv[2]; IC[0][1] = cv[3]; IC[1][0] = cv[6]; IC[1][1] = cv[7];
           ICoff = off0 + sY;
         }
-        if (dflow) {
+        if (want_flow) {
           if (add_flow && live) {                      // C == 3: d(out_c)/d(flow_c) has the identity term
             gz += c == 0 ? go : 0.f; gy += c == 1 ? go : 0.f; gx += c == 2 ? go : 0.f;
           }
@@ -440,22 +478,21 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
             gy += __shfl_xor(gy, o, 64);
             gx += __shfl_xor(gx, o, 64);
           }
-          if (inr && zin && yin && c == 0) {
-            float* dfp = dflow + (int64_t)n * 3;
-            dfp[0] = gz; dfp[1] = gy; dfp[2] = gx;
-          }
+          const wb_u32x3 g3 = {__float_as_uint(gz), __float_as_uint(gy), __float_as_uint(gx)};
+          __builtin_amdgcn_raw_buffer_store_b96(g3, r_df, (inr && zin && yin && c == 0) ? (unsigned)n * 12u : WB_OOB, 0, 0);
         }
       }
-      if (db) {                                        // run end: the last voxel's dy = 1 level
-        flush2(ICoff, IC[0][0], IC[0][1]);
+      if (want_src) {                                  // run end: the last voxel's dy = 1 level
+        atom(ICoff, IC[0][0]);
+        if (__builtin_amdgcn_ballot_w64(IC[0][1] != 0.f)) atom(ICoff + sX, IC[0][1]);
         ON[YR][0] = IC[1][0]; ON[YR][1] = IC[1][1]; ONoff[YR] = ICoff == WB_NONE ? WB_NONE : ICoff + sZ;
 #pragma unroll
         for (int k = 0; k <= YR; ++k) { OC[k][0] = ON[k][0]; OC[k][1] = ON[k][1]; OCoff[k] = ONoff[k]; }
       }
     }
-    if (db) {
+    if (want_src) {
 #pragma unroll
-      for (int k = 0; k <= YR; ++k) flush2(OCoff[k], OC[k][0], OC[k][1]);
+      for (int k = 0; k <= YR; ++k) { atom(OCoff[k], OC[k][0]); atom(OCoff[k] + sX, OC[k][1]); }
     }
   }
 }
@@ -917,6 +954,12 @@ int modet_warp_fwd(const float* src, const float* flow, float* out, int B, int D
   return modet_launch_status();
 }
 
+#ifdef MODET_TUNING
+int modet_debug_warp_census(unsigned long long* buf) {      // not in the header: tuning builds only
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wb_dbg), &buf, sizeof(buf));
+}
+#endif
+
 int modet_warp_bwd(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow, int B, int D,
                    int H, int W, int C, int add_flow, int flow_bound, modet_stream_t stream) {
   MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(d_out);
@@ -938,9 +981,10 @@ int modet_warp_bwd(const float* src, const float* flow, const float* d_out, floa
   // patch form (x, z AND y merges): 32-bit offsets, enough patch columns to fill the chip
   const int64_t total2 = (int64_t)B * cdiv(D, WB2_ZR) * cdiv(H, WB2_YR) * W * G;
   const char wb2 = modet_tuning_env("MODET_WARP_BWD2");
-  if (d_src && wb2 != '0' && (int64_t)B * D * H * W * C * 3 < 0x7fffffffLL && total2 < 0x7fffffffLL && total2 >= 256 * 256) {
+  if (d_src && wb2 != '0' && (int64_t)B * D * H * W * (C > 3 ? C : 3) * 4 < 0x7fffffffLL && (int64_t)(D + 3) * (H + 3) * (W + 3) < (1 << 23) &&
+      W * C * 4 < (1 << 23) && total2 < 0x7fffffffLL && total2 >= 256 * 256) {
     hipLaunchKernelGGL((warp_bwd2_kernel<WB2_ZR, WB2_YR>), dim3(flat_grid(total2, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src,
-                       d_flow, D, H, W, C, G, (unsigned)total2, add_flow);
+                       d_flow, B, D, H, W, C, G, (unsigned)total2, add_flow);
     return modet_launch_status();
   }
   const int64_t total = (int64_t)B * cdiv(D, ZRUN) * H * W * G;       // one item per (z run, y, x, channel slot)

@@ -186,27 +186,37 @@ def _e2e(shape, dtype, seed=24, batch=1):
             "grad_rel_l2": float((gv - rv).norm() / rv.norm()), "flow_absmax": float(f64.abs().max())}
 
 
+def _yardstick(shape):
+    """the reference's own bf16 behaviour at this shape: tests/golden/bf16_yardstick.json (see make_bf16_yardstick.py)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_yardstick.json")) as f:
+        return json.load(f)["x".join(map(str, shape))]
+
+
 @pytest.mark.parametrize("shape", [(32, 48, 32), (64, 64, 64)])
 def test_bf16_end_to_end_tolerances(shape):
-    """cfg 5 stated tolerance vs the fp64 oracle of the reference path (random non-degenerate weights, |flow| up to 9-14
-    voxels): flow rms <= 0.1 voxel and 99.9 % of the voxels within 0.75 voxel, loss within 5e-3, the full parameter
-    gradient within 20 % (relative L2) and cosine >= 0.98 -- bf16 carries 8 significand bits, and the LayerNorm over 6
-    nearly equal projections amplifies the 0.4 % feature error exactly as it amplifies fp32's 6e-8.  Measured
-    (profiles/r02_parity_bf16_*.json): rms 0.024 / 0.045 voxels, p99.9 0.23 / 0.33, gradient rel. L2 0.088 / 0.105,
-    cosine 0.9962 / 0.9951 at 32x48x32 / 64^3; the same harness on the fp32 path: rms 2e-6 / 5e-6, gradient 6e-4 / 9e-5."""
+    """cfg 5 tolerance vs the fp64 oracle of the reference path (random non-degenerate weights, |flow| up to 9-14 voxels),
+    stated against a YARDSTICK instead of free-standing constants: what the reference itself does in bf16 -- the real
+    ModeT under ``torch.autocast("cpu", bfloat16)`` against its own fp32 run on the same inputs and weights
+    (tests/golden/bf16_yardstick.json, generated from /root/reference by tests/golden/make_bf16_yardstick.py): flow rms
+    0.039 / 0.048 voxels, p99.9 0.39 / 0.32, gradient rel. L2 0.153 / 0.130, cosine 0.988 / 0.993 at 32x48x32 / 64^3.  The HIP
+    bf16-STORAGE path (fp32 accumulate) must stay within 1.5x of every one of them; it measures BELOW them (rms 0.024 / 0.045,
+    p99.9 0.23 / 0.33, gradient 0.088 / 0.105, cosine 0.996 / 0.995).  bf16 carries 8 significand bits, and the LayerNorm over
+    6 nearly equal projections amplifies the 0.4 % feature error exactly as it amplifies fp32's 6e-8 -- for ATen as for us.
+    The same harness on the fp32 path: rms 2e-6 / 5e-6, gradient 6e-4 / 9e-5."""
     import json
     import os
     r = _e2e(shape, torch.bfloat16)
     r32 = _e2e(shape, torch.float32)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    y = _yardstick(shape)
     with open(os.path.join(root, "gpurun_out", "parity_bf16_%dx%dx%d.json" % shape), "w") as f:
-        json.dump({"bf16": r, "fp32": r32}, f, indent=1, sort_keys=True)
-    # ~2x what these shapes measure (rms 0.024 / 0.045, p99.9 0.23 / 0.33)
-    big = shape[0] >= 64
-    assert r["flow_rms"] <= (0.09 if big else 0.05) and r["flow_p999"] <= (0.7 if big else 0.5), r
+        json.dump({"bf16": r, "fp32": r32, "reference_autocast_bf16": y}, f, indent=1, sort_keys=True)
+    assert r["flow_rms"] <= 1.5 * y["flow_rms"] and r["flow_p999"] <= 1.5 * y["flow_p999"], (r, y)
     assert r["loss_err"] <= 5e-3, r
-    assert r["grad_cos"] >= 0.98 and r["grad_rel_l2"] <= 0.20, r
+    assert r["grad_rel_l2"] <= 1.5 * y["grad_rel_l2"] and 1.0 - r["grad_cos"] <= 1.5 * (1.0 - y["grad_cos"]), (r, y)
     assert r32["flow_rms"] <= 1e-4 and r32["grad_rel_l2"] <= 1e-2, r32       # the same harness on the fp32 path
 
 
@@ -314,12 +324,14 @@ def test_cfg5_shape_fp32_parity_vs_fp64_oracle(cfg5_oracle):
 
 
 def test_cfg5_shape_bf16_flow_and_dice_vs_fp64_oracle(cfg5_oracle):
-    """VERDICT r2 next-1a, bf16 half (BASELINE.json configs[4] = bf16 storage, 160x192x224, 2 pairs per GPU): against the
-    fp64 oracle of the reference path, on both samples: flow rms <= 0.1 voxel and 99.9 % of the voxels within 0.75 (the
-    bounds stated and measured at the small shapes; ~2x what this shape measures), the first loss
-    within 5e-3 -- and north_star's Dice statement: |Dice(bf16 HIP flow) - Dice(fp64 oracle flow)| <= 1e-3 through the
-    fused label-warp / Dice tail on the synthetic 54-label maps.  The gradient bound at this shape (relative L2 <= 0.35,
-    cosine >= 0.95) is ~1.5x what it measures."""
+    """BASELINE.json configs[4] = bf16 storage, 160x192x224, 2 pairs per GPU, against the fp64 oracle of the reference path,
+    on both samples, with the bounds stated against the YARDSTICK of what the reference itself does in bf16 at this very
+    shape (tests/golden/bf16_yardstick.json: the real ModeT under torch.autocast("cpu", bfloat16) vs its own fp32 run,
+    sample 0: flow rms 0.131 voxels, p99.9 0.96, max 5.5; gradient relative L2 0.220, cosine 0.976).  The HIP bf16-storage
+    path must stay within 1.5x of each of those numbers (it measures rms 0.057, p99.9 0.39, max 4.8; gradient 0.226 / 0.975:
+    2.3x closer than autocast on the flow, the same on the gradient), the first loss within 5e-3 -- and north_star's Dice
+    statement: |Dice(bf16 HIP flow) - Dice(fp64 oracle flow)| <= 1e-3 through the fused label-warp / Dice tail on the
+    synthetic 54-label maps."""
     from smilecode_amd.utils import warp_labels_and_dice
     from tests.util import note
     o = cfg5_oracle
@@ -349,9 +361,12 @@ def test_cfg5_shape_bf16_flow_and_dice_vs_fp64_oracle(cfg5_oracle):
     note("cfg5_bf16[160x192x224].dice_fp64_oracle", o["dice0"])
     # measured on MI355X at this shape (profiles/r03_parity_cfg5.json): rms 0.057, p99.9 0.385, loss 2.2e-4, gradient
     # relative L2 0.223 / cosine 0.975 (a little beyond the 64^3 numbers: 0.045 / 0.33 / 0.105 / 0.995), Dice |delta| 3.6e-5
-    assert rms <= 0.12 and p999 <= 0.8, (rms, p999)
+    y = _yardstick(CFG5_SHAPE)
+    note("cfg5_bf16[160x192x224].reference_autocast_flow_rms", y["flow_rms"])
+    note("cfg5_bf16[160x192x224].reference_autocast_grad_rel_l2", y["grad_rel_l2"])
+    assert rms <= 1.5 * y["flow_rms"] and p999 <= 1.5 * y["flow_p999"], (rms, p999, y)
     assert abs(s0 + r0 - o["loss0"]) <= 5e-3
-    assert cos >= 0.95 and rel <= 0.35, (cos, rel)
+    assert rel <= 1.5 * y["grad_rel_l2"] and 1.0 - cos <= 1.5 * (1.0 - y["grad_cos"]), (cos, rel, y)
     assert abs(dice - o["dice0"]) <= 1e-3, f"Dice {dice:.5f} (bf16 HIP) vs {o['dice0']:.5f} (fp64 oracle)"
 
 
