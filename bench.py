@@ -462,7 +462,7 @@ def main():
         return float(t.item()) / n
 
     graphed = False
-    if args.workload == "train" and args.graph != "off" and not args.overlap:
+    if args.workload == "train" and args.graph != "off":
         t_eager = quick()
         try:
             trainer.capture(mov, fix)
@@ -613,7 +613,7 @@ def main():
                 *shape, "fp32" if args.dtype == "f32" else "bf16 storage / fp32 accumulate (ConvInsBlock chains), fp32 elsewhere", args.batch, "full train step NCC+Grad3d fwd+bwd+Adam-amsgrad" + (" + RCCL grad all-reduce" if world > 1 else "")
                 if args.workload == "train" else "forward+warp")),
                 "shape": list(shape), "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                "allreduce": "3 buckets from backward hooks, overlapped" if args.overlap else "one flat all-reduce after backward"},
+                "allreduce": "3 buckets, each launched after its stage of the backward (three hipGraph segments), overlapped" if args.overlap else "one flat all-reduce after backward"},
             "roofline": roof, "roofline_top": roof_top, "host_enqueue_ms_per_step": host_graph_ms if graphed else host_ms,
             "loss_after_timed_region": loss_timed,
             "hip_graph": graphed, "eager": {"host_enqueue_ms_per_step": host_ms,

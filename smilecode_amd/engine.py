@@ -20,8 +20,14 @@ def poly_lr(epoch, max_epoch=30, init_lr=1e-4, power=0.9):
 class Trainer:
     def __init__(self, model, lr=1e-4, max_epoch=30, weights=(1.0, 1.0), betas=(0.9, 0.999), eps=1e-8, group=None,
                  overlap_allreduce=False):
-        """``overlap_allreduce``: all-reduce the gradients in three buckets launched from backward hooks (eager steps only;
-        a hipGraph-replayed step reduces the whole 4 MB buffer in one call after the replay)"""
+        """``overlap_allreduce``: all-reduce the gradients in three buckets while the rest of the backward runs
+        (BASELINE.json configs[4]).  The backward is cut into THREE AUTOGRAD STAGES at the bucket boundaries
+        (parallel.MODET_BUCKETS: per-level heads | encoder levels 3-5 | encoder levels 1-2; cut tensors = the encoder's
+        per-level features and the pooled input of level 3): stage k writes bucket k's gradients into the flat buffer, then
+        its ``all_reduce(async_op=True)`` is launched and stage k + 1 runs beside it.  Eager steps run the stages directly;
+        ``capture()`` captures them as three hipGraphs sharing one memory pool and a step is replay 0 -> all-reduce 0 ->
+        replay 1 -> all-reduce 1 -> replay 2 -> all-reduce 2 -> join -> Adam (host enqueue ~0.3 ms, no Python in the step).
+        Without it: one all-reduce of the whole 4 MB buffer after backward / after the single graph's replay."""
         self.model = model
         self.lr0, self.max_epoch, self.weights = lr, max_epoch, weights
         self.betas, self.eps, self.group = betas, eps, group
@@ -32,6 +38,7 @@ class Trainer:
         self.vmax = torch.zeros_like(self.fp.flat)
         self.step = 0
         self._graph = self._static_in = self._static_out = self._graph_key = None
+        self._stage_graphs = None           # overlap_allreduce: the three captured stage graphs
         self._steps = {}                    # (shape, device, grad mode) -> ops.StepContext, least recently used first
         self.max_step_contexts = 4
         self.batch_small_launches = os.environ.get("MODET_STEP_BATCHING", "1") != "0"
@@ -66,20 +73,7 @@ class Trainer:
         # one caller-owned step context per computation this trainer has run (shape, device, grad mode): its recorded
         # packing jobs and its packed-weights arena stay valid for as long as the trainer lives, so a captured graph of
         # shape A keeps working however many other shapes run eagerly in between
-        key = (tuple(moving.shape), moving.device, torch.is_grad_enabled())
-        sc = self._steps.pop(key, None)
-        if sc is None:
-            sc = ops.StepContext()
-        self._steps[key] = sc                           # most recently used last
-        # bounded: a long-lived trainer fed variable-sized volumes must not keep a native context + packed-weights arena per
-        # shape forever; the context of the captured graph's shape is never dropped (its arena is baked into the graph)
-        while len(self._steps) > self.max_step_contexts:
-            for k in self._steps:
-                if k != key and not (self._graph_key is not None and k[:2] == self._graph_key):
-                    del self._steps[k]
-                    break
-            else:
-                break
+        sc = self._step_context(moving)
         # the parameters are constant from here to the end of backward: pack all conv weights in one launch up front
         with sc.prepacked():
             with ops.trace_range("forward+loss"):
@@ -90,6 +84,143 @@ class Trainer:
                     loss.backward()
                 self.fp.gather_grads(scope.written)
         return loss.detach(), sim.detach(), reg.detach()
+
+    # ---------------------------------------------------------------- backward in three stages (overlapped all-reduce)
+    def _step_context(self, moving):
+        key = (tuple(moving.shape), moving.device, torch.is_grad_enabled())
+        sc = self._steps.pop(key, None)
+        if sc is None:
+            sc = ops.StepContext()
+        self._steps[key] = sc
+        while len(self._steps) > self.max_step_contexts:
+            for k in self._steps:
+                if k != key and not (self._graph_key is not None and k[:2] == self._graph_key):
+                    del self._steps[k]
+                    break
+            else:
+                break
+        return sc
+
+    def _staged_forward(self, moving, fixed):
+        """forward + losses with the autograd graph cut at the bucket boundaries (models.ModeT.stage_cuts: the heads see
+        leaves that share the encoder features' storage; Encoder.stage_cut: the same in front of level 3); returns the
+        state the three backward stages hand on"""
+        m, enc = self.model, self.model.encoder
+        m.stage_cuts, enc.stage_cut = True, True
+        try:
+            loss, sim, reg = self.loss(moving, fixed)
+        finally:
+            m.stage_cuts, enc.stage_cut = False, False
+        (M, Fx), (Ml, Fl) = m.cut_features, m.cut_leaves
+        p3, p3leaf = enc.cut
+        m.cut_features = m.cut_leaves = enc.cut = None
+        return {"loss": loss, "out": (loss.detach(), sim.detach(), reg.detach()), "feat": list(M) + list(Fx),
+                "leaf": list(Ml) + list(Fl), "p3": p3, "p3leaf": p3leaf, "g": None}
+
+    def _staged_backward(self, st, k, sc):
+        """stage k of the backward: gradients of bucket k's parameters -> flat buffer (conv weights through the deferred
+        reductions of this stage's own scope); gradients of the cut leaves -> st["g"] for the stages that own their producers"""
+        members = self.buckets.members[k]
+        params = [self.fp.params[i] for i in members]
+        if k == 0:                                      # loss -> heads -> feature leaves
+            outs, gouts, extra = [st["loss"]], [None], st["leaf"]
+        else:
+            lv = (2, 3, 4) if k == 1 else (0, 1)        # encoder levels 3-5, then 1-2 (feat = [M1..M5, F1..F5])
+            idx = [i for i in lv] + [5 + i for i in lv]
+            idx = [i for i in idx if st["g"][i] is not None]             # (a feature no loss term reaches has no gradient)
+            outs, gouts = [st["feat"][i] for i in idx], [st["g"][i] for i in idx]
+            extra = [st["p3leaf"]] if k == 1 else []
+            if k == 2 and st["gp3"] is not None:
+                outs.append(st["p3"]); gouts.append(st["gp3"])
+        with sc.deferred(self.fp.grad_destinations()) as scope:
+            grads = torch.autograd.grad(outs, params + extra, gouts, allow_unused=True)
+        views, srcs, missing = [], [], []
+        for i, gi in zip(members, grads[:len(params)]):
+            off, n = self.fp.offsets[i]
+            v = self.fp.grad[off:off + n].view(self.fp.params[i].shape)
+            if gi is not None:
+                if self.fp.params[i].data_ptr() in scope.written:           # a second use of the weight went through autograd
+                    v.add_(gi)
+                else:
+                    views.append(v); srcs.append(gi)
+            elif self.fp.params[i].data_ptr() not in scope.written:
+                missing.append(v)
+        if views:
+            torch._foreach_copy_(views, srcs)
+        if missing:
+            torch._foreach_zero_(missing)
+        if k == 0:
+            st["g"] = list(grads[len(params):])
+            st["loss"] = None
+        elif k == 1:
+            st["gp3"] = grads[len(params)]
+            for i in idx:
+                st["g"][i] = None                                            # consumed: let the buffers go
+
+    def _fwd_bwd_staged(self, moving, fixed, launch=None):
+        """eager form: forward, then stage 0..2, ``launch(k)`` after each (the bucket's all-reduce)"""
+        sc = self._step_context(moving)
+        with sc.prepacked():
+            with ops.trace_range("forward+loss"):
+                st = self._staged_forward(moving, fixed)
+            for k in range(3):
+                with ops.trace_range("backward stage %d" % k):
+                    self._staged_backward(st, k, sc)
+                if launch is not None:
+                    launch(k)
+        return st["out"]
+
+    def _capture_staged(self, moving, fixed, warmup, verify):
+        """three hipGraphs sharing one pool: [forward + losses + stage 0] [stage 1] [stage 2]"""
+        import torch.distributed as dist
+        self._static_in = (moving.clone(), fixed.clone())
+        side = torch.cuda.Stream(device=moving.device)
+        side.wait_stream(torch.cuda.current_stream(moving.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 2)):
+                self._fwd_bwd_staged(*self._static_in)
+        torch.cuda.current_stream(moving.device).wait_stream(side)
+        torch.cuda.synchronize(moving.device)
+        ref = self.fp.grad.clone() if verify else None
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        sc = self._step_context(self._static_in[0])
+        graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+        with sc.prepacked():
+            with torch.cuda.graph(graphs[0], capture_error_mode=mode):
+                st = self._staged_forward(*self._static_in)
+                self._staged_backward(st, 0, sc)
+            pool = graphs[0].pool()
+            for k in (1, 2):
+                with torch.cuda.graph(graphs[k], pool=pool, capture_error_mode=mode):
+                    self._staged_backward(st, k, sc)
+        self._static_out = st["out"]
+        st["loss"] = None
+        self._stage_graphs, self._graph = graphs, graphs[0]
+        self._graph_key = (tuple(moving.shape), moving.device)
+        if verify:
+            self._verify_replay(ref, lambda: [gr.replay() for gr in graphs])
+
+    def _verify_replay(self, ref, replay):
+        # PER PARAMETER, relative L2: a replay that is wrong only in a tensor whose gradients are 100x below the global
+        # maximum must not pass on the strength of the large ones.  What a healthy replay differs by is the float-atomic
+        # reorder of the warp scatter (~1e-6 in fp32; with bf16 storage a flipped rounding downstream makes it up to ~0.2
+        # of the max of a tiny-gradient tensor, a few % in L2); a broken one (stale buffer, NaN, 1e20) is >= 1.
+        seg = self.fp.segment_index()
+        nseg = len(self.fp.params)
+        ref_sq = torch.zeros(nseg, device=ref.device, dtype=torch.float64).index_add_(0, seg, ref.double() ** 2)
+        floor = 1e-10 * float(ref_sq.max())             # analytically-zero bias gradients (conv bias under InstanceNorm)
+        for rep in range(2):
+            self.fp.grad.fill_(float("nan"))
+            replay()
+            d = (self.fp.grad - ref).double() ** 2
+            err_sq = torch.zeros(nseg, device=ref.device, dtype=torch.float64).index_add_(0, seg, d)   # NaN propagates
+            bad = torch.nonzero(~(err_sq <= 0.25 ** 2 * ref_sq + floor)).flatten().tolist()
+            if bad:
+                self.release_graph()
+                i = bad[0]
+                raise RuntimeError(f"hipGraph replay {rep} of the train step does not reproduce the eager gradients: "
+                                   f"{len(bad)} of {nseg} parameter tensors differ, first #{i} (|diff|_2 {float(err_sq[i]) ** 0.5:.3e} "
+                                   f"vs |grad|_2 {float(ref_sq[i]) ** 0.5:.3e}); running eagerly is the fallback")
 
     def capture(self, moving, fixed, warmup=2, verify=True):
         """Capture forward + losses + backward + gradient packing for this input shape into ONE hipGraph
@@ -104,6 +235,9 @@ class Trainer:
         differently from how it ran (round 3: a hipMemsetAsync node cleared its buffer on the first replay only and the step
         was silently wrong from the second one on); two eager-sized steps, once per capture.  Returns self."""
         self.model.train()
+        if self.buckets is not None:
+            self._capture_staged(moving, fixed, warmup, verify)
+            return self
         self._static_in = (moving.clone(), fixed.clone())
         side = torch.cuda.Stream(device=moving.device)
         side.wait_stream(torch.cuda.current_stream(moving.device))
@@ -126,30 +260,11 @@ class Trainer:
         self._graph_key = (tuple(moving.shape), moving.device)
         if verify:
             ref = self.fp.grad.clone()                      # the last warm-up pass = the eager step on these parameters
-            # PER PARAMETER, relative L2: a replay that is wrong only in a tensor whose gradients are 100x below the global
-            # maximum must not pass on the strength of the large ones.  What a healthy replay differs by is the float-atomic
-            # reorder of the warp scatter (~1e-6 in fp32; with bf16 storage a flipped rounding downstream makes it up to ~0.2
-            # of the max of a tiny-gradient tensor, a few % in L2); a broken one (stale buffer, NaN, 1e20) is >= 1.
-            seg = self.fp.segment_index()
-            nseg = len(self.fp.params)
-            ref_sq = torch.zeros(nseg, device=ref.device, dtype=torch.float64).index_add_(0, seg, ref.double() ** 2)
-            floor = 1e-10 * float(ref_sq.max())             # analytically-zero bias gradients (conv bias under InstanceNorm)
-            for rep in range(2):
-                self.fp.grad.fill_(float("nan"))
-                g.replay()
-                d = (self.fp.grad - ref).double() ** 2
-                err_sq = torch.zeros(nseg, device=ref.device, dtype=torch.float64).index_add_(0, seg, d)   # NaN propagates
-                bad = torch.nonzero(~(err_sq <= 0.25 ** 2 * ref_sq + floor)).flatten().tolist()
-                if bad:
-                    self.release_graph()
-                    i = bad[0]
-                    raise RuntimeError(f"hipGraph replay {rep} of the train step does not reproduce the eager gradients: "
-                                       f"{len(bad)} of {nseg} parameter tensors differ, first #{i} (|diff|_2 {float(err_sq[i]) ** 0.5:.3e} "
-                                       f"vs |grad|_2 {float(ref_sq[i]) ** 0.5:.3e}); running eagerly is the fallback")
+            self._verify_replay(ref, g.replay)
         return self
 
     def release_graph(self):
-        self._graph = self._static_in = self._static_out = self._graph_key = None
+        self._graph = self._static_in = self._static_out = self._graph_key = self._stage_graphs = None
 
     def release_steps(self):
         """drop every cached step context (recorded packing jobs + packed-weights arenas) that no captured graph uses"""
@@ -162,18 +277,20 @@ class Trainer:
         if getattr(self, "_graph", None) is not None and self._graph_key == (tuple(moving.shape), moving.device):
             self._static_in[0].copy_(moving, non_blocking=True)
             self._static_in[1].copy_(fixed, non_blocking=True)
-            self._graph.replay()
+            if self._stage_graphs is not None:              # overlapped: replay k -> all-reduce of bucket k (async) -> replay k + 1
+                self.buckets.begin_staged()
+                for k, gr in enumerate(self._stage_graphs):
+                    gr.replay()
+                    self.buckets.launch(k)
+                scale = self.buckets.finish_staged()
+            else:
+                self._graph.replay()
+                scale = self.fp.allreduce_grads(self.group)
             loss, sim, reg = self._static_out
-            scale = self.fp.allreduce_grads(self.group)
         elif self.buckets is not None:
-            self.fp.zero_grad()
-            with ops.trace_range("forward+loss"):
-                loss, sim, reg = self.loss(moving, fixed)
-            self.buckets.begin()
-            with ops.trace_range("backward+allreduce"):
-                loss.backward()
-                scale = self.buckets.finish()
-            loss, sim, reg = loss.detach(), sim.detach(), reg.detach()
+            self.buckets.begin_staged()
+            loss, sim, reg = self._fwd_bwd_staged(moving, fixed, self.buckets.launch)
+            scale = self.buckets.finish_staged()
         else:
             loss, sim, reg = self._fwd_bwd(moving, fixed)
             scale = self.fp.allreduce_grads(self.group)

@@ -162,19 +162,33 @@ class Encoder(nn.Module):
         outs.append(cur)
         return tuple(outs)
 
+    stage_cut = False       # engine.Trainer (overlapped all-reduce): cut the autograd graph in front of level 3
+
+    def _cut(self, t):
+        """graph cut for a staged backward: the consumer sees a fresh leaf sharing t's storage (no copy); the stage that owns
+        the producer later backpropagates ``leaf.grad`` into ``t`` (self.cut = (t, leaf))"""
+        leaf = t.detach().requires_grad_(True)
+        self.cut = (t, leaf)
+        return leaf
+
     def forward_pair(self, x, B):
         """x = [moving; fixed] as one batch of 2B (InstanceNorm is per sample, so this is exact); returns the per-level
         features of each half: ([M1..M5], [F1..F5])"""
         Ms, Fs = [], []
+        pooled_in = []
         if not self.bf16:
             # fp32: the last InstanceNorm of a level writes the level's features and their pooled copy in one pass
             pooled, m, f = _two_blocks_pool(self.conv0[0](x), self.conv0[1], self.conv0[2], B)
             Ms.append(m)
             Fs.append(f)
+            pooled_in.append(pooled)
             for blk in (self.conv1, self.conv2, self.conv3):
+                if blk is self.conv2 and self.stage_cut:
+                    pooled = self._cut(pooled)
                 pooled, m, f = _two_blocks_pool(pooled, blk[1], blk[2], B)
                 Ms.append(m)
                 Fs.append(f)
+                pooled_in.append(pooled)
             cur = _two_blocks(pooled, self.conv4[1], self.conv4[2], False)
         else:
             cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2], self.bf16)
@@ -182,6 +196,9 @@ class Encoder(nn.Module):
                 pooled, m, f = ops.pool_tee_split(cur, B)
                 Ms.append(m)
                 Fs.append(f)
+                pooled_in.append(pooled)
+                if blk is self.conv2 and self.stage_cut:
+                    pooled = self._cut(pooled)
                 cur = _two_blocks(pooled, blk[1], blk[2], self.bf16)        # blk[0] is the AvgPool3d(2) the tee already applied
         m, f = _SplitBatch.apply(cur, B)
         Ms.append(m)
@@ -339,6 +356,7 @@ class ModeT(nn.Module):
     """reference ModeT/models.py:338-412 (scale=None -> head_dim**-0.5)."""
 
     _flavour = "grid"
+    stage_cuts = False      # set by engine.Trainer around a forward whose backward runs in stages
 
     def __init__(self, inshape=(160, 192, 160), in_channel=1, channels=4, head_dim=6, num_heads=[8, 4, 2, 1, 1],
                  scale=None, legacy_grid_buffers=False, act_dtype=torch.float32, fused_attention=True):
@@ -394,6 +412,15 @@ class ModeT(nn.Module):
         # shared encoder on both images as one batch (InstanceNorm is per sample, so this is exact)
         with ops.trace_range("encoder"):
             M, Fx = self.encoder.forward_pair(torch.cat([mov_cl, fix_cl], 0), B)
+        if self.stage_cuts:
+            # staged backward (engine.Trainer, overlapped all-reduce): the heads consume fresh LEAVES that share the features'
+            # storage, so the heads' graph and the encoder's are disconnected and each stage's autograd run touches its own
+            # nodes only (a cut at a non-leaf does not do that: autograd marks everything that can reach a node with a
+            # captured output as needed, and the first stage would run -- and free -- half of the encoder's backward)
+            self.cut_features = (M, Fx)
+            M = [m.detach().requires_grad_(True) for m in M]
+            Fx = [f.detach().requires_grad_(True) for f in Fx]
+            self.cut_leaves = (M, Fx)
         ST = self.transformer
 
         with ops.trace_range("level5"):

@@ -186,6 +186,28 @@ class BucketedAllReduce:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             self.works.append(dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    # ---- staged form (engine.Trainer: the backward runs as three autograd stages, or three hipGraph replays): bucket k's
+    # gradients are complete in the flat buffer when stage k has been enqueued -- no hooks involved
+    def begin_staged(self):
+        self.enabled = False
+        self.works = []
+
+    def launch(self, k):
+        """all-reduce bucket k asynchronously: torch.distributed's stream waits for everything enqueued on the current
+        stream so far (stage k) and then runs beside stage k + 1"""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            a, b = self.ranges[k]
+            self.works.append(dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish_staged(self):
+        """join every collective (the current stream waits); returns 1/world"""
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if dist.is_available() and dist.is_initialized():
+            return 1.0 / dist.get_world_size(self.group)
+        return 1.0
+
     def begin(self):
         """call right before backward()"""
         self.pending = [len(m) for m in self.members]

@@ -83,6 +83,8 @@ def main(argv=None):
     ap.add_argument("--no-restore-optimizer", action="store_true",
                     help="resume exactly like the reference: weights only, Adam restarts from zero moments (train.py:84)")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel of a step from Python instead of replaying a hipGraph")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="multi-GPU: all-reduce the gradients in three buckets beside the backward (three hipGraph segments)")
     ap.add_argument("--host-loader", action="store_true",
                     help="read the .pkl pair from the host every iteration instead of caching all subjects in HBM")
     args = ap.parse_args(argv)
@@ -114,7 +116,8 @@ def main(argv=None):
         model.load_state_dict(resume["state_dict"])
         if rank == 0:
             print(ck)
-    trainer = Trainer(model, lr=args.lr, max_epoch=args.max_epoch, weights=weights)   # Adam(amsgrad) + NCC + Grad3d('l2')
+    trainer = Trainer(model, lr=args.lr, max_epoch=args.max_epoch, weights=weights,   # Adam(amsgrad) + NCC + Grad3d('l2')
+                      overlap_allreduce=args.overlap_allreduce)
     if resume is not None and not args.no_restore_optimizer and isinstance(resume.get("optimizer"), dict) \
             and "state" in resume["optimizer"]:
         # the reference saves optimizer.state_dict() but never loads it back (train.py:80-85): a resumed run restarts

@@ -20,6 +20,11 @@ models.load_numpy_weights(model, synth.make_weights(24 + rank))      # rank 1 st
 tr = Trainer(model, overlap_allreduce=os.environ.get("MODET_OVERLAP") == "1")
 mov, fix = synth.make_pair(shape, 24, world)                          # the same batch the single-process run uses
 mov, fix = torch.from_numpy(mov[rank:rank + 1]).cuda(), torch.from_numpy(fix[rank:rank + 1]).cuda()
+if os.environ.get("MODET_GRAPH") == "1":                             # the captured step (overlap: three stage graphs)
+    tr.capture(mov, fix)
+    flag = torch.tensor([1 if tr._graph is not None else 0], device="cuda")
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)     # every rank on the same path
+    assert int(flag) == 1
 tr.train_step(mov, fix, epoch=0)
 torch.cuda.synchronize()
 np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=tr.fp.flat.cpu().numpy(), grad=(tr.fp.grad / world).cpu().numpy())

@@ -339,18 +339,19 @@ def test_full_size_gradient_parity_vs_oracle(oracle_job):
     assert worst <= 2e-2, f"worst gradient error {worst:.3e} of max|g| in {worst_name}"
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
-def test_data_parallel_two_ranks_equal_batch_two(tmp_path, overlap):
+@pytest.mark.parametrize("overlap,graph", [("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")])
+def test_data_parallel_two_ranks_equal_batch_two(tmp_path, overlap, graph):
     """N ranks x 1 pair with one averaged all-reduce == one process with batch N (N = 2 ranks sharing
-    this GPU over gloo; on the 8-GPU node the same code runs over RCCL).  overlap=1: the three-bucket all-reduce launched
-    from backward hooks (cfg 5) instead of one all-reduce after backward."""
+    this GPU over gloo; on the 8-GPU node the same code runs over RCCL).  overlap=1: the backward in three autograd stages,
+    bucket k's all-reduce launched after stage k (cfg 5) instead of one all-reduce after backward; graph=1: the step
+    replayed from hipGraphs (overlap: three stage graphs with the all-reduces between the replays)."""
     import subprocess
     import sys
     from smilecode_amd import models, synth
     from smilecode_amd.engine import Trainer
     shape = (32, 48, 32)
-    env = dict(os.environ, MODET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MODET_OVERLAP=overlap)
-    port = 29700 + os.getpid() % 200 + int(overlap)
+    env = dict(os.environ, MODET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MODET_OVERLAP=overlap, MODET_GRAPH=graph)
+    port = 29700 + os.getpid() % 200 + int(overlap) + 2 * int(graph)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path),
            ",".join(map(str, shape))]
