@@ -327,6 +327,84 @@ def test_bucketed_overlapped_allreduce_gloo_world2():
         assert sum(any(n.startswith(q) for q in pre) for pre in MODET_BUCKETS) == 1, n
 
 
+def _staged_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from smilecode_amd.parallel import BucketedAllReduce, FlatParams, broadcast_parameters, init_from_env
+    init_from_env("gloo")
+    torch.manual_seed(7)
+    # stand-in with ModeT's shape of dependencies: an "encoder" of two parts (buckets 2 and 1, the second fed by the first),
+    # "heads" (bucket 0) that read BOTH encoder outputs -- cut with leaves exactly as engine.Trainer._staged_forward does
+    net = torch.nn.ModuleDict({"heads": torch.nn.Linear(8, 3), "enc_hi": torch.nn.Linear(8, 4), "enc_lo": torch.nn.Linear(6, 8)})
+    fp = FlatParams(net)
+    broadcast_parameters(fp)
+    bk = BucketedAllReduce(fp, list(net.named_parameters()), (("heads.",), ("enc_hi.",), ("enc_lo.",)))
+    x = torch.full((5, 6), 0.1 * (rank + 1))
+
+    def plain():
+        fp.zero_grad()
+        f1 = torch.tanh(net["enc_lo"](x)); f2 = torch.tanh(net["enc_hi"](f1))
+        loss = net["heads"](torch.cat([f1[:, :4] * f2, f1[:, 4:]], 1)).square().sum()
+        loss.backward()
+        fp.gather_grads()
+        return (fp.grad * fp.allreduce_grads()).clone()
+
+    def staged():
+        f1 = torch.tanh(net["enc_lo"](x))
+        f1_hi = f1.detach().requires_grad_(True)                 # cut in front of the second encoder part
+        f2 = torch.tanh(net["enc_hi"](f1_hi))
+        l1, l2 = f1.detach().requires_grad_(True), f2.detach().requires_grad_(True)     # the heads see leaves
+        loss = net["heads"](torch.cat([l1[:, :4] * l2, l1[:, 4:]], 1)).square().sum()
+        fp.grad.fill_(float("nan"))
+        bk.begin_staged()
+        stages = [([loss], [None], [l1, l2]), None, None]
+        carried = {}
+        for k in range(3):
+            params = [fp.params[i] for i in bk.members[k]]
+            if k == 0:
+                outs, gouts, extra = [loss], [None], [l1, l2]
+            elif k == 1:
+                outs, gouts, extra = [f2], [carried["l2"]], [f1_hi]
+            else:
+                outs, gouts, extra = [f1, f1], [carried["l1"], carried["f1_hi"]], []
+            g = torch.autograd.grad(outs, params + extra, gouts, allow_unused=True)
+            for i, gi in zip(bk.members[k], g[:len(params)]):
+                off, n = fp.offsets[i]
+                fp.grad[off:off + n].copy_(gi.reshape(-1))
+            if k == 0:
+                carried["l1"], carried["l2"] = g[len(params):]
+            elif k == 1:
+                carried["f1_hi"] = g[len(params)]
+            bk.launch(k)                                         # all-reduce of bucket k while stage k + 1 runs
+        return (fp.grad * bk.finish_staged()).clone()
+
+    a, b = plain(), staged()
+    q.put((rank, a.numpy(), b.numpy()))
+    dist.destroy_process_group()
+
+
+def test_staged_backward_with_bucket_allreduce_gloo_world2():
+    """the graph-compatible form of cfg 5's overlapped all-reduce (engine.Trainer with overlap_allreduce=True): the backward
+    as three autograd stages cut with leaves at the bucket boundaries, bucket k reduced right after stage k
+    (BucketedAllReduce.begin_staged / launch / finish_staged) -- equals the plain backward + one all-reduce, on two gloo
+    ranks with different data; every gradient slot is rewritten (NaN pre-fill)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29411 + os.getpid() % 200
+    procs = [ctx.Process(target=_staged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, plain, staged in res:
+        assert np.isfinite(staged).all()
+        assert np.allclose(plain, staged, rtol=0, atol=1e-6), np.abs(plain - staged).max()
+    assert np.array_equal(res[0][2], res[1][2]), "ranks must end with identical averaged gradients"
+
+
 def test_bench_self_launches_n_ranks_and_refuses_missing_gpus():
     """`python bench.py --gpus N` (no torchrun env) must itself start N ranks and prove it in the JSON line; with fewer
     than N GPUs it must fail loudly instead of silently running world=1.  Exercised on gloo with the
