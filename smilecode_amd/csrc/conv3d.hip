@@ -1352,13 +1352,25 @@ __global__ __launch_bounds__(NTHR) void conv_c1_wgrad_mfma_kernel(const float* _
     }
     __builtin_amdgcn_s_setprio(0);
   }
-  // part[(blk*4 + wave)*2 + grp][tap row][col]
+  // The four waves are summed through LDS in fixed order (deterministic), ONE partial per workgroup:
+  // part[blk*2 + grp][tap row][col].  (Per-wave partials made 4 096 rows of 512 floats: the reduction -- eight quarter-tile
+  // workgroups walking them in dependent batches -- took 49 us of every step for 108 weights.)
+  float* red = dys;                                  // 2 x 256 floats
+  for (int w4 = 0; w4 < 4; ++w4) {
+    __syncthreads();
+    if (wave == w4) {
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    float* pp = part + (((int64_t)blockIdx.x * 4 + wave) * 2 + g) * 256;
+      for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pp[(lk * 4 + j) * 16 + li] = acc[g][j];
+        for (int j = 0; j < 4; ++j) {
+          float* slot = red + g * 256 + (lk * 4 + j) * 16 + li;
+          *slot = w4 == 0 ? acc[g][j] : *slot + acc[g][j];
+        }
+    }
   }
+  __syncthreads();
+  float* pp = part + (int64_t)blockIdx.x * 512;
+  for (int i = tid; i < 512; i += NTHR) pp[i] = red[i];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -2135,7 +2147,7 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
     const int nblk = ntiles < C1_MFMA_BLOCKS ? ntiles : C1_MFMA_BLOCKS;
     hipLaunchKernelGGL(conv_c1_wgrad_mfma_kernel, dim3(nblk), dim3(NTHR), 0, s, x, d_y, y_act, (float*)ws, D, H, W, tx, ty, tz,
                        ntiles);
-    reduce_or_defer(ReduceJob{(const float*)ws, d_w, d_bias, 1, 4, nblk * 4, 1, 1, 1, 2, 0}, 2 * 4, s, defer);
+    reduce_or_defer(ReduceJob{(const float*)ws, d_w, d_bias, 1, 4, nblk, 1, 1, 1, 2, 0}, 2 * 4, s, defer);
     return modet_launch_status();
   }
   if (!y_act && use_x3_wgrad(B, D, H, W, Cin, Cout))

@@ -593,49 +593,58 @@ __global__ __launch_bounds__(NTHR) void conv3d_bf16_wgrad_kernel(const void* __r
   for (int i = tid; i < RED_FL; i += NTHR) out[i] = red[i];
 }
 
-// stage 1 of the partial reduction: red[j] = sum_g part[g][j] over the gx workgroup partials, j over gy * RED_FL floats.
-// 1024 threads = 64 consecutive j x 16 g-lanes: coalesced 256-byte rows, fixed assignment and fixed order (fp64):
-// deterministic.  (One thread per output element walking 512 partials 28 KB apart took longer than the MFMA kernel.)
+// stage 1 of the partial reduction: red[j] = sum_g part[g][j] over the gx workgroup partials, j over row_fl floats (a
+// multiple of 256).  256 threads = (256 / RG) column QUADS x RG row lanes: a thread owns 4 consecutive columns (16-byte loads:
+// a wave reads 1 KB of one partial row per instruction) and every RG-th row, eight rows in flight (fenced: one load -> wait
+// -> add per row is a chain of dependent round trips), fp64 accumulators, the RG row lanes summed through LDS in fixed
+// order: deterministic.  RG follows the number of partial rows (colsum_rg: 512 rows -> 16 lanes of 32 rows, 16 rows -> one
+// lane): the first form (64 columns x 16 row lanes of scalar loads, whatever gx) ran the 390 MB of one step's partials at
+// 2.9 TB/s, and layers with few partial rows used one load per thread.
+__host__ __device__ inline int colsum_rg(int gx) { return gx >= 512 ? 16 : (gx >= 256 ? 8 : (gx >= 128 ? 4 : (gx >= 64 ? 2 : 1))); }
+__host__ __device__ inline int colsum_blocks(int64_t row_fl, int gx) { return (int)cdiv64(row_fl / 4, 256 / colsum_rg(gx)); }
 __device__ __forceinline__ void wgrad_bf16_colsum_body(const float* __restrict__ part, float* __restrict__ red, int gx,
-                                                       int64_t row_fl, int blk, double (*sm)[64]) {
-  const int o = threadIdx.x & 63, gl = threadIdx.x >> 6;
-  const int64_t j = (int64_t)blk * 64 + o;
-  double a = 0.0;
+                                                       int64_t row_fl, int blk, double (*sm)[4]) {
+  const int RG = colsum_rg(gx), QPB = 256 / RG;
+  const int q = threadIdx.x % QPB, rg = threadIdx.x / QPB;
+  const int64_t j = ((int64_t)blk * QPB + q) * 4;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (j < row_fl) {
-    // eight partial rows in flight per thread (fenced: one load -> wait -> add per row was a chain of gx / 16 round trips);
-    // the adds keep their order
-    int g = gl;
-    for (; g + 7 * 16 < gx; g += 8 * 16) {
-      float r[8];
+    const float* base = part + j;
+    int g = rg;
+    for (; g + 7 * RG < gx; g += 8 * RG) {
+      float4 r[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) r[u] = part[(int64_t)(g + 16 * u) * row_fl + j];
+      for (int u = 0; u < 8; ++u) r[u] = *reinterpret_cast<const float4*>(base + (int64_t)(g + RG * u) * row_fl);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(r[u]));
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(r[u].x), "+v"(r[u].y), "+v"(r[u].z), "+v"(r[u].w));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += (double)r[u];
+      for (int u = 0; u < 8; ++u) { a0 += (double)r[u].x; a1 += (double)r[u].y; a2 += (double)r[u].z; a3 += (double)r[u].w; }
     }
     {
-      float r[8];
+      float4 r[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) r[u] = part[(int64_t)(g + 16 * u < gx ? g + 16 * u : 0) * row_fl + j];     // row 0 always exists
+      for (int u = 0; u < 8; ++u) r[u] = *reinterpret_cast<const float4*>(base + (int64_t)(g + RG * u < gx ? g + RG * u : 0) * row_fl);   // row 0 always exists
 #pragma unroll
-      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(r[u]));
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(r[u].x), "+v"(r[u].y), "+v"(r[u].z), "+v"(r[u].w));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += g + 16 * u < gx ? (double)r[u] : 0.0;
+      for (int u = 0; u < 8; ++u) {
+        const bool in = g + RG * u < gx;
+        a0 += in ? (double)r[u].x : 0.0; a1 += in ? (double)r[u].y : 0.0; a2 += in ? (double)r[u].z : 0.0; a3 += in ? (double)r[u].w : 0.0;
+      }
     }
   }
-  sm[gl][o] = a;
-  __syncthreads();
-  if (gl == 0 && j < row_fl) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sm[k][o];
-    red[j] = (float)t;
+  if (RG > 1) {
+    sm[threadIdx.x][0] = a0; sm[threadIdx.x][1] = a1; sm[threadIdx.x][2] = a2; sm[threadIdx.x][3] = a3;
+    __syncthreads();
+    if (rg == 0) {
+      for (int k = 1; k < RG; ++k) { a0 += sm[k * QPB + q][0]; a1 += sm[k * QPB + q][1]; a2 += sm[k * QPB + q][2]; a3 += sm[k * QPB + q][3]; }
+    }
   }
+  if (rg == 0 && j < row_fl) *reinterpret_cast<float4*>(red + j) = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
 }
-__global__ __launch_bounds__(1024) void wgrad_bf16_colsum_kernel(const float* __restrict__ part, float* __restrict__ red,
-                                                                 int gx, int64_t row_fl) {
-  __shared__ double sm[16][64];
+__global__ __launch_bounds__(256) void wgrad_bf16_colsum_kernel(const float* __restrict__ part, float* __restrict__ red,
+                                                                int gx, int64_t row_fl) {
+  __shared__ double sm[256][4];
   wgrad_bf16_colsum_body(part, red, gx, row_fl, blockIdx.x, sm);
 }
 
@@ -729,8 +738,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
 // weight gradient in two launches instead of two per layer; job tables by value in the kernel arguments.
 constexpr int BRED_MAX_JOBS = 24;
 struct BRedTable { BRedJob job[BRED_MAX_JOBS]; int first[BRED_MAX_JOBS + 1]; int n; };
-__global__ __launch_bounds__(1024) void wgrad_bf16_colsum_many_kernel(const BRedTable t) {
-  __shared__ double sm[16][64];
+__global__ __launch_bounds__(256) void wgrad_bf16_colsum_many_kernel(const BRedTable t) {
+  __shared__ double sm[256][4];
   int j = 0;
   while (j + 1 < t.n && (int)blockIdx.x >= t.first[j + 1]) ++j;
   const BRedJob& J = t.job[j];
@@ -920,7 +929,7 @@ int modetx_wgrad_partials_reduce(modet_step_ctx* defer, const float* part, float
     defer->brjobs.push_back(BRedJob{part, red, dw, db, row_fl, gx, Cin, Cout, cib, u, 1, 1, 1, layout});
     return modet_launch_status();
   }
-  hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, part, red, gx, row_fl);
+  hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3(colsum_blocks(row_fl, gx)), dim3(256), 0, s, part, red, gx, row_fl);
   hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(cdiv(Cout * Cin * 27 + Cout, 256)), dim3(256), 0, s, (const float*)red, dw, db,
                      Cin, Cout, cib, u, 1, 1, 1, 1, layout);
   return modet_launch_status();
@@ -935,7 +944,7 @@ int modetx_wgrad_partials_reduce2(modet_step_ctx* defer, const float* part, floa
     defer->brjobs.push_back(BRedJob{part, red, dw, db, row_fl, gx, Cin, Cout, nq, mt, nt, gy, n_coblk, 2});
     return modet_launch_status();
   }
-  hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, part, red, gx, row_fl);
+  hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3(colsum_blocks(row_fl, gx)), dim3(256), 0, s, part, red, gx, row_fl);
   hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(cdiv(Cout * Cin * 27 + Cout, 256)), dim3(256), 0, s, (const float*)red, dw, db,
                      Cin, Cout, nq, mt, nt, 1, gy, n_coblk, 2);
   return modet_launch_status();
@@ -953,9 +962,9 @@ void modetx_bf16_defer_flush(modet_step_ctx* c, hipStream_t stream) {
     const int n = (int)(jobs.size() - i0 < (size_t)BRED_MAX_JOBS ? jobs.size() - i0 : (size_t)BRED_MAX_JOBS);
     t.n = n;
     int total = 0;
-    for (int i = 0; i < n; ++i) { t.job[i] = jobs[i0 + i]; t.first[i] = total; total += (int)cdiv64(t.job[i].row_fl, 64); }
+    for (int i = 0; i < n; ++i) { t.job[i] = jobs[i0 + i]; t.first[i] = total; total += colsum_blocks(t.job[i].row_fl, t.job[i].gx); }
     for (int i = n; i <= BRED_MAX_JOBS; ++i) t.first[i] = total;
-    hipLaunchKernelGGL(wgrad_bf16_colsum_many_kernel, dim3(total), dim3(1024), 0, stream, t);
+    hipLaunchKernelGGL(wgrad_bf16_colsum_many_kernel, dim3(total), dim3(256), 0, stream, t);
     total = 0;
     for (int i = 0; i < n; ++i) { t.first[i] = total; total += cdiv(t.job[i].Cout * t.job[i].Cin * 27 + t.job[i].Cout, 256); }
     for (int i = n; i <= BRED_MAX_JOBS; ++i) t.first[i] = total;
@@ -1134,7 +1143,7 @@ static int bf16_bwd_weight_impl(const void* x, int x_bf16, const void* d_y, floa
     defer->brjobs.push_back(BRedJob{(const float*)ws, red, d_w, d_bias, row_fl, p.gx, Cin, Cout, p.cib, p.u, p.ntb, p.gy, p.n_coblk, 0});
     return modet_launch_status();
   }
-  hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3((unsigned)cdiv64(row_fl, 64)), dim3(1024), 0, s, (const float*)ws, red, p.gx, row_fl);
+  hipLaunchKernelGGL(wgrad_bf16_colsum_kernel, dim3(colsum_blocks(row_fl, p.gx)), dim3(256), 0, s, (const float*)ws, red, p.gx, row_fl);
   hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, s, (const float*)red, d_w, d_bias, Cin, Cout,
                      p.cib, p.u, p.ntb, 1, p.gy, p.n_coblk, 0);
   return modet_launch_status();

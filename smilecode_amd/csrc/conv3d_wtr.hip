@@ -362,7 +362,8 @@ inline WtrPlan wtr_plan(int B, int D, int H, int W, int Cin, int Cout) {
   p.gy = p.n_cib * p.n_coblk;
   p.tiles_x = cdiv(W, TX); p.tiles_y = cdiv(H, TY); p.tiles_z = cdiv(D, TZ);
   p.ntiles = B * p.tiles_x * p.tiles_y * p.tiles_z;
-  const int slots = 512;                               // resident workgroups (LDS 58 / 71 KB, <= 256 registers: two per CU)
+  int slots = 512;                                     // resident workgroups (LDS 58 / 71 KB, <= 256 registers: two per CU)
+  if (const char e = modet_tuning_env("MODET_WTR_SLOTS")) slots = e == '1' ? 256 : (e == '2' ? 384 : 512);
   int gx = slots / p.gy;
   if (gx < 1) gx = 1;
   if (gx > p.ntiles) gx = p.ntiles;
