@@ -52,6 +52,8 @@ def family(tag):
     if base in ("conv_fwd", "conv_dgrad"):
         if tag.endswith("@direct"):
             return "conv_direct_kernel"
+        if tag.endswith("@q"):
+            return "conv_q_kernel"
         return "conv_x3_kernel" if tag.endswith("@x3") else ("conv3d_bf16_kernel<SP=3>" if tag.endswith("@split") else "conv3d_mfma_kernel")
     if base == "conv_wgrad":
         return "conv_x3_wgrad_kernel" if tag.endswith("@x3") else ("conv_wgrad_tr_kernel" if tag.endswith("@tr") else "conv3d_wgrad_kernel")
@@ -66,7 +68,7 @@ def family(tag):
 # algorithmic (fp32) FLOP/s is the dense bf16 peak / 6
 PEAK_MFMA_BF16_TFLOPS = 2500.0
 MFMA_F32_FAMILIES = ("conv3d_mfma_kernel", "conv3d_wgrad_kernel", "conv_c1_wgrad_mfma_kernel", "conv_direct_kernel")
-MFMA_X3_FAMILIES = ("conv_x3_kernel", "conv_x3_wgrad_kernel", "conv_wgrad_tr_kernel", "conv3d_bf16_kernel<SP=3>")
+MFMA_X3_FAMILIES = ("conv_x3_kernel", "conv_x3_wgrad_kernel", "conv_wgrad_tr_kernel", "conv_q_kernel", "conv3d_bf16_kernel<SP=3>")
 
 
 def csrc_sha16():

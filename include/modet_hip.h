@@ -113,13 +113,16 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
  *   3 = exact-f32 MFMA straight from global memory for volumes of <= 16 k voxels (pyramid level 5, the CWM layers at
  *       level-4 resolution): one wave per 16 voxels x 16/32 output channels, no LDS (plain forward / dgrad launches only;
  *       launches with fused statistics, a lazily normalised input or an activation run family 0)   conv3d.hip (conv_direct_kernel)
- * Families 1 and 2 produce the fused InstanceNorm statistics (modet_conv3d_fwd_stats) at no cost for every Cout.
+ *   5 = (forward / data gradient) bf16x3 with the K index packed in channel quads: 2 x 8 x 8-voxel tiles, any channel count
+ *       (12 / 24 / 48 / 6 without padding), fused statistics and the lazily normalised input as template variants: pyramid
+ *       levels 3-5, the CWM layers, everything family 2 does not take up to 1.5 M voxels             conv3d_q.hip
+ * Families 1, 2 and 5 produce the fused InstanceNorm statistics (modet_conv3d_fwd_stats) at no cost for every Cout.
  *   4 = (weight gradient only) bf16x3 through LDS transpose reads, ds_read_b64_tr_b16: every layer with Cin >= 12 or an
  *       odd channel count, and Cout = 16                                                           conv3d_wtr.hip
  * Families 1 and 2 produce the fused InstanceNorm statistics (modet_conv3d_fwd_stats) at no cost for every Cout.
  * The choice is a function of the arguments alone: the product library reads NO environment variable.  The A/B switches
  * MODET_CONV_X3=0 (no family 2), MODET_CONV_SPLIT=0 / 1 (no / forced family 1), MODET_CONV_DIRECT=0 (no family 3),
- * MODET_CONV_WTR=0 (no family 4) exist only in tuning builds of the library (-DMODET_TUNING, tools/build_variant.sh).
+ * MODET_CONV_WTR=0 (no family 4), MODET_CONV_Q=0 (no family 5) exist only in tuning builds of the library (-DMODET_TUNING, tools/build_variant.sh).
  * `variant` tells what the launch fuses, because that changes the routing: 0 = plain (modet_conv3d_fwd with act = 0,
  * modet_conv3d_fwd_stats, _bwd_data, _bwd_weight), 1 = fused LeakyReLU (modet_conv3d_fwd with act = 1: never family 1 or 3),
  * 2 = lazily normalised input (modet_conv3d_fwd_normin: family 2 or 0), 3 = fused statistics (modet_conv3d_fwd_stats:

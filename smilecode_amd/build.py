@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "libmodet_hip.so")
-SOURCES = ["api.hip", "na.hip", "qk_op.hip", "warp.hip", "norm_act.hip", "proj_ln.hip", "losses.hip", "conv3d.hip", "conv3d_bf16.hip", "conv3d_x3.hip", "conv3d_wtr.hip", "corr3d.hip", "eval.hip"]
+SOURCES = ["api.hip", "na.hip", "qk_op.hip", "warp.hip", "norm_act.hip", "proj_ln.hip", "losses.hip", "conv3d.hip", "conv3d_bf16.hip", "conv3d_x3.hip", "conv3d_wtr.hip", "conv3d_q.hip", "corr3d.hip", "eval.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc"]
 if os.environ.get("MODET_TUNING"):          # kernel-configuration overrides for tools/sweep_conv.py; never set for the product build
     FLAGS.append("-DMODET_TUNING")

@@ -1790,6 +1790,22 @@ static bool use_x3_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   // Cout = 16 (8 -> 16 at level 2) runs 1.7x faster on the transpose-read kernel (102 -> 60 us): the march keeps Cout <= 8
   return on && !wtr_first && Cout <= 8 && modetx_x3_wgrad_eligible(B, D, H, W, Cin, Cout);
 }
+// bf16x3 forward / data gradient with the K index packed in channel quads (conv3d_q.hip): everything the z-march kernel does
+// not take -- pyramid levels 3-5, the CWM layers, odd channel counts, launches with a lazily normalised input -- up to 1.5 M
+// voxels; MODET_CONV_Q=0 (tuning builds) restores the tiled bf16x3 / exact-f32 / direct kernels
+bool modetx_q_eligible(int B, int D, int H, int W, int Cin, int Cout);
+size_t modetx_q_ws_bytes(int Cin, int Cout);
+size_t modetx_q_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
+                  const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int mode,
+                  hipStream_t s);
+static bool use_q(int B, int D, int H, int W, int Cin, int Cout) {
+  static const bool on = modet_tuning_env("MODET_CONV_Q") != '0';
+  // (volumes of <= 16 k voxels -- level 5, CWM at level-4 resolution -- stay on conv_direct_kernel where that one applies: a
+  // 128-voxel tile x 16-channel stage is a chain of 8 stagings there, 48-80 us against 41-57)
+  return on && Cin > 1 && !use_x3(B, D, H, W, Cin, Cout) && !use_direct(B, D, H, W, Cin, Cout) && (int64_t)B * D * H * W <= 1500000 &&
+         modetx_q_eligible(B, D, H, W, Cin, Cout);
+}
 static bool use_wtr_wgrad(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = modet_tuning_env("MODET_CONV_WTR") != '0';
   return on && !use_x3_wgrad(B, D, H, W, Cin, Cout) && modetx_wtr_eligible(B, D, H, W, Cin, Cout);
@@ -1818,6 +1834,7 @@ int modet_conv3d_kernel_family_v(int B, int D, int H, int W, int Cin, int Cout, 
   if (pass == 2) return use_x3_wgrad(B, D, H, W, Cin, Cout) ? 2 : (use_wtr_wgrad(B, D, H, W, Cin, Cout) ? 4 : 0);
   const int ci = pass == 1 ? Cout : Cin, co = pass == 1 ? Cin : Cout;      // the data gradient convolves d_y (Cout channels)
   if (use_x3(B, D, H, W, ci, co)) return 2;
+  if (variant != 1 && use_q(B, D, H, W, ci, co)) return 5;     // (a fused activation only occurs in the 1 -> 4 ConvBlock)
   if (variant == 1 || variant == 2) return 0;                  // fused activation / normalised input: exact-f32 tiles otherwise
   if (use_split(ci, co, (int64_t)B * D * H * W)) return 1;
   if (variant == 3) return 0;                                  // fused statistics: never the direct kernel
@@ -1906,9 +1923,10 @@ int modet_conv3d_prepack_end(modet_step_ctx_t* c) {
 size_t modet_conv3d_ws_bytes(int Cin, int Cout) {
   const int m = Cin > Cout ? Cin : Cout;       // bwd_data swaps the roles
   size_t a = fwd_ws_elems(m, m) * sizeof(float);
-  const size_t b = modetx_split_ws_bytes(Cin, Cout), c = modetx_x3_ws_bytes(Cin, Cout);
+  const size_t b = modetx_split_ws_bytes(Cin, Cout), c = modetx_x3_ws_bytes(Cin, Cout), d = modetx_q_ws_bytes(m, m);
   a = a > b ? a : b;
-  return a > c ? a : c;
+  a = a > c ? a : c;
+  return a > d ? a : d;
 }
 
 int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
@@ -1937,6 +1955,10 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
     if (ws_bytes < modetx_x3_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     return modetx_x3_conv(step, x, w, bias, y, ws, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
   }
+  if (!act && use_q(B, D, H, W, Cin, Cout)) {
+    if (ws_bytes < modetx_q_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
+    return modetx_q_conv(step, x, w, bias, y, ws, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
+  }
   if (!act && use_split(Cin, Cout, (int64_t)B * D * H * W)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     return modetx_split_conv(step, x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
@@ -1957,12 +1979,14 @@ static int conv_stats_rows(int B, int D, int H, int W, int Cin, int Cout) {
 size_t modet_conv3d_normin_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
   if (use_x3(B, D, H, W, Cin, Cout)) return modetx_x3_stats_bytes(B, D, H, W, Cin, Cout);
+  if (use_q(B, D, H, W, Cin, Cout)) return modetx_q_stats_bytes(B, D, H, W, Cin, Cout);
   return ((size_t)B * Cout + (size_t)B * conv_stats_rows(B, D, H, W, Cin, Cout) * Cout * 2) * sizeof(float);
 }
 
 size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   if (!conv_stats_ok(Cin, Cout) || B > 32) return 0;
   if (use_x3(B, D, H, W, Cin, Cout)) return modetx_x3_stats_bytes(B, D, H, W, Cin, Cout);    // one row per workgroup
+  if (use_q(B, D, H, W, Cin, Cout)) return modetx_q_stats_bytes(B, D, H, W, Cin, Cout);      // one row per output tile
   if (use_split(Cin, Cout, (int64_t)B * D * H * W)) return modetx_split_stats_bytes(B, D, H, W, Cin, Cout);     // one row per output tile
   // [sample][Cout] shift header, then [sample][workgroup][Cout][2] partial sums of (y - shift), (y - shift)^2; reduced by
   // modet_instnorm_lrelu_fwd_stats / modet_instnorm_stats
@@ -1982,6 +2006,12 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
     hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                        (const float*)nullptr, (const float*)nullptr, stats, B, D, H, W, Cin, Cout);
     return modetx_x3_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream);
+  }
+  if (use_q(B, D, H, W, Cin, Cout)) {
+    if (ws_bytes < modetx_q_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
+    hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                       (const float*)nullptr, (const float*)nullptr, stats, B, D, H, W, Cin, Cout);
+    return modetx_q_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
   }
   if (use_split(Cin, Cout, (int64_t)B * D * H * W)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
@@ -2009,6 +2039,13 @@ int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const floa
       hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x_raw, w, bias, in_mean,
                          in_rstd, stats, B, D, H, W, Cin, Cout);
     return modetx_x3_conv(step, x_raw, w, bias, y, ws, stats, in_mean, in_rstd, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream);
+  }
+  if (use_q(B, D, H, W, Cin, Cout)) {
+    if (ws_bytes < modetx_q_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
+    if (stats)
+      hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x_raw, w, bias, in_mean,
+                         in_rstd, stats, B, D, H, W, Cin, Cout);
+    return modetx_q_conv(step, x_raw, w, bias, y, ws, stats, in_mean, in_rstd, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
   }
   return conv_launch(step, x_raw, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
                      ConvIn{in_mean, in_rstd, stats ? conv_stats_rows(B, D, H, W, Cin, Cout) : 0, nullptr});
@@ -2041,6 +2078,10 @@ int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws
   if (use_x3(B, D, H, W, Cout, Cin)) {
     if (ws_bytes < modetx_x3_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
     return modetx_x3_conv(step, d_y, w, nullptr, d_x, ws, nullptr, nullptr, nullptr, B, D, H, W, Cout, Cin, 0, 1, (hipStream_t)stream);
+  }
+  if (use_q(B, D, H, W, Cout, Cin)) {
+    if (ws_bytes < modetx_q_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
+    return modetx_q_conv(step, d_y, w, nullptr, d_x, ws, nullptr, nullptr, nullptr, B, D, H, W, Cout, Cin, 1, (hipStream_t)stream);
   }
   if (use_split(Cout, Cin, (int64_t)B * D * H * W)) {
     if (ws_bytes < modetx_split_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;

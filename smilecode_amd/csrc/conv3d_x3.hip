@@ -1149,7 +1149,8 @@ int modetx_x3_bf16_wgrad(modet_step_ctx* defer, const void* x, int x_bf16, const
   return modetx_wgrad_partials_reduce(defer, (const float*)ws, red, dw, db, p.gx, Cin, Cout, p.cib, p.u, p.np ? 1 : 0, s);
 }
 
-// the recorded 16-bit packing jobs with layout >= 2 belong to this file (conv3d_bf16.hip's prepack launch skips them)
+void modetx_q_prepack_begin(modet_step_ctx* c, hipStream_t stream);      // conv3d_q.hip: layout 4
+// the recorded 16-bit packing jobs with layout 2 / 3 belong to this file (conv3d_bf16.hip's prepack launch skips layouts >= 2)
 void modetx_x3_prepack_begin(modet_step_ctx* c, hipStream_t stream) {
   std::vector<PackBKey> jobs;
   std::vector<size_t> off;
@@ -1166,9 +1167,10 @@ void modetx_x3_prepack_begin(modet_step_ctx* c, hipStream_t stream) {
   };
   for (size_t i = 0; i < jobs.size(); ++i) {
     const PackBKey& k = jobs[i];
-    if (k.layout < 2) continue;
+    if (k.layout != 2 && k.layout != 3) continue;        // (layout 4: conv3d_q.hip)
     t.job[t.n++] = X3PackJob{k.w, arena + off[i], k.Cin, k.Cout, k.CK, k.layout - 1, k.mode, k.npiece};
     if (t.n == X3PACK_MAX_JOBS) go();
   }
   go();
+  modetx_q_prepack_begin(c, stream);
 }

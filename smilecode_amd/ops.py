@@ -152,7 +152,7 @@ class trace_range:
 
 
 _FAM_CACHE = {}
-_FAM_SUFFIX = ("", "@split", "@x3", "@direct", "@tr")
+_FAM_SUFFIX = ("", "@split", "@x3", "@direct", "@tr", "@q")
 
 
 def _conv_tag(kind, x_shape, Cin, Cout, variant=0):
@@ -505,7 +505,7 @@ def _fuse_stats(x, w, needs_grad=None):
     L = _L()
     if L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout) == 0:
         return False
-    if L.modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 0) in (1, 2):  # the bf16x3 kernels carry the statistics at no cost
+    if L.modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 0) in (1, 2, 5):  # the bf16x3 kernels carry the statistics at no cost
         return True
     if needs_grad is None:     # (inside an autograd.Function.forward grad mode is off: such callers pass their ctx.needs_input_grad)
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
