@@ -1801,9 +1801,10 @@ int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const fl
                   hipStream_t s);
 static bool use_q(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = modet_tuning_env("MODET_CONV_Q") != '0';
-  // (volumes of <= 16 k voxels -- level 5, CWM at level-4 resolution -- stay on conv_direct_kernel where that one applies: a
-  // 128-voxel tile x 16-channel stage is a chain of 8 stagings there, 48-80 us against 41-57)
-  return on && Cin > 1 && !use_x3(B, D, H, W, Cin, Cout) && !use_direct(B, D, H, W, Cin, Cout) && (int64_t)B * D * H * W <= 1500000 &&
+  // (level 5 -- 2.4 k voxels, 64 / 128 channels -- stays on conv_direct_kernel: 8 stagings of a 128-voxel tile in a row there,
+  // 40-62 us against 40-55; the CWM layers at level-4 resolution, 9.6 k voxels, are faster here: 24->48 35 -> 26 us, 48->48 41 -> 33)
+  const int64_t n = (int64_t)B * D * H * W;
+  return on && Cin > 1 && !use_x3(B, D, H, W, Cin, Cout) && !(n < 4096 && use_direct(B, D, H, W, Cin, Cout)) && n <= 1500000 &&
          modetx_q_eligible(B, D, H, W, Cin, Cout);
 }
 static bool use_wtr_wgrad(int B, int D, int H, int W, int Cin, int Cout) {

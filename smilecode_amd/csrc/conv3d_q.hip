@@ -119,6 +119,7 @@ template <int NQ, int WC, int CT, bool NORM, bool STATS>
 __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kernel(const QArgs a) {
   constexpr int VT = 2 * WC;                           // voxel tiles per wave
   constexpr int CB = WC * CT;                          // cout tiles per workgroup
+  constexpr int PF = CT == 1 ? 4 : (CT == 2 ? 3 : 2);   // k-steps of weight lookahead
   constexpr int KS = (27 * NQ + 7) / 8;                // k-steps per channel block
   constexpr int XS_BYTES = 3 * XPL;
   constexpr int TAB = 27 * NQ + 8;                     // chunk -> LDS byte offset (tap, quad); the tail entries are dummies
@@ -171,18 +172,19 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
   const uint4* wbase = a.wpk + (size_t)ctw * 64 + lane;
   const size_t wstep = (size_t)a.ct_total * 64;       // uint4 between consecutive (k-step, piece) slabs
 
-  for (int s = 0; s < a.nstage; ++s) {
+  // a stage's tile: loads issued into registers one stage AHEAD (they fly during the previous stage's k-steps)
+  u32x4 xr[NPASS];
+  bool okv[NPASS];
+  float4 nm = make_float4(0.f, 0.f, 0.f, 0.f), nr = make_float4(1.f, 1.f, 1.f, 1.f);
+  auto issue_tile = [&](const int s) {
     const int cx_t = s * 4 * NQ + qd_t * 4;
     const bool xok = x_act && xx >= 0 && xx < W && cx_t < Cin;
     const unsigned xterm = ((unsigned)xx * (unsigned)Cin + (unsigned)cx_t) * 4u;
     const unsigned rowb = (unsigned)(W * Cin) * 4u;
-    float4 nm = make_float4(0.f, 0.f, 0.f, 0.f), nr = make_float4(1.f, 1.f, 1.f, 1.f);
     if (NORM && cx_t < Cin) {                          // (Cin % 4 == 0 whenever NORM: checked on the host)
       nm = *reinterpret_cast<const float4*>(a.in_mean + b * Cin + cx_t);
       nr = *reinterpret_cast<const float4*>(a.in_rstd + b * Cin + cx_t);
     }
-    u32x4 xr[NPASS];
-    bool okv[NPASS];
     unsigned offv[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -205,13 +207,21 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
         xr[i] = v;
       }
     }
-    // first weights of the stage in flight beside the tile
+  };
+  issue_tile(0);
+
+  for (int s = 0; s < a.nstage; ++s) {
+    // the first PF k-steps' weights of the stage in flight beside the tile (ring of PF register sets: a k-step is ~100-200
+    // clocks of MFMA per wave, an L2 hit several hundred: one k-step of lookahead left every k-step waiting on its weights)
     const uint4* wst = wbase + (size_t)s * KS * 3 * wstep;
-    uint4 wc[3][CT], wn[3][CT];
+    uint4 wq[PF][3][CT];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int j = 0; j < PF; ++j)
 #pragma unroll
-      for (int n = 0; n < CT; ++n) wc[p][n] = wst[(size_t)p * wstep + n * 64];
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int n = 0; n < CT; ++n)
+          if (j < KS) wq[j][p][n] = wst[((size_t)j * 3 + p) * wstep + n * 64];
     if (s > 0) __syncthreads();                        // every wave is done reading the previous stage's image
     if (x_act) {
 #pragma unroll
@@ -231,36 +241,43 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
       }
     }
     __syncthreads();
+    if (s + 1 < a.nstage) issue_tile(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- k-steps: a lane's 8 k = chunks 8 ks + 2 kg, + 1 (table offsets), two 8-byte reads per piece and voxel tile
-#pragma unroll 1
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
+    // fully unrolled (KS is a constant <= 14): every condition below is a compile-time one, so the waits in front of the
+    // MFMAs are exact vmcnt(n) counts -- with a run-time trip count hipcc fell back to vmcnt(0) at the head of each group
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+    for (int ks0 = 0; ks0 < KS; ks0 += PF) {
 #pragma unroll
-          for (int n = 0; n < CT; ++n) wn[p][n] = wst[((size_t)(ks + 1) * 3 + p) * wstep + n * 64];
-      }
-      const int2 co2 = *reinterpret_cast<const int2*>(tab + 8 * ks + 2 * kg);
+      for (int j = 0; j < PF; ++j) {
+        const int ks = ks0 + j;
+        if (ks < KS) {
+          const int2 co2 = *reinterpret_cast<const int2*>(tab + 8 * ks + 2 * kg);
 #pragma unroll
-      for (int v = 0; v < VT; ++v) {
-        bf16x8 xf[3];
+          for (int v = 0; v < VT; ++v) {
+            bf16x8 xf[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const uint2 lo = *reinterpret_cast<const uint2*>(lds + p * XPL + voff[v] + co2.x);
-          const uint2 hi = *reinterpret_cast<const uint2*>(lds + p * XPL + voff[v] + co2.y);
-          const u32x4 q4 = {lo.x, lo.y, hi.x, hi.y};
-          xf[p] = __builtin_bit_cast(bf16x8, q4);
-        }
+            for (int p = 0; p < 3; ++p) {
+              const uint2 lo = *reinterpret_cast<const uint2*>(lds + p * XPL + voff[v] + co2.x);
+              const uint2 hi = *reinterpret_cast<const uint2*>(lds + p * XPL + voff[v] + co2.y);
+              const u32x4 q4 = {lo.x, lo.y, hi.x, hi.y};
+              xf[p] = __builtin_bit_cast(bf16x8, q4);
+            }
 #define MMQ(PW, PX)                                                                                                           \
-        _Pragma("unroll") for (int n = 0; n < CT; ++n)                                                                        \
-          acc[v][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[PW][n]), xf[PX], acc[v][n], 0, 0, 0);
-        MMQ(2, 0) MMQ(0, 2) MMQ(1, 1) MMQ(1, 0) MMQ(0, 1) MMQ(0, 0)
+            _Pragma("unroll") for (int n = 0; n < CT; ++n)                                                                    \
+              acc[v][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[j][PW][n]), xf[PX], acc[v][n], 0, 0, 0);
+            MMQ(2, 0) MMQ(0, 2) MMQ(1, 1) MMQ(1, 0) MMQ(0, 1) MMQ(0, 0)
 #undef MMQ
+          }
+          if (ks + PF < KS) {                          // this slot's next use
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int n = 0; n < CT; ++n) wq[j][p][n] = wst[((size_t)(ks + PF) * 3 + p) * wstep + n * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);           // (the scheduler otherwise sinks these loads to their use, PF k-steps on)
+        }
       }
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int n = 0; n < CT; ++n) wc[p][n] = wn[p][n];
     }
   }
 
