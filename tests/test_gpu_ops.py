@@ -496,6 +496,60 @@ def test_conv_x3_march_vs_fp64(ops, cin, cout, shape):
     assert torch.equal(ops.conv3d_forward(xd, wd, bd, False), ops.conv3d_forward(xd, wd, bd, False))
 
 
+@pytest.mark.parametrize("cin,cout,shape,B", [(16, 32, (9, 17, 28), 2), (32, 32, (10, 12, 19), 2), (12, 2, (12, 18, 21), 1),
+                                              (6, 12, (17, 10, 27), 1), (24, 4, (9, 24, 20), 1), (24, 24, (8, 17, 31), 2),
+                                              (48, 8, (13, 15, 22), 1), (24, 48, (16, 16, 17), 1), (64, 64, (8, 9, 30), 2),
+                                              (2, 12, (12, 18, 21), 1), (20, 20, (11, 19, 20), 1)])
+def test_conv_q_and_transpose_read_wgrad_vs_fp64(ops, cin, cout, shape, B):
+    """csrc/conv3d_q.hip (kernel family 5: forward / data gradient with k = (tap, channel quad)) and csrc/conv3d_wtr.hip (family
+    4: weight gradient through LDS transpose reads) at the channel counts of pyramid levels 3-4 and the CWM layers, on shapes
+    ragged against the 2x8x8 tiles: the dispatch is asserted, the results hold the fp32 kernels' tolerances against ATen-CPU
+    fp64 -- forward, fused InstanceNorm statistics, lazily normalised input, data gradient, weight / bias gradient -- and
+    are run-to-run identical."""
+    import torch.nn.functional as F
+    L = ops._L()
+    assert L.modet_conv3d_kernel_family_v(B, *shape, cin, cout, 0, 0) == 5, "forward does not take conv_q_kernel"
+    assert L.modet_conv3d_kernel_family_v(B, *shape, cin, cout, 1, 0) == 5, "data gradient does not take conv_q_kernel"
+    if cin >= 4:                                                         # (2 -> 12 only occurs as the data gradient of 12 -> 2)
+        assert L.modet_conv3d_kernel_family_v(B, *shape, cin, cout, 2, 0) == 4, "weight gradient does not take conv_wgrad_tr_kernel"
+    gen = torch.Generator().manual_seed(cin * 389 + cout)
+    x = torch.randn((B, cin) + shape, generator=gen).double()
+    x[:, :, :, : shape[1] // 3] = -0.5                                   # a constant region
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(cin * 27)).double()
+    b = (0.1 * torch.randn(cout, generator=gen)).double()
+    ref = F.conv3d(x, w, b, padding=1)
+    xd, wd, bd = cl(x.numpy()), w.float().cuda(), b.float().cuda()
+    y = ops.conv3d_forward(xd, wd, bd, False)
+    assert_close(ncdhw(y), ref.numpy(), what="q fwd")
+    assert torch.equal(y, ops.conv3d_forward(xd, wd, bd, False)), "forward not deterministic"
+    gy = torch.randn(ref.shape, generator=gen).double()
+    gd = cl(gy.numpy())
+    rx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
+    assert_close(ncdhw(ops.conv3d_backward_data(gd, wd, cin)), rx.numpy(), atol=5e-5, what="q dgrad")
+    rw = torch.nn.grad.conv3d_weight(x, w.shape, gy, padding=1)
+    dw, db = ops.conv3d_backward_weight(xd, gd, True)
+    dw2, db2 = ops.conv3d_backward_weight(xd, gd, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "weight gradient not deterministic"
+    assert float((dw.double().cpu() - rw).abs().max() / rw.abs().max()) < 2e-5, "tr wgrad"
+    rb = gy.sum((0, 2, 3, 4))
+    assert float((db.double().cpu() - rb).abs().max() / rb.abs().max()) < 2e-5, "tr d_bias"
+    if cout % 4 == 0:
+        z = ops.conv3d_instnorm_lrelu(xd, wd, bd)
+        refn = F.leaky_relu(F.instance_norm(ref, eps=1e-5), 0.1)
+        assert_close(ncdhw(z), refn.numpy(), atol=5e-5, rtol=5e-5, what="q fwd + fused InstanceNorm statistics")
+    if cin % 4 == 0:
+        with torch.no_grad():
+            mean, rstd = ops.instnorm_stats(xd)
+            z, zst = ops.conv3d_forward_normin(xd, mean, rstd, wd, bd, cout % 4 == 0)
+        xin = F.leaky_relu(F.instance_norm(x, eps=1e-5), 0.1)
+        refz = F.conv3d(xin, w, b, padding=1)
+        assert_close(ncdhw(z), refz.numpy(), atol=1e-4, rtol=5e-5, what="q fwd, normalised on load")
+        if cout % 4 == 0:
+            zn = ops._InstNormLReLU.apply(z, 1e-5, zst)
+            assert_close(ncdhw(zn), F.leaky_relu(F.instance_norm(refz, eps=1e-5), 0.1).numpy(), atol=1e-4, rtol=5e-5,
+                         what="q normin + statistics")
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(8, 8, (40, 50, 52)), (4, 8, (37, 46, 63)), (8, 16, (33, 42, 75)), (8, 4, (40, 41, 66))])
 def test_conv_x3_weight_gradient_vs_fp64(ops, cin, cout, shape):
     """csrc/conv3d_x3.hip, weight gradient: the z-marching bf16x3 kernel (Cin 4/8, Cout <= 16, >= 200 k voxels) against
