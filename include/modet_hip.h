@@ -372,6 +372,11 @@ int modet_instnorm_lrelu_fwd_stats_bf16(const void* x, void* y, int y_bf16, floa
                                         size_t stats_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream);
 int modet_instnorm_lrelu_bwd_bf16(const void* d_y, int dy_bf16, const void* x, const float* mean, const float* rstd,
                                   void* d_x, void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream);
+/* modet_instnorm_lrelu_bwd_pool (above) for the bf16 chain: the gradient of a level's OUTPUT block,
+ * unpool(g_pooled) / 8 + [add_a ; add_b] (all fp32), is formed inside the two backward passes; x / d_x are bf16.  C % 8 == 0. */
+int modet_instnorm_lrelu_bwd_pool_bf16(const float* g_pooled, const float* add_a, const float* add_b, int Bh, const void* x,
+                                       const float* mean, const float* rstd, void* d_x, void* ws, size_t ws_bytes, int B, int D,
+                                       int H, int W, int C, modet_stream_t stream);
 /* element-wise cast between fp32 and bf16 (round to nearest even), n % 8 == 0 */
 int modet_cast_bf16(const void* x, void* y, int64_t n, int to_bf16, modet_stream_t stream);
 

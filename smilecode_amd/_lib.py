@@ -101,6 +101,7 @@ SIGNATURES = {
     "modet_instnorm_bf16_ws_bytes": (SZ, [I, I64, I]),
     "modet_instnorm_lrelu_fwd_stats_bf16": (I, [P, P, I, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_bwd_bf16": (I, [P, I, P, P, P, P, P, SZ, I, I64, I, P]),
+    "modet_instnorm_lrelu_bwd_pool_bf16": (I, [P, P, P, I, P, P, P, P, P, SZ, I, I, I, I, I, P]),
     "modet_cast_bf16": (I, [P, P, I64, I, P]),
 }
 

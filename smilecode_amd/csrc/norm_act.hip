@@ -579,6 +579,27 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
 // voxels per partial-sum workgroup: 16 passes (twice the workgroups of the fp32 kernel per byte: a pass moves half the bytes)
 static inline int in_chunk8(int C) { return C >= 8 ? (BLK / (C >> 3)) * 16 : BLK * 16; }   // C % 8 != 0 is refused by the callers
 
+// d_y of a level's output block formed on the fly from PoolSrc (fp32 gradients of the level's consumers + the pooled gradient),
+// 8 channels per thread: DYM = 2 of the two backward kernels below (0: d_y fp32, 1: d_y bf16)
+struct PoolDy8 { Raw8 g, a; bool has; };
+__device__ __forceinline__ PoolDy8 pool_dy8_load(const PoolSrc& ps, int b, int64_t v, int64_t V, int C, int g8) {
+  const float *pg, *pa;
+  pool_dy_addr(ps, b, v, V, C, g8 * 2, pg, pa);
+  PoolDy8 r;
+  r.has = pa != nullptr;
+  r.g = load8_raw<false>(pg, 0);
+  r.a = load8_raw<false>(r.has ? pa : pg, 0);
+  return r;
+}
+__device__ __forceinline__ void pool_dy8_fence(PoolDy8& r) { raw8_fence<false>(r.g); raw8_fence<false>(r.a); }
+__device__ __forceinline__ void pool_dy8_unpack(const PoolDy8& r, float (&f)[8]) {
+  float gv[8], av[8];
+  unpack8<false>(r.g, gv);
+  unpack8<false>(r.a, av);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) f[c] = r.has ? gv[c] * 0.125f + av[c] : gv[c] * 0.125f;      // (as pool_dy_value: mul, then add)
+}
+
 template <bool OUT_BF>
 __global__ __launch_bounds__(BLK) void in_apply_bf16_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -611,10 +632,12 @@ __global__ __launch_bounds__(BLK) void in_apply_bf16_kernel(const void* __restri
 }
 
 // (sum g, sum g*xhat), g = dy * lrelu'(xhat); x is the bf16 raw conv output
-template <bool DY_BF>
+template <int DYM>
 __global__ __launch_bounds__(BLK) void in_partial_bf16_kernel(const void* __restrict__ x, const void* __restrict__ dy,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              float* __restrict__ part, int64_t V, int C, int chunk) {
+                                                              float* __restrict__ part, int64_t V, int C, int chunk,
+                                                              const PoolSrc ps = PoolSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0}) {
+  constexpr bool DY_BF = DYM == 1, POOL = DYM == 2;
   __shared__ float red[BLK * 16];
   const int G = C >> 3, VPB = BLK / G;
   const int b = blockIdx.y;
@@ -630,10 +653,9 @@ __global__ __launch_bounds__(BLK) void in_partial_bf16_kernel(const void* __rest
   const int64_t v0 = (int64_t)blockIdx.x * chunk;
   const int64_t v1 = v0 + chunk < V ? v0 + chunk : V;
   if (active) {
-    auto acc1 = [&](const Raw8& rx, const Raw8& rg) {
-      float xs[8], gs[8];
+    auto accg = [&](const Raw8& rx, const float (&gs)[8]) {
+      float xs[8];
       unpack8<true>(rx, xs);
-      unpack8<DY_BF>(rg, gs);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const float xh = (xs[c] - mu[c]) * rs[c];
@@ -641,25 +663,39 @@ __global__ __launch_bounds__(BLK) void in_partial_bf16_kernel(const void* __rest
         a[c] += gg; q[c] = fmaf(gg, xh, q[c]);
       }
     };
+    auto acc1 = [&](const Raw8& rx, const Raw8& rg) {
+      float gs[8];
+      unpack8<DY_BF>(rg, gs);
+      accg(rx, gs);
+    };
     // the loads of PU passes are issued and fenced together, the sums keep their order (bit-identical)
-    constexpr int PU = 4;
+    constexpr int PU = POOL ? 2 : 4;
     int64_t v = v0 + vl;
     for (; v + (PU - 1) * VPB < v1; v += PU * VPB) {
       Raw8 rx[PU], rg[PU];
+      PoolDy8 pd[PU];
 #pragma unroll
       for (int u = 0; u < PU; ++u) {
         const int64_t i8 = ((int64_t)b * V + v + u * VPB) * G + g;
         rx[u] = load8_raw<true>(x, i8);
-        rg[u] = load8_raw<DY_BF>(dy, i8);
+        if constexpr (POOL) pd[u] = pool_dy8_load(ps, b, v + u * VPB, V, C, g);
+        else rg[u] = load8_raw<DY_BF>(dy, i8);
       }
 #pragma unroll
-      for (int u = 0; u < PU; ++u) { raw8_fence<true>(rx[u]); raw8_fence<DY_BF>(rg[u]); }
+      for (int u = 0; u < PU; ++u) {
+        raw8_fence<true>(rx[u]);
+        if constexpr (POOL) pool_dy8_fence(pd[u]); else raw8_fence<DY_BF>(rg[u]);
+      }
 #pragma unroll
-      for (int u = 0; u < PU; ++u) acc1(rx[u], rg[u]);
+      for (int u = 0; u < PU; ++u) {
+        if constexpr (POOL) { float gs[8]; pool_dy8_unpack(pd[u], gs); accg(rx[u], gs); }
+        else acc1(rx[u], rg[u]);
+      }
     }
     for (; v < v1; v += VPB) {
       const int64_t i8 = ((int64_t)b * V + v) * G + g;
-      acc1(load8_raw<true>(x, i8), load8_raw<DY_BF>(dy, i8));
+      if constexpr (POOL) { float gs[8]; pool_dy8_unpack(pool_dy8_load(ps, b, v, V, C, g), gs); accg(load8_raw<true>(x, i8), gs); }
+      else acc1(load8_raw<true>(x, i8), load8_raw<DY_BF>(dy, i8));
     }
   }
   if ((G & (G - 1)) == 0 && G <= 64) {                   // see in_partial_kernel: shuffle tree, then the 4 waves through LDS
@@ -704,21 +740,27 @@ __global__ __launch_bounds__(BLK) void in_partial_bf16_kernel(const void* __rest
   }
 }
 
-template <bool DY_BF>
+template <int DYM>
 __global__ __launch_bounds__(BLK) void in_bwd_apply_bf16_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ s1, const float* __restrict__ s2,
-                                                                void* __restrict__ dx, int64_t V, int C, int64_t total8) {
+                                                                void* __restrict__ dx, int64_t V, int C, int64_t total8,
+                                                                const PoolSrc ps = PoolSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0}) {
+  constexpr bool DY_BF = DYM == 1, POOL = DYM == 2;
   const int G = C >> 3;
   const bool small = total8 < (1ll << 31) && V < (1ll << 31);
   const int64_t stride = (int64_t)gridDim.x * BLK;
-  auto one = [&](int64_t i, const Raw8& rx, const Raw8& rg) {
+  auto pool_of = [&](int64_t i) {
+    int g, b;
+    in_elem(i, G, V, small, g, b);
+    return pool_dy8_load(ps, b, i / G - (int64_t)b * V, V, C, g);
+  };
+  auto oneg = [&](int64_t i, const Raw8& rx, const float (&gs)[8]) {
     int g, b;
     in_elem(i, G, V, small, g, b);
     const int bc0 = b * C + g * 8;
-    float xs[8], gs[8], o[8], m[8], rs[8], a1[8], a2[8];
+    float xs[8], o[8], m[8], rs[8], a1[8], a2[8];
     unpack8<true>(rx, xs);
-    unpack8<DY_BF>(rg, gs);
     ld8f(mean + bc0, m); ld8f(rstd + bc0, rs); ld8f(s1 + bc0, a1); ld8f(s2 + bc0, a2);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -729,18 +771,36 @@ __global__ __launch_bounds__(BLK) void in_bwd_apply_bf16_kernel(const void* __re
     }
     store8<true>(dx, i, o);
   };
+  auto one = [&](int64_t i, const Raw8& rx, const Raw8& rg) {
+    float gs[8];
+    unpack8<DY_BF>(rg, gs);
+    oneg(i, rx, gs);
+  };
   constexpr int ILP = 2;
   int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
   for (; i + (ILP - 1) * stride < total8; i += ILP * stride) {
     Raw8 rx[ILP], rg[ILP];
+    PoolDy8 pd[ILP];
 #pragma unroll
-    for (int u = 0; u < ILP; ++u) { rx[u] = load8_raw<true>(x, i + u * stride); rg[u] = load8_raw<DY_BF>(dy, i + u * stride); }
+    for (int u = 0; u < ILP; ++u) {
+      rx[u] = load8_raw<true>(x, i + u * stride);
+      if constexpr (POOL) pd[u] = pool_of(i + u * stride); else rg[u] = load8_raw<DY_BF>(dy, i + u * stride);
+    }
 #pragma unroll
-    for (int u = 0; u < ILP; ++u) { raw8_fence<true>(rx[u]); raw8_fence<DY_BF>(rg[u]); }
+    for (int u = 0; u < ILP; ++u) {
+      raw8_fence<true>(rx[u]);
+      if constexpr (POOL) pool_dy8_fence(pd[u]); else raw8_fence<DY_BF>(rg[u]);
+    }
 #pragma unroll
-    for (int u = 0; u < ILP; ++u) one(i + u * stride, rx[u], rg[u]);
+    for (int u = 0; u < ILP; ++u) {
+      if constexpr (POOL) { float gs[8]; pool_dy8_unpack(pd[u], gs); oneg(i + u * stride, rx[u], gs); }
+      else one(i + u * stride, rx[u], rg[u]);
+    }
   }
-  for (; i < total8; i += stride) one(i, load8_raw<true>(x, i), load8_raw<DY_BF>(dy, i));
+  for (; i < total8; i += stride) {
+    if constexpr (POOL) { float gs[8]; pool_dy8_unpack(pool_of(i), gs); oneg(i, load8_raw<true>(x, i), gs); }
+    else one(i, load8_raw<true>(x, i), load8_raw<DY_BF>(dy, i));
+  }
 }
 
 template <bool TO_BF>
@@ -1000,11 +1060,37 @@ int modet_instnorm_lrelu_bwd_bf16(const void* d_y, int dy_bf16, const void* x, c
   float* s1 = part + (size_t)B * nchunk * C * 2;
   float* s2 = s1 + (size_t)B * C;
   const int64_t total8 = (int64_t)B * V * (C / 8);
-  if (dy_bf16) hipLaunchKernelGGL(in_partial_bf16_kernel<true>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C, chunk);
-  else hipLaunchKernelGGL(in_partial_bf16_kernel<false>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C, chunk);
+  if (dy_bf16) hipLaunchKernelGGL(in_partial_bf16_kernel<1>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C, chunk);
+  else hipLaunchKernelGGL(in_partial_bf16_kernel<0>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C, chunk);
   hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f);
-  if (dy_bf16) hipLaunchKernelGGL(in_bwd_apply_bf16_kernel<true>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2, d_x, V, C, total8);
-  else hipLaunchKernelGGL(in_bwd_apply_bf16_kernel<false>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2, d_x, V, C, total8);
+  if (dy_bf16) hipLaunchKernelGGL(in_bwd_apply_bf16_kernel<1>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2, d_x, V, C, total8);
+  else hipLaunchKernelGGL(in_bwd_apply_bf16_kernel<0>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2, d_x, V, C, total8);
+  return modet_launch_status();
+}
+
+/* modet_instnorm_lrelu_bwd_pool for the bf16 chain: x (the block's raw conv output) and d_x are bf16, the gradients of the
+ * level's consumers and the pooled gradient fp32 */
+int modet_instnorm_lrelu_bwd_pool_bf16(const float* g_pooled, const float* add_a, const float* add_b, int Bh, const void* x,
+                                       const float* mean, const float* rstd, void* d_x, void* ws, size_t ws_bytes, int B, int D,
+                                       int H, int W, int C, modet_stream_t stream) {
+  MODET_CHECK_PTR(g_pooled); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1 && C > 0 && Bh >= 0 && Bh <= B);
+  MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
+  const int64_t V = (int64_t)D * H * W;
+  if (C % 8 != 0 || C > 512 || V >= (1ll << 31)) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_instnorm_bf16_ws_bytes(B, V, C)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const PoolSrc ps{g_pooled, add_a, add_b, Bh, D, H, W};
+  const int chunk = in_chunk8(C);
+  const int nchunk = (int)cdiv64(V, chunk);
+  float* part = (float*)ws;
+  float* s1 = part + (size_t)B * nchunk * C * 2;
+  float* s2 = s1 + (size_t)B * C;
+  const int64_t total8 = (int64_t)B * V * (C / 8);
+  hipLaunchKernelGGL(in_partial_bf16_kernel<2>, dim3(nchunk, B), dim3(BLK), 0, s, x, nullptr, mean, rstd, part, V, C, chunk, ps);
+  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f);
+  hipLaunchKernelGGL(in_bwd_apply_bf16_kernel<2>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, nullptr, x, mean, rstd, s1, s2, d_x,
+                     V, C, total8, ps);
   return modet_launch_status();
 }
 

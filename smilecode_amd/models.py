@@ -191,15 +191,19 @@ class Encoder(nn.Module):
                 pooled_in.append(pooled)
             cur = _two_blocks(pooled, self.conv4[1], self.conv4[2], False)
         else:
-            cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2], self.bf16)
-            for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
-                pooled, m, f = ops.pool_tee_split(cur, B)
+            # bf16 chain: the level's last InstanceNorm writes fp32 features; its BACKWARD forms the pool gradient + the two
+            # halves' gradients on the fly (ops.conv_ins_pair_bf16_pool_split)
+            inp, blocks = self.conv0[0](x), (self.conv0, self.conv1, self.conv2, self.conv3)
+            for lvl, blk in enumerate(blocks):
+                if blk is self.conv2 and self.stage_cut:
+                    inp = self._cut(inp)
+                pooled, m, f = ops.conv_ins_pair_bf16_pool_split(inp, blk[1].main.weight, blk[1].main.bias, blk[2].main.weight,
+                                                                 blk[2].main.bias, B)
                 Ms.append(m)
                 Fs.append(f)
                 pooled_in.append(pooled)
-                if blk is self.conv2 and self.stage_cut:
-                    pooled = self._cut(pooled)
-                cur = _two_blocks(pooled, blk[1], blk[2], self.bf16)        # blk[0] is the AvgPool3d(2) the tee already applied
+                inp = pooled
+            cur = _two_blocks(inp, self.conv4[1], self.conv4[2], self.bf16)
         m, f = _SplitBatch.apply(cur, B)
         Ms.append(m)
         Fs.append(f)

@@ -1464,6 +1464,78 @@ class _InstNormLReLUBF16(Function):
         return dx, None, None, None
 
 
+class _InstNormLReLUBF16PoolSplit(Function):
+    """_InstNormLReLUBF16 (fp32 output) followed by _PoolTeeSplit as ONE node, bf16 chain: x_raw bf16 (2B,...) ->
+    (avgpool2(y), y[:B], y[B:]) with y = LeakyReLU(InstanceNorm(x_raw)) in fp32.  Forward: the two kernels unchanged (a fused
+    apply + pool was measured and bought nothing for the bf16 chain); backward: d_y = unpool(g_pooled) / 8 + [g_a ; g_b] is
+    formed inside the two InstanceNorm backward passes (modet_instnorm_lrelu_bwd_pool_bf16) instead of written by the pool
+    backward and read back twice: same arithmetic, same order of the sums -- bit-identical to the two-node form."""
+
+    @staticmethod
+    def forward(ctx, x, stats, eps, Bh):
+        _chk16(x)
+        if x.dtype != torch.bfloat16:
+            raise RuntimeError("instnorm bf16: the raw conv output must be bfloat16")
+        B, D, H, W, C = x.shape
+        V = D * H * W
+        L = _L()
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        nel = float(x.numel())
+        with _Guard(x, "instnorm_bf16_fwd", 8.0 * nel, nel * 6.0):
+            _lib.check(L.modet_instnorm_lrelu_fwd_stats_bf16(_p(x), _p(y), 0, _p(mean), _p(rstd), _p(stats), stats.numel() * 4, B, V,
+                                                             C, eps, _stream()), "modet_instnorm_lrelu_fwd_stats_bf16")
+        pooled = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+        with _Guard(y, "avgpool2_fwd", y.numel(), 4.5 * y.numel()):
+            _lib.check(L.modet_avgpool2_fwd(_p(y), _p(pooled), B, D, H, W, C, _stream()), "modet_avgpool2_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.Bh = Bh
+        ctx.set_materialize_grads(False)
+        return pooled, y[:Bh], y[Bh:]
+
+    @staticmethod
+    def backward(ctx, gy, ga, gb):
+        if not ctx.needs_input_grad[0] or (gy is None and ga is None and gb is None):
+            return None, None, None, None
+        x, mean, rstd = ctx.saved_tensors
+        B, D, H, W, C = x.shape
+        Bh = ctx.Bh
+        V = D * H * W
+        L = _L()
+        dx = torch.empty_like(x)
+        nb = L.modet_instnorm_bf16_ws_bytes(B, V, C)
+        ws = _ws(nb, x)
+        nel = float(x.numel())
+        if gy is not None:
+            gy = gy.contiguous()
+            ga = None if ga is None else ga.contiguous()
+            gb = None if gb is None else gb.contiguous()
+            with _Guard(x, "instnorm_bf16_bwd", 15.0 * nel, nel * 14.5):
+                _lib.check(L.modet_instnorm_lrelu_bwd_pool_bf16(_p(gy), _p(ga), _p(gb), Bh, _p(x), _p(mean), _p(rstd), _p(dx), _p(ws),
+                                                                nb, B, D, H, W, C, _stream()), "modet_instnorm_lrelu_bwd_pool_bf16")
+            return dx, None, None, None
+        dy = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        for sl, g in ((slice(0, Bh), ga), (slice(Bh, B), gb)):
+            if g is None:
+                dy[sl].zero_()
+            else:
+                dy[sl].copy_(g)
+        with _Guard(x, "instnorm_bf16_bwd", 14.0 * nel, nel * 14.0):
+            _lib.check(L.modet_instnorm_lrelu_bwd_bf16(_p(dy), 0, _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C, _stream()),
+                       "modet_instnorm_lrelu_bwd_bf16")
+        return dx, None, None, None
+
+
+def conv_ins_pair_bf16_pool_split(inp, w1, b1, w2, b2, Bh, eps=1e-5):
+    """conv_ins_pair_bf16 whose fp32 output goes to AvgPool3d(2) and, split into its two batch halves, to the level's consumers:
+    (pooled, y[:Bh], y[Bh:]); see _InstNormLReLUBF16PoolSplit"""
+    raw1, st1 = _Conv3dBF16.apply(inp, w1, b1)
+    y1 = _InstNormLReLUBF16.apply(raw1, st1, eps, True)
+    raw2, st2 = _Conv3dBF16.apply(y1, w2, b2)
+    return _InstNormLReLUBF16PoolSplit.apply(raw2, st2, eps, Bh)
+
+
 def conv_ins_pair_bf16(inp, w1, b1, w2, b2, eps=1e-5):
     """ConvInsBlock -> ConvInsBlock with bf16 storage inside the chain: fp32 (or bf16) in, fp32 out"""
     raw1, st1 = _Conv3dBF16.apply(inp, w1, b1)

@@ -153,6 +153,39 @@ def test_instnorm_bf16_forward_backward(C, dybf):
     assert float((e - (1.01 * BF_ULP * gr.abs() + 1e-4 * gr.abs().max())).max()) <= 0, float(e.max())
 
 
+@pytest.mark.parametrize("C,shape,Bh", [(8, (12, 20, 34), 1), (16, (10, 18, 22), 2), (64, (4, 6, 8), 1)])
+def test_bf16_chain_level_output_fused_pool_backward_is_bit_identical(C, shape, Bh):
+    """ops.conv_ins_pair_bf16_pool_split (the level's last InstanceNorm backward forms unpool(g_pooled)/8 + [g_a ; g_b] on the fly,
+    modet_instnorm_lrelu_bwd_pool_bf16) against conv_ins_pair_bf16 + pool_tee_split (pool backward writes it, the two InstanceNorm
+    passes read it back): outputs and every gradient bit-identical, with and without a gradient for either half."""
+    from smilecode_amd import ops
+    g = torch.Generator().manual_seed(C)
+    B = 2 * Bh
+    x = torch.randn((B,) + shape + (C // 2,), generator=g).cuda()
+    w1 = (torch.randn((C, C // 2, 3, 3, 3), generator=g) / (13.5 * C) ** 0.5).cuda()
+    w2 = (torch.randn((C, C, 3, 3, 3), generator=g) / (27 * C) ** 0.5).cuda()
+    b1, b2 = (0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    gp = torch.randn((B,) + tuple(v // 2 for v in shape) + (C,), generator=g).cuda()
+    ga = torch.randn((Bh,) + shape + (C,), generator=g).cuda()
+    gb = torch.randn((Bh,) + shape + (C,), generator=g).cuda()
+    for use_a, use_b in ((True, True), (True, False), (False, True)):
+        res = []
+        for fused in (True, False):
+            leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+            if fused:
+                pooled, m, f = ops.conv_ins_pair_bf16_pool_split(*leaves, Bh)
+            else:
+                pooled, m, f = ops.pool_tee_split(ops.conv_ins_pair_bf16(*leaves), Bh)
+            outs, grads = [pooled], [gp]
+            if use_a:
+                outs.append(m); grads.append(ga)
+            if use_b:
+                outs.append(f); grads.append(gb)
+            res.append(([pooled.detach(), m.detach(), f.detach()], torch.autograd.grad(outs, leaves, grads)))
+        for a, b in zip(res[0][0] + list(res[0][1]), res[1][0] + list(res[1][1])):
+            assert torch.equal(a, b), "fused pool backward of the bf16 chain differs from the two-node form"
+
+
 def test_cast_kernel_round_to_nearest_even():
     from smilecode_amd import ops
     x = torch.randn(4096, device="cuda") * 3
