@@ -307,6 +307,13 @@ int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, v
                       int B, int D, int H, int W, modet_stream_t stream);
 int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes,
                           int B, int D, int H, int W, int win, modet_stream_t stream);
+/* NCC_vxm(win=[wz, wy, wx]) for ANY window (losses.py:52-59 accepts any list): the reference pads every axis by
+ * floor(wz / 2), so for even / anisotropic windows the window sums -- and the mean -- live on a grid of
+ * (D + 2p - wz + 1, H + 2p - wy + 1, W + 2p - wx + 1) voxels; reproduced exactly (separable sums through the workspace; the
+ * cubic odd windows 3..9 have the fast kernel above).  MODET_ERR_DIM if that grid is empty. */
+size_t modet_ncc_box_ws_bytes(int B, int D, int H, int W, int wz, int wy, int wx);
+int modet_ncc_fwd_bwd_box(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B, int D,
+                          int H, int W, int wz, int wy, int wx, modet_stream_t stream);
 /* Grad3d (losses.py:6-31) on a planar flow (B,3,D,H,W): loss[0], d_flow (NULL to skip).
  * penalty = 1 ('l1', |forward differences|, the class default) or 2 ('l2', squared; what train.py:104 uses). */
 size_t modet_grad3d_ws_bytes(int B, int D, int H, int W);

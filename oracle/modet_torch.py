@@ -224,17 +224,19 @@ def modet_forward(p, moving, fixed, num_heads=(8, 4, 2, 1, 1), head_dim=6, scale
 
 # ----------------------------------------------------------------------------- losses
 def ncc_loss(y_true, y_pred, win=9):
-    """NCC_vxm (ModeT/losses.py:34-94): zero-padded 9^3 box sums, -mean(cc)."""
+    """NCC_vxm (ModeT/losses.py:34-94): zero-padded box sums, -mean(cc).  win = an int (cubic) or [wz, wy, wx]; as the reference
+    (losses.py:57) EVERY axis is padded by floor(win[0] / 2), whatever the other two sizes are."""
     Ii, Ji = y_true, y_pred
-    filt = torch.ones(1, 1, win, win, win, dtype=Ii.dtype, device=Ii.device)
-    pad = win // 2
+    w = [int(win)] * 3 if isinstance(win, int) else [int(v) for v in win]
+    filt = torch.ones(1, 1, *w, dtype=Ii.dtype, device=Ii.device)
+    pad = w[0] // 2
 
     def box(t):
         return F.conv3d(t, filt, padding=pad)
 
     I_sum, J_sum = box(Ii), box(Ji)
     I2_sum, J2_sum, IJ_sum = box(Ii * Ii), box(Ji * Ji), box(Ii * Ji)
-    n = float(win ** 3)
+    n = float(w[0] * w[1] * w[2])
     u_I, u_J = I_sum / n, J_sum / n
     cross = IJ_sum - u_J * I_sum - u_I * J_sum + u_I * u_J * n
     I_var = I2_sum - 2 * u_I * I_sum + u_I * u_I * n

@@ -81,6 +81,8 @@ SIGNATURES = {
     "modet_ncc_ws_bytes": (SZ, [I, I, I, I]),
     "modet_ncc_fwd_bwd": (I, [P, P, P, P, P, SZ, I, I, I, I, P]),
     "modet_ncc_fwd_bwd_win": (I, [P, P, P, P, P, SZ, I, I, I, I, I, P]),
+    "modet_ncc_box_ws_bytes": (SZ, [I, I, I, I, I, I, I]),
+    "modet_ncc_fwd_bwd_box": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P]),
     "modet_grad3d_ws_bytes": (SZ, [I, I, I, I]),
     "modet_grad3d_fwd_bwd": (I, [P, P, P, P, SZ, I, I, I, I, I, P]),
     "modet_scale_by_dev_scalar": (I, [P, P, P, I64, P]),

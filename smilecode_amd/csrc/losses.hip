@@ -310,6 +310,76 @@ __global__ void scalar_finalize_kernel(const float* __restrict__ part, int n, do
   }
 }
 
+// ------------------------------------------------------------------------------------------------ NCC, any window
+// NCC_vxm(win=[wz, wy, wx]) for the windows the z-march kernel is not instantiated for -- even, anisotropic or > 9 voxels.
+// The reference pads EVERY axis by p = floor(win[0] / 2) (losses.py:57), so the five window sums live on a grid of
+// (D + 2p - wz + 1) x (H + 2p - wy + 1) x (W + 2p - wx + 1) voxels that differs from the volume's unless the window is cubic
+// and odd; cc is averaged over THAT grid.  Plain separable form through a workspace (this path is about the API contract, not
+// speed): products -> box sums along x, y, z (window [o - p, o - p + w) clipped to the axis = zero padding) -> pointwise cc +
+// coefficients -> the adjoint box sums z, y, x (voxel i collects the outputs o in [i + p - w + 1, i + p]) -> d_J.
+struct AxisBox { int nvol, outer, n_src, n_dst, inner, w, off; };     // dst[j] = sum_{t = j + off}^{j + off + w - 1} src[t], t clipped
+__global__ __launch_bounds__(BLK) void ncc_box_axis_kernel(const float* __restrict__ src, float* __restrict__ dst, const AxisBox a,
+                                                           int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLK) {
+    const int in = (int)(i % a.inner);
+    const int64_t t1 = i / a.inner;
+    const int j = (int)(t1 % a.n_dst);
+    const int64_t vo = t1 / a.n_dst;                        // (volume, outer) index, shared by src and dst
+    const int lo = max(j + a.off, 0), hi = min(j + a.off + a.w, a.n_src);
+    const float* sp = src + (vo * a.n_src) * a.inner + in;
+    float acc = 0.f;
+    for (int t = lo; t < hi; ++t) acc += sp[(int64_t)t * a.inner];
+    dst[i] = acc;
+  }
+}
+__global__ __launch_bounds__(BLK) void ncc_products_kernel(const float* __restrict__ I, const float* __restrict__ J,
+                                                           float* __restrict__ v5, int64_t N) {
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
+    const float a = I[i], b = J[i];
+    v5[i] = a; v5[N + i] = b; v5[2 * N + i] = a * a; v5[3 * N + i] = b * b; v5[4 * N + i] = a * b;
+  }
+}
+// the reference's own (expanded) order, losses.py:81-91, with true divisions; coef = {cB, cD, cE} as in ncc_march_kernel
+__global__ __launch_bounds__(BLK) void ncc_cc_kernel(const float* __restrict__ s5, float* __restrict__ coef, float* __restrict__ part,
+                                                     int64_t M, float win_size) {
+  __shared__ float red[16];
+  float lsum = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < M; i += (int64_t)gridDim.x * BLK) {
+    const float I_sum = s5[i], J_sum = s5[M + i], I2_sum = s5[2 * M + i], J2_sum = s5[3 * M + i], IJ_sum = s5[4 * M + i];
+    const float u_I = I_sum / win_size, u_J = J_sum / win_size;
+    const float cross = IJ_sum - u_J * I_sum - u_I * J_sum + u_I * u_J * win_size;
+    const float I_var = I2_sum - 2.f * u_I * I_sum + u_I * u_I * win_size;
+    const float J_var = J2_sum - 2.f * u_J * J_sum + u_J * u_J * win_size;
+    const float den = I_var * J_var + 1e-5f;
+    const float cc = cross * cross / den;
+    lsum += cc;
+    if (coef) {
+      const float cE = 2.f * cross / den;
+      const float cD = -cc * I_var / den;
+      const float cB = -(cE * I_sum + 2.f * cD * J_sum) / win_size;
+      coef[i] = cB; coef[M + i] = cD; coef[2 * M + i] = cE;
+    }
+  }
+  const float r = block_sum(lsum, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(BLK) void ncc_dj_kernel(const float* __restrict__ g3, const float* __restrict__ I,
+                                                     const float* __restrict__ J, float* __restrict__ dJ, int64_t N, float g) {
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK)
+    dJ[i] = g * (g3[i] + 2.f * J[i] * g3[N + i] + I[i] * g3[2 * N + i]);
+}
+struct BoxGeo { int p, Do, Ho, Wo; int64_t M, cap; };
+inline bool box_geo(int B, int D, int H, int W, int wz, int wy, int wx, BoxGeo& g) {
+  if (wz < 1 || wy < 1 || wx < 1) return false;
+  g.p = wz / 2;
+  g.Do = D + 2 * g.p - wz + 1; g.Ho = H + 2 * g.p - wy + 1; g.Wo = W + 2 * g.p - wx + 1;
+  if (g.Do < 1 || g.Ho < 1 || g.Wo < 1) return false;
+  g.M = (int64_t)B * g.Do * g.Ho * g.Wo;
+  g.cap = (int64_t)B * (D > g.Do ? D : g.Do) * (H > g.Ho ? H : g.Ho) * (W > g.Wo ? W : g.Wo);      // any intermediate volume fits
+  return true;
+}
+constexpr int NCC_BOX_PARTS = 1024;
+
 // Grad3d: flow (B,3,D,H,W) planar.  'l2': loss = (mean dH^2 + mean dD^2 + mean dW^2)/3; 'l1' (L1 = true): the same with
 // |d| instead of d^2 (losses.py:11-27); the gradient of |t| at t = 0 is 0, as torch.abs's backward (sign(0) = 0).
 template <bool L1>
@@ -396,6 +466,47 @@ int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_
 int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B, int D,
                       int H, int W, modet_stream_t stream) {
   return modet_ncc_fwd_bwd_win(I, J, loss, d_J, ws, ws_bytes, B, D, H, W, 9, stream);
+}
+
+size_t modet_ncc_box_ws_bytes(int B, int D, int H, int W, int wz, int wy, int wx) {
+  BoxGeo g;
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || !box_geo(B, D, H, W, wz, wy, wx, g)) return 0;
+  return ((size_t)10 * g.cap + NCC_BOX_PARTS + 64) * sizeof(float);       // two ping-pong buffers of five volumes + loss partials
+}
+
+int modet_ncc_fwd_bwd_box(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B, int D,
+                          int H, int W, int wz, int wy, int wx, modet_stream_t stream) {
+  MODET_CHECK_PTR(I); MODET_CHECK_PTR(J); MODET_CHECK_PTR(loss); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0);
+  BoxGeo g;
+  if (!box_geo(B, D, H, W, wz, wy, wx, g)) return MODET_ERR_DIM;           // (the reference's conv3d fails on an empty output too)
+  if (ws_bytes < modet_ncc_box_ws_bytes(B, D, H, W, wz, wy, wx)) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t N = (int64_t)B * D * H * W, M = g.M;
+  float* X = (float*)ws;
+  float* Y = X + 5 * g.cap;
+  float* part = Y + 5 * g.cap;
+  auto box = [&](const float* src, float* dst, int nvol, int outer, int n_src, int n_dst, int inner, int w, int off) {
+    const AxisBox a{nvol, outer, n_src, n_dst, inner, w, off};
+    const int64_t total = (int64_t)nvol * outer * n_dst * inner;
+    hipLaunchKernelGGL(ncc_box_axis_kernel, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, dst, a, total);
+  };
+  hipLaunchKernelGGL(ncc_products_kernel, dim3(flat_grid(N, BLK)), dim3(BLK), 0, s, I, J, X, N);
+  // (volume, outer) is one flat index: the five volumes are stacked, so nvol * outer = 5 * B * (dims in front of the axis)
+  box(X, Y, 5, B * D * H, W, g.Wo, 1, wx, -g.p);                            // x: (B, D, H, W)   -> (B, D, H, Wo)
+  box(Y, X, 5, B * D, H, g.Ho, g.Wo, wy, -g.p);                             // y: (B, D, H, Wo)  -> (B, D, Ho, Wo)
+  box(X, Y, 5, B, D, g.Do, g.Ho * g.Wo, wz, -g.p);                          // z: (B, D, Ho, Wo) -> (B, Do, Ho, Wo)
+  const float win_size = (float)wz * (float)wy * (float)wx;
+  const int gp = flat_grid(M, BLK) < NCC_BOX_PARTS ? flat_grid(M, BLK) : NCC_BOX_PARTS;
+  hipLaunchKernelGGL(ncc_cc_kernel, dim3(gp), dim3(BLK), 0, s, (const float*)Y, d_J ? X : (float*)nullptr, part, M, win_size);
+  hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(BLK), 0, s, (const float*)part, gp, -1.0 / (double)M, loss);
+  if (d_J) {
+    box(X, Y, 3, B, g.Do, D, g.Ho * g.Wo, wz, g.p - wz + 1);                // adjoint z: (B, Do, Ho, Wo) -> (B, D, Ho, Wo)
+    box(Y, X, 3, B * D, g.Ho, H, g.Wo, wy, g.p - wy + 1);                   // adjoint y
+    box(X, Y, 3, B * D * H, g.Wo, W, 1, wx, g.p - wx + 1);                  // adjoint x: -> (B, D, H, W)
+    hipLaunchKernelGGL(ncc_dj_kernel, dim3(flat_grid(N, BLK)), dim3(BLK), 0, s, (const float*)Y, I, J, d_J, N, -1.f / (float)M);
+  }
+  return modet_launch_status();
 }
 
 size_t modet_grad3d_ws_bytes(int, int, int, int) { return 2048 * sizeof(float); }

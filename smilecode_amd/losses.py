@@ -25,17 +25,19 @@ class Grad3d(torch.nn.Module):
 
 
 class NCC_vxm(torch.nn.Module):
-    """local normalized cross correlation loss over win^3 windows (reference losses.py:34-94); ``win`` = None (the
-    reference's default [9, 9, 9], what train.py:103 uses) or a cubic window [w, w, w] with w in {3, 5, 7, 9}.  The
-    reference pads every axis by floor(win[0] / 2) (losses.py:57), so only cubic odd windows keep the volume's shape there."""
+    """local normalized cross correlation loss over windows of ``win`` voxels (reference losses.py:34-94); ``win`` = None (the
+    reference's default [9, 9, 9], what train.py:103 uses) or any [wz, wy, wx].  The reference pads EVERY axis by
+    floor(win[0] / 2) (losses.py:57), so an even or anisotropic window averages cc over a grid that differs from the volume's
+    by a voxel or more per axis -- reproduced as is.  Cubic windows of 3 / 5 / 7 / 9 voxels run the z-marching kernel, all
+    others the general separable path (csrc/losses.hip)."""
 
     def __init__(self, win=None):
         super().__init__()
         w = [9, 9, 9] if win is None else [int(v) for v in win]
-        if len(w) != 3 or w[0] != w[1] or w[0] != w[2] or w[0] not in (3, 5, 7, 9):
-            raise RuntimeError(f"NCC_vxm: cubic windows of 3, 5, 7 or 9 voxels are implemented on the HIP path, got {win}")
+        if len(w) != 3 or min(w) < 1:
+            raise RuntimeError(f"NCC_vxm: 3-D volumes take a window of three positive sizes, got {win}")
         self.win = win
-        self._w = w[0]
+        self._w = w
 
     def forward(self, y_true, y_pred):
         return ops.ncc_loss(y_true.contiguous(), y_pred.contiguous(), self._w)

@@ -1183,11 +1183,23 @@ def _scale_by(x, s):
 
 
 def _ncc_launch(I, J, want_grad, win=9):
-    """modet_ncc_fwd_bwd_win(I, J): (loss (1,), d loss / d J or None)"""
+    """modet_ncc_fwd_bwd_win(I, J): (loss (1,), d loss / d J or None); win = 3 | 5 | 7 | 9 (cubic: the z-marching kernel) or a
+    tuple (wz, wy, wx) of any positive sizes (modet_ncc_fwd_bwd_box: the reference's padding rule, separable sums)"""
     B, _, D, H, W = I.shape
     loss = torch.empty(1, dtype=torch.float32, device=I.device)
     dJ = torch.empty_like(J) if want_grad else None
     L = _L()
+    if isinstance(win, tuple):
+        wz, wy, wx = win
+        nb = L.modet_ncc_box_ws_bytes(B, D, H, W, wz, wy, wx)
+        if nb == 0:
+            raise RuntimeError(f"NCC: window {list(win)} leaves no output voxel on a {(D, H, W)} volume")
+        ws = _ws(nb, I)
+        nv = float(I.numel())
+        with _Guard(I, "ncc_fwd_bwd_box", 30.0 * (wz + wy + wx) * nv, 150.0 * nv):
+            _lib.check(L.modet_ncc_fwd_bwd_box(_p(I), _p(J), _p(loss), _p(dJ), _p(ws), nb, B, D, H, W, wz, wy, wx, _stream()),
+                       "modet_ncc_fwd_bwd_box")
+        return loss, dJ
     nb = L.modet_ncc_ws_bytes(B, D, H, W)
     ws = _ws(nb, I)
     nv = float(I.numel())               # reads I,J once, writes d_J once
@@ -1226,8 +1238,17 @@ class _NCC(Function):
 
 
 def ncc_loss(y_true, y_pred, win=9):
-    """NCC_vxm: -mean(cc) over win^3 windows (win 3 / 5 / 7 / 9; default 9).  reference: losses.py:34-94"""
-    return _NCC.apply(y_true, y_pred, int(win))
+    """NCC_vxm: -mean(cc) over the windows; win = an int (cubic) or [wz, wy, wx].  Cubic 3 / 5 / 7 / 9 run the z-marching
+    kernel, every other window the general separable path.  reference: losses.py:34-94"""
+    if isinstance(win, (list, tuple)):
+        w = tuple(int(v) for v in win)
+        if len(w) != 3 or min(w) < 1:
+            raise RuntimeError(f"NCC: a window is three positive sizes, got {win}")
+    else:
+        w = (int(win),) * 3
+    if w[0] == w[1] == w[2] and w[0] in (3, 5, 7, 9):
+        return _NCC.apply(y_true, y_pred, w[0])
+    return _NCC.apply(y_true, y_pred, w)
 
 
 class _Grad3d(Function):

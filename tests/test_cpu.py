@@ -610,6 +610,20 @@ def test_oracle_eval_goldens(orc):
         assert_close(db.numpy(), g[f"nccw{w}.db"], atol=1e-15, rtol=1e-9, what=f"ncc win {w} d y_pred")
 
 
+def test_oracle_ncc_any_window_goldens(orc):
+    """the oracle's NCC for even / anisotropic / > 9-voxel windows (every axis padded by floor(win[0] / 2), losses.py:57) against
+    the vectors captured from the reference's own class (tests/golden/make_goldens_ncc_windows.py)"""
+    g = gold("op_ncc_windows.npz")
+    for w in ([4, 4, 4], [5, 3, 7], [11, 11, 11], [2, 6, 3], [6, 9, 9], [9, 9, 5], [1, 1, 1]):
+        tag = "x".join(map(str, w))
+        a, b = T(g[f"ncc[{tag}].a"]).requires_grad_(True), T(g[f"ncc[{tag}].b"]).requires_grad_(True)
+        l = orc.ncc_loss(a, b, win=w)
+        assert abs(float(l) - float(g[f"ncc[{tag}].val"])) < 1e-12
+        da, db = torch.autograd.grad(l, [a, b])
+        assert_close(da.numpy(), g[f"ncc[{tag}].da"], atol=1e-15, rtol=1e-9, what=f"ncc win {w} d y_true")
+        assert_close(db.numpy(), g[f"ncc[{tag}].db"], atol=1e-15, rtol=1e-9, what=f"ncc win {w} d y_pred")
+
+
 # ------------------------------------------------------------------------------------------------ C oracle pins
 def test_c_oracle_against_reference_goldens(orc):
     """oracle/modet_ref.c (plain C, fp64) vs the vectors captured from the real reference, and vs the ATen oracle."""

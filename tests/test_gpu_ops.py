@@ -895,9 +895,31 @@ def test_ncc_other_windows_golden(ops, w):
     da, db = torch.autograd.grad(l, [a, b])
     assert_close(np64(da), g[f"nccw{w}.da"], atol=2e-6, rtol=2e-3, what="ncc d y_true")
     assert_close(np64(db), g[f"nccw{w}.db"], atol=2e-6, rtol=2e-3, what="ncc d y_pred")
-    for bad in ([4, 4, 4], [9, 9, 5], [11, 11, 11], [9, 9]):
+    for bad in ([9, 9], [9, 0, 9], [3, 3, 3, 3]):                          # not a 3-D window
         with pytest.raises(RuntimeError):
             losses.NCC_vxm(win=bad)
+
+
+@pytest.mark.parametrize("w", [[4, 4, 4], [5, 3, 7], [11, 11, 11], [2, 6, 3], [6, 9, 9], [9, 9, 5], [1, 1, 1]])
+def test_ncc_any_window_golden(ops, w):
+    """NCC_vxm(win=[wz, wy, wx]) for even / anisotropic / > 9-voxel windows (losses.py:52-59 accepts any list and pads EVERY axis
+    by floor(win[0] / 2), so cc lives on a grid that differs from the volume's): goldens from the reference's own class, batch 2,
+    value and both gradients; the general separable path (modet_ncc_fwd_bwd_box)."""
+    from smilecode_amd import losses
+    g = gold("op_ncc_windows.npz")
+    tag = "x".join(map(str, w))
+    a, b = cu(g[f"ncc[{tag}].a"]).requires_grad_(True), cu(g[f"ncc[{tag}].b"]).requires_grad_(True)
+    l = losses.NCC_vxm(win=w)(a, b)
+    assert_close(np64(l), g[f"ncc[{tag}].val"], atol=2e-5, what="ncc value")
+    da, db = torch.autograd.grad(l, [a, b])
+    assert_close(np64(da), g[f"ncc[{tag}].da"], atol=2e-6, rtol=2e-3, what="ncc d y_true")
+    assert_close(np64(db), g[f"ncc[{tag}].db"], atol=2e-6, rtol=2e-3, what="ncc d y_pred")
+    # only the first argument differentiated (train.py:127's order) takes the swapped-roles launch
+    a1 = cu(g[f"ncc[{tag}].a"]).requires_grad_(True)
+    (da1,) = torch.autograd.grad(losses.NCC_vxm(win=w)(a1, cu(g[f"ncc[{tag}].b"])), [a1])
+    assert_close(np64(da1), g[f"ncc[{tag}].da"], atol=2e-6, rtol=2e-3, what="ncc d y_true alone")
+    with pytest.raises(RuntimeError):                                    # a window that leaves no output voxel
+        losses.NCC_vxm(win=[2, 40, 3])(a, b)
 
 
 @pytest.mark.parametrize("shape,B", [((37, 50, 70), 2), ((9, 24, 32), 1), ((4, 5, 6), 1), ((70, 49, 33), 1)])
