@@ -8,7 +8,8 @@
 // the tiled bf16x3 kernel (conv3d_bf16.hip, SP = 3: 4x8x16-voxel tiles, one workgroup per tile -- at level 3 a 40-wide
 // volume wastes 17 % of every 16-wide x tile and 720 tiles over 512 slots leave the second round half empty: 100 TFLOP/s),
 // the exact-f32 MFMA kernel (conv3d.hip: every launch with a lazily normalised input, every odd channel count: 38 TFLOP/s)
-// and the direct kernel (level 5: operands straight from L2, 50 TFLOP/s).  This one covers all of them:
+// and the direct kernel (level 5: operands straight from L2, 50 TFLOP/s).  This one covers all of them but level 5 (2 400 voxels,
+// where the direct kernel stays faster):
 //   * tile = 2 x 8 x 8 voxels (x tiles of 8 fit W = 40 / 80 exactly), staged once per 16-channel block into the tensor's own
 //     layout [halo'd voxel][16 ch] bf16 x three pieces (the staging code of conv3d_wtr.hip, plus the lazily applied
 //     InstanceNorm + LeakyReLU of modet_conv3d_fwd_normin);
@@ -18,7 +19,7 @@
 //   * the MFMA takes the WEIGHTS as A (16 couts) and 16 VOXELS (2 rows x 8 x) as B, so a lane ends with 4 consecutive
 //     couts of one voxel: bias, statistics and a 16-byte store without a transpose; weights come pre-split and
 //     pre-arranged in fragment order from L2 (16 bytes per lane and (k-step, piece, cout tile), shared by the four waves
-//     through L1), next k-step prefetched;
+//     through L1) through a ring of 3-4 k-steps of lookahead; the next channel block's tile is loaded during the k-steps;
 //   * workgroup = (tile, block of cout tiles), wave = 2 voxel tiles x 1 | 2 cout tiles (template <WC, CT>, chosen by
 //     q_plan from a measured sweep); the channel blocks (stages) accumulate in registers; fused InstanceNorm statistics
 //     as shifted sums, one row per (sample, tile).
