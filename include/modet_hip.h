@@ -98,6 +98,14 @@ size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads);
 int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* out, const float* lse,
                  const float* d_out, float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes,
                  int B, int D, int H, int W, int heads, int hd, float scale, modet_stream_t stream);
+/* The same two entry points with bf16 q / k (qk_bf16 != 0: two channels per 32-bit word, channels-last as above; BASELINE.json
+ * configs[4], bf16 storage): every product and sum stays fp32 -- the result is bit-identical to the fp32 entry points fed with
+ * the bf16 values widened to fp32.  d_q / d_k are fp32.  head_dim 6 only. */
+int modet_na_fwd_t(const void* q, const void* k, int qk_bf16, const float* rpb, float* out, float* lse, int B, int D, int H, int W,
+                   int heads, int hd, float scale, modet_stream_t stream);
+int modet_na_bwd_t(const void* q, const void* k, int qk_bf16, const float* rpb, const float* out, const float* lse,
+                   const float* d_out, float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes, int B, int D,
+                   int H, int W, int heads, int hd, float scale, modet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 3x3x3 convolution, stride 1, zero pad 1 (nn.Conv3d call sites ModeT/models.py:127,:144,:254)

@@ -30,6 +30,8 @@ SIGNATURES = {
     "modet_na_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, P]),
     "modet_na_bwd_ws_bytes": (SZ, [I, I, I, I, I]),
     "modet_na_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, F, P]),
+    "modet_na_fwd_t": (I, [P, P, I, P, P, P, I, I, I, I, I, I, F, P]),
+    "modet_na_bwd_t": (I, [P, P, I, P, P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, F, P]),
     "modet_conv3d_kernel_family": (I, [I, I, I, I, I, I, I]),
     "modet_conv3d_kernel_family_v": (I, [I, I, I, I, I, I, I, I]),
     "modet_conv3d_ws_bytes": (SZ, [I, I]),

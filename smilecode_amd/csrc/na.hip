@@ -35,6 +35,9 @@ __device__ __forceinline__ void tile_origin(int tile, const TileGeom g, int& z0,
 // then the LDS writes.  As one loop with a load per `if (inside)` every item was its own memory round trip: eight in
 // series per tile (and nineteen in na_bwd_kernel) in front of ~10 us of work.
 constexpr int KT_IT = (HVOX * 3 + NTHREADS - 1) / NTHREADS;
+// QK16 (cfg 5, bf16 storage of q / k): the tensor holds bf16, two channels per 32-bit word; everything past the load is fp32
+__device__ __forceinline__ float2 bf2_unpack(unsigned u) { return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)); }
+template <bool QK16 = false>
 __device__ __forceinline__ void stage_k_load(float2 (&r)[KT_IT], const float* __restrict__ k, int64_t bbase, int z0, int y0,
                                              int x0, int D, int H, int W, int C, int hoff) {
   bool inside[KT_IT];
@@ -47,7 +50,8 @@ __device__ __forceinline__ void stage_k_load(float2 (&r)[KT_IT], const float* __
     const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
     const bool in = z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
     const int64_t off = (bbase + (in ? ((int64_t)z * H + y) * W + x : 0)) * C + hoff + part * 2;
-    r[j] = *reinterpret_cast<const float2*>(k + off);
+    if constexpr (QK16) r[j] = bf2_unpack(reinterpret_cast<const unsigned*>(k)[off >> 1]);      // (C, hoff even: off is even)
+    else r[j] = *reinterpret_cast<const float2*>(k + off);
     inside[j] = in;
   }
   // the loaded values are "used" here, unconditionally and all at once: without this hipcc sinks every load back under its
@@ -65,10 +69,11 @@ __device__ __forceinline__ void stage_k_store(float* __restrict__ kt, const floa
     if (idx < HVOX * 3) *reinterpret_cast<float2*>(kt + idx * 2) = r[j];
   }
 }
+template <bool QK16 = false>
 __device__ __forceinline__ void stage_k_tile(float* __restrict__ kt, const float* __restrict__ k, int64_t bbase,
                                              int z0, int y0, int x0, int D, int H, int W, int C, int hoff) {
   float2 r[KT_IT];
-  stage_k_load(r, k, bbase, z0, y0, x0, D, H, W, C, hoff);
+  stage_k_load<QK16>(r, k, bbase, z0, y0, x0, D, H, W, C, hoff);
   stage_k_store(kt, r);
 }
 
@@ -77,6 +82,17 @@ __device__ __forceinline__ void load6(const float* __restrict__ p, float (&r)[HD
   const float2 b = *reinterpret_cast<const float2*>(p + 2);
   const float2 c = *reinterpret_cast<const float2*>(p + 4);
   r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y; r[4] = c.x; r[5] = c.y;
+}
+
+template <bool QK16>
+__device__ __forceinline__ void load6g(const float* __restrict__ base, int64_t el, float (&r)[HD]) {     // el: element index (even)
+  if constexpr (QK16) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(base) + (el >> 1);
+    const float2 a = bf2_unpack(p[0]), b = bf2_unpack(p[1]), c = bf2_unpack(p[2]);
+    r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y; r[4] = c.x; r[5] = c.y;
+  } else {
+    load6(base + el, r);
+  }
 }
 
 // 27 logits of one voxel from the LDS tile; lt = linear halo index of the voxel's (-1,-1,-1) neighbour
@@ -112,6 +128,7 @@ __device__ __forceinline__ float softmax27(float (&lg)[27], float& m) {   // lg 
 }
 
 // ------------------------------------------------------------------------------------------ fused forward
+template <bool QK16>
 __global__ __launch_bounds__(NTHREADS) void na_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ rpb, float* __restrict__ out,
                                                           float* __restrict__ lse, int D, int H, int W, int heads,
@@ -124,7 +141,7 @@ __global__ __launch_bounds__(NTHREADS) void na_fwd_kernel(const float* __restric
   int z0, y0, x0;
   tile_origin(blockIdx.x, g, z0, y0, x0);
   if (threadIdx.x < 27) rp[threadIdx.x] = rpb[h * 27 + threadIdx.x];
-  stage_k_tile(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
+  stage_k_tile<QK16>(kt, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
   __syncthreads();
 
   const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tz = threadIdx.x / (TX * TY);
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(NTHREADS) void na_fwd_kernel(const float* __restric
   if (z >= D || y >= H || x >= W) return;
   const int64_t n = (int64_t)b * V + ((int64_t)z * H + y) * W + x;
   float qs[HD];
-  load6(q + n * C + h * HD, qs);
+  load6g<QK16>(q, n * C + h * HD, qs);
 #pragma unroll
   for (int c = 0; c < HD; ++c) qs[c] *= scale;
   float p[27];
@@ -191,6 +208,7 @@ __device__ __forceinline__ float wave_reduce_scatter32(const float (&v27)[27], i
 // No atomics, deterministic.
 constexpr int AUX = 5;      // per halo voxel: d_out[3], u, lse
 
+template <bool QK16>
 __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ rpb, const float* __restrict__ out,
                                                           const float* __restrict__ lse, const float* __restrict__ dout,
@@ -214,8 +232,8 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
     float2 rk[KT_IT], rq[KT_IT];
     float ra[AX_IT][7];
     bool ain[AX_IT];
-    stage_k_load(rk, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
-    stage_k_load(rq, q, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
+    stage_k_load<QK16>(rk, k, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
+    stage_k_load<QK16>(rq, q, (int64_t)b * V, z0, y0, x0, D, H, W, C, h * HD);
 #pragma unroll
     for (int j = 0; j < AX_IT; ++j) {
       const int v = min((int)threadIdx.x + j * NTHREADS, HVOX - 1);
@@ -372,6 +390,7 @@ struct NaMarchArgs {
   float scale;
 };
 
+template <bool QK16>
 __global__ __launch_bounds__(NTHREADS, 2) void na_bwd_march_kernel(const NaMarchArgs a) {
   // ring slot: k[MHV][6] | q'[MHV][6] | (g0, g1, g2, u)[MHV] | lse'[MHV]   with q' = scale * log2(e) * q, lse' = log2(e) * lse:
   // the logits are kept in the base-2 domain (p = exp2(logit' - lse'): no multiply in front of v_exp_f32), d_k divides the
@@ -392,12 +411,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void na_bwd_march_kernel(const NaMarch
 #pragma unroll
   for (int i = 0; i < 27; ++i) rp[i] = a.rpb[h * 27 + i];  // (unscaled: the log2(e) rides on the fma that subtracts lse')
   const int64_t V = (int64_t)D * H * W, HW = (int64_t)H * W;
-  const float* qb = a.q + (int64_t)b * V * C + h * HD;
-  const float* kb = a.k + (int64_t)b * V * C + h * HD;
+  constexpr int QSZ = QK16 ? 2 : 4;                         // bytes per q / k element in HBM
+  const float* qb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.q) + ((int64_t)b * V * C + h * HD) * QSZ);
+  const float* kb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.k) + ((int64_t)b * V * C + h * HD) * QSZ);
   const float* gb = a.dout + (int64_t)b * V * C3 + h * 3;
   const float* ob = a.out + (int64_t)b * V * C3 + h * 3;
   const float* lb = a.lse + (int64_t)b * V * heads + h;
-  const unsigned qbytes = (unsigned)(HW * C * 4), gbytes = (unsigned)(HW * C3 * 4), lbytes = (unsigned)(HW * heads * 4);
+  const unsigned qbytes = (unsigned)(HW * C * QSZ), gbytes = (unsigned)(HW * C3 * 4), lbytes = (unsigned)(HW * heads * 4);
   const float qmul = a.scale * LOG2E;
 
   // staging items: halo voxel v = tid (and v = 256 + tid for the first MHV - 256 threads)
@@ -412,7 +432,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void na_bwd_march_kernel(const NaMarch
     const int y = y0 + hy - 1, x = x0 + hx - 1;
     const bool ok = on && y >= 0 && y < H && x >= 0 && x < W;
     const unsigned n = (unsigned)(y * W + x);
-    oq[j] = ok ? n * (unsigned)(C * 4) : NA_OOB;
+    oq[j] = ok ? n * (unsigned)(C * QSZ) : NA_OOB;
     og[j] = ok ? n * (unsigned)(C3 * 4) : NA_OOB;
     ol[j] = ok ? n * (unsigned)(heads * 4) : NA_OOB;
     sl_[j] = on ? v : -1;
@@ -422,15 +442,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void na_bwd_march_kernel(const NaMarch
   auto load_plane = [&](int z) {
     const bool live = z >= 0 && z < D;
     const int64_t zo = live ? z : 0;
-    const NaBuf bq = na_rsrc(qb + zo * HW * C, live ? qbytes : 0u), bk = na_rsrc(kb + zo * HW * C, live ? qbytes : 0u);
+    const NaBuf bq = na_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(qb) + zo * HW * C * QSZ), live ? qbytes : 0u);
+    const NaBuf bk = na_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(kb) + zo * HW * C * QSZ), live ? qbytes : 0u);
     const NaBuf bg = na_rsrc(gb + zo * HW * C3, live ? gbytes : 0u), bo = na_rsrc(ob + zo * HW * C3, live ? gbytes : 0u);
     const NaBuf bl = na_rsrc(lb + zo * HW * heads, live ? lbytes : 0u);
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        rk[j][c] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(bk, (int)(oq[j] + c * 8), 0, 0));
-        rq[j][c] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(bq, (int)(oq[j] + c * 8), 0, 0));
+        if constexpr (QK16) {
+          rk[j][c] = bf2_unpack(__builtin_amdgcn_raw_buffer_load_b32(bk, (int)(oq[j] + c * 4), 0, 0));
+          rq[j][c] = bf2_unpack(__builtin_amdgcn_raw_buffer_load_b32(bq, (int)(oq[j] + c * 4), 0, 0));
+        } else {
+          rk[j][c] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(bk, (int)(oq[j] + c * 8), 0, 0));
+          rq[j][c] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(bq, (int)(oq[j] + c * 8), 0, 0));
+        }
         rg[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bg, (int)(og[j] + c * 4), 0, 0));
         ro[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bo, (int)(og[j] + c * 4), 0, 0));
       }
@@ -816,6 +842,19 @@ inline TileGeom geom(int D, int H, int W) { return TileGeom{cdiv(W, TX), cdiv(H,
 
 extern "C" {
 
+int modet_na_fwd_t(const void* q, const void* k, int qk_bf16, const float* rpb, float* out, float* lse, int B, int D, int H, int W,
+                   int heads, int hd, float scale, modet_stream_t stream) {
+  if (!qk_bf16) return modet_na_fwd((const float*)q, (const float*)k, rpb, out, lse, B, D, H, W, heads, hd, scale, stream);
+  MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(out);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
+  if (hd != HD) return MODET_ERR_UNSUPPORTED;
+  const TileGeom g = geom(D, H, W);
+  dim3 grid(g.tiles_x * g.tiles_y * g.tiles_z, heads, B);
+  hipLaunchKernelGGL(na_fwd_kernel<true>, grid, dim3(NTHREADS), 0, (hipStream_t)stream, (const float*)q, (const float*)k, rpb, out,
+                     lse, D, H, W, heads, scale, g);
+  return modet_launch_status();
+}
+
 int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, float* lse, int B, int D, int H, int W,
                  int heads, int hd, float scale, modet_stream_t stream) {
   MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(out);
@@ -824,7 +863,7 @@ int modet_na_fwd(const float* q, const float* k, const float* rpb, float* out, f
   const TileGeom g = geom(D, H, W);
   dim3 grid(g.tiles_x * g.tiles_y * g.tiles_z, heads, B);
   if (hd == HD)
-    hipLaunchKernelGGL(na_fwd_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, q, k, rpb, out, lse, D, H, W, heads,
+    hipLaunchKernelGGL(na_fwd_kernel<false>, grid, dim3(NTHREADS), 0, (hipStream_t)stream, q, k, rpb, out, lse, D, H, W, heads,
                        scale, g);
   else
     hipLaunchKernelGGL(na_fwd_gen_kernel, grid, dim3(NTHREADS), 0, (hipStream_t)stream, q, k, rpb, out, lse, D, H, W,
@@ -839,20 +878,23 @@ size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads) {
   return fl * sizeof(float) + drpb_scratch_bytes(B, heads);
 }
 
-int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* out, const float* lse,
-                 const float* d_out, float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes, int B, int D,
-                 int H, int W, int heads, int hd, float scale, modet_stream_t stream) {
+int modet_na_bwd_t(const void* qv, const void* kv, int qk_bf16, const float* rpb, const float* out, const float* lse,
+                   const float* d_out, float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes, int B, int D,
+                   int H, int W, int heads, int hd, float scale, modet_stream_t stream) {
+  const float* q = (const float*)qv;
+  const float* k = (const float*)kv;
   MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(out); MODET_CHECK_PTR(lse);
   MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_q); MODET_CHECK_PTR(d_k); MODET_CHECK_PTR(d_rpb); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
-  if (hd != HD && !gen_hd_ok(hd)) return MODET_ERR_UNSUPPORTED;
+  if (hd != HD && (qk_bf16 || !gen_hd_ok(hd))) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_na_bwd_ws_bytes(B, D, H, W, heads)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const NaMarchPlan mp = na_march_plan(B, D, H, W, heads, hd);
   if (mp.on) {
     const int64_t nblk = (int64_t)mp.tiles_x * mp.tiles_y * mp.nchunk;
     NaMarchArgs a{q, k, rpb, out, lse, d_out, d_q, d_k, (float*)ws, D, H, W, heads, mp.tiles_x, mp.tiles_y, mp.nchunk, mp.zc, scale};
-    hipLaunchKernelGGL(na_bwd_march_kernel, dim3((unsigned)nblk, heads, B), dim3(NTHREADS), 0, s, a);
+    if (qk_bf16) hipLaunchKernelGGL(na_bwd_march_kernel<true>, dim3((unsigned)nblk, heads, B), dim3(NTHREADS), 0, s, a);
+    else hipLaunchKernelGGL(na_bwd_march_kernel<false>, dim3((unsigned)nblk, heads, B), dim3(NTHREADS), 0, s, a);
     size_t fl = (size_t)B * heads * nblk * 27;
     fl += fl & 1;
     drpb_reduce((float*)ws, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
@@ -862,16 +904,25 @@ int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* 
   const int64_t nblk = (int64_t)g.tiles_x * g.tiles_y * g.tiles_z;
   float* part = (float*)ws;
   dim3 grid((unsigned)nblk, heads, B);
-  if (hd == HD)
-    hipLaunchKernelGGL(na_bwd_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, out, lse, d_out, d_q, d_k, part, D, H, W,
-                       heads, scale, g);
-  else
+  if (hd == HD) {
+    if (qk_bf16) hipLaunchKernelGGL(na_bwd_kernel<true>, grid, dim3(NTHREADS), 0, s, q, k, rpb, out, lse, d_out, d_q, d_k, part, D, H, W,
+                                    heads, scale, g);
+    else hipLaunchKernelGGL(na_bwd_kernel<false>, grid, dim3(NTHREADS), 0, s, q, k, rpb, out, lse, d_out, d_q, d_k, part, D, H, W,
+                            heads, scale, g);
+  } else {
     hipLaunchKernelGGL(na_bwd_gen_kernel, grid, dim3(NTHREADS), 0, s, q, k, rpb, out, lse, d_out, d_q, d_k, part, D, H, W,
                        heads, hd, scale, g);
+  }
   size_t fl = (size_t)B * heads * nblk * 27;
   fl += fl & 1;
   drpb_reduce(part, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
   return modet_launch_status();
+}
+
+int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* out, const float* lse,
+                 const float* d_out, float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes, int B, int D,
+                 int H, int W, int heads, int hd, float scale, modet_stream_t stream) {
+  return modet_na_bwd_t(q, k, 0, rpb, out, lse, d_out, d_q, d_k, d_rpb, ws, ws_bytes, B, D, H, W, heads, hd, scale, stream);
 }
 
 }  // extern "C"

@@ -425,3 +425,35 @@ def test_cfg5_shape_160x192x224_batch2_bf16_train_step():
         torch.cuda.empty_cache()
     assert abs(first[torch.float32][0] - first[torch.bfloat16][0]) < 5e-3, first
     assert first[torch.bfloat16][-1] < first[torch.bfloat16][0]
+
+
+@pytest.mark.parametrize("shape,heads", [((9, 14, 21), 1), ((8, 12, 20), 2), ((128, 96, 128), 1)])
+def test_attention_with_bf16_q_k_is_the_fp32_kernel_on_widened_operands(shape, heads):
+    """modet_na_fwd_t / modet_na_bwd_t with bf16 q / k (cfg 5 storage): only the loads differ, every product and sum is fp32, so
+    out, lse, d_q, d_k and d_rpb are BIT-IDENTICAL to the fp32 entry points fed with the same values widened to fp32 -- on the
+    tile kernels and (last case, 1.5 M voxels) the z-marching backward."""
+    from smilecode_amd import _lib
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    D, H, W = shape
+    B, C = 1, heads * 6
+    g = torch.Generator(device="cuda").manual_seed(11 + heads)
+    q16 = torch.randn((B, D, H, W, C), device="cuda", generator=g).bfloat16()
+    k16 = torch.randn((B, D, H, W, C), device="cuda", generator=g).bfloat16()
+    q32, k32 = q16.float(), k16.float()
+    rpb = torch.randn((heads, 3, 3, 3), device="cuda", generator=g)
+    gy = torch.randn((B, D, H, W, heads * 3), device="cuda", generator=g)
+    P = lambda t: t.data_ptr()
+    res = []
+    for q, k, bf in ((q32, k32, 0), (q16, k16, 1)):
+        out = torch.empty((B, D, H, W, heads * 3), device="cuda")
+        lse = torch.empty((B, D, H, W, heads), device="cuda")
+        dq, dk, dr = torch.empty_like(q32), torch.empty_like(k32), torch.empty_like(rpb)
+        nb = L.modet_na_bwd_ws_bytes(B, D, H, W, heads)
+        ws = torch.empty(nb // 4 + 2, device="cuda")
+        _lib.check(L.modet_na_fwd_t(P(q), P(k), bf, P(rpb), P(out), P(lse), B, D, H, W, heads, 6, 0.7, st), "na_fwd_t")
+        _lib.check(L.modet_na_bwd_t(P(q), P(k), bf, P(rpb), P(out), P(lse), P(gy), P(dq), P(dk), P(dr), P(ws), nb, B, D, H, W, heads,
+                                    6, 0.7, st), "na_bwd_t")
+        res.append((out, lse, dq, dk, dr))
+    for name, a, b in zip(("out", "lse", "d_q", "d_k", "d_rpb"), res[0], res[1]):
+        assert torch.equal(a, b), f"bf16 q / k: {name} differs from the fp32 kernel on the widened operands"
