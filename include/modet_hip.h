@@ -269,6 +269,15 @@ int modet_proj_ln_bwd_pair(const float* x1, const float* d_y1, float* d_x1, cons
                            const float* Wt, const float* bias, const float* gamma, float* d_Wt, float* d_bias,
                            float* d_gamma, float* d_beta, void* ws, size_t ws_bytes, int64_t N, int Cin, int dim,
                            float eps, modet_stream_t stream);
+/* Typed variants (BASELINE.json configs[4], bf16 storage): x_bf16 / y_bf16 != 0 means that tensor holds bf16 (channels-last);
+ * values are widened on load and rounded to nearest even on store, everything in between is the fp32 arithmetic above -- a bf16
+ * input gives bit-identical results to the fp32 entry point fed with the widened values, a bf16 output is the fp32 output rounded. */
+int modet_proj_ln_fwd_t(const void* x, int x_bf16, const float* Wt, const float* bias, const float* gamma, const float* beta,
+                        void* y, int y_bf16, int64_t N, int Cin, int dim, float eps, modet_stream_t stream);
+int modet_proj_ln_bwd_pair_t(const void* x1, int x1_bf16, const float* d_y1, float* d_x1, const void* x2, int x2_bf16,
+                             const float* d_y2, float* d_x2, const float* Wt, const float* bias, const float* gamma, float* d_Wt,
+                             float* d_bias, float* d_gamma, float* d_beta, void* ws, size_t ws_bytes, int64_t N, int Cin, int dim,
+                             float eps, modet_stream_t stream);
 
 /* SpatialTransformer (models.py:25-67; utils.py:30-83 for mode 1):
  *   out[b,p,c] = sample(src[b,:,c], p + flow[b,p,:]), zero padding, voxel coordinates
@@ -278,6 +287,10 @@ int modet_proj_ln_bwd_pair(const float* x1, const float* d_y1, float* d_x1, cons
  * add_flow=1 (needs C==3): out = warp(src,flow) + flow, the composition of models.py:392,:398,:403,:408. */
 int modet_warp_fwd(const float* src, const float* flow, float* out, int B, int D, int H, int W, int C,
                    int mode, int add_flow, modet_stream_t stream);
+/* trilinear warp whose OUTPUT is stored as bf16 (rounded to nearest even; BASELINE.json configs[4]: the warped moving features
+ * feed only the projection).  C % 4 == 0; fp32 src and flow, fp32 arithmetic. */
+int modet_warp_fwd_o16(const float* src, const float* flow, void* out_bf16, int B, int D, int H, int W, int C,
+                       modet_stream_t stream);
 /* d_src and/or d_flow; either may be NULL.  Trilinear only.
  * flow_bound = 0: arbitrary flow, d_src is zeroed here and scatter-added with float atomics (as ATen does).
  * flow_bound = 1: the CALLER guarantees |flow| <= 1 voxel everywhere (true for the attention output w of

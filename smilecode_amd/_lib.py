@@ -70,7 +70,10 @@ SIGNATURES = {
     "modet_proj_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
     "modet_proj_ln_bwd_pair_ws_bytes": (SZ, [I64, I, I]),
     "modet_proj_ln_bwd_pair": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
+    "modet_proj_ln_fwd_t": (I, [P, I, P, P, P, P, P, I, I64, I, I, F, P]),
+    "modet_proj_ln_bwd_pair_t": (I, [P, I, P, P, P, I, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
     "modet_warp_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
+    "modet_warp_fwd_o16": (I, [P, P, P, I, I, I, I, I, P]),
     "modet_warp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "modet_upsample2_fwd": (I, [P, P, I, I, I, I, I, F, P]),
     "modet_upsample2_bwd": (I, [P, P, I, I, I, I, I, F, P]),

@@ -15,15 +15,30 @@ namespace {
 constexpr int BLK = 256;
 constexpr int MAXW = 48 * 128;
 
-template <int DIM>
-__device__ __forceinline__ void linear_ln(const float* __restrict__ xp, const float* __restrict__ Ws /*[Cin][DIM]*/,
+// bf16 storage of the input / output (BASELINE.json configs[4]): X16 / Y16 = the tensor holds bf16 (channels-last, two per 32-bit
+// word); the values are widened while loaded / rounded to nearest even while stored, every product and sum in between is fp32
+__device__ __forceinline__ float4 ld4x(const float* __restrict__ base, int64_t el, bool x16) {      // 4 consecutive elements from el
+  if (x16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + el);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(base + el);
+}
+__device__ __forceinline__ unsigned short bf16_rne(float v) {
+  const __bf16 b = (__bf16)v;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+template <int DIM, bool X16 = false>
+__device__ __forceinline__ void linear_ln(const float* __restrict__ xbase, int64_t xel, const float* __restrict__ Ws /*[Cin][DIM]*/,
                                           const float* __restrict__ bs, int Cin, float eps, float (&zh)[DIM],
                                           float& rstd) {
   float z[DIM];
 #pragma unroll
   for (int o = 0; o < DIM; ++o) z[o] = bs[o];
   for (int c = 0; c < Cin; c += 4) {
-    const float4 xv = *reinterpret_cast<const float4*>(xp + c);
+    const float4 xv = ld4x(xbase, xel + c, X16);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -56,7 +71,7 @@ __device__ __forceinline__ void stage_w(float* Ws, float* ps, const float* __res
   }
 }
 
-template <int DIM>
+template <int DIM, bool X16 = false, bool Y16 = false>
 __global__ __launch_bounds__(BLK) void proj_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
@@ -68,14 +83,15 @@ __global__ __launch_bounds__(BLK) void proj_ln_fwd_kernel(const float* __restric
   __syncthreads();
   for (int64_t n = (int64_t)blockIdx.x * BLK + threadIdx.x; n < N; n += (int64_t)gridDim.x * BLK) {
     float zh[DIM], rstd;
-    linear_ln<DIM>(x + n * Cin, Ws, ps, Cin, eps, zh, rstd);
+    linear_ln<DIM, X16>(x, n * Cin, Ws, ps, Cin, eps, zh, rstd);
     float* yp = y + n * DIM;
 #pragma unroll
     for (int o = 0; o < DIM; o += 2) {
       float2 v;
       v.x = fmaf(zh[o], ps[DIM + o], ps[2 * DIM + o]);
       v.y = fmaf(zh[o + 1], ps[DIM + o + 1], ps[2 * DIM + o + 1]);
-      *reinterpret_cast<float2*>(yp + o) = v;
+      if constexpr (Y16) reinterpret_cast<unsigned*>(y)[(n * DIM + o) >> 1] = (unsigned)bf16_rne(v.x) | ((unsigned)bf16_rne(v.y) << 16);
+      else *reinterpret_cast<float2*>(yp + o) = v;
     }
   }
 }
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(BLK) void proj_ln_bwd_kernel(const float* __restric
   for (int64_t n = (int64_t)blockIdx.x * BLK + threadIdx.x; n < N; n += (int64_t)gridDim.x * BLK) {
     float zh[DIM], rstd;
     const float* xp = x + n * Cin;
-    linear_ln<DIM>(xp, Ws, ps, Cin, eps, zh, rstd);
+    linear_ln<DIM>(xp, 0, Ws, ps, Cin, eps, zh, rstd);
     float dzh[DIM];
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
@@ -283,14 +299,14 @@ __device__ __forceinline__ void stage_group(float* Ws, float* ps, float* xs, con
 }
 
 // x tile -> LDS (coalesced float4), rows past N zero filled
-template <int DIM, int CIN, int G>
+template <int DIM, int CIN, int G, bool X16 = false>
 __device__ __forceinline__ void load_x_tile(float* xs, const float* __restrict__ x, int64_t n0, int64_t N) {
   using C = ProjCfg<DIM, CIN, G>;
   constexpr int Q = CIN / 4;
   for (int i = threadIdx.x; i < C::VPB * Q; i += BLK) {
     const int v = i / Q, c4 = i - v * Q;
     float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n0 + v < N) val = *reinterpret_cast<const float4*>(x + (n0 + v) * CIN + c4 * 4);
+    if (n0 + v < N) val = ld4x(x, (n0 + v) * CIN + c4 * 4, X16);
     *reinterpret_cast<float4*>(xs + v * C::XS + c4 * 4) = val;
   }
 }
@@ -325,7 +341,7 @@ __device__ __forceinline__ void linear_ln_group(const float* xrow, const float* 
   for (int j = 0; j < C::OS; ++j) zh[j] = (z[j] - mu) * rstd;
 }
 
-template <int DIM, int CIN, int G>
+template <int DIM, int CIN, int G, bool X16 = false, bool Y16 = false>
 __global__ __launch_bounds__(BLK) void proj_ln_fwd_g_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(BLK) void proj_ln_fwd_g_kernel(const float* __restr
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t n0 = t * C::VPB, n = n0 + v;
     __syncthreads();
-    load_x_tile<DIM, CIN, G>(xs, x, n0, N);
+    load_x_tile<DIM, CIN, G, X16>(xs, x, n0, N);
     __syncthreads();
     float zh[C::OS], rstd;
     linear_ln_group<DIM, CIN, G>(xs + v * C::XS, Ws, ps, g, eps, zh, rstd);
@@ -348,13 +364,15 @@ __global__ __launch_bounds__(BLK) void proj_ln_fwd_g_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < C::OS; ++j) {
         const int o = j * G + g;
-        y[n * DIM + o] = fmaf(zh[j], ps[DIM + o], ps[2 * DIM + o]);
+        const float val = fmaf(zh[j], ps[DIM + o], ps[2 * DIM + o]);
+        if constexpr (Y16) reinterpret_cast<unsigned short*>(y)[n * DIM + o] = bf16_rne(val);
+        else y[n * DIM + o] = val;
       }
     }
   }
 }
 
-template <int DIM, int CIN, int G>
+template <int DIM, int CIN, int G, bool X16 = false>
 __global__ __launch_bounds__(BLK) void proj_ln_bwd_g_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
                                                             const float* __restrict__ dy, float* __restrict__ dx,
@@ -381,7 +399,7 @@ __global__ __launch_bounds__(BLK) void proj_ln_bwd_g_kernel(const float* __restr
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t n0 = t * C::VPB, n = n0 + v;
     __syncthreads();                                   // previous tile's MFMA reads of xs / dzs are done
-    load_x_tile<DIM, CIN, G>(xs, x, n0, N);
+    load_x_tile<DIM, CIN, G, X16>(xs, x, n0, N);
     __syncthreads();
     float zh[C::OS], rstd;
     linear_ln_group<DIM, CIN, G>(xs + v * C::XS, Ws, ps, g, eps, zh, rstd);
@@ -530,33 +548,51 @@ inline int reg_cin(int, int) { return 0; }     // generic path: d_z to the works
 
 }  // namespace
 
+namespace {
+template <bool X16, bool Y16>
+int proj_fwd_launch(const float* x, const float* Wt, const float* bias, const float* gamma, const float* beta, float* y, int64_t N,
+                    int Cin, int dim, float eps, hipStream_t s) {
+  const size_t sh = ((size_t)Cin * dim + 3 * dim) * sizeof(float);
+  const int grid = flat_grid(N, BLK);
+  const int G = group_of(Cin, dim);
+  if (G > 1) {          // levels 3-5: several lanes per voxel
+    const int gg = group_grid(N, G);
+    if (G == 4) hipLaunchKernelGGL((proj_ln_fwd_g_kernel<12, 32, 4, X16, Y16>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, beta, y, N, eps);
+    else if (G == 8) hipLaunchKernelGGL((proj_ln_fwd_g_kernel<24, 64, 8, X16, Y16>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, beta, y, N, eps);
+    else hipLaunchKernelGGL((proj_ln_fwd_g_kernel<48, 128, 16, X16, Y16>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, beta, y, N, eps);
+    return modet_launch_status();
+  }
+  switch (dim) {
+    case 6:  hipLaunchKernelGGL((proj_ln_fwd_kernel<6, X16, Y16>),  dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
+    case 12: hipLaunchKernelGGL((proj_ln_fwd_kernel<12, X16, Y16>), dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
+    case 24: hipLaunchKernelGGL((proj_ln_fwd_kernel<24, X16, Y16>), dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
+    case 48: hipLaunchKernelGGL((proj_ln_fwd_kernel<48, X16, Y16>), dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
+    default: return MODET_ERR_UNSUPPORTED;
+  }
+  return modet_launch_status();
+}
+}  // namespace
+
 extern "C" {
 
-int modet_proj_ln_fwd(const float* x, const float* Wt, const float* bias, const float* gamma, const float* beta,
-                      float* y, int64_t N, int Cin, int dim, float eps, modet_stream_t stream) {
+int modet_proj_ln_fwd_t(const void* x, int x_bf16, const float* Wt, const float* bias, const float* gamma, const float* beta,
+                        void* y, int y_bf16, int64_t N, int Cin, int dim, float eps, modet_stream_t stream) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(Wt); MODET_CHECK_PTR(bias); MODET_CHECK_PTR(gamma); MODET_CHECK_PTR(beta);
   MODET_CHECK_PTR(y);
   MODET_CHECK_DIM(N > 0 && Cin > 0 && dim > 0);
   if (Cin % 4 != 0 || Cin > 128) return MODET_ERR_UNSUPPORTED;
-  const size_t sh = ((size_t)Cin * dim + 3 * dim) * sizeof(float);
-  const int grid = flat_grid(N, BLK);
   hipStream_t s = (hipStream_t)stream;
-  const int G = group_of(Cin, dim);
-  if (G > 1) {          // levels 3-5: several lanes per voxel
-    const int gg = group_grid(N, G);
-    if (G == 4) hipLaunchKernelGGL((proj_ln_fwd_g_kernel<12, 32, 4>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, beta, y, N, eps);
-    else if (G == 8) hipLaunchKernelGGL((proj_ln_fwd_g_kernel<24, 64, 8>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, beta, y, N, eps);
-    else hipLaunchKernelGGL((proj_ln_fwd_g_kernel<48, 128, 16>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, beta, y, N, eps);
-    return modet_launch_status();
-  }
-  switch (dim) {
-    case 6:  hipLaunchKernelGGL(proj_ln_fwd_kernel<6>,  dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
-    case 12: hipLaunchKernelGGL(proj_ln_fwd_kernel<12>, dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
-    case 24: hipLaunchKernelGGL(proj_ln_fwd_kernel<24>, dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
-    case 48: hipLaunchKernelGGL(proj_ln_fwd_kernel<48>, dim3(grid), dim3(BLK), sh, s, x, Wt, bias, gamma, beta, y, N, Cin, eps); break;
-    default: return MODET_ERR_UNSUPPORTED;
-  }
-  return modet_launch_status();
+  const float* xf = (const float*)x;
+  float* yf = (float*)y;
+  if (x_bf16 && y_bf16) return proj_fwd_launch<true, true>(xf, Wt, bias, gamma, beta, yf, N, Cin, dim, eps, s);
+  if (x_bf16) return proj_fwd_launch<true, false>(xf, Wt, bias, gamma, beta, yf, N, Cin, dim, eps, s);
+  if (y_bf16) return proj_fwd_launch<false, true>(xf, Wt, bias, gamma, beta, yf, N, Cin, dim, eps, s);
+  return proj_fwd_launch<false, false>(xf, Wt, bias, gamma, beta, yf, N, Cin, dim, eps, s);
+}
+
+int modet_proj_ln_fwd(const float* x, const float* Wt, const float* bias, const float* gamma, const float* beta,
+                      float* y, int64_t N, int Cin, int dim, float eps, modet_stream_t stream) {
+  return modet_proj_ln_fwd_t(x, 0, Wt, bias, gamma, beta, y, 0, N, Cin, dim, eps, stream);
 }
 
 size_t modet_proj_ln_bwd_ws_bytes(int64_t N, int Cin, int dim) {
@@ -580,6 +616,16 @@ int modet_proj_ln_bwd_pair(const float* x1, const float* d_y1, float* d_x1, cons
                            const float* Wt, const float* bias, const float* gamma, float* d_Wt, float* d_bias,
                            float* d_gamma, float* d_beta, void* ws, size_t ws_bytes, int64_t N, int Cin, int dim, float eps,
                            modet_stream_t stream) {
+  return modet_proj_ln_bwd_pair_t(x1, 0, d_y1, d_x1, x2, 0, d_y2, d_x2, Wt, bias, gamma, d_Wt, d_bias, d_gamma, d_beta, ws, ws_bytes, N,
+                                  Cin, dim, eps, stream);
+}
+
+int modet_proj_ln_bwd_pair_t(const void* x1v, int x1_bf16, const float* d_y1, float* d_x1, const void* x2v, int x2_bf16,
+                             const float* d_y2, float* d_x2, const float* Wt, const float* bias, const float* gamma, float* d_Wt,
+                             float* d_bias, float* d_gamma, float* d_beta, void* ws, size_t ws_bytes, int64_t N, int Cin, int dim,
+                             float eps, modet_stream_t stream) {
+  const float* x1 = (const float*)x1v;
+  const float* x2 = (const float*)x2v;
   MODET_CHECK_PTR(x1); MODET_CHECK_PTR(d_y1); MODET_CHECK_PTR(d_x1); MODET_CHECK_PTR(x2); MODET_CHECK_PTR(d_y2);
   MODET_CHECK_PTR(d_x2); MODET_CHECK_PTR(Wt); MODET_CHECK_PTR(bias); MODET_CHECK_PTR(gamma); MODET_CHECK_PTR(d_Wt);
   MODET_CHECK_PTR(d_bias); MODET_CHECK_PTR(d_gamma); MODET_CHECK_PTR(d_beta); MODET_CHECK_PTR(ws);
@@ -595,8 +641,14 @@ int modet_proj_ln_bwd_pair(const float* x1, const float* d_y1, float* d_x1, cons
     const float* d_y = u ? d_y2 : d_y1;
     float* d_x = u ? d_x2 : d_x1;
     float* part = gpart + (size_t)u * gg * row;
-#define LAUNCH_G(D_, C_, G_) hipLaunchKernelGGL((proj_ln_bwd_g_kernel<D_, C_, G_>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, \
-                                                d_y, d_x, part, N, eps)
+    const bool x16 = (u ? x2_bf16 : x1_bf16) != 0;
+#define LAUNCH_G(D_, C_, G_)                                                                                                      \
+    do {                                                                                                                          \
+      if (x16) hipLaunchKernelGGL((proj_ln_bwd_g_kernel<D_, C_, G_, true>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, d_y, d_x, \
+                                  part, N, eps);                                                                                 \
+      else hipLaunchKernelGGL((proj_ln_bwd_g_kernel<D_, C_, G_, false>), dim3(gg), dim3(BLK), 0, s, x, Wt, bias, gamma, d_y, d_x,  \
+                              part, N, eps);                                                                                     \
+    } while (0)
     if (G == 1 && Cin == 8) LAUNCH_G(6, 8, 1);
     else if (G == 1) LAUNCH_G(6, 16, 1);
     else if (G == 4) LAUNCH_G(12, 32, 4);

@@ -48,7 +48,8 @@ __device__ __forceinline__ Tri tri_setup(float z, float y, float x) {
 }
 
 // ------------------------------------------------------------------------------------------------ warp fwd
-template <int CPT>
+// O16 (BASELINE.json configs[4], bf16 storage of the warped features; CPT = 4): the output is rounded to bf16 (nearest even)
+template <int CPT, bool O16 = false>
 __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                        float* __restrict__ out, int D, int H, int W, int C, int G,
                                                        int64_t total, int mode, int add_flow) {
@@ -110,7 +111,14 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
     if (add_flow) {                            // C == 3, CPT == 3, G == 1
       if constexpr (CPT == 3) { acc[0] += f0; acc[1] += f1; acc[2] += f2; }
     }
-    stv<CPT>(out + n * C + g * CPT, acc);
+    if constexpr (O16 && CPT == 4) {
+      const __bf16 b0 = (__bf16)acc[0], b1 = (__bf16)acc[1], b2 = (__bf16)acc[2], b3 = (__bf16)acc[3];
+      const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+      const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + n * C + g * CPT) = make_uint2(lo, hi);
+    } else {
+      stv<CPT>(out + n * C + g * CPT, acc);
+    }
   }
 }
 
@@ -990,6 +998,19 @@ int modet_warp_bwd(const float* src, const float* flow, const float* d_out, floa
   const int64_t total = (int64_t)B * cdiv(D, ZRUN) * H * W * G;       // one item per (z run, y, x, channel slot)
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow, D,
                      H, W, C, G, total, add_flow);
+  return modet_launch_status();
+}
+
+int modet_warp_fwd_o16(const float* src, const float* flow, void* out_bf16, int B, int D, int H, int W, int C,
+                       modet_stream_t stream) {
+  MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(out_bf16);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
+  if (C % 4 != 0) return MODET_ERR_UNSUPPORTED;
+  const int G = C / 4;
+  const int64_t total = (int64_t)B * D * H * W * G;
+  if (total >= ((int64_t)1 << 31) - (int64_t)256 * 16 * BLK) return MODET_ERR_UNSUPPORTED;     // 32-bit item index
+  hipLaunchKernelGGL((warp_fwd_kernel<4, true>), dim3(flat_grid(total, BLK)), dim3(BLK), 0, (hipStream_t)stream, src, flow,
+                     (float*)out_bf16, D, H, W, C, G, total, 0, 0);
   return modet_launch_status();
 }
 

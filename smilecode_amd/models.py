@@ -366,7 +366,9 @@ class ModeT(nn.Module):
                  scale=None, legacy_grid_buffers=False, act_dtype=torch.float32, fused_attention=True):
         """``act_dtype=torch.bfloat16`` (not in the reference, BASELINE.json configs[4]): the encoder's ConvInsBlock chains
         store their activations in bf16 and run on the bf16 matrix pipe with fp32 accumulation; parameters, statistics,
-        level features, flows, losses and the optimizer stay fp32, so checkpoints are unchanged.
+        level features, flows, losses and the optimizer stay fp32, so checkpoints are unchanged; each level's warped moving
+        features and its q / k projections -- tensors only the level's own matching step reads -- are stored as bf16 too
+        (one autograd node per level, ops.level_attention_bf16).
         ``fused_attention=False``: every ModeTransformer runs the reference ModeT-cu decomposition through the operator
         boundary ``modetqkrpb_cu`` (see ModeTransformer.forward_operator); every level dim must then be >= 3, as the
         reference's CHECK_3DFEATMAP demands (utils.h:10)."""
@@ -375,6 +377,9 @@ class ModeT(nn.Module):
         if act_dtype not in (torch.float32, torch.bfloat16):
             raise RuntimeError("ModeT: act_dtype must be torch.float32 or torch.bfloat16")
         self.act_dtype = act_dtype
+        # bf16 storage of every level's warped features, q and k (ops.level_attention_bf16): head_dim 6 and the model's channel
+        # counts only (the kernels the fused node runs), with the fused attention
+        self.level_bf16 = (act_dtype == torch.bfloat16 and fused_attention and head_dim == 6 and channels == 4)
         # like the reference's constructor (models.py:338-375) any inshape is accepted here; shapes that four 2x poolings
         # do not divide fail in forward(), where the reference fails too (its x2-upsampled flow no longer matches the
         # next level's grid: "The size of tensor a must match the size of tensor b")
@@ -427,33 +432,34 @@ class ModeT(nn.Module):
             self.cut_leaves = (M, Fx)
         ST = self.transformer
 
+        def match(lvl, proj, mdt, st, flow):
+            """the level's matching step: attention(proj(F), proj(warp(M, flow))) -> expected offset field.  bf16 storage mode
+            (act_dtype=bfloat16, fused attention): one node whose warped features, q and k are bf16 in HBM"""
+            if self.level_bf16 and mdt.fused and mdt.use_rpb:
+                return ops.level_attention_bf16(Fx[lvl], M[lvl], flow, proj.proj.weight, proj.proj.bias, proj.norm.weight,
+                                                proj.norm.bias, mdt.rpb, mdt.num_heads, mdt.scale)
+            Mw = M[lvl] if flow is None else st.forward_cl(M[lvl], flow)
+            q, k = proj.forward_pair(Fx[lvl], Mw)
+            return mdt(q, k)
+
         with ops.trace_range("level5"):
-            q5, k5 = self.projblock5.forward_pair(Fx[4], M[4])
-            flow = self.cwm5(self.mdt5(q5, k5))
+            flow = self.cwm5(match(4, self.projblock5, self.mdt5, None, None))
 
         with ops.trace_range("level4"):
-            M4 = ST[3].forward_cl(M[3], flow)
-            q4, k4 = self.projblock4.forward_pair(Fx[3], M4)
-            w = self.cwm4(self.mdt4(q4, k4))
+            w = self.cwm4(match(3, self.projblock4, self.mdt4, ST[3], flow))
             flow = ST[2].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
         with ops.trace_range("level3"):
-            M3 = ST[2].forward_cl(M[2], flow)
-            q3, k3 = self.projblock3.forward_pair(Fx[2], M3)
-            w = self.cwm3(self.mdt3(q3, k3))
+            w = self.cwm3(match(2, self.projblock3, self.mdt3, ST[2], flow))
             flow = ST[1].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
         with ops.trace_range("level2"):
-            M2 = ST[1].forward_cl(M[1], flow)
-            q2, k2 = self.projblock2.forward_pair(Fx[1], M2)
-            w = self.mdt2(q2, k2)
+            w = match(1, self.projblock2, self.mdt2, ST[1], flow)
             # w comes straight from the attention (expected offset in [-1,1]^3): bounded-flow backward, no atomics
             flow = ops.upsample2(ST[1].forward_cl(flow, w, add_flow=True, flow_bound=1), 2.0)
 
         with ops.trace_range("level1"):
-            M1 = ST[0].forward_cl(M[0], flow)
-            q1, k1 = self.projblock1.forward_pair(Fx[0], M1)
-            w = self.mdt1(q1, k1)
+            w = match(0, self.projblock1, self.mdt1, ST[0], flow)
             flow = ST[0].forward_cl(flow, w, add_flow=True, flow_bound=1)
             y_moved = ST[0].forward_cl(mov_cl, flow)
         return ops.to_ncdhw(y_moved), ops.to_ncdhw(flow)

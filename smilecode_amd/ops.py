@@ -981,6 +981,96 @@ class _NA(Function):
         return dq, dk, drpb, None, None
 
 
+class _LevelAttnBF16(Function):
+    """One pyramid level's matching step with bf16 STORAGE of its internal tensors (BASELINE.json configs[4]):
+        Mw = warp(M, flow) (or M itself at the coarsest level)  ->  q = proj_ln(F), k = proj_ln(Mw)  ->  out = NA(q, k, rpb)
+    as ONE autograd node, so that Mw, q and k -- which no other op reads -- live in HBM as bf16 and never cross an autograd edge
+    (autograd would cast fp32 gradients arriving at a bf16 tensor; here every gradient stays fp32).  All arithmetic is the fp32
+    kernels': a bf16 input is widened on load, a bf16 output rounded to nearest even on store
+    (modet_warp_fwd_o16, modet_proj_ln_fwd_t, modet_na_fwd_t / _bwd_t, modet_proj_ln_bwd_pair_t).
+    reference: ModeT/models.py:371-376 (projection + attention of a level), :55-67 (the warp in front of it)."""
+
+    @staticmethod
+    def forward(ctx, F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps):
+        _chk(F, M, Wt, b, gamma, beta, rpb)
+        B, D, H, W, Cin = F.shape
+        dim = Wt.shape[0]
+        N = B * D * H * W
+        L = _L()
+        n = float(N)
+        if flow is not None:
+            _chk(flow)
+            Mw = torch.empty(M.shape, dtype=torch.bfloat16, device=M.device)
+            with _Guard(M, f"warp_fwd[C{Cin}]", n * (24.0 * Cin + 30.0), n * (6.0 * Cin + 12.0)):
+                _lib.check(L.modet_warp_fwd_o16(_p(M), _p(flow), _p(Mw), B, D, H, W, Cin, _stream()), "modet_warp_fwd_o16")
+        else:
+            Mw = M
+        q = torch.empty((B, D, H, W, dim), dtype=torch.bfloat16, device=F.device)
+        k = torch.empty_like(q)
+        for x, y in ((F, q), (Mw, k)):
+            x16 = int(x.dtype == torch.bfloat16)
+            with _Guard(F, f"proj_ln_fwd[{Cin}->{dim}]", n * (2.0 * Cin * dim + 8.0 * dim), n * ((2.0 if x16 else 4.0) * Cin + 2.0 * dim)):
+                _lib.check(L.modet_proj_ln_fwd_t(_p(x), x16, _p(Wt), _p(b), _p(gamma), _p(beta), _p(y), 1, N, Cin, dim, eps, _stream()),
+                           "modet_proj_ln_fwd_t")
+        out = torch.empty((B, D, H, W, heads * 3), dtype=torch.float32, device=F.device)
+        need_grad = any(ctx.needs_input_grad)
+        lse = torch.empty((B, D, H, W, heads), dtype=torch.float32, device=F.device) if need_grad else None
+        nvh = n * heads
+        with _Guard(F, f"na_fwd[h{heads}]", 620.0 * nvh, 36.0 * nvh):
+            _lib.check(L.modet_na_fwd_t(_p(q), _p(k), 1, _p(rpb), _p(out), _p(lse), B, D, H, W, heads, dim // heads, float(scale),
+                                        _stream()), "modet_na_fwd_t")
+        if need_grad:
+            ctx.save_for_backward(F, M, flow, Mw if flow is not None else None, q, k, Wt, b, gamma, rpb, out, lse)
+        ctx.heads, ctx.scale, ctx.eps = heads, float(scale), eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        F, M, flow, Mw, q, k, Wt, b, gamma, rpb, out, lse = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, D, H, W, Cin = F.shape
+        dim = Wt.shape[0]
+        heads = ctx.heads
+        N = B * D * H * W
+        n = float(N)
+        L = _L()
+        dq = torch.empty((B, D, H, W, dim), dtype=torch.float32, device=F.device)
+        dk, drpb = torch.empty_like(dq), torch.empty_like(rpb)
+        nb = L.modet_na_bwd_ws_bytes(B, D, H, W, heads)
+        ws = _ws(nb, F)
+        nvh = n * heads
+        with _Guard(F, f"na_bwd[h{heads}]", 1900.0 * nvh, 100.0 * nvh):
+            _lib.check(L.modet_na_bwd_t(_p(q), _p(k), 1, _p(rpb), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(drpb), _p(ws), nb, B, D,
+                                        H, W, heads, dim // heads, ctx.scale, _stream()), "modet_na_bwd_t")
+        x2 = Mw if flow is not None else M
+        dF = torch.empty_like(F)
+        dMw = torch.empty(M.shape, dtype=torch.float32, device=M.device)
+        dW, db, dg, dbeta = torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma), torch.empty_like(gamma)
+        nb2 = L.modet_proj_ln_bwd_pair_ws_bytes(N, Cin, dim)
+        if nb2 == 0:
+            raise RuntimeError(f"level attention (bf16): no paired projection backward for Cin {Cin}, dim {dim}")
+        ws2 = _ws(nb2, F)
+        with _Guard(F, f"proj_ln_bwd[{Cin}->{dim}]", 2 * n * (6.0 * Cin * dim + 20.0 * dim), n * (14.0 * Cin + 8.0 * dim)):
+            _lib.check(L.modet_proj_ln_bwd_pair_t(_p(F), 0, _p(dq), _p(dF), _p(x2), int(x2.dtype == torch.bfloat16), _p(dk), _p(dMw),
+                                                  _p(Wt), _p(b), _p(gamma), _p(dW), _p(db), _p(dg), _p(dbeta), _p(ws2), nb2, N, Cin, dim,
+                                                  ctx.eps, _stream()), "modet_proj_ln_bwd_pair_t")
+        if flow is None:
+            return dF, dMw, None, dW, db, dg, dbeta, drpb, None, None, None
+        dM = torch.empty_like(M) if ctx.needs_input_grad[1] else None
+        dflow = torch.empty_like(flow) if ctx.needs_input_grad[2] else None
+        if dM is not None or dflow is not None:
+            with _Guard(M, f"warp_bwd[C{Cin}]", n * (60.0 * Cin + 40.0), 4.0 * n * (3 * Cin + 6)):
+                _lib.check(L.modet_warp_bwd(_p(M), _p(flow), _p(dMw), _p(dM), _p(dflow), B, D, H, W, Cin, 0, 0, _stream()),
+                           "modet_warp_bwd")
+        return dF, dM, dflow, dW, db, dg, dbeta, drpb, None, None, None
+
+
+def level_attention_bf16(F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps=1e-5):
+    """NA(proj_ln(F), proj_ln(warp(M, flow))) with the warped features, q and k stored as bf16 (flow None: no warp); see
+    _LevelAttnBF16.  Returns the expected offset (B, D, H, W, heads * 3), fp32."""
+    return _LevelAttnBF16.apply(F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps)
+
+
 class _Corr3d(Function):
     @staticmethod
     def forward(ctx, mov, fix):

@@ -457,3 +457,104 @@ def test_attention_with_bf16_q_k_is_the_fp32_kernel_on_widened_operands(shape, h
         res.append((out, lse, dq, dk, dr))
     for name, a, b in zip(("out", "lse", "d_q", "d_k", "d_rpb"), res[0], res[1]):
         assert torch.equal(a, b), f"bf16 q / k: {name} differs from the fp32 kernel on the widened operands"
+
+
+@pytest.mark.parametrize("Cin,dim,N", [(8, 6, 70001), (16, 6, 33333), (32, 12, 9001), (64, 24, 4097), (128, 48, 1200)])
+def test_projection_with_bf16_input_and_output_is_the_fp32_kernel_on_widened_operands(Cin, dim, N):
+    """modet_proj_ln_fwd_t / modet_proj_ln_bwd_pair_t (cfg 5 storage of the warped features and of q / k): a bf16 input gives
+    results BIT-IDENTICAL to the fp32 entry points fed with the widened values; a bf16 output is the fp32 output rounded to
+    nearest even -- every (Cin, dim) of the model, ragged N."""
+    from smilecode_amd import _lib
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(Cin + dim)
+    x16 = torch.randn((N, Cin), device="cuda", generator=g).bfloat16()
+    x32 = x16.float()
+    xo = torch.randn((N, Cin), device="cuda", generator=g)                # the pair's other (fp32) input
+    Wt = torch.randn((dim, Cin), device="cuda", generator=g) * 0.3
+    b, gam, bet = (torch.randn(dim, device="cuda", generator=g) for _ in range(3))
+    P = lambda t: t.data_ptr()
+    y32 = torch.empty((N, dim), device="cuda")
+    _lib.check(L.modet_proj_ln_fwd_t(P(x32), 0, P(Wt), P(b), P(gam), P(bet), P(y32), 0, N, Cin, dim, 1e-5, st), "fwd")
+    ya = torch.empty_like(y32)
+    _lib.check(L.modet_proj_ln_fwd_t(P(x16), 1, P(Wt), P(b), P(gam), P(bet), P(ya), 0, N, Cin, dim, 1e-5, st), "fwd x16")
+    assert torch.equal(ya, y32), "bf16 input: forward differs from the fp32 kernel on the widened input"
+    yb = torch.empty((N, dim), device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.modet_proj_ln_fwd_t(P(x16), 1, P(Wt), P(b), P(gam), P(bet), P(yb), 1, N, Cin, dim, 1e-5, st), "fwd x16 y16")
+    # (another template instantiation: the compiler may contract the LayerNorm's multiply-adds differently, so the fp32 value
+    #  in front of the rounding can differ in its last bit -- one bf16 ulp at a rounding tie, never more)
+    ulp = torch.maximum(y32.abs(), torch.full_like(y32, 1e-30)) * 2.0 ** -7
+    assert bool(((yb.float() - y32).abs() <= ulp).all()), "bf16 output is not the fp32 output rounded"
+    assert float((yb != y32.bfloat16()).float().mean()) < 1e-3
+    yc = torch.empty((N, dim), device="cuda", dtype=torch.bfloat16)
+    _lib.check(L.modet_proj_ln_fwd_t(P(x32), 0, P(Wt), P(b), P(gam), P(bet), P(yc), 1, N, Cin, dim, 1e-5, st), "fwd y16")
+    assert float((yc != yb).float().mean()) < 1e-3
+    # backward pair: (fp32 x1, bf16 x2) against (fp32 x1, widened x2)
+    dy1, dy2 = torch.randn((N, dim), device="cuda", generator=g), torch.randn((N, dim), device="cuda", generator=g)
+    nb = L.modet_proj_ln_bwd_pair_ws_bytes(N, Cin, dim)
+    res = []
+    for x2, bf in ((x32, 0), (x16, 1)):
+        ws = torch.empty(nb // 4 + 4, device="cuda")
+        dx1, dx2 = torch.empty((N, Cin), device="cuda"), torch.empty((N, Cin), device="cuda")
+        dW, db, dg, dbe = torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
+        _lib.check(L.modet_proj_ln_bwd_pair_t(P(xo), 0, P(dy1), P(dx1), P(x2), bf, P(dy2), P(dx2), P(Wt), P(b), P(gam), P(dW), P(db),
+                                              P(dg), P(dbe), P(ws), nb, N, Cin, dim, 1e-5, st), "bwd pair")
+        res.append((dx1, dx2, dW, db, dg, dbe))
+    for name, a_, b_ in zip(("d_x1", "d_x2", "d_W", "d_bias", "d_gamma", "d_beta"), res[0], res[1]):
+        assert torch.equal(a_, b_), f"bf16 x2: {name} differs from the fp32 kernel on the widened input"
+
+
+def test_warp_forward_with_bf16_output_is_the_fp32_output_rounded():
+    """modet_warp_fwd_o16 (cfg 5: the warped moving features are stored as bf16): the fp32 kernel's result rounded to nearest even"""
+    from smilecode_amd import _lib
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for (B, D, H, W, C) in ((1, 9, 14, 21, 8), (2, 8, 12, 20, 16), (1, 5, 6, 7, 64)):
+        g = torch.Generator(device="cuda").manual_seed(C)
+        src = torch.randn((B, D, H, W, C), device="cuda", generator=g)
+        flow = torch.randn((B, D, H, W, 3), device="cuda", generator=g) * 3.0
+        o32 = torch.empty_like(src)
+        o16 = torch.empty(src.shape, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.modet_warp_fwd(src.data_ptr(), flow.data_ptr(), o32.data_ptr(), B, D, H, W, C, 0, 0, st), "warp_fwd")
+        _lib.check(L.modet_warp_fwd_o16(src.data_ptr(), flow.data_ptr(), o16.data_ptr(), B, D, H, W, C, st), "warp_fwd_o16")
+        assert torch.equal(o16, o32.bfloat16())
+
+
+def test_level_attention_bf16_node_matches_the_unfused_ops_on_rounded_tensors():
+    """ops.level_attention_bf16 (warp -> projection pair -> attention with bf16 storage in between, one autograd node) against the
+    same chain built from the fp32 ops with the intermediate tensors rounded by hand: identical forward, gradients equal to the
+    fp32 ops' gradients evaluated at the rounded tensors (straight-through rounding)."""
+    from smilecode_amd import ops
+
+    class _Round(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.bfloat16().float()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, D, H, W, Cin, heads = 1, 12, 16, 20, 16, 1
+    dim = 6 * heads
+    mk = lambda *sh, s=1.0: (torch.randn(sh, device="cuda", generator=g) * s)
+    F0, M0, fl0 = mk(B, D, H, W, Cin), mk(B, D, H, W, Cin), mk(B, D, H, W, 3, s=2.0)
+    Wt0, b0, ga0, be0, rpb0 = mk(dim, Cin, s=0.3), mk(dim), mk(dim), mk(dim), mk(heads, 3, 3, 3)
+    gout = mk(B, D, H, W, heads * 3)
+    res = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (F0, M0, fl0, Wt0, b0, ga0, be0, rpb0)]
+        F, M, fl, Wt, b, ga, be, rpb = leaves
+        if fused:
+            out = ops.level_attention_bf16(F, M, fl, Wt, b, ga, be, rpb, heads, 0.7)
+        else:
+            Mw = _Round.apply(ops.warp(M, fl))
+            q, k = ops.proj_ln_pair(F, Mw, Wt, b, ga, be)
+            out = ops.neighbourhood_attention(_Round.apply(q), _Round.apply(k), rpb, heads, 0.7)
+        res.append((out.detach(), torch.autograd.grad(out, leaves, gout)))
+    assert torch.equal(res[0][0], res[1][0]), "forward of the fused bf16 level node differs"
+    for name, a, b_ in zip(("d_F", "d_M", "d_flow", "d_W", "d_b", "d_gamma", "d_beta", "d_rpb"), res[0][1], res[1][1]):
+        # (d_M / d_flow pass through the warp backward's float atomics: order-dependent rounding)
+        tol = 1e-5 * float(b_.abs().max()) if name in ("d_M", "d_flow") else 0.0
+        assert float((a - b_).abs().max()) <= tol, f"{name} of the fused bf16 level node differs"
