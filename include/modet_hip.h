@@ -242,6 +242,8 @@ int modet_instnorm_lrelu_bwd_pool(const float* g_pooled, const float* add_a, con
 int modet_lrelu_bwd(const float* d_y, const float* y, float* d_x, int64_t n, modet_stream_t stream);
 /* AvgPool3d(2) (models.py:201,:207,:213,:219); D,H,W are the INPUT dims (even). */
 int modet_avgpool2_fwd(const float* x, float* y, int B, int D, int H, int W, int C, modet_stream_t stream);
+/* the same pooling of a bf16 tensor into an fp32 one (BASELINE.json configs[4]) */
+int modet_avgpool2_fwd_x16(const void* x_bf16, float* y, int B, int D, int H, int W, int C, modet_stream_t stream);
 /* The apply pass of InstanceNorm + LeakyReLU (mean / rstd from modet_instnorm_stats) fused with the AvgPool3d(2) that follows
  * the last ConvInsBlock of an encoder level (models.py:186-219): y = LeakyReLU((x - mean) * rstd) (B,D,H,W,C) and
  * pooled = AvgPool3d(2)(y) (B,D/2,H/2,W/2,C) in one pass over x; bit-identical to modet_instnorm_lrelu_fwd* followed by
@@ -291,6 +293,13 @@ int modet_warp_fwd(const float* src, const float* flow, float* out, int B, int D
  * feed only the projection).  C % 4 == 0; fp32 src and flow, fp32 arithmetic. */
 int modet_warp_fwd_o16(const float* src, const float* flow, void* out_bf16, int B, int D, int H, int W, int C,
                        modet_stream_t stream);
+/* typed forms (BASELINE.json configs[4]): src_bf16 / out_bf16 != 0 = that tensor holds bf16 (widened on load / rounded to nearest
+ * even on store; fp32 arithmetic, fp32 gradients).  Plain trilinear warps only (no add_flow, no flow bound); C % 4 == 0 for the
+ * forward.  A bf16 src gives results bit-identical to the fp32 entry point fed with the widened values. */
+int modet_warp_fwd_t(const void* src, int src_bf16, const float* flow, void* out, int out_bf16, int B, int D, int H, int W, int C,
+                     modet_stream_t stream);
+int modet_warp_bwd_t(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow, int B,
+                     int D, int H, int W, int C, int add_flow, int flow_bound, modet_stream_t stream);
 /* d_src and/or d_flow; either may be NULL.  Trilinear only.
  * flow_bound = 0: arbitrary flow, d_src is zeroed here and scatter-added with float atomics (as ATen does).
  * flow_bound = 1: the CALLER guarantees |flow| <= 1 voxel everywhere (true for the attention output w of
@@ -398,6 +407,10 @@ int modet_conv3d_bf16_bwd_weight_defer(const void* x, int x_bf16, const void* d_
 size_t modet_instnorm_bf16_ws_bytes(int B, int64_t V, int C);
 int modet_instnorm_lrelu_fwd_stats_bf16(const void* x, void* y, int y_bf16, float* mean, float* rstd, const float* stats,
                                         size_t stats_bytes, int B, int64_t V, int C, float eps, modet_stream_t stream);
+/* modet_instnorm_lrelu_fwd_stats_bf16 with a bf16 output AND the AvgPool3d(2) of the output's fp32 values (before the rounding)
+ * in the same pass: a level's output block whose features are stored as bf16.  pooled: (B, D/2, H/2, W/2, C) fp32. */
+int modet_instnorm_lrelu_fwd_stats_pool_bf16(const void* x, void* y_bf16, float* pooled, float* mean, float* rstd, const float* stats,
+                                             size_t stats_bytes, int B, int D, int H, int W, int C, float eps, modet_stream_t stream);
 int modet_instnorm_lrelu_bwd_bf16(const void* d_y, int dy_bf16, const void* x, const float* mean, const float* rstd,
                                   void* d_x, void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream);
 /* modet_instnorm_lrelu_bwd_pool (above) for the bf16 chain: the gradient of a level's OUTPUT block,

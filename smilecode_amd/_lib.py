@@ -62,6 +62,7 @@ SIGNATURES = {
     "modet_instnorm_lrelu_bwd": (I, [P, P, P, P, P, P, SZ, I, I64, I, P]),
     "modet_lrelu_bwd": (I, [P, P, P, I64, P]),
     "modet_avgpool2_fwd": (I, [P, P, I, I, I, I, I, P]),
+    "modet_avgpool2_fwd_x16": (I, [P, P, I, I, I, I, I, P]),
     "modet_instnorm_lrelu_apply_pool": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "modet_instnorm_lrelu_bwd_pool": (I, [P, P, P, I, P, P, P, P, P, SZ, I, I, I, I, I, P]),
     "modet_avgpool2_bwd": (I, [P, P, P, I, I, I, I, I, P]),
@@ -74,6 +75,8 @@ SIGNATURES = {
     "modet_proj_ln_bwd_pair_t": (I, [P, I, P, P, P, I, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
     "modet_warp_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "modet_warp_fwd_o16": (I, [P, P, P, I, I, I, I, I, P]),
+    "modet_warp_fwd_t": (I, [P, I, P, P, I, I, I, I, I, I, P]),
+    "modet_warp_bwd_t": (I, [P, I, P, P, P, P, I, I, I, I, I, I, I, P]),
     "modet_warp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "modet_upsample2_fwd": (I, [P, P, I, I, I, I, I, F, P]),
     "modet_upsample2_bwd": (I, [P, P, I, I, I, I, I, F, P]),
@@ -109,6 +112,7 @@ SIGNATURES = {
     "modet_instnorm_lrelu_fwd_stats_bf16": (I, [P, P, I, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_bwd_bf16": (I, [P, I, P, P, P, P, P, SZ, I, I64, I, P]),
     "modet_instnorm_lrelu_bwd_pool_bf16": (I, [P, P, P, I, P, P, P, P, P, SZ, I, I, I, I, I, P]),
+    "modet_instnorm_lrelu_fwd_stats_pool_bf16": (I, [P, P, P, P, P, P, SZ, I, I, I, I, I, F, P]),
     "modet_cast_bf16": (I, [P, P, I64, I, P]),
 }
 

@@ -374,6 +374,7 @@ __global__ __launch_bounds__(BLK) void scale_kernel(const float* __restrict__ x,
 }
 
 // ---- AvgPool3d(2): (B,D,H,W,C) -> (B,D/2,H/2,W/2,C), float4 channel groups
+template <bool X16>                                  // X16: x holds bf16 (widened on load), y is fp32 either way
 __global__ __launch_bounds__(BLK) void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int D,
                                                            int H, int W, int C, int64_t total4) {
   const int G = C >> 2, d = D / 2, h = H / 2, w = W / 2;
@@ -404,7 +405,14 @@ __global__ __launch_bounds__(BLK) void avgpool2_fwd_kernel(const float* __restri
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
           const int64_t off = (((b * D + 2 * zo + dz) * H + 2 * yo + dy) * W + 2 * xo + dx) * C + g * 4;
-          const float4 v = *reinterpret_cast<const float4*>(x + off);
+          float4 v;
+          if constexpr (X16) {
+            const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + off);
+            v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                            __uint_as_float(u.y & 0xffff0000u));
+          } else {
+            v = *reinterpret_cast<const float4*>(x + off);
+          }
           s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     s.x *= 0.125f; s.y *= 0.125f; s.z *= 0.125f; s.w *= 0.125f;
@@ -629,6 +637,63 @@ __global__ __launch_bounds__(BLK) void in_apply_bf16_kernel(const void* __restri
     for (int u = 0; u < IN_ILP; ++u) one(i + u * stride, rx[u]);
   }
   for (; i < total8; i += stride) one(i, load8_raw<true>(x, i));
+}
+
+// in_apply_bf16_kernel<true> + AvgPool3d(2) in one pass (BASELINE.json configs[4], a level's output block whose features are stored
+// as bf16): thread = (pooled voxel, 8 channels) reads its 2x2x2 raw voxels (all eight 16-byte loads in flight), writes the eight
+// normalised voxels as bf16 and their mean -- formed from the fp32 values IN FRONT of the rounding -- as fp32: pooling the
+// rounded features instead was measured to cost the gradient (relative L2 0.12 -> 0.19 at 64^3, tools/micro/emul_t1.py)
+__global__ __launch_bounds__(BLK) void in_apply_pool_bf16_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                                 float* __restrict__ pooled, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, int D, int H, int W, int C,
+                                                                 int64_t total8) {
+  const int G = C >> 3, d = D / 2, h = H / 2, w = W / 2;
+  const bool small = total8 < (1ll << 31);
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < total8; i += (int64_t)gridDim.x * BLK) {
+    int g, xo, yo, zo;
+    int64_t b;
+    if (small) {
+      unsigned t = (unsigned)i, q = t / (unsigned)G;
+      g = (int)(t - q * (unsigned)G); t = q;
+      q = t / (unsigned)w; xo = (int)(t - q * (unsigned)w); t = q;
+      q = t / (unsigned)h; yo = (int)(t - q * (unsigned)h); t = q;
+      q = t / (unsigned)d; zo = (int)(t - q * (unsigned)d);
+      b = q;
+    } else {
+      g = (int)(i % G);
+      int64_t t = i / G;
+      xo = (int)(t % w); t /= w;
+      yo = (int)(t % h); t /= h;
+      zo = (int)(t % d);
+      b = t / d;
+    }
+    float m[8], r[8];
+    ld8f(mean + b * C + g * 8, m);
+    ld8f(rstd + b * C + g * 8, r);
+    Raw8 rv[8];
+    int64_t i8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      i8[k] = (((b * D + 2 * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1)) * G + g;
+      rv[k] = load8_raw<true>(x, i8[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw8_fence<true>(rv[k]);
+    float s[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float xv[8], o[8];
+      unpack8<true>(rv[k], xv);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { o[c] = lrelu((xv[c] - m[c]) * r[c]); s[c] += o[c]; }
+      store8<true>(y, i8[k], o);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] *= 0.125f;
+    store8<false>(pooled, i, s);
+  }
 }
 
 // (sum g, sum g*xhat), g = dy * lrelu'(xhat); x is the bf16 raw conv output
@@ -976,8 +1041,20 @@ int modet_avgpool2_fwd(const float* x, float* y, int B, int D, int H, int W, int
   MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
   if (C % 4 != 0) return MODET_ERR_UNSUPPORTED;
   const int64_t total4 = (int64_t)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, y, D, H,
+  hipLaunchKernelGGL(avgpool2_fwd_kernel<false>, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, (hipStream_t)stream, x, y, D, H,
                      W, C, total4);
+  return modet_launch_status();
+}
+
+/* AvgPool3d(2) of a bf16 tensor into an fp32 one (BASELINE.json configs[4]: a level's bf16 features -> the next level's input) */
+int modet_avgpool2_fwd_x16(const void* x_bf16, float* y, int B, int D, int H, int W, int C, modet_stream_t stream) {
+  MODET_CHECK_PTR(x_bf16); MODET_CHECK_PTR(y);
+  MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1 && C > 0);
+  MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
+  if (C % 4 != 0) return MODET_ERR_UNSUPPORTED;
+  const int64_t total4 = (int64_t)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(avgpool2_fwd_kernel<true>, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, (hipStream_t)stream, (const float*)x_bf16,
+                     y, D, H, W, C, total4);
   return modet_launch_status();
 }
 
@@ -1043,6 +1120,31 @@ int modet_instnorm_lrelu_fwd_stats_bf16(const void* x, void* y, int y_bf16, floa
   const int64_t total8 = (int64_t)B * V * (C / 8);
   if (y_bf16) hipLaunchKernelGGL(in_apply_bf16_kernel<true>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total8);
   else hipLaunchKernelGGL(in_apply_bf16_kernel<false>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total8);
+  return modet_launch_status();
+}
+
+/* modet_instnorm_lrelu_fwd_stats_bf16 with y stored as bf16, plus AvgPool3d(2) of y -- of its fp32 values, before the rounding --
+ * into `pooled` (fp32), in the same pass */
+int modet_instnorm_lrelu_fwd_stats_pool_bf16(const void* x, void* y_bf16, float* pooled, float* mean, float* rstd, const float* stats,
+                                             size_t stats_bytes, int B, int D, int H, int W, int C, float eps, modet_stream_t stream) {
+  MODET_CHECK_PTR(x); MODET_CHECK_PTR(y_bf16); MODET_CHECK_PTR(pooled); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(stats);
+  MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1 && C > 0);
+  MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
+  if (C % 8 != 0 || 2 * C > 256) return MODET_ERR_UNSUPPORTED;
+  const int64_t V = (int64_t)D * H * W;
+  int64_t rows;
+  if (rows_from_bytes(stats_bytes, B, C, &rows) != MODET_OK) return MODET_ERR_DIM;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t tiles = rows - IN_SLICES;
+  if (tiles <= 0) return MODET_ERR_DIM;
+  const float* trows = stats + (size_t)B * C;
+  float* tail = const_cast<float*>(trows) + (size_t)B * tiles * 2 * C;
+  hipLaunchKernelGGL(in_rows_slice_kernel, dim3(IN_SLICES, B), dim3(256), 0, s, trows, tail, C, tiles);
+  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, (const float*)tail, mean, rstd, V, C,
+                     (int64_t)IN_SLICES, eps);
+  const int64_t total8 = (int64_t)B * (D / 2) * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(in_apply_pool_bf16_kernel, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, x, y_bf16, pooled, mean, rstd, D, H, W, C,
+                     total8);
   return modet_launch_status();
 }
 

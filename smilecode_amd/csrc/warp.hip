@@ -49,7 +49,18 @@ __device__ __forceinline__ Tri tri_setup(float z, float y, float x) {
 
 // ------------------------------------------------------------------------------------------------ warp fwd
 // O16 (BASELINE.json configs[4], bf16 storage of the warped features; CPT = 4): the output is rounded to bf16 (nearest even)
-template <int CPT, bool O16 = false>
+// S16: src holds bf16 (widened on load; CPT = 4).  Everything between the load and the store is fp32.
+template <int CPT, bool S16>
+__device__ __forceinline__ void ldsrc(const float* base, int64_t el, float (&r)[CPT]) {
+  if constexpr (S16 && CPT == 4) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + el);
+    r[0] = __uint_as_float(u.x << 16); r[1] = __uint_as_float(u.x & 0xffff0000u);
+    r[2] = __uint_as_float(u.y << 16); r[3] = __uint_as_float(u.y & 0xffff0000u);
+  } else {
+    ldv<CPT>(base + el, r);
+  }
+}
+template <int CPT, bool O16 = false, bool S16 = false>
 __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                        float* __restrict__ out, int D, int H, int W, int C, int G,
                                                        int64_t total, int mode, int add_flow) {
@@ -68,14 +79,14 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
     const float* fp = flow + n * 3;
     const float f0 = fp[0], f1 = fp[1], f2 = fp[2];
     const float z = (float)zi + f0, y = (float)yi + f1, x = (float)xi + f2;
-    const float* sb = src + b * V * C + g * CPT;
+    const int64_t sbe = b * V * C + g * CPT;       // element offset of (sample, channel group) inside src
     float acc[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
     if (mode == 1) {
       const float zr = rintf(z), yr = rintf(y), xr = rintf(x);     // round half to even = nearbyint
       if (zr >= 0.f && zr < (float)D && yr >= 0.f && yr < (float)H && xr >= 0.f && xr < (float)W)
-        ldv<CPT>(sb + (((int64_t)zr * H + (int64_t)yr) * W + (int64_t)xr) * C, acc);
+        ldsrc<CPT, S16>(src, sbe + (((int64_t)zr * H + (int64_t)yr) * W + (int64_t)xr) * C, acc);
     } else {
       // branch-free: the eight corner loads are issued back to back (out-of-range corners read a clamped, valid voxel and
       // the VALUE is replaced by 0 afterwards -- as grid_sample's zeros padding and the backward kernels do, so an Inf / NaN
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
       }
       float s[8][CPT];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) ldv<CPT>(sb + zo[q >> 2] + yo[(q >> 1) & 1] + xo[q & 1], s[q]);
+      for (int q = 0; q < 8; ++q) ldsrc<CPT, S16>(src, sbe + zo[q >> 2] + yo[(q >> 1) & 1] + xo[q & 1], s[q]);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const float wgt = wzv[q >> 2] * wyv[(q >> 1) & 1] * wxv[q & 1];
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
 //    source plane higher it absorbs them into its dz=0 half, otherwise they are flushed.
 // Smooth flow: ~2 atomics per (voxel, channel) instead of 8.
 constexpr int ZRUN = 8;
+template <bool S16>
 __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                        const float* __restrict__ dout, float* __restrict__ dsrc,
                                                        float* __restrict__ dflow, int D, int H, int W, int C, int G,
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
     const int zr = (int)(r % nrun);
     const int64_t b = r / nrun;
     const int cc = livec ? c : 0;
-    const float* sb = src + b * V * C + cc;
+    const int64_t sbe = b * V * C + cc;            // element offset inside src (fp32 or, S16, bf16)
     float* db = dsrc ? dsrc + b * V * C + cc : nullptr;
     // x-neighbour bookkeeping that does not depend on z
     const int up = lane + G, dn = lane - G;
@@ -215,7 +227,8 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
         for (int q = 0; q < 8; ++q) {
           const bool ok = live && zok[q >> 2] && yok[(q >> 1) & 1] && xok[q & 1];
           const int64_t off = off0 + ((q >> 2) ? sZc : 0) + (((q >> 1) & 1) ? sYc : 0) + ((q & 1) ? sXc : 0);
-          sv[q] = sb[ok ? off : 0];
+          if constexpr (S16) sv[q] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(src)[sbe + (ok ? off : 0)] << 16);
+          else sv[q] = src[sbe + (ok ? off : 0)];
         }
       }
 #pragma unroll
@@ -329,7 +342,7 @@ __device__ __forceinline__ WbRsrc wb_rsrc(const void* base, unsigned bytes) {
 // 24-bit integer multiplies (full rate; v_mul_lo_u32 is quarter rate), per-axis validity as -1 / 0 masks folded into the
 // weights, flow as ONE 12-byte load, the x neighbour test on ONE shuffled value (the cell's byte offset: equal offsets = same
 // cell, see above), d_flow sums as (upper - lower) differences.
-template <int ZR, int YR>
+template <int ZR, int YR, bool S16>
 __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                         const float* __restrict__ dout, float* __restrict__ dsrc,
                                                         float* __restrict__ dflow, int B, int D, int H, int W, int C, int G,
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63;
   const int sX = C * 4, sY = W * C * 4, sZ = H * W * C * 4;       // byte strides of a channel's volume
   const unsigned tbytes = (unsigned)B * (unsigned)V * (unsigned)C * 4u, fbytes = (unsigned)B * (unsigned)V * 12u;
-  const WbRsrc r_src = wb_rsrc(src, tbytes), r_flow = wb_rsrc(flow, fbytes), r_do = wb_rsrc(dout, tbytes);
+  const WbRsrc r_src = wb_rsrc(src, S16 ? tbytes / 2 : tbytes), r_flow = wb_rsrc(flow, fbytes), r_do = wb_rsrc(dout, tbytes);
   const WbRsrc r_ds = wb_rsrc(dsrc, dsrc ? tbytes : 0u), r_df = wb_rsrc(dflow, dflow ? fbytes : 0u);
   const bool want_src = dsrc != nullptr, want_flow = dflow != nullptr;
   for (unsigned idx = blockIdx.x * BLK + threadIdx.x; idx < total_pad; idx += gridDim.x * BLK) {
@@ -434,7 +447,9 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
 #pragma unroll
           for (int q = 0; q < 8; ++q) {                // an offset outside the tensor reads 0; an aliased one is masked
             const int off = off0 + ((q >> 2) ? sZ : 0) + (((q >> 1) & 1) ? sY : 0) + ((q & 1) ? sX : 0);
-            const float sv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_src, (unsigned)off, 0, 0));
+            float sv;                                  // (offsets are bytes of the fp32 layout: a bf16 src sits at half of them)
+            if constexpr (S16) sv = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r_src, (unsigned)off >> 1, 0, 0) << 16);
+            else sv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_src, (unsigned)off, 0, 0));
             dot[q] = msk(sv, mzy[q >> 1] & ((q & 1) ? mx1 : mx0)) * go;
           }
 #pragma unroll
@@ -970,10 +985,17 @@ int modet_debug_warp_census(unsigned long long* buf) {      // not in the header
 
 int modet_warp_bwd(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow, int B, int D,
                    int H, int W, int C, int add_flow, int flow_bound, modet_stream_t stream) {
+  return modet_warp_bwd_t(src, 0, flow, d_out, d_src, d_flow, B, D, H, W, C, add_flow, flow_bound, stream);
+}
+
+int modet_warp_bwd_t(const void* srcv, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow, int B,
+                     int D, int H, int W, int C, int add_flow, int flow_bound, modet_stream_t stream) {
+  const float* src = (const float*)srcv;
   MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(d_out);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
   if (add_flow && C != 3) return MODET_ERR_DIM;
   if (flow_bound != 0 && (flow_bound != 1 || C != 3)) return MODET_ERR_UNSUPPORTED;
+  if (src_bf16 && (add_flow || flow_bound)) return MODET_ERR_UNSUPPORTED;      // (flow compositions stay fp32)
   if (!d_src && !d_flow) return MODET_OK;
   if (flow_bound == 1) {
     const int tx = cdiv(W, G3X), ty = cdiv(H, G3Y), tz = cdiv(D, G3Z);
@@ -991,27 +1013,42 @@ int modet_warp_bwd(const float* src, const float* flow, const float* d_out, floa
   const char wb2 = modet_tuning_env("MODET_WARP_BWD2");
   if (d_src && wb2 != '0' && (int64_t)B * D * H * W * (C > 3 ? C : 3) * 4 < 0x7fffffffLL && (int64_t)(D + 3) * (H + 3) * (W + 3) < (1 << 23) &&
       W * C * 4 < (1 << 23) && total2 < 0x7fffffffLL && total2 >= 256 * 256) {
-    hipLaunchKernelGGL((warp_bwd2_kernel<WB2_ZR, WB2_YR>), dim3(flat_grid(total2, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src,
-                       d_flow, B, D, H, W, C, G, (unsigned)total2, add_flow);
+    if (src_bf16) hipLaunchKernelGGL((warp_bwd2_kernel<WB2_ZR, WB2_YR, true>), dim3(flat_grid(total2, BLK)), dim3(BLK), 0, s, src, flow,
+                                     d_out, d_src, d_flow, B, D, H, W, C, G, (unsigned)total2, add_flow);
+    else hipLaunchKernelGGL((warp_bwd2_kernel<WB2_ZR, WB2_YR, false>), dim3(flat_grid(total2, BLK)), dim3(BLK), 0, s, src, flow, d_out,
+                            d_src, d_flow, B, D, H, W, C, G, (unsigned)total2, add_flow);
     return modet_launch_status();
   }
   const int64_t total = (int64_t)B * cdiv(D, ZRUN) * H * W * G;       // one item per (z run, y, x, channel slot)
-  hipLaunchKernelGGL(warp_bwd_kernel, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow, D,
-                     H, W, C, G, total, add_flow);
+  if (src_bf16) hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow,
+                                   D, H, W, C, G, total, add_flow);
+  else hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow, D,
+                          H, W, C, G, total, add_flow);
   return modet_launch_status();
 }
 
-int modet_warp_fwd_o16(const float* src, const float* flow, void* out_bf16, int B, int D, int H, int W, int C,
-                       modet_stream_t stream) {
-  MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(out_bf16);
+int modet_warp_fwd_t(const void* src, int src_bf16, const float* flow, void* out, int out_bf16, int B, int D, int H, int W, int C,
+                     modet_stream_t stream) {
+  if (!src_bf16 && !out_bf16) return modet_warp_fwd((const float*)src, flow, (float*)out, B, D, H, W, C, 0, 0, stream);
+  MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(out);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
   if (C % 4 != 0) return MODET_ERR_UNSUPPORTED;
   const int G = C / 4;
   const int64_t total = (int64_t)B * D * H * W * G;
   if (total >= ((int64_t)1 << 31) - (int64_t)256 * 16 * BLK) return MODET_ERR_UNSUPPORTED;     // 32-bit item index
-  hipLaunchKernelGGL((warp_fwd_kernel<4, true>), dim3(flat_grid(total, BLK)), dim3(BLK), 0, (hipStream_t)stream, src, flow,
-                     (float*)out_bf16, D, H, W, C, G, total, 0, 0);
+  const dim3 grid(flat_grid(total, BLK));
+  hipStream_t s = (hipStream_t)stream;
+  const float* sf = (const float*)src;
+  float* of = (float*)out;
+  if (src_bf16 && out_bf16) hipLaunchKernelGGL((warp_fwd_kernel<4, true, true>), grid, dim3(BLK), 0, s, sf, flow, of, D, H, W, C, G, total, 0, 0);
+  else if (src_bf16) hipLaunchKernelGGL((warp_fwd_kernel<4, false, true>), grid, dim3(BLK), 0, s, sf, flow, of, D, H, W, C, G, total, 0, 0);
+  else hipLaunchKernelGGL((warp_fwd_kernel<4, true, false>), grid, dim3(BLK), 0, s, sf, flow, of, D, H, W, C, G, total, 0, 0);
   return modet_launch_status();
+}
+
+int modet_warp_fwd_o16(const float* src, const float* flow, void* out_bf16, int B, int D, int H, int W, int C,
+                       modet_stream_t stream) {
+  return modet_warp_fwd_t(src, 0, flow, out_bf16, 1, B, D, H, W, C, stream);
 }
 
 int modet_upsample2_fwd(const float* x, float* y, int B, int d, int h, int w, int C, float scale,

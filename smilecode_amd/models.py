@@ -163,6 +163,7 @@ class Encoder(nn.Module):
         return tuple(outs)
 
     stage_cut = False       # engine.Trainer (overlapped all-reduce): cut the autograd graph in front of level 3
+    features16 = False      # ModeT(act_dtype=bfloat16) with the fused level nodes: level features 1-4 stored as bf16 (fp32 handles)
 
     def _cut(self, t):
         """graph cut for a staged backward: the consumer sees a fresh leaf sharing t's storage (no copy); the stage that owns
@@ -198,7 +199,7 @@ class Encoder(nn.Module):
                 if blk is self.conv2 and self.stage_cut:
                     inp = self._cut(inp)
                 pooled, m, f = ops.conv_ins_pair_bf16_pool_split(inp, blk[1].main.weight, blk[1].main.bias, blk[2].main.weight,
-                                                                 blk[2].main.bias, B)
+                                                                 blk[2].main.bias, B, features16=self.features16)
                 Ms.append(m)
                 Fs.append(f)
                 pooled_in.append(pooled)
@@ -392,6 +393,8 @@ class ModeT(nn.Module):
         fl = self._flavour
         mk = dict(qk_scale=scale, buffer_flavour=fl, fused=fused_attention)
         self.encoder = Encoder(in_channel=in_channel, first_out_channel=c, bf16=act_dtype == torch.bfloat16)
+        # the level features of levels 1-4 as bf16 too: only the fused level nodes read them (as ``.data16`` of fp32 handles)
+        self.encoder.features16 = self.level_bf16
         self.projblock1 = ProjectionLayer(2 * c, dim=head_dim * num_heads[4])
         self.mdt1 = ModeTransformer(head_dim * num_heads[4], num_heads[4], **mk)
         self.projblock2 = ProjectionLayer(4 * c, dim=head_dim * num_heads[3])
@@ -427,8 +430,8 @@ class ModeT(nn.Module):
             # nodes only (a cut at a non-leaf does not do that: autograd marks everything that can reach a node with a
             # captured output as needed, and the first stage would run -- and free -- half of the encoder's backward)
             self.cut_features = (M, Fx)
-            M = [m.detach().requires_grad_(True) for m in M]
-            Fx = [f.detach().requires_grad_(True) for f in Fx]
+            M = [ops.feature_handle_like(m.detach().requires_grad_(True), m) for m in M]
+            Fx = [ops.feature_handle_like(f.detach().requires_grad_(True), f) for f in Fx]
             self.cut_leaves = (M, Fx)
         ST = self.transformer
 
@@ -438,6 +441,8 @@ class ModeT(nn.Module):
             if self.level_bf16 and mdt.fused and mdt.use_rpb:
                 return ops.level_attention_bf16(Fx[lvl], M[lvl], flow, proj.proj.weight, proj.proj.bias, proj.norm.weight,
                                                 proj.norm.bias, mdt.rpb, mdt.num_heads, mdt.scale)
+            if getattr(Fx[lvl], "data16", None) is not None:
+                raise RuntimeError("ModeT: bf16 level features are only readable by the fused level nodes")
             Mw = M[lvl] if flow is None else st.forward_cl(M[lvl], flow)
             q, k = proj.forward_pair(Fx[lvl], Mw)
             return mdt(q, k)

@@ -998,16 +998,21 @@ class _LevelAttnBF16(Function):
         N = B * D * H * W
         L = _L()
         n = float(N)
+        # level features handed over as fp32 handles with bf16 data (_InstNormLReLUBF16PoolSplit, features16): read the data
+        Fd, Md = getattr(F, "data16", None), getattr(M, "data16", None)
+        Fd = F if Fd is None else Fd
+        Md = M if Md is None else Md
+        m16 = int(Md.dtype == torch.bfloat16)
         if flow is not None:
             _chk(flow)
             Mw = torch.empty(M.shape, dtype=torch.bfloat16, device=M.device)
-            with _Guard(M, f"warp_fwd[C{Cin}]", n * (24.0 * Cin + 30.0), n * (6.0 * Cin + 12.0)):
-                _lib.check(L.modet_warp_fwd_o16(_p(M), _p(flow), _p(Mw), B, D, H, W, Cin, _stream()), "modet_warp_fwd_o16")
+            with _Guard(M, f"warp_fwd[C{Cin}]", n * (24.0 * Cin + 30.0), n * ((2.0 if m16 else 4.0) * Cin + 2.0 * Cin + 12.0)):
+                _lib.check(L.modet_warp_fwd_t(_p(Md), m16, _p(flow), _p(Mw), 1, B, D, H, W, Cin, _stream()), "modet_warp_fwd_t")
         else:
-            Mw = M
+            Mw = Md
         q = torch.empty((B, D, H, W, dim), dtype=torch.bfloat16, device=F.device)
         k = torch.empty_like(q)
-        for x, y in ((F, q), (Mw, k)):
+        for x, y in ((Fd, q), (Mw, k)):
             x16 = int(x.dtype == torch.bfloat16)
             with _Guard(F, f"proj_ln_fwd[{Cin}->{dim}]", n * (2.0 * Cin * dim + 8.0 * dim), n * ((2.0 if x16 else 4.0) * Cin + 2.0 * dim)):
                 _lib.check(L.modet_proj_ln_fwd_t(_p(x), x16, _p(Wt), _p(b), _p(gamma), _p(beta), _p(y), 1, N, Cin, dim, eps, _stream()),
@@ -1020,13 +1025,13 @@ class _LevelAttnBF16(Function):
             _lib.check(L.modet_na_fwd_t(_p(q), _p(k), 1, _p(rpb), _p(out), _p(lse), B, D, H, W, heads, dim // heads, float(scale),
                                         _stream()), "modet_na_fwd_t")
         if need_grad:
-            ctx.save_for_backward(F, M, flow, Mw if flow is not None else None, q, k, Wt, b, gamma, rpb, out, lse)
+            ctx.save_for_backward(Fd, Md, flow, Mw if flow is not None else None, q, k, Wt, b, gamma, rpb, out, lse)
         ctx.heads, ctx.scale, ctx.eps = heads, float(scale), eps
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        F, M, flow, Mw, q, k, Wt, b, gamma, rpb, out, lse = ctx.saved_tensors
+        F, M, flow, Mw, q, k, Wt, b, gamma, rpb, out, lse = ctx.saved_tensors      # (F, M: the data, fp32 or bf16)
         dout = dout.contiguous()
         B, D, H, W, Cin = F.shape
         dim = Wt.shape[0]
@@ -1043,7 +1048,7 @@ class _LevelAttnBF16(Function):
             _lib.check(L.modet_na_bwd_t(_p(q), _p(k), 1, _p(rpb), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(drpb), _p(ws), nb, B, D,
                                         H, W, heads, dim // heads, ctx.scale, _stream()), "modet_na_bwd_t")
         x2 = Mw if flow is not None else M
-        dF = torch.empty_like(F)
+        dF = torch.empty(F.shape, dtype=torch.float32, device=F.device)
         dMw = torch.empty(M.shape, dtype=torch.float32, device=M.device)
         dW, db, dg, dbeta = torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma), torch.empty_like(gamma)
         nb2 = L.modet_proj_ln_bwd_pair_ws_bytes(N, Cin, dim)
@@ -1051,17 +1056,18 @@ class _LevelAttnBF16(Function):
             raise RuntimeError(f"level attention (bf16): no paired projection backward for Cin {Cin}, dim {dim}")
         ws2 = _ws(nb2, F)
         with _Guard(F, f"proj_ln_bwd[{Cin}->{dim}]", 2 * n * (6.0 * Cin * dim + 20.0 * dim), n * (14.0 * Cin + 8.0 * dim)):
-            _lib.check(L.modet_proj_ln_bwd_pair_t(_p(F), 0, _p(dq), _p(dF), _p(x2), int(x2.dtype == torch.bfloat16), _p(dk), _p(dMw),
+            _lib.check(L.modet_proj_ln_bwd_pair_t(_p(F), int(F.dtype == torch.bfloat16), _p(dq), _p(dF), _p(x2),
+                                                  int(x2.dtype == torch.bfloat16), _p(dk), _p(dMw),
                                                   _p(Wt), _p(b), _p(gamma), _p(dW), _p(db), _p(dg), _p(dbeta), _p(ws2), nb2, N, Cin, dim,
                                                   ctx.eps, _stream()), "modet_proj_ln_bwd_pair_t")
         if flow is None:
             return dF, dMw, None, dW, db, dg, dbeta, drpb, None, None, None
-        dM = torch.empty_like(M) if ctx.needs_input_grad[1] else None
+        dM = torch.empty(M.shape, dtype=torch.float32, device=M.device) if ctx.needs_input_grad[1] else None
         dflow = torch.empty_like(flow) if ctx.needs_input_grad[2] else None
         if dM is not None or dflow is not None:
             with _Guard(M, f"warp_bwd[C{Cin}]", n * (60.0 * Cin + 40.0), 4.0 * n * (3 * Cin + 6)):
-                _lib.check(L.modet_warp_bwd(_p(M), _p(flow), _p(dMw), _p(dM), _p(dflow), B, D, H, W, Cin, 0, 0, _stream()),
-                           "modet_warp_bwd")
+                _lib.check(L.modet_warp_bwd_t(_p(M), int(M.dtype == torch.bfloat16), _p(flow), _p(dMw), _p(dM), _p(dflow), B, D, H, W,
+                                              Cin, 0, 0, _stream()), "modet_warp_bwd_t")
         return dF, dM, dflow, dW, db, dg, dbeta, drpb, None, None, None
 
 
@@ -1583,32 +1589,48 @@ class _InstNormLReLUBF16PoolSplit(Function):
     backward and read back twice: same arithmetic, same order of the sums -- bit-identical to the two-node form."""
 
     @staticmethod
-    def forward(ctx, x, stats, eps, Bh):
+    def forward(ctx, x, stats, eps, Bh, features16=False):
         _chk16(x)
         if x.dtype != torch.bfloat16:
             raise RuntimeError("instnorm bf16: the raw conv output must be bfloat16")
         B, D, H, W, C = x.shape
         V = D * H * W
         L = _L()
-        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        y = torch.empty(x.shape, dtype=torch.bfloat16 if features16 else torch.float32, device=x.device)
         mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        nel = float(x.numel())
-        with _Guard(x, "instnorm_bf16_fwd", 8.0 * nel, nel * 6.0):
-            _lib.check(L.modet_instnorm_lrelu_fwd_stats_bf16(_p(x), _p(y), 0, _p(mean), _p(rstd), _p(stats), stats.numel() * 4, B, V,
-                                                             C, eps, _stream()), "modet_instnorm_lrelu_fwd_stats_bf16")
         pooled = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
-        with _Guard(y, "avgpool2_fwd", y.numel(), 4.5 * y.numel()):
-            _lib.check(L.modet_avgpool2_fwd(_p(y), _p(pooled), B, D, H, W, C, _stream()), "modet_avgpool2_fwd")
+        nel = float(x.numel())
+        if features16:
+            # one pass: bf16 features + the pooled tensor from their fp32 values (pooling the ROUNDED features costs the gradient)
+            with _Guard(x, "instnorm_bf16_fwd", 9.0 * nel, nel * 4.5):
+                _lib.check(L.modet_instnorm_lrelu_fwd_stats_pool_bf16(_p(x), _p(y), _p(pooled), _p(mean), _p(rstd), _p(stats),
+                                                                      stats.numel() * 4, B, D, H, W, C, eps, _stream()),
+                           "modet_instnorm_lrelu_fwd_stats_pool_bf16")
+        else:
+            with _Guard(x, "instnorm_bf16_fwd", 8.0 * nel, nel * 6.0):
+                _lib.check(L.modet_instnorm_lrelu_fwd_stats_bf16(_p(x), _p(y), 0, _p(mean), _p(rstd), _p(stats), stats.numel() * 4, B,
+                                                                 V, C, eps, _stream()), "modet_instnorm_lrelu_fwd_stats_bf16")
+            with _Guard(y, "avgpool2_fwd", y.numel(), 4.5 * y.numel()):
+                _lib.check(L.modet_avgpool2_fwd(_p(y), _p(pooled), B, D, H, W, C, _stream()), "modet_avgpool2_fwd")
         ctx.save_for_backward(x, mean, rstd)
         ctx.Bh = Bh
         ctx.set_materialize_grads(False)
-        return pooled, y[:Bh], y[Bh:]
+        if not features16:
+            return pooled, y[:Bh], y[Bh:]
+        # bf16 level features: the two halves leave as fp32 HANDLES -- allocated, never written, never read -- that carry the
+        # bf16 tensor as ``.data16``.  Autograd sees fp32 tensors of the right shape, so the consumers' fp32 gradients arrive
+        # here uncast (a bf16 tensor on the edge would have them rounded to bf16, with a cast pass each); the consumers
+        # (level_attention_bf16) read ``.data16`` only.
+        hm = torch.empty((Bh,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        hf = torch.empty((B - Bh,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        hm.data16, hf.data16 = y[:Bh], y[Bh:]
+        return pooled, hm, hf
 
     @staticmethod
     def backward(ctx, gy, ga, gb):
         if not ctx.needs_input_grad[0] or (gy is None and ga is None and gb is None):
-            return None, None, None, None
+            return None, None, None, None, None
         x, mean, rstd = ctx.saved_tensors
         B, D, H, W, C = x.shape
         Bh = ctx.Bh
@@ -1625,7 +1647,7 @@ class _InstNormLReLUBF16PoolSplit(Function):
             with _Guard(x, "instnorm_bf16_bwd", 15.0 * nel, nel * 14.5):
                 _lib.check(L.modet_instnorm_lrelu_bwd_pool_bf16(_p(gy), _p(ga), _p(gb), Bh, _p(x), _p(mean), _p(rstd), _p(dx), _p(ws),
                                                                 nb, B, D, H, W, C, _stream()), "modet_instnorm_lrelu_bwd_pool_bf16")
-            return dx, None, None, None
+            return dx, None, None, None, None
         dy = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         for sl, g in ((slice(0, Bh), ga), (slice(Bh, B), gb)):
             if g is None:
@@ -1635,16 +1657,25 @@ class _InstNormLReLUBF16PoolSplit(Function):
         with _Guard(x, "instnorm_bf16_bwd", 14.0 * nel, nel * 14.0):
             _lib.check(L.modet_instnorm_lrelu_bwd_bf16(_p(dy), 0, _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C, _stream()),
                        "modet_instnorm_lrelu_bwd_bf16")
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def conv_ins_pair_bf16_pool_split(inp, w1, b1, w2, b2, Bh, eps=1e-5):
-    """conv_ins_pair_bf16 whose fp32 output goes to AvgPool3d(2) and, split into its two batch halves, to the level's consumers:
-    (pooled, y[:Bh], y[Bh:]); see _InstNormLReLUBF16PoolSplit"""
+def conv_ins_pair_bf16_pool_split(inp, w1, b1, w2, b2, Bh, eps=1e-5, features16=False):
+    """conv_ins_pair_bf16 whose output goes to AvgPool3d(2) and, split into its two batch halves, to the level's consumers:
+    (pooled, y[:Bh], y[Bh:]); see _InstNormLReLUBF16PoolSplit.  features16: the two halves are stored as bf16 and handed out as
+    fp32 handles with ``.data16`` (only level_attention_bf16 understands those)."""
     raw1, st1 = _Conv3dBF16.apply(inp, w1, b1)
     y1 = _InstNormLReLUBF16.apply(raw1, st1, eps, True)
     raw2, st2 = _Conv3dBF16.apply(y1, w2, b2)
-    return _InstNormLReLUBF16PoolSplit.apply(raw2, st2, eps, Bh)
+    return _InstNormLReLUBF16PoolSplit.apply(raw2, st2, eps, Bh, features16)
+
+
+def feature_handle_like(new, old):
+    """``new`` (a detached copy / leaf of the fp32 handle ``old``) carries the same bf16 level features"""
+    d16 = getattr(old, "data16", None)
+    if d16 is not None:
+        new.data16 = d16
+    return new
 
 
 def conv_ins_pair_bf16(inp, w1, b1, w2, b2, eps=1e-5):

@@ -558,3 +558,100 @@ def test_level_attention_bf16_node_matches_the_unfused_ops_on_rounded_tensors():
         # (d_M / d_flow pass through the warp backward's float atomics: order-dependent rounding)
         tol = 1e-5 * float(b_.abs().max()) if name in ("d_M", "d_flow") else 0.0
         assert float((a - b_).abs().max()) <= tol, f"{name} of the fused bf16 level node differs"
+
+
+def test_warp_and_pool_with_bf16_source_are_the_fp32_kernels_on_widened_operands():
+    """modet_warp_fwd_t / modet_warp_bwd_t with a bf16 src and modet_avgpool2_fwd_x16 (cfg 5: level features stored as bf16): bit-
+    identical to the fp32 entry points fed with the widened values (d_src goes through float atomics: compared to rounding noise),
+    on the patch kernel (large case) and the run kernel (small case)."""
+    from smilecode_amd import _lib
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    for (B, D, H, W, C) in ((1, 9, 14, 21, 8), (1, 40, 48, 40, 16), (2, 6, 8, 10, 64)):
+        g = torch.Generator(device="cuda").manual_seed(C + D)
+        s16 = torch.randn((B, D, H, W, C), device="cuda", generator=g).bfloat16()
+        s32 = s16.float()
+        flow = torch.randn((B, D, H, W, 3), device="cuda", generator=g) * 2.5
+        gy = torch.randn((B, D, H, W, C), device="cuda", generator=g)
+        o_a, o_b = torch.empty_like(s32), torch.empty_like(s32)
+        _lib.check(L.modet_warp_fwd_t(P(s32), 0, P(flow), P(o_a), 0, B, D, H, W, C, st), "fwd")
+        _lib.check(L.modet_warp_fwd_t(P(s16), 1, P(flow), P(o_b), 0, B, D, H, W, C, st), "fwd s16")
+        assert torch.equal(o_a, o_b)
+        o_c = torch.empty(s32.shape, device="cuda", dtype=torch.bfloat16)
+        _lib.check(L.modet_warp_fwd_t(P(s16), 1, P(flow), P(o_c), 1, B, D, H, W, C, st), "fwd s16 o16")
+        assert torch.equal(o_c, o_a.bfloat16())
+        res = []
+        for src, bf in ((s32, 0), (s16, 1)):
+            ds, df = torch.empty_like(s32), torch.empty_like(flow)
+            _lib.check(L.modet_warp_bwd_t(P(src), bf, P(flow), P(gy), P(ds), P(df), B, D, H, W, C, 0, 0, st), "bwd")
+            res.append((ds, df))
+        assert torch.equal(res[0][1], res[1][1]), "d_flow"
+        assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-5 * float(res[0][0].abs().max()), "d_src"
+        if D % 2 == 0 and H % 2 == 0 and W % 2 == 0:
+            p_a = torch.empty((B, D // 2, H // 2, W // 2, C), device="cuda")
+            p_b = torch.empty_like(p_a)
+            _lib.check(L.modet_avgpool2_fwd(P(s32), P(p_a), B, D, H, W, C, st), "pool")
+            _lib.check(L.modet_avgpool2_fwd_x16(P(s16), P(p_b), B, D, H, W, C, st), "pool x16")
+            assert torch.equal(p_a, p_b)
+
+
+def test_level_attention_bf16_node_reads_bf16_features_through_fp32_handles():
+    """level features as fp32 HANDLES carrying bf16 data (`.data16`): the fused level node must give exactly what it gives for
+    fp32 features holding the same (rounded) values, and return fp32 gradients of the handles' shape"""
+    from smilecode_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, D, H, W, Cin, heads = 1, 12, 16, 20, 8, 1
+    dim = 6 * heads
+    mk = lambda *sh, s=1.0: (torch.randn(sh, device="cuda", generator=g) * s)
+    F16, M16 = mk(B, D, H, W, Cin).bfloat16(), mk(B, D, H, W, Cin).bfloat16()
+    fl0 = mk(B, D, H, W, 3, s=2.0)
+    Wt0, b0, ga0, be0, rpb0 = mk(dim, Cin, s=0.3), mk(dim), mk(dim), mk(dim), mk(heads, 3, 3, 3)
+    gout = mk(B, D, H, W, heads * 3)
+    res = []
+    for handles in (True, False):
+        if handles:
+            F = torch.empty((B, D, H, W, Cin), device="cuda").requires_grad_(True)      # never read
+            M = torch.empty((B, D, H, W, Cin), device="cuda").requires_grad_(True)
+            F.data16, M.data16 = F16, M16
+        else:
+            F, M = F16.float().requires_grad_(True), M16.float().requires_grad_(True)
+        rest = [t.clone().requires_grad_(True) for t in (fl0, Wt0, b0, ga0, be0, rpb0)]
+        out = ops.level_attention_bf16(F, M, *rest, heads, 0.7)
+        grads = torch.autograd.grad(out, [F, M] + rest, gout)
+        assert grads[0].dtype == torch.float32 and grads[1].dtype == torch.float32
+        res.append((out.detach(), grads))
+    assert torch.equal(res[0][0], res[1][0])
+    for name, a, b_ in zip(("d_F", "d_M", "d_flow", "d_W", "d_b", "d_gamma", "d_beta", "d_rpb"), res[0][1], res[1][1]):
+        tol = 1e-5 * float(b_.abs().max()) if name in ("d_M",) else 0.0
+        assert float((a - b_).abs().max()) <= tol, f"{name} differs with bf16 feature handles"
+
+
+def test_instnorm_apply_pool_bf16_is_the_two_pass_form():
+    """modet_instnorm_lrelu_fwd_stats_pool_bf16: y (bf16) bit-identical to modet_instnorm_lrelu_fwd_stats_bf16's bf16 output, and
+    pooled == AvgPool3d(2) of the fp32-output form (the pooled tensor is formed in front of the rounding)"""
+    from smilecode_amd import _lib, ops
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    for (B, D, H, W, Cin, C) in ((2, 8, 12, 20, 4, 8), (2, 6, 8, 16, 16, 16)):
+        g = torch.Generator(device="cuda").manual_seed(C)
+        x = torch.randn((B, D, H, W, Cin), device="cuda", generator=g)
+        w = torch.randn((C, Cin, 3, 3, 3), device="cuda", generator=g) / (27 * Cin) ** 0.5
+        b = torch.randn(C, device="cuda", generator=g) * 0.1
+        with torch.no_grad():
+            raw, stats = ops._Conv3dBF16.apply(x, w, b)
+        V = D * H * W
+        mk = lambda: (torch.empty(B * C, device="cuda"), torch.empty(B * C, device="cuda"))
+        y16, y32 = torch.empty(raw.shape, device="cuda", dtype=torch.bfloat16), torch.empty(raw.shape, device="cuda")
+        (m1, r1), (m2, r2), (m3, r3) = mk(), mk(), mk()
+        _lib.check(L.modet_instnorm_lrelu_fwd_stats_bf16(P(raw), P(y16), 1, P(m1), P(r1), P(stats.clone()), stats.numel() * 4, B, V, C, 1e-5, st), "a")
+        _lib.check(L.modet_instnorm_lrelu_fwd_stats_bf16(P(raw), P(y32), 0, P(m2), P(r2), P(stats.clone()), stats.numel() * 4, B, V, C, 1e-5, st), "b")
+        yp = torch.empty_like(y16)
+        pooled = torch.empty((B, D // 2, H // 2, W // 2, C), device="cuda")
+        _lib.check(L.modet_instnorm_lrelu_fwd_stats_pool_bf16(P(raw), P(yp), P(pooled), P(m3), P(r3), P(stats.clone()), stats.numel() * 4, B, D, H,
+                                                              W, C, 1e-5, st), "c")
+        assert torch.equal(yp, y16) and torch.equal(m3, m1) and torch.equal(r3, r1)
+        ref = torch.empty_like(pooled)
+        _lib.check(L.modet_avgpool2_fwd(P(y32), P(ref), B, D, H, W, C, st), "pool")
+        assert torch.equal(pooled, ref)
