@@ -655,3 +655,21 @@ def test_instnorm_apply_pool_bf16_is_the_two_pass_form():
         ref = torch.empty_like(pooled)
         _lib.check(L.modet_avgpool2_fwd(P(y32), P(ref), B, D, H, W, C, st), "pool")
         assert torch.equal(pooled, ref)
+
+
+def test_bf16_staged_backward_matches_the_plain_one():
+    """engine.Trainer(overlap_allreduce=True) cuts the autograd graph at the level features; in bf16 mode those are fp32 handles
+    carrying bf16 data (ops.feature_handle_like keeps the data on the cut leaves): the three-stage backward must give the plain
+    backward's gradients (up to the warp scatter's atomic order and the bf16 roundings that order flips)"""
+    from smilecode_amd import engine, models, synth
+    shape = (32, 48, 32)
+    res = []
+    for overlap in (False, True):
+        m = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1, act_dtype=torch.bfloat16).cuda()
+        models.load_numpy_weights(m, synth.make_weights(24))
+        tr = engine.Trainer(m, overlap_allreduce=overlap)
+        mov, fix = (torch.from_numpy(a).cuda() for a in synth.make_pair(shape, 24))
+        out = tr._fwd_bwd_staged(mov, fix) if overlap else tr._fwd_bwd(mov, fix)
+        res.append((tr.fp.grad.clone().double(), float(out[0])))
+    assert res[0][1] == res[1][1]
+    assert float((res[0][0] - res[1][0]).norm() / res[0][0].norm()) < 5e-3
