@@ -155,6 +155,8 @@ class BucketedAllReduce:
         self.ranges = [(flat.offsets[m[0]][0], flat.offsets[m[-1]][0] + flat.offsets[m[-1]][1]) for m in self.members]
         self.pending, self.works, self.fired = [0] * self.nb, [], [False] * self.nb
         self.enabled = False
+        self.always_reduce = False      # issue the collectives in a one-rank group too (tests: RCCL's stream ordering at world size 1)
+        self.n_launched = 0
         for i, prm in enumerate(flat.params):
             prm.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -195,9 +197,10 @@ class BucketedAllReduce:
     def launch(self, k):
         """all-reduce bucket k asynchronously: torch.distributed's stream waits for everything enqueued on the current
         stream so far (stage k) and then runs beside stage k + 1"""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always_reduce):
             a, b = self.ranges[k]
             self.works.append(dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.n_launched += 1
 
     def finish_staged(self):
         """join every collective (the current stream waits); returns 1/world"""

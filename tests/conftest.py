@@ -37,13 +37,27 @@ def _start_job(name):
     return _jobs[name]
 
 
+_MULTI_PROCESS = ("test_data_parallel_two_ranks_equal_batch_two", "test_staged_step_through_the_nccl_backend",
+                  "test_train_and_infer_scripts_synthetic")
+
+
 def pytest_collection_modifyitems(config, items):
-    """the tests that wait for a background oracle job run LAST (160x192x160 first, then the longer cfg-5 job), so the jobs
-    overlap with every other GPU test"""
+    """Order of the -m gpu run (the driver runs it with -x, so whatever fails hides everything behind it -- VERDICT r4):
+    0 per-op parity (test_gpu_ops.py), 1 end-to-end goldens / oracle comparisons and the in-process engine tests
+    (test_gpu_e2e.py), 2 bf16 storage mode, 3 everything that launches processes or scripts (timing-sensitive, ports), then
+    the tests that wait for a background oracle job (4: 160x192x160, 5: the longer cfg-5 job), so the jobs overlap with
+    every other GPU test.  The sort is stable: inside a group the file order stays."""
     def rank(it):
         n = it.name.split("[")[0]
-        return 2 if n in _ORACLE_USERS["cfg5"] else (1 if n in _ORACLE_USERS["full160"] else 0)
-    items.sort(key=rank)                               # stable: everything else keeps its order
+        if n in _ORACLE_USERS["cfg5"]:
+            return 5
+        if n in _ORACLE_USERS["full160"]:
+            return 4
+        if n in _MULTI_PROCESS:
+            return 3
+        f = os.path.basename(str(it.fspath))
+        return {"test_gpu_ops.py": 0, "test_gpu_e2e.py": 1, "test_gpu_bf16.py": 2}.get(f, 0)
+    items.sort(key=rank)
 
 
 def pytest_collection_finish(session):

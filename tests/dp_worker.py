@@ -20,13 +20,24 @@ models.load_numpy_weights(model, synth.make_weights(24 + rank))      # rank 1 st
 tr = Trainer(model, overlap_allreduce=os.environ.get("MODET_OVERLAP") == "1")
 mov, fix = synth.make_pair(shape, 24, world)                          # the same batch the single-process run uses
 mov, fix = torch.from_numpy(mov[rank:rank + 1]).cuda(), torch.from_numpy(fix[rank:rank + 1]).cuda()
+diag = {}
+want_diag = os.environ.get("MODET_DP_DIAG") == "1"                   # tools/repro_dp.py: this rank's LOCAL gradients, eager and replayed
 if os.environ.get("MODET_GRAPH") == "1":                             # the captured step (overlap: three stage graphs)
-    tr.capture(mov, fix)
+    tr.capture(mov, fix, verify=not want_diag)
+    if want_diag:
+        torch.cuda.synchronize()
+        diag["eager_local"] = tr.fp.grad.cpu().numpy()               # capturing executes nothing: still the last eager warm-up's
+        for rep in range(2):
+            tr.fp.grad.fill_(float("nan"))
+            for gr in (tr._stage_graphs or [tr._graph]):
+                gr.replay()
+            torch.cuda.synchronize()
+            diag["replay%d_local" % rep] = tr.fp.grad.cpu().numpy()
     flag = torch.tensor([1 if tr._graph is not None else 0], device="cuda")
     torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)     # every rank on the same path
     assert int(flag) == 1
 tr.train_step(mov, fix, epoch=0)
 torch.cuda.synchronize()
-np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=tr.fp.flat.cpu().numpy(), grad=(tr.fp.grad / world).cpu().numpy())
+np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=tr.fp.flat.cpu().numpy(), grad=(tr.fp.grad / world).cpu().numpy(), **diag)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()

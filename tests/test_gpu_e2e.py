@@ -367,13 +367,86 @@ def test_data_parallel_two_ranks_equal_batch_two(tmp_path, overlap, graph):
     tr.train_step(mov, fix, epoch=0)
     g1, f1 = tr.fp.grad.cpu().numpy(), tr.fp.flat.cpu().numpy()
     gerr = np.abs(ranks[0]["grad"] - g1).max() / np.abs(g1).max()
-    _note("dp2_vs_batch2_grad_relerr", gerr)
-    assert gerr < 2e-4, gerr
+    _note(f"dp2_vs_batch2_grad_relerr[overlap={overlap},graph={graph}]", gerr)
+    if not gerr < 2e-5:
+        # name the side and the tensors: the batch-2 reference a second time (fresh trainer), then every parameter tensor
+        tr2 = Trainer(_model(shape, 1.0))
+        tr2.train_step(mov, fix, epoch=0)
+        g2 = tr2.fp.grad.cpu().numpy()
+        gm = np.abs(g1).max()
+        lines = ["overlap=%s graph=%s: ranks vs reference %.3e, reference run 1 vs run 2 %.3e, ranks vs reference run 2 %.3e (of max|g|)"
+                 % (overlap, graph, gerr, np.abs(g1 - g2).max() / gm, np.abs(ranks[0]["grad"] - g2).max() / gm)]
+        for (n, _), (off, k) in zip(model.named_parameters(), tr.fp.offsets):
+            sl = slice(off, off + k)
+            lines.append("  %-36s %8d  ranks-ref %.3e  ref1-ref2 %.3e  (own max %.3e)" % (
+                n, k, np.abs(ranks[0]["grad"][sl] - g1[sl]).max() / gm, np.abs(g1[sl] - g2[sl]).max() / gm, np.abs(g1[sl]).max() / gm))
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"dp_diag_{overlap}{graph}.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+        print("\n".join(lines))
+    assert gerr < 2e-5, gerr
     # the first Adam step moves every parameter by lr * g/(|g| + eps) ~ +-1e-4: compare where the gradient is not pure
     # rounding noise (biases in front of an InstanceNorm have analytically zero gradient, their sign is arbitrary)
     sig = np.abs(g1) > 1e-4 * np.abs(g1).max()
     assert sig.mean() > 0.5
     assert np.abs(ranks[0]["flat"] - f1)[sig].max() < 2e-5
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_staged_step_through_the_nccl_backend(tmp_path, graph):
+    """the overlapped step (three stages, bucket k's all-reduce issued after stage k) on the `nccl`
+    backend = RCCL, whose collectives are stream-ordered work on RCCL's own stream -- ordering semantics the two-rank gloo
+    test cannot show.  One rank (this box has one GPU), the three collectives really issued; three consecutive steps must
+    be the plain eager trainer's steps: losses, gradients, parameters."""
+    import subprocess
+    import sys
+    from smilecode_amd.engine import Trainer
+    shape = (32, 48, 32)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29900 + os.getpid() % 90 + int(graph)))
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "nccl_worker.py"), str(tmp_path), ",".join(map(str, shape)), graph, "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(tmp_path / "nccl.npz")
+    assert int(z["n_collectives"]) == 9, "three bucket all-reduces per step must have been issued"
+    tr = Trainer(_model(shape, 1.0))
+    mov, fix = _pair(shape)
+    for step in range(3):
+        out = tr.train_step(mov, fix, epoch=0)
+        g = tr.fp.grad.cpu().numpy()
+        gerr = np.abs(z["grads"][step] - g).max() / np.abs(g).max()
+        _note(f"nccl_staged[graph={graph}].step{step}_grad_relerr", gerr)
+        # step 0 runs on identical parameters; later steps on parameters that differ by Adam's unit-size response to the
+        # float-atomic noise of step 0 (see test_hip_graph_training_trajectory_equals_eager)
+        assert gerr < (2e-5 if step == 0 else 5e-2), (step, gerr)
+        assert abs(float(out[0]) - float(z["losses"][step][0])) < (1e-6 if step == 0 else 4e-3)
+    assert np.abs(z["flat"] - tr.fp.flat.cpu().numpy()).max() < 1e-3
+
+
+def test_staged_graphs_follow_the_parameters():
+    """the three stage graphs must pack the conv weights INSIDE graph 0 -- packed once at capture, every
+    replay after the first optimizer step would convolve with the weights of capture time.  Capture, then change every
+    parameter by 10 % and compare the replayed gradients with the eager staged step on the same parameters; then three
+    optimizer steps through the graphs against the eager trainer."""
+    from smilecode_amd.engine import Trainer
+    shape = (32, 48, 32)
+    mov, fix = _pair(shape)
+    a, b = Trainer(_model(shape, 1.0), overlap_allreduce=True), Trainer(_model(shape, 1.0), overlap_allreduce=True)
+    b.capture(mov, fix)
+    assert b._stage_graphs is not None and len(b._stage_graphs) == 3
+    for t in (a, b):
+        t.fp.flat.mul_(1.1)
+    a._fwd_bwd_staged(mov, fix)
+    b.fp.grad.fill_(float("nan"))
+    for gr in b._stage_graphs:
+        gr.replay()
+    gerr = float((a.fp.grad - b.fp.grad).abs().max() / a.fp.grad.abs().max())
+    _note("staged_graph.grad_relerr_after_parameter_change", gerr)
+    assert gerr < 2e-5, gerr
+    for step in range(3):
+        la, lb = a.train_step(mov, fix), b.train_step(mov, fix)
+        assert abs(float(la[0]) - float(lb[0])) < 4e-3, (step, float(la[0]), float(lb[0]))
+    assert float((a.fp.flat - b.fp.flat).abs().max()) < 1e-3
 
 
 def test_checkpoint_resume_is_identical_to_never_stopping(tmp_path):
