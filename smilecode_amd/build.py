@@ -18,7 +18,18 @@ OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "libmodet_hip.so")
 SOURCES = ["api.hip", "na.hip", "qk_op.hip", "warp.hip", "norm_act.hip", "proj_ln.hip", "losses.hip", "conv3d.hip", "conv3d_bf16.hip", "conv3d_x3.hip", "conv3d_wtr.hip", "conv3d_q.hip", "corr3d.hip", "eval.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
+         # NO packed-fp32 code from the SLP vectoriser (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 pairs formed out of scalar
+         # source).  Round 5: with -O3 alone na_bwd_kernel's query role (27 x v_exp_f32 feeding v_pk_mul_f32 / v_pk_fma_f32
+         # chains) and cwm_tail_bwd_kernel return WRONG values in lanes 48..63 of a wave about once per 100 launches when a
+         # second process time-shares the GPU and a few high-priority streams exist in both (what two ranks on one GPU over
+         # torch.distributed's gloo CUDA path look like: tests/test_gpu_e2e.py::test_data_parallel_two_ranks_equal_batch_two,
+         # the red test of round 4).  A process alone never shows it; LDS / barrier / register probes with the same footprint
+         # never show it (tools/micro/barrier_probe.hip, reg_probe.hip); forcing every s_waitcnt to zero does not cure it; the
+         # scalar code does: 0 wrong launches in 20 000 (tools/exp_na_iso.py) and 0 bad steps in 8 000 (tools/race_hunt.py),
+         # against 227 and 63-96.  The scalar build is not slower (8.40 vs 8.46 ms per train step: the packed pairs bought
+         # nothing, the kernels that use them are latency- or memory-bound).  DESIGN.md section 6 has the whole hunt.
+         "-fno-slp-vectorize"]
 if os.environ.get("MODET_TUNING"):          # kernel-configuration overrides for tools/sweep_conv.py; never set for the product build
     FLAGS.append("-DMODET_TUNING")
 

@@ -226,6 +226,15 @@ __global__ __launch_bounds__(NTHREADS) void na_bwd_kernel(const float* __restric
   int z0, y0, x0;
   tile_origin(blockIdx.x, g, z0, y0, x0);
   if (threadIdx.x < 27) rp[threadIdx.x] = rpb[h * 27 + threadIdx.x];
+#ifdef NA_BWD_LDS_PAD            // tools: resource-footprint variants for the preemption hunt (never defined in the product build)
+  __shared__ float lds_pad[NA_BWD_LDS_PAD];
+  if (g.tiles_x < 0) { lds_pad[threadIdx.x % NA_BWD_LDS_PAD] = scale; __syncthreads(); rp[0] += lds_pad[(threadIdx.x * 7 + 1) % NA_BWD_LDS_PAD]; }
+#endif
+#ifdef NA_BWD_VGPR_CLOBBER
+#define NA_STR2(x) #x
+#define NA_STR(x) NA_STR2(x)
+  asm volatile("" ::: "v" NA_STR(NA_BWD_VGPR_CLOBBER));
+#endif
   {
     // every global load of the three staged tiles is in flight before the first LDS write (see stage_k_load)
     constexpr int AX_IT = (HVOX + NTHREADS - 1) / NTHREADS;

@@ -1,0 +1,73 @@
+"""Hypothesis H1 for the rare 1e-4 gradient error of the 2-rank overlapped test: the step's FIRST all-reduce over gloo allocates
+pinned host memory (hipHostMalloc: the buffer is mapped into the GPU's page tables) while the stage graphs are executing; later
+steps reuse the cached pinned blocks, which is why only a cold process ever fails.  Here, one process: the captured train step is
+replayed N times and, while each replay is in flight, the host does one of
+    none      nothing (control)
+    pinned    a fresh pinned allocation of a new size (hipHostMalloc) + a D2H copy into it
+    pinfree   the same, and the block is freed again (hipHostFree) right away
+    devmalloc a fresh device allocation of a new size (hipMalloc), freed with empty_cache() every few steps
+The gradient of every replay is compared with replay 0 on the device.
+
+    python tools/exp_hostmalloc.py [--replays N] [--mode none|pinned|pinfree|devmalloc] [--staged]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smilecode_amd import models, synth                      # noqa: E402
+from smilecode_amd.engine import Trainer                      # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--replays", type=int, default=400)
+ap.add_argument("--mode", default="pinned")
+ap.add_argument("--staged", action="store_true")
+ap.add_argument("--shape", default="32,48,32")
+args = ap.parse_args()
+shape = tuple(int(s) for s in args.shape.split(","))
+dev = torch.device("cuda")
+model = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).to(dev)
+models.load_numpy_weights(model, synth.make_weights(24))
+mov, fix = (torch.from_numpy(a).to(dev) for a in synth.make_pair(shape, 24, 1))
+tr = Trainer(model, overlap_allreduce=args.staged)
+tr.capture(mov, fix)
+graphs = tr._stage_graphs or [tr._graph]
+for g in graphs:
+    g.replay()
+torch.cuda.synchronize()
+ref = tr.fp.grad.clone()
+gmax = ref.abs().max()
+side = torch.cuda.Stream()
+keep, errs = [], []
+for i in range(args.replays):
+    for k, g in enumerate(graphs):
+        g.replay()
+        n = 100_000 + (1021 * i + 31 * k) % 900_000                          # a size the caching allocators have never seen
+        if args.mode in ("pinned", "pinfree"):
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                h = torch.empty(n, dtype=torch.float32, pin_memory=True)
+                h.copy_(tr.fp.grad[:n], non_blocking=True)
+            if args.mode == "pinned":
+                keep.append(h)
+            else:
+                side.synchronize()
+                del h
+                torch._C._host_emptyCache() if hasattr(torch._C, "_host_emptyCache") else None
+        elif args.mode == "devmalloc":
+            keep.append(torch.empty(n * 16, dtype=torch.float32, device=dev))
+            if i % 8 == 7:
+                keep.clear()
+                torch.cuda.empty_cache()
+    errs.append((tr.fp.grad - ref).abs().max() / gmax)
+    if i % 50 == 49:
+        torch.cuda.synchronize()
+torch.cuda.synchronize()
+E = torch.stack(errs).cpu()
+bad = torch.nonzero(E > 2e-5).flatten().tolist()
+print("mode %-9s staged %s: %d replays, gradient error vs replay 0: median %.2e max %.2e; replays above 2e-5: %d %s" % (
+    args.mode, args.staged, args.replays, E.median(), E.max(), len(bad), [(i, "%.1e" % E[i]) for i in bad[:10]]))

@@ -28,6 +28,11 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--bf16", action="store_true")
 ap.add_argument("--thresh", type=float, default=2e-5)
 ap.add_argument("--as-noise", type=float, default=0.0, help="(internal) run as the noise process for this many seconds")
+ap.add_argument("--streams", type=int, default=0, help="every process also opens this many high- and normal-priority streams and keeps "
+                "tiny kernels going on them (torch.distributed's gloo path opens a pool of 32 + 32): more hardware queues than the "
+                "GPU has slots -> the scheduler time-slices the processes' queues by preempting running waves")
+ap.add_argument("--dump", default="", help="stop at the first bad replays (up to 4) and save every tap that left its noise floor "
+                "(reference + bad values) to this .pt file")
 ap.add_argument("--eager", action="store_true", help="run the step eagerly instead of replaying a graph")
 args = ap.parse_args()
 shape = tuple(int(s) for s in args.shape.split(","))
@@ -39,6 +44,18 @@ models.load_numpy_weights(model, synth.make_weights(24))
 mov, fix = (torch.from_numpy(a).to(dev) for a in synth.make_pair(shape, 24, args.batch))
 tr = Trainer(model)
 
+extra_streams, tick = [], None
+if args.streams:
+    extra_streams = [torch.cuda.Stream(priority=-1) for _ in range(args.streams)] + [torch.cuda.Stream() for _ in range(args.streams)]
+    tick = [torch.zeros(256, device=dev) for _ in extra_streams]
+
+
+def poke():
+    for st, t in zip(extra_streams, tick):
+        with torch.cuda.stream(st):
+            t.add_(1.0)
+
+
 if args.as_noise > 0:
     tr.capture(mov, fix, verify=False)
     t0 = time.time()
@@ -46,6 +63,7 @@ if args.as_noise > 0:
     while time.time() - t0 < args.as_noise:
         for _ in range(20):
             tr._graph.replay()
+            poke()
         torch.cuda.synchronize()
         n += 20
     print("noise process: %d replays" % n)
@@ -105,10 +123,10 @@ tr.loss = loss_reset
 noise = []
 if args.noise:
     ns = args.noise_shape or args.shape
-    secs = 25 + args.replays * 0.02
+    secs = 30 + args.replays * 0.004
     for _ in range(args.noise):
         noise.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--as-noise", str(secs), "--shape", ns,
-                                       "--batch", str(args.batch)] + (["--bf16"] if args.bf16 else [])))
+                                       "--batch", str(args.batch), "--streams", str(args.streams)] + (["--bf16"] if args.bf16 else [])))
     time.sleep(12)                                   # the noise processes import torch, capture and start replaying
 
 if args.eager:
@@ -134,13 +152,43 @@ print("%d taps (%d forward, %d backward, %d parameter gradients); %d noise proce
     len(taps), len(keys_f), len(keys_b), len(names), len(noise)), flush=True)
 
 rows = []
+dumped = []
 t0 = time.time()
 for i in range(args.replays):
     step()
+    poke()
     d = torch._foreach_sub(bufs, refs)
     rows.append(torch.stack(torch._foreach_norm(d, float("inf"))) / scale)
+    if args.dump:
+        e = rows[-1].cpu()
+        hit = [j for j in range(len(taps)) if float(e[j]) > 1e-4]
+        if any(not taps[j][0].startswith("G ") for j in hit) and len(dumped) < 4:
+            dumped.append({"replay": i, "taps": {taps[j][0]: (refs[j].cpu(), bufs[j].cpu()) for j in hit}})
+            if len(dumped) == 4:
+                break
     if i % 200 == 199:
         torch.cuda.synchronize()
+if args.dump:
+    print("stopped after %d bad replays" % len(dumped))
+    for dmp in dumped:
+        name = [n for n in (t[0] for t in taps) if n in dmp["taps"] and not n.startswith("G ")][0]
+        ref, badv = dmp["taps"][name]
+        diff = (badv - ref).abs()
+        m = float(ref.abs().max())
+        idx = torch.nonzero(diff > 1e-3 * m)
+        print("==== replay %d, first bad tap %s: %d of %d elements differ by > 1e-3 of max (max|ref| %.3e, max|diff| %.3e)" % (
+            dmp["replay"], name, idx.shape[0], ref.numel(), m, float(diff.max())))
+        if idx.numel():
+            lo, hi = idx.min(0).values.tolist(), idx.max(0).values.tolist()
+            print("     index box (b, z, y, x, c): lo %s hi %s" % (lo, hi))
+            for d_ in range(1, idx.shape[1]):
+                vals = sorted(set(idx[:, d_].tolist()))
+                print("     dim %d values: %s" % (d_, vals[:40]))
+            for r_ in idx[:12].tolist():
+                t_ = tuple(r_)
+                print("       %s  ref % .5e  got % .5e" % (t_, float(ref[t_]), float(badv[t_])))
+            zeros = int((badv[diff > 1e-3 * m] == 0).sum())
+            print("     of those, exactly zero in the bad run: %d; non-finite: %d" % (zeros, int((~torch.isfinite(badv)).sum())))
 E = torch.stack(rows).cpu()                          # (replays, taps)
 dt = time.time() - t0
 alive = sum(p.poll() is None for p in noise)
@@ -153,7 +201,17 @@ print("parameter gradients vs replay 0, of global max|g|: median %.2e  p99 %.2e 
 floor = E.median(0).values
 bad = torch.nonzero(gerr > args.thresh).flatten().tolist()
 print("replays above %.0e: %d of %d %s" % (args.thresh, len(bad), args.replays, bad[:20]), flush=True)
-for i in bad[:6]:
+from collections import Counter
+first = Counter()
+for i in bad:
+    for j, (n, _) in enumerate(taps):
+        if E[i, j] > max(20 * float(floor[j]), 1e-5):
+            first[n] += 1
+            break
+print("first tap (execution order) that left its noise floor, over all bad replays:")
+for n, c in first.most_common():
+    print("   %3d x %s" % (c, n))
+for i in bad[:3]:
     print("---- replay %d: parameter-gradient error %.3e of max|g|; taps that left their noise floor, in execution order:" % (i, gerr[i]))
     shown = 0
     for j, (n, _) in enumerate(taps):
