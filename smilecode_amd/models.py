@@ -381,6 +381,13 @@ class ModeT(nn.Module):
         # bf16 storage of every level's warped features, q and k (ops.level_attention_bf16): head_dim 6 and the model's channel
         # counts only (the kernels the fused node runs), with the fused attention
         self.level_bf16 = (act_dtype == torch.bfloat16 and fused_attention and head_dim == 6 and channels == 4)
+        if self.level_bf16:
+            # the fused level node's backward is the PAIRED projection backward, which exists for the (C_in, dim) pairs of
+            # the grouped kernels only (the default num_heads gives them at every level); another head layout keeps the bf16
+            # conv chains and runs the levels on fp32 features (it used to raise in backward)
+            L = ops._L()
+            pairs = [(2 * channels * 2 ** i, head_dim * num_heads[4 - i]) for i in range(5)]
+            self.level_bf16 = all(L.modet_proj_ln_bwd_pair_ws_bytes(4096, cin, dim) > 0 for cin, dim in pairs)
         # like the reference's constructor (models.py:338-375) any inshape is accepted here; shapes that four 2x poolings
         # do not divide fail in forward(), where the reference fails too (its x2-upsampled flow no longer matches the
         # next level's grid: "The size of tensor a must match the size of tensor b")

@@ -289,6 +289,8 @@ class StepContext:
         self.dst = None              # parameter.data_ptr() -> gradient destination, while a deferred() scope is open
         self.written = set()
         self._keep = []
+        self._side = {}              # device index -> the stream the small levels' weight gradients run on (see side_stream)
+        self._side_used = None
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -351,6 +353,9 @@ class StepContext:
             sc = self.sc
             super().__exit__(*exc)
             sc.dst = None
+            if sc._side_used is not None:                # the partial tiles the side stream produced: join before reducing them
+                torch.cuda.current_stream().wait_stream(sc._side_used)
+                sc._side_used = None
             rc = _L().modet_conv3d_wgrad_defer_flush(sc.handle, _stream())    # always empties the queue, also on an exception
             sc._keep = []
             if exc[0] is None:
@@ -367,6 +372,21 @@ class StepContext:
         pointers written are in ``scope.written``.  A conv without a destination, or a second use of the same weight inside
         one scope, takes the immediate path."""
         return StepContext._Deferred(self, dst)
+
+    def side_stream(self, like):
+        """Fork: the stream the weight gradients of the SMALL levels run on, made to wait for everything enqueued on the
+        current stream so far (their operands).  Pyramid levels 3-5 and the CWM layers are latency-bound launches of 100-1000
+        workgroups on 256 CUs; the data gradient is what the next layer waits for, the weight gradient is needed only at the end
+        of the pass (the deferred reduction), so the two chains run side by side -- as two branches of the captured hipGraph.
+        The scope's flush joins.  Callers keep the operands alive until then (``_keep``): a tensor freed on the main stream
+        could otherwise be handed out again while the side stream still reads it."""
+        dev = like.device.index if like.device.index is not None else torch.cuda.current_device()
+        side = self._side.get(dev)
+        if side is None:
+            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        self._side_used = side
+        return side
 
     def destinations(self, w, b, want_bias):
         """(d_w, d_bias) destinations for this call, or None -> immediate path"""
@@ -395,6 +415,14 @@ def _h(step):
     return None if step is None else step.handle
 
 
+# Weight gradients of launches with at most this many voxels (batch included) run on the step context's side stream, beside
+# the data-gradient chain (StepContext.side_stream); 0 = everything on one stream (the default).  Measured in round 5
+# (profiles/r05s_ab_side_wgrad.txt, 160x192x160, one box, alternating): 0 -> 8.29 / 8.35 ms, 700 000 (levels 3-5 + CWM) ->
+# 8.65 / 8.32, 1 300 000 -> 8.34, everything -> 8.34: no gain -- every fork is an extra cross-stream edge of the hipGraph (the
+# host cost of a replay goes from 0.27 to 1.03 ms) and the 17 forks cost what the overlap of those 20-50 us kernels buys.
+SIDE_WGRAD_MAX_VOXELS = float(os.environ.get("MODET_SIDE_WGRAD_MAX_VOXELS", "0"))
+
+
 def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=None):
     """d_w, d_bias; with y_act (ConvBlock 1 -> 4 only) dy is the gradient w.r.t. LeakyReLU(conv) and the activation's
     derivative is applied while loading it.  With a StepContext (given, or bound to this thread) whose ``deferred()`` scope
@@ -405,20 +433,28 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
     Cout = dy.shape[-1]
     L = _L()
     nb = L.modet_conv3d_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)
-    ws = _ws(nb, x)
     n = float(B) * D * H * W
     scope = step if step is not None else current_step()
     dst = scope.destinations(w, b, want_bias) if scope is not None else None
     if dst is not None:
         dw, db = dst
-        with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
-            _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
-                                                       Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
+        if SIDE_WGRAD_MAX_VOXELS and n <= SIDE_WGRAD_MAX_VOXELS and _TIMER is None:
+            with torch.cuda.stream(scope.side_stream(x)):
+                ws = _ws(nb, x)
+                _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
+                                                           Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
+            scope._keep.extend((x, dy, y_act))                # read by the side stream: alive until the flush joins it
+        else:
+            ws = _ws(nb, x)
+            with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+                _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
+                                                           Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
         scope._keep.append(ws)                                # the partial tiles must survive until the flush
         scope.written.add(w.data_ptr())
         if db is not None:
             scope.written.add(b.data_ptr())
         return None, None
+    ws = _ws(nb, x)
     dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
@@ -455,8 +491,9 @@ class _Conv3d(Function):
             with _Guard(dy, "lrelu_bwd", dy.numel(), 12.0 * dy.numel()):
                 _lib.check(_L().modet_lrelu_bwd(_p(dy), _p(y), _p(g), dy.numel(), _stream()), "modet_lrelu_bwd")
             dy = g
-        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step) if ctx.needs_input_grad[0] else None
+        # (the weight gradient first: on the small levels it goes to the side stream and runs beside the data gradient)
         dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step)
+        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step) if ctx.needs_input_grad[0] else None
         return dx, dw, db, None
 
 
@@ -491,8 +528,8 @@ class _Conv3dStats(Function):
             return None, None, None
         x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step) if ctx.needs_input_grad[0] else None
         dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step)
+        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step) if ctx.needs_input_grad[0] else None
         return dx, dw, db
 
 
@@ -599,6 +636,7 @@ class _InstNormConv(Function):
         V = D * H * W
         L = _L()
         d_raw = None
+        dw, db = conv3d_backward_weight(y, dz, ctx.has_bias, w=w, b=b, step=ctx.step)      # (first: see _Conv3d.backward)
         if ctx.needs_input_grad[0]:
             d_raw = torch.empty_like(x_raw)
             rb = L.modet_conv3d_bwd_data_instats_bytes(B, D, H, W, C, Cout) if FUSE_IN_DGRAD else 0
@@ -624,7 +662,6 @@ class _InstNormConv(Function):
                 with _Guard(x_raw, "instnorm_lrelu_bwd", 14.0 * x_raw.numel(), 12.0 * x_raw.numel()):
                     _lib.check(L.modet_instnorm_lrelu_bwd(_p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(d_raw), _p(ws), nb, B, V, C,
                                                           _stream()), "modet_instnorm_lrelu_bwd")
-        dw, db = conv3d_backward_weight(y, dz, ctx.has_bias, w=w, b=b, step=ctx.step)
         return d_raw, None, dw, db, None, None
 
 

@@ -38,7 +38,7 @@ def _start_job(name):
 
 
 _MULTI_PROCESS = ("test_data_parallel_two_ranks_equal_batch_two", "test_staged_step_through_the_nccl_backend",
-                  "test_train_and_infer_scripts_synthetic")
+                  "test_train_and_infer_scripts_synthetic", "test_attention_backward_is_bit_stable_beside_another_process")
 
 
 def pytest_collection_modifyitems(config, items):

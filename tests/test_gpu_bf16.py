@@ -657,6 +657,21 @@ def test_instnorm_apply_pool_bf16_is_the_two_pass_form():
         assert torch.equal(pooled, ref)
 
 
+def test_bf16_mode_with_another_head_layout_trains():
+    """the fused bf16 level node needs the paired projection backward, which exists for the default
+    (C_in, dim) pairs only; num_heads=[4,4,2,1,1] (level 5: 128 -> 24) used to run forward and raise in backward.  Such a
+    model now keeps the bf16 conv chains and runs its levels on fp32 features."""
+    from smilecode_amd import losses, models, synth
+    shape = (32, 48, 32)
+    m = models.ModeT(shape, head_dim=6, num_heads=[4, 4, 2, 1, 1], scale=1, act_dtype=torch.bfloat16).cuda()
+    assert not m.level_bf16 and not m.encoder.features16
+    mov, fix = (torch.from_numpy(a).cuda() for a in synth.make_pair(shape, 24))
+    y, flow = m(mov, fix)
+    loss = losses.NCC_vxm()(fix, y) + losses.Grad3d(penalty="l2")(flow, fix)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
 def test_bf16_staged_backward_matches_the_plain_one():
     """engine.Trainer(overlap_allreduce=True) cuts the autograd graph at the level features; in bf16 mode those are fp32 handles
     carrying bf16 data (ops.feature_handle_like keeps the data on the cut leaves): the three-stage backward must give the plain
