@@ -209,6 +209,11 @@ int modet_conv3d_bwd_weight_defer(const float* x, const float* d_y, const float*
                                   void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
                                   modet_stream_t stream, modet_step_ctx_t* step);
 int modet_conv3d_wgrad_defer_flush(modet_step_ctx_t* step, modet_stream_t stream);
+/* Round 5: for the many-channel layers of the small pyramid levels the deferred call queues the partial-tile LAUNCH as well
+ * (17 launches of 20-50 us per train step, most too small to fill the chip); the flush runs all queued layers of one kernel
+ * variant as one grid, then the reductions.  modet_conv3d_wgrad_defers_operands(..) == 1 says that a deferred call of this
+ * shape reads x and d_y at the FLUSH, not at the call: the caller keeps them alive and untouched until then, too. */
+int modet_conv3d_wgrad_defers_operands(int B, int D, int H, int W, int Cin, int Cout);
 
 
 /* InstanceNorm3d(affine=False, eps, biased variance) + LeakyReLU(0.1) (ConvInsBlock, models.py:135-151).
@@ -300,6 +305,13 @@ int modet_warp_fwd_t(const void* src, int src_bf16, const float* flow, void* out
                      modet_stream_t stream);
 int modet_warp_bwd_t(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow, int B,
                      int D, int H, int W, int C, int add_flow, int flow_bound, modet_stream_t stream);
+/* Round 5: the same with a SECOND gradient of `flow` added on the way out (d_flow = d loss / d flow through this warp +
+ * d_flow_add; d_flow_add may be NULL).  A flow field feeds a feature warp AND the next composition: autograd would run an
+ * element-wise add over two full-size tensors (5 launches and 0.07 ms per 160x192x160 step); the warp node that sees the
+ * other consumer's gradient first hands it in here instead (ops.warp_tee).  Not with flow_bound. */
+int modet_warp_bwd_acc(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow,
+                       const float* d_flow_add, int B, int D, int H, int W, int C, int add_flow, int flow_bound,
+                       modet_stream_t stream);
 /* d_src and/or d_flow; either may be NULL.  Trilinear only.
  * flow_bound = 0: arbitrary flow, d_src is zeroed here and scatter-added with float atomics (as ATen does).
  * flow_bound = 1: the CALLER guarantees |flow| <= 1 voxel everywhere (true for the attention output w of

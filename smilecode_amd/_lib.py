@@ -52,6 +52,7 @@ SIGNATURES = {
     "modet_conv3d_prepack_end": (I, [P]),
     "modet_conv3d_bwd_weight_defer": (I, [P, P, P, P, P, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_wgrad_defer_flush": (I, [P, P]),
+    "modet_conv3d_wgrad_defers_operands": (I, [I, I, I, I, I, I]),
     "modet_instnorm_ws_bytes": (SZ, [I, I64, I]),
     "modet_instnorm_lrelu_fwd": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
     "modet_instnorm_lrelu_fwd_stats": (I, [P, P, P, P, P, SZ, I, I64, I, F, P]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "modet_warp_fwd_o16": (I, [P, P, P, I, I, I, I, I, P]),
     "modet_warp_fwd_t": (I, [P, I, P, P, I, I, I, I, I, I, P]),
     "modet_warp_bwd_t": (I, [P, I, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "modet_warp_bwd_acc": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "modet_warp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "modet_upsample2_fwd": (I, [P, P, I, I, I, I, I, F, P]),
     "modet_upsample2_bwd": (I, [P, P, I, I, I, I, I, F, P]),

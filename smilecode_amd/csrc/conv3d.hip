@@ -1778,6 +1778,8 @@ int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, floa
 // (Cin >= 12, and the few-channel layers below its voxel threshold); MODET_CONV_WTR=0 restores the exact-f32 kernels (A/B switch)
 bool modetx_wtr_eligible(int B, int D, int H, int W, int Cin, int Cout);
 size_t modetx_wtr_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
+bool modetx_wtr_batches(int B, int D, int H, int W);
+void modetx_wtr_flush(modet_step_ctx* c, hipStream_t s);
 int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
                      int W, int Cin, int Cout, hipStream_t s);
 static bool use_x3(int B, int D, int H, int W, int Cin, int Cout) {
@@ -2132,9 +2134,14 @@ static void reduce_or_defer(const ReduceJob& j, int blocks, hipStream_t s, modet
                        j.n_ci, j.cit, j.ng);
 }
 
+int modet_conv3d_wgrad_defers_operands(int B, int D, int H, int W, int Cin, int Cout) {
+  return use_wtr_wgrad(B, D, H, W, Cin, Cout) && modetx_wtr_batches(B, D, H, W) ? 1 : 0;
+}
+
 int modet_conv3d_wgrad_defer_flush(modet_step_ctx_t* c, modet_stream_t stream) {
   MODET_CHECK_PTR(c);
-  modetx_bf16_defer_flush(c, (hipStream_t)stream);        // the queue of modet_conv3d_bf16_bwd_weight_defer
+  modetx_wtr_flush(c, (hipStream_t)stream);               // queued partial-tile launches, one grid per kernel variant ...
+  modetx_bf16_defer_flush(c, (hipStream_t)stream);        // ... then the queue of reductions (modet_conv3d_bf16_bwd_weight_defer's too)
   std::vector<ReduceJob> jobs;
   std::vector<int> blocks;
   {

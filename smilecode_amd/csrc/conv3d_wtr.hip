@@ -88,13 +88,31 @@ struct WtrArgs {
   const float* x; const float* dy; float* part;
   int B, D, H, W, Cin, Cout, tiles_x, tiles_y, tiles_z, ntiles, n_coblk;
 };
+// One launch, SEVERAL layers (round 5): the weight gradients of pyramid levels 3-5 and of the CWM layers are 17 launches per
+// train step of 20-50 us each, most of them far too small to fill 256 CUs (level 5: 24 workgroups) and every one paying its
+// own ramp-up and tail.  Nothing waits for a weight gradient before the end of the backward pass, so the step context queues
+// them (modetx_wtr_wgrad with a deferring context) and the flush launches all queued layers of one kernel variant as ONE grid:
+// workgroup b belongs to the job whose [first, first + gx * gy) range holds it.  Per workgroup nothing changes (same tiles,
+// same order, same partial row), so the results are bit-identical to the one-launch-per-layer form.
+constexpr int WTR_MAX_JOBS = 8;
+struct WtrTable {
+  WtrArgs job[WTR_MAX_JOBS];
+  int first[WTR_MAX_JOBS + 1], gx[WTR_MAX_JOBS], gy[WTR_MAX_JOBS];
+  int n;
+};
 
 #ifndef WTR_VARIANT
 #define WTR_VARIANT 8
 #endif
 // WTR_VARIANT bit 1: no register prefetch of the next tile's global loads; bit 2: no operand prefetch of the next family
 template <int NQ, int NT, bool VEC>
-__global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrArgs a) {
+__global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrTable t) {
+  int job = 0;
+  while (job + 1 < t.n && (int)blockIdx.x >= t.first[job + 1]) ++job;     // (scalar: blockIdx is uniform)
+  const WtrArgs a = t.job[job];
+  const int grid_x = t.gx[job], grid_y = t.gy[job];
+  const int lb = (int)blockIdx.x - t.first[job];       // flat index inside the job's (grid_x, grid_y) grid, y fastest
+  const int blk_x = lb / grid_y, blk_y = lb - blk_x * grid_y;
   constexpr int NF = (9 * NQ + 3) / 4;                 // families: 4 chunks of the list q = (dz, dy) * NQ + quad
   constexpr int MT = 3 * NF;                           // M tiles = (family, dx); slot MT = bias
   constexpr int KS = NT;                               // k-steps per wave and tile
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrArgs a)
   const int kg = lane >> 4, S = lane & 15, sj = S >> 2, sc = S & 3;
   const int nw = NT == 2 ? (wave & 1) : 0;             // this wave's N tile
   const int s_first = NT == 2 ? 2 * (wave >> 1) : wave;                 // its first k-step: z = s >> 1, rows 4 (s & 1) + kg
-  const int cib = blockIdx.y / a.n_coblk, cob = blockIdx.y - cib * a.n_coblk;
+  const int cib = blk_y / a.n_coblk, cob = blk_y - cib * a.n_coblk;
   const int ci0 = cib * 4 * NQ, co0 = cob * 16 * NT;
   const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
 
@@ -236,13 +254,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrArgs a)
 #else
 #define TPH(k) do { } while (0)
 #endif
-  int tile = blockIdx.x;
+  int tile = blk_x;
   if (!(WTR_VARIANT & 2) && tile < a.ntiles) load_tile(tile);
 #ifdef MODET_TUNING
   tq0 = __builtin_readcyclecounter();
   tph[5] = tq0 - t_entry;
 #endif
-  for (; tile < a.ntiles; tile += gridDim.x) {
+  for (; tile < a.ntiles; tile += grid_x) {
     if (WTR_VARIANT & 2) load_tile(tile);
     TPH(0);
     __syncthreads();                                   // every wave is done with the previous tile's images
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrArgs a)
     TPH(2);
     __syncthreads();
     TPH(3);
-    if (!(WTR_VARIANT & 2) && tile + (int)gridDim.x < a.ntiles) load_tile(tile + gridDim.x);
+    if (!(WTR_VARIANT & 2) && tile + grid_x < a.ntiles) load_tile(tile + grid_x);
     if (WTR_VARIANT & 8) __builtin_amdgcn_s_setprio(0);
     TPH(0);
     // ---- MFMA phase.  Unit = (k-step ks, family f): 9 transpose reads -> fragments of dx = 0, 1, 2 -> 18 MFMAs on three
@@ -339,12 +357,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrArgs a)
     }
   }
   __syncthreads();
-  float* out = a.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)RED_FL;
+  float* out = a.part + (size_t)lb * (size_t)RED_FL;   // = (blk_x * grid_y + blk_y): the row order the reduction expects
   for (int i = tid * 4; i < RED_FL; i += NTHR * 4) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(red + i);
 #ifdef MODET_TUNING
   TPH(6);
   if (g_wtr_dbg && lane == 0) {
-    long long* o = g_wtr_dbg + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    long long* o = g_wtr_dbg + ((int64_t)(blk_y * grid_x + blk_x) * 4 + wave) * 8;
     for (int i = 0; i < 7; ++i) o[i] = tph[i];
     o[7] = t_entry;
   }
@@ -394,19 +412,67 @@ size_t modetx_wtr_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   const int gx = p.gy >= 512 ? 1 : 512 / p.gy;         // upper bound of the plan's gx
   return ((size_t)gx + 1) * p.gy * p.red_fl * sizeof(float);      // workgroup partials + their column sums
 }
-int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
-                     int W, int Cin, int Cout, hipStream_t s) {
-  const WtrPlan p = wtr_plan(B, D, H, W, Cin, Cout);
-  WtrArgs a{x, dy, (float*)ws, B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles, p.n_coblk};
-  const dim3 grid(p.gx, p.gy);
-  const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
-#define WTR_L(NQ_, NT_, V_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<NQ_, NT_, V_>), grid, dim3(NTHR), 0, s, a)
-#define WTR_Q(NT_, V_) do { if (p.nq == 4) WTR_L(4, NT_, V_); else if (p.nq == 3) WTR_L(3, NT_, V_); else if (p.nq == 2) WTR_L(2, NT_, V_); else WTR_L(1, NT_, V_); } while (0)
-  if (p.nt == 2) WTR_Q(2, true);                       // (eligibility: the odd channel counts only come with Cout <= 16)
+// launch the jobs of ONE kernel variant (nq, nt, vec) as one grid
+static void wtr_launch(const WtrTable& t, int nq, int nt, bool vec, hipStream_t s) {
+  const dim3 grid(t.first[t.n]);
+#define WTR_L(NQ_, NT_, V_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<NQ_, NT_, V_>), grid, dim3(NTHR), 0, s, t)
+#define WTR_Q(NT_, V_) do { if (nq == 4) WTR_L(4, NT_, V_); else if (nq == 3) WTR_L(3, NT_, V_); else if (nq == 2) WTR_L(2, NT_, V_); else WTR_L(1, NT_, V_); } while (0)
+  if (nt == 2) WTR_Q(2, true);                         // (eligibility: the odd channel counts only come with Cout <= 16)
   else if (vec) WTR_Q(1, true);
   else WTR_Q(1, false);
 #undef WTR_Q
 #undef WTR_L
+}
+
+// does a DEFERRED call keep reading x / d_y until the context's flush?  (the caller must keep them alive then)
+#ifndef WTR_BATCH_MAX_VOXELS
+#define WTR_BATCH_MAX_VOXELS 1500000      // (tools: build with -DWTR_BATCH_MAX_VOXELS=0 for the one-launch-per-layer A side)
+#endif
+bool modetx_wtr_batches(int B, int D, int H, int W) { return (int64_t)B * D * H * W <= WTR_BATCH_MAX_VOXELS; }
+
+int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
+                     int W, int Cin, int Cout, hipStream_t s) {
+  const WtrPlan p = wtr_plan(B, D, H, W, Cin, Cout);
+  const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
   float* red = (float*)ws + (size_t)p.gx * p.gy * p.red_fl;
+  if (defer && modetx_wtr_batches(B, D, H, W)) {       // queued: the flush launches it together with its variant's other layers
+    WtrQueued j{x, dy, (float*)ws, B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles, p.n_coblk, p.nq, p.nt, vec ? 1 : 0,
+                p.gx, p.gy};
+    {
+      std::lock_guard<std::mutex> lk(defer->mu);
+      defer->wtrjobs.push_back(j);
+    }
+    return modetx_wgrad_partials_reduce2(defer, (const float*)ws, red, dw, db, p.gx, p.gy, Cin, Cout, p.nq, p.mt, p.nt, p.n_coblk, s);
+  }
+  WtrTable t;
+  t.job[0] = WtrArgs{x, dy, (float*)ws, B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles, p.n_coblk};
+  t.first[0] = 0; t.first[1] = p.gx * p.gy; t.gx[0] = p.gx; t.gy[0] = p.gy; t.n = 1;
+  wtr_launch(t, p.nq, p.nt, vec, s);
   return modetx_wgrad_partials_reduce2(defer, (const float*)ws, red, dw, db, p.gx, p.gy, Cin, Cout, p.nq, p.mt, p.nt, p.n_coblk, s);
+}
+
+// the queued partial-tile launches of a deferring context, grouped by kernel variant (called by the flush BEFORE the reductions)
+void modetx_wtr_flush(modet_step_ctx* c, hipStream_t s) {
+  std::vector<WtrQueued> jobs;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    jobs.swap(c->wtrjobs);
+  }
+  std::vector<char> done(jobs.size(), 0);
+  for (size_t i = 0; i < jobs.size(); ++i) {
+    if (done[i]) continue;
+    WtrTable t;
+    t.n = 0; t.first[0] = 0;
+    for (size_t k = i; k < jobs.size() && t.n < WTR_MAX_JOBS; ++k) {
+      const WtrQueued& q = jobs[k];
+      if (done[k] || q.nq != jobs[i].nq || q.nt != jobs[i].nt || q.vec != jobs[i].vec) continue;
+      t.job[t.n] = WtrArgs{q.x, q.dy, q.part, q.B, q.D, q.H, q.W, q.Cin, q.Cout, q.tiles_x, q.tiles_y, q.tiles_z, q.ntiles, q.n_coblk};
+      t.gx[t.n] = q.gx; t.gy[t.n] = q.gy;
+      t.first[t.n + 1] = t.first[t.n] + q.gx * q.gy;
+      ++t.n;
+      done[k] = 1;
+    }
+    for (int k = t.n; k < WTR_MAX_JOBS; ++k) { t.first[k + 1] = t.first[t.n]; t.gx[k] = 1; t.gy[k] = 1; }
+    wtr_launch(t, jobs[i].nq, jobs[i].nt, jobs[i].vec != 0, s);
+  }
 }

@@ -41,6 +41,13 @@ struct BRedJob {
                 // 2: conv_wgrad_tr_kernel (conv3d_wtr.hip): cib = NQ, u = MT, ntb = NT; M tile = 4 chunks of q = tap * NQ + quad
 };
 
+// a queued conv_wgrad_tr_kernel launch (conv3d_wtr.hip): the flush groups them by kernel variant (nq, nt, vec) into one grid each
+struct WtrQueued {
+  const float* x; const float* dy; float* part;
+  int B, D, H, W, Cin, Cout, tiles_x, tiles_y, tiles_z, ntiles, n_coblk;
+  int nq, nt, vec, gx, gy;
+};
+
 struct modet_step_ctx {
   std::mutex mu;                      // forward runs on the caller's thread, backward on the autograd engine's
   bool recording = false, active = false;
@@ -53,4 +60,5 @@ struct modet_step_ctx {
   std::vector<ReduceJob> rjobs;       // deferred fp32 weight-gradient reductions
   std::vector<int> rblocks;
   std::vector<BRedJob> brjobs;        // deferred bf16 weight-gradient reductions
+  std::vector<WtrQueued> wtrjobs;     // deferred partial-tile launches of the many-channel weight gradients
 };

@@ -154,8 +154,8 @@ constexpr int ZRUN = 8;
 template <bool S16>
 __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                        const float* __restrict__ dout, float* __restrict__ dsrc,
-                                                       float* __restrict__ dflow, int D, int H, int W, int C, int G,
-                                                       int64_t total, int add_flow) {
+                                                       float* __restrict__ dflow, const float* __restrict__ dfadd, int D, int H,
+                                                       int W, int C, int G, int64_t total, int add_flow) {
   // total = B * ceil(D/ZRUN) * H * W * G items (one per run)
   const int64_t V = (int64_t)D * H * W;
   const int nrun = (D + ZRUN - 1) / ZRUN;
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
         }
         if (inr && zin && c == 0) {
           float* dfp = dflow + n * 3;
+          if (dfadd) { const float* ap = dfadd + n * 3; gz += ap[0]; gy += ap[1]; gx += ap[2]; }     // (uniform)
           dfp[0] = gz; dfp[1] = gy; dfp[2] = gx;
         }
       }
@@ -345,8 +346,8 @@ __device__ __forceinline__ WbRsrc wb_rsrc(const void* base, unsigned bytes) {
 template <int ZR, int YR, bool S16>
 __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                         const float* __restrict__ dout, float* __restrict__ dsrc,
-                                                        float* __restrict__ dflow, int B, int D, int H, int W, int C, int G,
-                                                        unsigned total, int add_flow) {
+                                                        float* __restrict__ dflow, const float* __restrict__ dfadd, int B, int D,
+                                                        int H, int W, int C, int G, unsigned total, int add_flow) {
   // total = B * ceil(D/ZR) * ceil(H/YR) * W * G items (one per patch column)
   const int V = D * H * W;
   const unsigned nzr = (unsigned)((D + ZR - 1) / ZR), nyr = (unsigned)((H + YR - 1) / YR);
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
   const unsigned tbytes = (unsigned)B * (unsigned)V * (unsigned)C * 4u, fbytes = (unsigned)B * (unsigned)V * 12u;
   const WbRsrc r_src = wb_rsrc(src, S16 ? tbytes / 2 : tbytes), r_flow = wb_rsrc(flow, fbytes), r_do = wb_rsrc(dout, tbytes);
   const WbRsrc r_ds = wb_rsrc(dsrc, dsrc ? tbytes : 0u), r_df = wb_rsrc(dflow, dflow ? fbytes : 0u);
+  const WbRsrc r_da = wb_rsrc(dfadd ? dfadd : flow, dfadd ? fbytes : 0u);    // a second gradient of the same flow, added on the way out (0 bytes: reads 0)
   const bool want_src = dsrc != nullptr, want_flow = dflow != nullptr;
   for (unsigned idx = blockIdx.x * BLK + threadIdx.x; idx < total_pad; idx += gridDim.x * BLK) {
     const bool inr = idx < total;
@@ -501,8 +503,11 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
             gy += __shfl_xor(gy, o, 64);
             gx += __shfl_xor(gx, o, 64);
           }
-          const wb_u32x3 g3 = {__float_as_uint(gz), __float_as_uint(gy), __float_as_uint(gx)};
-          __builtin_amdgcn_raw_buffer_store_b96(g3, r_df, (inr && zin && yin && c == 0) ? (unsigned)n * 12u : WB_OOB, 0, 0);
+          const unsigned dfo = (inr && zin && yin && c == 0) ? (unsigned)n * 12u : WB_OOB;
+          const wb_u32x3 ad = __builtin_amdgcn_raw_buffer_load_b96(r_da, dfo, 0, 0);
+          const wb_u32x3 g3 = {__float_as_uint(gz + __uint_as_float(ad[0])), __float_as_uint(gy + __uint_as_float(ad[1])),
+                               __float_as_uint(gx + __uint_as_float(ad[2]))};
+          __builtin_amdgcn_raw_buffer_store_b96(g3, r_df, dfo, 0, 0);
         }
       }
       if (want_src) {                                  // run end: the last voxel's dy = 1 level
@@ -990,7 +995,14 @@ int modet_warp_bwd(const float* src, const float* flow, const float* d_out, floa
 
 int modet_warp_bwd_t(const void* srcv, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow, int B,
                      int D, int H, int W, int C, int add_flow, int flow_bound, modet_stream_t stream) {
+  return modet_warp_bwd_acc(srcv, src_bf16, flow, d_out, d_src, d_flow, nullptr, B, D, H, W, C, add_flow, flow_bound, stream);
+}
+
+int modet_warp_bwd_acc(const void* srcv, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow,
+                       const float* d_flow_add, int B, int D, int H, int W, int C, int add_flow, int flow_bound,
+                       modet_stream_t stream) {
   const float* src = (const float*)srcv;
+  if (d_flow_add && (!d_flow || flow_bound != 0)) return MODET_ERR_UNSUPPORTED;
   MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(d_out);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
   if (add_flow && C != 3) return MODET_ERR_DIM;
@@ -1014,16 +1026,16 @@ int modet_warp_bwd_t(const void* srcv, int src_bf16, const float* flow, const fl
   if (d_src && wb2 != '0' && (int64_t)B * D * H * W * (C > 3 ? C : 3) * 4 < 0x7fffffffLL && (int64_t)(D + 3) * (H + 3) * (W + 3) < (1 << 23) &&
       W * C * 4 < (1 << 23) && total2 < 0x7fffffffLL && total2 >= 256 * 256) {
     if (src_bf16) hipLaunchKernelGGL((warp_bwd2_kernel<WB2_ZR, WB2_YR, true>), dim3(flat_grid(total2, BLK)), dim3(BLK), 0, s, src, flow,
-                                     d_out, d_src, d_flow, B, D, H, W, C, G, (unsigned)total2, add_flow);
+                                     d_out, d_src, d_flow, d_flow_add, B, D, H, W, C, G, (unsigned)total2, add_flow);
     else hipLaunchKernelGGL((warp_bwd2_kernel<WB2_ZR, WB2_YR, false>), dim3(flat_grid(total2, BLK)), dim3(BLK), 0, s, src, flow, d_out,
-                            d_src, d_flow, B, D, H, W, C, G, (unsigned)total2, add_flow);
+                            d_src, d_flow, d_flow_add, B, D, H, W, C, G, (unsigned)total2, add_flow);
     return modet_launch_status();
   }
   const int64_t total = (int64_t)B * cdiv(D, ZRUN) * H * W * G;       // one item per (z run, y, x, channel slot)
   if (src_bf16) hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow,
-                                   D, H, W, C, G, total, add_flow);
-  else hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow, D,
-                          H, W, C, G, total, add_flow);
+                                   d_flow_add, D, H, W, C, G, total, add_flow);
+  else hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow,
+                          d_flow_add, D, H, W, C, G, total, add_flow);
   return modet_launch_status();
 }
 

@@ -174,7 +174,7 @@ class Trainer:
     def _capture_staged(self, moving, fixed, warmup, verify):
         """three hipGraphs sharing one pool: [forward + losses + stage 0] [stage 1] [stage 2]"""
         import torch.distributed as dist
-        self._static_in = (moving.clone(), fixed.clone())
+        self._static_in = self._static_pair(moving, fixed)
         side = torch.cuda.Stream(device=moving.device)
         side.wait_stream(torch.cuda.current_stream(moving.device))
         with torch.cuda.stream(side):
@@ -204,6 +204,16 @@ class Trainer:
         self._graph_key = (tuple(moving.shape), moving.device)
         if verify:
             self._verify_replay(ref, None, stages=graphs)
+
+    @staticmethod
+    def _static_pair(moving, fixed):
+        """the captured step's input buffers as the two halves of ONE allocation: the model's [moving; fixed] encoder batch is
+        then a view (ops.cat_batch), not a copy"""
+        B = moving.shape[0]
+        pair = torch.empty((2 * B,) + tuple(moving.shape[1:]), dtype=moving.dtype, device=moving.device)
+        pair[:B].copy_(moving)
+        pair[B:].copy_(fixed)
+        return pair[:B], pair[B:]
 
     def _verify_tolerance(self):
         """(relative L2 bound per parameter tensor, absolute floor as a fraction of the largest tensor's norm).  A healthy fp32
@@ -274,7 +284,7 @@ class Trainer:
         if self.buckets is not None:
             self._capture_staged(moving, fixed, warmup, verify)
             return self
-        self._static_in = (moving.clone(), fixed.clone())
+        self._static_in = self._static_pair(moving, fixed)
         side = torch.cuda.Stream(device=moving.device)
         side.wait_stream(torch.cuda.current_stream(moving.device))
         with torch.cuda.stream(side):

@@ -430,7 +430,7 @@ class ModeT(nn.Module):
         fix_cl = ops.to_channels_last(fixed.contiguous())
         # shared encoder on both images as one batch (InstanceNorm is per sample, so this is exact)
         with ops.trace_range("encoder"):
-            M, Fx = self.encoder.forward_pair(torch.cat([mov_cl, fix_cl], 0), B)
+            M, Fx = self.encoder.forward_pair(ops.cat_batch(mov_cl, fix_cl), B)
         if self.stage_cuts:
             # staged backward (engine.Trainer, overlapped all-reduce): the heads consume fresh LEAVES that share the features'
             # storage, so the heads' graph and the encoder's are disconnected and each stage's autograd run touches its own
@@ -442,38 +442,45 @@ class ModeT(nn.Module):
             self.cut_leaves = (M, Fx)
         ST = self.transformer
 
-        def match(lvl, proj, mdt, st, flow):
-            """the level's matching step: attention(proj(F), proj(warp(M, flow))) -> expected offset field.  bf16 storage mode
-            (act_dtype=bfloat16, fused attention): one node whose warped features, q and k are bf16 in HBM"""
+        def match(lvl, proj, mdt, flow):
+            """the level's matching step: attention(proj(F), proj(warp(M, flow))) -> (expected offset field, flow).  The
+            RETURNED flow is what the caller goes on with: the flow has a second consumer (the next composition), and the
+            feature warp's node adds that consumer's gradient inside its own backward kernel (ops.warp_tee).  bf16 storage
+            mode (act_dtype=bfloat16, fused attention): one node whose warped features, q and k are bf16 in HBM"""
             if self.level_bf16 and mdt.fused and mdt.use_rpb:
                 return ops.level_attention_bf16(Fx[lvl], M[lvl], flow, proj.proj.weight, proj.proj.bias, proj.norm.weight,
-                                                proj.norm.bias, mdt.rpb, mdt.num_heads, mdt.scale)
+                                                proj.norm.bias, mdt.rpb, mdt.num_heads, mdt.scale), flow
             if getattr(Fx[lvl], "data16", None) is not None:
                 raise RuntimeError("ModeT: bf16 level features are only readable by the fused level nodes")
-            Mw = M[lvl] if flow is None else st.forward_cl(M[lvl], flow)
+            if flow is None:
+                Mw = M[lvl]
+            else:
+                Mw, flow = ops.warp_tee(M[lvl], flow)
             q, k = proj.forward_pair(Fx[lvl], Mw)
-            return mdt(q, k)
+            return mdt(q, k), flow
 
         with ops.trace_range("level5"):
-            flow = self.cwm5(match(4, self.projblock5, self.mdt5, None, None))
+            flow = self.cwm5(match(4, self.projblock5, self.mdt5, None)[0])
 
         with ops.trace_range("level4"):
-            w = self.cwm4(match(3, self.projblock4, self.mdt4, ST[3], flow))
+            field, flow = match(3, self.projblock4, self.mdt4, flow)
+            w = self.cwm4(field)
             flow = ST[2].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
         with ops.trace_range("level3"):
-            w = self.cwm3(match(2, self.projblock3, self.mdt3, ST[2], flow))
+            field, flow = match(2, self.projblock3, self.mdt3, flow)
+            w = self.cwm3(field)
             flow = ST[1].forward_cl(ops.upsample2(flow, 2.0), w, add_flow=True)
 
         with ops.trace_range("level2"):
-            w = match(1, self.projblock2, self.mdt2, ST[1], flow)
+            w, flow = match(1, self.projblock2, self.mdt2, flow)
             # w comes straight from the attention (expected offset in [-1,1]^3): bounded-flow backward, no atomics
             flow = ops.upsample2(ST[1].forward_cl(flow, w, add_flow=True, flow_bound=1), 2.0)
 
         with ops.trace_range("level1"):
-            w = match(0, self.projblock1, self.mdt1, ST[0], flow)
+            w, flow = match(0, self.projblock1, self.mdt1, flow)
             flow = ST[0].forward_cl(flow, w, add_flow=True, flow_bound=1)
-            y_moved = ST[0].forward_cl(mov_cl, flow)
+            y_moved, flow = ops.warp_tee(mov_cl, flow)      # (the flow's other consumer: the caller, Grad3d in training)
         return ops.to_ncdhw(y_moved), ops.to_ncdhw(flow)
 
 

@@ -450,6 +450,8 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
                 _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
                                                            Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
         scope._keep.append(ws)                                # the partial tiles must survive until the flush
+        if y_act is None and L.modet_conv3d_wgrad_defers_operands(B, D, H, W, Cin, Cout):
+            scope._keep.extend((x, dy))                       # small levels: the launch itself is queued and reads them at the flush
         scope.written.add(w.data_ptr())
         if db is not None:
             scope.written.add(b.data_ptr())
@@ -1188,6 +1190,58 @@ class _Warp(Function):
             _lib.check(_L().modet_warp_bwd(_p(src), _p(flow), _p(dout), _p(dsrc), _p(dflow), B, D, H, W, C,
                                            ctx.add_flow, ctx.flow_bound if C == 3 else 0, _stream()), "modet_warp_bwd")
         return dsrc, dflow, None, None, None
+
+
+class _WarpTee(Function):
+    """warp(src, flow) for a flow that has a SECOND consumer: returns (out, flow_alias) -- the other consumer takes the alias.
+    In the backward pass the other consumer's gradient arrives here (it ran later in the forward pass, so its backward ran
+    first) and the warp kernel adds it while writing its own d_flow (modet_warp_bwd_acc): one pass instead of the
+    element-wise add autograd would launch over two full-size tensors."""
+
+    @staticmethod
+    def forward(ctx, src, flow):
+        _chk(src, flow)
+        B, D, H, W, C = src.shape
+        if tuple(flow.shape) != (B, D, H, W, 3):
+            raise RuntimeError(f"warp: flow {tuple(flow.shape)} does not match src {tuple(src.shape)}")
+        out = torch.empty_like(src)
+        n = float(B) * D * H * W
+        with _Guard(src, f"warp_fwd[C{C}]", n * (24.0 * C + 30.0), 4.0 * n * (2 * C + 3)):
+            _lib.check(_L().modet_warp_fwd(_p(src), _p(flow), _p(out), B, D, H, W, C, 0, 0, _stream()), "modet_warp_fwd")
+        ctx.save_for_backward(src, flow)
+        ctx.set_materialize_grads(False)
+        return out, flow.view_as(flow)
+
+    @staticmethod
+    def backward(ctx, dout, galias):
+        src, flow = ctx.saved_tensors
+        if dout is None:
+            return None, galias
+        dout = dout.contiguous()
+        galias = None if galias is None else galias.contiguous()
+        B, D, H, W, C = src.shape
+        dsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
+        dflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
+        n = float(B) * D * H * W
+        with _Guard(src, f"warp_bwd[C{C}]", n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6 + (3 if galias is not None else 0))):
+            _lib.check(_L().modet_warp_bwd_acc(_p(src), 0, _p(flow), _p(dout), _p(dsrc), _p(dflow), _p(galias if dflow is not None else None),
+                                               B, D, H, W, C, 0, 0, _stream()), "modet_warp_bwd_acc")
+        return dsrc, dflow
+
+
+def warp_tee(src, flow):
+    """(warp(src, flow), flow) for a flow with a second consumer, which must take the RETURNED flow; see _WarpTee"""
+    return _WarpTee.apply(src, flow)
+
+
+def cat_batch(a, b):
+    """torch.cat([a, b], 0) -- without the copy when the two are adjacent halves of one buffer (engine.Trainer's static input
+    buffer of a captured step: the [moving; fixed] batch of the shared encoder then costs nothing)"""
+    if (a.shape == b.shape and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel() and not a.requires_grad and not b.requires_grad):
+        return torch.as_strided(a, (2 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+    return torch.cat([a, b], 0)
 
 
 def warp(src, flow, mode=0, add_flow=False, flow_bound=0):

@@ -229,6 +229,58 @@ def test_warp_golden(ops, tag):
     assert np.array_equal(ncdhw(outn), g[f"{tag}.out_n"]), "nearest warp must be exact"
 
 
+@pytest.mark.parametrize("C,shape", [(8, (1, 16, 24, 32)), (1, (2, 12, 16, 20)), (16, (1, 8, 12, 16)), (8, (1, 40, 48, 40))])
+def test_warp_tee_adds_the_second_flow_gradient_in_the_kernel(C, shape):
+    """ops.warp_tee (round 5): a flow with two consumers -- the feature warp and the next composition -- whose second
+    gradient is added inside the warp's backward kernel (modet_warp_bwd_acc) instead of by an autograd add.  d_flow must be
+    BIT-identical to the two-node form (one float addition per element either way; both kernel forms: the patch kernel
+    and the z-run kernel, which the image warp without d_src takes), d_src equal up to the atomic order."""
+    from smilecode_amd import ops
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    src = torch.randn(B, D, H, W, C, generator=g).cuda()
+    flow = (torch.randn(B, D, H, W, 3, generator=g) * 2.0).cuda()
+    r1 = torch.randn(B, D, H, W, C, generator=g).cuda()
+    r2 = torch.randn(B, D, H, W, 3, generator=g).cuda()
+    for src_grad in (True, False):
+        res = []
+        for tee in (False, True):
+            s_ = src.clone().requires_grad_(src_grad)
+            f_ = flow.clone().requires_grad_(True)
+            if tee:
+                out, fl = ops.warp_tee(s_, f_)
+            else:
+                out, fl = ops.warp(s_, f_), f_
+            ((out * r1).sum() + (fl * fl * r2).sum()).backward()
+            res.append((out.detach(), f_.grad, s_.grad))
+        assert torch.equal(res[0][0], res[1][0])
+        assert torch.equal(res[0][1], res[1][1]), float((res[0][1] - res[1][1]).abs().max())
+        if src_grad:
+            assert float((res[0][2] - res[1][2]).abs().max()) <= 1e-5 * float(res[0][2].abs().max())
+    # only the alias is used / only the warp is used
+    f_ = flow.clone().requires_grad_(True)
+    out, fl = ops.warp_tee(src, f_)
+    (fl * r2).sum().backward()
+    assert torch.equal(f_.grad, r2)
+    f_ = flow.clone().requires_grad_(True)
+    out, fl = ops.warp_tee(src, f_)
+    (out * r1).sum().backward()
+    f2 = flow.clone().requires_grad_(True)
+    (ops.warp(src, f2) * r1).sum().backward()
+    assert torch.equal(f_.grad, f2.grad)
+
+
+def test_cat_batch_is_a_view_for_adjacent_halves():
+    from smilecode_amd import ops
+    pair = torch.randn(4, 6, 8, 10, 1).cuda()
+    v = ops.cat_batch(pair[:2], pair[2:])
+    assert v.data_ptr() == pair.data_ptr() and torch.equal(v, pair)
+    a, b = torch.randn(2, 6, 8, 10, 1).cuda(), torch.randn(2, 6, 8, 10, 1).cuda()
+    c = ops.cat_batch(a, b)
+    assert torch.equal(c, torch.cat([a, b], 0)) and c.data_ptr() != a.data_ptr()
+    assert torch.equal(ops.cat_batch(pair[2:], pair[:2]), torch.cat([pair[2:], pair[:2]], 0))
+
+
 def test_warp_compose_and_wide_channels(ops, orc):
     gen = torch.Generator().manual_seed(3)
     for C, shape in ((3, (7, 9, 11)), (64, (4, 5, 6)), (16, (6, 5, 9)), (1, (8, 8, 8))):
