@@ -172,9 +172,12 @@ class Encoder(nn.Module):
         self.cut = (t, leaf)
         return leaf
 
-    def forward_pair(self, x, B):
+    def forward_pair(self, x, B, handles=False):
         """x = [moving; fixed] as one batch of 2B (InstanceNorm is per sample, so this is exact); returns the per-level
-        features of each half: ([M1..M5], [F1..F5])"""
+        features of each half: ([M1..M5], [F1..F5]).  ``handles`` (ModeT.forward with the fused bf16 level nodes only): levels
+        1-4 come back as fp32 HANDLES carrying bf16 data (``.data16``) that only ops.level_attention_bf16 can read; every other
+        caller gets real fp32 features whatever ``features16`` says."""
+        features16 = self.features16 and handles
         Ms, Fs = [], []
         pooled_in = []
         if not self.bf16:
@@ -199,7 +202,7 @@ class Encoder(nn.Module):
                 if blk is self.conv2 and self.stage_cut:
                     inp = self._cut(inp)
                 pooled, m, f = ops.conv_ins_pair_bf16_pool_split(inp, blk[1].main.weight, blk[1].main.bias, blk[2].main.weight,
-                                                                 blk[2].main.bias, B, features16=self.features16)
+                                                                 blk[2].main.bias, B, features16=features16)
                 Ms.append(m)
                 Fs.append(f)
                 pooled_in.append(pooled)
@@ -430,7 +433,7 @@ class ModeT(nn.Module):
         fix_cl = ops.to_channels_last(fixed.contiguous())
         # shared encoder on both images as one batch (InstanceNorm is per sample, so this is exact)
         with ops.trace_range("encoder"):
-            M, Fx = self.encoder.forward_pair(ops.cat_batch(mov_cl, fix_cl), B)
+            M, Fx = self.encoder.forward_pair(ops.cat_batch(mov_cl, fix_cl), B, handles=self.level_bf16)
         if self.stage_cuts:
             # staged backward (engine.Trainer, overlapped all-reduce): the heads consume fresh LEAVES that share the features'
             # storage, so the heads' graph and the encoder's are disconnected and each stage's autograd run touches its own

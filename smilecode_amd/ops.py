@@ -1031,16 +1031,18 @@ class _LevelAttnBF16(Function):
 
     @staticmethod
     def forward(ctx, F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps):
-        _chk(F, M, Wt, b, gamma, beta, rpb)
+        _chk(Wt, b, gamma, beta, rpb)
         B, D, H, W, Cin = F.shape
         dim = Wt.shape[0]
         N = B * D * H * W
         L = _L()
         n = float(N)
         # level features handed over as fp32 handles with bf16 data (_InstNormLReLUBF16PoolSplit, features16): read the data
+        # (the handles themselves own one element of storage expanded to the shape)
         Fd, Md = getattr(F, "data16", None), getattr(M, "data16", None)
         Fd = F if Fd is None else Fd
         Md = M if Md is None else Md
+        _chk16(Fd, Md)
         m16 = int(Md.dtype == torch.bfloat16)
         if flow is not None:
             _chk(flow)
@@ -1713,8 +1715,10 @@ class _InstNormLReLUBF16PoolSplit(Function):
         # bf16 tensor as ``.data16``.  Autograd sees fp32 tensors of the right shape, so the consumers' fp32 gradients arrive
         # here uncast (a bf16 tensor on the edge would have them rounded to bf16, with a cast pass each); the consumers
         # (level_attention_bf16) read ``.data16`` only.
-        hm = torch.empty((Bh,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
-        hf = torch.empty((B - Bh,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        # (one element of storage expanded to the shape -- autograd checks sizes only -- not a full fp32 allocation
+        # beside the bf16 data; and only ModeT.forward ever asks for handles: Encoder.forward_pair(handles=True))
+        hm = torch.empty(1, dtype=torch.float32, device=x.device).expand((Bh,) + tuple(x.shape[1:]))
+        hf = torch.empty(1, dtype=torch.float32, device=x.device).expand((B - Bh,) + tuple(x.shape[1:]))
         hm.data16, hf.data16 = y[:Bh], y[Bh:]
         return pooled, hm, hf
 
