@@ -451,8 +451,9 @@ class ModeT(nn.Module):
             feature warp's node adds that consumer's gradient inside its own backward kernel (ops.warp_tee).  bf16 storage
             mode (act_dtype=bfloat16, fused attention): one node whose warped features, q and k are bf16 in HBM"""
             if self.level_bf16 and mdt.fused and mdt.use_rpb:
-                return ops.level_attention_bf16(Fx[lvl], M[lvl], flow, proj.proj.weight, proj.proj.bias, proj.norm.weight,
-                                                proj.norm.bias, mdt.rpb, mdt.num_heads, mdt.scale), flow
+                res = ops.level_attention_bf16(Fx[lvl], M[lvl], flow, proj.proj.weight, proj.proj.bias, proj.norm.weight,
+                                               proj.norm.bias, mdt.rpb, mdt.num_heads, mdt.scale, tee=flow is not None)
+                return res if flow is not None else (res, None)
             if getattr(Fx[lvl], "data16", None) is not None:
                 raise RuntimeError("ModeT: bf16 level features are only readable by the fused level nodes")
             if flow is None:

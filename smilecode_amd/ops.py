@@ -1030,8 +1030,10 @@ class _LevelAttnBF16(Function):
     reference: ModeT/models.py:371-376 (projection + attention of a level), :55-67 (the warp in front of it)."""
 
     @staticmethod
-    def forward(ctx, F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps):
+    def forward(ctx, F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps, tee=False):
         _chk(Wt, b, gamma, beta, rpb)
+        ctx.tee = bool(tee) and flow is not None
+        ctx.set_materialize_grads(False)
         B, D, H, W, Cin = F.shape
         dim = Wt.shape[0]
         N = B * D * H * W
@@ -1068,12 +1070,17 @@ class _LevelAttnBF16(Function):
         if need_grad:
             ctx.save_for_backward(Fd, Md, flow, Mw if flow is not None else None, q, k, Wt, b, gamma, rpb, out, lse)
         ctx.heads, ctx.scale, ctx.eps = heads, float(scale), eps
+        if ctx.tee:                                        # the flow's second consumer takes this alias (see _WarpTee)
+            return out, flow.view_as(flow)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, galias=None):
         F, M, flow, Mw, q, k, Wt, b, gamma, rpb, out, lse = ctx.saved_tensors      # (F, M: the data, fp32 or bf16)
+        if dout is None:                                   # (only the alias was used)
+            return None, None, galias, None, None, None, None, None, None, None, None, None
         dout = dout.contiguous()
+        galias = None if galias is None else galias.contiguous()
         B, D, H, W, Cin = F.shape
         dim = Wt.shape[0]
         heads = ctx.heads
@@ -1102,20 +1109,25 @@ class _LevelAttnBF16(Function):
                                                   _p(Wt), _p(b), _p(gamma), _p(dW), _p(db), _p(dg), _p(dbeta), _p(ws2), nb2, N, Cin, dim,
                                                   ctx.eps, _stream()), "modet_proj_ln_bwd_pair_t")
         if flow is None:
-            return dF, dMw, None, dW, db, dg, dbeta, drpb, None, None, None
+            return dF, dMw, None, dW, db, dg, dbeta, drpb, None, None, None, None
         dM = torch.empty(M.shape, dtype=torch.float32, device=M.device) if ctx.needs_input_grad[1] else None
         dflow = torch.empty_like(flow) if ctx.needs_input_grad[2] else None
         if dM is not None or dflow is not None:
             with _Guard(M, f"warp_bwd[C{Cin}]", n * (60.0 * Cin + 40.0), 4.0 * n * (3 * Cin + 6)):
-                _lib.check(L.modet_warp_bwd_t(_p(M), int(M.dtype == torch.bfloat16), _p(flow), _p(dMw), _p(dM), _p(dflow), B, D, H, W,
-                                              Cin, 0, 0, _stream()), "modet_warp_bwd_t")
-        return dF, dM, dflow, dW, db, dg, dbeta, drpb, None, None, None
+                _lib.check(L.modet_warp_bwd_acc(_p(M), int(M.dtype == torch.bfloat16), _p(flow), _p(dMw), _p(dM), _p(dflow),
+                                                _p(galias if dflow is not None else None), B, D, H, W, Cin, 0, 0, _stream()),
+                           "modet_warp_bwd_acc")
+        elif galias is not None:
+            dflow = galias
+        return dF, dM, dflow, dW, db, dg, dbeta, drpb, None, None, None, None
 
 
-def level_attention_bf16(F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps=1e-5):
+def level_attention_bf16(F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps=1e-5, tee=False):
     """NA(proj_ln(F), proj_ln(warp(M, flow))) with the warped features, q and k stored as bf16 (flow None: no warp); see
-    _LevelAttnBF16.  Returns the expected offset (B, D, H, W, heads * 3), fp32."""
-    return _LevelAttnBF16.apply(F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps)
+    _LevelAttnBF16.  Returns the expected offset (B, D, H, W, heads * 3), fp32; with ``tee`` (and a flow) the pair
+    (offset, flow): the flow's other consumer takes the returned flow and its gradient is added inside the node's warp
+    backward kernel (as ops.warp_tee)."""
+    return _LevelAttnBF16.apply(F, M, flow, Wt, b, gamma, beta, rpb, heads, scale, eps, tee)
 
 
 class _Corr3d(Function):

@@ -560,6 +560,33 @@ def test_level_attention_bf16_node_matches_the_unfused_ops_on_rounded_tensors():
         assert float((a - b_).abs().max()) <= tol, f"{name} of the fused bf16 level node differs"
 
 
+def test_level_attention_bf16_node_tee_adds_the_second_flow_gradient():
+    """round 5: ``tee=True`` hands the flow back as a second output; the gradient its other consumer sends is added inside the
+    node's warp backward kernel.  d_flow must be bit-identical to the node without tee + autograd's own add; everything else
+    unchanged."""
+    from smilecode_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    B, D, H, W, Cin, heads = 1, 12, 16, 20, 16, 1
+    dim = 6 * heads
+    mk = lambda *sh, s=1.0: (torch.randn(sh, device="cuda", generator=g) * s)
+    F0, M0, fl0 = mk(B, D, H, W, Cin), mk(B, D, H, W, Cin), mk(B, D, H, W, 3, s=2.0)
+    Wt0, b0, ga0, be0, rpb0 = mk(dim, Cin, s=0.3), mk(dim), mk(dim), mk(dim), mk(heads, 3, 3, 3)
+    gout, r2 = mk(B, D, H, W, heads * 3), mk(B, D, H, W, 3)
+    res = []
+    for tee in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (F0, M0, fl0, Wt0, b0, ga0, be0, rpb0)]
+        F, M, fl, Wt, b, ga, be, rpb = leaves
+        if tee:
+            out, fl2 = ops.level_attention_bf16(F, M, fl, Wt, b, ga, be, rpb, heads, 0.7, tee=True)
+        else:
+            out, fl2 = ops.level_attention_bf16(F, M, fl, Wt, b, ga, be, rpb, heads, 0.7), fl
+        res.append((out.detach(), torch.autograd.grad([out, (fl2 * fl2 * r2).sum()], leaves, [gout, None])))
+    assert torch.equal(res[0][0], res[1][0])
+    for name, a, b_ in zip(("d_F", "d_M", "d_flow", "d_W", "d_b", "d_gamma", "d_beta", "d_rpb"), res[0][1], res[1][1]):
+        tol = 1e-5 * float(b_.abs().max()) if name == "d_M" else 0.0      # (d_M: float atomics)
+        assert float((a - b_).abs().max()) <= tol, f"{name} differs with tee"
+
+
 def test_warp_and_pool_with_bf16_source_are_the_fp32_kernels_on_widened_operands():
     """modet_warp_fwd_t / modet_warp_bwd_t with a bf16 src and modet_avgpool2_fwd_x16 (cfg 5: level features stored as bf16): bit-
     identical to the fp32 entry points fed with the widened values (d_src goes through float atomics: compared to rounding noise),
