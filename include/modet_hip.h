@@ -312,6 +312,16 @@ int modet_warp_bwd_t(const void* src, int src_bf16, const float* flow, const flo
 int modet_warp_bwd_acc(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow,
                        const float* d_flow_add, int B, int D, int H, int W, int C, int add_flow, int flow_bound,
                        modet_stream_t stream);
+/* Round 5, opt-in: the same backward with a DETERMINISTIC d_src.  The scatter-add of the eight corner weights runs on float
+ * atomics above (as ATen's grid_sampler_3d_backward, reference ModeT/models.py:67): d_src depends on the order the hardware
+ * retires them, ~1e-6 run to run.  Here every contribution is a 64-bit fixed-point integer (scale: a power of two from
+ * max |d_out|, 2^-40 of it per unit) added with an integer atomic -- associative, so the result is bit-identical from run to
+ * run, and with it the whole train step (these are its only atomics).  ws: modet_warp_bwd_det_ws_bytes (8 bytes per element
+ * of d_src + a header); costs a max pre-pass and a decode pass.  d_src is required; no flow_bound (that path has no atomics). */
+size_t modet_warp_bwd_det_ws_bytes(int B, int D, int H, int W, int C);
+int modet_warp_bwd_det(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow,
+                       const float* d_flow_add, void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, int add_flow,
+                       modet_stream_t stream);
 /* d_src and/or d_flow; either may be NULL.  Trilinear only.
  * flow_bound = 0: arbitrary flow, d_src is zeroed here and scatter-added with float atomics (as ATen does).
  * flow_bound = 1: the CALLER guarantees |flow| <= 1 voxel everywhere (true for the attention output w of

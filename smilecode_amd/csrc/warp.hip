@@ -151,12 +151,48 @@ __global__ __launch_bounds__(BLK) void warp_fwd_kernel(const float* __restrict__
 //    source plane higher it absorbs them into its dz=0 half, otherwise they are flushed.
 // Smooth flow: ~2 atomics per (voxel, channel) instead of 8.
 constexpr int ZRUN = 8;
-template <bool S16>
+// DETERMINISTIC form of the scatter (round 5, opt-in: modet_warp_bwd_det): float atomics make d_src depend on the order the
+// hardware retires them (1e-6 run to run -- as ATen's grid_sampler_3d_backward, reference ModeT/models.py:67).  Here every
+// contribution is converted to a 64-bit FIXED-POINT integer (scale = a power of two chosen from max |d_out| so that 2^23
+// contributions of the largest size fit) and added with an integer atomic: integer addition is associative, so the sums --
+// and with them the whole train step, whose only atomics these are -- are bit-identical from run to run.  What a thread adds
+// (its merged carries) is itself a fixed sequence of float operations.  Resolution 2^-40 of max |d_out|: finer than fp32.
+// Costs the max pre-pass, an 8-byte accumulator per element and the decode pass (tests, debugging, exact reproduction).
+__device__ __forceinline__ double det_scale(const unsigned* header) {
+  const float m = __uint_as_float(header[0]);                       // max |d_out| (bit pattern: atomicMax on the uint is exact)
+  int e;
+  frexpf(m > 0.f ? m : 1.f, &e);                                    // m < 2^e
+  return ldexp(1.0, 40 - e);
+}
+template <bool DET>
+__device__ __forceinline__ void scat_add(float* p, float v, const float* base, long long* acc, double scale) {
+  if constexpr (DET) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc + (p - base)), (unsigned long long)__double2ll_rn((double)v * scale));
+  } else {
+    atomicAdd(p, v);
+  }
+}
+__global__ __launch_bounds__(BLK) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ header) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(header, __float_as_uint(m));
+}
+__global__ __launch_bounds__(BLK) void det_decode_kernel(const long long* __restrict__ acc, float* __restrict__ out, int64_t n,
+                                                         const unsigned* __restrict__ header) {
+  const double inv = 1.0 / det_scale(header);
+  for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) out[i] = (float)((double)acc[i] * inv);
+}
+
+template <bool S16, bool DET = false>
 __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                        const float* __restrict__ dout, float* __restrict__ dsrc,
                                                        float* __restrict__ dflow, const float* __restrict__ dfadd, int D, int H,
-                                                       int W, int C, int G, int64_t total, int add_flow) {
+                                                       int W, int C, int G, int64_t total, int add_flow,
+                                                       long long* __restrict__ dacc = nullptr, const unsigned* __restrict__ dhdr = nullptr) {
   // total = B * ceil(D/ZRUN) * H * W * G items (one per run)
+  const double dscale = DET ? det_scale(dhdr) : 0.0;
   const int64_t V = (int64_t)D * H * W;
   const int nrun = (D + ZRUN - 1) / ZRUN;
   const int64_t HW = (int64_t)H * W;
@@ -271,12 +307,12 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (pend[q] != 0.f) atomicAdd(db + poff + ((q >> 1) ? sYc : 0) + ((q & 1) ? sXc : 0), pend[q]);
+              if (pend[q] != 0.f) scat_add<DET>(db + poff + ((q >> 1) ? sYc : 0) + ((q & 1) ? sXc : 0), pend[q], dsrc, dacc, dscale);
           }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                        // the dz=0 half is final now
-          if (cv[q] != 0.f) atomicAdd(db + off0 + ((q >> 1) ? sYc : 0) + ((q & 1) ? sXc : 0), cv[q]);
+          if (cv[q] != 0.f) scat_add<DET>(db + off0 + ((q >> 1) ? sYc : 0) + ((q & 1) ? sXc : 0), cv[q], dsrc, dacc, dscale);
           pend[q] = cv[4 + q];
         }
         pz = t.z0 + 1; py = t.y0; px = t.x0; poff = off0 + sZc;
@@ -301,7 +337,7 @@ __global__ __launch_bounds__(BLK) void warp_bwd_kernel(const float* __restrict__
     if (db && have) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (pend[q] != 0.f) atomicAdd(db + poff + ((q >> 1) ? sYc : 0) + ((q & 1) ? sXc : 0), pend[q]);
+        if (pend[q] != 0.f) scat_add<DET>(db + poff + ((q >> 1) ? sYc : 0) + ((q & 1) ? sXc : 0), pend[q], dsrc, dacc, dscale);
     }
   }
 }
@@ -343,12 +379,14 @@ __device__ __forceinline__ WbRsrc wb_rsrc(const void* base, unsigned bytes) {
 // 24-bit integer multiplies (full rate; v_mul_lo_u32 is quarter rate), per-axis validity as -1 / 0 masks folded into the
 // weights, flow as ONE 12-byte load, the x neighbour test on ONE shuffled value (the cell's byte offset: equal offsets = same
 // cell, see above), d_flow sums as (upper - lower) differences.
-template <int ZR, int YR, bool S16>
+template <int ZR, int YR, bool S16, bool DET = false>
 __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                         const float* __restrict__ dout, float* __restrict__ dsrc,
                                                         float* __restrict__ dflow, const float* __restrict__ dfadd, int B, int D,
-                                                        int H, int W, int C, int G, unsigned total, int add_flow) {
+                                                        int H, int W, int C, int G, unsigned total, int add_flow,
+                                                        long long* __restrict__ dacc = nullptr, const unsigned* __restrict__ dhdr = nullptr) {
   // total = B * ceil(D/ZR) * ceil(H/YR) * W * G items (one per patch column)
+  const double dscale = DET ? det_scale(dhdr) : 0.0;
   const int V = D * H * W;
   const unsigned nzr = (unsigned)((D + ZR - 1) / ZR), nyr = (unsigned)((H + YR - 1) / YR);
   const unsigned total_pad = (total + BLK - 1) / BLK * BLK;       // keep whole waves alive for the shuffles
@@ -386,7 +424,12 @@ __global__ __launch_bounds__(BLK) void warp_bwd2_kernel(const float* __restrict_
         if (lane == 0) { atomicAdd(g_wb_dbg, 1ull); atomicAdd(g_wb_dbg + 1, (unsigned long long)__builtin_popcountll(m)); }
       }
 #endif
-      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r_ds, v != 0.f ? (unsigned)off : WB_OOB, 0, 0);
+      if constexpr (DET) {                             // (see scat_add: 64-bit fixed point, order-independent)
+        if (v != 0.f) atomicAdd(reinterpret_cast<unsigned long long*>(dacc) + ((unsigned)off >> 2),
+                                (unsigned long long)__double2ll_rn((double)v * dscale));
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r_ds, v != 0.f ? (unsigned)off : WB_OOB, 0, 0);
+      }
     };
     auto flush2 = [&](int off, float v0, float v1) {   // (for the rarely taken paths: skipped when no lane has anything)
       if (v0 != 0.f) atom(off, v0);
@@ -1036,6 +1079,47 @@ int modet_warp_bwd_acc(const void* srcv, int src_bf16, const float* flow, const 
                                    d_flow_add, D, H, W, C, G, total, add_flow);
   else hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src, d_flow,
                           d_flow_add, D, H, W, C, G, total, add_flow);
+  return modet_launch_status();
+}
+
+size_t modet_warp_bwd_det_ws_bytes(int B, int D, int H, int W, int C) {
+  return 64 + (size_t)B * D * H * W * C * sizeof(long long);
+}
+
+int modet_warp_bwd_det(const void* srcv, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow,
+                       const float* d_flow_add, void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, int add_flow,
+                       modet_stream_t stream) {
+  const float* src = (const float*)srcv;
+  MODET_CHECK_PTR(src); MODET_CHECK_PTR(flow); MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_src); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
+  if (add_flow && C != 3) return MODET_ERR_DIM;
+  if (src_bf16 && add_flow) return MODET_ERR_UNSUPPORTED;
+  if (d_flow_add && !d_flow) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_warp_bwd_det_ws_bytes(B, D, H, W, C)) return MODET_ERR_WORKSPACE;
+  int G = 1;
+  while (G < C) G <<= 1;
+  if (G > 64) return MODET_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = (int64_t)B * D * H * W * C;
+  unsigned* hdr = (unsigned*)ws;
+  long long* acc = (long long*)((char*)ws + 64);
+  modet_zero_async(ws, 64 + (size_t)n * sizeof(long long), s);
+  hipLaunchKernelGGL(absmax_kernel, dim3(flat_grid(n, BLK)), dim3(BLK), 0, s, d_out, n, hdr);
+  const int64_t total2 = (int64_t)B * cdiv(D, WB2_ZR) * cdiv(H, WB2_YR) * W * G;
+  if ((int64_t)B * D * H * W * (C > 3 ? C : 3) * 4 < 0x7fffffffLL && (int64_t)(D + 3) * (H + 3) * (W + 3) < (1 << 23) &&
+      W * C * 4 < (1 << 23) && total2 < 0x7fffffffLL && total2 >= 256 * 256) {
+    if (src_bf16) hipLaunchKernelGGL((warp_bwd2_kernel<WB2_ZR, WB2_YR, true, true>), dim3(flat_grid(total2, BLK)), dim3(BLK), 0, s, src,
+                                     flow, d_out, d_src, d_flow, d_flow_add, B, D, H, W, C, G, (unsigned)total2, add_flow, acc, hdr);
+    else hipLaunchKernelGGL((warp_bwd2_kernel<WB2_ZR, WB2_YR, false, true>), dim3(flat_grid(total2, BLK)), dim3(BLK), 0, s, src, flow,
+                            d_out, d_src, d_flow, d_flow_add, B, D, H, W, C, G, (unsigned)total2, add_flow, acc, hdr);
+  } else {
+    const int64_t total = (int64_t)B * cdiv(D, ZRUN) * H * W * G;
+    if (src_bf16) hipLaunchKernelGGL((warp_bwd_kernel<true, true>), dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src,
+                                     d_flow, d_flow_add, D, H, W, C, G, total, add_flow, acc, hdr);
+    else hipLaunchKernelGGL((warp_bwd_kernel<false, true>), dim3(flat_grid(total, BLK)), dim3(BLK), 0, s, src, flow, d_out, d_src,
+                            d_flow, d_flow_add, D, H, W, C, G, total, add_flow, acc, hdr);
+  }
+  hipLaunchKernelGGL(det_decode_kernel, dim3(flat_grid(n, BLK)), dim3(BLK), 0, s, (const long long*)acc, d_src, n, (const unsigned*)hdr);
   return modet_launch_status();
 }
 

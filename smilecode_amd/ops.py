@@ -1114,9 +1114,7 @@ class _LevelAttnBF16(Function):
         dflow = torch.empty_like(flow) if ctx.needs_input_grad[2] else None
         if dM is not None or dflow is not None:
             with _Guard(M, f"warp_bwd[C{Cin}]", n * (60.0 * Cin + 40.0), 4.0 * n * (3 * Cin + 6)):
-                _lib.check(L.modet_warp_bwd_acc(_p(M), int(M.dtype == torch.bfloat16), _p(flow), _p(dMw), _p(dM), _p(dflow),
-                                                _p(galias if dflow is not None else None), B, D, H, W, Cin, 0, 0, _stream()),
-                           "modet_warp_bwd_acc")
+                _warp_backward(M, flow, dMw, dM, dflow, galias, 0, 0)
         elif galias is not None:
             dflow = galias
         return dF, dM, dflow, dW, db, dg, dbeta, drpb, None, None, None, None
@@ -1201,9 +1199,35 @@ class _Warp(Function):
         n = float(B) * D * H * W
         tag = "warp_bwd_gather3[C3]" if (C == 3 and ctx.flow_bound) else f"warp_bwd[C{C}]"     # the kernel that runs
         with _Guard(src, tag, n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6)):
-            _lib.check(_L().modet_warp_bwd(_p(src), _p(flow), _p(dout), _p(dsrc), _p(dflow), B, D, H, W, C,
-                                           ctx.add_flow, ctx.flow_bound if C == 3 else 0, _stream()), "modet_warp_bwd")
+            _warp_backward(src, flow, dout, dsrc, dflow, None, ctx.add_flow, ctx.flow_bound if C == 3 else 0)
         return dsrc, dflow, None, None, None
+
+
+# Deterministic warp backward (opt-in; modet_warp_bwd_det): d_src through 64-bit fixed-point integer atomics instead of float
+# atomics -- bit-identical from run to run, and so is the whole train step (the warp scatter holds its only atomics).
+DETERMINISTIC = os.environ.get("MODET_DETERMINISTIC", "0") == "1"
+
+
+def set_deterministic(on=True):
+    """run-to-run bit-identical gradients (costs ~0.2 ms per 160x192x160 train step); returns the previous setting"""
+    global DETERMINISTIC
+    prev, DETERMINISTIC = DETERMINISTIC, bool(on)
+    return prev
+
+
+def _warp_backward(src, flow, dout, dsrc, dflow, galias, add_flow, flow_bound):
+    """launch the warp backward: plain (float atomics; galias = a second flow gradient added on the way out) or deterministic"""
+    B, D, H, W, C = src.shape
+    L = _L()
+    s16 = int(src.dtype == torch.bfloat16)
+    if DETERMINISTIC and dsrc is not None and not flow_bound:
+        nb = L.modet_warp_bwd_det_ws_bytes(B, D, H, W, C)
+        ws = torch.empty((nb + 7) // 8, dtype=torch.int64, device=src.device)
+        _lib.check(L.modet_warp_bwd_det(_p(src), s16, _p(flow), _p(dout), _p(dsrc), _p(dflow), _p(galias if dflow is not None else None),
+                                        _p(ws), nb, B, D, H, W, C, int(add_flow), _stream()), "modet_warp_bwd_det")
+        return
+    _lib.check(L.modet_warp_bwd_acc(_p(src), s16, _p(flow), _p(dout), _p(dsrc), _p(dflow), _p(galias if dflow is not None else None),
+                                    B, D, H, W, C, int(add_flow), int(flow_bound), _stream()), "modet_warp_bwd_acc")
 
 
 class _WarpTee(Function):
@@ -1238,8 +1262,7 @@ class _WarpTee(Function):
         dflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
         n = float(B) * D * H * W
         with _Guard(src, f"warp_bwd[C{C}]", n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6 + (3 if galias is not None else 0))):
-            _lib.check(_L().modet_warp_bwd_acc(_p(src), 0, _p(flow), _p(dout), _p(dsrc), _p(dflow), _p(galias if dflow is not None else None),
-                                               B, D, H, W, C, 0, 0, _stream()), "modet_warp_bwd_acc")
+            _warp_backward(src, flow, dout, dsrc, dflow, galias, 0, 0)
         return dsrc, dflow
 
 

