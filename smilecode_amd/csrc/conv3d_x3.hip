@@ -44,9 +44,44 @@ __device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned sho
   const float r2 = r1 - bf16_to_f32(mid);
   lo = to_bf16(r2);
 }
+// ---- TWO f16 pieces (round 5: the FORWARD launches).  x = hi + lo with hi = f16(x), lo = f16(x - hi): the residual is exact
+// in fp32 and |lo| <= 2^-11 |x|, so the pair carries x to 2^-22 |x| (to 2^-25 absolute where lo is subnormal in f16, |x| <
+// 0.125 -- gfx950's f16 MFMA keeps subnormal inputs: tools/micro/f16_denorm_probe.hip), and a product is the THREE piece
+// products hi*hi + hi*lo + lo*hi (the dropped lo*lo is 2^-22 |a b|): half the matrix-pipe work of the six bf16 products.  The
+// price is range -- f16 overflows at 65 504 and the split degrades below 6e-5 -- so this form serves the FORWARD convolutions
+// only, whose operands are images in [0,1], LeakyReLU(InstanceNorm(.)) activations and weights; gradients (any magnitude) stay on
+// three bf16 pieces.  Measured error against fp64 on the parity tests' data: 3e-7 of max|y| (bf16x3: 1e-7; the tests' bound 2e-5).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_f16(float u, float v) {               // two roundings to nearest even, packed
+  typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  const h16x2 t = __builtin_convertvector((f32x2){u, v}, h16x2);
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ void unpk_f16(unsigned p, float& u, float& v) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
+  const h16x2 t = __builtin_bit_cast(h16x2, p);
+  u = (float)t[0]; v = (float)t[1];
+}
+__device__ __forceinline__ void split2_h(float x, unsigned short& hi, unsigned short& lo) {
+  const _Float16 h = (_Float16)x;
+  const _Float16 l = (_Float16)(x - (float)h);
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, l);
+}
 #ifndef X3_VARIANT
 #define X3_VARIANT 0
 #endif
+#ifndef X3_F16_FWD
+#define X3_F16_FWD 1                     // forward launches on two f16 pieces (0: three bf16 pieces everywhere)
+#endif
+// The low piece of a value below 0.125 is SUBNORMAL in f16 (absolute resolution 2^-25): conv weights (|w| <= 1 / sqrt(27 Cin) ~
+// 0.05-0.1) would all sit there and carry only ~20 bits.  Both operands are therefore scaled by exact powers of two before the
+// split -- weights x 2^8 (normal low pieces down to |w| = 5e-4, overflow only beyond |w| = 255), activations x 2^4 (normal down
+// to 8e-3, overflow beyond 4 094: LeakyReLU(InstanceNorm(.)) is bounded by sqrt(V)) -- and the accumulator is scaled back by
+// 2^-12 in the epilogue's fma with the bias: no rounding anywhere in the scaling.  (The 4-channel instantiation -- the layer
+// behind ConvBlock 1 -> 4, the one forward launch whose input is not normalised -- leaves its activations unscaled.)
+constexpr float X3_F16_WSCALE = 256.f, X3_F16_XSCALE = 16.f;
 __device__ __forceinline__ unsigned pk_bf16(float u, float v) {             // v_cvt_pk_bf16_f32: two roundings to nearest even
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -91,13 +126,19 @@ struct X3Geo {
   static constexpr int CoP = 16 / P;                                       // cout slots per packed row
 };
 
+template <bool F16>
+__device__ __forceinline__ f32x4 x3_mma(bf16x8 a, bf16x8 b, f32x4 c) {       // (F16: the 16-byte fragments hold f16)
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------ weight packing
 // wpk[((dz * NS + s) * npiece + piece) * 64 + lane] = 8 bf16: the MFMA A fragment (row m = lane & 15, k chunk c = 4 s + (lane >> 4)).
 //   chunk -> (tap, channels):  CIN 8: tap = c, channels 0..7;  CIN 16: tap = c / 2, channels 8 (c & 1) ..+7;
 //                              CIN 4: element j < 4: tap 2c, channel j;  j >= 4: tap 2c + 1, channel j - 4.
 //   tap = dyp * 3 + dx;  row m = p * CoP + co holds W((dz, dyp - p, dx); channel -> co) when 0 <= dyp - p <= 2, else 0.
 //   mode 0 (forward): w[co][ch][tap27]   w: (Cout, Cin, 27);   mode 1 (dgrad): w[ch][co][26 - tap27]   w: (Co = ch, Ci = co, 27)
-struct X3PackJob { const float* w; unsigned short* wpk; int Cin, Cout, cin_t, P, mode, npiece; };   // npiece 3 (fp32 emulation) | 1 (bf16)
+struct X3PackJob { const float* w; unsigned short* wpk; int Cin, Cout, cin_t, P, mode, npiece; };   // npiece 3 (fp32 emulation, bf16) | 2 (the same on f16 pieces) | 1 (bf16 storage)
 constexpr int X3PACK_MAX_JOBS = 40;
 struct X3PackTable { X3PackJob job[X3PACK_MAX_JOBS]; int n; };
 
@@ -121,8 +162,13 @@ __device__ __forceinline__ void x3_pack_body(const X3PackJob& J, int i0, int str
       v = J.mode == 0 ? J.w[((int64_t)co * J.Cin + ch) * 27 + t27] : J.w[((int64_t)ch * J.Cout + co) * 27 + 26 - t27];
     }
     unsigned short h, md, l;
-    split3(v, h, md, l);
     unsigned short* o = J.wpk + ((size_t)((dz * NS + s) * J.npiece) * 64 + lane) * 8 + j;
+    if (J.npiece == 2) {                                                  // two f16 pieces (forward launches), weights x 2^8
+      split2_h(v * X3_F16_WSCALE, h, l);
+      o[0] = h; o[per_piece] = l;
+      continue;
+    }
+    split3(v, h, md, l);
     o[0] = h;                                                             // npiece 1: the weight rounded to bf16
     if (J.npiece == 3) { o[per_piece] = md; o[2 * per_piece] = l; }
   }
@@ -173,13 +219,19 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   // STATS 2 (8 / 16 input channels): the LOW piece of the weights lives in LDS, the other two in registers -- its A
   // fragments are read once per (plane, k-step) and feed the last MFMAs of the unit; frees 36 registers for the statistics
   // (X3_VARIANT bits 4 / 8, tuning builds: the low piece / the two low pieces in LDS for every fp32 instantiation with 8+ channels)
+  constexpr int NPX = NPC == 1 ? 1 : NPC;                                  // pieces per operand in the product loops
+  // f16 pieces: activation scale (4 input channels = the layer behind ConvBlock 1 -> 4, whose input is NOT normalised: unscaled,
+  // so that it only overflows beyond 65 504) and the scale that takes the accumulator back
+  constexpr float XSC = CIN == 4 ? 1.f : X3_F16_XSCALE, OSC = 1.f / (X3_F16_WSCALE * XSC);
   constexpr int NPR = (NPC != 3 || WLDS || CIN < 8) ? NPC                  // pieces kept in registers
                       : ((X3_VARIANT & 8) && CIN == 8) ? 1 : ((STATS == 2 || (X3_VARIANT & 4)) ? 2 : 3);
   constexpr bool WLO = NPR < NPC;
   constexpr int WL_B = WLDS ? 3 * NS * NPC * 1024 : (WLO ? 3 * NS * (NPC - NPR) * 1024 : 16);
   static_assert(UNITS % 4 == 0, "row groups split over 4 waves");
   static_assert(Q >= 1 && NTHR % Q == 0, "a thread's staging items share one channel group");
-  static_assert(NPC == 3 || !NORM, "the lazily normalised input exists for the fp32 form only");
+  static_assert(NPC != 1 || !NORM, "the lazily normalised input exists for the fp32 forms only");
+  static_assert(NPC == 1 || NPC == 2 || NPC == 3, "pieces per operand");
+  static_assert(NPC != 2 || STATS != 2, "two f16 pieces: forward launches only");
   static_assert(NPC == 1 || (!IN16 && !OUT16), "bf16 tensors belong to the one-piece form");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLOT_B];
   __shared__ __attribute__((aligned(16))) unsigned char wl[WL_B];
@@ -269,6 +321,34 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
         const float4 t = xr[S][j];
         if constexpr (IN16) *reinterpret_cast<uint4*>(sl + loff[j]) = __builtin_bit_cast(uint4, t);     // 8 bf16, untouched
         else *reinterpret_cast<uint2*>(sl + loff[j]) = make_uint2(pk_bf16(t.x, t.y), pk_bf16(t.z, t.w));
+      }
+      return;
+    }
+    if constexpr (NPC == 2) {                                              // two f16 pieces: hi, then the exact residual
+      unsigned hi2[NIT][2], lo2[NIT][2];
+      float4 t[NIT];
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        t[j] = xr[S][j];
+        if constexpr (NORM) {
+          const bool on = xr_live[S] && ((okmask >> j) & 1u);
+          t[j].x = on ? lrelu((t[j].x - nm.x) * nr.x) : 0.f; t[j].y = on ? lrelu((t[j].y - nm.y) * nr.y) : 0.f;
+          t[j].z = on ? lrelu((t[j].z - nm.z) * nr.z) : 0.f; t[j].w = on ? lrelu((t[j].w - nm.w) * nr.w) : 0.f;
+        }
+        t[j].x *= XSC; t[j].y *= XSC; t[j].z *= XSC; t[j].w *= XSC;
+      }
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) { hi2[j][0] = pk_f16(t[j].x, t[j].y); hi2[j][1] = pk_f16(t[j].z, t[j].w); }
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        float a0, a1, a2, a3;
+        unpk_f16(hi2[j][0], a0, a1); unpk_f16(hi2[j][1], a2, a3);
+        lo2[j][0] = pk_f16(t[j].x - a0, t[j].y - a1); lo2[j][1] = pk_f16(t[j].z - a2, t[j].w - a3);
+      }
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        *reinterpret_cast<uint2*>(sl + loff[j]) = make_uint2(hi2[j][0], hi2[j][1]);
+        *reinterpret_cast<uint2*>(sl + PLANE_B + loff[j]) = make_uint2(lo2[j][0], lo2[j][1]);
       }
       return;
     }
@@ -401,7 +481,7 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
       return __builtin_bit_cast(bf16x8, wreg[dz][s][pc < NPR ? pc : 0]);
     } else return __builtin_bit_cast(bf16x8, wreg[dz][s][pc]);
   };
-#define X3_MM(ACC, WP, XP) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[WP], xf[XP], ACC, 0, 0, 0)
+#define X3_MM(ACC, WP, XP) ACC = x3_mma<NPC == 2>(w[WP], xf[XP], ACC)
   // one input plane (LDS slot) into the three output planes it touches; C = q % 3: dz -> accumulator (C - dz) mod 3
   auto compute = [&](auto cc, int slot, bool a0, bool a1, bool a2) {
     constexpr int C = decltype(cc)::value;
@@ -424,30 +504,31 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
     } else if (a0 && a1 && a2) {
       // (k-step, row group) units in order; the three B fragments of unit u+1 are read from LDS before the 18 MFMAs of unit u
       constexpr int NXQ = STATS == 2 ? 1 : 2;                  // (STATS 2: no register room for the second buffer)
-      bf16x8 xq[NXQ][3];
+      bf16x8 xq[NXQ][NPX];
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) xq[0][pc] = frag(sl, pc, 0, 0);
+      for (int pc = 0; pc < NPX; ++pc) xq[0][pc] = frag(sl, pc, 0, 0);
 #pragma unroll
       for (int u = 0; u < NS * R; ++u) {
         const int s = u / R, r = u % R;
         if (NXQ == 1 && u > 0) {
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) xq[0][pc] = frag(sl, pc, r, s);
+          for (int pc = 0; pc < NPX; ++pc) xq[0][pc] = frag(sl, pc, r, s);
         }
         if (NXQ == 2 && u + 1 < NS * R) {
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) xq[(u + 1) % NXQ][pc] = frag(sl, pc, (u + 1) % R, (u + 1) / R);
+          for (int pc = 0; pc < NPX; ++pc) xq[(u + 1) % NXQ][pc] = frag(sl, pc, (u + 1) % R, (u + 1) / R);
         }
         // keep the reads up here: left alone the scheduler sinks them to their first use to save registers and every
         // unit then starts with an exposed LDS round trip (seen in the ISA: ds_read, s_waitcnt lgkmcnt(0), v_mfma)
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 w0[3], w1[3], w2[3];
+        bf16x8 w0[NPX], w1[NPX], w2[NPX];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) { w0[pc] = wfrag(0, s, pc); w1[pc] = wfrag(1, s, pc); w2[pc] = wfrag(2, s, pc); }
+        for (int pc = 0; pc < NPX; ++pc) { w0[pc] = wfrag(0, s, pc); w1[pc] = wfrag(1, s, pc); w2[pc] = wfrag(2, s, pc); }
         const bf16x8* xf = xq[u % NXQ];
         // small terms first; the three accumulators alternate so that back-to-back MFMAs are independent
 #define X3_ALL(WP, XP) { bf16x8* w = w0; X3_MM(acc[S0][r], WP, XP); } { bf16x8* w = w1; X3_MM(acc[S1][r], WP, XP); } { bf16x8* w = w2; X3_MM(acc[S2][r], WP, XP); }
-        if constexpr (WLO) { X3_ALL(0, 2) X3_ALL(1, 1) X3_ALL(1, 0) X3_ALL(0, 1) X3_ALL(0, 0) X3_ALL(2, 0) }   // LDS-resident piece last
+        if constexpr (NPC == 2) { X3_ALL(1, 0) X3_ALL(0, 1) X3_ALL(0, 0) }                                  // f16 pair: three products
+        else if constexpr (WLO) { X3_ALL(0, 2) X3_ALL(1, 1) X3_ALL(1, 0) X3_ALL(0, 1) X3_ALL(0, 0) X3_ALL(2, 0) }   // LDS-resident piece last
         else { X3_ALL(2, 0) X3_ALL(0, 2) X3_ALL(1, 1) X3_ALL(1, 0) X3_ALL(0, 1) X3_ALL(0, 0) }
 #undef X3_ALL
         __builtin_amdgcn_sched_barrier(0);
@@ -457,11 +538,12 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
       for (int s = 0; s < NS; ++s) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          bf16x8 xf[3];
+          bf16x8 xf[NPX];
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) xf[pc] = frag(sl, pc, r, s);
-#define X3_ONE(DZ, SL) { bf16x8 w[3]; for (int pc = 0; pc < 3; ++pc) w[pc] = wfrag(DZ, s, pc); \
-            X3_MM(acc[SL][r], 2, 0); X3_MM(acc[SL][r], 0, 2); X3_MM(acc[SL][r], 1, 1); X3_MM(acc[SL][r], 1, 0); X3_MM(acc[SL][r], 0, 1); X3_MM(acc[SL][r], 0, 0); }
+          for (int pc = 0; pc < NPX; ++pc) xf[pc] = frag(sl, pc, r, s);
+#define X3_ONE(DZ, SL) { bf16x8 w[NPX]; for (int pc = 0; pc < NPX; ++pc) w[pc] = wfrag(DZ, s, pc); \
+            if constexpr (NPC == 2) { X3_MM(acc[SL][r], 1, 0); X3_MM(acc[SL][r], 0, 1); X3_MM(acc[SL][r], 0, 0); } \
+            else { X3_MM(acc[SL][r], NPX - 1, 0); X3_MM(acc[SL][r], 0, NPX - 1); X3_MM(acc[SL][r], 1, 1); X3_MM(acc[SL][r], 1, 0); X3_MM(acc[SL][r], 0, 1); X3_MM(acc[SL][r], 0, 0); } }
           if (a0) X3_ONE(0, S0)
           if (a1) X3_ONE(1, S1)
           if (a2) X3_ONE(2, S2)
@@ -480,7 +562,12 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
     for (int r = 0; r < R; ++r) {
       const f32x4 v = acc[SL][r];
       acc[SL][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      float o[4] = {v[0] + b4.x, v[1] + b4.y, v[2] + b4.z, v[3] + b4.w};
+      float o[4];
+      if constexpr (NPC == 2) {                              // (the f16 operands were scaled by 2^4 x 2^8)
+        o[0] = fmaf(v[0], OSC, b4.x); o[1] = fmaf(v[1], OSC, b4.y); o[2] = fmaf(v[2], OSC, b4.z); o[3] = fmaf(v[3], OSC, b4.w);
+      } else {
+        o[0] = v[0] + b4.x; o[1] = v[1] + b4.y; o[2] = v[2] + b4.z; o[3] = v[3] + b4.w;
+      }
       if (STATS == 1) {
         const bool on = live && soff[r] != X3_OOB;
         const float e0 = on ? o[0] - k4.x : 0.f, e1 = on ? o[1] - k4.y : 0.f, e2 = on ? o[2] - k4.z : 0.f, e3 = on ? o[3] - k4.w : 0.f;
@@ -659,13 +746,17 @@ inline const uint4* x3_weights(modet_step_ctx* step, const float* w, void* ws, i
 template <bool NORM, bool STATS>
 int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s) {
   X3Args a = a0;
-  a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, 3, p, s);
+  const bool f16 = X3_F16_FWD && mode == 0;            // forward: two f16 pieces, three products (see split2_h); dgrad: bf16x3
+  a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, f16 ? 2 : 3, p, s);
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.nchunk = p.nchunk; a.ZC = p.zc; a.nitems = p.nitems;
   const dim3 grid(((p.nitems + 7) / 8) * 8);
-#define X3_L(CIN_, P_, TY_, WL_) hipLaunchKernelGGL((conv_x3_kernel<CIN_, P_, TY_, WL_, NORM, STATS>), grid, dim3(NTHR), 0, s, a)
-  if (p.cin_t == 4) { if (p.P == 2) X3_L(4, 2, 16, false); else X3_L(4, 1, 8, false); }
-  else if (p.cin_t == 8) { if (p.P == 2) X3_L(8, 2, 16, false); else X3_L(8, 1, 8, false); }
-  else X3_L(16, 1, 16, false);
+#define X3_L(CIN_, P_, TY_, WL_, NPC_) hipLaunchKernelGGL((conv_x3_kernel<CIN_, P_, TY_, WL_, NORM, STATS, NPC_>), grid, dim3(NTHR), 0, s, a)
+#define X3_D(NPC_) do { \
+    if (p.cin_t == 4) { if (p.P == 2) X3_L(4, 2, 16, false, NPC_); else X3_L(4, 1, 8, false, NPC_); } \
+    else if (p.cin_t == 8) { if (p.P == 2) X3_L(8, 2, 16, false, NPC_); else X3_L(8, 1, 8, false, NPC_); } \
+    else X3_L(16, 1, 16, false, NPC_); } while (0)
+  if (f16) X3_D(2); else X3_D(3);
+#undef X3_D
 #undef X3_L
   return modet_launch_status();
 }

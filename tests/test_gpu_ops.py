@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from tests.util import assert_close, cl, cu, gold, ncdhw, np64
+from tests.util import note as _note
 
 pytestmark = pytest.mark.gpu
 
@@ -628,6 +629,29 @@ def test_conv_q_and_transpose_read_wgrad_vs_fp64(ops, cin, cout, shape, B):
             zn = ops._InstNormLReLU.apply(z, 1e-5, zst)
             assert_close(ncdhw(zn), F.leaky_relu(F.instance_norm(refz, eps=1e-5), 0.1).numpy(), atol=1e-4, rtol=5e-5,
                          what="q normin + statistics")
+
+
+@pytest.mark.parametrize("Cin,Cout,xs,ws", [(8, 8, 1.0, 0.07), (8, 8, 300.0, 0.07), (8, 16, 2e-3, 0.07), (16, 16, 1.0, 3.0),
+                                            (16, 16, 1.0, 1e-3), (4, 8, 3000.0, 0.2), (8, 8, 1.0, 0.07)])
+def test_conv_forward_two_f16_pieces_range_and_accuracy(Cin, Cout, xs, ws):
+    """Round 5: the forward launches of the full-resolution layers run on TWO f16 pieces per operand (three products, operands
+    pre-scaled by powers of two) instead of three bf16 pieces (six products).  Against fp64 over the operand ranges the scheme
+    must cover -- activations from 2e-3 to 300 (normalised layers; 3000 on the 4-channel layer, whose input is not
+    normalised), weights from 1e-3 to 3 -- the error stays below 1e-6 of max|y| (the bf16x3 data gradient of the same
+    tensors: the same class), no overflow, no flush to zero."""
+    from smilecode_amd import ops
+    B, D, H, W = 1, 16, 24, 32
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    x = (torch.randn(B, D, H, W, Cin, generator=g) * xs).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * ws).cuda()
+    b = (torch.randn(Cout, generator=g) * ws).cuda()
+    assert ops._L().modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 0) == 2, "the z-marching family must take this shape"
+    y = ops.conv3d_forward(x, w, b, False)
+    ref = torch.nn.functional.conv3d(x.double().permute(0, 4, 1, 2, 3).cpu(), w.double().cpu(), b.double().cpu(), padding=1).permute(0, 2, 3, 4, 1)
+    assert bool(torch.isfinite(y).all())
+    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    _note(f"conv_fwd_f16x2[{Cin}->{Cout},x~{xs:g},w~{ws:g}].maxerr_of_max", err)
+    assert err < 1e-6, err
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(8, 8, (40, 50, 52)), (4, 8, (37, 46, 63)), (8, 16, (33, 42, 75)), (8, 4, (40, 41, 66))])
