@@ -64,9 +64,16 @@ def family(tag):
     return base
 
 
-# fp32-accurate matrix work on the bf16 pipe costs six bf16 MFMAs per fp32 product (csrc/conv3d_x3.hip): its ceiling in
-# algorithmic (fp32) FLOP/s is the dense bf16 peak / 6
+# fp32-accurate matrix work on the 16-bit pipe costs six bf16 MFMAs per fp32 product (three bf16 pieces per operand,
+# csrc/conv3d_x3.hip), or three f16 MFMAs (two f16 pieces per operand: the FORWARD launches of the z-marching kernel since round
+# 5; f16 and bf16 MFMA have the same dense peak): the ceiling of a family in algorithmic (fp32) FLOP/s is the dense 16-bit peak
+# divided by the FLOP-weighted mean number of piece products of its launches
 PEAK_MFMA_BF16_TFLOPS = 2500.0
+
+
+def piece_products(tag):
+    """MFMA piece products per fp32 product of one launch tag"""
+    return 3.0 if tag.split("[")[0] == "conv_fwd" and tag.endswith("@x3") else 6.0
 MFMA_F32_FAMILIES = ("conv3d_mfma_kernel", "conv3d_wgrad_kernel", "conv_c1_wgrad_mfma_kernel", "conv_direct_kernel")
 MFMA_X3_FAMILIES = ("conv_x3_kernel", "conv_x3_wgrad_kernel", "conv_wgrad_tr_kernel", "conv_q_kernel", "conv3d_bf16_kernel<SP=3>")
 
@@ -83,16 +90,21 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def roof_of(fam, flops, nbytes, sec):
-    """roofline object of one kernel family from its algorithmic work and summed duration"""
+def roof_of(fam, flops, nbytes, sec, pflops=None):
+    """roofline object of one kernel family from its algorithmic work and summed duration (pflops: the launches' FLOPs times
+    their piece products, summed -- the MFMA work actually issued)"""
     if fam in MFMA_F32_FAMILIES:
         ach = flops / sec / 1e12
         return {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS}
     if fam in MFMA_X3_FAMILIES:
-        ach, peak = flops / sec / 1e12, PEAK_MFMA_BF16_TFLOPS / 6.0
+        prod = (pflops / flops) if (pflops and flops) else 6.0
+        ach, peak = flops / sec / 1e12, PEAK_MFMA_BF16_TFLOPS / prod
         return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "peak_note": "fp32-accurate FLOPs on the bf16 pipe: dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per "
-                             "fp32 product; against the exact-f32 MFMA peak (157.3) the same number is frac_of_f32_mfma_peak",
+                "piece_products_per_fp32_product": prod,
+                "peak_note": "fp32-accurate FLOPs on the 16-bit pipe: dense bf16 / f16 MFMA peak 2500 TFLOP/s / the FLOP-weighted "
+                             "piece products per fp32 product of these launches (6 = three bf16 pieces per operand, 3 = two f16 "
+                             "pieces: the forward launches); against the exact-f32 MFMA peak (157.3) the same number is "
+                             "frac_of_f32_mfma_peak",
                 "frac_of_f32_mfma_peak": ach / PEAK_MFMA_F32_TFLOPS}
     ach = nbytes / sec / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
@@ -419,9 +431,10 @@ def main():
         breakdown[k] = dict(runs[len(runs) // 2])            # the median run of this tag
     fams = {}
     for k, v in breakdown.items():
-        d = fams.setdefault(family(k), {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "tags": set()})
+        d = fams.setdefault(family(k), {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "pflops": 0.0, "tags": set()})
         for f in ("calls", "ms", "flops", "bytes"):
             d[f] += v[f]
+        d["pflops"] += v["flops"] * piece_products(k)
         d["tags"].add(k)
     dominant = max(fams, key=lambda k: fams[k]["ms"]) if fams else None
     if rank == 0:
@@ -570,11 +583,13 @@ def main():
         roof = None
         if dominant:
             d = {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
-            for v in tsel.summary().values():
+            pfl = 0.0
+            for k, v in tsel.summary().items():
                 for f in d:
                     d[f] += v[f]
+                pfl += v["flops"] * piece_products(k)
             sec = d["ms"] * 1e-3
-            roof = roof_of(dominant, d["flops"], d["bytes"], sec)
+            roof = roof_of(dominant, d["flops"], d["bytes"], sec, pfl)
             roof["traffic"] = None
             roof.update({"kernel": dominant, "launches": d["calls"], "launches_per_step": d["calls"] / roof_steps,
                          "avg_launch_ms": d["ms"] / d["calls"], "share_of_step": d["ms"] / ((dt_eager or dt) * 1e3),
@@ -602,7 +617,7 @@ def main():
         tot_ms = sum(v["ms"] for v in fams.values()) or 1.0
         roof_top = []
         for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])[:6]:
-            r = roof_of(k, v["flops"], v["bytes"], v["ms"] * 1e-3)
+            r = roof_of(k, v["flops"], v["bytes"], v["ms"] * 1e-3, v.get("pflops"))
             r.pop("peak_note", None)
             r.update({"kernel": k, "ms_per_step": v["ms"], "launches_per_step": v["calls"], "share_of_kernel_time": v["ms"] / tot_ms})
             roof_top.append(r)

@@ -171,6 +171,20 @@ size_t modet_conv3d_bwd_data_instats_bytes(int B, int D, int H, int W, int Cin, 
 int modet_conv3d_bwd_data_instats(const float* d_y, const float* w, float* d_x, const float* x_raw, const float* mean,
                                   const float* rstd, float* rows, size_t rows_bytes, void* ws, size_t ws_bytes,
                                   int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step);
+/* modet_conv3d_bwd_data / _instats given a bound of |d_y|: dy_amax (device memory, MODET_AMAX_FLOATS floats, the bound is the
+ * max over its MODET_AMAX_SLOTS slots) >= max |d_y| over the whole tensor, as left by modet_instnorm_lrelu_bwd*_amax.  The z-marching kernel family (2) then runs the gradient on TWO f16 pieces per operand
+ * (three MFMA products, like its forward launches since round 5) instead of three bf16 pieces (six): f16 has the mantissa for
+ * it but not the range, and a gradient has no a-priori range -- d_y is scaled by the power of two that takes dy_amax to
+ * [2^14, 2^15) while it is split, the accumulator is scaled back (exact).  Elements below 2^-18 dy_amax keep an ABSOLUTE
+ * resolution of 2^-40 dy_amax (their low piece is subnormal), everything above a relative one of 2^-22; a dy_amax that is too
+ * small overflows (inf), one that is too large only moves that floor.  dy_amax == NULL, or a shape of another kernel family:
+ * exactly the plain call. */
+int modet_conv3d_bwd_data_amax(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,
+                               int W, int Cin, int Cout, const float* dy_amax, modet_stream_t stream, modet_step_ctx_t* step);
+int modet_conv3d_bwd_data_instats_amax(const float* d_y, const float* w, float* d_x, const float* x_raw, const float* mean,
+                                       const float* rstd, float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B,
+                                       int D, int H, int W, int Cin, int Cout, const float* dy_amax, modet_stream_t stream,
+                                       modet_step_ctx_t* step);
 /* d_w (Cout,Cin,3,3,3), d_bias (Cout) or NULL; deterministic two-stage reduction */
 size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modet_conv3d_bwd_weight(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes,
@@ -209,6 +223,14 @@ int modet_conv3d_bwd_weight_defer(const float* x, const float* d_y, const float*
                                   void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
                                   modet_stream_t stream, modet_step_ctx_t* step);
 int modet_conv3d_wgrad_defer_flush(modet_step_ctx_t* step, modet_stream_t stream);
+/* modet_conv3d_bwd_weight_defer (step != NULL) / modet_conv3d_bwd_weight (step == NULL) given a bound of |d_y| (see
+ * modet_conv3d_bwd_data_amax) and the promise that x is an ACTIVATION -- LeakyReLU(InstanceNorm(.)) or the first ConvBlock's
+ * output, |x| < 4000: the z-marching weight-gradient kernel then splits both operands into two f16 pieces (x by a fixed power
+ * of two, d_y by the one dy_amax gives) and runs three products instead of six.  y_act must be NULL.  dy_amax == NULL or a shape
+ * of another kernel: exactly the plain call. */
+int modet_conv3d_bwd_weight_amax(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes, int B,
+                                 int D, int H, int W, int Cin, int Cout, const float* dy_amax, modet_stream_t stream,
+                                 modet_step_ctx_t* step);
 /* Round 5: for the many-channel layers of the small pyramid levels the deferred call queues the partial-tile LAUNCH as well
  * (17 launches of 20-50 us per train step, most too small to fill the chip); the flush runs all queued layers of one kernel
  * variant as one grid, then the reductions.  modet_conv3d_wgrad_defers_operands(..) == 1 says that a deferred call of this
@@ -243,6 +265,25 @@ int modet_instnorm_lrelu_bwd_rows(const float* d_y, const float* x, const float*
 int modet_instnorm_lrelu_bwd_pool(const float* g_pooled, const float* add_a, const float* add_b, int Bh, const float* x,
                                   const float* mean, const float* rstd, float* d_x, void* ws, size_t ws_bytes, int B, int D,
                                   int H, int W, int C, modet_stream_t stream);
+/* The three InstanceNorm backward forms above that ALSO leave max |d_x| over the whole tensor in `amax` (device memory,
+ * MODET_AMAX_FLOATS floats, written by this call).  The maximum is the max over the MODET_AMAX_SLOTS elements
+ * amax[i * MODET_AMAX_STRIDE]: every wave of the apply pass maxes into the slot of its workgroup with an integer atomic on the
+ * float's bits (order-independent: deterministic), and 16 000 waves finishing together on ONE address serialise in a single L2
+ * channel (measured: +0.5 ms per train step), so the slots are 128 bytes apart.  The finalize launch in front zeroes them.
+ * It is the scale with which the convolutions that consume d_x as their d_y split it into two f16 pieces
+ * (modet_conv3d_bwd_data_amax, modet_conv3d_bwd_data_instats_amax, modet_conv3d_bwd_weight_amax).
+ * amax == NULL: exactly the plain call.  d_x is bit-identical with and without. */
+#define MODET_AMAX_SLOTS 64
+#define MODET_AMAX_STRIDE 32
+#define MODET_AMAX_FLOATS (MODET_AMAX_SLOTS * MODET_AMAX_STRIDE)
+int modet_instnorm_lrelu_bwd_amax(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
+                                  void* ws, size_t ws_bytes, int B, int64_t V, int C, float* amax, modet_stream_t stream);
+int modet_instnorm_lrelu_bwd_rows_amax(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
+                                       const float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B, int64_t V, int C,
+                                       float* amax, modet_stream_t stream);
+int modet_instnorm_lrelu_bwd_pool_amax(const float* g_pooled, const float* add_a, const float* add_b, int Bh, const float* x,
+                                       const float* mean, const float* rstd, float* d_x, void* ws, size_t ws_bytes, int B, int D,
+                                       int H, int W, int C, float* amax, modet_stream_t stream);
 /* d_x = d_y * (y > 0 ? 1 : 0.1): backward of the LeakyReLU fused into modet_conv3d_fwd(act=1) */
 int modet_lrelu_bwd(const float* d_y, const float* y, float* d_x, int64_t n, modet_stream_t stream);
 /* AvgPool3d(2) (models.py:201,:207,:213,:219); D,H,W are the INPUT dims (even). */

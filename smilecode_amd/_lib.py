@@ -66,6 +66,12 @@ SIGNATURES = {
     "modet_avgpool2_fwd_x16": (I, [P, P, I, I, I, I, I, P]),
     "modet_instnorm_lrelu_apply_pool": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "modet_instnorm_lrelu_bwd_pool": (I, [P, P, P, I, P, P, P, P, P, SZ, I, I, I, I, I, P]),
+    "modet_instnorm_lrelu_bwd_amax": (I, [P, P, P, P, P, P, SZ, I, I64, I, P, P]),
+    "modet_instnorm_lrelu_bwd_rows_amax": (I, [P, P, P, P, P, P, SZ, P, SZ, I, I64, I, P, P]),
+    "modet_instnorm_lrelu_bwd_pool_amax": (I, [P, P, P, I, P, P, P, P, P, SZ, I, I, I, I, I, P, P]),
+    "modet_conv3d_bwd_data_amax": (I, [P, P, P, P, SZ, I, I, I, I, I, I, P, P, P]),
+    "modet_conv3d_bwd_data_instats_amax": (I, [P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P, P]),
+    "modet_conv3d_bwd_weight_amax": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, P, P, P]),
     "modet_avgpool2_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "modet_proj_ln_fwd": (I, [P, P, P, P, P, P, I64, I, I, F, P]),
     "modet_proj_ln_bwd_ws_bytes": (SZ, [I64, I, I]),

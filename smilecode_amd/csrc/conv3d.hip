@@ -1766,14 +1766,15 @@ size_t modetx_x3_ws_bytes(int Cin, int Cout);
 size_t modetx_x3_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                    const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int act, int mode,
-                   hipStream_t s);
+                   hipStream_t s, const float* amax = nullptr);
 size_t modetx_x3_bst_rows_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_dgrad_bst(modet_step_ctx* step, const float* dy, const float* w, float* dx, const float* xraw, const float* mean,
-                        const float* rstd, float* rows, void* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t s);
+                        const float* rstd, float* rows, void* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t s,
+                        const float* amax = nullptr);
 bool modetx_x3_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout);
 size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
-                    int W, int Cin, int Cout, hipStream_t s);
+                    int W, int Cin, int Cout, hipStream_t s, const float* amax = nullptr);
 // bf16x3 weight gradient through LDS transpose reads (conv3d_wtr.hip): every layer the z-march kernel does not take
 // (Cin >= 12, and the few-channel layers below its voxel threshold); MODET_CONV_WTR=0 restores the exact-f32 kernels (A/B switch)
 bool modetx_wtr_eligible(int B, int D, int H, int W, int Cin, int Cout);
@@ -2062,6 +2063,14 @@ size_t modet_conv3d_bwd_data_instats_bytes(int B, int D, int H, int W, int Cin, 
 int modet_conv3d_bwd_data_instats(const float* d_y, const float* w, float* d_x, const float* x_raw, const float* mean,
                                   const float* rstd, float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B, int D,
                                   int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step) {
+  return modet_conv3d_bwd_data_instats_amax(d_y, w, d_x, x_raw, mean, rstd, rows, rows_bytes, ws, ws_bytes, B, D, H, W, Cin, Cout,
+                                            nullptr, stream, step);
+}
+
+int modet_conv3d_bwd_data_instats_amax(const float* d_y, const float* w, float* d_x, const float* x_raw, const float* mean,
+                                       const float* rstd, float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B, int D,
+                                       int H, int W, int Cin, int Cout, const float* dy_amax, modet_stream_t stream,
+                                       modet_step_ctx_t* step) {
   MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(w); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
   MODET_CHECK_PTR(x_raw); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(rows);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
@@ -2069,18 +2078,24 @@ int modet_conv3d_bwd_data_instats(const float* d_y, const float* w, float* d_x, 
   if (need == 0) return MODET_ERR_UNSUPPORTED;
   if (rows_bytes < need) return MODET_ERR_WORKSPACE;
   if (ws_bytes < fwd_ws_elems(Cout, Cin) * sizeof(float) || ws_bytes < modetx_x3_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
-  return modetx_x3_dgrad_bst(step, d_y, w, d_x, x_raw, mean, rstd, rows, ws, B, D, H, W, Cin, Cout, (hipStream_t)stream);
+  return modetx_x3_dgrad_bst(step, d_y, w, d_x, x_raw, mean, rstd, rows, ws, B, D, H, W, Cin, Cout, (hipStream_t)stream, dy_amax);
 }
 
 int modet_conv3d_bwd_data(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,
                           int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step) {
+  return modet_conv3d_bwd_data_amax(d_y, w, d_x, ws, ws_bytes, B, D, H, W, Cin, Cout, nullptr, stream, step);
+}
+
+int modet_conv3d_bwd_data_amax(const float* d_y, const float* w, float* d_x, void* ws, size_t ws_bytes, int B, int D, int H,
+                               int W, int Cin, int Cout, const float* dy_amax, modet_stream_t stream, modet_step_ctx_t* step) {
   MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(w); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (ws_bytes < fwd_ws_elems(Cout, Cin) * sizeof(float)) return MODET_ERR_WORKSPACE;
   // a convolution of d_y (Cout channels) producing Cin channels
   if (use_x3(B, D, H, W, Cout, Cin)) {
     if (ws_bytes < modetx_x3_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
-    return modetx_x3_conv(step, d_y, w, nullptr, d_x, ws, nullptr, nullptr, nullptr, B, D, H, W, Cout, Cin, 0, 1, (hipStream_t)stream);
+    return modetx_x3_conv(step, d_y, w, nullptr, d_x, ws, nullptr, nullptr, nullptr, B, D, H, W, Cout, Cin, 0, 1, (hipStream_t)stream,
+                          dy_amax);
   }
   if (use_q(B, D, H, W, Cout, Cin)) {
     if (ws_bytes < modetx_q_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
@@ -2113,7 +2128,7 @@ size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int
 
 static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
                                 size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
-                                modet_step_ctx* defer = nullptr);
+                                modet_step_ctx* defer = nullptr, const float* dy_amax = nullptr);
 
 // ---- deferred reductions: modet_conv3d_bwd_weight*_defer only produce the partial tiles (the workspace must stay
 // untouched until the flush) and queue the reduction in the caller's step context; modet_conv3d_wgrad_defer_flush runs
@@ -2174,6 +2189,12 @@ int modet_conv3d_bwd_weight_defer(const float* x, const float* d_y, const float*
   return conv_bwd_weight_impl(x, d_y, y_act, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, step);
 }
 
+int modet_conv3d_bwd_weight_amax(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes, int B,
+                                 int D, int H, int W, int Cin, int Cout, const float* dy_amax, modet_stream_t stream,
+                                 modet_step_ctx_t* step) {
+  return conv_bwd_weight_impl(x, d_y, nullptr, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, step, dy_amax);
+}
+
 int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias,
                                 void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
                                 modet_stream_t stream) {
@@ -2184,7 +2205,7 @@ int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y
 
 static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
                                 size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
-                                modet_step_ctx* defer) {
+                                modet_step_ctx* defer, const float* dy_amax) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (Cout > NTHR) return MODET_ERR_UNSUPPORTED;
@@ -2200,7 +2221,7 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
     return modet_launch_status();
   }
   if (!y_act && use_x3_wgrad(B, D, H, W, Cin, Cout))
-    return modetx_x3_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s);
+    return modetx_x3_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s, dy_amax);
   if (!y_act && use_wtr_wgrad(B, D, H, W, Cin, Cout))
     return modetx_wtr_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s);
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);

@@ -192,7 +192,24 @@ struct X3Args {
                                                        // InstanceNorm(xraw))): rows of sum g, sum g*xhat, g = y * lrelu'(xhat)
   int D, H, W, Cin, Cout, tiles_x, tiles_y, nchunk, ZC, nitems, act;
   long long* dbg;                                      // MODET_TUNING builds: per-(workgroup, wave) cycle sums per phase
+  const float* amax;                                   // two f16 pieces, x = a GRADIENT: amax[0] >= max |x| sets its scale (else null)
 };
+// scale of a tensor whose magnitude is only known at run time (a gradient): amax = the maximum over the slots the producer
+// left (include/modet_hip.h: modet_instnorm_lrelu_bwd_amax); the scale is the power of two that takes it into [2^14, 2^15)
+// -- f16 overflows at 65 504 -- and its inverse.  amax = m 2^e with m in [0.5, 1): scale 2^(15 - e).  Zero / non-finite: 1.
+__device__ __forceinline__ void x3_dyn_scale(const float* amax, float& sc, float& inv) {
+  float m = amax[(threadIdx.x & 63) * MODET_AMAX_STRIDE];                  // MODET_AMAX_SLOTS = 64 slots, one per lane
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  sc = 1.f; inv = 1.f;
+  if (m > 0.f && m < __builtin_huge_valf()) {
+    int e;
+    (void)frexpf(m, &e);
+    int sh = 15 - e;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    sc = ldexpf(1.f, sh); inv = ldexpf(1.f, -sh);
+  }
+}
 #ifdef MODET_TUNING
 __device__ long long* g_x3_dbg = nullptr;
 #define X3_T(i) { const long long now_ = clock64(); dsum[i] += now_ - tprev; tprev = now_; }
@@ -223,6 +240,10 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   // f16 pieces: activation scale (4 input channels = the layer behind ConvBlock 1 -> 4, whose input is NOT normalised: unscaled,
   // so that it only overflows beyond 65 504) and the scale that takes the accumulator back
   constexpr float XSC = CIN == 4 ? 1.f : X3_F16_XSCALE, OSC = 1.f / (X3_F16_WSCALE * XSC);
+  float xsc = XSC, osc = OSC;                                              // (a.amax: the input is a gradient, scaled by its maximum)
+  if constexpr (NPC == 2) {
+    if (a.amax) { float sc, inv; x3_dyn_scale(a.amax, sc, inv); xsc = sc; osc = inv * (1.f / X3_F16_WSCALE); }
+  }
   constexpr int NPR = (NPC != 3 || WLDS || CIN < 8) ? NPC                  // pieces kept in registers
                       : ((X3_VARIANT & 8) && CIN == 8) ? 1 : ((STATS == 2 || (X3_VARIANT & 4)) ? 2 : 3);
   constexpr bool WLO = NPR < NPC;
@@ -231,7 +252,6 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
   static_assert(Q >= 1 && NTHR % Q == 0, "a thread's staging items share one channel group");
   static_assert(NPC != 1 || !NORM, "the lazily normalised input exists for the fp32 forms only");
   static_assert(NPC == 1 || NPC == 2 || NPC == 3, "pieces per operand");
-  static_assert(NPC != 2 || STATS != 2, "two f16 pieces: forward launches only");
   static_assert(NPC == 1 || (!IN16 && !OUT16), "bf16 tensors belong to the one-piece form");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLOT_B];
   __shared__ __attribute__((aligned(16))) unsigned char wl[WL_B];
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
           t[j].x = on ? lrelu((t[j].x - nm.x) * nr.x) : 0.f; t[j].y = on ? lrelu((t[j].y - nm.y) * nr.y) : 0.f;
           t[j].z = on ? lrelu((t[j].z - nm.z) * nr.z) : 0.f; t[j].w = on ? lrelu((t[j].w - nm.w) * nr.w) : 0.f;
         }
-        t[j].x *= XSC; t[j].y *= XSC; t[j].z *= XSC; t[j].w *= XSC;
+        t[j].x *= xsc; t[j].y *= xsc; t[j].z *= xsc; t[j].w *= xsc;
       }
 #pragma unroll
       for (int j = 0; j < NIT; ++j) { hi2[j][0] = pk_f16(t[j].x, t[j].y); hi2[j][1] = pk_f16(t[j].z, t[j].w); }
@@ -564,7 +584,7 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (
       acc[SL][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
       float o[4];
       if constexpr (NPC == 2) {                              // (the f16 operands were scaled by 2^4 x 2^8)
-        o[0] = fmaf(v[0], OSC, b4.x); o[1] = fmaf(v[1], OSC, b4.y); o[2] = fmaf(v[2], OSC, b4.z); o[3] = fmaf(v[3], OSC, b4.w);
+        o[0] = fmaf(v[0], osc, b4.x); o[1] = fmaf(v[1], osc, b4.y); o[2] = fmaf(v[2], osc, b4.z); o[3] = fmaf(v[3], osc, b4.w);
       } else {
         o[0] = v[0] + b4.x; o[1] = v[1] + b4.y; o[2] = v[2] + b4.z; o[3] = v[3] + b4.w;
       }
@@ -746,7 +766,10 @@ inline const uint4* x3_weights(modet_step_ctx* step, const float* w, void* ws, i
 template <bool NORM, bool STATS>
 int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s) {
   X3Args a = a0;
-  const bool f16 = X3_F16_FWD && mode == 0;            // forward: two f16 pieces, three products (see split2_h); dgrad: bf16x3
+  // forward: two f16 pieces, three products (see split2_h); data gradient: the same when the caller knows max |d_y| (a.amax),
+  // else three bf16 pieces.  (LeakyReLU(InstanceNorm(.)) is bounded by sqrt(V): beyond 2^24 voxels x 2^4 could overflow f16.)
+  const bool f16 = X3_F16_FWD && (int64_t)a.D * a.H * a.W < (1ll << 24) && (mode == 0 || a.amax != nullptr);
+  if (!f16) a.amax = nullptr;
   a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, f16 ? 2 : 3, p, s);
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.nchunk = p.nchunk; a.ZC = p.zc; a.nitems = p.nitems;
   const dim3 grid(((p.nitems + 7) / 8) * 8);
@@ -764,13 +787,18 @@ int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, 
 // data gradient + InstanceNorm-backward statistics of its output (STATS = 2)
 int x3_launch_bst(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s) {
   X3Args a = a0;
-  a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, 3, p, s);
+  const bool f16 = X3_F16_FWD && a.amax != nullptr && (int64_t)a.D * a.H * a.W < (1ll << 24);
+  if (!f16) a.amax = nullptr;
+  a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, f16 ? 2 : 3, p, s);
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.nchunk = p.nchunk; a.ZC = p.zc; a.nitems = p.nitems;
   const dim3 grid(((p.nitems + 7) / 8) * 8);
-#define X3_L(CIN_, P_, TY_) hipLaunchKernelGGL((conv_x3_kernel<CIN_, P_, TY_, false, false, 2>), grid, dim3(NTHR), 0, s, a)
-  if (p.cin_t == 4) { if (p.P == 2) X3_L(4, 2, 16); else X3_L(4, 1, 8); }
-  else if (p.cin_t == 8) { if (p.P == 2) X3_L(8, 2, 16); else X3_L(8, 1, 8); }
-  else X3_L(16, 1, 16);
+#define X3_L(CIN_, P_, TY_, NPC_) hipLaunchKernelGGL((conv_x3_kernel<CIN_, P_, TY_, false, false, 2, NPC_>), grid, dim3(NTHR), 0, s, a)
+#define X3_D(NPC_) do { \
+    if (p.cin_t == 4) { if (p.P == 2) X3_L(4, 2, 16, NPC_); else X3_L(4, 1, 8, NPC_); } \
+    else if (p.cin_t == 8) { if (p.P == 2) X3_L(8, 2, 16, NPC_); else X3_L(8, 1, 8, NPC_); } \
+    else X3_L(16, 1, 16, NPC_); } while (0)
+  if (f16) X3_D(2); else X3_D(3);
+#undef X3_D
 #undef X3_L
   return modet_launch_status();
 }
@@ -808,6 +836,7 @@ constexpr int WTX = 32, WHXP = 48, WTY = 4, WHY = WTY + 2;
 struct X3WArgs {
   const void* x; const void* dy; float* part;                    // fp32; bf16 in the one-piece (storage) form
   int D, H, W, Cin, Cout, tiles_x, tiles_y, nchunk, ZC, nitems;
+  const float* amax;                                             // NPC 2: amax[0] >= max |d_y| (device memory)
 };
 
 // NP (Cout <= 8, "N-packed"): the 16 N columns are (q in {0,1}) x 8 couts, column block q = 1 multiplies d_y shifted one
@@ -817,10 +846,14 @@ struct X3WArgs {
 // (u = 0, tap dx = -1) multiplies the zero padding x[-1], so nothing is lost; d_y rows carry one extra voxel.
 // NPC = 1 (BASELINE.json configs[4], bf16 storage): d_y is bf16 in HBM, x is bf16 (X16) or fp32 rounded while staged; one
 // piece per operand, one MFMA per tile instead of six, no split -- conv3d_bf16_wgrad_kernel's contract in this structure.
+// NPC = 2 (round 5): fp32 accuracy on TWO f16 pieces per operand, three products per tile (see split2_h above).  x is an
+// activation (scaled by 2^4; 4 channels: the un-normalised output of ConvBlock 1 -> 4, unscaled, like the forward launch), d_y a
+// gradient whose maximum the caller hands over (a.amax, left by the InstanceNorm backward that produced d_y): scaled by the power
+// of two that takes it to [2^14, 2^15).  The partial tiles are scaled back (exact) before they leave the workgroup.
 template <int CIB, int NCO, bool NP, int NPC = 3, bool X16 = false>
-__global__ __launch_bounds__(NTHR, NPC == 1 ? 3 : 2) void conv_x3_wgrad_kernel(const X3WArgs a) {
+__global__ __launch_bounds__(NTHR, NPC == 3 ? 2 : 3) void conv_x3_wgrad_kernel(const X3WArgs a) {
   static_assert(!NP || NCO == 8, "N packing: 2 x 8 couts");
-  static_assert(NPC == 3 || NPC == 1, "three pieces (fp32 accuracy) or one (bf16 storage)");
+  static_assert(NPC == 3 || NPC == 2 || NPC == 1, "three bf16 / two f16 pieces (fp32 accuracy) or one (bf16 storage)");
   static_assert(NPC == 1 || !X16, "bf16 x belongs to the one-piece form");
   constexpr bool D16 = NPC == 1;                                 // d_y is bf16 in HBM
   constexpr int U = CIB == 8 ? 5 : 3;                            // tap groups: 2 (dz,dy) combos x 8 channels, or 4 x 4
@@ -862,7 +895,12 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? 3 : 2) void conv_x3_wgrad_kernel(c
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int d = 0; d < NT; ++d) acc[u][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const unsigned one2 = li == 0 ? 0x3f803f80u : 0u;              // bf16 (1, 1): row 0 of the bias tile
+  const unsigned one2 = li == 0 ? (NPC == 2 ? 0x3c003c00u : 0x3f803f80u) : 0u;   // bf16 / f16 (1, 1): row 0 of the bias tile
+  float xsc = 1.f, dsc = 1.f, dinv = 1.f;                        // NPC 2: operand scales (powers of two)
+  if constexpr (NPC == 2) {
+    xsc = CIB == 4 ? 1.f : X3_F16_XSCALE;
+    x3_dyn_scale(a.amax, dsc, dinv);
+  }
   const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2));
 
   // ---- staging maps (constant over the march): x item = (halo row hy, voxel pair, 4-channel group), d_y item = (row, pair, group)
@@ -906,8 +944,24 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? 3 : 2) void conv_x3_wgrad_kernel(c
   };
   // a voxel pair's 4 channels -> packed (voxel, voxel + 1) words in the channel planes: split into three pieces each
   // (fp32 accuracy), or one bf16 piece (rounded here if the tensor is fp32, re-paired if it already is bf16)
-  auto put = [&](unsigned short* base, int piece_el, int plane_el, const Pair& pr, bool is16) {
-    if constexpr (NPC == 1) {
+  auto put = [&](unsigned short* base, int piece_el, int plane_el, const Pair& pr, bool is16, float sc) {
+    if constexpr (NPC == 2) {
+      const float p0[4] = {pr.v0.x * sc, pr.v0.y * sc, pr.v0.z * sc, pr.v0.w * sc}, p1[4] = {pr.v1.x * sc, pr.v1.y * sc, pr.v1.z * sc, pr.v1.w * sc};
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) h[c] = pk_f16(p0[c], p1[c]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a0, a1;
+        unpk_f16(h[c], a0, a1);
+        l[c] = pk_f16(p0[c] - a0, p1[c] - a1);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsigned* d = reinterpret_cast<unsigned*>(base + c * plane_el);
+        d[0] = h[c]; d[piece_el / 2] = l[c];
+      }
+    } else if constexpr (NPC == 1) {
       unsigned w[4];
       if (is16) {
         const unsigned a0 = __float_as_uint(pr.v0.x), a1 = __float_as_uint(pr.v0.y);     // voxel 0: (c0 | c1 << 16), (c2 | c3 << 16)
@@ -933,8 +987,8 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? 3 : 2) void conv_x3_wgrad_kernel(c
       }
     }
   };
-  auto store_x = [&](int slot, const Pair& pr) { if (xon) put(xs + slot * XSLOT + xl, XPIECE, PX, pr, X16); };
-  auto store_dy = [&](int slot, const Pair& pr) { if (don) put(dys + slot * DSLOT + dl, DPIECE, PD, pr, D16); };
+  auto store_x = [&](int slot, const Pair& pr) { if (xon) put(xs + slot * XSLOT + xl, XPIECE, PX, pr, X16, xsc); };
+  auto store_dy = [&](int slot, const Pair& pr) { if (don) put(dys + slot * DSLOT + dl, DPIECE, PD, pr, D16, dsc); };
 
   // ---- one d_y plane (slot ds) against the three x planes around it: x plane of tap dz sits in ring slot (q + dz) & 3
   auto compute = [&](int q, int ds) {
@@ -954,7 +1008,7 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? 3 : 2) void conv_x3_wgrad_kernel(c
       }
     }
 #pragma unroll
-    for (int pc = NPC - 1; pc >= 0; --pc) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[pc], accb, 0, 0, 0);
+    for (int pc = NPC - 1; pc >= 0; --pc) accb = x3_mma<NPC == 2>(ones, b[pc], accb);
     // raw operand words of a group (per piece: the aligned 16-byte block and its neighbours) are read one group AHEAD of
     // the MFMAs that use them, fenced: left alone the scheduler sinks each read to its first use and every group starts
     // with an exposed LDS round trip
@@ -995,8 +1049,9 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? 3 : 2) void conv_x3_wgrad_kernel(c
       // six piece products, small terms first; the row-tile accumulators alternate (independent back-to-back MFMAs)
 #define X3W(AP, BP)                                                                                      \
       _Pragma("unroll") for (int d = 0; d < NT; ++d)                                                      \
-        acc[u][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[AP][d], b[BP], acc[u][d], 0, 0, 0);
+        acc[u][d] = x3_mma<NPC == 2>(f[AP][d], b[BP], acc[u][d]);
       if constexpr (NPC == 3) { X3W(2, 0) X3W(0, 2) X3W(1, 1) X3W(1, 0) X3W(0, 1) }
+      if constexpr (NPC == 2) { X3W(1, 0) X3W(0, 1) }
       X3W(0, 0)
 #undef X3W
       __builtin_amdgcn_sched_barrier(0);
@@ -1072,6 +1127,14 @@ __global__ __launch_bounds__(NTHR, NPC == 1 ? 3 : 2) void conv_x3_wgrad_kernel(c
   }
 #endif
 
+  if constexpr (NPC == 2) {                                        // back from the f16 operands' scales (powers of two: exact)
+    const float winv = dinv * (1.f / xsc);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int d = 0; d < NT; ++d) { acc[u][d][0] *= winv; acc[u][d][1] *= winv; acc[u][d][2] *= winv; acc[u][d][3] *= winv; }
+    accb[0] *= dinv; accb[1] *= dinv; accb[2] *= dinv; accb[3] *= dinv;
+  }
   // ---- sum the 4 waves through LDS (fixed order), one partial per workgroup
   float* red = reinterpret_cast<float*>(lds);
   for (int w4 = 0; w4 < 4; ++w4) {
@@ -1108,7 +1171,8 @@ inline X3WPlan x3w_plan(int B, int D, int H, int W, int Cin, int Cout, int npc =
   p.tiles_x = cdiv(W, WTX);
   p.tiles_y = cdiv(H, WTY);
   const int cols = B * p.tiles_x * p.tiles_y;
-  const int slots = npc == 1 ? 768 : ((p.cib == 8 && p.nco == 16) ? 256 : 512);   // resident workgroups (LDS: two per CU, one for 8 x 16)
+  // resident workgroups (LDS): three bf16 pieces two per CU, one for 8 x 16; two f16 pieces (49 KB) three, two for x 16; one piece three
+  const int slots = npc == 1 ? 768 : (npc == 2 ? (p.nco == 16 ? 512 : 768) : ((p.cib == 8 && p.nco == 16) ? 256 : 512));
   // chunks of >= 8 planes (3 planes of prologue each), about eight items per workgroup to even out the tail
   int n = (int)((8LL * slots + cols - 1) / cols);
   const int maxn = D / 8 > 0 ? D / 8 : 1;
@@ -1139,9 +1203,10 @@ size_t modetx_x3_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
 // stats != null: stats = [B][Cout] shift header (filled by the caller's shift kernel) followed by the partial rows
 int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                    const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int act, int mode,
-                   hipStream_t s) {
+                   hipStream_t s, const float* amax) {
   const X3Plan p = x3_plan(B, D, H, W, Cin, Cout);
   X3Args a{};
+  a.amax = mode == 1 ? amax : nullptr;
   a.x = x; a.bias = bias; a.y = y; a.in_mean = in_mean; a.in_rstd = in_rstd;
   a.shift = stats; a.stats_rows = stats ? stats + (size_t)B * Cout : nullptr;
   a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
@@ -1155,9 +1220,11 @@ size_t modetx_x3_bst_rows_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   return (size_t)p.nitems * Cin * 2 * sizeof(float);
 }
 int modetx_x3_dgrad_bst(modet_step_ctx* step, const float* dy, const float* w, float* dx, const float* xraw, const float* mean,
-                        const float* rstd, float* rows, void* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t s) {
+                        const float* rstd, float* rows, void* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t s,
+                        const float* amax) {
   const X3Plan p = x3_plan(B, D, H, W, Cout, Cin);
   X3Args a{};
+  a.amax = amax;
   a.x = dy; a.bias = nullptr; a.y = dx;
   a.xraw = xraw; a.bmean = mean; a.brstd = rstd; a.stats_rows = rows;
   a.D = D; a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.act = 0;
@@ -1194,19 +1261,25 @@ bool modetx_x3_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout) {
 }
 size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout);
-  return ((size_t)512 + 1) * p.red_fl * sizeof(float);           // workgroup partials + their column sums
+  return ((size_t)768 + 1) * p.red_fl * sizeof(float);           // workgroup partials (up to 768 resident workgroups) + their column sums
 }
 int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
-                    int W, int Cin, int Cout, hipStream_t s) {
-  const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout);
-  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems};
-  if (p.cib == 4) {
-    if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 8, true>), dim3(p.gx), dim3(NTHR), 0, s, a);
-    else hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 16, false>), dim3(p.gx), dim3(NTHR), 0, s, a);
-  } else {
-    if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 8, true>), dim3(p.gx), dim3(NTHR), 0, s, a);
-    else hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 16, false>), dim3(p.gx), dim3(NTHR), 0, s, a);
-  }
+                    int W, int Cin, int Cout, hipStream_t s, const float* amax) {
+  const bool f16p = X3_F16_FWD && amax != nullptr && (int64_t)D * H * W < (1ll << 24);
+  const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout, f16p ? 2 : 3);
+  // two f16 pieces when the caller knows max |d_y| (and vouches for x: an activation), else three bf16 pieces
+  const bool f16 = X3_F16_FWD && amax != nullptr && (int64_t)D * H * W < (1ll << 24);
+  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems, f16 ? amax : nullptr};
+#define X3W_D(NPC_) do { \
+    if (p.cib == 4) { \
+      if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 8, true, NPC_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
+      else hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 16, false, NPC_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
+    } else { \
+      if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 8, true, NPC_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
+      else hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 16, false, NPC_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
+    } } while (0)
+  if (f16) X3W_D(2); else X3W_D(3);
+#undef X3W_D
   float* red = (float*)ws + (size_t)p.gx * p.red_fl;
   return modetx_wgrad_partials_reduce(defer, (const float*)ws, red, dw, db, p.gx, Cin, Cout, p.cib, p.u, p.np ? 1 : 0, s);
 }
@@ -1225,7 +1298,7 @@ size_t modetx_x3_bf16_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Co
 int modetx_x3_bf16_wgrad(modet_step_ctx* defer, const void* x, int x_bf16, const void* dy, float* dw, float* db, void* ws, int B,
                          int D, int H, int W, int Cin, int Cout, hipStream_t s) {
   const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout, 1);
-  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems};
+  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems, nullptr};
 #define X3W_L(CIB_, NCO_, NP_, X16_) hipLaunchKernelGGL((conv_x3_wgrad_kernel<CIB_, NCO_, NP_, 1, X16_>), dim3(p.gx), dim3(NTHR), 0, s, a)
   if (p.cib == 4) {
     if (x_bf16) return MODET_ERR_UNSUPPORTED;

@@ -155,8 +155,10 @@ __global__ __launch_bounds__(BLK) void in_partial_kernel(const float* __restrict
 // MODE 0: -> mean, rstd.   MODE 1: -> (sum g)/V, (sum g*xhat)/V in out0/out1.
 template <int MODE>
 __global__ __launch_bounds__(64) void in_finalize_kernel(const float* __restrict__ part, float* __restrict__ out0,
-                                                         float* __restrict__ out1, int64_t V, int C, int nchunk, float eps) {
+                                                         float* __restrict__ out1, int64_t V, int C, int nchunk, float eps,
+                                                         float* __restrict__ amax_zero = nullptr) {
   const int b = blockIdx.y, c = blockIdx.x;       // one wave per (b,c): fixed assignment + fixed tree, fp64
+  if (amax_zero && b == 0 && c == 0) amax_zero[threadIdx.x * MODET_AMAX_STRIDE] = 0.f;   // (64 threads = MODET_AMAX_SLOTS) the apply pass maxes into them
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < nchunk; i += 64) {
     const float* p = part + (((int64_t)b * nchunk + i) * C + c) * 2;
@@ -199,10 +201,12 @@ __global__ __launch_bounds__(256) void in_rows_finalize_kernel(const float* __re
 
 // the same column sums for the InstanceNorm BACKWARD rows a data-gradient kernel left (sum g, sum g*xhat): -> means over V
 __global__ __launch_bounds__(256) void in_rows_finalize_bwd_kernel(const float* __restrict__ rows, float* __restrict__ s1,
-                                                                   float* __restrict__ s2, int64_t V, int C, int64_t rows_per_b) {
+                                                                   float* __restrict__ s2, int64_t V, int C, int64_t rows_per_b,
+                                                                   float* __restrict__ amax_zero = nullptr) {
   __shared__ double sm[256];
   __shared__ double tot[256];
   const int b = blockIdx.x;
+  if (amax_zero && b == 0 && threadIdx.x < MODET_AMAX_SLOTS) amax_zero[threadIdx.x * MODET_AMAX_STRIDE] = 0.f;
   block_colsum_256(rows + (int64_t)b * rows_per_b * 2 * C, 0, rows_per_b, 2 * C, tot, sm);
   __syncthreads();
   if ((int)threadIdx.x < C) {
@@ -280,14 +284,19 @@ __global__ __launch_bounds__(BLK) void in_apply_kernel(const float* __restrict__
   }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g*xhat));  POOL: d_y is formed on the fly from PoolSrc (see above) instead of read
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat));  POOL: d_y is formed on the fly from PoolSrc (see above) instead of read.
+// amax != null: max |dx| over the whole tensor is left there (MODET_AMAX_SLOTS slots, one integer atomic max per wave on the
+// float's bits; the slots were zeroed by the finalize kernel in front) -- the scale with which the convolutions that consume dx split it into f16
+// pieces (modet_conv3d_bwd_data_amax / _bwd_weight_amax).
 template <bool POOL>
 __global__ __launch_bounds__(BLK) void in_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ s1, const float* __restrict__ s2,
                                                            float* __restrict__ dx, int64_t V, int C, int64_t total4,
-                                                           const PoolSrc ps = PoolSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0}) {
+                                                           const PoolSrc ps = PoolSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0},
+                                                           float* __restrict__ amax = nullptr) {
   const int G = C >> 2;
+  float tmax = 0.f;
   const bool small = total4 < (1ll << 31) && V < (1ll << 31);
   const int64_t stride = (int64_t)gridDim.x * BLK;
   auto one = [&](int64_t i, const float4 xv, const float4 gv, const float4 m4, const float4 r4, const float4 a4,
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(BLK) void in_bwd_apply_kernel(const float* __restri
       const float gg = gs[c] * (xh > 0.f ? 1.f : LRELU_SLOPE);
       o[c] = r * (gg - s1v[c] - xh * s2v[c]);
     }
+    tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   };
   auto cidx = [&](int64_t i) { int g, b; in_elem(i, G, V, small, g, b); return b * C + g * 4; };
@@ -358,6 +368,18 @@ __global__ __launch_bounds__(BLK) void in_bwd_apply_kernel(const float* __restri
     one(i, reinterpret_cast<const float4*>(x)[i], gv,
         *reinterpret_cast<const float4*>(mean + ci), *reinterpret_cast<const float4*>(rstd + ci),
         *reinterpret_cast<const float4*>(s1 + ci), *reinterpret_cast<const float4*>(s2 + ci));
+  }
+  if (amax) {                                            // (uniform branch; non-negative floats order like their bit patterns)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+    // all waves finish together: maxing into ONE address serialises them in a single L2 channel (measured +1.2 ms per train
+    // step; +0.5 with a read in front of the atomic) -- a workgroup's waves use slot blockIdx % 64, the slots 128 bytes apart,
+    // and only send the atomic when it would raise the slot (device-scope load, past the non-coherent L1)
+    if ((threadIdx.x & 63) == 0) {
+      unsigned* slot = reinterpret_cast<unsigned*>(amax) + (blockIdx.x % MODET_AMAX_SLOTS) * MODET_AMAX_STRIDE;
+      const unsigned mine = __float_as_uint(tmax);
+      if (mine > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mine);
+    }
   }
 }
 
@@ -952,6 +974,11 @@ int modet_instnorm_stats(const float* x, float* mean, float* rstd, const float* 
 
 int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
                              void* ws, size_t ws_bytes, int B, int64_t V, int C, modet_stream_t stream) {
+  return modet_instnorm_lrelu_bwd_amax(d_y, x, mean, rstd, d_x, ws, ws_bytes, B, V, C, nullptr, stream);
+}
+
+int modet_instnorm_lrelu_bwd_amax(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
+                                  void* ws, size_t ws_bytes, int B, int64_t V, int C, float* amax, modet_stream_t stream) {
   MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x);
   MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
@@ -964,10 +991,10 @@ int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean
   float* s1 = part + (size_t)B * nchunk * C * 2;
   float* s2 = s1 + (size_t)B * C;
   hipLaunchKernelGGL(in_partial_kernel<1>, dim3(nchunk, B), dim3(BLK), 0, s, x, d_y, mean, rstd, part, V, C, chunk);
-  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f);
+  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f, amax);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_bwd_apply_kernel<false>, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, s1, s2,
-                     d_x, V, C, total4);
+                     d_x, V, C, total4, PoolSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0}, amax);
   return modet_launch_status();
 }
 
@@ -977,6 +1004,12 @@ int modet_instnorm_lrelu_bwd(const float* d_y, const float* x, const float* mean
 int modet_instnorm_lrelu_bwd_rows(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
                                   const float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B, int64_t V, int C,
                                   modet_stream_t stream) {
+  return modet_instnorm_lrelu_bwd_rows_amax(d_y, x, mean, rstd, d_x, rows, rows_bytes, ws, ws_bytes, B, V, C, nullptr, stream);
+}
+
+int modet_instnorm_lrelu_bwd_rows_amax(const float* d_y, const float* x, const float* mean, const float* rstd, float* d_x,
+                                       const float* rows, size_t rows_bytes, void* ws, size_t ws_bytes, int B, int64_t V, int C,
+                                       float* amax, modet_stream_t stream) {
   MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x);
   MODET_CHECK_PTR(rows); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && V > 0 && C > 0);
@@ -987,10 +1020,10 @@ int modet_instnorm_lrelu_bwd_rows(const float* d_y, const float* x, const float*
   hipStream_t s = (hipStream_t)stream;
   float* s1 = (float*)ws;
   float* s2 = s1 + (size_t)B * C;
-  hipLaunchKernelGGL(in_rows_finalize_bwd_kernel, dim3(B), dim3(256), 0, s, rows, s1, s2, V, C, per);
+  hipLaunchKernelGGL(in_rows_finalize_bwd_kernel, dim3(B), dim3(256), 0, s, rows, s1, s2, V, C, per, amax);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_bwd_apply_kernel<false>, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, (const float*)s1,
-                     (const float*)s2, d_x, V, C, total4);
+                     (const float*)s2, d_x, V, C, total4, PoolSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0}, amax);
   return modet_launch_status();
 }
 
@@ -1000,6 +1033,12 @@ int modet_instnorm_lrelu_bwd_rows(const float* d_y, const float* x, const float*
 int modet_instnorm_lrelu_bwd_pool(const float* g_pooled, const float* add_a, const float* add_b, int Bh, const float* x,
                                   const float* mean, const float* rstd, float* d_x, void* ws, size_t ws_bytes, int B, int D,
                                   int H, int W, int C, modet_stream_t stream) {
+  return modet_instnorm_lrelu_bwd_pool_amax(g_pooled, add_a, add_b, Bh, x, mean, rstd, d_x, ws, ws_bytes, B, D, H, W, C, nullptr, stream);
+}
+
+int modet_instnorm_lrelu_bwd_pool_amax(const float* g_pooled, const float* add_a, const float* add_b, int Bh, const float* x,
+                                       const float* mean, const float* rstd, float* d_x, void* ws, size_t ws_bytes, int B, int D,
+                                       int H, int W, int C, float* amax, modet_stream_t stream) {
   MODET_CHECK_PTR(g_pooled); MODET_CHECK_PTR(x); MODET_CHECK_PTR(mean); MODET_CHECK_PTR(rstd); MODET_CHECK_PTR(d_x); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1 && C > 0 && Bh >= 0 && Bh <= B);
   MODET_CHECK_DIM(D % 2 == 0 && H % 2 == 0 && W % 2 == 0);
@@ -1014,10 +1053,10 @@ int modet_instnorm_lrelu_bwd_pool(const float* g_pooled, const float* add_a, con
   float* s1 = part + (size_t)B * nchunk * C * 2;
   float* s2 = s1 + (size_t)B * C;
   hipLaunchKernelGGL(in_partial_kernel<2>, dim3(nchunk, B), dim3(BLK), 0, s, x, nullptr, mean, rstd, part, V, C, chunk, ps);
-  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f);
+  hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(C, B), dim3(64), 0, s, part, s1, s2, V, C, nchunk, 0.f, amax);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_bwd_apply_kernel<true>, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, nullptr, x, mean, rstd, s1, s2,
-                     d_x, V, C, total4, ps);
+                     d_x, V, C, total4, ps, amax);
   return modet_launch_status();
 }
 

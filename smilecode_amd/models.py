@@ -117,7 +117,7 @@ class ConvInsBlock(nn.Module):
 def _two_blocks_pool(inp, first, second, Bh):
     """_two_blocks followed by the pool tee of the [moving; fixed] batch, fp32 path: the second block's InstanceNorm apply pass
     also writes the pooled tensor of the next level (ops.instnorm_lrelu_pool_tee_split); returns (pooled, moving, fixed)"""
-    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias)
+    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias, x_act=True)   # (inp: a block's / a pool's output)
     raw2, st2 = ops.lazy_instnorm_conv3d(raw, st, second.main.weight, second.main.bias)
     return ops.instnorm_lrelu_pool_tee_split(raw2, st2, Bh)
 
@@ -128,7 +128,7 @@ def _two_blocks(inp, first, second, bf16=False):
     bf16: the chain's internal tensors are stored in bf16 and the convs run on the bf16 matrix pipe (cfg 5)."""
     if bf16:
         return ops.conv_ins_pair_bf16(inp, first.main.weight, first.main.bias, second.main.weight, second.main.bias)
-    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias)
+    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias, x_act=True)   # (inp: a block's / a pool's output)
     raw2, st2 = ops.lazy_instnorm_conv3d(raw, st, second.main.weight, second.main.bias)
     return ops._InstNormLReLU.apply(raw2, 1e-5, st2)
 

@@ -246,7 +246,45 @@ def conv3d_forward_normin(x_raw, mean, rstd, w, b, want_stats=True, step=None):
     return y, stats
 
 
-def conv3d_backward_data(dy, w, Cin, step=None):
+# ---- gradient magnitudes for the f16 forms of the backward convolutions (round 5).  The z-marching kernels run on two f16 pieces
+# per operand (three MFMA products instead of the six of three bf16 pieces) when they know max |d_y|: f16 has the mantissa for
+# it, not the range.  The InstanceNorm backward that PRODUCES a d_y leaves that maximum in a one-float tensor for free
+# (modet_instnorm_lrelu_bwd*_amax) and tags its output with it; the conv backward that CONSUMES the tensor reads the tag.  The tag
+# carries the tensor's version counter: if autograd accumulated another gradient into the tensor on the way (in place), the
+# maximum no longer bounds it and the consumer falls back to the bf16 pieces.  MODET_GRAD_F16=0: never tag (A/B switch).
+GRAD_F16 = os.environ.get("MODET_GRAD_F16", "1") != "0"
+
+
+AMAX_FLOATS = 64 * 32                     # MODET_AMAX_FLOATS: 64 slots, 128 bytes apart (include/modet_hip.h)
+
+
+def _new_amax(like):
+    """the buffer an InstanceNorm backward leaves max |d_x| in -- only where a z-marching conv kernel can consume d_x as its d_y
+    (<= 16 channels, >= 4096 voxels per sample: modetx_x3_eligible), else None (the plain call)"""
+    if not GRAD_F16 or like.shape[-1] > 16 or like.numel() // (like.shape[0] * like.shape[-1]) < 4096:
+        return None
+    return torch.empty(AMAX_FLOATS, dtype=torch.float32, device=like.device)
+
+
+def amax_buffer(value):
+    """a gradient-maximum buffer (every slot = value) for callers that know a bound of |d_y| themselves"""
+    return value.detach().reshape(1).float().expand(AMAX_FLOATS).contiguous()
+
+
+def _tag_amax(t, amax):
+    if amax is not None:
+        t._modet_amax = (amax, t._version)
+    return t
+
+
+def _amax_of(t):
+    tag = getattr(t, "_modet_amax", None)
+    if tag is None or not GRAD_F16 or tag[1] != t._version:
+        return None
+    return tag[0]
+
+
+def conv3d_backward_data(dy, w, Cin, step=None, amax=None):
     _chk(dy, w)
     step = step if step is not None else current_step()
     B, D, H, W, Cout = dy.shape
@@ -256,8 +294,8 @@ def conv3d_backward_data(dy, w, Cin, step=None):
     ws = _ws(nb, dy)
     n = float(B) * D * H * W
     with _Guard(dy, _conv_tag("dgrad", dy.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
-        _lib.check(L.modet_conv3d_bwd_data(_p(dy), _p(w), _p(dx), _p(ws), nb, B, D, H, W, Cin, Cout, _stream(), _h(step)),
-                   "modet_conv3d_bwd_data")
+        _lib.check(L.modet_conv3d_bwd_data_amax(_p(dy), _p(w), _p(dx), _p(ws), nb, B, D, H, W, Cin, Cout, _p(amax), _stream(),
+                                                _h(step)), "modet_conv3d_bwd_data")
     return dx
 
 
@@ -423,11 +461,12 @@ def _h(step):
 SIDE_WGRAD_MAX_VOXELS = float(os.environ.get("MODET_SIDE_WGRAD_MAX_VOXELS", "0"))
 
 
-def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=None):
+def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=None, amax=None):
     """d_w, d_bias; with y_act (ConvBlock 1 -> 4 only) dy is the gradient w.r.t. LeakyReLU(conv) and the activation's
     derivative is applied while loading it.  With a StepContext (given, or bound to this thread) whose ``deferred()`` scope
     knows destinations for the parameters ``w`` / ``b``, the gradients go straight there at the scope's flush and
-    (None, None) is returned."""
+    (None, None) is returned.  amax: one-float tensor >= max |dy| (see _tag_amax) and the caller's word that x is an
+    activation: the z-marching kernel then runs on two f16 pieces."""
     _chk(x, dy)
     B, D, H, W, Cin = x.shape
     Cout = dy.shape[-1]
@@ -447,8 +486,12 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
         else:
             ws = _ws(nb, x)
             with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
-                _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
-                                                           Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
+                if amax is not None and y_act is None:
+                    _lib.check(L.modet_conv3d_bwd_weight_amax(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
+                                                              _p(amax), _stream(), _h(scope)), "modet_conv3d_bwd_weight_amax")
+                else:
+                    _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
+                                                               Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
         scope._keep.append(ws)                                # the partial tiles must survive until the flush
         if y_act is None and L.modet_conv3d_wgrad_defers_operands(B, D, H, W, Cin, Cout):
             scope._keep.extend((x, dy))                       # small levels: the launch itself is queued and reads them at the flush
@@ -463,6 +506,9 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
         if y_act is not None:
             _lib.check(L.modet_conv3d_bwd_weight_act(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
                                                      Cout, _stream()), "modet_conv3d_bwd_weight_act")
+        elif amax is not None:
+            _lib.check(L.modet_conv3d_bwd_weight_amax(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout, _p(amax),
+                                                      _stream(), None), "modet_conv3d_bwd_weight_amax")
         else:
             _lib.check(L.modet_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
                                                  _stream()), "modet_conv3d_bwd_weight")
@@ -494,8 +540,9 @@ class _Conv3d(Function):
                 _lib.check(_L().modet_lrelu_bwd(_p(dy), _p(y), _p(g), dy.numel(), _stream()), "modet_lrelu_bwd")
             dy = g
         # (the weight gradient first: on the small levels it goes to the side stream and runs beside the data gradient)
+        amax = None if ctx.act else _amax_of(dy)                 # (x is whatever the caller convolved: no f16 weight gradient)
         dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step)
-        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step) if ctx.needs_input_grad[0] else None
+        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step, amax) if ctx.needs_input_grad[0] else None
         return dx, dw, db, None
 
 
@@ -503,9 +550,10 @@ class _Conv3dStats(Function):
     """conv3d whose epilogue also produces InstanceNorm partial statistics (second output, not differentiable)"""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, x_act=False):
         _chk(x, w, b)
         ctx.step = current_step()
+        ctx.x_act = bool(x_act)                 # x is an activation (bounded: see modet_conv3d_bwd_weight_amax)
         B, D, H, W, Cin = x.shape
         Cout = w.shape[0]
         L = _L()
@@ -527,12 +575,13 @@ class _Conv3dStats(Function):
     @staticmethod
     def backward(ctx, dy, _dstats):
         if dy is None:
-            return None, None, None
+            return None, None, None, None
         x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
-        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step)
-        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step) if ctx.needs_input_grad[0] else None
-        return dx, dw, db
+        amax = _amax_of(dy)
+        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step, amax=amax if ctx.x_act else None)
+        dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step, amax) if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None
 
 
 def _fuse_stats(x, w, needs_grad=None):
@@ -638,9 +687,11 @@ class _InstNormConv(Function):
         V = D * H * W
         L = _L()
         d_raw = None
-        dw, db = conv3d_backward_weight(y, dz, ctx.has_bias, w=w, b=b, step=ctx.step)      # (first: see _Conv3d.backward)
+        amax = _amax_of(dz)
+        dw, db = conv3d_backward_weight(y, dz, ctx.has_bias, w=w, b=b, step=ctx.step, amax=amax)   # (first: see _Conv3d.backward)
         if ctx.needs_input_grad[0]:
             d_raw = torch.empty_like(x_raw)
+            amax_out = _new_amax(x_raw)
             rb = L.modet_conv3d_bwd_data_instats_bytes(B, D, H, W, C, Cout) if FUSE_IN_DGRAD else 0
             if rb > 0:
                 d_y = torch.empty_like(x_raw)
@@ -649,29 +700,32 @@ class _InstNormConv(Function):
                 ws = _ws(nb, dz)
                 n = float(B) * V
                 with _Guard(dz, _conv_tag("dgrad", dz.shape, C, Cout), 54.0 * C * Cout * n, 4.0 * n * (2 * C + Cout)):
-                    _lib.check(L.modet_conv3d_bwd_data_instats(_p(dz), _p(w), _p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(rows),
-                                                               rb, _p(ws), nb, B, D, H, W, C, Cout, _stream(), _h(ctx.step)),
-                               "modet_conv3d_bwd_data_instats")
+                    _lib.check(L.modet_conv3d_bwd_data_instats_amax(_p(dz), _p(w), _p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(rows),
+                                                                    rb, _p(ws), nb, B, D, H, W, C, Cout, _p(amax), _stream(),
+                                                                    _h(ctx.step)), "modet_conv3d_bwd_data_instats")
                 nb2 = 2 * B * C * 4
                 ws2 = _ws(nb2, x_raw)
                 with _Guard(x_raw, "instnorm_lrelu_bwd", 7.0 * x_raw.numel(), 12.0 * x_raw.numel()):
-                    _lib.check(L.modet_instnorm_lrelu_bwd_rows(_p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(d_raw), _p(rows), rb,
-                                                               _p(ws2), nb2, B, V, C, _stream()), "modet_instnorm_lrelu_bwd_rows")
+                    _lib.check(L.modet_instnorm_lrelu_bwd_rows_amax(_p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(d_raw), _p(rows), rb,
+                                                                    _p(ws2), nb2, B, V, C, _p(amax_out), _stream()),
+                               "modet_instnorm_lrelu_bwd_rows")
             else:
-                d_y = conv3d_backward_data(dz, w, C, ctx.step)
+                d_y = conv3d_backward_data(dz, w, C, ctx.step, amax)
                 nb = L.modet_instnorm_ws_bytes(B, V, C)
                 ws = _ws(nb, x_raw)
                 with _Guard(x_raw, "instnorm_lrelu_bwd", 14.0 * x_raw.numel(), 12.0 * x_raw.numel()):
-                    _lib.check(L.modet_instnorm_lrelu_bwd(_p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(d_raw), _p(ws), nb, B, V, C,
-                                                          _stream()), "modet_instnorm_lrelu_bwd")
+                    _lib.check(L.modet_instnorm_lrelu_bwd_amax(_p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(d_raw), _p(ws), nb, B, V, C,
+                                                               _p(amax_out), _stream()), "modet_instnorm_lrelu_bwd")
+            _tag_amax(d_raw, amax_out)
         return d_raw, None, dw, db, None, None
 
 
-def conv3d_with_stats(x, w, b):
+def conv3d_with_stats(x, w, b, x_act=False):
     """raw 3x3x3 conv output plus, when the configuration supports it, the InstanceNorm partial statistics from its
-    epilogue (else None)"""
+    epilogue (else None).  x_act: the caller's word that x is an activation (a ConvBlock / ConvInsBlock output or a pooled
+    one), which lets the weight gradient split it into f16 pieces with a fixed scale."""
     if _fuse_stats(x, w):
-        return _Conv3dStats.apply(x, w, b)
+        return _Conv3dStats.apply(x, w, b, x_act)
     return _Conv3d.apply(x, w, b, False), None
 
 
@@ -710,13 +764,14 @@ class _InstNormLReLU(Function):
         B, C = x.shape[0], x.shape[-1]
         V = x.numel() // (B * C)
         dx = torch.empty_like(x)
+        amax = _new_amax(x)
         L = _L()
         nb = L.modet_instnorm_ws_bytes(B, V, C)
         ws = _ws(nb, x)
         with _Guard(x, "instnorm_lrelu_bwd", 14.0 * x.numel(), 12.0 * x.numel()):
-            _lib.check(L.modet_instnorm_lrelu_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C,
-                                                  _stream()), "modet_instnorm_lrelu_bwd")
-        return dx, None, None
+            _lib.check(L.modet_instnorm_lrelu_bwd_amax(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C, _p(amax),
+                                                       _stream()), "modet_instnorm_lrelu_bwd")
+        return _tag_amax(dx, amax), None, None
 
 
 def instnorm_lrelu(x, eps=1e-5):
@@ -868,6 +923,7 @@ class _InstNormLReLUPoolSplit(Function):
         V = D * H * W
         L = _L()
         dx = torch.empty_like(x)
+        amax = _new_amax(x)
         nb = L.modet_instnorm_ws_bytes(B, V, C)
         ws = _ws(nb, x)
         if gy is not None:
@@ -876,9 +932,10 @@ class _InstNormLReLUPoolSplit(Function):
             ga = None if ga is None else ga.contiguous()
             gb = None if gb is None else gb.contiguous()
             with _Guard(x, "instnorm_lrelu_bwd", 15.0 * x.numel(), 12.5 * x.numel()):
-                _lib.check(L.modet_instnorm_lrelu_bwd_pool(_p(gy), _p(ga), _p(gb), Bh, _p(x), _p(mean), _p(rstd), _p(dx), _p(ws),
-                                                           nb, B, D, H, W, C, _stream()), "modet_instnorm_lrelu_bwd_pool")
-            return dx, None, None, None
+                _lib.check(L.modet_instnorm_lrelu_bwd_pool_amax(_p(gy), _p(ga), _p(gb), Bh, _p(x), _p(mean), _p(rstd), _p(dx), _p(ws),
+                                                                nb, B, D, H, W, C, _p(amax), _stream()),
+                           "modet_instnorm_lrelu_bwd_pool")
+            return _tag_amax(dx, amax), None, None, None
         dy = torch.empty_like(x)
         for sl, g in ((slice(0, Bh), ga), (slice(Bh, B), gb)):
             if g is None:
@@ -886,9 +943,9 @@ class _InstNormLReLUPoolSplit(Function):
             else:
                 dy[sl].copy_(g)
         with _Guard(x, "instnorm_lrelu_bwd", 14.0 * x.numel(), 12.0 * x.numel()):
-            _lib.check(L.modet_instnorm_lrelu_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C, _stream()),
-                       "modet_instnorm_lrelu_bwd")
-        return dx, None, None, None
+            _lib.check(L.modet_instnorm_lrelu_bwd_amax(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), _p(ws), nb, B, V, C, _p(amax),
+                                                       _stream()), "modet_instnorm_lrelu_bwd")
+        return _tag_amax(dx, amax), None, None, None
 
 
 def instnorm_lrelu_pool_tee_split(x_raw, stats, Bh, eps=1e-5):

@@ -668,3 +668,44 @@ def test_c_oracle_against_reference_goldens(orc):
     d = gold("op_dice.npz")
     shape = tuple(int(s) for s in d["shape"])
     assert abs(cref.dice(d["warped"], synth.make_labels(shape, 25)) - float(d["dice"])) < 1e-12
+
+
+def test_gradient_maximum_tag_dies_with_in_place_accumulation():
+    """ops._tag_amax / _amax_of (round 5): the InstanceNorm backward tags its output with max |d_x| so that the conv backward that
+    consumes it may split it into f16 pieces; the tag is valid only while the tensor is what the kernel wrote -- autograd's
+    in-place gradient accumulation bumps the version counter and must kill it (a stale maximum would overflow f16)."""
+    from torch.autograd import Function
+
+    from smilecode_amd import ops
+    seen = []
+
+    class Consumer(Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(ops._amax_of(g))
+            return g * 2
+
+    class Producer(Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x + 1
+
+        @staticmethod
+        def backward(ctx, g):
+            out = g.clone()
+            return ops._tag_amax(out, out.abs().max().reshape(1))
+
+    x = torch.randn(5, requires_grad=True)
+    Producer.apply(Consumer.apply(x)).sum().backward()
+    a = Consumer.apply(x)
+    (Producer.apply(a) + Producer.apply(a)).sum().backward()       # two gradients accumulated into one tensor
+    assert seen[0] is not None and float(seen[0]) == 1.0
+    assert seen[1] is None
+    t = ops._tag_amax(torch.zeros(3), torch.ones(1))
+    assert ops._amax_of(t) is not None
+    t.add_(1)
+    assert ops._amax_of(t) is None

@@ -654,6 +654,123 @@ def test_conv_forward_two_f16_pieces_range_and_accuracy(Cin, Cout, xs, ws):
     assert err < 1e-6, err
 
 
+def test_instnorm_backward_leaves_the_gradient_maximum(ops):
+    """modet_instnorm_lrelu_bwd*_amax: the three InstanceNorm backward forms also leave max |d_x| (one float, integer atomic
+    max on the bit pattern: exact and order-independent) and tag d_x with it; d_x itself is bit-identical to the plain call."""
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 12, 20, 36, 8), generator=gen).cuda().requires_grad_(True)
+    gy = (torch.randn(x.shape, generator=gen) * 3e-5).cuda()
+    y = ops.instnorm_lrelu(x)
+    dx, = torch.autograd.grad(y, x, gy)
+    tag = ops._amax_of(dx)
+    assert tag is not None and tag.numel() == ops.AMAX_FLOATS and float(tag[::32].max()) == float(dx.abs().max()) and float(tag[::32].max()) > 0
+    from smilecode_amd import _lib
+    L = ops._L()
+    B, C = x.shape[0], x.shape[-1]
+    V = x.numel() // (B * C)
+    mean, rstd = ops.instnorm_stats(x.detach())
+    nb = L.modet_instnorm_ws_bytes(B, V, C)
+    ws = torch.empty(nb // 4 + 1, device="cuda")
+    ref = torch.empty_like(dx)
+    _lib.check(L.modet_instnorm_lrelu_bwd(gy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ref.data_ptr(),
+                                          ws.data_ptr(), nb, B, V, C, None), "plain")
+    assert torch.equal(ref, dx)
+    # the tag dies with an in-place accumulation into the tensor (autograd's gradient accumulation does exactly that)
+    dx.add_(1.0)
+    assert ops._amax_of(dx) is None
+    # pooled form (a level's output block): gradient = unpool(g_pooled) / 8 + [ga; gb]
+    pooled, ya, yb = ops.instnorm_lrelu_pool_tee_split(x, None, 1)
+    gp = (torch.randn(pooled.shape, generator=gen) * 1e-3).cuda()
+    ga = (torch.randn(ya.shape, generator=gen) * 1e-3).cuda()
+    dx2, = torch.autograd.grad([pooled, ya], x, [gp, ga])
+    tag2 = ops._amax_of(dx2)
+    assert tag2 is not None and float(tag2[::32].max()) == float(dx2.abs().max())
+
+
+@pytest.mark.parametrize("Cin,Cout,gs,heavy", [(8, 8, 1.0, False), (8, 8, 3e-9, False), (8, 8, 2e3, True), (4, 8, 1e-6, True),
+                                               (8, 4, 1e-7, False), (16, 16, 1e-5, True), (8, 16, 40.0, False)])
+def test_conv_backward_two_f16_pieces_with_gradient_maximum(ops, Cin, Cout, gs, heavy):
+    """Round 5: with max |d_y| known (left by the InstanceNorm backward that produced d_y) the z-marching data-gradient and
+    weight-gradient kernels split their operands into TWO f16 pieces (three MFMA products) instead of three bf16 pieces (six):
+    d_y is scaled by the power of two that takes its maximum into [2^14, 2^15) while it is split.  Against fp64 over gradient
+    magnitudes from 3e-9 to 2e3, also heavy-tailed ones (a few elements 1e4 times the rest): same error class as the bf16x3
+    kernels (<= 1e-6 of max), nothing overflows, nothing is flushed; and an amax that OVERSTATES the maximum 1000-fold only moves
+    the absolute floor (documented contract), it does not break the result."""
+    B, D, H, W = 2, 52, 44, 45                         # 206 k voxels: the z-marching weight gradient's threshold is 200 k
+    gen = torch.Generator().manual_seed(Cin * 17 + Cout)
+    x = torch.nn.functional.leaky_relu(torch.randn((B, Cin, D, H, W), generator=gen), 0.1).double()
+    w = (torch.randn((Cout, Cin, 3, 3, 3), generator=gen) / np.sqrt(27 * Cin)).double()
+    gy = torch.randn((B, Cout, D, H, W), generator=gen).double() * gs
+    if heavy:
+        m = torch.rand(gy.shape, generator=gen) < 1e-4
+        gy = torch.where(m, gy * 1e4, gy)
+    rx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
+    rw = torch.nn.grad.conv3d_weight(x, w.shape, gy, padding=1)
+    rb = gy.sum((0, 2, 3, 4))
+    xd, gd, wd = cl(x.numpy()), cl(gy.numpy()), w.float().cuda()
+    amax = ops.amax_buffer(gd.abs().max())
+    L = ops._L()
+    assert L.modet_conv3d_kernel_family(B, D, H, W, Cout, Cin, 0) == 2, "the z-marching family must take this data gradient"
+    dx3 = ops.conv3d_backward_data(gd, wd, Cin)
+    dx2 = ops.conv3d_backward_data(gd, wd, Cin, amax=amax)
+    assert bool(torch.isfinite(dx2).all())
+    assert not torch.equal(dx2, dx3), "the f16 form must have run (it rounds differently)"
+    t64 = lambda t: torch.from_numpy(ncdhw(t))                                              # noqa: E731
+    e2 = float((t64(dx2) - rx).abs().max() / rx.abs().max())
+    e3 = float((t64(dx3) - rx).abs().max() / rx.abs().max())
+    _note(f"conv_dgrad_f16x2[{Cout}->{Cin},g~{gs:g}{',heavy' if heavy else ''}].maxerr_of_max", e2)
+    _note(f"conv_dgrad_bf16x3[{Cout}->{Cin},g~{gs:g}{',heavy' if heavy else ''}].maxerr_of_max", e3)
+    assert e2 < 1e-6, (e2, e3)
+    dx2b = ops.conv3d_backward_data(gd, wd, Cin, amax=amax * 1000.0)
+    e2b = float((t64(dx2b) - rx).abs().max() / rx.abs().max())
+    assert e2b < 1e-6, e2b
+    if Cin <= 8:
+        dw3, db3 = ops.conv3d_backward_weight(xd, gd, True)
+        dw2, db2 = ops.conv3d_backward_weight(xd, gd, True, amax=amax)
+        ew2 = float((dw2.double().cpu() - rw).abs().max() / rw.abs().max())
+        ew3 = float((dw3.double().cpu() - rw).abs().max() / rw.abs().max())
+        eb2 = float((db2.double().cpu() - rb).abs().max() / max(float(rb.abs().max()), 1e-30))
+        _note(f"conv_wgrad_f16x2[{Cin}->{Cout},g~{gs:g}{',heavy' if heavy else ''}].maxerr_of_max", ew2)
+        _note(f"conv_wgrad_bf16x3[{Cin}->{Cout},g~{gs:g}{',heavy' if heavy else ''}].maxerr_of_max", ew3)
+        assert bool(torch.isfinite(dw2).all()) and ew2 < 3e-6 and eb2 < 3e-5, (ew2, ew3, eb2)
+        if Cout <= 8:                                  # (Cout 16 runs the transpose-read kernel: bf16x3 either way)
+            assert not torch.equal(dw2, dw3), "the f16 form must have run"
+        dw2r, db2r = ops.conv3d_backward_weight(xd, gd, True, amax=amax)
+        assert torch.equal(dw2, dw2r) and torch.equal(db2, db2r), "weight gradient must be run-to-run deterministic"
+
+
+def test_block_chain_backward_runs_on_f16_pieces_and_matches_fp64(ops, monkeypatch):
+    """ConvInsBlock -> ConvInsBlock chain as the encoder runs it (conv + statistics, lazily normalised conv, InstanceNorm):
+    with the gradient-maximum tags the whole backward of the chain runs on f16 pieces; it must differ in rounding from the
+    untagged (bf16x3) backward -- i.e. the tags really travel through autograd -- and both must sit on the fp64 result."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(11)
+    shape, cin, c = (24, 44, 48), 4, 8
+    x = F.leaky_relu(torch.randn((2, cin) + shape, generator=gen), 0.1).double().requires_grad_(True)
+    w1 = (torch.randn((c, cin, 3, 3, 3), generator=gen) / np.sqrt(cin * 27)).double().requires_grad_(True)
+    w2 = (torch.randn((c, c, 3, 3, 3), generator=gen) / np.sqrt(c * 27)).double().requires_grad_(True)
+    b1 = (0.1 * torch.randn(c, generator=gen)).double().requires_grad_(True)
+    b2 = (0.1 * torch.randn(c, generator=gen)).double().requires_grad_(True)
+    gy = torch.randn((2, c) + shape, generator=gen).double() * 1e-6
+    h = F.leaky_relu(F.instance_norm(F.conv3d(x, w1, b1, padding=1), eps=1e-5), 0.1)
+    ref = F.leaky_relu(F.instance_norm(F.conv3d(h, w2, b2, padding=1), eps=1e-5), 0.1)
+    r = torch.autograd.grad(ref, [x, w1, w2], gy)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "GRAD_F16", on)
+        xd = cl(x.detach().numpy()).requires_grad_(True)
+        p = [t.detach().float().cuda().requires_grad_(True) for t in (w1, b1, w2, b2)]
+        raw, st = ops.conv3d_with_stats(xd, p[0], p[1], x_act=True)
+        raw2, st2 = ops.lazy_instnorm_conv3d(raw, st, p[2], p[3])
+        y = ops._InstNormLReLU.apply(raw2, 1e-5, st2)
+        res[on] = torch.autograd.grad(y, [xd, p[0], p[2]], cl(gy.numpy()))
+        for got, want, name in ((torch.from_numpy(ncdhw(res[on][0])), r[0], "dx"), (res[on][1].double().cpu(), r[1], "dw1"), (res[on][2].double().cpu(), r[2], "dw2")):
+            e = float((got - want).abs().max() / want.abs().max())
+            _note(f"block_chain_bwd[{'f16x2' if on else 'bf16x3'}].{name}_maxerr_of_max", e)
+            assert e < 2e-5, (on, name, e)
+    assert not torch.equal(res[True][1], res[False][1]) and not torch.equal(res[True][0], res[False][0])
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(8, 8, (40, 50, 52)), (4, 8, (37, 46, 63)), (8, 16, (33, 42, 75)), (8, 4, (40, 41, 66))])
 def test_conv_x3_weight_gradient_vs_fp64(ops, cin, cout, shape):
     """csrc/conv3d_x3.hip, weight gradient: the z-marching bf16x3 kernel (Cin 4/8, Cout <= 16, >= 200 k voxels) against

@@ -7,7 +7,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; src=$2; flags=$3
 mkdir -p $R/build/variants/obj_$name
 base=$(basename $src .hip)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-gpu-rdc $flags -c $R/smilecode_amd/csrc/$base.hip -o $R/build/variants/obj_$name/$base.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-gpu-rdc -fno-slp-vectorize $flags -c $R/smilecode_amd/csrc/$base.hip -o $R/build/variants/obj_$name/$base.o
 objs=""
 for o in $R/smilecode_amd/lib/obj/*.o; do
   b=$(basename $o)
