@@ -52,11 +52,11 @@ def family(tag):
     if base in ("conv_fwd", "conv_dgrad"):
         if tag.endswith("@direct"):
             return "conv_direct_kernel"
-        if tag.endswith("@q"):
+        if tag.endswith(("@q", "@qh")):
             return "conv_q_kernel"
-        return "conv_x3_kernel" if tag.endswith("@x3") else ("conv3d_bf16_kernel<SP=3>" if tag.endswith("@split") else "conv3d_mfma_kernel")
+        return "conv_x3_kernel" if tag.endswith(("@x3", "@x3h")) else ("conv3d_bf16_kernel<SP=3>" if tag.endswith("@split") else "conv3d_mfma_kernel")
     if base == "conv_wgrad":
-        return "conv_x3_wgrad_kernel" if tag.endswith("@x3") else ("conv_wgrad_tr_kernel" if tag.endswith("@tr") else "conv3d_wgrad_kernel")
+        return "conv_x3_wgrad_kernel" if tag.endswith(("@x3", "@x3h")) else ("conv_wgrad_tr_kernel" if tag.endswith(("@tr", "@trh")) else "conv3d_wgrad_kernel")
     if base == "warp_bwd":
         return "warp_bwd_kernel"
     if base == "warp_bwd_gather3":
@@ -73,7 +73,7 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0
 
 def piece_products(tag):
     """MFMA piece products per fp32 product of one launch tag"""
-    return 3.0 if tag.split("[")[0] == "conv_fwd" and tag.endswith("@x3") else 6.0
+    return 3.0 if tag.endswith(("@x3h", "@qh", "@trh")) else 6.0         # ops._conv_tag: 'h' = the launch ran on two f16 pieces
 MFMA_F32_FAMILIES = ("conv3d_mfma_kernel", "conv3d_wgrad_kernel", "conv_c1_wgrad_mfma_kernel", "conv_direct_kernel")
 MFMA_X3_FAMILIES = ("conv_x3_kernel", "conv_x3_wgrad_kernel", "conv_wgrad_tr_kernel", "conv_q_kernel", "conv3d_bf16_kernel<SP=3>")
 

@@ -1782,7 +1782,7 @@ size_t modetx_wtr_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 bool modetx_wtr_batches(int B, int D, int H, int W);
 void modetx_wtr_flush(modet_step_ctx* c, hipStream_t s);
 int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
-                     int W, int Cin, int Cout, hipStream_t s);
+                     int W, int Cin, int Cout, hipStream_t s, const float* amax = nullptr);
 static bool use_x3(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = modet_tuning_env("MODET_CONV_X3") != '0';
   return on && modetx_x3_eligible(B, D, H, W, Cin, Cout);
@@ -1801,7 +1801,7 @@ size_t modetx_q_ws_bytes(int Cin, int Cout);
 size_t modetx_q_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                   const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int mode,
-                  hipStream_t s);
+                  hipStream_t s, const float* amax = nullptr);
 static bool use_q(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = modet_tuning_env("MODET_CONV_Q") != '0';
   // (level 5 -- 2.4 k voxels, 64 / 128 channels -- stays on conv_direct_kernel: 8 stagings of a 128-voxel tile in a row there,
@@ -2099,7 +2099,8 @@ int modet_conv3d_bwd_data_amax(const float* d_y, const float* w, float* d_x, voi
   }
   if (use_q(B, D, H, W, Cout, Cin)) {
     if (ws_bytes < modetx_q_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
-    return modetx_q_conv(step, d_y, w, nullptr, d_x, ws, nullptr, nullptr, nullptr, B, D, H, W, Cout, Cin, 1, (hipStream_t)stream);
+    return modetx_q_conv(step, d_y, w, nullptr, d_x, ws, nullptr, nullptr, nullptr, B, D, H, W, Cout, Cin, 1, (hipStream_t)stream,
+                         dy_amax);
   }
   if (use_split(Cout, Cin, (int64_t)B * D * H * W)) {
     if (ws_bytes < modetx_split_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
@@ -2223,7 +2224,7 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
   if (!y_act && use_x3_wgrad(B, D, H, W, Cin, Cout))
     return modetx_x3_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s, dy_amax);
   if (!y_act && use_wtr_wgrad(B, D, H, W, Cin, Cout))
-    return modetx_wtr_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s);
+    return modetx_wtr_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s, dy_amax);
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);
   float* part = (float*)ws;
   if (p.np) {

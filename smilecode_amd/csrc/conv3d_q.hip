@@ -64,6 +64,32 @@ __device__ __forceinline__ void split3_pk(float a, float b, unsigned& hi, unsign
   const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
   lo = pk(sa, sb);
 }
+// ---- two f16 pieces (round 5, see conv3d_x3.hip split2_h): x = hi + lo, hi = f16(x), lo = f16(x - hi); a product is the three
+// piece products hi*hi + hi*lo + lo*hi.  f16 has the mantissa (x is carried to 2^-22 |x|) but not the range: weights are scaled
+// by 2^8, activations by 2^4 (LeakyReLU(InstanceNorm(.)) <= sqrt(V), pooled / upsampled copies of it, flow fields: < 4 094),
+// gradients by the power of two their producer's maximum gives (QArgs::amax), the accumulator is scaled back -- all exact.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr float Q_F16_WSCALE = 256.f, Q_F16_XSCALE = 16.f;
+#ifndef Q_F16
+#define Q_F16 1                                        // 0: three bf16 pieces everywhere (A/B builds)
+#endif
+__device__ __forceinline__ unsigned q_pk_f16(float u, float v) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  const h16x2 t = __builtin_convertvector((f32x2){u, v}, h16x2);
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ void split2h_pk(float a, float b, unsigned& hi, unsigned& lo) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
+  hi = q_pk_f16(a, b);
+  const h16x2 t = __builtin_bit_cast(h16x2, hi);
+  lo = q_pk_f16(a - (float)t[0], b - (float)t[1]);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 q_mma(bf16x8 a, bf16x8 b, f32x4 c) {       // (F16: the 16-byte fragments hold f16)
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ unsigned short q_bf16(float a) {
   const __bf16 x = (__bf16)a;
   return __builtin_bit_cast(unsigned short, x);
@@ -74,7 +100,7 @@ __device__ __forceinline__ unsigned short q_bf16(float a) {
 // (lane & 15), k = 8 (lane >> 4) + j = chunk 8 ks + 2 (lane >> 4) + (j >> 2), channel j & 3 of that chunk's quad.
 //   chunk q -> tap = q / NQ, quad = q % NQ, channel ci = stage * 4 NQ + 4 quad + (j & 3); zero for q >= 27 NQ, ci >= Cin, co >= Cout.
 //   mode 0 (forward): w[co][ci][tap]   w: (Cout, Cin, 27);   mode 1 (dgrad): w[ci][co][26 - tap]   w: (Co = ci, Ci = co, 27)
-struct QPackJob { const float* w; unsigned short* wpk; int Cin, Cout, nq, nstage, ks, ct, mode; };
+struct QPackJob { const float* w; unsigned short* wpk; int Cin, Cout, nq, nstage, ks, ct, mode, np; };   // np 3: bf16 pieces | 2: f16 pieces
 __device__ __forceinline__ void q_pack_body(const QPackJob& J, int i0, int stride) {
   const int total = J.nstage * J.ks * J.ct * 64 * 8;   // elements of ONE piece
   for (int i = i0; i < total; i += stride) {
@@ -88,12 +114,19 @@ __device__ __forceinline__ void q_pack_body(const QPackJob& J, int i0, int strid
     float v = 0.f;
     if (q < 27 * J.nq && ci < J.Cin && co < J.Cout)
       v = J.mode == 0 ? J.w[((int64_t)co * J.Cin + ci) * 27 + tap] : J.w[((int64_t)ci * J.Cout + co) * 27 + 26 - tap];
+    // piece p of (stage, ks) sits CT * 512 elements after piece p - 1
+    const size_t base = ((size_t)((stage * J.ks + ks) * J.np) * J.ct + ct) * 512 + lane * 8 + j;
+    if (J.np == 2) {
+      const _Float16 hh = (_Float16)(v * Q_F16_WSCALE);
+      const _Float16 ll = (_Float16)(v * Q_F16_WSCALE - (float)hh);
+      J.wpk[base] = __builtin_bit_cast(unsigned short, hh);
+      J.wpk[base + (size_t)J.ct * 512] = __builtin_bit_cast(unsigned short, ll);
+      continue;
+    }
     const unsigned short h = q_bf16(v);
     const float r1 = v - __uint_as_float((unsigned)h << 16);
     const unsigned short m = q_bf16(r1);
     const float r2 = r1 - __uint_as_float((unsigned)m << 16);
-    // piece p of (stage, ks) sits CT * 512 elements after piece p - 1
-    const size_t base = ((size_t)((stage * J.ks + ks) * 3) * J.ct + ct) * 512 + lane * 8 + j;
     J.wpk[base] = h;
     J.wpk[base + (size_t)J.ct * 512] = m;
     J.wpk[base + (size_t)2 * J.ct * 512] = q_bf16(r2);
@@ -111,18 +144,20 @@ struct QArgs {
   const float* in_mean; const float* in_rstd;          // NORM: the input is LeakyReLU((x - mean) * rstd), applied while staging
   float* stats_rows; const float* shift;               // STATS: rows [B][tiles][Cout][2] of sum(y - K), sum((y - K)^2); K = shift[b][co]
   int B, D, H, W, Cin, Cout, tiles_x, tiles_y, tiles_z, nstage, ct_total;
+  const float* amax;                                   // f16 pieces, x = a gradient: MODET_AMAX_SLOTS maxima of |x| (else null: x 2^4)
 };
 
 // Wave tiling <WC, CT>: the four waves form WC cout groups x (4 / WC) voxel groups; a wave owns CT cout tiles (cout block of
 // the workgroup = WC * CT tiles) and VT = 2 WC voxel tiles.  Per k-step it reads VT x 3 pieces x 2 x 8 bytes of voxels from LDS
 // and CT x 3 x 16 bytes of weights from L2 / L1 for VT * CT * 6 MFMAs; q_plan picks the tiling per shape (measured).
-template <int NQ, int WC, int CT, bool NORM, bool STATS>
+template <int NQ, int WC, int CT, bool NORM, bool STATS, int NP = 3>
 __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kernel(const QArgs a) {
+  static_assert(NP == 3 || NP == 2, "three bf16 pieces or two f16 pieces");
   constexpr int VT = 2 * WC;                           // voxel tiles per wave
   constexpr int CB = WC * CT;                          // cout tiles per workgroup
   constexpr int PF = CT == 1 ? 4 : (CT == 2 ? 3 : 2);   // k-steps of weight lookahead
   constexpr int KS = (27 * NQ + 7) / 8;                // k-steps per channel block
-  constexpr int XS_BYTES = 3 * XPL;
+  constexpr int XS_BYTES = NP * XPL;
   constexpr int TAB = 27 * NQ + 8;                     // chunk -> LDS byte offset (tap, quad); the tail entries are dummies
   __shared__ __attribute__((aligned(16))) unsigned char lds[XS_BYTES + TAB * 4 + (STATS ? 4 * CT * 16 * 2 * 4 : 0)];
   int* tab = reinterpret_cast<int*>(lds + XS_BYTES);
@@ -210,19 +245,35 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
     }
   };
   issue_tile(0);
+  float xsc = Q_F16_XSCALE, osc = 1.f / (Q_F16_XSCALE * Q_F16_WSCALE);      // NP 2: operand scale and the accumulator's way back
+  if constexpr (NP == 2) {
+    if (a.amax) {
+      float m = a.amax[lane * MODET_AMAX_STRIDE];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      xsc = 1.f; osc = 1.f / Q_F16_WSCALE;
+      if (m > 0.f && m < __builtin_huge_valf()) {
+        int e;
+        (void)frexpf(m, &e);
+        int sh = 15 - e;
+        sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+        xsc = ldexpf(1.f, sh); osc = ldexpf(1.f, -sh) * (1.f / Q_F16_WSCALE);
+      }
+    }
+  }
 
   for (int s = 0; s < a.nstage; ++s) {
     // the first PF k-steps' weights of the stage in flight beside the tile (ring of PF register sets: a k-step is ~100-200
     // clocks of MFMA per wave, an L2 hit several hundred: one k-step of lookahead left every k-step waiting on its weights)
-    const uint4* wst = wbase + (size_t)s * KS * 3 * wstep;
-    uint4 wq[PF][3][CT];
+    const uint4* wst = wbase + (size_t)s * KS * NP * wstep;
+    uint4 wq[PF][NP][CT];
 #pragma unroll
     for (int j = 0; j < PF; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int n = 0; n < CT; ++n)
-          if (j < KS) wq[j][p][n] = wst[((size_t)j * 3 + p) * wstep + n * 64];
+          if (j < KS) wq[j][p][n] = wst[((size_t)j * NP + p) * wstep + n * 64];
     if (s > 0) __syncthreads();                        // every wave is done reading the previous stage's image
     if (x_act) {
 #pragma unroll
@@ -232,13 +283,21 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
           f0 = okv[i] ? lrelu((f0 - nm.x) * nr.x) : 0.f; f1 = okv[i] ? lrelu((f1 - nm.y) * nr.y) : 0.f;
           f2 = okv[i] ? lrelu((f2 - nm.z) * nr.z) : 0.f; f3 = okv[i] ? lrelu((f3 - nm.w) * nr.w) : 0.f;
         }
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3_pk(f0, f1, h0, m0, l0);
-        split3_pk(f2, f3, h1, m1, l1);
         unsigned char* dst = lds + xlds_t + i * RP * PITCH;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(dst + XPL) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(dst + 2 * XPL) = make_uint2(l0, l1);
+        if constexpr (NP == 2) {
+          unsigned h0, l0, h1, l1;
+          split2h_pk(f0 * xsc, f1 * xsc, h0, l0);
+          split2h_pk(f2 * xsc, f3 * xsc, h1, l1);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dst + XPL) = make_uint2(l0, l1);
+        } else {
+          unsigned h0, m0, l0, h1, m1, l1;
+          split3_pk(f0, f1, h0, m0, l0);
+          split3_pk(f2, f3, h1, m1, l1);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dst + XPL) = make_uint2(m0, m1);
+          *reinterpret_cast<uint2*>(dst + 2 * XPL) = make_uint2(l0, l1);
+        }
       }
     }
     __syncthreads();
@@ -256,9 +315,9 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
           const int2 co2 = *reinterpret_cast<const int2*>(tab + 8 * ks + 2 * kg);
 #pragma unroll
           for (int v = 0; v < VT; ++v) {
-            bf16x8 xf[3];
+            bf16x8 xf[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
               const uint2 lo = *reinterpret_cast<const uint2*>(lds + p * XPL + voff[v] + co2.x);
               const uint2 hi = *reinterpret_cast<const uint2*>(lds + p * XPL + voff[v] + co2.y);
               const u32x4 q4 = {lo.x, lo.y, hi.x, hi.y};
@@ -266,15 +325,16 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
             }
 #define MMQ(PW, PX)                                                                                                           \
             _Pragma("unroll") for (int n = 0; n < CT; ++n)                                                                    \
-              acc[v][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[j][PW][n]), xf[PX], acc[v][n], 0, 0, 0);
-            MMQ(2, 0) MMQ(0, 2) MMQ(1, 1) MMQ(1, 0) MMQ(0, 1) MMQ(0, 0)
+              acc[v][n] = q_mma<NP == 2>(__builtin_bit_cast(bf16x8, wq[j][PW][n]), xf[PX], acc[v][n]);
+            if constexpr (NP == 3) { MMQ(2, 0) MMQ(0, 2) MMQ(1, 1) }
+            MMQ(1, 0) MMQ(0, 1) MMQ(0, 0)
 #undef MMQ
           }
           if (ks + PF < KS) {                          // this slot's next use
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-              for (int n = 0; n < CT; ++n) wq[j][p][n] = wst[((size_t)(ks + PF) * 3 + p) * wstep + n * 64];
+              for (int n = 0; n < CT; ++n) wq[j][p][n] = wst[((size_t)(ks + PF) * NP + p) * wstep + n * 64];
           }
           __builtin_amdgcn_sched_barrier(0);           // (the scheduler otherwise sinks these loads to their use, PF k-steps on)
         }
@@ -303,7 +363,7 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
       float o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        o[j] = acc[v][n][j] + bv[j];
+        o[j] = NP == 2 ? fmaf(acc[v][n][j], osc, bv[j]) : acc[v][n][j] + bv[j];
         if (STATS && ok && co + j < Cout) { const float e = o[j] - kv[j]; sx[j] += e; sq[j] = fmaf(e, e, sq[j]); }
       }
       if (ok) {
@@ -370,25 +430,25 @@ inline QPlan q_plan(int B, int D, int H, int W, int Cin, int Cout) {
 }
 inline size_t q_wpk_elems(const QPlan& p) { return (size_t)p.nstage * p.ks * 3 * p.ct_total * 512; }
 
-template <int NQ, int WC, int CT>
+template <int NQ, int WC, int CT, int NP>
 void q_launch_v(const QArgs& a, const dim3& grid, hipStream_t s) {
   if (a.in_mean) {
-    if (a.stats_rows) hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, true, true>), grid, dim3(NTHR), 0, s, a);
-    else hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, true, false>), grid, dim3(NTHR), 0, s, a);
+    if (a.stats_rows) hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, true, true, NP>), grid, dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, true, false, NP>), grid, dim3(NTHR), 0, s, a);
   } else {
-    if (a.stats_rows) hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, false, true>), grid, dim3(NTHR), 0, s, a);
-    else hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, false, false>), grid, dim3(NTHR), 0, s, a);
+    if (a.stats_rows) hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, false, true, NP>), grid, dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, false, false, NP>), grid, dim3(NTHR), 0, s, a);
   }
 }
-template <int NQ>
+template <int NQ, int NP>
 void q_launch_n(const QArgs& a, const QPlan& p, const dim3& grid, hipStream_t s) {
-  if (p.wc == 1 && p.ct == 1) q_launch_v<NQ, 1, 1>(a, grid, s);
-  else if (p.wc == 1 && p.ct == 2) q_launch_v<NQ, 1, 2>(a, grid, s);
+  if (p.wc == 1 && p.ct == 1) q_launch_v<NQ, 1, 1, NP>(a, grid, s);
+  else if (p.wc == 1 && p.ct == 2) q_launch_v<NQ, 1, 2, NP>(a, grid, s);
 #ifdef MODET_TUNING
-  else if (p.wc == 1 && p.ct == 4) q_launch_v<NQ, 1, 4>(a, grid, s);
-  else if (p.wc == 2 && p.ct == 1) q_launch_v<NQ, 2, 1>(a, grid, s);
-  else if (p.wc == 2 && p.ct == 2) q_launch_v<NQ, 2, 2>(a, grid, s);
-  else if (p.wc == 4 && p.ct == 1) q_launch_v<NQ, 4, 1>(a, grid, s);
+  else if (p.wc == 1 && p.ct == 4) q_launch_v<NQ, 1, 4, NP>(a, grid, s);
+  else if (p.wc == 2 && p.ct == 1) q_launch_v<NQ, 2, 1, NP>(a, grid, s);
+  else if (p.wc == 2 && p.ct == 2) q_launch_v<NQ, 2, 2, NP>(a, grid, s);
+  else if (p.wc == 4 && p.ct == 1) q_launch_v<NQ, 4, 1, NP>(a, grid, s);
 #endif
 }
 
@@ -411,11 +471,14 @@ size_t modetx_q_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
 // stats != null: [B][Cout] shift header (filled by the caller's shift kernel) followed by the rows [B][tiles][Cout][2]
 int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                   const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int mode,
-                  hipStream_t s) {
+                  hipStream_t s, const float* amax) {
   const QPlan p = q_plan(B, D, H, W, Cin, Cout);
   unsigned short* wpk = (unsigned short*)ws;
+  // forward: two f16 pieces (the input is an activation); data gradient: the same when the caller knows max |d_y|, else bf16x3
+  const bool f16 = Q_F16 && (int64_t)D * H * W < (1ll << 24) && (mode == 0 || amax != nullptr);
+  const int np = f16 ? 2 : 3;
   // CoutP = 16 ct makes the arena's size formula (nstage * ksteps * CoutP * 32 * npiece elements) this packing's size
-  const PackBKey key{w, Cin, Cout, p.ct_total * 16, p.nq, p.nstage, p.ks, mode, 3, 4};
+  const PackBKey key{w, Cin, Cout, p.ct_total * 16, p.nq, p.nstage, p.ks, mode, np, 4};
   const unsigned short* pre = nullptr;
   if (step) {
     std::lock_guard<std::mutex> lk(step->mu);
@@ -430,17 +493,20 @@ int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const fl
   }
   if (pre) wpk = const_cast<unsigned short*>(pre);
   else {
-    const QPackJob J{w, wpk, Cin, Cout, p.nq, p.nstage, p.ks, p.ct_total, mode};
+    const QPackJob J{w, wpk, Cin, Cout, p.nq, p.nstage, p.ks, p.ct_total, mode, np};
     const int total = p.nstage * p.ks * p.ct_total * 512;
     hipLaunchKernelGGL(q_pack_kernel, dim3(cdiv(total, 256) > 256 ? 256 : cdiv(total, 256)), dim3(256), 0, s, J);
   }
   QArgs a{x, (const uint4*)wpk, bias, y, in_mean, in_rstd, stats ? stats + (size_t)B * Cout : nullptr, stats,
-          B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.nstage, p.ct_total};
+          B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.nstage, p.ct_total, (f16 && mode == 1) ? amax : nullptr};
   const dim3 grid(B * p.tiles_x * p.tiles_y * p.tiles_z, p.ct_total / p.cb);
-  if (p.nq == 4) q_launch_n<4>(a, p, grid, s);
-  else if (p.nq == 3) q_launch_n<3>(a, p, grid, s);
-  else if (p.nq == 2) q_launch_n<2>(a, p, grid, s);
-  else q_launch_n<1>(a, p, grid, s);
+#define Q_GO(NP_) do { \
+    if (p.nq == 4) q_launch_n<4, NP_>(a, p, grid, s); \
+    else if (p.nq == 3) q_launch_n<3, NP_>(a, p, grid, s); \
+    else if (p.nq == 2) q_launch_n<2, NP_>(a, p, grid, s); \
+    else q_launch_n<1, NP_>(a, p, grid, s); } while (0)
+  if (f16) Q_GO(2); else Q_GO(3);
+#undef Q_GO
   return modet_launch_status();
 }
 // the recorded packing jobs with layout 4 belong to this file (called from modetx_x3_prepack_begin's chain)
@@ -461,7 +527,7 @@ void modetx_q_prepack_begin(modet_step_ctx* c, hipStream_t stream) {
   for (size_t i = 0; i < jobs.size(); ++i) {
     const PackBKey& k = jobs[i];
     if (k.layout != 4) continue;
-    t.job[t.n++] = QPackJob{k.w, arena + off[i], k.Cin, k.Cout, k.CK, k.nstage, k.ksteps, k.CoutP / 16, k.mode};
+    t.job[t.n++] = QPackJob{k.w, arena + off[i], k.Cin, k.Cout, k.CK, k.nstage, k.ksteps, k.CoutP / 16, k.mode, k.npiece};
     if (t.n == QPACK_MAX_JOBS) go();
   }
   go();

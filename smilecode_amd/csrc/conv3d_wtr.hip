@@ -71,6 +71,27 @@ __device__ __forceinline__ void split3_pk(float a, float b, unsigned& hi, unsign
   const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
   lo = pk(sa, sb);
 }
+// ---- two f16 pieces (round 5, see conv3d_x3.hip split2_h / conv_x3_wgrad_kernel NPC = 2): x = an activation, scaled by 2^4;
+// d_y scaled by the power of two its producer's maximum gives (WtrArgs::amax); three piece products instead of six; the partial
+// tiles are scaled back (exact) before they leave the workgroup
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr float WTR_F16_XSCALE = 16.f;
+#ifndef WTR_F16
+#define WTR_F16 1                                      // 0: three bf16 pieces everywhere (A/B builds)
+#endif
+__device__ __forceinline__ void split2h_pk(float a, float b, unsigned& hi, unsigned& lo) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  const h16x2 t = __builtin_convertvector((f32x2){a, b}, h16x2);
+  hi = __builtin_bit_cast(unsigned, t);
+  const h16x2 r = __builtin_convertvector((f32x2){a - (float)t[0], b - (float)t[1]}, h16x2);
+  lo = __builtin_bit_cast(unsigned, r);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 wtr_mma(bf16x8 a, bf16x8 b, f32x4 c) {     // (F16: the 16-byte fragments hold f16)
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ uint2 tr_read(const unsigned char* lds, int off) {
   typedef __attribute__((address_space(3))) v4s* lptr;
   return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off)));
@@ -87,6 +108,7 @@ __device__ long long* g_wtr_dbg = nullptr;
 struct WtrArgs {
   const float* x; const float* dy; float* part;
   int B, D, H, W, Cin, Cout, tiles_x, tiles_y, tiles_z, ntiles, n_coblk;
+  const float* amax;                                   // NP 2: MODET_AMAX_SLOTS maxima of |d_y|
 };
 // One launch, SEVERAL layers (round 5): the weight gradients of pyramid levels 3-5 and of the CWM layers are 17 launches per
 // train step of 20-50 us each, most of them far too small to fill 256 CUs (level 5: 24 workgroups) and every one paying its
@@ -105,8 +127,9 @@ struct WtrTable {
 #define WTR_VARIANT 8
 #endif
 // WTR_VARIANT bit 1: no register prefetch of the next tile's global loads; bit 2: no operand prefetch of the next family
-template <int NQ, int NT, bool VEC>
+template <int NQ, int NT, bool VEC, int NP = 3>
 __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrTable t) {
+  static_assert(NP == 3 || NP == 2, "three bf16 pieces or two f16 pieces");
   int job = 0;
   while (job + 1 < t.n && (int)blockIdx.x >= t.first[job + 1]) ++job;     // (scalar: blockIdx is uniform)
   const WtrArgs a = t.job[job];
@@ -116,7 +139,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrTable t
   constexpr int NF = (9 * NQ + 3) / 4;                 // families: 4 chunks of the list q = (dz, dy) * NQ + quad
   constexpr int MT = 3 * NF;                           // M tiles = (family, dx); slot MT = bias
   constexpr int KS = NT;                               // k-steps per wave and tile
-  constexpr int XS_BYTES = 3 * XPL, DS_BYTES = 3 * NT * DPL;
+  constexpr int XS_BYTES = NP * XPL, DS_BYTES = NP * NT * DPL;
   constexpr int RED_FL = (MT + 1) * NT * 256;
   constexpr int LDS_BYTES = XS_BYTES + DS_BYTES > RED_FL * 4 ? XS_BYTES + DS_BYTES : RED_FL * 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -148,7 +171,20 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrTable t
   const int bsw = (kg & 1) << 2;
   const int boff0 = XS_BYTES + nw * DPL + (bslot + (sj ^ bsw)) * ROWB + sc * 8;           // x = 0..3
   const int boff1 = XS_BYTES + nw * DPL + (bslot + ((4 + sj) ^ bsw)) * ROWB + sc * 8;     // x = 4..7
-  const unsigned one2 = S == 0 ? 0x3f803f80u : 0u;     // A = ones (hi piece): row 0 of the bias tile
+  const unsigned one2 = S == 0 ? (NP == 2 ? 0x3c003c00u : 0x3f803f80u) : 0u;     // A = ones (hi piece): row 0 of the bias tile
+  float dsc = 1.f, dinv = 1.f;                         // NP 2: scale of d_y and its inverse (powers of two)
+  if constexpr (NP == 2) {
+    float m = a.amax[lane * MODET_AMAX_STRIDE];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (m > 0.f && m < __builtin_huge_valf()) {
+      int e;
+      (void)frexpf(m, &e);
+      int sh = 15 - e;
+      sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+      dsc = ldexpf(1.f, sh); dinv = ldexpf(1.f, -sh);
+    }
+  }
 
   f32x4 acc[NF][3], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -225,26 +261,42 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrTable t
     if (x_act) {
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3_pk(__uint_as_float(xr[i][0]), __uint_as_float(xr[i][1]), h0, m0, l0);
-        split3_pk(__uint_as_float(xr[i][2]), __uint_as_float(xr[i][3]), h1, m1, l1);
         unsigned char* dst = lds + xlds_t + i * RP * XP * ROWB;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(dst + XPL) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(dst + 2 * XPL) = make_uint2(l0, l1);
+        if constexpr (NP == 2) {
+          unsigned h0, l0, h1, l1;
+          split2h_pk(__uint_as_float(xr[i][0]) * WTR_F16_XSCALE, __uint_as_float(xr[i][1]) * WTR_F16_XSCALE, h0, l0);
+          split2h_pk(__uint_as_float(xr[i][2]) * WTR_F16_XSCALE, __uint_as_float(xr[i][3]) * WTR_F16_XSCALE, h1, l1);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dst + XPL) = make_uint2(l0, l1);
+        } else {
+          unsigned h0, m0, l0, h1, m1, l1;
+          split3_pk(__uint_as_float(xr[i][0]), __uint_as_float(xr[i][1]), h0, m0, l0);
+          split3_pk(__uint_as_float(xr[i][2]), __uint_as_float(xr[i][3]), h1, m1, l1);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dst + XPL) = make_uint2(m0, m1);
+          *reinterpret_cast<uint2*>(dst + 2 * XPL) = make_uint2(l0, l1);
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NDP; ++i) {
       const int v = i * DVP + dv_t;
       const int slot = (v & ~7) | ((v & 7) ^ (((v >> 3) & 1) << 2));          // x ^ 4 (y & 1)
-      unsigned h0, m0, l0, h1, m1, l1;
-      split3_pk(__uint_as_float(dr[i][0]), __uint_as_float(dr[i][1]), h0, m0, l0);
-      split3_pk(__uint_as_float(dr[i][2]), __uint_as_float(dr[i][3]), h1, m1, l1);
       unsigned char* dst = lds + dlds_t + slot * ROWB;
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(dst + NT * DPL) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(dst + 2 * NT * DPL) = make_uint2(l0, l1);
+      if constexpr (NP == 2) {
+        unsigned h0, l0, h1, l1;
+        split2h_pk(__uint_as_float(dr[i][0]) * dsc, __uint_as_float(dr[i][1]) * dsc, h0, l0);
+        split2h_pk(__uint_as_float(dr[i][2]) * dsc, __uint_as_float(dr[i][3]) * dsc, h1, l1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + NT * DPL) = make_uint2(l0, l1);
+      } else {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3_pk(__uint_as_float(dr[i][0]), __uint_as_float(dr[i][1]), h0, m0, l0);
+        split3_pk(__uint_as_float(dr[i][2]), __uint_as_float(dr[i][3]), h1, m1, l1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + NT * DPL) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(dst + 2 * NT * DPL) = make_uint2(l0, l1);
+      }
     }
   };
 
@@ -276,23 +328,23 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrTable t
     // ---- MFMA phase.  Unit = (k-step ks, family f): 9 transpose reads -> fragments of dx = 0, 1, 2 -> 18 MFMAs on three
     // accumulators; the reads of the next unit are issued before the MFMAs of this one (left alone, hipcc emits
     // read -> lgkmcnt(0) -> MFMA chains).
-    auto load_raw = [&](int u, uint2 (&R)[3][3]) {
+    auto load_raw = [&](int u, uint2 (&R)[NP][3]) {
       const int ks = u / NF, f = u - ks * NF;
       const int o = abase + aoff[f] + ks * 4 * XP * ROWB;
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int b = 0; b < 3; ++b) R[p][b] = tr_read(lds, o + p * XPL + b * 4 * ROWB);
     };
-    uint2 Rc[3][3], Rn[3][3];
-    bf16x8 bq[3];
+    uint2 Rc[NP][3], Rn[NP][3];
+    bf16x8 bq[NP];
     load_raw(0, Rc);
 #pragma unroll
     for (int u = 0; u < KS * NF; ++u) {
       const int ks = u / NF, f = u - ks * NF;
       if (f == 0) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
           const uint2 lo = tr_read(lds, boff0 + p * NT * DPL + ks * 4 * TX * ROWB), hi = tr_read(lds, boff1 + p * NT * DPL + ks * 4 * TX * ROWB);
           bq[p] = frag(lo.x, lo.y, hi.x, hi.y);
         }
@@ -301,13 +353,13 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrTable t
       __builtin_amdgcn_sched_barrier(0);
       if (f == 0) {                                    // d_bias: ones x d_y (the mid / lo pieces of "ones" are zero)
         const bf16x8 on = frag(one2, one2, one2, one2);
-        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(on, bq[2], accb, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(on, bq[1], accb, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(on, bq[0], accb, 0, 0, 0);
+        if constexpr (NP == 3) accb = wtr_mma<false>(on, bq[NP - 1], accb);
+        accb = wtr_mma<NP == 2>(on, bq[1], accb);
+        accb = wtr_mma<NP == 2>(on, bq[0], accb);
       }
-      bf16x8 d0[3], d1[3], d2[3];
+      bf16x8 d0[NP], d1[NP], d2[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NP; ++p) {
         const unsigned r0 = Rc[p][0].x, r1 = Rc[p][0].y, r2 = Rc[p][1].x, r3 = Rc[p][1].y, r4 = Rc[p][2].x;
         d0[p] = frag(r0, r1, r2, r3);
         d2[p] = frag(r1, r2, r3, r4);
@@ -315,23 +367,32 @@ __global__ __launch_bounds__(NTHR, 2) void conv_wgrad_tr_kernel(const WtrTable t
                      __builtin_amdgcn_alignbit(r3, r2, 16), __builtin_amdgcn_alignbit(r4, r3, 16));
       }
 #define MM3(PA, PB)                                                                                   \
-      acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0[PA], bq[PB], acc[f][0], 0, 0, 0);       \
-      acc[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1[PA], bq[PB], acc[f][1], 0, 0, 0);       \
-      acc[f][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d2[PA], bq[PB], acc[f][2], 0, 0, 0);
-      MM3(2, 0) MM3(0, 2) MM3(1, 1) MM3(1, 0) MM3(0, 1) MM3(0, 0)
+      acc[f][0] = wtr_mma<NP == 2>(d0[PA], bq[PB], acc[f][0]);       \
+      acc[f][1] = wtr_mma<NP == 2>(d1[PA], bq[PB], acc[f][1]);       \
+      acc[f][2] = wtr_mma<NP == 2>(d2[PA], bq[PB], acc[f][2]);
+      if constexpr (NP == 3) { MM3(NP - 1, 0) MM3(0, NP - 1) MM3(1, 1) }
+      MM3(1, 0) MM3(0, 1) MM3(0, 0)
 #undef MM3
       __builtin_amdgcn_sched_barrier(0);
       if (u + 1 < KS * NF) {
         if (WTR_VARIANT & 4) load_raw(u + 1, Rc);
         else {
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int b = 0; b < 3; ++b) Rc[p][b] = Rn[p][b];
         }
       }
     }
     TPH(4);
+  }
+  if constexpr (NP == 2) {                             // back from the f16 operands' scales (powers of two: exact)
+    const float winv = dinv * (1.f / WTR_F16_XSCALE);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { acc[f][d][0] *= winv; acc[f][d][1] *= winv; acc[f][d][2] *= winv; acc[f][d][3] *= winv; }
+    accb[0] *= dinv; accb[1] *= dinv; accb[2] *= dinv; accb[3] *= dinv;
   }
   // ---- sum the waves that share an N tile through LDS in fixed order; ONE fragment-major partial per workgroup:
   // part[bx][by][mt <= MT][n][lane * 4 + reg]
@@ -413,13 +474,16 @@ size_t modetx_wtr_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   return ((size_t)gx + 1) * p.gy * p.red_fl * sizeof(float);      // workgroup partials + their column sums
 }
 // launch the jobs of ONE kernel variant (nq, nt, vec) as one grid
-static void wtr_launch(const WtrTable& t, int nq, int nt, bool vec, hipStream_t s) {
+static void wtr_launch(const WtrTable& t, int nq, int nt, bool vec, bool f16, hipStream_t s) {
   const dim3 grid(t.first[t.n]);
-#define WTR_L(NQ_, NT_, V_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<NQ_, NT_, V_>), grid, dim3(NTHR), 0, s, t)
-#define WTR_Q(NT_, V_) do { if (nq == 4) WTR_L(4, NT_, V_); else if (nq == 3) WTR_L(3, NT_, V_); else if (nq == 2) WTR_L(2, NT_, V_); else WTR_L(1, NT_, V_); } while (0)
-  if (nt == 2) WTR_Q(2, true);                         // (eligibility: the odd channel counts only come with Cout <= 16)
-  else if (vec) WTR_Q(1, true);
-  else WTR_Q(1, false);
+#define WTR_L(NQ_, NT_, V_, NP_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<NQ_, NT_, V_, NP_>), grid, dim3(NTHR), 0, s, t)
+#define WTR_Q(NT_, V_, NP_) do { if (nq == 4) WTR_L(4, NT_, V_, NP_); else if (nq == 3) WTR_L(3, NT_, V_, NP_); else if (nq == 2) WTR_L(2, NT_, V_, NP_); else WTR_L(1, NT_, V_, NP_); } while (0)
+#define WTR_P(NP_) do { \
+    if (nt == 2) WTR_Q(2, true, NP_);                  /* (eligibility: the odd channel counts only come with Cout <= 16) */ \
+    else if (vec) WTR_Q(1, true, NP_); \
+    else WTR_Q(1, false, NP_); } while (0)
+  if (f16) WTR_P(2); else WTR_P(3);
+#undef WTR_P
 #undef WTR_Q
 #undef WTR_L
 }
@@ -431,13 +495,14 @@ static void wtr_launch(const WtrTable& t, int nq, int nt, bool vec, hipStream_t 
 bool modetx_wtr_batches(int B, int D, int H, int W) { return (int64_t)B * D * H * W <= WTR_BATCH_MAX_VOXELS; }
 
 int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
-                     int W, int Cin, int Cout, hipStream_t s) {
+                     int W, int Cin, int Cout, hipStream_t s, const float* amax) {
   const WtrPlan p = wtr_plan(B, D, H, W, Cin, Cout);
   const bool vec = Cin % 4 == 0 && Cout % 4 == 0;
+  if (!WTR_F16 || (int64_t)D * H * W >= (1ll << 24)) amax = nullptr;     // (two f16 pieces: the caller knows max |d_y|, x is an activation)
   float* red = (float*)ws + (size_t)p.gx * p.gy * p.red_fl;
   if (defer && modetx_wtr_batches(B, D, H, W)) {       // queued: the flush launches it together with its variant's other layers
     WtrQueued j{x, dy, (float*)ws, B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles, p.n_coblk, p.nq, p.nt, vec ? 1 : 0,
-                p.gx, p.gy};
+                p.gx, p.gy, amax};
     {
       std::lock_guard<std::mutex> lk(defer->mu);
       defer->wtrjobs.push_back(j);
@@ -445,9 +510,9 @@ int modetx_wtr_wgrad(modet_step_ctx* defer, const float* x, const float* dy, flo
     return modetx_wgrad_partials_reduce2(defer, (const float*)ws, red, dw, db, p.gx, p.gy, Cin, Cout, p.nq, p.mt, p.nt, p.n_coblk, s);
   }
   WtrTable t;
-  t.job[0] = WtrArgs{x, dy, (float*)ws, B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles, p.n_coblk};
+  t.job[0] = WtrArgs{x, dy, (float*)ws, B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.ntiles, p.n_coblk, amax};
   t.first[0] = 0; t.first[1] = p.gx * p.gy; t.gx[0] = p.gx; t.gy[0] = p.gy; t.n = 1;
-  wtr_launch(t, p.nq, p.nt, vec, s);
+  wtr_launch(t, p.nq, p.nt, vec, amax != nullptr, s);
   return modetx_wgrad_partials_reduce2(defer, (const float*)ws, red, dw, db, p.gx, p.gy, Cin, Cout, p.nq, p.mt, p.nt, p.n_coblk, s);
 }
 
@@ -465,14 +530,14 @@ void modetx_wtr_flush(modet_step_ctx* c, hipStream_t s) {
     t.n = 0; t.first[0] = 0;
     for (size_t k = i; k < jobs.size() && t.n < WTR_MAX_JOBS; ++k) {
       const WtrQueued& q = jobs[k];
-      if (done[k] || q.nq != jobs[i].nq || q.nt != jobs[i].nt || q.vec != jobs[i].vec) continue;
-      t.job[t.n] = WtrArgs{q.x, q.dy, q.part, q.B, q.D, q.H, q.W, q.Cin, q.Cout, q.tiles_x, q.tiles_y, q.tiles_z, q.ntiles, q.n_coblk};
+      if (done[k] || q.nq != jobs[i].nq || q.nt != jobs[i].nt || q.vec != jobs[i].vec || (q.amax != nullptr) != (jobs[i].amax != nullptr)) continue;
+      t.job[t.n] = WtrArgs{q.x, q.dy, q.part, q.B, q.D, q.H, q.W, q.Cin, q.Cout, q.tiles_x, q.tiles_y, q.tiles_z, q.ntiles, q.n_coblk, q.amax};
       t.gx[t.n] = q.gx; t.gy[t.n] = q.gy;
       t.first[t.n + 1] = t.first[t.n] + q.gx * q.gy;
       ++t.n;
       done[k] = 1;
     }
     for (int k = t.n; k < WTR_MAX_JOBS; ++k) { t.first[k + 1] = t.first[t.n]; t.gx[k] = 1; t.gy[k] = 1; }
-    wtr_launch(t, jobs[i].nq, jobs[i].nt, jobs[i].vec != 0, s);
+    wtr_launch(t, jobs[i].nq, jobs[i].nt, jobs[i].vec != 0, jobs[i].amax != nullptr, s);
   }
 }

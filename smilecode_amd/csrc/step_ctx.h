@@ -46,6 +46,7 @@ struct WtrQueued {
   const float* x; const float* dy; float* part;
   int B, D, H, W, Cin, Cout, tiles_x, tiles_y, tiles_z, ntiles, n_coblk;
   int nq, nt, vec, gx, gy;
+  const float* amax;                  // two f16 pieces: the maxima of |d_y| (MODET_AMAX_SLOTS slots), else null (three bf16 pieces)
 };
 
 struct modet_step_ctx {

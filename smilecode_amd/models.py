@@ -259,7 +259,7 @@ class CWM(nn.Module):
     def forward(self, x):
         x = ops.upsample2(x, 1.0)
         # ConvIns -> ConvIns -> Conv: both normalised intermediates live only inside the consuming conv's kernels
-        raw0, st0 = ops.conv3d_with_stats(x, self.conv[0].main.weight, self.conv[0].main.bias)
+        raw0, st0 = ops.conv3d_with_stats(x, self.conv[0].main.weight, self.conv[0].main.bias, x_act=True)   # (x: flow fields, |x| <= 1)
         raw1, st1 = ops.lazy_instnorm_conv3d(raw0, st0, self.conv[1].main.weight, self.conv[1].main.bias)
         logits, _ = ops.lazy_instnorm_conv3d(raw1, st1, self.conv[2].weight, self.conv[2].bias, want_stats=False)
         return ops.cwm_tail(x, logits)

@@ -155,20 +155,24 @@ _FAM_CACHE = {}
 _FAM_SUFFIX = ("", "@split", "@x3", "@direct", "@tr", "@q")
 
 
-def _conv_tag(kind, x_shape, Cin, Cout, variant=0):
+def _conv_tag(kind, x_shape, Cin, Cout, variant=0, f16=None):
     """KernelTimer tag of a conv launch: 'conv_fwd[8->8]@x3' names the kernel family that runs this shape (exact-f32
     MFMA: no suffix; tiled bf16x3: @split; z-marching bf16x3: @x3; small-volume direct MFMA: @direct; transpose-read weight
     gradient: @tr) -- only evaluated while a timer is installed.  ``variant`` = what the launch fuses (it changes the routing,
-    include/modet_hip.h modet_conv3d_kernel_family_v): 0 plain, 1 LeakyReLU, 2 normalised input, 3 statistics."""
+    include/modet_hip.h modet_conv3d_kernel_family_v): 0 plain, 1 LeakyReLU, 2 normalised input, 3 statistics.  '@x3h': the
+    z-marching kernel on two f16 pieces (three products per fp32 product instead of six) -- every forward launch, and the
+    backward launches that were given max |d_y| (f16=True)."""
     if _TIMER is None:
         return None
-    key = (kind, tuple(x_shape[:4]), Cin, Cout, variant)
+    f16 = (kind == "fwd") if f16 is None else bool(f16)
+    key = (kind, tuple(x_shape[:4]), Cin, Cout, variant, f16)
     t = _FAM_CACHE.get(key)
     if t is None:
         B, D, H, W = x_shape[:4]
         fam = _L().modet_conv3d_kernel_family_v(B, D, H, W, Cin, Cout, {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind], variant)
         arrow = f"{Cout}->{Cin}" if kind == "dgrad" else f"{Cin}->{Cout}"
-        t = _FAM_CACHE[key] = f"conv_{kind}[{arrow}]{_FAM_SUFFIX[fam]}"
+        half = f16 and D * H * W < (1 << 24) and fam in (2, 4, 5)
+        t = _FAM_CACHE[key] = f"conv_{kind}[{arrow}]{_FAM_SUFFIX[fam]}" + ("h" if half else "")
     return t
 
 
@@ -259,11 +263,18 @@ AMAX_FLOATS = 64 * 32                     # MODET_AMAX_FLOATS: 64 slots, 128 byt
 
 
 def _new_amax(like):
-    """the buffer an InstanceNorm backward leaves max |d_x| in -- only where a z-marching conv kernel can consume d_x as its d_y
-    (<= 16 channels, >= 4096 voxels per sample: modetx_x3_eligible), else None (the plain call)"""
-    if not GRAD_F16 or like.shape[-1] > 16 or like.numel() // (like.shape[0] * like.shape[-1]) < 4096:
+    """the buffer an InstanceNorm backward leaves max |d_x| in -- only where a conv kernel with an f16 form (families 2 and 5)
+    would consume d_x as its d_y, else None (the plain call)"""
+    if not GRAD_F16:
         return None
-    return torch.empty(AMAX_FLOATS, dtype=torch.float32, device=like.device)
+    if like.dim() != 5:
+        return None
+    B, D, H, W, C = like.shape
+    key = ("amax", B, D, H, W, C)
+    use = _FAM_CACHE.get(key)
+    if use is None:          # (the consumer's other channel count is not known here; the families split by volume and channel class)
+        use = _FAM_CACHE[key] = _L().modet_conv3d_kernel_family(B, D, H, W, C, C, 1) in (2, 5)
+    return torch.empty(AMAX_FLOATS, dtype=torch.float32, device=like.device) if use else None
 
 
 def amax_buffer(value):
@@ -293,7 +304,7 @@ def conv3d_backward_data(dy, w, Cin, step=None, amax=None):
     nb = L.modet_conv3d_ws_bytes(Cin, Cout)
     ws = _ws(nb, dy)
     n = float(B) * D * H * W
-    with _Guard(dy, _conv_tag("dgrad", dy.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+    with _Guard(dy, _conv_tag("dgrad", dy.shape, Cin, Cout, f16=amax is not None), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
         _lib.check(L.modet_conv3d_bwd_data_amax(_p(dy), _p(w), _p(dx), _p(ws), nb, B, D, H, W, Cin, Cout, _p(amax), _stream(),
                                                 _h(step)), "modet_conv3d_bwd_data")
     return dx
@@ -485,7 +496,8 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
             scope._keep.extend((x, dy, y_act))                # read by the side stream: alive until the flush joins it
         else:
             ws = _ws(nb, x)
-            with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+            with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout, f16=amax is not None and y_act is None), 54.0 * Cin * Cout * n,
+                        4.0 * n * (Cin + Cout)):
                 if amax is not None and y_act is None:
                     _lib.check(L.modet_conv3d_bwd_weight_amax(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
                                                               _p(amax), _stream(), _h(scope)), "modet_conv3d_bwd_weight_amax")
@@ -493,6 +505,8 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
                     _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
                                                                Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
         scope._keep.append(ws)                                # the partial tiles must survive until the flush
+        if amax is not None:
+            scope._keep.append(amax)                          # (a queued launch reads the maximum at the flush, too)
         if y_act is None and L.modet_conv3d_wgrad_defers_operands(B, D, H, W, Cin, Cout):
             scope._keep.extend((x, dy))                       # small levels: the launch itself is queued and reads them at the flush
         scope.written.add(w.data_ptr())
@@ -502,7 +516,8 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
     ws = _ws(nb, x)
     dw = torch.empty((Cout, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
-    with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+    with _Guard(x, _conv_tag("wgrad", x.shape, Cin, Cout, f16=amax is not None and y_act is None), 54.0 * Cin * Cout * n,
+                4.0 * n * (Cin + Cout)):
         if y_act is not None:
             _lib.check(L.modet_conv3d_bwd_weight_act(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
                                                      Cout, _stream()), "modet_conv3d_bwd_weight_act")
@@ -699,7 +714,7 @@ class _InstNormConv(Function):
                 nb = L.modet_conv3d_ws_bytes(C, Cout)
                 ws = _ws(nb, dz)
                 n = float(B) * V
-                with _Guard(dz, _conv_tag("dgrad", dz.shape, C, Cout), 54.0 * C * Cout * n, 4.0 * n * (2 * C + Cout)):
+                with _Guard(dz, _conv_tag("dgrad", dz.shape, C, Cout, f16=amax is not None), 54.0 * C * Cout * n, 4.0 * n * (2 * C + Cout)):
                     _lib.check(L.modet_conv3d_bwd_data_instats_amax(_p(dz), _p(w), _p(d_y), _p(x_raw), _p(mean), _p(rstd), _p(rows),
                                                                     rb, _p(ws), nb, B, D, H, W, C, Cout, _p(amax), _stream(),
                                                                     _h(ctx.step)), "modet_conv3d_bwd_data_instats")

@@ -687,6 +687,56 @@ def test_instnorm_backward_leaves_the_gradient_maximum(ops):
     assert tag2 is not None and float(tag2[::32].max()) == float(dx2.abs().max())
 
 
+@pytest.mark.parametrize("Cin,Cout,shape,xs,ws", [(32, 32, (40, 48, 40), 1.0, 1.0), (16, 32, (40, 48, 40), 30.0, 0.05), (64, 64, (20, 24, 20), 2e-3, 4.0),
+                                                  (24, 48, (20, 24, 28), 1.0, 1.0), (6, 12, (40, 48, 56), 0.5, 1.0), (32, 64, (20, 24, 20), 200.0, 1.0)])
+def test_conv_q_two_f16_pieces_forward_and_gradient(ops, Cin, Cout, shape, xs, ws):
+    """Round 5: the channel-quad kernel of the mid / coarse levels and the CWM layers (family 5) on two f16 pieces: forward
+    (activations x 2^4, weights x 2^8) and, given max |d_y|, the data gradient -- against fp64 over activation scales 2e-3..200,
+    weight scales 0.05..4, gradients of 1e-7: <= 3e-6 of max and no worse than the bf16x3 launch (the fp32 accumulation of up to
+    1 728 terms is what both are limited by), finite; the gradient differs in rounding from the bf16x3 launch
+    (i.e. the f16 form ran)."""
+    B = 2
+    D, H, W = shape
+    gen = torch.Generator().manual_seed(Cin * 5 + Cout)
+    x = (torch.randn((B, Cin, D, H, W), generator=gen) * xs).double()
+    w = (torch.randn((Cout, Cin, 3, 3, 3), generator=gen) * ws / np.sqrt(27 * Cin)).double()
+    b = (torch.randn(Cout, generator=gen) * 0.1).double()
+    gy = torch.randn((B, Cout, D, H, W), generator=gen).double() * 1e-7
+    L = ops._L()
+    assert L.modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 0) == 5 and L.modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 1) == 5
+    ry = torch.nn.functional.conv3d(x, w, b, padding=1)
+    rx = torch.nn.grad.conv3d_input(x.shape, w, gy, padding=1)
+    xd, gd, wd, bd = cl(x.numpy()), cl(gy.numpy()), w.float().cuda(), b.float().cuda()
+    t64 = lambda t: torch.from_numpy(ncdhw(t))                                              # noqa: E731
+    y = ops.conv3d_forward(xd, wd, bd, False)
+    ey = float((t64(y) - ry).abs().max() / ry.abs().max())
+    assert bool(torch.isfinite(y).all()) and ey < 3e-6, ey              # (1 728 fp32-accumulated terms at 64 channels)
+    dx3 = ops.conv3d_backward_data(gd, wd, Cin)
+    dx2 = ops.conv3d_backward_data(gd, wd, Cin, amax=ops.amax_buffer(gd.abs().max()))
+    e2 = float((t64(dx2) - rx).abs().max() / rx.abs().max())
+    e3 = float((t64(dx3) - rx).abs().max() / rx.abs().max())
+    _note(f"convq_f16x2[{Cin}->{Cout},x~{xs:g},w~{ws:g}].fwd_maxerr_of_max", ey)
+    _note(f"convq_f16x2[{Cin}->{Cout},x~{xs:g},w~{ws:g}].dgrad_maxerr_of_max", e2)
+    _note(f"convq_bf16x3[{Cin}->{Cout},x~{xs:g},w~{ws:g}].dgrad_maxerr_of_max", e3)
+    assert bool(torch.isfinite(dx2).all()) and e2 < 3e-6 and e2 <= 1.5 * e3 + 2e-7 and not torch.equal(dx2, dx3), (e2, e3)
+    # weight gradient (family 4, transpose-read kernel) with x an activation
+    xa = torch.nn.functional.leaky_relu(x / xs, 0.1)
+    rw = torch.nn.grad.conv3d_weight(xa, w.shape, gy, padding=1)
+    rb = gy.sum((0, 2, 3, 4))
+    xad = cl(xa.numpy())
+    if L.modet_conv3d_kernel_family(B, D, H, W, Cin, Cout, 2) == 4:
+        dw3, db3 = ops.conv3d_backward_weight(xad, gd, True)
+        dw2, db2 = ops.conv3d_backward_weight(xad, gd, True, amax=ops.amax_buffer(gd.abs().max()))
+        ew2 = float((dw2.double().cpu() - rw).abs().max() / rw.abs().max())
+        ew3 = float((dw3.double().cpu() - rw).abs().max() / rw.abs().max())
+        eb2 = float((db2.double().cpu() - rb).abs().max() / rb.abs().max())
+        _note(f"convwtr_f16x2[{Cin}->{Cout}].wgrad_maxerr_of_max", ew2)
+        _note(f"convwtr_bf16x3[{Cin}->{Cout}].wgrad_maxerr_of_max", ew3)
+        assert bool(torch.isfinite(dw2).all()) and ew2 < 3e-6 and eb2 < 3e-5 and not torch.equal(dw2, dw3), (ew2, ew3, eb2)
+        dw2r, _ = ops.conv3d_backward_weight(xad, gd, True, amax=ops.amax_buffer(gd.abs().max()))
+        assert torch.equal(dw2, dw2r)
+
+
 @pytest.mark.parametrize("Cin,Cout,gs,heavy", [(8, 8, 1.0, False), (8, 8, 3e-9, False), (8, 8, 2e3, True), (4, 8, 1e-6, True),
                                                (8, 4, 1e-7, False), (16, 16, 1e-5, True), (8, 16, 40.0, False)])
 def test_conv_backward_two_f16_pieces_with_gradient_maximum(ops, Cin, Cout, gs, heavy):
