@@ -128,6 +128,21 @@ int modet_na_bwd_t(const void* q, const void* k, int qk_bf16, const float* rpb, 
  *   4 = (weight gradient only) bf16x3 through LDS transpose reads, ds_read_b64_tr_b16: every layer with Cin >= 12 or an
  *       odd channel count, and Cout = 16                                                           conv3d_wtr.hip
  * Families 1 and 2 produce the fused InstanceNorm statistics (modet_conv3d_fwd_stats) at no cost for every Cout.
+ * TWO f16 PIECES (round 5).  Families 2, 4 and 5 have a second form of the same fp32-accurate arithmetic: every operand split
+ * into two f16 pieces (x = hi + lo, |lo| <= 2^-11 |x|: x carried to 2^-22 |x|), a product as the THREE piece products
+ * hi*hi + hi*lo + lo*hi (the dropped lo*lo is 2^-22 |a b|) -- half the matrix-pipe work of the six bf16 products; measured
+ * against fp64 it sits in the same error class (tests/test_gpu_ops.py, test_conv_*_f16_*: <= 7e-7 of max|y|, never worse than
+ * the bf16x3 launch of the same tensors).  f16 has the mantissa for this but not the range (65 504; subnormal below 6e-5), so
+ * the operands are scaled by exact powers of two while they are split and the accumulator is scaled back:
+ *   weights x 2^8 (|w| < 255);
+ *   activations x 2^4: FORWARD launches take this form unconditionally -- their x is a ConvBlock / ConvInsBlock output, a
+ *     pooled or upsampled copy of one, or a flow field; LeakyReLU(InstanceNorm(.)) is bounded by sqrt(V), so volumes below 2^24
+ *     voxels cannot overflow; CONTRACT: |x| < 4 094 for forward launches of families 2 and 5 (65 504 for family 2 with
+ *     Cin = 4, the layer behind the un-normalised ConvBlock 1 -> 4, which stays unscaled); beyond that the result is inf.
+ *     (The model never leaves that range; the Cin = 1 layer that sees the raw image is family 0, any range.)
+ *   gradients by the power of two that takes max |d_y| into [2^14, 2^15): BACKWARD launches take the f16 form only when the
+ *     caller hands that maximum over (the *_amax entry points below; the InstanceNorm backward that produces a d_y leaves it
+ *     for free), otherwise they run the three bf16 pieces, which need no range information.
  * The choice is a function of the arguments alone: the product library reads NO environment variable.  The A/B switches
  * MODET_CONV_X3=0 (no family 2), MODET_CONV_SPLIT=0 / 1 (no / forced family 1), MODET_CONV_DIRECT=0 (no family 3),
  * MODET_CONV_WTR=0 (no family 4), MODET_CONV_Q=0 (no family 5) exist only in tuning builds of the library (-DMODET_TUNING, tools/build_variant.sh).
@@ -172,7 +187,8 @@ int modet_conv3d_bwd_data_instats(const float* d_y, const float* w, float* d_x, 
                                   const float* rstd, float* rows, size_t rows_bytes, void* ws, size_t ws_bytes,
                                   int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream, modet_step_ctx_t* step);
 /* modet_conv3d_bwd_data / _instats given a bound of |d_y|: dy_amax (device memory, MODET_AMAX_FLOATS floats, the bound is the
- * max over its MODET_AMAX_SLOTS slots) >= max |d_y| over the whole tensor, as left by modet_instnorm_lrelu_bwd*_amax.  The z-marching kernel family (2) then runs the gradient on TWO f16 pieces per operand
+ * max over its MODET_AMAX_SLOTS slots) >= max |d_y| over the whole tensor, as left by modet_instnorm_lrelu_bwd*_amax.  The z-marching and channel-quad kernel families (2, 5)
+ * then run the gradient on TWO f16 pieces per operand
  * (three MFMA products, like its forward launches since round 5) instead of three bf16 pieces (six): f16 has the mantissa for
  * it but not the range, and a gradient has no a-priori range -- d_y is scaled by the power of two that takes dy_amax to
  * [2^14, 2^15) while it is split, the accumulator is scaled back (exact).  Elements below 2^-18 dy_amax keep an ABSOLUTE
@@ -226,8 +242,9 @@ int modet_conv3d_wgrad_defer_flush(modet_step_ctx_t* step, modet_stream_t stream
 /* modet_conv3d_bwd_weight_defer (step != NULL) / modet_conv3d_bwd_weight (step == NULL) given a bound of |d_y| (see
  * modet_conv3d_bwd_data_amax) and the promise that x is an ACTIVATION -- LeakyReLU(InstanceNorm(.)) or the first ConvBlock's
  * output, |x| < 4000: the z-marching weight-gradient kernel then splits both operands into two f16 pieces (x by a fixed power
- * of two, d_y by the one dy_amax gives) and runs three products instead of six.  y_act must be NULL.  dy_amax == NULL or a shape
- * of another kernel: exactly the plain call. */
+ * of two, d_y by the one dy_amax gives) and runs three products instead of six; so does the transpose-read kernel (family 4;
+ * a launch it queues in `step` reads dy_amax at the flush: keep it alive until then, like x and d_y).  y_act must be NULL.
+ * dy_amax == NULL or a shape of another kernel: exactly the plain call. */
 int modet_conv3d_bwd_weight_amax(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes, int B,
                                  int D, int H, int W, int Cin, int Cout, const float* dy_amax, modet_stream_t stream,
                                  modet_step_ctx_t* step);

@@ -451,6 +451,23 @@ class StepContext:
                 return None
         return dw, db
 
+    def claim(self, *params):
+        """gradient destinations of a node's parameters (projection weight / bias / gamma / beta, an attention's rpb): the
+        list of destination tensors when EVERY one has a destination and none was written in this scope yet -- they are then
+        marked written and the node's backward kernel writes its results straight there (no gradient returned to autograd,
+        no packing copy) -- else None -> the node returns its gradients to autograd as usual."""
+        if self.dst is None:
+            return None
+        out = []
+        for p in params:
+            d = self.dst.get(p.data_ptr())
+            if d is None or d.shape != p.shape or p.data_ptr() in self.written:
+                return None
+            out.append(d)
+        for p in params:
+            self.written.add(p.data_ptr())
+        return out
+
 
 _TLS = threading.local()
 
@@ -979,25 +996,30 @@ class _ProjLN(Function):
         with _Guard(x, f"proj_ln_fwd[{Cin}->{dim}]", N * (2.0 * Cin * dim + 8.0 * dim), 4.0 * N * (Cin + dim)):
             _lib.check(_L().modet_proj_ln_fwd(_p(x), _p(Wt), _p(b), _p(gamma), _p(beta), _p(y), N, Cin, dim, eps,
                                               _stream()), "modet_proj_ln_fwd")
-        ctx.save_for_backward(x, Wt, b, gamma)
+        ctx.save_for_backward(x, Wt, b, gamma, beta)
         ctx.eps = eps
+        ctx.step = current_step()
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, Wt, b, gamma = ctx.saved_tensors
+        x, Wt, b, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
         Cin = x.shape[-1]
         dim = Wt.shape[0]
         N = x.numel() // Cin
         dx = torch.empty_like(x)
-        dW, db, dg, dbeta = torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma), torch.empty_like(gamma)
+        dst = ctx.step.claim(Wt, b, gamma, beta) if ctx.step is not None else None
+        dW, db, dg, dbeta = dst if dst is not None else (torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma),
+                                                         torch.empty_like(gamma))
         L = _L()
         nb = L.modet_proj_ln_bwd_ws_bytes(N, Cin, dim)
         ws = _ws(nb, x)
         with _Guard(x, f"proj_ln_bwd[{Cin}->{dim}]", N * (6.0 * Cin * dim + 20.0 * dim), 4.0 * N * (2 * Cin + dim)):
             _lib.check(L.modet_proj_ln_bwd(_p(x), _p(Wt), _p(b), _p(gamma), _p(dy), _p(dx), _p(dW), _p(db), _p(dg),
                                            _p(dbeta), _p(ws), nb, N, Cin, dim, ctx.eps, _stream()), "modet_proj_ln_bwd")
+        if dst is not None:
+            return dx, None, None, None, None, None
         return dx, dW, db, dg, dbeta, None
 
 
@@ -1019,19 +1041,22 @@ class _ProjLNPair(Function):
                 _lib.check(L.modet_proj_ln_fwd(_p(x), _p(Wt), _p(b), _p(gamma), _p(beta), _p(y), N, Cin, dim, eps, _stream()),
                            "modet_proj_ln_fwd")
             ys.append(y)
-        ctx.save_for_backward(x1, x2, Wt, b, gamma)
+        ctx.save_for_backward(x1, x2, Wt, b, gamma, beta)
         ctx.eps = eps
+        ctx.step = current_step()
         return ys[0], ys[1]
 
     @staticmethod
     def backward(ctx, dy1, dy2):
-        x1, x2, Wt, b, gamma = ctx.saved_tensors
+        x1, x2, Wt, b, gamma, beta = ctx.saved_tensors
         dy1, dy2 = dy1.contiguous(), dy2.contiguous()
         Cin = x1.shape[-1]
         dim = Wt.shape[0]
         N = x1.numel() // Cin
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
-        dW, db, dg, dbeta = torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma), torch.empty_like(gamma)
+        dst = ctx.step.claim(Wt, b, gamma, beta) if ctx.step is not None else None
+        dW, db, dg, dbeta = dst if dst is not None else (torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma),
+                                                         torch.empty_like(gamma))
         L = _L()
         nb = L.modet_proj_ln_bwd_pair_ws_bytes(N, Cin, dim)
         ws = _ws(nb, x1)
@@ -1039,6 +1064,8 @@ class _ProjLNPair(Function):
             _lib.check(L.modet_proj_ln_bwd_pair(_p(x1), _p(dy1), _p(dx1), _p(x2), _p(dy2), _p(dx2), _p(Wt), _p(b), _p(gamma),
                                                 _p(dW), _p(db), _p(dg), _p(dbeta), _p(ws), nb, N, Cin, dim, ctx.eps,
                                                 _stream()), "modet_proj_ln_bwd_pair")
+        if dst is not None:
+            return dx1, dx2, None, None, None, None, None
         return dx1, dx2, dW, db, dg, dbeta, None
 
 
@@ -1073,6 +1100,7 @@ class _NA(Function):
         if need_grad:
             ctx.save_for_backward(q, k, rpb, out, lse)
         ctx.heads, ctx.scale = heads, float(scale)
+        ctx.step = current_step()
         return out
 
     @staticmethod
@@ -1081,7 +1109,9 @@ class _NA(Function):
         dout = dout.contiguous()
         B, D, H, W, C = q.shape
         heads = ctx.heads
-        dq, dk, drpb = torch.empty_like(q), torch.empty_like(k), torch.empty_like(rpb)
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        dst = ctx.step.claim(rpb) if ctx.step is not None else None
+        drpb = dst[0] if dst is not None else torch.empty_like(rpb)
         L = _L()
         nb = L.modet_na_bwd_ws_bytes(B, D, H, W, heads)
         ws = _ws(nb, q)
@@ -1089,7 +1119,7 @@ class _NA(Function):
         with _Guard(q, f"na_bwd[h{heads}]", 1900.0 * nvh, 124.0 * nvh):
             _lib.check(L.modet_na_bwd(_p(q), _p(k), _p(rpb), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(drpb), _p(ws),
                                       nb, B, D, H, W, heads, C // heads, ctx.scale, _stream()), "modet_na_bwd")
-        return dq, dk, drpb, None, None
+        return dq, dk, (None if dst is not None else drpb), None, None
 
 
 class _LevelAttnBF16(Function):
