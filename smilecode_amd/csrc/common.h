@@ -91,21 +91,24 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats 
 // Fixed assignment + fixed order: deterministic.  Used as stage 1 of the two-stage statistics reductions
 // (stage 2 adds the per-slice results in slice order).
 constexpr int COLSUM_SLICES = 64;
+// `stride` > 0: the matrix has `stride` columns per row and this call sums its columns [base .. base + ncol) only (a column
+// group per workgroup: the per-column order of the additions does not depend on the grouping's width only on `per`).
 template <typename T>
 __device__ __forceinline__ void block_colsum_256(const T* __restrict__ base, int64_t r0, int64_t r1, int ncol,
-                                                 double* __restrict__ out, double* sm /* [256] shared */) {
+                                                 double* __restrict__ out, double* sm /* [256] shared */, int stride = 0) {
   const int per = 256 / ncol;
   const int col = threadIdx.x % ncol, rl = threadIdx.x / ncol;
+  const int64_t rs = stride > 0 ? stride : ncol;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (rl < per) {
     int64_t r = r0 + rl;
     for (; r + 3 * per < r1; r += 4 * per) {
-      a0 += (double)base[r * ncol + col];
-      a1 += (double)base[(r + per) * ncol + col];
-      a2 += (double)base[(r + 2 * per) * ncol + col];
-      a3 += (double)base[(r + 3 * per) * ncol + col];
+      a0 += (double)base[r * rs + col];
+      a1 += (double)base[(r + per) * rs + col];
+      a2 += (double)base[(r + 2 * per) * rs + col];
+      a3 += (double)base[(r + 3 * per) * rs + col];
     }
-    for (; r < r1; r += per) a0 += (double)base[r * ncol + col];
+    for (; r < r1; r += per) a0 += (double)base[r * rs + col];
   }
   sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();

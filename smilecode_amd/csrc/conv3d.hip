@@ -1801,7 +1801,9 @@ size_t modetx_q_ws_bytes(int Cin, int Cout);
 size_t modetx_q_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                   const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int mode,
-                  hipStream_t s, const float* amax = nullptr);
+                  hipStream_t s, const float* amax = nullptr, const float* xraw = nullptr, const float* bmean = nullptr,
+                  const float* brstd = nullptr, float* bst_rows = nullptr);
+size_t modetx_q_bst_rows_bytes(int B, int D, int H, int W, int Cin, int Cout);
 static bool use_q(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = modet_tuning_env("MODET_CONV_Q") != '0';
   // (level 5 -- 2.4 k voxels, 64 / 128 channels -- stays on conv_direct_kernel: 8 stagings of a 128-voxel tile in a row there,
@@ -2056,8 +2058,11 @@ int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const floa
 }
 
 size_t modet_conv3d_bwd_data_instats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
-  if (B > 32 || Cin % 4 != 0 || !use_x3(B, D, H, W, Cout, Cin)) return 0;
-  return modetx_x3_bst_rows_bytes(B, D, H, W, Cin, Cout);
+  if (B > 32 || Cin % 4 != 0) return 0;
+  if (use_x3(B, D, H, W, Cout, Cin)) return modetx_x3_bst_rows_bytes(B, D, H, W, Cin, Cout);
+  // the channel-quad kernel (family 5) carries the same epilogue; 2 Cin <= 256: the rows' finalize sums 2 Cin columns
+  if (use_q(B, D, H, W, Cout, Cin) && 2 * Cin <= 256) return modetx_q_bst_rows_bytes(B, D, H, W, Cout, Cin);
+  return 0;
 }
 
 int modet_conv3d_bwd_data_instats(const float* d_y, const float* w, float* d_x, const float* x_raw, const float* mean,
@@ -2077,6 +2082,11 @@ int modet_conv3d_bwd_data_instats_amax(const float* d_y, const float* w, float* 
   const size_t need = modet_conv3d_bwd_data_instats_bytes(B, D, H, W, Cin, Cout);
   if (need == 0) return MODET_ERR_UNSUPPORTED;
   if (rows_bytes < need) return MODET_ERR_WORKSPACE;
+  if (!use_x3(B, D, H, W, Cout, Cin)) {
+    if (ws_bytes < modetx_q_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
+    return modetx_q_conv(step, d_y, w, nullptr, d_x, ws, nullptr, nullptr, nullptr, B, D, H, W, Cout, Cin, 1, (hipStream_t)stream,
+                         dy_amax, x_raw, mean, rstd, rows);
+  }
   if (ws_bytes < fwd_ws_elems(Cout, Cin) * sizeof(float) || ws_bytes < modetx_x3_ws_bytes(Cout, Cin)) return MODET_ERR_WORKSPACE;
   return modetx_x3_dgrad_bst(step, d_y, w, d_x, x_raw, mean, rstd, rows, ws, B, D, H, W, Cin, Cout, (hipStream_t)stream, dy_amax);
 }

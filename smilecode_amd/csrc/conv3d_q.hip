@@ -142,7 +142,10 @@ __global__ void q_pack_many_kernel(const QPackTable t) {
 struct QArgs {
   const float* x; const uint4* wpk; const float* bias; float* y;
   const float* in_mean; const float* in_rstd;          // NORM: the input is LeakyReLU((x - mean) * rstd), applied while staging
-  float* stats_rows; const float* shift;               // STATS: rows [B][tiles][Cout][2] of sum(y - K), sum((y - K)^2); K = shift[b][co]
+  float* stats_rows; const float* shift;               // STATS 1: rows [B][tiles][Cout][2] of sum(y - K), sum((y - K)^2); K = shift[b][co]
+  const float* xraw; const float* bmean; const float* brstd;   // STATS 2 (a data gradient whose output is the gradient w.r.t.
+                                                       // LeakyReLU(InstanceNorm(xraw))): rows of sum g, sum g * xhat, g = y * lrelu'(xhat)
+                                                       // -- the first pass of that norm's backward (as conv3d_x3.hip STATS = 2)
   int B, D, H, W, Cin, Cout, tiles_x, tiles_y, tiles_z, nstage, ct_total;
   const float* amax;                                   // f16 pieces, x = a gradient: MODET_AMAX_SLOTS maxima of |x| (else null: x 2^4)
 };
@@ -150,7 +153,7 @@ struct QArgs {
 // Wave tiling <WC, CT>: the four waves form WC cout groups x (4 / WC) voxel groups; a wave owns CT cout tiles (cout block of
 // the workgroup = WC * CT tiles) and VT = 2 WC voxel tiles.  Per k-step it reads VT x 3 pieces x 2 x 8 bytes of voxels from LDS
 // and CT x 3 x 16 bytes of weights from L2 / L1 for VT * CT * 6 MFMAs; q_plan picks the tiling per shape (measured).
-template <int NQ, int WC, int CT, bool NORM, bool STATS, int NP = 3>
+template <int NQ, int WC, int CT, bool NORM, int STATS, int NP = 3>
 __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kernel(const QArgs a) {
   static_assert(NP == 3 || NP == 2, "three bf16 pieces or two f16 pieces");
   constexpr int VT = 2 * WC;                           // voxel tiles per wave
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
     for (int j = 0; j < 4; ++j) {
       if (co + j < Cout) {
         if (a.bias) bv[j] = a.bias[co + j];
-        if (STATS) kv[j] = a.shift[b * Cout + co + j];
+        if (STATS == 1) kv[j] = a.shift[b * Cout + co + j];
       }
     }
 #pragma unroll
@@ -364,7 +367,22 @@ __global__ __launch_bounds__(NTHR, (2 * WC * CT >= 8) ? 2 : 3) void conv_q_kerne
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         o[j] = NP == 2 ? fmaf(acc[v][n][j], osc, bv[j]) : acc[v][n][j] + bv[j];
-        if (STATS && ok && co + j < Cout) { const float e = o[j] - kv[j]; sx[j] += e; sq[j] = fmaf(e, e, sq[j]); }
+        if (STATS == 1 && ok && co + j < Cout) { const float e = o[j] - kv[j]; sx[j] += e; sq[j] = fmaf(e, e, sq[j]); }
+      }
+      if constexpr (STATS == 2) {                      // (Cout % 4 == 0: checked on the host)
+        if (ok && co < Cout) {
+          const int64_t vox = (int64_t)((b * D + z) * H + yy) * W + xo;
+          const float4 xr = *reinterpret_cast<const float4*>(a.xraw + vox * Cout + co);
+          const float4 m4 = *reinterpret_cast<const float4*>(a.bmean + b * Cout + co);
+          const float4 r4 = *reinterpret_cast<const float4*>(a.brstd + b * Cout + co);
+          const float xv[4] = {xr.x, xr.y, xr.z, xr.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xh = (xv[j] - mv[j]) * rv[j];
+            const float gg = o[j] * (xh > 0.f ? 1.f : LRELU_SLOPE);
+            sx[j] += gg; sq[j] = fmaf(gg, xh, sq[j]);
+          }
+        }
       }
       if (ok) {
         float* dst = a.y + ((int64_t)((b * D + z) * H + yy) * W + xo) * Cout + co;
@@ -432,12 +450,14 @@ inline size_t q_wpk_elems(const QPlan& p) { return (size_t)p.nstage * p.ks * 3 *
 
 template <int NQ, int WC, int CT, int NP>
 void q_launch_v(const QArgs& a, const dim3& grid, hipStream_t s) {
-  if (a.in_mean) {
-    if (a.stats_rows) hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, true, true, NP>), grid, dim3(NTHR), 0, s, a);
-    else hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, true, false, NP>), grid, dim3(NTHR), 0, s, a);
+  if (a.xraw) {
+    hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, false, 2, NP>), grid, dim3(NTHR), 0, s, a);
+  } else if (a.in_mean) {
+    if (a.stats_rows) hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, true, 1, NP>), grid, dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, true, 0, NP>), grid, dim3(NTHR), 0, s, a);
   } else {
-    if (a.stats_rows) hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, false, true, NP>), grid, dim3(NTHR), 0, s, a);
-    else hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, false, false, NP>), grid, dim3(NTHR), 0, s, a);
+    if (a.stats_rows) hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, false, 1, NP>), grid, dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL((conv_q_kernel<NQ, WC, CT, false, 0, NP>), grid, dim3(NTHR), 0, s, a);
   }
 }
 template <int NQ, int NP>
@@ -463,6 +483,11 @@ size_t modetx_q_ws_bytes(int Cin, int Cout) {
   // generous: any plan pads the chunk list to 8 per k-step (<= 14 k-steps per 16 channels) and Cout to 64
   return (size_t)cdiv(Cin, 4) * 4 * 27 * 2 * ((Cout + 63) / 64 * 64) * 3 * sizeof(unsigned short) + 65536;
 }
+// rows [B][tiles][Cout][2] of the data gradient's InstanceNorm-backward statistics (STATS 2); Cout = the gradient's channels
+size_t modetx_q_bst_rows_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  const QPlan p = q_plan(B, D, H, W, Cin, Cout);
+  return (size_t)B * p.tiles_x * p.tiles_y * p.tiles_z * Cout * 2 * sizeof(float);
+}
 size_t modetx_q_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   const QPlan p = q_plan(B, D, H, W, Cin, Cout);
   const size_t tiles = (size_t)p.tiles_x * p.tiles_y * p.tiles_z;
@@ -471,7 +496,7 @@ size_t modetx_q_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
 // stats != null: [B][Cout] shift header (filled by the caller's shift kernel) followed by the rows [B][tiles][Cout][2]
 int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                   const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int mode,
-                  hipStream_t s, const float* amax) {
+                  hipStream_t s, const float* amax, const float* xraw, const float* bmean, const float* brstd, float* bst_rows) {
   const QPlan p = q_plan(B, D, H, W, Cin, Cout);
   unsigned short* wpk = (unsigned short*)ws;
   // forward: two f16 pieces (the input is an activation); data gradient: the same when the caller knows max |d_y|, else bf16x3
@@ -497,8 +522,8 @@ int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const fl
     const int total = p.nstage * p.ks * p.ct_total * 512;
     hipLaunchKernelGGL(q_pack_kernel, dim3(cdiv(total, 256) > 256 ? 256 : cdiv(total, 256)), dim3(256), 0, s, J);
   }
-  QArgs a{x, (const uint4*)wpk, bias, y, in_mean, in_rstd, stats ? stats + (size_t)B * Cout : nullptr, stats,
-          B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.nstage, p.ct_total, (f16 && mode == 1) ? amax : nullptr};
+  QArgs a{x, (const uint4*)wpk, bias, y, in_mean, in_rstd, xraw ? bst_rows : (stats ? stats + (size_t)B * Cout : nullptr), stats,
+          xraw, bmean, brstd, B, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_z, p.nstage, p.ct_total, (f16 && mode == 1) ? amax : nullptr};
   const dim3 grid(B * p.tiles_x * p.tiles_y * p.tiles_z, p.ct_total / p.cb);
 #define Q_GO(NP_) do { \
     if (p.nq == 4) q_launch_n<4, NP_>(a, p, grid, s); \

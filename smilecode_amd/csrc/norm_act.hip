@@ -181,18 +181,22 @@ __global__ __launch_bounds__(64) void in_finalize_kernel(const float* __restrict
 // statistics from the conv epilogue: stats = [B][C] shift K, then partial rows [(b*rows_per_b + r)][C][2] of
 // sum(y - K), sum((y - K)^2) (one row per workgroup of the conv; see ConvIn in conv3d.hip for why they are shifted):
 // one workgroup per sample, coalesced fixed-order fp64 column sums, then mean = K + s1/V, var = s2/V - (s1/V)^2 in fp64
+constexpr int IN_FIN_COLS = 8;                        // columns (= 8 channels x 2 sums) per finalize workgroup
 __global__ __launch_bounds__(256) void in_rows_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ rows,
                                                                float* __restrict__ mean, float* __restrict__ rstd, int64_t V,
                                                                int C, int64_t rows_per_b, float eps) {
   __shared__ double sm[256];
   __shared__ double tot[256];
-  const int b = blockIdx.x;
-  block_colsum_256(rows + (int64_t)b * rows_per_b * 2 * C, 0, rows_per_b, 2 * C, tot, sm);
+  // grid (B, column groups): a workgroup sums IN_FIN_COLS of the 2 C columns (one workgroup per sample walked thousands of
+  // rows with 4 row lanes at 64 columns: 20-40 us of dependent L2 latency per launch, 14 launches per train step)
+  const int b = blockIdx.x, c0 = blockIdx.y * IN_FIN_COLS;
+  const int ncol = 2 * C - c0 < IN_FIN_COLS ? 2 * C - c0 : IN_FIN_COLS;
+  block_colsum_256(rows + (int64_t)b * rows_per_b * 2 * C + c0, 0, rows_per_b, ncol, tot, sm, 2 * C);
   __syncthreads();
-  if ((int)threadIdx.x < C) {
-    const int c = threadIdx.x;
-    const double m = tot[2 * c] / (double)V;
-    double var = tot[2 * c + 1] / (double)V - m * m;
+  if ((int)threadIdx.x < ncol / 2) {
+    const int cl = threadIdx.x, c = c0 / 2 + cl;
+    const double m = tot[2 * cl] / (double)V;
+    double var = tot[2 * cl + 1] / (double)V - m * m;
     if (var < 0.0) var = 0.0;
     mean[b * C + c] = (float)((double)stats[b * C + c] + m);
     rstd[b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -205,14 +209,15 @@ __global__ __launch_bounds__(256) void in_rows_finalize_bwd_kernel(const float* 
                                                                    float* __restrict__ amax_zero = nullptr) {
   __shared__ double sm[256];
   __shared__ double tot[256];
-  const int b = blockIdx.x;
-  if (amax_zero && b == 0 && threadIdx.x < MODET_AMAX_SLOTS) amax_zero[threadIdx.x * MODET_AMAX_STRIDE] = 0.f;
-  block_colsum_256(rows + (int64_t)b * rows_per_b * 2 * C, 0, rows_per_b, 2 * C, tot, sm);
+  const int b = blockIdx.x, c0 = blockIdx.y * IN_FIN_COLS;
+  const int ncol = 2 * C - c0 < IN_FIN_COLS ? 2 * C - c0 : IN_FIN_COLS;
+  if (amax_zero && b == 0 && blockIdx.y == 0 && threadIdx.x < MODET_AMAX_SLOTS) amax_zero[threadIdx.x * MODET_AMAX_STRIDE] = 0.f;
+  block_colsum_256(rows + (int64_t)b * rows_per_b * 2 * C + c0, 0, rows_per_b, ncol, tot, sm, 2 * C);
   __syncthreads();
-  if ((int)threadIdx.x < C) {
-    const int c = threadIdx.x;
-    s1[b * C + c] = (float)(tot[2 * c] / (double)V);
-    s2[b * C + c] = (float)(tot[2 * c + 1] / (double)V);
+  if ((int)threadIdx.x < ncol / 2) {
+    const int cl = threadIdx.x, c = c0 / 2 + cl;
+    s1[b * C + c] = (float)(tot[2 * cl] / (double)V);
+    s2[b * C + c] = (float)(tot[2 * cl + 1] / (double)V);
   }
 }
 
@@ -940,7 +945,7 @@ int modet_instnorm_lrelu_fwd_stats(const float* x, float* y, float* mean, float*
   int64_t rows;
   if (rows_from_bytes(stats_bytes, B, C, &rows) != MODET_OK) return MODET_ERR_DIM;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, stats + (size_t)B * C, mean, rstd, V, C, rows, eps);
+  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B, (2 * C + IN_FIN_COLS - 1) / IN_FIN_COLS), dim3(256), 0, s, stats, stats + (size_t)B * C, mean, rstd, V, C, rows, eps);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_apply_kernel, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total4);
   return modet_launch_status();
@@ -958,7 +963,7 @@ int modet_instnorm_stats(const float* x, float* mean, float* rstd, const float* 
     if (2 * C > 256) return MODET_ERR_UNSUPPORTED;
     int64_t rows;
     if (rows_from_bytes(stats_bytes, B, C, &rows) != MODET_OK) return MODET_ERR_DIM;
-    hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, (const float*)stats, (const float*)stats + (size_t)B * C,
+    hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B, (2 * C + IN_FIN_COLS - 1) / IN_FIN_COLS), dim3(256), 0, s, (const float*)stats, (const float*)stats + (size_t)B * C,
                        mean, rstd, V, C, rows, eps);
     return modet_launch_status();
   }
@@ -1020,7 +1025,7 @@ int modet_instnorm_lrelu_bwd_rows_amax(const float* d_y, const float* x, const f
   hipStream_t s = (hipStream_t)stream;
   float* s1 = (float*)ws;
   float* s2 = s1 + (size_t)B * C;
-  hipLaunchKernelGGL(in_rows_finalize_bwd_kernel, dim3(B), dim3(256), 0, s, rows, s1, s2, V, C, per, amax);
+  hipLaunchKernelGGL(in_rows_finalize_bwd_kernel, dim3(B, (2 * C + IN_FIN_COLS - 1) / IN_FIN_COLS), dim3(256), 0, s, rows, s1, s2, V, C, per, amax);
   const int64_t total4 = (int64_t)B * V * (C / 4);
   hipLaunchKernelGGL(in_bwd_apply_kernel<false>, dim3(flat_grid(total4, BLK)), dim3(BLK), 0, s, d_y, x, mean, rstd, (const float*)s1,
                      (const float*)s2, d_x, V, C, total4, PoolSrc{nullptr, nullptr, nullptr, 0, 0, 0, 0}, amax);
@@ -1154,7 +1159,7 @@ int modet_instnorm_lrelu_fwd_stats_bf16(const void* x, void* y, int y_bf16, floa
   const float* trows = stats + (size_t)B * C;
   float* tail = const_cast<float*>(trows) + (size_t)B * tiles * 2 * C;
   hipLaunchKernelGGL(in_rows_slice_kernel, dim3(IN_SLICES, B), dim3(256), 0, s, trows, tail, C, tiles);
-  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, (const float*)tail, mean, rstd, V, C,
+  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B, (2 * C + IN_FIN_COLS - 1) / IN_FIN_COLS), dim3(256), 0, s, stats, (const float*)tail, mean, rstd, V, C,
                      (int64_t)IN_SLICES, eps);
   const int64_t total8 = (int64_t)B * V * (C / 8);
   if (y_bf16) hipLaunchKernelGGL(in_apply_bf16_kernel<true>, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, x, y, mean, rstd, V, C, total8);
@@ -1179,7 +1184,7 @@ int modet_instnorm_lrelu_fwd_stats_pool_bf16(const void* x, void* y_bf16, float*
   const float* trows = stats + (size_t)B * C;
   float* tail = const_cast<float*>(trows) + (size_t)B * tiles * 2 * C;
   hipLaunchKernelGGL(in_rows_slice_kernel, dim3(IN_SLICES, B), dim3(256), 0, s, trows, tail, C, tiles);
-  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B), dim3(256), 0, s, stats, (const float*)tail, mean, rstd, V, C,
+  hipLaunchKernelGGL(in_rows_finalize_kernel, dim3(B, (2 * C + IN_FIN_COLS - 1) / IN_FIN_COLS), dim3(256), 0, s, stats, (const float*)tail, mean, rstd, V, C,
                      (int64_t)IN_SLICES, eps);
   const int64_t total8 = (int64_t)B * (D / 2) * (H / 2) * (W / 2) * (C / 8);
   hipLaunchKernelGGL(in_apply_pool_bf16_kernel, dim3(flat_grid(total8, BLK)), dim3(BLK), 0, s, x, y_bf16, pooled, mean, rstd, D, H, W, C,

@@ -970,12 +970,17 @@ def test_conv_instnorm_fused_vs_oracle(ops, cin, cout, shape):
 
 @pytest.mark.parametrize("c0,c1,c2,shape,B", [(4, 8, 8, (20, 24, 28), 2), (8, 16, 16, (17, 21, 40), 1), (8, 8, 4, (33, 40, 48), 1),
                                               (6, 12, 12, (18, 20, 35), 1), (16, 32, 32, (12, 10, 20), 2),
+                                              (32, 64, 64, (20, 24, 20), 2), (12, 24, 8, (20, 24, 28), 1),
                                               (8, 8, 8, (64, 96, 112), 1)])
 def test_instnorm_conv_chain_with_fused_backward_statistics(ops, c0, c1, c2, shape, B):
     """conv -> InstanceNorm + LeakyReLU -> conv as the model runs it in training (ops.lazy_instnorm_conv3d = one autograd
     node): the second conv's data gradient forms the norm's backward statistics in its epilogue
-    (modet_conv3d_bwd_data_instats, z-march family; the other shapes take the two-kernel form) -- against fp64 autograd,
-    and against the unfused form of the same build."""
+    (modet_conv3d_bwd_data_instats: the z-march family and, since round 5, the channel-quad family of the mid / coarse levels
+    and the CWM layers; the remaining shapes take the two-kernel form) -- against fp64 autograd, and against the unfused form
+    of the same build."""
+    L = ops._L()
+    if L.modet_conv3d_kernel_family(B, *shape, c1, c2, 1) in (2, 5) and c1 % 4 == 0:
+        assert L.modet_conv3d_bwd_data_instats_bytes(B, *shape, c1, c2) > 0, "this shape must take the fused form"
     gen = torch.Generator().manual_seed(c0 * 101 + c1 * 7 + c2)
     x = torch.randn((B, c0) + shape, generator=gen).double().requires_grad_(True)
     w1 = (torch.randn((c1, c0, 3, 3, 3), generator=gen) / np.sqrt(c0 * 27)).double().requires_grad_(True)
