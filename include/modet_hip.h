@@ -248,6 +248,15 @@ int modet_conv3d_wgrad_defer_flush(modet_step_ctx_t* step, modet_stream_t stream
 int modet_conv3d_bwd_weight_amax(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes, int B,
                                  int D, int H, int W, int Cin, int Cout, const float* dy_amax, modet_stream_t stream,
                                  modet_step_ctx_t* step);
+/* Weight gradient of a conv whose INPUT was LeakyReLU(InstanceNorm(x_raw)) (ConvInsBlock -> conv), given the RAW tensor and
+ * its statistics: the normalisation is applied while x is staged (zero padding stays zero), so a training step never
+ * materialises the normalised tensor of such a chain (the forward has modet_conv3d_fwd_normin, the data gradient works on d_y
+ * alone).  Only the shapes of the z-marching weight-gradient kernel (modet_conv3d_bwd_weight_normin_ok() == 1; the level-1 layers,
+ * where the saved pass is 0.12 ms of a train step); dy_amax as in modet_conv3d_bwd_weight_amax (may be NULL); step NULL = reduce now. */
+int modet_conv3d_bwd_weight_normin_ok(int B, int D, int H, int W, int Cin, int Cout);
+int modet_conv3d_bwd_weight_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* d_y, float* d_w,
+                                   float* d_bias, void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                                   const float* dy_amax, modet_stream_t stream, modet_step_ctx_t* step);
 /* Round 5: for the many-channel layers of the small pyramid levels the deferred call queues the partial-tile LAUNCH as well
  * (17 launches of 20-50 us per train step, most too small to fill the chip); the flush runs all queued layers of one kernel
  * variant as one grid, then the reductions.  modet_conv3d_wgrad_defers_operands(..) == 1 says that a deferred call of this

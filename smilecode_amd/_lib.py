@@ -72,6 +72,8 @@ SIGNATURES = {
     "modet_conv3d_bwd_data_amax": (I, [P, P, P, P, SZ, I, I, I, I, I, I, P, P, P]),
     "modet_conv3d_bwd_data_instats_amax": (I, [P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P, P]),
     "modet_conv3d_bwd_weight_amax": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, P, P, P]),
+    "modet_conv3d_bwd_weight_normin_ok": (I, [I, I, I, I, I, I]),
+    "modet_conv3d_bwd_weight_normin": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, P, P, P]),
     "modet_avgpool2_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "modet_proj_ln_fwd": (I, [P, P, P, P, P, P, I64, I, I, F, P]),
     "modet_proj_ln_bwd_ws_bytes": (SZ, [I64, I, I]),

@@ -1774,7 +1774,8 @@ int modetx_x3_dgrad_bst(modet_step_ctx* step, const float* dy, const float* w, f
 bool modetx_x3_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout);
 size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
-                    int W, int Cin, int Cout, hipStream_t s, const float* amax = nullptr);
+                    int W, int Cin, int Cout, hipStream_t s, const float* amax = nullptr, const float* in_mean = nullptr,
+                    const float* in_rstd = nullptr);
 // bf16x3 weight gradient through LDS transpose reads (conv3d_wtr.hip): every layer the z-march kernel does not take
 // (Cin >= 12, and the few-channel layers below its voxel threshold); MODET_CONV_WTR=0 restores the exact-f32 kernels (A/B switch)
 bool modetx_wtr_eligible(int B, int D, int H, int W, int Cin, int Cout);
@@ -2204,6 +2205,20 @@ int modet_conv3d_bwd_weight_amax(const float* x, const float* d_y, float* d_w, f
                                  int D, int H, int W, int Cin, int Cout, const float* dy_amax, modet_stream_t stream,
                                  modet_step_ctx_t* step) {
   return conv_bwd_weight_impl(x, d_y, nullptr, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, step, dy_amax);
+}
+
+int modet_conv3d_bwd_weight_normin_ok(int B, int D, int H, int W, int Cin, int Cout) {
+  return use_x3_wgrad(B, D, H, W, Cin, Cout) ? 1 : 0;
+}
+
+int modet_conv3d_bwd_weight_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* d_y, float* d_w,
+                                   float* d_bias, void* ws, size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                                   const float* dy_amax, modet_stream_t stream, modet_step_ctx_t* step) {
+  MODET_CHECK_PTR(x_raw); MODET_CHECK_PTR(in_mean); MODET_CHECK_PTR(in_rstd); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  if (!use_x3_wgrad(B, D, H, W, Cin, Cout)) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < modet_conv3d_bwd_weight_ws_bytes(B, D, H, W, Cin, Cout)) return MODET_ERR_WORKSPACE;
+  return modetx_x3_wgrad(step, x_raw, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, (hipStream_t)stream, dy_amax, in_mean, in_rstd);
 }
 
 int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias,

@@ -837,6 +837,7 @@ struct X3WArgs {
   const void* x; const void* dy; float* part;                    // fp32; bf16 in the one-piece (storage) form
   int D, H, W, Cin, Cout, tiles_x, tiles_y, nchunk, ZC, nitems;
   const float* amax;                                             // NPC 2: amax[0] >= max |d_y| (device memory)
+  const float* in_mean; const float* in_rstd;                    // NORM: x is a RAW ConvInsBlock output, LeakyReLU((x - mean) * rstd) while staged
 };
 
 // NP (Cout <= 8, "N-packed"): the 16 N columns are (q in {0,1}) x 8 couts, column block q = 1 multiplies d_y shifted one
@@ -850,8 +851,12 @@ struct X3WArgs {
 // activation (scaled by 2^4; 4 channels: the un-normalised output of ConvBlock 1 -> 4, unscaled, like the forward launch), d_y a
 // gradient whose maximum the caller hands over (a.amax, left by the InstanceNorm backward that produced d_y): scaled by the power
 // of two that takes it to [2^14, 2^15).  The partial tiles are scaled back (exact) before they leave the workgroup.
-template <int CIB, int NCO, bool NP, int NPC = 3, bool X16 = false>
+// NORM (round 5): x is the raw output of the previous ConvInsBlock and is normalised while it is staged (zero padding stays
+// zero) -- the normalised tensor of a ConvInsBlock -> ConvInsBlock chain then never exists in HBM in training either (the forward
+// conv has had this form since round 2: conv_x3_kernel NORM); 5 VALU operations per staged element on the x operand.
+template <int CIB, int NCO, bool NP, int NPC = 3, bool X16 = false, bool NORM = false>
 __global__ __launch_bounds__(NTHR, NPC == 3 ? 2 : 3) void conv_x3_wgrad_kernel(const X3WArgs a) {
+  static_assert(!NORM || (NPC != 1 && !X16), "the lazily normalised input belongs to the fp32 forms");
   static_assert(!NP || NCO == 8, "N packing: 2 x 8 couts");
   static_assert(NPC == 3 || NPC == 2 || NPC == 1, "three bf16 / two f16 pieces (fp32 accuracy) or one (bf16 storage)");
   static_assert(NPC == 1 || !X16, "bf16 x belongs to the one-piece form");
@@ -917,8 +922,9 @@ __global__ __launch_bounds__(NTHR, NPC == 3 ? 2 : 3) void conv_x3_wgrad_kernel(c
   unsigned gx0 = X3_OOB, gx1 = X3_OOB, gd0 = X3_OOB, gd1 = X3_OOB;
   const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
   const unsigned char* db_ = reinterpret_cast<const unsigned char*>(a.dy);
-  struct Pair { float4 v0, v1; };                                // the two voxels of a thread's x pair / d_y pair (4 channels each;
-                                                                 // bf16 tensors: 8 bytes per voxel in .x, .y)
+  struct Pair { float4 v0, v1; bool live; };                     // the two voxels of a thread's x pair / d_y pair (4 channels each;
+                                                                 // bf16 tensors: 8 bytes per voxel in .x, .y); live: the plane exists
+  float4 nm = make_float4(0.f, 0.f, 0.f, 0.f), nr = make_float4(1.f, 1.f, 1.f, 1.f);   // NORM: this thread's 4 channels of the item's sample
   auto ld4 = [&](const BufRsrc rs, unsigned off, bool is16) -> float4 {
     if (is16) {
       const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
@@ -932,6 +938,7 @@ __global__ __launch_bounds__(NTHR, NPC == 3 ? 2 : 3) void conv_x3_wgrad_kernel(c
     Pair p;
     p.v0 = ld4(rs, gx0, X16);
     p.v1 = ld4(rs, gx1, X16);
+    p.live = live;
     return p;
   };
   auto load_dy = [&](int z, int ze) -> Pair {
@@ -940,6 +947,7 @@ __global__ __launch_bounds__(NTHR, NPC == 3 ? 2 : 3) void conv_x3_wgrad_kernel(c
     Pair p;
     p.v0 = ld4(rs, gd0, D16);
     p.v1 = ld4(rs, gd1, D16);
+    p.live = live;
     return p;
   };
   // a voxel pair's 4 channels -> packed (voxel, voxel + 1) words in the channel planes: split into three pieces each
@@ -987,7 +995,20 @@ __global__ __launch_bounds__(NTHR, NPC == 3 ? 2 : 3) void conv_x3_wgrad_kernel(c
       }
     }
   };
-  auto store_x = [&](int slot, const Pair& pr) { if (xon) put(xs + slot * XSLOT + xl, XPIECE, PX, pr, X16, xsc); };
+  auto store_x = [&](int slot, const Pair& pr0) {
+    if (!xon) return;
+    if constexpr (NORM) {                                        // out-of-volume voxels (the padding) stay exactly zero
+      Pair pr = pr0;
+      const bool k0 = pr.live && gx0 != X3_OOB, k1 = pr.live && gx1 != X3_OOB;
+      pr.v0.x = k0 ? lrelu((pr.v0.x - nm.x) * nr.x) : 0.f; pr.v0.y = k0 ? lrelu((pr.v0.y - nm.y) * nr.y) : 0.f;
+      pr.v0.z = k0 ? lrelu((pr.v0.z - nm.z) * nr.z) : 0.f; pr.v0.w = k0 ? lrelu((pr.v0.w - nm.w) * nr.w) : 0.f;
+      pr.v1.x = k1 ? lrelu((pr.v1.x - nm.x) * nr.x) : 0.f; pr.v1.y = k1 ? lrelu((pr.v1.y - nm.y) * nr.y) : 0.f;
+      pr.v1.z = k1 ? lrelu((pr.v1.z - nm.z) * nr.z) : 0.f; pr.v1.w = k1 ? lrelu((pr.v1.w - nm.w) * nr.w) : 0.f;
+      put(xs + slot * XSLOT + xl, XPIECE, PX, pr, X16, xsc);
+    } else {
+      put(xs + slot * XSLOT + xl, XPIECE, PX, pr0, X16, xsc);
+    }
+  };
   auto store_dy = [&](int slot, const Pair& pr) { if (don) put(dys + slot * DSLOT + dl, DPIECE, PD, pr, D16, dsc); };
 
   // ---- one d_y plane (slot ds) against the three x planes around it: x plane of tap dz sits in ring slot (q + dz) & 3
@@ -1077,6 +1098,12 @@ __global__ __launch_bounds__(NTHR, NPC == 3 ? 2 : 3) void conv_x3_wgrad_kernel(c
       const bool dok = don && dyy < H && dc4 * 4 < Cout;
       gd0 = (dok && dxx < W) ? (unsigned)(((dyy * W + dxx) * Cout + dc4 * 4) * DSZ) : X3_OOB;
       gd1 = (dok && dxx + 1 < W) ? (unsigned)(((dyy * W + dxx + 1) * Cout + dc4 * 4) * DSZ) : X3_OOB;
+      if constexpr (NORM) {
+        if (xon && xc4 * 4 < Cin) {
+          nm = *reinterpret_cast<const float4*>(a.in_mean + b * Cin + xc4 * 4);
+          nr = *reinterpret_cast<const float4*>(a.in_rstd + b * Cin + xc4 * 4);
+        }
+      }
     }
     __syncthreads();                                             // every wave is done with the previous item's planes
     // prologue: x planes zs-1, zs, zs+1 -> ring slots 0, 1, 2; d_y plane zs -> slot 0 (all four loads in flight together);
@@ -1264,21 +1291,22 @@ size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   return ((size_t)768 + 1) * p.red_fl * sizeof(float);           // workgroup partials (up to 768 resident workgroups) + their column sums
 }
 int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
-                    int W, int Cin, int Cout, hipStream_t s, const float* amax) {
+                    int W, int Cin, int Cout, hipStream_t s, const float* amax, const float* in_mean, const float* in_rstd) {
   const bool f16p = X3_F16_FWD && amax != nullptr && (int64_t)D * H * W < (1ll << 24);
   const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout, f16p ? 2 : 3);
   // two f16 pieces when the caller knows max |d_y| (and vouches for x: an activation), else three bf16 pieces
   const bool f16 = X3_F16_FWD && amax != nullptr && (int64_t)D * H * W < (1ll << 24);
-  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems, f16 ? amax : nullptr};
-#define X3W_D(NPC_) do { \
+  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems, f16 ? amax : nullptr, in_mean, in_rstd};
+#define X3W_D(NPC_, NORM_) do { \
     if (p.cib == 4) { \
-      if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 8, true, NPC_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
-      else hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 16, false, NPC_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
+      if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 8, true, NPC_, false, NORM_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
+      else hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 16, false, NPC_, false, NORM_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
     } else { \
-      if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 8, true, NPC_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
-      else hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 16, false, NPC_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
+      if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 8, true, NPC_, false, NORM_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
+      else hipLaunchKernelGGL((conv_x3_wgrad_kernel<8, 16, false, NPC_, false, NORM_>), dim3(p.gx), dim3(NTHR), 0, s, a); \
     } } while (0)
-  if (f16) X3W_D(2); else X3W_D(3);
+  if (in_mean) { if (f16) X3W_D(2, true); else X3W_D(3, true); }
+  else { if (f16) X3W_D(2, false); else X3W_D(3, false); }
 #undef X3W_D
   float* red = (float*)ws + (size_t)p.gx * p.red_fl;
   return modetx_wgrad_partials_reduce(defer, (const float*)ws, red, dw, db, p.gx, Cin, Cout, p.cib, p.u, p.np ? 1 : 0, s);
@@ -1298,7 +1326,7 @@ size_t modetx_x3_bf16_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Co
 int modetx_x3_bf16_wgrad(modet_step_ctx* defer, const void* x, int x_bf16, const void* dy, float* dw, float* db, void* ws, int B,
                          int D, int H, int W, int Cin, int Cout, hipStream_t s) {
   const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout, 1);
-  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems, nullptr};
+  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems, nullptr, nullptr, nullptr};
 #define X3W_L(CIB_, NCO_, NP_, X16_) hipLaunchKernelGGL((conv_x3_wgrad_kernel<CIB_, NCO_, NP_, 1, X16_>), dim3(p.gx), dim3(NTHR), 0, s, a)
   if (p.cib == 4) {
     if (x_bf16) return MODET_ERR_UNSUPPORTED;

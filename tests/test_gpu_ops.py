@@ -1022,6 +1022,50 @@ def test_instnorm_conv_chain_with_fused_backward_statistics(ops, c0, c1, c2, sha
         assert torch.equal(a, b), "the fused form must be run-to-run deterministic"
 
 
+@pytest.mark.parametrize("c0,c1,c2,f16", [(4, 8, 8, True), (8, 8, 8, True), (8, 8, 8, False), (4, 4, 8, True)])
+def test_training_chain_without_the_normalised_tensor(ops, monkeypatch, c0, c1, c2, f16):
+    """Round 5: where the z-marching weight-gradient kernel takes the second conv of a ConvInsBlock ->
+    ConvInsBlock chain, the TRAINING step never writes LeakyReLU(InstanceNorm(raw)): the forward conv and the weight gradient
+    normalise while they stage (modet_conv3d_fwd_normin / modet_conv3d_bwd_weight_normin).  Against the materialised form of
+    the same build (same arithmetic: output and data gradient bit-identical, weight gradient equal to rounding of the sums)
+    and against fp64, with and without the f16 gradient form."""
+    import torch.nn.functional as F
+    monkeypatch.setattr(ops, "GRAD_F16", f16)
+    B, shape = 2, (52, 44, 45)
+    L = ops._L()
+    assert L.modet_conv3d_bwd_weight_normin_ok(B, *shape, c1, c2) == 1
+    gen = torch.Generator().manual_seed(c0 * 11 + c1 + c2)
+    x = F.leaky_relu(torch.randn((B, c0) + shape, generator=gen), 0.1).double()
+    w1 = (torch.randn((c1, c0, 3, 3, 3), generator=gen) / np.sqrt(c0 * 27)).double().requires_grad_(True)
+    w2 = (torch.randn((c2, c1, 3, 3, 3), generator=gen) / np.sqrt(c1 * 27)).double().requires_grad_(True)
+    b2 = (0.1 * torch.randn(c2, generator=gen)).double().requires_grad_(True)
+    gy = torch.randn((B, c2) + shape, generator=gen).double() * 1e-4
+    h = F.leaky_relu(F.instance_norm(F.conv3d(x, w1, None, padding=1), eps=1e-5), 0.1)
+    ref = F.leaky_relu(F.instance_norm(F.conv3d(h, w2, b2, padding=1), eps=1e-5), 0.1)
+    r = torch.autograd.grad(ref, [w1, w2, b2], gy)
+    res = {}
+    for lazy in (True, False):
+        monkeypatch.setattr(ops, "LAZY_IN_TRAIN", lazy)
+        xd = cl(x.numpy()).requires_grad_(True)
+        p = [t.detach().float().cuda().requires_grad_(True) for t in (w1, w2, b2)]
+        raw, st = ops.conv3d_with_stats(xd, p[0], None, x_act=True)
+        raw2, st2 = ops.lazy_instnorm_conv3d(raw, st, p[1], p[2])
+        y = ops._InstNormLReLU.apply(raw2, 1e-5, st2)
+        g = torch.autograd.grad(y, [xd, p[0], p[1], p[2]], cl(gy.numpy()))
+        res[lazy] = (y.detach(), raw2.detach()) + tuple(g)
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][0], res[False][0]), "forward must be bit-identical"
+    assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3]), "d_x / d_w1 must be bit-identical"
+    for i, (name, want) in enumerate((("dw1", r[0]), ("dw2", r[1]), ("db2", r[2]))):
+        for lazy in (True, False):
+            got = res[lazy][3 + i].double().cpu()
+            e = float((got - want).abs().max() / want.abs().max())
+            if name != "db2":                                  # (db2 sits under an InstanceNorm: analytically zero)
+                _note(f"lazy_train_chain[{c0}-{c1}-{c2},{'f16' if f16 else 'bf16x3'},{'lazy' if lazy else 'materialised'}].{name}_maxerr_of_max", e)
+                assert e < 2e-5, (name, lazy, e)
+    d = float((res[True][4] - res[False][4]).abs().max() / res[False][4].abs().max())
+    assert d < 2e-6, d
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(8, 8, (33, 40, 48)), (16, 16, (9, 11, 37)), (32, 32, (12, 10, 20)),
                                             (12, 2, (7, 9, 18)), (48, 48, (5, 6, 7))])
 def test_lazy_instnorm_conv_inference(ops, cin, cout, shape):
