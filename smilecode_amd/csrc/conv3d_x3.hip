@@ -225,7 +225,10 @@ __device__ long long* g_x3_dbg = nullptr;
 // HBM (a staging item = 8 channels = 16 bytes goes to LDS untouched), else fp32 rounded while staged; OUT16: y is stored as bf16.
 // A plane then carries 18 MFMAs per wave instead of 108: the kernel is HBM-bound (8->8: 32 bytes per voxel).
 template <int CIN, int P, int TY, bool WLDS, bool NORM, int STATS, int NPC = 3, bool IN16 = false, bool OUT16 = false>
-__global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (CIN == 16 ? 1 : (((X3_VARIANT & 8) && CIN == 8) ? 3 : 2))) void conv_x3_kernel(const X3Args a) {
+#ifndef X3_OCC3
+#define X3_OCC3 0                        // tuning builds: three workgroups per CU for the two-f16-piece forms with < 16 channels
+#endif
+__global__ __launch_bounds__(NTHR, NPC == 1 ? ((P == 2 && CIN < 16) ? 3 : 2) : (CIN == 16 ? 1 : ((((X3_VARIANT & 8) && CIN == 8) || (X3_OCC3 && NPC == 2)) ? 3 : 2))) void conv_x3_kernel(const X3Args a) {
   using G = X3Geo<CIN, P>;
   constexpr int NS = G::NS, NTAP = G::NTAP;
   constexpr int HY = TY + 2, UNITS = TY / P, R = UNITS / 4;
@@ -719,7 +722,7 @@ inline X3Plan x3_plan(int B, int D, int H, int W, int Cin, int Cout, int npc = 3
   p.ty = (p.P == 2 || p.cin_t == 16 || npc == 1) ? 16 : 8;
   p.wlds = 0;
   const int slots = npc == 1 ? ((p.P == 2 && p.cin_t < 16) ? 768 : 512)                                      // resident workgroups
-                             : (p.cin_t == 16 ? 256 : (((X3_VARIANT & 8) && p.cin_t == 8) ? 768 : 512));
+                             : (p.cin_t == 16 ? 256 : ((((X3_VARIANT & 8) && p.cin_t == 8) || X3_OCC3) ? 768 : 512));
   p.tiles_x = cdiv(W, TX);
   p.tiles_y = cdiv(H, p.ty);
   // z chunks: enough workgroups to fill 256 CUs x 2 several times over (the dispatcher balances them), but chunks long

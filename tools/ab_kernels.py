@@ -58,6 +58,10 @@ def main():
                 out[f"conv_fwd[{cin}->{cout}]@{lvl}"] = timeit(lambda: ops.conv3d_forward(x, w, b, False), args.iters)
                 out[f"conv_dgrad[{cout}->{cin}]@{lvl}"] = timeit(lambda: ops.conv3d_backward_data(dy, w, cin), args.iters)
                 out[f"conv_wgrad[{cin}->{cout}]@{lvl}"] = timeit(lambda: ops.conv3d_backward_weight(x, dy, True), args.iters)
+                if hasattr(ops, "amax_buffer"):              # round 5: the two-f16-piece forms the train step runs (max |d_y| known)
+                    am = ops.amax_buffer(dy.abs().max())
+                    out[f"conv_dgrad_f16[{cout}->{cin}]@{lvl}"] = timeit(lambda: ops.conv3d_backward_data(dy, w, cin, amax=am), args.iters)
+                    out[f"conv_wgrad_f16[{cin}->{cout}]@{lvl}"] = timeit(lambda: ops.conv3d_backward_weight(x, dy, True, amax=am), args.iters)
             del x, dy
         if want("instnorm"):
             x = rnd(*L1, 8)
