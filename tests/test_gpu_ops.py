@@ -821,6 +821,24 @@ def test_block_chain_backward_runs_on_f16_pieces_and_matches_fp64(ops, monkeypat
     assert not torch.equal(res[True][1], res[False][1]) and not torch.equal(res[True][0], res[False][0])
 
 
+@pytest.mark.parametrize("Cin,Cout,shape", [(8, 8, (16, 24, 32)), (32, 32, (20, 24, 20))])
+def test_conv_forward_f16_range_violation_is_loud(ops, Cin, Cout, shape):
+    """include/modet_hip.h, range contract of the two-f16-piece forward forms (families 2 and 5): |x| < 4 094 (activations are
+    scaled by 2^4 before the split).  A tensor beyond it must not come back silently wrong: the f16 conversion overflows to inf and
+    the output carries inf / nan; inside the range -- 4 000 -- the result is the fp64 one."""
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn((1, Cin) + shape, generator=gen).double()
+    w = (torch.randn((Cout, Cin, 3, 3, 3), generator=gen) / np.sqrt(27 * Cin)).double()
+    xin = x / x.abs().max() * 4000.0
+    ref = torch.nn.functional.conv3d(xin, w, None, padding=1)
+    y = ops.conv3d_forward(cl(xin.numpy()), w.float().cuda(), None, False)
+    assert bool(torch.isfinite(y).all())
+    assert float((torch.from_numpy(ncdhw(y)) - ref).abs().max() / ref.abs().max()) < 2e-6
+    xout = x / x.abs().max() * 1.0e5
+    y2 = ops.conv3d_forward(cl(xout.numpy()), w.float().cuda(), None, False)
+    assert not bool(torch.isfinite(y2).all()), "an out-of-range input must produce inf / nan, not a finite wrong answer"
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(8, 8, (40, 50, 52)), (4, 8, (37, 46, 63)), (8, 16, (33, 42, 75)), (8, 4, (40, 41, 66))])
 def test_conv_x3_weight_gradient_vs_fp64(ops, cin, cout, shape):
     """csrc/conv3d_x3.hip, weight gradient: the z-marching bf16x3 kernel (Cin 4/8, Cout <= 16, >= 200 k voxels) against
