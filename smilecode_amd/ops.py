@@ -1165,6 +1165,8 @@ class _LevelAttnBF16(Function):
         _chk(Wt, b, gamma, beta, rpb)
         ctx.tee = bool(tee) and flow is not None
         ctx.set_materialize_grads(False)
+        ctx.step = current_step()
+        ctx.beta_ref = beta                  # (only its address and shape: the key of its gradient destination)
         B, D, H, W, Cin = F.shape
         dim = Wt.shape[0]
         N = B * D * H * W
@@ -1219,7 +1221,10 @@ class _LevelAttnBF16(Function):
         n = float(N)
         L = _L()
         dq = torch.empty((B, D, H, W, dim), dtype=torch.float32, device=F.device)
-        dk, drpb = torch.empty_like(dq), torch.empty_like(rpb)
+        dk = torch.empty_like(dq)
+        # the five parameter gradients straight into the flat gradient buffer when a deferred() scope offers destinations
+        dst = ctx.step.claim(Wt, b, gamma, ctx.beta_ref, rpb) if ctx.step is not None else None
+        drpb = dst[4] if dst is not None else torch.empty_like(rpb)
         nb = L.modet_na_bwd_ws_bytes(B, D, H, W, heads)
         ws = _ws(nb, F)
         nvh = n * heads
@@ -1229,7 +1234,8 @@ class _LevelAttnBF16(Function):
         x2 = Mw if flow is not None else M
         dF = torch.empty(F.shape, dtype=torch.float32, device=F.device)
         dMw = torch.empty(M.shape, dtype=torch.float32, device=M.device)
-        dW, db, dg, dbeta = torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma), torch.empty_like(gamma)
+        dW, db, dg, dbeta = dst[:4] if dst is not None else (torch.empty_like(Wt), torch.empty_like(b), torch.empty_like(gamma),
+                                                             torch.empty_like(gamma))
         nb2 = L.modet_proj_ln_bwd_pair_ws_bytes(N, Cin, dim)
         if nb2 == 0:
             raise RuntimeError(f"level attention (bf16): no paired projection backward for Cin {Cin}, dim {dim}")
@@ -1239,6 +1245,8 @@ class _LevelAttnBF16(Function):
                                                   int(x2.dtype == torch.bfloat16), _p(dk), _p(dMw),
                                                   _p(Wt), _p(b), _p(gamma), _p(dW), _p(db), _p(dg), _p(dbeta), _p(ws2), nb2, N, Cin, dim,
                                                   ctx.eps, _stream()), "modet_proj_ln_bwd_pair_t")
+        if dst is not None:
+            dW = db = dg = dbeta = drpb = None           # (written in place: nothing for autograd to hand on)
         if flow is None:
             return dF, dMw, None, dW, db, dg, dbeta, drpb, None, None, None, None
         dM = torch.empty(M.shape, dtype=torch.float32, device=M.device) if ctx.needs_input_grad[1] else None
