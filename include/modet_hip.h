@@ -123,7 +123,7 @@ int modet_na_bwd_t(const void* q, const void* k, int qk_bf16, const float* rpb, 
  *       launches with fused statistics, a lazily normalised input or an activation run family 0)   conv3d.hip (conv_direct_kernel)
  *   5 = (forward / data gradient) bf16x3 with the K index packed in channel quads: 2 x 8 x 8-voxel tiles, any channel count
  *       (12 / 24 / 48 / 6 without padding), fused statistics and the lazily normalised input as template variants: pyramid
- *       levels 3-5, the CWM layers, everything family 2 does not take up to 1.5 M voxels             conv3d_q.hip
+ *       levels 3-5, the CWM layers, everything family 2 does not take up to 6 M voxels               conv3d_q.hip
  * Families 1, 2 and 5 produce the fused InstanceNorm statistics (modet_conv3d_fwd_stats) at no cost for every Cout.
  *   4 = (weight gradient only) bf16x3 through LDS transpose reads, ds_read_b64_tr_b16: every layer with Cin >= 12 or an
  *       odd channel count, and Cout = 16                                                           conv3d_wtr.hip

@@ -1810,7 +1810,9 @@ static bool use_q(int B, int D, int H, int W, int Cin, int Cout) {
   // (level 5 -- 2.4 k voxels, 64 / 128 channels -- stays on conv_direct_kernel: 8 stagings of a 128-voxel tile in a row there,
   // 40-62 us against 40-55; the CWM layers at level-4 resolution, 9.6 k voxels, are faster here: 24->48 35 -> 26 us, 48->48 41 -> 33)
   const int64_t n = (int64_t)B * D * H * W;
-  return on && Cin > 1 && !use_x3(B, D, H, W, Cin, Cout) && !(n < 4096 && use_direct(B, D, H, W, Cin, Cout)) && n <= 1500000 &&
+  // (up to 6 M voxels: at cfg 5's shape -- 160x192x224, two pairs per GPU -- the CWM layers of level 3 run at 1.72 M voxels; with
+  // the round-4 limit of 1.5 M they fell back to the exact-f32 kernels there, 0.42 ms of its 15 ms step)
+  return on && Cin > 1 && !use_x3(B, D, H, W, Cin, Cout) && !(n < 4096 && use_direct(B, D, H, W, Cin, Cout)) && n <= 6000000 &&
          modetx_q_eligible(B, D, H, W, Cin, Cout);
 }
 static bool use_wtr_wgrad(int B, int D, int H, int W, int Cin, int Cout) {

@@ -688,7 +688,9 @@ def test_instnorm_backward_leaves_the_gradient_maximum(ops):
 
 
 @pytest.mark.parametrize("Cin,Cout,shape,xs,ws", [(32, 32, (40, 48, 40), 1.0, 1.0), (16, 32, (40, 48, 40), 30.0, 0.05), (64, 64, (20, 24, 20), 2e-3, 4.0),
-                                                  (24, 48, (20, 24, 28), 1.0, 1.0), (6, 12, (40, 48, 56), 0.5, 1.0), (32, 64, (20, 24, 20), 200.0, 1.0)])
+                                                  (24, 48, (20, 24, 28), 1.0, 1.0), (6, 12, (40, 48, 56), 0.5, 1.0), (32, 64, (20, 24, 20), 200.0, 1.0),
+                                                  # cfg 5's level-3 CWM layers: 1.72 M voxels (beyond the round-4 routing limit of 1.5 M)
+                                                  (6, 12, (80, 96, 112), 1.0, 1.0), (12, 2, (80, 96, 112), 1.0, 1.0)])
 def test_conv_q_two_f16_pieces_forward_and_gradient(ops, Cin, Cout, shape, xs, ws):
     """Round 5: the channel-quad kernel of the mid / coarse levels and the CWM layers (family 5) on two f16 pieces: forward
     (activations x 2^4, weights x 2^8) and, given max |d_y|, the data gradient -- against fp64 over activation scales 2e-3..200,
