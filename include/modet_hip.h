@@ -426,6 +426,11 @@ int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, v
                       int B, int D, int H, int W, modet_stream_t stream);
 int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes,
                           int B, int D, int H, int W, int win, modet_stream_t stream);
+/* The same with d_J = grad_scale * d loss / d J (loss[0] unscaled): grad_scale is the loss term's weight (train.py:127-129,
+ * weights[0]), so a training step seeds its backward with d_J as it is -- no pass that multiplies it by an upstream scalar.
+ * grad_scale = 1 is bit-identical to modet_ncc_fwd_bwd_win. */
+int modet_ncc_fwd_bwd_win_scaled(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes,
+                                 int B, int D, int H, int W, int win, float grad_scale, modet_stream_t stream);
 /* NCC_vxm(win=[wz, wy, wx]) for ANY window (losses.py:52-59 accepts any list): the reference pads every axis by
  * floor(wz / 2), so for even / anisotropic windows the window sums -- and the mean -- live on a grid of
  * (D + 2p - wz + 1, H + 2p - wy + 1, W + 2p - wx + 1) voxels; reproduced exactly (separable sums through the workspace; the
@@ -438,6 +443,13 @@ int modet_ncc_fwd_bwd_box(const float* I, const float* J, float* loss, float* d_
 size_t modet_grad3d_ws_bytes(int B, int D, int H, int W);
 int modet_grad3d_fwd_bwd(const float* flow, float* loss, float* d_flow, void* ws, size_t ws_bytes,
                          int B, int D, int H, int W, int penalty, modet_stream_t stream);
+/* Grad3d on a CHANNELS-LAST flow (B,D,H,W,3) -- the layout ModeT's last composition writes -- with
+ * d_flow_cl = grad_scale * d loss / d flow in the same layout (loss[0] unscaled).  Element for element the arithmetic of
+ * modet_grad3d_fwd_bwd (d_flow equal bit for bit after the layout change when grad_scale = 1; the loss is the same sum in
+ * another order).  A training step uses it to skip the planar copy of the flow (losses.py:6-31 indexes (B,3,D,H,W)) and
+ * the copy of its gradient back. */
+int modet_grad3d_fwd_bwd_cl(const float* flow_cl, float* loss, float* d_flow_cl, void* ws, size_t ws_bytes,
+                            int B, int D, int H, int W, int penalty, float grad_scale, modet_stream_t stream);
 /* y = x * s[0] with s a DEVICE scalar (chains an upstream scalar gradient without a host sync) */
 int modet_scale_by_dev_scalar(const float* x, const float* s, float* y, int64_t n, modet_stream_t stream);
 

@@ -105,6 +105,8 @@ SIGNATURES = {
     "modet_ncc_fwd_bwd_box": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P]),
     "modet_grad3d_ws_bytes": (SZ, [I, I, I, I]),
     "modet_grad3d_fwd_bwd": (I, [P, P, P, P, SZ, I, I, I, I, I, P]),
+    "modet_grad3d_fwd_bwd_cl": (I, [P, P, P, P, SZ, I, I, I, I, I, F, P]),
+    "modet_ncc_fwd_bwd_win_scaled": (I, [P, P, P, P, P, SZ, I, I, I, I, I, F, P]),
     "modet_scale_by_dev_scalar": (I, [P, P, P, I64, P]),
     "modet_adam_amsgrad_step": (I, [P, P, P, P, P, I64, F, F, F, F, I, F, P]),
     "modet_corr3d_ws_bytes": (SZ, [I, I, I, I, I]),

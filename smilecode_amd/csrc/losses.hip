@@ -380,20 +380,24 @@ inline bool box_geo(int B, int D, int H, int W, int wz, int wy, int wx, BoxGeo& 
 }
 constexpr int NCC_BOX_PARTS = 1024;
 
-// Grad3d: flow (B,3,D,H,W) planar.  'l2': loss = (mean dH^2 + mean dD^2 + mean dW^2)/3; 'l1' (L1 = true): the same with
-// |d| instead of d^2 (losses.py:11-27); the gradient of |t| at t = 0 is 0, as torch.abs's backward (sign(0) = 0).
-template <bool L1>
+// Grad3d: flow (B,3,D,H,W) planar (CS = 1: d = {3 B, D, H, W}) or channels-last (B,D,H,W,3) (CS = 3: d = {B, D, H, W}, the
+// three components of a voxel are neighbours in memory and the spatial neighbours CS elements apart -- the layout the
+// model's last composition writes, so a training step needs neither the planar copy of the flow nor the copy of its
+// gradient back).  'l2': loss = (mean dH^2 + mean dD^2 + mean dW^2)/3; 'l1' (L1 = true): the same with |d| instead of d^2
+// (losses.py:11-27); the gradient of |t| at t = 0 is 0, as torch.abs's backward (sign(0) = 0).  df = gscale * d loss / d f
+// (gscale = the loss term's weight, train.py:127-129; the product with 1.0f is exact).
+template <bool L1, int CS>
 __global__ __launch_bounds__(BLK) void grad3d_kernel(const float* __restrict__ f, float* __restrict__ df,
                                                      float* __restrict__ part, Dims d, int64_t N, float inD, float inH,
-                                                     float inW) {
+                                                     float inW, float gscale) {
   __shared__ float red[BLK / 64];
-  const int64_t sD = (int64_t)d.H * d.W, sH = d.W;
+  const int64_t sD = (int64_t)d.H * d.W * CS, sH = (int64_t)d.W * CS;
   float lsum = 0.f;
   const bool small = N < (1ll << 31);
   for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLK) {
     int z, y, x;
-    if (small) decode32((unsigned)i, d, z, y, x);
-    else decode(i, d, z, y, x);
+    if (small) decode32((unsigned)i / (unsigned)CS, d, z, y, x);
+    else decode(i / CS, d, z, y, x);
     const float v = f[i];
     float g = 0.f;
     // pen(t) = t^2 (l2) or |t| (l1); dpen(t) = t (the factor 2 is applied at the end) or sign(t)
@@ -403,14 +407,14 @@ __global__ __launch_bounds__(BLK) void grad3d_kernel(const float* __restrict__ f
     // difference is an exact 0 and adds nothing (a load per `if (inside)` was a memory round trip each, in series)
     const float zp = f[z + 1 < d.D ? i + sD : i], zm = f[z > 0 ? i - sD : i];
     const float yp = f[y + 1 < d.H ? i + sH : i], ym = f[y > 0 ? i - sH : i];
-    const float xp = f[x + 1 < d.W ? i + 1 : i], xm = f[x > 0 ? i - 1 : i];
+    const float xp = f[x + 1 < d.W ? i + CS : i], xm = f[x > 0 ? i - CS : i];
     { const float t = zp - v; lsum = fmaf(pen(t), inD, lsum); g -= dpen(t) * inD; }
     { const float t = v - zm; g += dpen(t) * inD; }
     { const float t = yp - v; lsum = fmaf(pen(t), inH, lsum); g -= dpen(t) * inH; }
     { const float t = v - ym; g += dpen(t) * inH; }
     { const float t = xp - v; lsum = fmaf(pen(t), inW, lsum); g -= dpen(t) * inW; }
     { const float t = v - xm; g += dpen(t) * inW; }
-    if (df) df[i] = g * (L1 ? 1.f / 3.f : 2.f / 3.f);
+    if (df) df[i] = (g * (L1 ? 1.f / 3.f : 2.f / 3.f)) * gscale;
   }
   const float r = block_sum(lsum, red);
   if (threadIdx.x == 0) part[blockIdx.x] = r;
@@ -431,8 +435,8 @@ size_t modet_ncc_ws_bytes(int B, int D, int H, int W) {
   return ((size_t)3 * N + (size_t)march_plan(B, D, H, W, 3).grid + 64) * sizeof(float);
 }
 
-int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B, int D,
-                          int H, int W, int win, modet_stream_t stream) {
+int modet_ncc_fwd_bwd_win_scaled(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B,
+                                 int D, int H, int W, int win, float grad_scale, modet_stream_t stream) {
   MODET_CHECK_PTR(I); MODET_CHECK_PTR(J); MODET_CHECK_PTR(loss); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0);
   if (win != 3 && win != 5 && win != 7 && win != 9) return MODET_ERR_UNSUPPORTED;
@@ -453,7 +457,7 @@ int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_
     if (d_J)                                                                                                               \
       hipLaunchKernelGGL((ncc_march_kernel<W_, false>), dim3(p.grid), dim3(BLK), 0, s, (const float*)coef,                \
                          (const float*)nullptr, I, J, d_J, (float*)nullptr, d, N, p.tiles_x, p.tiles_y, p.nchunk, p.zc,    \
-                         -1.f / (float)N);                                                                                 \
+                         -grad_scale / (float)N);                                                                          \
   } while (0)
   if (win == 9) NCC_GO(9);
   else if (win == 7) NCC_GO(7);
@@ -461,6 +465,11 @@ int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_
   else NCC_GO(3);
 #undef NCC_GO
   return modet_launch_status();
+}
+
+int modet_ncc_fwd_bwd_win(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B, int D,
+                          int H, int W, int win, modet_stream_t stream) {
+  return modet_ncc_fwd_bwd_win_scaled(I, J, loss, d_J, ws, ws_bytes, B, D, H, W, win, 1.f, stream);
 }
 
 int modet_ncc_fwd_bwd(const float* I, const float* J, float* loss, float* d_J, void* ws, size_t ws_bytes, int B, int D,
@@ -511,23 +520,37 @@ int modet_ncc_fwd_bwd_box(const float* I, const float* J, float* loss, float* d_
 
 size_t modet_grad3d_ws_bytes(int, int, int, int) { return 2048 * sizeof(float); }
 
-int modet_grad3d_fwd_bwd(const float* flow, float* loss, float* d_flow, void* ws, size_t ws_bytes, int B, int D, int H,
-                         int W, int penalty, modet_stream_t stream) {
+static int grad3d_launch(const float* flow, float* loss, float* d_flow, void* ws, size_t ws_bytes, int B, int D, int H,
+                         int W, int penalty, bool channels_last, float grad_scale, modet_stream_t stream) {
   MODET_CHECK_DIM(penalty == 1 || penalty == 2);
   MODET_CHECK_PTR(flow); MODET_CHECK_PTR(loss); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 1 && H > 1 && W > 1);
   if (ws_bytes < modet_grad3d_ws_bytes(B, D, H, W)) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const Dims d{B * 3, D, H, W};
+  const Dims d{channels_last ? B : B * 3, D, H, W};
   const int64_t N = (int64_t)B * 3 * D * H * W;
   const float inD = (float)(1.0 / ((double)B * 3 * (D - 1) * H * W));
   const float inH = (float)(1.0 / ((double)B * 3 * D * (H - 1) * W));
   const float inW = (float)(1.0 / ((double)B * 3 * D * H * (W - 1)));
   const int rg = red_grid(N);
-  if (penalty == 1) hipLaunchKernelGGL(grad3d_kernel<true>, dim3(rg), dim3(BLK), 0, s, flow, d_flow, (float*)ws, d, N, inD, inH, inW);
-  else hipLaunchKernelGGL(grad3d_kernel<false>, dim3(rg), dim3(BLK), 0, s, flow, d_flow, (float*)ws, d, N, inD, inH, inW);
+#define GRAD3D_GO(L1_, CS_)                                                                                                 \
+  hipLaunchKernelGGL((grad3d_kernel<L1_, CS_>), dim3(rg), dim3(BLK), 0, s, flow, d_flow, (float*)ws, d, N, inD, inH, inW,  \
+                     grad_scale)
+  if (penalty == 1) { if (channels_last) GRAD3D_GO(true, 3); else GRAD3D_GO(true, 1); }
+  else { if (channels_last) GRAD3D_GO(false, 3); else GRAD3D_GO(false, 1); }
+#undef GRAD3D_GO
   hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(BLK), 0, s, (const float*)ws, rg, 1.0 / 3.0, loss);
   return modet_launch_status();
+}
+
+int modet_grad3d_fwd_bwd(const float* flow, float* loss, float* d_flow, void* ws, size_t ws_bytes, int B, int D, int H,
+                         int W, int penalty, modet_stream_t stream) {
+  return grad3d_launch(flow, loss, d_flow, ws, ws_bytes, B, D, H, W, penalty, false, 1.f, stream);
+}
+
+int modet_grad3d_fwd_bwd_cl(const float* flow_cl, float* loss, float* d_flow_cl, void* ws, size_t ws_bytes, int B, int D,
+                            int H, int W, int penalty, float grad_scale, modet_stream_t stream) {
+  return grad3d_launch(flow_cl, loss, d_flow_cl, ws, ws_bytes, B, D, H, W, penalty, true, grad_scale, stream);
 }
 
 }  // extern "C"

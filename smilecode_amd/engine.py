@@ -13,6 +13,12 @@ from .losses import Grad3d, NCC_vxm
 from .parallel import FlatParams, broadcast_parameters
 
 
+# the step's backward starts from (y_moved, flow) with the gradients the loss kernels wrote (Trainer._seeded_loss); False: from
+# the scalar loss through the autograd nodes of ops.ncc_loss / ops.grad3d_loss (read when a Trainer is constructed;
+# tools/ab_graphs.py attr:smilecode_amd.engine.SEED_BACKWARD=True,False times the two in one process)
+SEED_BACKWARD = True
+
+
 def poly_lr(epoch, max_epoch=30, init_lr=1e-4, power=0.9):
     """adjust_learning_rate (reference train.py:166-168)"""
     return round(init_lr * (1 - epoch / max_epoch) ** power, 8)
@@ -43,6 +49,7 @@ class Trainer:
         self._steps = {}                    # (shape, device, grad mode) -> ops.StepContext, least recently used first
         self.max_step_contexts = 4
         self.batch_small_launches = os.environ.get("MODET_STEP_BATCHING", "1") != "0"
+        self.seed_backward = SEED_BACKWARD  # False: the step goes through loss(...)[0].backward() (tests compare the two)
         self.lr_last = lr
         self.sim = NCC_vxm()
         self.reg = Grad3d(penalty="l2")
@@ -61,14 +68,46 @@ class Trainer:
             reg = reg * self.weights[1]
         return sim + reg, sim, reg
 
+    def _seedable(self):
+        """the step's own loss path applies: the reference's two loss terms as the HIP kernels have them (cubic NCC window of
+        3 / 5 / 7 / 9 voxels, Grad3d without ``loss_mult``) on a model that hands out its channels-last results"""
+        return (self.seed_backward and type(self.sim) is NCC_vxm and type(self.reg) is Grad3d and self.reg.loss_mult is None
+                and len(set(self.sim._w)) == 1 and self.sim._w[0] in (3, 5, 7, 9) and hasattr(self.model, "forward_cl"))
+
+    def _seeded_loss(self, moving, fixed):
+        """``loss`` for the step itself: ((loss, sim, reg) detached, roots, seeds) with ``seeds[i]`` = d loss / d ``roots[i]``
+        -- the two loss kernels write value AND weighted gradient in one call (they always did: the autograd nodes of
+        ops.ncc_loss / ops.grad3d_loss save the gradient in forward and multiply it by the upstream scalar in backward), so the
+        backward starts from y_moved and the flow instead of from the scalar.  Gone from the step: the planar copy of the
+        flow (reference losses.py:11-13 indexes (B,3,D,H,W); the kernel reads the channels-last flow the last composition
+        wrote) and the copy of its gradient back, the two d * 1.0 passes, autograd's ``ones_like`` root.  Same arithmetic
+        element for element: gradients bit-identical to ``loss(...)[0].backward()`` up to the warp scatter's atomic order."""
+        y_cl, flow_cl = self.model.forward_cl(moving, fixed)
+        B, D, H, W, _ = y_cl.shape
+        w0, w1 = float(self.weights[0]), float(self.weights[1])
+        sim, d_y = ops.ncc_value_and_grad(fixed.contiguous(), y_cl.detach().reshape(B, 1, D, H, W), self.sim._w[0], w0)
+        reg, d_flow = ops.grad3d_value_and_grad_cl(flow_cl.detach(), self.reg.penalty, w1)
+        if w0 != 1.0:
+            sim = sim * w0
+        if w1 != 1.0:
+            reg = reg * w1
+        return (sim + reg, sim, reg), [y_cl, flow_cl], [d_y.reshape(y_cl.shape), d_flow]
+
     # ---------------------------------------------------------------- hipGraph replay of forward + backward
     def _fwd_bwd(self, moving, fixed):
         self.fp.zero_grad()
+        seeded = self._seedable()
         if not self.batch_small_launches:               # MODET_STEP_BATCHING=0: every conv packs / reduces on its own (A/B)
             with ops.trace_range("forward+loss"):
-                loss, sim, reg = self.loss(moving, fixed)
+                if seeded:
+                    (loss, sim, reg), roots, seeds = self._seeded_loss(moving, fixed)
+                else:
+                    loss, sim, reg = self.loss(moving, fixed)
             with ops.trace_range("backward"):
-                loss.backward()
+                if seeded:
+                    torch.autograd.backward(roots, seeds)
+                else:
+                    loss.backward()
                 self.fp.gather_grads()
             return loss.detach(), sim.detach(), reg.detach()
         # one caller-owned step context per computation this trainer has run (shape, device, grad mode): its recorded
@@ -78,11 +117,17 @@ class Trainer:
         # the parameters are constant from here to the end of backward: pack all conv weights in one launch up front
         with sc.prepacked():
             with ops.trace_range("forward+loss"):
-                loss, sim, reg = self.loss(moving, fixed)
+                if seeded:
+                    (loss, sim, reg), roots, seeds = self._seeded_loss(moving, fixed)
+                else:
+                    loss, sim, reg = self.loss(moving, fixed)
             with ops.trace_range("backward"):
                 # the ~20 per-layer partial-tile reductions as one launch, written straight into the flat gradient buffer
                 with sc.deferred(self.fp.grad_destinations()) as scope:
-                    loss.backward()
+                    if seeded:
+                        torch.autograd.backward(roots, seeds)
+                    else:
+                        loss.backward()
                 self.fp.gather_grads(scope.written)
         return loss.detach(), sim.detach(), reg.detach()
 
@@ -109,13 +154,17 @@ class Trainer:
         m, enc = self.model, self.model.encoder
         m.stage_cuts, enc.stage_cut = True, True
         try:
-            loss, sim, reg = self.loss(moving, fixed)
+            if self._seedable():
+                (loss, sim, reg), roots, seeds = self._seeded_loss(moving, fixed)
+            else:
+                loss, sim, reg = self.loss(moving, fixed)
+                roots, seeds = [loss], [None]
         finally:
             m.stage_cuts, enc.stage_cut = False, False
         (M, Fx), (Ml, Fl) = m.cut_features, m.cut_leaves
         p3, p3leaf = enc.cut
         m.cut_features = m.cut_leaves = enc.cut = None
-        return {"loss": loss, "out": (loss.detach(), sim.detach(), reg.detach()), "feat": list(M) + list(Fx),
+        return {"roots": roots, "seeds": seeds, "out": (loss.detach(), sim.detach(), reg.detach()), "feat": list(M) + list(Fx),
                 "leaf": list(Ml) + list(Fl), "p3": p3, "p3leaf": p3leaf, "g": None}
 
     def _staged_backward(self, st, k, sc):
@@ -124,7 +173,7 @@ class Trainer:
         members = self.buckets.members[k]
         params = [self.fp.params[i] for i in members]
         if k == 0:                                      # loss -> heads -> feature leaves
-            outs, gouts, extra = [st["loss"]], [None], st["leaf"]
+            outs, gouts, extra = st["roots"], st["seeds"], st["leaf"]
         else:
             lv = (2, 3, 4) if k == 1 else (0, 1)        # encoder levels 3-5, then 1-2 (feat = [M1..M5, F1..F5])
             idx = [i for i in lv] + [5 + i for i in lv]
@@ -152,7 +201,7 @@ class Trainer:
             torch._foreach_zero_(missing)
         if k == 0:
             st["g"] = list(grads[len(params):])
-            st["loss"] = None
+            st["roots"] = st["seeds"] = None
         elif k == 1:
             st["gp3"] = grads[len(params)]
             for i in idx:
@@ -199,7 +248,7 @@ class Trainer:
                 with torch.cuda.graph(graphs[k], pool=pool, capture_error_mode=mode):
                     self._staged_backward(st, k, sc)
         self._static_out = st["out"]
-        st["loss"] = None
+        st["roots"] = st["seeds"] = None
         self._stage_graphs, self._graph = graphs, graphs[0]
         self._graph_key = (tuple(moving.shape), moving.device)
         if verify:

@@ -423,6 +423,14 @@ class ModeT(nn.Module):
              for i in range(4)])
 
     def forward(self, moving, fixed):
+        """(y_moved (B,1,D,H,W), flow (B,3,D,H,W)) -- reference models.py:380-412"""
+        y_moved, flow = self.forward_cl(moving, fixed)
+        return ops.to_ncdhw(y_moved), ops.to_ncdhw(flow)
+
+    def forward_cl(self, moving, fixed):
+        """``forward`` with both results in the layout the kernels wrote them: y_moved (B,D,H,W,1), flow (B,D,H,W,3).  The
+        trainer takes these (its Grad3d kernel reads the channels-last flow and writes the gradient in place of the planar
+        round trip); ``forward`` adds the reference's (B,C,D,H,W) views / copies."""
         if moving.shape != fixed.shape or moving.dim() != 5:
             raise RuntimeError("ModeT.forward expects two (B,C,D,H,W) volumes of the same shape")
         if any(int(v) % 16 != 0 for v in moving.shape[2:]):
@@ -485,7 +493,7 @@ class ModeT(nn.Module):
             w, flow = match(0, self.projblock1, self.mdt1, flow)
             flow = ST[0].forward_cl(flow, w, add_flow=True, flow_bound=1)
             y_moved, flow = ops.warp_tee(mov_cl, flow)      # (the flow's other consumer: the caller, Grad3d in training)
-        return ops.to_ncdhw(y_moved), ops.to_ncdhw(flow)
+        return y_moved, flow
 
 
 class ModeT_cu(ModeT):

@@ -1646,6 +1646,46 @@ def grad3d_loss(flow, penalty="l2"):
 
 
 # ------------------------------------------------------------------------------------------------ non-autograd
+def ncc_value_and_grad(y_true, y_pred, win=9, grad_scale=1.0):
+    """(NCC_vxm(y_true, y_pred) as a device scalar, grad_scale * d loss / d y_pred) from one call -- no autograd node: the
+    trainer seeds its backward with the gradient (engine.Trainer._seeded_loss).  Cubic windows 3 / 5 / 7 / 9.
+    reference: losses.py:34-94, train.py:127"""
+    _chk(y_true, y_pred)
+    if y_true.shape != y_pred.shape or y_true.dim() != 5 or y_true.shape[1] != 1:
+        raise RuntimeError("NCC: expects two (B,1,D,H,W) volumes")
+    B, _, D, H, W = y_true.shape
+    loss = torch.empty(1, dtype=torch.float32, device=y_true.device)
+    dJ = torch.empty_like(y_pred)
+    L = _L()
+    nb = L.modet_ncc_ws_bytes(B, D, H, W)
+    ws = _ws(nb, y_true)
+    nv = float(y_true.numel())
+    with _Guard(y_true, "ncc_fwd_bwd", 400.0 * nv, 12.0 * nv):
+        _lib.check(L.modet_ncc_fwd_bwd_win_scaled(_p(y_true), _p(y_pred), _p(loss), _p(dJ), _p(ws), nb, B, D, H, W, int(win),
+                                                  float(grad_scale), _stream()), "modet_ncc_fwd_bwd_win_scaled")
+    return loss.reshape(()), dJ
+
+
+def grad3d_value_and_grad_cl(flow_cl, penalty="l2", grad_scale=1.0):
+    """(Grad3d(penalty) as a device scalar, grad_scale * d loss / d flow) of a CHANNELS-LAST flow (B,D,H,W,3), gradient in the
+    same layout -- no autograd node, no planar copy of the flow.  reference: losses.py:6-31, train.py:128"""
+    _chk(flow_cl)
+    if flow_cl.dim() != 5 or flow_cl.shape[-1] != 3:
+        raise RuntimeError("Grad3d: expects a channels-last (B,D,H,W,3) flow")
+    if penalty not in ("l1", "l2"):
+        raise RuntimeError(f"Grad3d: unknown penalty {penalty!r}")
+    B, D, H, W, _ = flow_cl.shape
+    loss = torch.empty(1, dtype=torch.float32, device=flow_cl.device)
+    df = torch.empty_like(flow_cl)
+    L = _L()
+    nb = L.modet_grad3d_ws_bytes(B, D, H, W)
+    ws = _ws(nb, flow_cl)
+    with _Guard(flow_cl, "grad3d_fwd_bwd", 20.0 * flow_cl.numel(), 8.0 * flow_cl.numel()):
+        _lib.check(L.modet_grad3d_fwd_bwd_cl(_p(flow_cl), _p(loss), _p(df), _p(ws), nb, B, D, H, W, 1 if penalty == "l1" else 2,
+                                             float(grad_scale), _stream()), "modet_grad3d_fwd_bwd_cl")
+    return loss.reshape(()), df
+
+
 def adam_amsgrad_step_(p, g, m, v, vmax, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     """in-place Adam(amsgrad=True) over flat buffers.  reference: train.py:101,:131-133"""
     _chk(p, g, m, v, vmax)

@@ -509,6 +509,47 @@ def test_deterministic_train_step_is_bit_reproducible():
     assert gerr < 1e-5, gerr
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_step_seeded_with_the_loss_gradients_equals_loss_backward(overlap):
+    """The product step starts its backward from (y_moved, flow) with the gradients the two loss kernels wrote
+    (Trainer._seeded_loss: channels-last Grad3d, no planar copy of the flow, no d * 1.0 passes, no ``ones_like`` root)
+    instead of from the scalar.  With the reference's weights [1, 1] (train.py:106) that is the same arithmetic element for
+    element: in deterministic mode (fixed-point warp scatter) losses and gradients are IDENTICAL to
+    ``Trainer.loss(...)[0].backward()``; with other weights the weight enters one multiplication earlier (<= 1e-6)."""
+    from smilecode_amd import ops
+    from smilecode_amd.engine import Trainer
+    shape = (32, 48, 32)
+    mov, fix = _pair(shape)
+    prev = ops.set_deterministic(True)
+    try:
+        for weights in ((1.0, 1.0), (0.7, 2.5)):
+            res = {}
+            for seeded in (True, False):
+                tr = Trainer(_model(shape, 1.0), weights=weights, overlap_allreduce=overlap)
+                tr.seed_backward = seeded
+                assert tr._seedable() == seeded
+                out = tr._fwd_bwd_staged(mov, fix) if overlap else tr._fwd_bwd(mov, fix)
+                res[seeded] = (tr.fp.grad.clone(), [float(v) for v in out])
+            (ga, la), (gb, lb) = res[True], res[False]
+            assert la[1] == lb[1], "NCC value"
+            assert abs(la[2] - lb[2]) <= 2e-6 * abs(lb[2]) and abs(la[0] - lb[0]) <= 2e-6 * abs(lb[0]), (la, lb)
+            if weights == (1.0, 1.0):
+                assert torch.equal(ga, gb), float((ga - gb).abs().max())
+            else:
+                gerr = float((ga - gb).abs().max() / gb.abs().max())
+                _note(f"seeded_step[overlap={int(overlap)}].grad_relerr_weights_0.7_2.5", gerr)
+                assert gerr < 2e-6, gerr
+    finally:
+        ops.set_deterministic(prev)
+    # a loss the kernels' value-and-gradient calls do not cover keeps the autograd path
+    from smilecode_amd import losses
+    tr = Trainer(_model(shape, 1.0))
+    tr.sim = losses.NCC_vxm(win=[5, 3, 7])
+    assert not tr._seedable()
+    tr._fwd_bwd(mov, fix)
+    assert bool(torch.isfinite(tr.fp.grad).all())
+
+
 def test_staged_graphs_follow_the_parameters():
     """the three stage graphs must pack the conv weights INSIDE graph 0 -- packed once at capture, every
     replay after the first optimizer step would convolve with the weights of capture time.  Capture, then change every

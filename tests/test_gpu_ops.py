@@ -1295,6 +1295,39 @@ def test_grad3d_l1_golden(ops):
         losses.Grad3d(penalty="l3")
 
 
+@pytest.mark.parametrize("scale", [1.0, 0.37])
+def test_loss_value_and_gradient_calls_of_the_train_step(ops, scale):
+    """the step's own loss calls (engine.Trainer._seeded_loss: value + weighted gradient, no autograd node, Grad3d on the
+    CHANNELS-LAST flow) against the reference's goldens -- NCC_vxm (losses.py:34-94) and Grad3d 'l2' / 'l1' (losses.py:6-31) --
+    and bit for bit against the autograd nodes' gradients when the weight is 1 (same arithmetic, another layout)"""
+    g, ge = gold("op_misc.npz"), gold("op_eval.npz")
+    a, b = cu(g["ncc.a"]), cu(g["ncc.b"])
+    l, db = ops.ncc_value_and_grad(a, b, 9, scale)
+    assert_close(np64(l), g["ncc.val"], atol=2e-5, what="ncc value (unscaled)")
+    assert_close(np64(db), scale * g["ncc.db"], atol=2e-6, rtol=2e-3, what="ncc weighted d y_pred")
+    for w in (3, 5, 7):
+        aw, bw = cu(ge[f"nccw{w}.a"]), cu(ge[f"nccw{w}.b"])
+        lw, dbw = ops.ncc_value_and_grad(aw, bw, w, scale)
+        assert_close(np64(lw), ge[f"nccw{w}.val"], atol=2e-5, what="ncc value")
+        assert_close(np64(dbw), scale * ge[f"nccw{w}.db"], atol=2e-6, rtol=2e-3, what="ncc weighted d y_pred")
+    for key, pen, src in (("g3d", "l2", g), ("g3d_l1", "l1", ge)):
+        f = cu(src[f"{key}.flow"])                                   # (B,3,D,H,W) planar, as the reference has it
+        f_cl = f.permute(0, 2, 3, 4, 1).contiguous()
+        lv, df_cl = ops.grad3d_value_and_grad_cl(f_cl, pen, scale)
+        assert_close(np64(lv), src[f"{key}.val"], what="grad3d value (unscaled)")
+        assert_close(np64(df_cl.permute(0, 4, 1, 2, 3)), scale * src[f"{key}.dflow"], atol=1e-7, rtol=1e-4, what="grad3d weighted dflow")
+        if scale == 1.0:
+            fp = f.clone().requires_grad_(True)
+            (df,) = torch.autograd.grad(ops.grad3d_loss(fp, pen), fp)
+            assert torch.equal(df_cl.permute(0, 4, 1, 2, 3), df), "channels-last Grad3d gradient == planar one, bit for bit"
+    if scale == 1.0:
+        bp = b.clone().requires_grad_(True)
+        (db_node,) = torch.autograd.grad(ops.ncc_loss(a, bp), bp)
+        assert torch.equal(db, db_node)
+    with pytest.raises(RuntimeError):
+        ops.grad3d_value_and_grad_cl(cu(g["g3d.flow"]), "l2")        # a planar flow is refused, not misread
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_jacobian_determinant_golden(ops, tag):
     """det(J) <= 0 count of infer.py:89-90 on the GPU: integer-exact against the reference's jacobian_determinant_vxm
