@@ -98,6 +98,10 @@ size_t modet_na_bwd_ws_bytes(int B, int D, int H, int W, int heads);
 int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* out, const float* lse,
                  const float* d_out, float* d_q, float* d_k, float* d_rpb, void* ws, size_t ws_bytes,
                  int B, int D, int H, int W, int heads, int hd, float scale, modet_stream_t stream);
+/* d_rpb == NULL (modet_na_bwd / _t): the two reduction launches are skipped and the per-workgroup partial rows stay at the start
+ * of ws as float [B][heads][rows][27] with rows = modet_na_bwd_partial_rows(...): the caller sums them later, with the other leaf
+ * reductions of its backward pass, in one modet_leaf_reduce_many launch (ws must live until then). */
+int64_t modet_na_bwd_partial_rows(int B, int D, int H, int W, int heads, int hd);
 /* The same two entry points with bf16 q / k (qk_bf16 != 0: two channels per 32-bit word, channels-last as above; BASELINE.json
  * configs[4], bf16 storage): every product and sum stays fp32 -- the result is bit-identical to the fp32 entry points fed with
  * the bf16 values widened to fp32.  d_q / d_k are fp32.  head_dim 6 only. */
@@ -343,6 +347,26 @@ int modet_proj_ln_bwd_pair(const float* x1, const float* d_y1, float* d_x1, cons
                            const float* Wt, const float* bias, const float* gamma, float* d_Wt, float* d_bias,
                            float* d_gamma, float* d_beta, void* ws, size_t ws_bytes, int64_t N, int Cin, int dim,
                            float eps, modet_stream_t stream);
+/* d_Wt == d_bias == d_gamma == d_beta == NULL (modet_proj_ln_bwd_pair / _t): the column-sum launch is skipped and the partial
+ * rows stay at the start of ws as float [rows][3 dim + dim Cin], a row = [d_gamma | d_beta | d_bias | d_W], rows =
+ * modet_proj_ln_bwd_pair_partial_rows(N, Cin, dim) -- to be summed by modet_leaf_reduce_many. */
+int64_t modet_proj_ln_bwd_pair_partial_rows(int64_t N, int Cin, int dim);
+/* Every leaf reduction of a backward pass in ONE launch (15 launches of 5-8 us per ModeT train step otherwise: two per
+ * attention level, one per projection level).  Job: output column i (0 <= i < ncols) is the fp64 sum, in a fixed order, over
+ * o < outer and r < rows of part[o * outer_stride + r * row_stride + (i / col_group) * col_group_stride + i % col_group],
+ * rounded to float and written to the segment it falls in: columns [0, n[0]) -> dst[0], the next n[1] -> dst[1], ...
+ * (n[0] + .. + n[3] == ncols).  d_rpb of modet_na_bwd: outer = B, outer_stride = heads * rows * 27, row_stride = 27,
+ * ncols = heads * 27, col_group = 27, col_group_stride = rows * 27.  Projection pair: outer = 1, row_stride = ncols =
+ * col_group = 3 dim + dim Cin, segments d_gamma, d_beta, d_bias, d_W.  `jobs` is a HOST array (copied into the launch). */
+#define MODET_LEAF_MAX_JOBS 16
+typedef struct {
+  const float* part;
+  int64_t outer, outer_stride, rows, row_stride, col_group_stride;
+  int ncols, col_group;
+  float* dst[4];
+  int n[4];
+} modet_leaf_job_t;
+int modet_leaf_reduce_many(const modet_leaf_job_t* jobs, int njobs, modet_stream_t stream);
 /* Typed variants (BASELINE.json configs[4], bf16 storage): x_bf16 / y_bf16 != 0 means that tensor holds bf16 (channels-last);
  * values are widened on load and rounded to nearest even on store, everything in between is the fp32 arithmetic above -- a bf16
  * input gives bit-identical results to the fp32 entry point fed with the widened values, a bf16 output is the fp32 output rounded. */

@@ -17,6 +17,12 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "modet_hip.h")
 
 P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
+class LeafJob(C.Structure):
+    """modet_leaf_job_t (include/modet_hip.h)"""
+    _fields_ = [("part", P), ("outer", I64), ("outer_stride", I64), ("rows", I64), ("row_stride", I64),
+                ("col_group_stride", I64), ("ncols", I), ("col_group", I), ("dst", P * 4), ("n", I * 4)]
+
+
 # name -> (restype, argtypes); mirrors include/modet_hip.h one to one
 SIGNATURES = {
     "modet_hip_version": (I, []),
@@ -29,6 +35,7 @@ SIGNATURES = {
     "modet_qk_bwd_f64": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
     "modet_na_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, P]),
     "modet_na_bwd_ws_bytes": (SZ, [I, I, I, I, I]),
+    "modet_na_bwd_partial_rows": (I64, [I, I, I, I, I, I]),
     "modet_na_bwd": (I, [P, P, P, P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, F, P]),
     "modet_na_fwd_t": (I, [P, P, I, P, P, P, I, I, I, I, I, I, F, P]),
     "modet_na_bwd_t": (I, [P, P, I, P, P, P, P, P, P, P, P, SZ, I, I, I, I, I, I, F, P]),
@@ -79,6 +86,8 @@ SIGNATURES = {
     "modet_proj_ln_bwd_ws_bytes": (SZ, [I64, I, I]),
     "modet_proj_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
     "modet_proj_ln_bwd_pair_ws_bytes": (SZ, [I64, I, I]),
+    "modet_proj_ln_bwd_pair_partial_rows": (I64, [I64, I, I]),
+    "modet_leaf_reduce_many": (I, [P, I, P]),
     "modet_proj_ln_bwd_pair": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
     "modet_proj_ln_fwd_t": (I, [P, I, P, P, P, P, P, I, I64, I, I, F, P]),
     "modet_proj_ln_bwd_pair_t": (I, [P, I, P, P, P, I, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),

@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 431;
+int modet_hip_version(void) { return 432;
   /* 0.4.0: + modet_conv3d_kernel_family_v, conv kernel family 4 (conv_wgrad_tr_kernel); no environment reads in product builds
      0.4.1: + typed (fp32 | bf16) entry points modet_na_{fwd,bwd}_t, modet_proj_ln_*_t, modet_warp_*_t, modet_warp_fwd_o16,
               modet_avgpool2_fwd_x16, modet_instnorm_*_pool_bf16; modet_ncc_*_box (any window); conv kernel family 5 (conv_q_kernel)
@@ -13,7 +13,10 @@ int modet_hip_version(void) { return 431;
             + modet_instnorm_lrelu_bwd{,_rows,_pool}_amax, modet_conv3d_bwd_data{,_instats}_amax, modet_conv3d_bwd_weight_amax,
               MODET_AMAX_SLOTS / _STRIDE / _FLOATS
      0.4.3.1: + modet_grad3d_fwd_bwd_cl (channels-last flow, weighted gradient), modet_ncc_fwd_bwd_win_scaled (weighted gradient):
-              a training step seeds its backward with the two loss gradients as the kernels wrote them */ }
+              a training step seeds its backward with the two loss gradients as the kernels wrote them
+     0.4.3.2: + modet_leaf_reduce_many / modet_leaf_job_t, modet_na_bwd_partial_rows, modet_proj_ln_bwd_pair_partial_rows; d_rpb == NULL
+              (modet_na_bwd[_t]) and d_Wt == d_bias == d_gamma == d_beta == NULL (modet_proj_ln_bwd_pair[_t]) leave the partial rows
+              in the workspace: every leaf reduction of a backward pass in one launch */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {

@@ -893,7 +893,7 @@ int modet_na_bwd_t(const void* qv, const void* kv, int qk_bf16, const float* rpb
   const float* q = (const float*)qv;
   const float* k = (const float*)kv;
   MODET_CHECK_PTR(q); MODET_CHECK_PTR(k); MODET_CHECK_PTR(rpb); MODET_CHECK_PTR(out); MODET_CHECK_PTR(lse);
-  MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_q); MODET_CHECK_PTR(d_k); MODET_CHECK_PTR(d_rpb); MODET_CHECK_PTR(ws);
+  MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_q); MODET_CHECK_PTR(d_k); MODET_CHECK_PTR(ws);        // (d_rpb may be NULL: header)
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && heads > 0);
   if (hd != HD && (qk_bf16 || !gen_hd_ok(hd))) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < modet_na_bwd_ws_bytes(B, D, H, W, heads)) return MODET_ERR_WORKSPACE;
@@ -906,7 +906,7 @@ int modet_na_bwd_t(const void* qv, const void* kv, int qk_bf16, const float* rpb
     else hipLaunchKernelGGL(na_bwd_march_kernel<false>, dim3((unsigned)nblk, heads, B), dim3(NTHREADS), 0, s, a);
     size_t fl = (size_t)B * heads * nblk * 27;
     fl += fl & 1;
-    drpb_reduce((float*)ws, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
+    if (d_rpb) drpb_reduce((float*)ws, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
     return modet_launch_status();
   }
   const TileGeom g = geom(D, H, W);
@@ -924,8 +924,16 @@ int modet_na_bwd_t(const void* qv, const void* kv, int qk_bf16, const float* rpb
   }
   size_t fl = (size_t)B * heads * nblk * 27;
   fl += fl & 1;
-  drpb_reduce(part, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
+  if (d_rpb) drpb_reduce(part, ws, fl * sizeof(float), d_rpb, B, heads, nblk, s);
   return modet_launch_status();
+}
+
+int64_t modet_na_bwd_partial_rows(int B, int D, int H, int W, int heads, int hd) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || heads <= 0) return 0;
+  const NaMarchPlan mp = na_march_plan(B, D, H, W, heads, hd);
+  if (mp.on) return (int64_t)mp.tiles_x * mp.tiles_y * mp.nchunk;
+  const TileGeom g = geom(D, H, W);
+  return (int64_t)g.tiles_x * g.tiles_y * g.tiles_z;
 }
 
 int modet_na_bwd(const float* q, const float* k, const float* rpb, const float* out, const float* lse,

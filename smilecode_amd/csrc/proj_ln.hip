@@ -627,8 +627,9 @@ int modet_proj_ln_bwd_pair_t(const void* x1v, int x1_bf16, const float* d_y1, fl
   const float* x1 = (const float*)x1v;
   const float* x2 = (const float*)x2v;
   MODET_CHECK_PTR(x1); MODET_CHECK_PTR(d_y1); MODET_CHECK_PTR(d_x1); MODET_CHECK_PTR(x2); MODET_CHECK_PTR(d_y2);
-  MODET_CHECK_PTR(d_x2); MODET_CHECK_PTR(Wt); MODET_CHECK_PTR(bias); MODET_CHECK_PTR(gamma); MODET_CHECK_PTR(d_Wt);
-  MODET_CHECK_PTR(d_bias); MODET_CHECK_PTR(d_gamma); MODET_CHECK_PTR(d_beta); MODET_CHECK_PTR(ws);
+  MODET_CHECK_PTR(d_x2); MODET_CHECK_PTR(Wt); MODET_CHECK_PTR(bias); MODET_CHECK_PTR(gamma); MODET_CHECK_PTR(ws);
+  const bool reduce_here = d_Wt || d_bias || d_gamma || d_beta;       // all four NULL: the partial rows stay in ws (header)
+  if (reduce_here) { MODET_CHECK_PTR(d_Wt); MODET_CHECK_PTR(d_bias); MODET_CHECK_PTR(d_gamma); MODET_CHECK_PTR(d_beta); }
   MODET_CHECK_DIM(N > 0 && Cin > 0 && dim > 0);
   const int G = group_of(Cin, dim);
   if (Cin % 4 != 0 || Cin > 128 || !G) return MODET_ERR_UNSUPPORTED;
@@ -656,8 +657,79 @@ int modet_proj_ln_bwd_pair_t(const void* x1v, int x1_bf16, const float* d_y1, fl
     else LAUNCH_G(48, 128, 16);
 #undef LAUNCH_G
   }
-  hipLaunchKernelGGL(colsum_kernel, dim3(row), dim3(64), 0, s, (const float*)gpart, 2 * gg, row, d_gamma, dim, d_beta, dim,
-                     d_bias, dim, d_Wt, dim * Cin);
+  if (reduce_here)
+    hipLaunchKernelGGL(colsum_kernel, dim3(row), dim3(64), 0, s, (const float*)gpart, 2 * gg, row, d_gamma, dim, d_beta, dim,
+                       d_bias, dim, d_Wt, dim * Cin);
+  return modet_launch_status();
+}
+
+int64_t modet_proj_ln_bwd_pair_partial_rows(int64_t N, int Cin, int dim) {
+  const int G = group_of(Cin, dim);
+  return (N > 0 && G) ? 2 * (int64_t)group_grid(N, G) : 0;
+}
+
+// ---- every leaf reduction of a backward pass in ONE launch.  The attention's d_rpb (two launches per level) and the paired
+// projection's d_gamma / d_beta / d_bias / d_W (one per level) are column sums of per-workgroup partial rows whose only consumer
+// is the gradient buffer: nothing downstream waits for them, but on one stream -- and in the captured graph -- each is a 5-8 us
+// node of its own, fifteen per step.  A caller that passes NULL for those outputs keeps the partial rows in its workspace and
+// hands the jobs over here at the end of the pass: one wave per output column, fixed lane assignment and a fixed tree in fp64
+// (deterministic), as colsum_kernel.
+struct LeafTable { modet_leaf_job_t j[MODET_LEAF_MAX_JOBS]; int first[MODET_LEAF_MAX_JOBS + 1]; int njobs; };
+__global__ __launch_bounds__(64) void leaf_reduce_many_kernel(const LeafTable t) {
+  const int c = blockIdx.x;
+  int ji = 0;
+  while (ji + 1 < t.njobs && c >= t.first[ji + 1]) ++ji;
+  const modet_leaf_job_t& J = t.j[ji];
+  const int i = c - t.first[ji];
+  const float* p = J.part + (int64_t)(i / J.col_group) * J.col_group_stride + (i % J.col_group);
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t o = 0; o < J.outer; ++o) {
+    const float* po = p + o * J.outer_stride;
+    int64_t b = threadIdx.x;
+    for (; b + 192 < J.rows; b += 256) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += (double)po[(b + 64 * u) * J.row_stride];
+    }
+    for (; b < J.rows; b += 64) s4[0] += (double)po[b * J.row_stride];
+  }
+  double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  s = wave_sum_d(s);
+  if (threadIdx.x != 0) return;
+  int k = i;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (k < J.n[u]) { J.dst[u][k] = (float)s; return; }
+    k -= J.n[u];
+  }
+}
+
+int modet_leaf_reduce_many(const modet_leaf_job_t* jobs, int njobs, modet_stream_t stream) {
+  if (njobs == 0) return MODET_OK;
+  MODET_CHECK_PTR(jobs);
+  MODET_CHECK_DIM(njobs > 0);
+  hipStream_t s = (hipStream_t)stream;
+  for (int j0 = 0; j0 < njobs; j0 += MODET_LEAF_MAX_JOBS) {
+    LeafTable t;
+    t.njobs = njobs - j0 < MODET_LEAF_MAX_JOBS ? njobs - j0 : MODET_LEAF_MAX_JOBS;
+    int total = 0;
+    for (int j = 0; j < t.njobs; ++j) {
+      const modet_leaf_job_t& J = jobs[j0 + j];
+      MODET_CHECK_PTR(J.part);
+      MODET_CHECK_DIM(J.outer > 0 && J.rows > 0 && J.ncols > 0 && J.col_group > 0);
+      int nsum = 0;
+      for (int u = 0; u < 4; ++u) {
+        MODET_CHECK_DIM(J.n[u] >= 0);
+        if (J.n[u] > 0) MODET_CHECK_PTR(J.dst[u]);
+        nsum += J.n[u];
+      }
+      MODET_CHECK_DIM(nsum == J.ncols);
+      t.j[j] = J;
+      t.first[j] = total;
+      total += J.ncols;
+    }
+    t.first[t.njobs] = total;
+    hipLaunchKernelGGL(leaf_reduce_many_kernel, dim3(total), dim3(64), 0, s, t);
+  }
   return modet_launch_status();
 }
 

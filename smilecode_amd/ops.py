@@ -338,6 +338,7 @@ class StepContext:
         self.dst = None              # parameter.data_ptr() -> gradient destination, while a deferred() scope is open
         self.written = set()
         self._keep = []
+        self._leaf = []              # queued leaf reductions (modet_leaf_job_t) of the open deferred() scope, see defer_leaf
         self._side = {}              # device index -> the stream the small levels' weight gradients run on (see side_stream)
         self._side_used = None
 
@@ -395,7 +396,7 @@ class StepContext:
             sc = self.sc
             if sc.dst is not None:
                 raise RuntimeError("StepContext.deferred scopes do not nest")
-            sc.dst, sc.written, sc._keep = self.dst, self.written, []
+            sc.dst, sc.written, sc._keep, sc._leaf = self.dst, self.written, [], []
             return super().__enter__()
 
         def __exit__(self, *exc):
@@ -406,6 +407,11 @@ class StepContext:
                 torch.cuda.current_stream().wait_stream(sc._side_used)
                 sc._side_used = None
             rc = _L().modet_conv3d_wgrad_defer_flush(sc.handle, _stream())    # always empties the queue, also on an exception
+            jobs, sc._leaf = sc._leaf, []
+            if exc[0] is None and jobs:                  # the attention / projection parameter gradients of every level: one launch
+                arr = (_lib.LeafJob * len(jobs))(*jobs)
+                import ctypes
+                _lib.check(_L().modet_leaf_reduce_many(ctypes.addressof(arr), len(jobs), _stream()), "modet_leaf_reduce_many")
             sc._keep = []
             if exc[0] is None:
                 _lib.check(rc, "modet_conv3d_wgrad_defer_flush")
@@ -451,6 +457,20 @@ class StepContext:
                 return None
         return dw, db
 
+    def defer_leaf(self, ws, outer, outer_stride, rows, row_stride, ncols, col_group, col_group_stride, dsts):
+        """queue one column-sum job over the partial rows a backward kernel left at the start of ``ws`` (kept alive until the
+        scope's flush): see modet_leaf_reduce_many.  ``dsts``: up to four destination tensors, consecutive column segments."""
+        j = _lib.LeafJob()
+        j.part, j.outer, j.outer_stride, j.rows, j.row_stride = ws.data_ptr(), outer, outer_stride, rows, row_stride
+        j.col_group_stride, j.ncols, j.col_group = col_group_stride, ncols, col_group
+        for u in range(4):
+            j.dst[u] = dsts[u].data_ptr() if u < len(dsts) else None
+            j.n[u] = dsts[u].numel() if u < len(dsts) else 0
+        if sum(j.n) != ncols:
+            raise RuntimeError("defer_leaf: the destination segments do not add up to the job's columns")
+        self._leaf.append(j)
+        self._keep.append(ws)
+
     def claim(self, *params):
         """gradient destinations of a node's parameters (projection weight / bias / gamma / beta, an attention's rpb): the
         list of destination tensors when EVERY one has a destination and none was written in this scope yet -- they are then
@@ -469,7 +489,25 @@ class StepContext:
         return out
 
 
+# the parameter gradients of the attention / projection nodes (d_rpb; d_gamma, d_beta, d_bias, d_W) of all levels are summed
+# by ONE launch at the end of the deferred() scope instead of 2 + 1 launches per level (read at backward time)
+DEFER_LEAF_REDUCTIONS = True
+
 _TLS = threading.local()
+
+
+def _defer_rpb(step, ws, B, D, H, W, heads, hd, drpb):
+    """the d_rpb column sums of one attention backward (partial rows at the start of ``ws``: [B][heads][rows][27]) -> the scope's
+    single leaf-reduction launch"""
+    rows = int(_L().modet_na_bwd_partial_rows(B, D, H, W, heads, hd))
+    step.defer_leaf(ws, B, heads * rows * 27, rows, 27, heads * 27, 27, rows * 27, [drpb])
+
+
+def _defer_proj(step, ws, N, Cin, dim, dW, db, dg, dbeta):
+    """the parameter-gradient column sums of one paired projection backward (rows [d_gamma | d_beta | d_bias | d_W])"""
+    rows = int(_L().modet_proj_ln_bwd_pair_partial_rows(N, Cin, dim))
+    ncols = 3 * dim + dim * Cin
+    step.defer_leaf(ws, 1, 0, rows, ncols, ncols, ncols, 0, [dg, dbeta, db, dW])
 
 
 def current_step():
@@ -1089,10 +1127,14 @@ class _ProjLNPair(Function):
         L = _L()
         nb = L.modet_proj_ln_bwd_pair_ws_bytes(N, Cin, dim)
         ws = _ws(nb, x1)
+        later = dst is not None and DEFER_LEAF_REDUCTIONS
+        out4 = (None, None, None, None) if later else (dW, db, dg, dbeta)
         with _Guard(x1, f"proj_ln_bwd[{Cin}->{dim}]", 2 * N * (6.0 * Cin * dim + 20.0 * dim), 8.0 * N * (2 * Cin + dim)):
             _lib.check(L.modet_proj_ln_bwd_pair(_p(x1), _p(dy1), _p(dx1), _p(x2), _p(dy2), _p(dx2), _p(Wt), _p(b), _p(gamma),
-                                                _p(dW), _p(db), _p(dg), _p(dbeta), _p(ws), nb, N, Cin, dim, ctx.eps,
+                                                _p(out4[0]), _p(out4[1]), _p(out4[2]), _p(out4[3]), _p(ws), nb, N, Cin, dim, ctx.eps,
                                                 _stream()), "modet_proj_ln_bwd_pair")
+        if later:
+            _defer_proj(ctx.step, ws, N, Cin, dim, dW, db, dg, dbeta)
         if dst is not None:
             return dx1, dx2, None, None, None, None, None
         return dx1, dx2, dW, db, dg, dbeta, None
@@ -1145,9 +1187,12 @@ class _NA(Function):
         nb = L.modet_na_bwd_ws_bytes(B, D, H, W, heads)
         ws = _ws(nb, q)
         nvh = float(B) * D * H * W * heads      # reads q,k,d_out,out,lse (19 floats), writes d_q,d_k (12)
+        later = dst is not None and DEFER_LEAF_REDUCTIONS
         with _Guard(q, f"na_bwd[h{heads}]", 1900.0 * nvh, 124.0 * nvh):
-            _lib.check(L.modet_na_bwd(_p(q), _p(k), _p(rpb), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(drpb), _p(ws),
-                                      nb, B, D, H, W, heads, C // heads, ctx.scale, _stream()), "modet_na_bwd")
+            _lib.check(L.modet_na_bwd(_p(q), _p(k), _p(rpb), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(None if later else drpb),
+                                      _p(ws), nb, B, D, H, W, heads, C // heads, ctx.scale, _stream()), "modet_na_bwd")
+        if later:
+            _defer_rpb(ctx.step, ws, B, D, H, W, heads, C // heads, drpb)
         return dq, dk, (None if dst is not None else drpb), None, None
 
 
@@ -1228,9 +1273,12 @@ class _LevelAttnBF16(Function):
         nb = L.modet_na_bwd_ws_bytes(B, D, H, W, heads)
         ws = _ws(nb, F)
         nvh = n * heads
+        later = dst is not None and DEFER_LEAF_REDUCTIONS
         with _Guard(F, f"na_bwd[h{heads}]", 1900.0 * nvh, 100.0 * nvh):
-            _lib.check(L.modet_na_bwd_t(_p(q), _p(k), 1, _p(rpb), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(drpb), _p(ws), nb, B, D,
-                                        H, W, heads, dim // heads, ctx.scale, _stream()), "modet_na_bwd_t")
+            _lib.check(L.modet_na_bwd_t(_p(q), _p(k), 1, _p(rpb), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(None if later else drpb),
+                                        _p(ws), nb, B, D, H, W, heads, dim // heads, ctx.scale, _stream()), "modet_na_bwd_t")
+        if later:
+            _defer_rpb(ctx.step, ws, B, D, H, W, heads, dim // heads, drpb)
         x2 = Mw if flow is not None else M
         dF = torch.empty(F.shape, dtype=torch.float32, device=F.device)
         dMw = torch.empty(M.shape, dtype=torch.float32, device=M.device)
@@ -1241,10 +1289,13 @@ class _LevelAttnBF16(Function):
             raise RuntimeError(f"level attention (bf16): no paired projection backward for Cin {Cin}, dim {dim}")
         ws2 = _ws(nb2, F)
         with _Guard(F, f"proj_ln_bwd[{Cin}->{dim}]", 2 * n * (6.0 * Cin * dim + 20.0 * dim), n * (14.0 * Cin + 8.0 * dim)):
+            out4 = (None, None, None, None) if later else (dW, db, dg, dbeta)
             _lib.check(L.modet_proj_ln_bwd_pair_t(_p(F), int(F.dtype == torch.bfloat16), _p(dq), _p(dF), _p(x2),
                                                   int(x2.dtype == torch.bfloat16), _p(dk), _p(dMw),
-                                                  _p(Wt), _p(b), _p(gamma), _p(dW), _p(db), _p(dg), _p(dbeta), _p(ws2), nb2, N, Cin, dim,
-                                                  ctx.eps, _stream()), "modet_proj_ln_bwd_pair_t")
+                                                  _p(Wt), _p(b), _p(gamma), _p(out4[0]), _p(out4[1]), _p(out4[2]), _p(out4[3]), _p(ws2),
+                                                  nb2, N, Cin, dim, ctx.eps, _stream()), "modet_proj_ln_bwd_pair_t")
+        if later:
+            _defer_proj(ctx.step, ws2, N, Cin, dim, dW, db, dg, dbeta)
         if dst is not None:
             dW = db = dg = dbeta = drpb = None           # (written in place: nothing for autograd to hand on)
         if flow is None:

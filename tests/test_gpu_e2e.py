@@ -550,6 +550,44 @@ def test_step_seeded_with_the_loss_gradients_equals_loss_backward(overlap):
     assert bool(torch.isfinite(tr.fp.grad).all())
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_leaf_reductions_in_one_launch_equal_the_per_level_ones(bf16, monkeypatch):
+    """The attention's d_rpb and the projection's d_gamma / d_beta / d_bias / d_W of ALL levels are summed by one
+    modet_leaf_reduce_many launch at the end of the backward pass (15 launches of 5-8 us otherwise).  Same partial rows, fp64
+    sums in another order: with the deterministic warp scatter every other gradient is IDENTICAL and these agree to the last
+    bit or two; the plain and the three-stage backward both take the path."""
+    from smilecode_amd import models, ops, synth
+    from smilecode_amd.engine import Trainer
+    shape = (32, 48, 32)
+    mov, fix = _pair(shape)
+    prev = ops.set_deterministic(True)
+    try:
+        for overlap in (False, True):
+            res = []
+            for defer in (True, False):
+                monkeypatch.setattr(ops, "DEFER_LEAF_REDUCTIONS", defer)
+                m = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1.0,
+                                 act_dtype=torch.bfloat16 if bf16 else torch.float32).cuda()
+                models.load_numpy_weights(m, synth.make_weights(24))
+                tr = Trainer(m, overlap_allreduce=overlap)
+                tr.fp.grad.fill_(float("nan"))
+                tr._fwd_bwd_staged(mov, fix) if overlap else tr._fwd_bwd(mov, fix)
+                assert bool(torch.isfinite(tr.fp.grad).all())
+                res.append((tr.fp.grad.clone(), {n: tr.fp.offsets[i] for i, (n, _) in enumerate(m.named_parameters())}))
+            (ga, off), (gb, _) = res
+            leaf = torch.zeros_like(ga, dtype=torch.bool)
+            for n, (o, k) in off.items():
+                if n.startswith(("projblock", "mdt")):
+                    leaf[o:o + k] = True
+            assert torch.equal(ga[~leaf], gb[~leaf]), "a gradient that is not a deferred leaf reduction changed"
+            scale = float(gb[leaf].abs().max())
+            err = float((ga[leaf] - gb[leaf]).abs().max())
+            _note(f"leaf_reduce[bf16={int(bf16)},overlap={int(overlap)}].maxdiff_of_max", err / scale)
+            assert err <= 2e-7 * scale, (err, scale)
+    finally:
+        ops.set_deterministic(prev)
+
+
 def test_staged_graphs_follow_the_parameters():
     """the three stage graphs must pack the conv weights INSIDE graph 0 -- packed once at capture, every
     replay after the first optimizer step would convolve with the weights of capture time.  Capture, then change every

@@ -1328,6 +1328,49 @@ def test_loss_value_and_gradient_calls_of_the_train_step(ops, scale):
         ops.grad3d_value_and_grad_cl(cu(g["g3d.flow"]), "l2")        # a planar flow is refused, not misread
 
 
+def test_leaf_reduce_many_vs_fp64_sums():
+    """modet_leaf_reduce_many: any number of column-sum jobs in one call (more than one table's worth here), both addressing
+    forms -- the attention's [B][heads][rows][27] partials and the projection's [rows][cols] -- against torch fp64 sums"""
+    import ctypes
+    from smilecode_amd import _lib
+    L = _lib.load()
+    gen = torch.Generator().manual_seed(5)
+    jobs, want, keep = [], [], []
+    for j in range(19):
+        if j % 2 == 0:                                   # d_rpb form
+            B, heads, rows = 1 + j % 3, 1 + j % 4, 7 + 61 * j
+            part = torch.randn((B, heads, rows, 27), generator=gen).cuda()
+            dst = [torch.full((heads, 3, 3, 3), float("nan"), device="cuda")]
+            job = _lib.LeafJob()
+            job.part, job.outer, job.outer_stride, job.rows, job.row_stride = part.data_ptr(), B, heads * rows * 27, rows, 27
+            job.col_group_stride, job.ncols, job.col_group = rows * 27, heads * 27, 27
+            ref = [part.double().sum((0, 2)).reshape(heads, 3, 3, 3)]
+        else:                                            # projection form, four segments
+            dim, cin, rows = 6 * (1 + j % 3), 8 * (1 + j % 2), 5 + 97 * j
+            ncols = 3 * dim + dim * cin
+            part = torch.randn((rows, ncols), generator=gen).cuda()
+            dst = [torch.full((dim,), float("nan"), device="cuda") for _ in range(3)] + [torch.full((dim, cin), float("nan"), device="cuda")]
+            job = _lib.LeafJob()
+            job.part, job.outer, job.outer_stride, job.rows, job.row_stride = part.data_ptr(), 1, 0, rows, ncols
+            job.col_group_stride, job.ncols, job.col_group = 0, ncols, ncols
+            cs = part.double().sum(0)
+            ref = [cs[:dim], cs[dim:2 * dim], cs[2 * dim:3 * dim], cs[3 * dim:].reshape(dim, cin)]
+        for u in range(4):
+            job.dst[u] = dst[u].data_ptr() if u < len(dst) else None
+            job.n[u] = dst[u].numel() if u < len(dst) else 0
+        jobs.append(job); want.append((dst, ref)); keep.append(part)
+    arr = (_lib.LeafJob * len(jobs))(*jobs)
+    _lib.check(L.modet_leaf_reduce_many(ctypes.addressof(arr), len(jobs), torch.cuda.current_stream().cuda_stream), "leaf_reduce")
+    torch.cuda.synchronize()
+    for dst, ref in want:
+        for d, r in zip(dst, ref):
+            assert torch.equal(d.cpu(), r.float().cpu().reshape(d.shape)) or float((d.double().cpu() - r.cpu().reshape(d.shape)).abs().max()) < 1e-5
+    assert L.modet_leaf_reduce_many(None, 0, None) == 0                       # nothing queued: no launch, no error
+    jobs[0].n[0] += 1                                                         # segments that do not add up are refused
+    bad = (_lib.LeafJob * 1)(jobs[0])
+    assert L.modet_leaf_reduce_many(ctypes.addressof(bad), 1, None) != 0
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_jacobian_determinant_golden(ops, tag):
     """det(J) <= 0 count of infer.py:89-90 on the GPU: integer-exact against the reference's jacobian_determinant_vxm
