@@ -39,3 +39,18 @@ if len(sys.argv) > 2 and sys.argv[2] == "--census" and len(cuts) >= 2:
     print("# launches shorter than 12 us in the last step: %d, %.3f ms" % (sum(cnt.values()), sum(tot.values()) / 1e6))
     for n, c in cnt.most_common(40):
         print("%4d x %6.1f us  %s" % (c, tot[n] / c / 1e3, n))
+
+if len(sys.argv) > 2 and sys.argv[2] == "--timeline" and len(cuts) >= 2:
+    # the last step in launch order: offset from the step's start, duration, gap to the previous launch's end, grid, name
+    import re
+    a, b = cuts[-2], cuts[-1]
+    seg = rows[a + 1:b + 1]
+    t0 = int(seg[0]["Start_Timestamp"])
+    prev_end = t0
+    for r in seg:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        n = re.sub(r"^void ", "", n)[:90]
+        grid = r.get("Grid_Size_X", r.get("Grid_Size", "?"))
+        print("%8.1f us  dur %7.1f  gap %6.1f  grid %9s  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, grid, n))
+        prev_end = max(prev_end, e)
