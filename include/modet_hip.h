@@ -343,6 +343,11 @@ int modet_proj_ln_bwd(const float* x, const float* Wt, const float* bias, const 
  * models.py:371-372): both data gradients and the parameter gradients of BOTH uses, summed in one fixed-order fp64
  * reduction.  _ws_bytes returns 0 when the shape is not covered (use two modet_proj_ln_bwd calls and add). */
 size_t modet_proj_ln_bwd_pair_ws_bytes(int64_t N, int Cin, int dim);
+/* y1 = layer(x1), y2 = layer(x2): one launch for the grouped shapes (pyramid levels 3-5), two modet_proj_ln_fwd otherwise;
+ * bit-identical to two calls. */
+int modet_proj_ln_fwd_pair(const float* x1, const float* x2, const float* Wt, const float* bias, const float* gamma,
+                           const float* beta, float* y1, float* y2, int64_t N, int Cin, int dim, float eps,
+                           modet_stream_t stream);
 int modet_proj_ln_bwd_pair(const float* x1, const float* d_y1, float* d_x1, const float* x2, const float* d_y2, float* d_x2,
                            const float* Wt, const float* bias, const float* gamma, float* d_Wt, float* d_bias,
                            float* d_gamma, float* d_beta, void* ws, size_t ws_bytes, int64_t N, int Cin, int dim,

@@ -86,6 +86,7 @@ SIGNATURES = {
     "modet_proj_ln_bwd_ws_bytes": (SZ, [I64, I, I]),
     "modet_proj_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),
     "modet_proj_ln_bwd_pair_ws_bytes": (SZ, [I64, I, I]),
+    "modet_proj_ln_fwd_pair": (I, [P, P, P, P, P, P, P, P, I64, I, I, F, P]),
     "modet_proj_ln_bwd_pair_partial_rows": (I64, [I64, I, I]),
     "modet_leaf_reduce_many": (I, [P, I, P]),
     "modet_proj_ln_bwd_pair": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, SZ, I64, I, I, F, P]),

@@ -342,10 +342,15 @@ __device__ __forceinline__ void linear_ln_group(const float* xrow, const float* 
 }
 
 template <int DIM, int CIN, int G, bool X16 = false, bool Y16 = false>
-__global__ __launch_bounds__(BLK) void proj_ln_fwd_g_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+__global__ __launch_bounds__(BLK) void proj_ln_fwd_g_kernel(const float* __restrict__ x_, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ y,
-                                                            int64_t N, float eps) {
+                                                            const float* __restrict__ beta, float* __restrict__ y_,
+                                                            int64_t N, float eps, const float* __restrict__ x2_ = nullptr,
+                                                            float* __restrict__ y2_ = nullptr) {
+  // gridDim.y == 2: the layer applied to two inputs (q and k projections of a level) in one launch -- at levels 3-5 one use is
+  // 75-600 workgroups of a latency-bound kernel, two of them side by side cost the time of one
+  const float* __restrict__ x = blockIdx.y ? x2_ : x_;
+  float* __restrict__ y = blockIdx.y ? y2_ : y_;
   using C = ProjCfg<DIM, CIN, G>;
   __shared__ __attribute__((aligned(16))) float Ws[CIN * C::DIMS];
   __shared__ float ps[3 * DIM];
@@ -373,10 +378,18 @@ __global__ __launch_bounds__(BLK) void proj_ln_fwd_g_kernel(const float* __restr
 }
 
 template <int DIM, int CIN, int G, bool X16 = false>
-__global__ __launch_bounds__(BLK) void proj_ln_bwd_g_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+__global__ __launch_bounds__(BLK) void proj_ln_bwd_g_kernel(const float* __restrict__ x_, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                            const float* __restrict__ dy, float* __restrict__ dx,
-                                                            float* __restrict__ part, int64_t N, float eps) {
+                                                            const float* __restrict__ dy_, float* __restrict__ dx_,
+                                                            float* __restrict__ part_, int64_t N, float eps,
+                                                            const float* __restrict__ x2_ = nullptr,
+                                                            const float* __restrict__ dy2_ = nullptr,
+                                                            float* __restrict__ dx2_ = nullptr, float* __restrict__ part2_ = nullptr) {
+  // gridDim.y == 2: both uses of a paired projection in one launch (see proj_ln_fwd_g_kernel)
+  const float* __restrict__ x = blockIdx.y ? x2_ : x_;
+  const float* __restrict__ dy = blockIdx.y ? dy2_ : dy_;
+  float* __restrict__ dx = blockIdx.y ? dx2_ : dx_;
+  float* __restrict__ part = blockIdx.y ? part2_ : part_;
   using C = ProjCfg<DIM, CIN, G>;
   __shared__ __attribute__((aligned(16))) float Ws[CIN * C::DIMS];
   __shared__ float ps[2 * DIM];
@@ -595,6 +608,24 @@ int modet_proj_ln_fwd(const float* x, const float* Wt, const float* bias, const 
   return modet_proj_ln_fwd_t(x, 0, Wt, bias, gamma, beta, y, 0, N, Cin, dim, eps, stream);
 }
 
+int modet_proj_ln_fwd_pair(const float* x1, const float* x2, const float* Wt, const float* bias, const float* gamma,
+                           const float* beta, float* y1, float* y2, int64_t N, int Cin, int dim, float eps, modet_stream_t stream) {
+  MODET_CHECK_PTR(x1); MODET_CHECK_PTR(x2); MODET_CHECK_PTR(Wt); MODET_CHECK_PTR(bias); MODET_CHECK_PTR(gamma); MODET_CHECK_PTR(beta);
+  MODET_CHECK_PTR(y1); MODET_CHECK_PTR(y2);
+  MODET_CHECK_DIM(N > 0 && Cin > 0 && dim > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int G = group_of(Cin, dim);
+  if (G > 1) {
+    const int gg = group_grid(N, G);
+    if (G == 4) hipLaunchKernelGGL((proj_ln_fwd_g_kernel<12, 32, 4, false, false>), dim3(gg, 2), dim3(BLK), 0, s, x1, Wt, bias, gamma, beta, y1, N, eps, x2, y2);
+    else if (G == 8) hipLaunchKernelGGL((proj_ln_fwd_g_kernel<24, 64, 8, false, false>), dim3(gg, 2), dim3(BLK), 0, s, x1, Wt, bias, gamma, beta, y1, N, eps, x2, y2);
+    else hipLaunchKernelGGL((proj_ln_fwd_g_kernel<48, 128, 16, false, false>), dim3(gg, 2), dim3(BLK), 0, s, x1, Wt, bias, gamma, beta, y1, N, eps, x2, y2);
+    return modet_launch_status();
+  }
+  const int rc = modet_proj_ln_fwd(x1, Wt, bias, gamma, beta, y1, N, Cin, dim, eps, stream);
+  return rc != MODET_OK ? rc : modet_proj_ln_fwd(x2, Wt, bias, gamma, beta, y2, N, Cin, dim, eps, stream);
+}
+
 size_t modet_proj_ln_bwd_ws_bytes(int64_t N, int Cin, int dim) {
   if (const int G = group_of(Cin, dim)) return (size_t)group_grid(N, G) * (3 * dim + dim * Cin) * sizeof(float);
   const int rc = reg_cin(Cin, dim);
@@ -637,6 +668,20 @@ int modet_proj_ln_bwd_pair_t(const void* x1v, int x1_bf16, const float* d_y1, fl
   hipStream_t s = (hipStream_t)stream;
   const int gg = group_grid(N, G), row = 3 * dim + dim * Cin;
   float* gpart = (float*)ws;
+  if (G > 1 && (x1_bf16 != 0) == (x2_bf16 != 0)) {      // levels 3-5: the two uses side by side in ONE launch (grid.y = 2)
+    float* part2 = gpart + (size_t)gg * row;
+#define LAUNCH_G2(D_, C_, G_)                                                                                                     \
+    do {                                                                                                                          \
+      if (x1_bf16) hipLaunchKernelGGL((proj_ln_bwd_g_kernel<D_, C_, G_, true>), dim3(gg, 2), dim3(BLK), 0, s, x1, Wt, bias, gamma,  \
+                                      d_y1, d_x1, gpart, N, eps, x2, d_y2, d_x2, part2);                                          \
+      else hipLaunchKernelGGL((proj_ln_bwd_g_kernel<D_, C_, G_, false>), dim3(gg, 2), dim3(BLK), 0, s, x1, Wt, bias, gamma, d_y1,   \
+                              d_x1, gpart, N, eps, x2, d_y2, d_x2, part2);                                                        \
+    } while (0)
+    if (G == 4) LAUNCH_G2(12, 32, 4);
+    else if (G == 8) LAUNCH_G2(24, 64, 8);
+    else LAUNCH_G2(48, 128, 16);
+#undef LAUNCH_G2
+  } else
   for (int u = 0; u < 2; ++u) {
     const float* x = u ? x2 : x1;
     const float* d_y = u ? d_y2 : d_y1;

@@ -1101,13 +1101,10 @@ class _ProjLNPair(Function):
         dim = Wt.shape[0]
         N = x1.numel() // Cin
         L = _L()
-        ys = []
-        for x in (x1, x2):
-            y = torch.empty(x.shape[:-1] + (dim,), dtype=torch.float32, device=x.device)
-            with _Guard(x, f"proj_ln_fwd[{Cin}->{dim}]", N * (2.0 * Cin * dim + 8.0 * dim), 4.0 * N * (Cin + dim)):
-                _lib.check(L.modet_proj_ln_fwd(_p(x), _p(Wt), _p(b), _p(gamma), _p(beta), _p(y), N, Cin, dim, eps, _stream()),
-                           "modet_proj_ln_fwd")
-            ys.append(y)
+        ys = [torch.empty(x.shape[:-1] + (dim,), dtype=torch.float32, device=x.device) for x in (x1, x2)]
+        with _Guard(x1, f"proj_ln_fwd[{Cin}->{dim}]", 2 * N * (2.0 * Cin * dim + 8.0 * dim), 8.0 * N * (Cin + dim)):
+            _lib.check(L.modet_proj_ln_fwd_pair(_p(x1), _p(x2), _p(Wt), _p(b), _p(gamma), _p(beta), _p(ys[0]), _p(ys[1]), N, Cin, dim,
+                                                eps, _stream()), "modet_proj_ln_fwd_pair")
         ctx.save_for_backward(x1, x2, Wt, b, gamma, beta)
         ctx.eps = eps
         ctx.step = current_step()
