@@ -45,6 +45,29 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.modet_conv3d_ws_bytes(8, 8) >= 27 * 8 * 16 * 4
 
 
+def test_header_is_plain_c_and_the_ctypes_structs_match_it(tmp_path):
+    """include/modet_hip.h is the C ABI a cgo / JNI / ctypes binding compiles against: it must parse as C (gcc -std=c99, no HIP
+    headers), and the one struct that crosses the boundary by value (modet_leaf_job_t) must have the layout smilecode_amd._lib
+    declares for ctypes"""
+    import ctypes
+    from smilecode_amd import _lib
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "modet_hip.h"\n'
+        'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(modet_leaf_job_t), offsetof(modet_leaf_job_t, outer), '
+        'offsetof(modet_leaf_job_t, col_group_stride), offsetof(modet_leaf_job_t, ncols), offsetof(modet_leaf_job_t, col_group), '
+        'offsetof(modet_leaf_job_t, dst), offsetof(modet_leaf_job_t, n), MODET_LEAF_MAX_JOBS); return 0; }\n')
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
+    J = _lib.LeafJob
+    assert got[:7] == [ctypes.sizeof(J), J.outer.offset, J.col_group_stride.offset, J.ncols.offset, J.col_group.offset,
+                       J.dst.offset, J.n.offset], got
+    assert got[7] == 16
+
+
 def test_product_path_has_no_cpu_fallback():
     from smilecode_amd import ops
     x = torch.zeros(1, 4, 4, 4, 8)
