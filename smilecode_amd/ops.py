@@ -8,6 +8,7 @@ There is no eager / CPU fallback: a missing library or a non-GPU tensor raises.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import threading
 
@@ -409,8 +410,7 @@ class StepContext:
             rc = _L().modet_conv3d_wgrad_defer_flush(sc.handle, _stream())    # always empties the queue, also on an exception
             jobs, sc._leaf = sc._leaf, []
             if exc[0] is None and jobs:                  # the attention / projection parameter gradients of every level: one launch
-                arr = (_lib.LeafJob * len(jobs))(*jobs)
-                import ctypes
+                arr = (_lib.LeafJob * len(jobs))(*jobs)            # host table: copied into the launch's arguments
                 _lib.check(_L().modet_leaf_reduce_many(ctypes.addressof(arr), len(jobs), _stream()), "modet_leaf_reduce_many")
             sc._keep = []
             if exc[0] is None:
