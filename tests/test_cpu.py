@@ -483,6 +483,39 @@ def test_trainer_state_dict_is_torch_adam_compatible():
         tr2.load_state_dict({"step": 1, "lr": 1e-4})                       # round 1's stub format is rejected loudly
 
 
+def test_trainer_picks_the_seeded_backward_only_for_the_losses_its_kernels_cover():
+    """host logic of engine.Trainer._seedable: the step seeds its backward with the loss kernels' gradients only for the
+    reference's two terms as the kernels have them -- cubic NCC window 3 / 5 / 7 / 9, Grad3d without loss_mult -- on a model that
+    hands out channels-last results; everything else keeps the autograd expression (no silent approximation)"""
+    from smilecode_amd import engine, losses, models
+
+    class WithCl(torch.nn.Linear):
+        def forward_cl(self, a, b):
+            raise AssertionError("not called here")
+
+    tr = engine.Trainer(WithCl(3, 2))
+    assert tr._seedable()
+    tr.seed_backward = False
+    assert not tr._seedable()
+    tr.seed_backward = True
+    for sim, ok in ((losses.NCC_vxm(win=[7, 7, 7]), True), (losses.NCC_vxm(win=[5, 3, 7]), False),
+                    (losses.NCC_vxm(win=[11, 11, 11]), False), (losses.NCC_vxm(win=[4, 4, 4]), False)):
+        tr.sim = sim
+        assert tr._seedable() == ok, sim._w
+    tr.sim = losses.NCC_vxm()
+    tr.reg = losses.Grad3d(penalty="l2", loss_mult=2)
+    assert not tr._seedable()
+    tr.reg = losses.Grad3d(penalty="l1")
+    assert tr._seedable()
+
+    class Sub(losses.Grad3d):                            # a subclass may compute anything: not the kernel's contract
+        pass
+    tr.reg = Sub()
+    assert not tr._seedable()
+    assert not engine.Trainer(torch.nn.Linear(3, 2))._seedable()          # a model without forward_cl
+    assert hasattr(models.ModeT, "forward_cl") and hasattr(models.ModeT_cu, "forward_cl")
+
+
 def test_resume_from_a_checkpoint_the_reference_wrote(tmp_path):
     """the reference's train.py stores ``param_groups[0]['lr'] = round(INIT_LR * np.power(..), 8)`` -- a
     numpy.float64 (train.py:117,:166-168) -- in the optimizer state it saves (train.py:158-163).  torch >= 2.6 refuses to
