@@ -1,0 +1,250 @@
+// PROTOTYPE (not part of libmodet_hip.so): the scatter of the warp backward (d_src of SpatialTransformer, reference
+// ModeT/models.py:55-67 -> ATen grid_sampler_3d_backward) WITHOUT global float atomics, built on the measurement of
+// profiles/r05y_lds_atomic_microbench.txt: ds_add_u64 runs 20-37 x faster than ds_add_f32 on gfx950.
+//   A  bin the source voxels by the 8^3 DESTINATION tile of their base corner: per source workgroup an LDS hash histogram
+//      (integer LDS atomics), one returning global atomic per (workgroup, tile); run twice: count -> exclusive scan -> fill
+//   B  one workgroup per destination tile: its list -> a 9^3 x C window of 64-bit fixed-point sums in LDS (ds_add_u64), the
+//      8^3 owned cells leave as plain stores (no zero-fill of d_src), the 217 high-face cells go to a side buffer
+//   C  every owned cell on a low tile face adds the neighbours' side-buffer cells (gather)
+// Integer sums: the result does not depend on the order of the list -> deterministic.
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/micro/warp_tile_proto.hip -o build/micro/libwarp_tile.so
+//   python tools/exp_warp_tile.py        (the model's own level-1 flow, against modet_warp_bwd)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+constexpr int TL = 8, WN = 9, CELLS = WN * WN * WN, NBORDER = CELLS - TL * TL * TL;      // 729 window cells, 217 on the high faces
+constexpr int SZ = 4, SY = 8, SX = 32, SVOX = SZ * SY * SX;                             // source block of pass A: 1024 voxels
+constexpr int HASH = 256;
+struct Geo { int D, H, W, C, tz, ty, tx, ntiles; };
+
+struct Entry { int tile, bz, by, bx; float fz, fy, fx; };
+__device__ __forceinline__ bool make_entry(const float* __restrict__ flow, int64_t p, int z, int y, int x, const Geo g, Entry& e) {
+  const float pz = (float)z + flow[p * 3], py = (float)y + flow[p * 3 + 1], px = (float)x + flow[p * 3 + 2];
+  const float flz = floorf(pz), fly = floorf(py), flx = floorf(px);
+  if (!(flz >= -1.f && flz <= (float)(g.D - 1) && fly >= -1.f && fly <= (float)(g.H - 1) && flx >= -1.f && flx <= (float)(g.W - 1)))
+    return false;                                   // every corner outside the volume (or a non-finite flow)
+  e.bz = (int)flz; e.by = (int)fly; e.bx = (int)flx;
+  e.fz = pz - flz; e.fy = py - fly; e.fx = px - flx;
+  const int cz = (e.bz < 0 ? 0 : e.bz) >> 3, cy = (e.by < 0 ? 0 : e.by) >> 3, cx = (e.bx < 0 ? 0 : e.bx) >> 3;
+  e.tile = (cz * g.ty + cy) * g.tx + cx;
+  return true;
+}
+
+// ---- A: FILL = false: tile_count[tile] += entries;  FILL = true: cursor[tile] (initialised to the tile's list offset) hands out
+// a segment per (workgroup, tile) and the voxel indices are written there
+template <bool FILL>
+__global__ __launch_bounds__(256) void bin_kernel(const float* __restrict__ flow, unsigned* __restrict__ counter, int* __restrict__ list,
+                                                  const Geo g, int bx_n, int by_n) {
+  __shared__ int keys[HASH];
+  __shared__ unsigned cnt[HASH], off[HASH];
+  const int tid = threadIdx.x;
+  keys[tid] = -1; cnt[tid] = 0;
+  __syncthreads();
+  int t = blockIdx.x;
+  const int x0 = (t % bx_n) * SX; t /= bx_n;
+  const int y0 = (t % by_n) * SY;
+  const int z0 = (t / by_n) * SZ;
+  const int x = x0 + (tid & 31), y = y0 + (tid >> 5);
+  int slot[SZ];
+  unsigned rank[SZ];
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) {
+    const int z = z0 + k;
+    slot[k] = -1; rank[k] = 0;
+    if (x >= g.W || y >= g.H || z >= g.D) continue;
+    const int64_t p = ((int64_t)z * g.H + y) * g.W + x;
+    Entry e;
+    if (!make_entry(flow, p, z, y, x, g, e)) continue;
+    int s = (e.tile * 40503) & (HASH - 1);
+    for (int probe = 0; probe < HASH; ++probe) {
+      const int k0 = atomicCAS(&keys[s], -1, e.tile);
+      if (k0 == -1 || k0 == e.tile) break;
+      s = (s + 1) & (HASH - 1);
+    }
+    slot[k] = s;
+    rank[k] = atomicAdd(&cnt[s], 1u);
+  }
+  __syncthreads();
+  if (keys[tid] >= 0) off[tid] = atomicAdd(&counter[keys[tid]], cnt[tid]);
+  if (!FILL) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) {
+    if (slot[k] < 0) continue;
+    list[off[slot[k]] + rank[k]] = ((z0 + k) << 20) | (y << 10) | x;          // (dimensions <= 1024)
+  }
+}
+
+// exclusive scan of the tile counts (one workgroup): offsets[t], cursor[t] = offsets[t]
+__global__ __launch_bounds__(1024) void scan_kernel(const unsigned* __restrict__ count, unsigned* __restrict__ offsets,
+                                                    unsigned* __restrict__ cursor, int n) {
+  __shared__ unsigned part[1024];
+  const int per = (n + 1023) / 1024, b = threadIdx.x * per;
+  unsigned s = 0;
+  for (int i = 0; i < per; ++i) if (b + i < n) s += count[b + i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const unsigned v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (int i = 0; i < per; ++i)
+    if (b + i < n) { offsets[b + i] = run; cursor[b + i] = run; run += count[b + i]; }
+}
+
+__device__ __forceinline__ int border_index(int lz, int ly, int lx) {      // cells with max(l) == 8
+  if (lz == 8) return ly * 9 + lx;                   // 81
+  if (ly == 8) return 81 + lz * 9 + lx;              // 72 (lz < 8)
+  return 153 + lz * 8 + ly;                          // 64 (lx == 8, lz, ly < 8)
+}
+
+// ---- B: the tile's list -> fixed-point window -> owned cells (plain stores) + high-face cells (side buffer).  TWO lanes per
+// entry (four channels each: one float4 of d_out; C == 8), so the corner / weight arithmetic of an entry is done twice, not
+// eight times; U entries per lane in flight.
+__global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict__ flow, const float* __restrict__ dout,
+                                                         const unsigned* __restrict__ offsets, const unsigned* __restrict__ count,
+                                                         const int* __restrict__ list, float* __restrict__ dsrc,
+                                                         float* __restrict__ border, const Geo g, float scale, float inv_scale,
+                                                         int dbg) {
+  __shared__ unsigned long long win[CELLS * 8];
+  long long sink = 0;
+  const int tid = threadIdx.x, half = tid & 1, sub = tid >> 1;
+  for (int i = tid; i < CELLS * 8; i += 256) win[i] = 0ull;
+  const int tile = blockIdx.x;
+  int t = tile;
+  const int ox = (t % g.tx) * TL; t /= g.tx;
+  const int oy = (t % g.ty) * TL;
+  const int oz = (t / g.ty) * TL;
+  const unsigned n = count[tile], base = offsets[tile];
+  __syncthreads();
+  constexpr int U = 4;
+  for (unsigned i0 = sub; i0 < ((dbg & 2) ? 0u : n); i0 += 128 * U) {
+    int pk[U];
+    float f0[U], f1[U], f2[U];
+    float4 gv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const unsigned i = i0 + 128 * u; pk[u] = i < n ? list[base + i] : -1; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = pk[u] < 0 ? 0 : pk[u];
+      const int64_t v = ((int64_t)(q >> 20) * g.H + ((q >> 10) & 1023)) * g.W + (q & 1023);
+      f0[u] = flow[v * 3]; f1[u] = flow[v * 3 + 1]; f2[u] = flow[v * 3 + 2];
+      gv[u] = *reinterpret_cast<const float4*>(dout + v * 8 + half * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (pk[u] < 0) continue;
+      const float pz = (float)(pk[u] >> 20) + f0[u], py = (float)((pk[u] >> 10) & 1023) + f1[u], px = (float)(pk[u] & 1023) + f2[u];
+      const float flz = floorf(pz), fly = floorf(py), flx = floorf(px);
+      const int bz = (int)flz, by = (int)fly, bx = (int)flx;
+      const float fz = pz - flz, fy = py - fly, fx = px - flx;
+      const float v0 = gv[u].x * scale, v1 = gv[u].y * scale, v2 = gv[u].z * scale, v3 = gv[u].w * scale;
+      const int cell0 = ((bz - oz) * WN + (by - oy)) * WN + (bx - ox);
+      // every corner inside the volume (all but the entries at the volume's faces): no per-corner tests
+      const bool inner = bz >= 0 && bz + 1 < g.D && by >= 0 && by + 1 < g.H && bx >= 0 && bx + 1 < g.W;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int dz = c >> 2, dy = (c >> 1) & 1, dx = c & 1;
+        if (!inner) {
+          const int gz = bz + dz, gy = by + dy, gx = bx + dx;
+          if (gz < 0 || gz >= g.D || gy < 0 || gy >= g.H || gx < 0 || gx >= g.W) continue;
+        }
+        const float w = (dz ? fz : 1.f - fz) * (dy ? fy : 1.f - fy) * (dx ? fx : 1.f - fx);
+        unsigned long long* wp = win + (cell0 + (dz * WN + dy) * WN + dx) * 8 + half * 4;
+        if (dbg & 1) {
+          sink += (long long)__float2int_rn(v0 * w) + (long long)__float2int_rn(v1 * w) + (long long)__float2int_rn(v2 * w) +
+                  (long long)__float2int_rn(v3 * w) + (wp - win);
+          continue;
+        }
+        atomicAdd(wp + 0, (unsigned long long)(long long)__float2int_rn(v0 * w));
+        atomicAdd(wp + 1, (unsigned long long)(long long)__float2int_rn(v1 * w));
+        atomicAdd(wp + 2, (unsigned long long)(long long)__float2int_rn(v2 * w));
+        atomicAdd(wp + 3, (unsigned long long)(long long)__float2int_rn(v3 * w));
+      }
+    }
+  }
+  if (sink == 0x7fffffffffffffffll) win[0] = 1;
+  __syncthreads();
+  for (int j = tid; j < CELLS * 8; j += 256) {
+    const int cell = j >> 3;
+    const int lx = cell % WN, lr = cell / WN, ly = lr % WN, lz = lr / WN;
+    const float val = (float)(long long)win[j] * inv_scale;
+    if (lz < TL && ly < TL && lx < TL) {
+      const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
+      if (gz < g.D && gy < g.H && gx < g.W) dsrc[(((int64_t)gz * g.H + gy) * g.W + gx) * 8 + (j & 7)] = val;
+    } else {
+      border[((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * 8 + (j & 7)] = val;
+    }
+  }
+}
+
+// ---- C: owned cells on a low face of their tile (169 of 512) += the high-face cells of the up to seven neighbours; every
+// side-buffer cell is read exactly once
+__global__ __launch_bounds__(256) void border_kernel(float* __restrict__ dsrc, const float* __restrict__ border, const Geo g) {
+  const int tile = blockIdx.x;
+  int t = tile;
+  const int tx = t % g.tx; t /= g.tx;
+  const int ty = t % g.ty, tz = t / g.ty;
+  for (int j = threadIdx.x; j < 169 * 8; j += 256) {
+    const int ch = j & 7, k = j >> 3;
+    int lz, ly, lx;
+    if (k < 64) { lz = 0; ly = k >> 3; lx = k & 7; }
+    else if (k < 120) { const int r = k - 64; ly = 0; lz = 1 + r / 8; lx = r & 7; }
+    else { const int r = k - 120; lx = 0; lz = 1 + r / 7; ly = 1 + r % 7; }
+    const int gz = tz * 8 + lz, gy = ty * 8 + ly, gx = tx * 8 + lx;
+    if (gz >= g.D || gy >= g.H || gx >= g.W) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int m = 1; m < 8; ++m) {
+      const int dz = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
+      if ((dz && (lz || tz == 0)) || (dy && (ly || ty == 0)) || (dx && (lx || tx == 0))) continue;
+      const int nt = ((tz - dz) * g.ty + (ty - dy)) * g.tx + (tx - dx);
+      s += border[((int64_t)nt * NBORDER + border_index(dz ? 8 : lz, dy ? 8 : ly, dx ? 8 : lx)) * 8 + ch];
+    }
+    dsrc[(((int64_t)gz * g.H + gy) * g.W + gx) * 8 + ch] += s;
+  }
+}
+}  // namespace
+
+extern "C" {
+// workspace: [count ntiles][offsets ntiles][cursor ntiles] unsigned, [list D*H*W] int, [border ntiles*217*8] float
+size_t wt_ws_bytes(int D, int H, int W) {
+  const size_t nt = (size_t)((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8);
+  return 3 * nt * 4 + (size_t)D * H * W * 4 + nt * NBORDER * 8 * 4 + 256;
+}
+// phases: bit 0 bin (count, scan, fill), bit 1 accumulate, bit 2 border gather; bits 4-5: timing variants of accumulate (16: no
+// LDS atomics, 32: no entry loop at all -- zero + flush only).  C must be 8, one sample.  amax = max |d_out|.
+int wt_run(const float* flow, const float* dout, float* dsrc, void* ws, int D, int H, int W, int C, float amax, int phases,
+           hipStream_t s) {
+  if (C != 8) return -1;
+  Geo g{D, H, W, C, (D + 7) / 8, (H + 7) / 8, (W + 7) / 8, 0};
+  g.ntiles = g.tz * g.ty * g.tx;
+  unsigned* count = (unsigned*)ws;
+  unsigned* offsets = count + g.ntiles;
+  unsigned* cursor = offsets + g.ntiles;
+  int* list = (int*)(cursor + g.ntiles);
+  float* border = (float*)(list + (size_t)D * H * W);
+  const int bx_n = (W + SX - 1) / SX, by_n = (H + SY - 1) / SY, bz_n = (D + SZ - 1) / SZ;
+  if (phases & 1) {
+    hipMemsetAsync(count, 0, (size_t)g.ntiles * 4, s);
+    hipLaunchKernelGGL(bin_kernel<false>, dim3(bx_n * by_n * bz_n), dim3(256), 0, s, flow, count, list, g, bx_n, by_n);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)count, offsets, cursor, g.ntiles);
+    hipLaunchKernelGGL(bin_kernel<true>, dim3(bx_n * by_n * bz_n), dim3(256), 0, s, flow, cursor, list, g, bx_n, by_n);
+  }
+  int e = 0;
+  float m = frexpf(amax > 0.f ? amax : 1.f, &e);          // amax = m 2^e, m in [0.5, 1): |d_out| * 2^(30 - e) < 2^30
+  (void)m;
+  const float scale = ldexpf(1.f, 30 - e), inv = ldexpf(1.f, e - 30);
+  if (phases & 2)
+    hipLaunchKernelGGL(accumulate_kernel, dim3(g.ntiles), dim3(256), 0, s, flow, dout, (const unsigned*)offsets, (const unsigned*)count,
+                       (const int*)list, dsrc, border, g, scale, inv, (phases >> 4) & 3);
+  if (phases & 4) {
+    hipLaunchKernelGGL(border_kernel, dim3(g.ntiles), dim3(256), 0, s, dsrc, (const float*)border, g);
+  }
+  return (int)hipGetLastError();
+}
+}
