@@ -93,3 +93,20 @@ print("deterministic (two runs bit-identical):", bool(torch.equal(out, out2)))
 tb, ta, tc = timed(lambda: proto(1)), timed(lambda: proto(2)), timed(lambda: proto(4))
 print(f"prototype: bin (count + scan + fill) {tb:.3f} ms, accumulate {ta:.3f} ms, border gather {tc:.3f} ms, all {timed(lambda: proto(7)):.3f} ms")
 print(f"accumulate variants: without the LDS atomics {timed(lambda: proto(2 | 16)):.3f} ms, zero + flush only {timed(lambda: proto(2 | 32)):.3f} ms")
+dflow = torch.empty_like(fl)
+
+
+def shipped_both():
+    _lib.check(L.modet_warp_bwd(src.data_ptr(), fl.data_ptr(), dout.data_ptr(), ref.data_ptr(), dflow.data_ptr(), B, D, H, W, C, 0, 0, st), "warp_bwd")
+
+
+def shipped_dflow():
+    _lib.check(L.modet_warp_bwd(src.data_ptr(), fl.data_ptr(), dout.data_ptr(), None, dflow.data_ptr(), B, D, H, W, C, 0, 0, st), "warp_bwd")
+
+
+print(f"shipped, same dense random d_out: d_src + d_flow {timed(shipped_both):.3f} ms, d_flow only {timed(shipped_dflow):.3f} ms")
+# the step's d_out is not dense: zero it where the fixed image is background (the shipped kernel skips zero contributions)
+mask = (fix[0, 0] > 0).unsqueeze(-1).unsqueeze(0).to(dout.dtype)
+dout.mul_(mask)
+print(f"d_out zero on the fixed image's background ({100 * float(1 - mask.mean()):.0f} % of the voxels): shipped d_src + d_flow "
+      f"{timed(shipped_both):.3f} ms, d_src only {timed(shipped):.3f} ms; prototype {timed(lambda: proto(7)):.3f} ms")
