@@ -102,18 +102,28 @@ __device__ __forceinline__ int border_index(int lz, int ly, int lx) {      // ce
   return 153 + lz * 8 + ly;                          // 64 (lx == 8, lz, ly < 8)
 }
 
-// ---- B: the tile's list -> fixed-point window -> owned cells (plain stores) + high-face cells (side buffer).  TWO lanes per
-// entry (four channels each: one float4 of d_out; C == 8), so the corner / weight arithmetic of an entry is done twice, not
-// eight times; U entries per lane in flight.
+// ---- B: the tile's list -> fixed-point window -> owned cells (plain stores) + high-face cells (side buffer).  ONE lane per
+// entry, all eight channels (two float4 of d_out; C == 8): the corner / weight arithmetic of an entry is done once; an entry
+// whose d_out is all zero (the step's d_out is: background) costs its loads only; U entries per lane in flight.
+__device__ __forceinline__ float fx_to_float(unsigned long long u, float inv_scale) {
+  const long long x = (long long)u;
+  const unsigned long long a = x < 0 ? (unsigned long long)(-x) : (unsigned long long)x;      // sign-magnitude: no cancellation
+  const float m = fmaf((float)(unsigned)(a >> 32), 4294967296.f, (float)(unsigned)a);
+  return (x < 0 ? -m : m) * inv_scale;
+}
 __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict__ flow, const float* __restrict__ dout,
                                                          const unsigned* __restrict__ offsets, const unsigned* __restrict__ count,
                                                          const int* __restrict__ list, float* __restrict__ dsrc,
                                                          float* __restrict__ border, const Geo g, float scale, float inv_scale,
                                                          int dbg) {
-  __shared__ unsigned long long win[CELLS * 8];
+  __shared__ __attribute__((aligned(16))) unsigned long long win[CELLS * 8];
   long long sink = 0;
-  const int tid = threadIdx.x, half = tid & 1, sub = tid >> 1;
-  for (int i = tid; i < CELLS * 8; i += 256) win[i] = 0ull;
+  const int tid = threadIdx.x;
+  {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2* w2 = reinterpret_cast<u64x2*>(win);
+    for (int i = tid; i < CELLS * 4; i += 256) w2[i] = (u64x2){0ull, 0ull};
+  }
   const int tile = blockIdx.x;
   int t = tile;
   const int ox = (t % g.tx) * TL; t /= g.tx;
@@ -121,28 +131,36 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict
   const int oz = (t / g.ty) * TL;
   const unsigned n = count[tile], base = offsets[tile];
   __syncthreads();
-  constexpr int U = 4;
-  for (unsigned i0 = sub; i0 < ((dbg & 2) ? 0u : n); i0 += 128 * U) {
+  constexpr int U = 2;
+  for (unsigned i0 = tid; i0 < ((dbg & 2) ? 0u : n); i0 += 256 * U) {
     int pk[U];
     float f0[U], f1[U], f2[U];
-    float4 gv[U];
+    float4 ga[U], gb[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const unsigned i = i0 + 128 * u; pk[u] = i < n ? list[base + i] : -1; }
+    for (int u = 0; u < U; ++u) { const unsigned i = i0 + 256 * u; pk[u] = i < n ? list[base + i] : -1; }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int q = pk[u] < 0 ? 0 : pk[u];
       const int64_t v = ((int64_t)(q >> 20) * g.H + ((q >> 10) & 1023)) * g.W + (q & 1023);
       f0[u] = flow[v * 3]; f1[u] = flow[v * 3 + 1]; f2[u] = flow[v * 3 + 2];
-      gv[u] = *reinterpret_cast<const float4*>(dout + v * 8 + half * 4);
+      ga[u] = *reinterpret_cast<const float4*>(dout + v * 8);
+      gb[u] = *reinterpret_cast<const float4*>(dout + v * 8 + 4);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (pk[u] < 0) continue;
+      const float gvv[8] = {ga[u].x, ga[u].y, ga[u].z, ga[u].w, gb[u].x, gb[u].y, gb[u].z, gb[u].w};
+      bool any = false;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) any = any || gvv[c] != 0.f;
+      if (!any) continue;
       const float pz = (float)(pk[u] >> 20) + f0[u], py = (float)((pk[u] >> 10) & 1023) + f1[u], px = (float)(pk[u] & 1023) + f2[u];
       const float flz = floorf(pz), fly = floorf(py), flx = floorf(px);
       const int bz = (int)flz, by = (int)fly, bx = (int)flx;
       const float fz = pz - flz, fy = py - fly, fx = px - flx;
-      const float v0 = gv[u].x * scale, v1 = gv[u].y * scale, v2 = gv[u].z * scale, v3 = gv[u].w * scale;
+      float vs[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) vs[c] = gvv[c] * scale;
       const int cell0 = ((bz - oz) * WN + (by - oy)) * WN + (bx - ox);
       // every corner inside the volume (all but the entries at the volume's faces): no per-corner tests
       const bool inner = bz >= 0 && bz + 1 < g.D && by >= 0 && by + 1 < g.H && bx >= 0 && bx + 1 < g.W;
@@ -154,31 +172,36 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict
           if (gz < 0 || gz >= g.D || gy < 0 || gy >= g.H || gx < 0 || gx >= g.W) continue;
         }
         const float w = (dz ? fz : 1.f - fz) * (dy ? fy : 1.f - fy) * (dx ? fx : 1.f - fx);
-        unsigned long long* wp = win + (cell0 + (dz * WN + dy) * WN + dx) * 8 + half * 4;
+        unsigned long long* wp = win + (cell0 + (dz * WN + dy) * WN + dx);       // window = [channel][cell]: a wave's lanes (different entries) spread over the banks
         if (dbg & 1) {
-          sink += (long long)__float2int_rn(v0 * w) + (long long)__float2int_rn(v1 * w) + (long long)__float2int_rn(v2 * w) +
-                  (long long)__float2int_rn(v3 * w) + (wp - win);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sink += (long long)__float2int_rn(vs[k] * w);
+          sink += wp - win;
           continue;
         }
-        atomicAdd(wp + 0, (unsigned long long)(long long)__float2int_rn(v0 * w));
-        atomicAdd(wp + 1, (unsigned long long)(long long)__float2int_rn(v1 * w));
-        atomicAdd(wp + 2, (unsigned long long)(long long)__float2int_rn(v2 * w));
-        atomicAdd(wp + 3, (unsigned long long)(long long)__float2int_rn(v3 * w));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(wp + k * CELLS, (unsigned long long)(long long)__float2int_rn(vs[k] * w));
       }
     }
   }
   if (sink == 0x7fffffffffffffffll) win[0] = 1;
   __syncthreads();
-  for (int j = tid; j < CELLS * 8; j += 256) {
-    const int cell = j >> 3;
+  // flush: one cell (8 channels = 32 bytes of output) per thread and trip
+  for (int cell = tid; cell < CELLS; cell += 256) {
     const int lx = cell % WN, lr = cell / WN, ly = lr % WN, lz = lr / WN;
-    const float val = (float)(long long)win[j] * inv_scale;
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = fx_to_float(win[k * CELLS + cell], inv_scale);
+    float* dst;
     if (lz < TL && ly < TL && lx < TL) {
       const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
-      if (gz < g.D && gy < g.H && gx < g.W) dsrc[(((int64_t)gz * g.H + gy) * g.W + gx) * 8 + (j & 7)] = val;
+      if (gz >= g.D || gy >= g.H || gx >= g.W) continue;
+      dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * 8;
     } else {
-      border[((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * 8 + (j & 7)] = val;
+      dst = border + ((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * 8;
     }
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
   }
 }
 
