@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict
   const int oz = (t / g.ty) * TL;
   const unsigned n = count[tile], base = offsets[tile];
   __syncthreads();
-  constexpr int U = 2;
+  constexpr int U = 4;
   for (unsigned i0 = tid; i0 < ((dbg & 2) ? 0u : n); i0 += 256 * U) {
     int pk[U];
     float f0[U], f1[U], f2[U];
