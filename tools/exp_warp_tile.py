@@ -18,9 +18,9 @@ from smilecode_amd import _lib, models, ops, synth  # noqa: E402
 L = _lib.load()
 P = ctypes.CDLL(os.path.join(ROOT, "build", "micro", "libwarp_tile.so"))
 P.wt_ws_bytes.restype = ctypes.c_size_t
-P.wt_ws_bytes.argtypes = [ctypes.c_int] * 3
+P.wt_ws_bytes.argtypes = [ctypes.c_int] * 5
 P.wt_run.restype = ctypes.c_int
-P.wt_run.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+P.wt_run.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
 
 shape = (160, 192, 160)
 m = models.ModeT(shape, head_dim=6, num_heads=[8, 4, 2, 1, 1], scale=1).cuda().eval()
@@ -31,8 +31,8 @@ orig = ops.warp_tee
 
 
 def spy(src, flow):
-    if src.shape[-1] == 8:
-        rec[8] = (src.detach().clone(), flow.detach().clone())
+    if src.shape[-1] in (8, 16, 32):
+        rec[src.shape[-1]] = (src.detach().clone(), flow.detach().clone())
     return orig(src, flow)
 
 
@@ -40,14 +40,7 @@ ops.warp_tee = spy
 with torch.no_grad():
     m(mov, fix)
 ops.warp_tee = orig
-src, fl = rec[8]
-B, D, H, W, C = src.shape
 st = torch.cuda.current_stream().cuda_stream
-d = fl[:, :, :, 1:] - fl[:, :, :, :-1]
-print(f"C={C} {D}x{H}x{W}: |flow|max {float(fl.abs().max()):.2f}, |d flow/dx| mean {float(d.abs().mean()):.4f} max {float(d.abs().max()):.3f}")
-torch.manual_seed(0)
-dout = torch.randn_like(src)
-ref = torch.empty_like(src)
 
 
 def timed(fn, n=10):
@@ -63,50 +56,62 @@ def timed(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 
-def shipped():
-    _lib.check(L.modet_warp_bwd(src.data_ptr(), fl.data_ptr(), dout.data_ptr(), ref.data_ptr(), None, B, D, H, W, C, 0, 0, st), "warp_bwd")
+def case(src, fl, label, sparse_mask=None, detail=False):
+    B, D, H, W, C = src.shape
+    d = fl[:, :, :, 1:] - fl[:, :, :, :-1]
+    print(f"--- {label}: B={B} C={C} {D}x{H}x{W}: |flow|max {float(fl.abs().max()):.2f}, |d flow/dx| mean {float(d.abs().mean()):.4f} max {float(d.abs().max()):.3f}")
+    torch.manual_seed(0)
+    dout = torch.randn_like(src)
+    if sparse_mask is not None:
+        dout.mul_(sparse_mask)
+    ref, dflow = torch.empty_like(src), torch.empty_like(fl)
+
+    def shipped(ds=True, df=False):
+        _lib.check(L.modet_warp_bwd(src.data_ptr(), fl.data_ptr(), dout.data_ptr(), ref.data_ptr() if ds else None,
+                                    dflow.data_ptr() if df else None, B, D, H, W, C, 0, 0, st), "warp_bwd")
+
+    ws = torch.empty(P.wt_ws_bytes(B, D, H, W, C) // 4 + 16, dtype=torch.float32, device="cuda")
+    out = torch.full_like(src, float("nan"))
+
+    def proto(phases, dst=None):
+        rc = P.wt_run(fl.data_ptr(), dout.data_ptr(), (out if dst is None else dst).data_ptr(), ws.data_ptr(), B, D, H, W, C, phases, st)
+        assert rc == 0, rc
+
+    shipped()
+    proto(7)
+    torch.cuda.synchronize()
+    err = float((out - ref).abs().max())
+    out2 = torch.full_like(src, float("nan"))
+    proto(7, out2)
+    torch.cuda.synchronize()
+    print(f"    prototype vs shipped: max |diff| {err:.3e} of max |d_src| {float(ref.abs().max()):.3f}; NaN left {int(torch.isnan(out).sum())}; "
+          f"two runs bit-identical: {bool(torch.equal(out, out2))}")
+    print(f"    shipped: d_src {timed(shipped):.3f} ms, d_src + d_flow {timed(lambda: shipped(True, True)):.3f}, d_flow only "
+          f"{timed(lambda: shipped(False, True)):.3f} | prototype d_src {timed(lambda: proto(7)):.3f} ms")
+    if detail:
+        print(f"    prototype by pass: bin {timed(lambda: proto(1)):.3f}, absmax + accumulate {timed(lambda: proto(2)):.3f} "
+              f"(no LDS atomics {timed(lambda: proto(2 | 16)):.3f}, zero + flush only {timed(lambda: proto(2 | 32)):.3f}), border {timed(lambda: proto(4)):.3f}")
+    # the sequence is kernels with fixed arguments: capture it and replay
+    g = torch.cuda.CUDAGraph()
+    out.fill_(float("nan"))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sst = side.cuda_stream
+        with torch.cuda.graph(g, stream=side):
+            rc = P.wt_run(fl.data_ptr(), dout.data_ptr(), out.data_ptr(), ws.data_ptr(), B, D, H, W, C, 7, sst)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        out.fill_(float("nan"))
+        g.replay()
+    torch.cuda.synchronize()
+    print(f"    hipGraph replay == eager result: {bool(torch.equal(out, out2))}")
 
 
-print(f"shipped modet_warp_bwd, d_src only (zero-fill + float atomics): {timed(shipped):.3f} ms")
-ws = torch.empty(P.wt_ws_bytes(D, H, W) // 4 + 16, dtype=torch.float32, device="cuda")
-out = torch.full_like(src, float("nan"))
-amax = float(dout.abs().max())
-
-
-def proto(phases):
-    rc = P.wt_run(fl.data_ptr(), dout.data_ptr(), out.data_ptr(), ws.data_ptr(), D, H, W, C, amax, phases, st)
-    assert rc == 0, rc
-
-
-proto(7)
-torch.cuda.synchronize()
-nt = (D // 8) * (H // 8) * (W // 8)
-cnt = ws[:nt].view(torch.int32)
-print(f"tiles {nt}, entries {int(cnt.sum())} of {D * H * W}, per tile mean {float(cnt.float().mean()):.0f} max {int(cnt.max())}")
-err = float((out - ref).abs().max())
-print(f"prototype vs shipped: max |diff| {err:.3e} (max |d_src| {float(ref.abs().max()):.3f}), NaN left: {int(torch.isnan(out).sum())}")
-again = torch.full_like(src, float('nan'))
-out2, out = out, again
-proto(7)
-torch.cuda.synchronize()
-print("deterministic (two runs bit-identical):", bool(torch.equal(out, out2)))
-tb, ta, tc = timed(lambda: proto(1)), timed(lambda: proto(2)), timed(lambda: proto(4))
-print(f"prototype: bin (count + scan + fill) {tb:.3f} ms, accumulate {ta:.3f} ms, border gather {tc:.3f} ms, all {timed(lambda: proto(7)):.3f} ms")
-print(f"accumulate variants: without the LDS atomics {timed(lambda: proto(2 | 16)):.3f} ms, zero + flush only {timed(lambda: proto(2 | 32)):.3f} ms")
-dflow = torch.empty_like(fl)
-
-
-def shipped_both():
-    _lib.check(L.modet_warp_bwd(src.data_ptr(), fl.data_ptr(), dout.data_ptr(), ref.data_ptr(), dflow.data_ptr(), B, D, H, W, C, 0, 0, st), "warp_bwd")
-
-
-def shipped_dflow():
-    _lib.check(L.modet_warp_bwd(src.data_ptr(), fl.data_ptr(), dout.data_ptr(), None, dflow.data_ptr(), B, D, H, W, C, 0, 0, st), "warp_bwd")
-
-
-print(f"shipped, same dense random d_out: d_src + d_flow {timed(shipped_both):.3f} ms, d_flow only {timed(shipped_dflow):.3f} ms")
-# the step's d_out is not dense: zero it where the fixed image is background (the shipped kernel skips zero contributions)
-mask = (fix[0, 0] > 0).unsqueeze(-1).unsqueeze(0).to(dout.dtype)
-dout.mul_(mask)
-print(f"d_out zero on the fixed image's background ({100 * float(1 - mask.mean()):.0f} % of the voxels): shipped d_src + d_flow "
-      f"{timed(shipped_both):.3f} ms, d_src only {timed(shipped):.3f} ms; prototype {timed(lambda: proto(7)):.3f} ms")
+src8, fl8 = rec[8]
+case(src8, fl8, "level 1, dense random d_out", detail=True)
+mask = (fix[0, 0] > 0).unsqueeze(-1).unsqueeze(0).to(src8.dtype)
+case(src8, fl8, "level 1, d_out zero on the fixed image's background (%d %% of the voxels)" % round(100 * float(1 - mask.mean())), sparse_mask=mask)
+if 16 in rec:
+    case(*rec[16], "level 2 (two channel passes)")
+case(torch.cat([src8[:, :80], src8[:, 80:]], 0).contiguous(), torch.cat([fl8[:, :80], fl8[:, 80:]], 0).contiguous(), "two samples (the level-1 volume cut in two along z)")

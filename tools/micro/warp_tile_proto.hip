@@ -16,7 +16,7 @@ namespace {
 constexpr int TL = 8, WN = 9, CELLS = WN * WN * WN, NBORDER = CELLS - TL * TL * TL;      // 729 window cells, 217 on the high faces
 constexpr int SZ = 4, SY = 8, SX = 32, SVOX = SZ * SY * SX;                             // source block of pass A: 1024 voxels
 constexpr int HASH = 256;
-struct Geo { int D, H, W, C, tz, ty, tx, ntiles; };
+struct Geo { int D, H, W, C, tz, ty, tx, ntiles, B; };      // ntiles = tiles per sample
 
 struct Entry { int tile, bz, by, bx; float fz, fy, fx; };
 __device__ __forceinline__ bool make_entry(const float* __restrict__ flow, int64_t p, int z, int y, int x, const Geo g, Entry& e) {
@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256) void bin_kernel(const float* __restrict__ flow
   const int y0 = (t % by_n) * SY;
   const int z0 = (t / by_n) * SZ;
   const int x = x0 + (tid & 31), y = y0 + (tid >> 5);
+  const int b = blockIdx.y;                                   // sample: its tiles are [b * ntiles, (b + 1) * ntiles)
+  flow += (int64_t)b * g.D * g.H * g.W * 3;
   int slot[SZ];
   unsigned rank[SZ];
 #pragma unroll
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(256) void bin_kernel(const float* __restrict__ flow
     const int64_t p = ((int64_t)z * g.H + y) * g.W + x;
     Entry e;
     if (!make_entry(flow, p, z, y, x, g, e)) continue;
+    e.tile += b * g.ntiles;
     int s = (e.tile * 40503) & (HASH - 1);
     for (int probe = 0; probe < HASH; ++probe) {
       const int k0 = atomicCAS(&keys[s], -1, e.tile);
@@ -96,6 +99,33 @@ __global__ __launch_bounds__(1024) void scan_kernel(const unsigned* __restrict__
     if (b + i < n) { offsets[b + i] = run; cursor[b + i] = run; run += count[b + i]; }
 }
 
+__global__ __launch_bounds__(256) void zero_kernel(unsigned* __restrict__ p, int n) {       // (a kernel, not hipMemsetAsync: round 3
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;         //  met a memset node that replayed once)
+}
+// amax[0] = bits of max |x| (non-negative floats order like their bit patterns); amax[0] must be zero on entry
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ amax) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i * 4 < n; i += (int64_t)gridDim.x * 256) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {                                     // ONE atomic per workgroup (8 192 same-address atomics cost 0.1 ms)
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (m > 0.f) atomicMax(amax, __float_as_uint(m));
+  }
+}
+// scale = 2^(30 - e) with max |d_out| = m 2^e, m in [0.5, 1): |d_out| * scale < 2^30 (an int32 per contribution, int64 sums)
+__device__ __forceinline__ void fx_scales(const unsigned* amax, float& scale, float& inv) {
+  const float a = __uint_as_float(amax[0]);
+  int e = 0;
+  (void)frexpf(a > 0.f && a < 3.0e38f ? a : 1.f, &e);
+  scale = ldexpf(1.f, 30 - e); inv = ldexpf(1.f, e - 30);
+}
+
 __device__ __forceinline__ int border_index(int lz, int ly, int lx) {      // cells with max(l) == 8
   if (lz == 8) return ly * 9 + lx;                   // 81
   if (ly == 8) return 81 + lz * 9 + lx;              // 72 (lz < 8)
@@ -114,22 +144,34 @@ __device__ __forceinline__ float fx_to_float(unsigned long long u, float inv_sca
 __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict__ flow, const float* __restrict__ dout,
                                                          const unsigned* __restrict__ offsets, const unsigned* __restrict__ count,
                                                          const int* __restrict__ list, float* __restrict__ dsrc,
-                                                         float* __restrict__ border, const Geo g, float scale, float inv_scale,
+                                                         float* __restrict__ border, const Geo g, const unsigned* __restrict__ amax,
                                                          int dbg) {
   __shared__ __attribute__((aligned(16))) unsigned long long win[CELLS * 8];
   long long sink = 0;
   const int tid = threadIdx.x;
+  float scale, inv_scale;
+  fx_scales(amax, scale, inv_scale);
+  const int tile = blockIdx.x;                                // over all samples
+  const int b = tile / g.ntiles;
+  int t = tile - b * g.ntiles;
+  const int ox = (t % g.tx) * TL; t /= g.tx;
+  const int oy = (t % g.ty) * TL;
+  const int oz = (t / g.ty) * TL;
+  const unsigned n = count[tile], base = offsets[tile];
+  const int64_t V = (int64_t)g.D * g.H * g.W;
+  flow += (int64_t)b * V * 3;
+  dout += (int64_t)b * V * g.C;
+  dsrc += (int64_t)b * V * g.C;
+  const int C = g.C;
+  // C channels in passes of eight: the window is 46 KB whatever C is (three workgroups per CU); the list and the flow are re-read
+  // per pass (L2), d_out once in total
+  for (int c0 = 0; c0 < C; c0 += 8) {
+  if (c0) __syncthreads();                                    // the previous pass's flush has read the window
   {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     u64x2* w2 = reinterpret_cast<u64x2*>(win);
     for (int i = tid; i < CELLS * 4; i += 256) w2[i] = (u64x2){0ull, 0ull};
   }
-  const int tile = blockIdx.x;
-  int t = tile;
-  const int ox = (t % g.tx) * TL; t /= g.tx;
-  const int oy = (t % g.ty) * TL;
-  const int oz = (t / g.ty) * TL;
-  const unsigned n = count[tile], base = offsets[tile];
   __syncthreads();
   constexpr int U = 4;
   for (unsigned i0 = tid; i0 < ((dbg & 2) ? 0u : n); i0 += 256 * U) {
@@ -143,8 +185,8 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict
       const int q = pk[u] < 0 ? 0 : pk[u];
       const int64_t v = ((int64_t)(q >> 20) * g.H + ((q >> 10) & 1023)) * g.W + (q & 1023);
       f0[u] = flow[v * 3]; f1[u] = flow[v * 3 + 1]; f2[u] = flow[v * 3 + 2];
-      ga[u] = *reinterpret_cast<const float4*>(dout + v * 8);
-      gb[u] = *reinterpret_cast<const float4*>(dout + v * 8 + 4);
+      ga[u] = *reinterpret_cast<const float4*>(dout + v * C + c0);
+      gb[u] = *reinterpret_cast<const float4*>(dout + v * C + c0 + 4);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -196,78 +238,88 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict
     if (lz < TL && ly < TL && lx < TL) {
       const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
       if (gz >= g.D || gy >= g.H || gx >= g.W) continue;
-      dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * 8;
+      dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C + c0;
     } else {
-      dst = border + ((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * 8;
+      dst = border + ((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * C + c0;
     }
     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
     *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
   }
+  }       // channel pass
 }
 
 // ---- C: owned cells on a low face of their tile (169 of 512) += the high-face cells of the up to seven neighbours; every
 // side-buffer cell is read exactly once
 __global__ __launch_bounds__(256) void border_kernel(float* __restrict__ dsrc, const float* __restrict__ border, const Geo g) {
   const int tile = blockIdx.x;
-  int t = tile;
+  const int b = tile / g.ntiles;
+  int t = tile - b * g.ntiles;
   const int tx = t % g.tx; t /= g.tx;
   const int ty = t % g.ty, tz = t / g.ty;
-  for (int j = threadIdx.x; j < 169 * 8; j += 256) {
-    const int ch = j & 7, k = j >> 3;
+  const int C = g.C, q4 = C / 4;                              // a thread = four channels of one face cell
+  dsrc += (int64_t)b * g.D * g.H * g.W * C;
+  for (int j = threadIdx.x; j < 169 * q4; j += 256) {
+    const int ch = (j % q4) * 4, k = j / q4;
     int lz, ly, lx;
     if (k < 64) { lz = 0; ly = k >> 3; lx = k & 7; }
     else if (k < 120) { const int r = k - 64; ly = 0; lz = 1 + r / 8; lx = r & 7; }
     else { const int r = k - 120; lx = 0; lz = 1 + r / 7; ly = 1 + r % 7; }
     const int gz = tz * 8 + lz, gy = ty * 8 + ly, gx = tx * 8 + lx;
     if (gz >= g.D || gy >= g.H || gx >= g.W) continue;
-    float s = 0.f;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any = false;
 #pragma unroll
     for (int m = 1; m < 8; ++m) {
       const int dz = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
       if ((dz && (lz || tz == 0)) || (dy && (ly || ty == 0)) || (dx && (lx || tx == 0))) continue;
-      const int nt = ((tz - dz) * g.ty + (ty - dy)) * g.tx + (tx - dx);
-      s += border[((int64_t)nt * NBORDER + border_index(dz ? 8 : lz, dy ? 8 : ly, dx ? 8 : lx)) * 8 + ch];
+      const int nt = b * g.ntiles + ((tz - dz) * g.ty + (ty - dy)) * g.tx + (tx - dx);
+      const float4 v = *reinterpret_cast<const float4*>(border + ((int64_t)nt * NBORDER + border_index(dz ? 8 : lz, dy ? 8 : ly, dx ? 8 : lx)) * C + ch);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      any = true;
     }
-    dsrc[(((int64_t)gz * g.H + gy) * g.W + gx) * 8 + ch] += s;
+    if (!any) continue;
+    float4* dp = reinterpret_cast<float4*>(dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C + ch);
+    float4 d = *dp;
+    d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+    *dp = d;
   }
 }
 }  // namespace
 
 extern "C" {
-// workspace: [count ntiles][offsets ntiles][cursor ntiles] unsigned, [list D*H*W] int, [border ntiles*217*8] float
-size_t wt_ws_bytes(int D, int H, int W) {
-  const size_t nt = (size_t)((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8);
-  return 3 * nt * 4 + (size_t)D * H * W * 4 + nt * NBORDER * 8 * 4 + 256;
+// workspace: [amax 1 + pad 63][count nt][offsets nt][cursor nt] unsigned, [list B*D*H*W] int, [border nt*217*C] float  (nt = all samples)
+size_t wt_ws_bytes(int B, int D, int H, int W, int C) {
+  const size_t nt = (size_t)B * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 7) / 8);
+  return (64 + 3 * nt) * 4 + (size_t)B * D * H * W * 4 + nt * NBORDER * C * 4 + 256;
 }
-// phases: bit 0 bin (count, scan, fill), bit 1 accumulate, bit 2 border gather; bits 4-5: timing variants of accumulate (16: no
-// LDS atomics, 32: no entry loop at all -- zero + flush only).  C must be 8, one sample.  amax = max |d_out|.
-int wt_run(const float* flow, const float* dout, float* dsrc, void* ws, int D, int H, int W, int C, float amax, int phases,
-           hipStream_t s) {
-  if (C != 8) return -1;
-  Geo g{D, H, W, C, (D + 7) / 8, (H + 7) / 8, (W + 7) / 8, 0};
+// d_src of the trilinear warp's backward, (B,D,H,W,C) channels-last, C a multiple of 8, dimensions <= 1024.  Every launch is a
+// kernel with fixed arguments: capturable.  phases: bit 0 bin (zero, count, scan, fill), bit 1 absmax + accumulate, bit 2 border
+// gather; bits 4-5: timing variants of accumulate (16: no LDS atomics, 32: zero + flush only).
+int wt_run(const float* flow, const float* dout, float* dsrc, void* ws, int B, int D, int H, int W, int C, int phases, hipStream_t s) {
+  if (C % 8 != 0 || D > 1024 || H > 1024 || W > 1024 || B < 1) return -1;
+  Geo g{D, H, W, C, (D + 7) / 8, (H + 7) / 8, (W + 7) / 8, 0, B};
   g.ntiles = g.tz * g.ty * g.tx;
-  unsigned* count = (unsigned*)ws;
-  unsigned* offsets = count + g.ntiles;
-  unsigned* cursor = offsets + g.ntiles;
-  int* list = (int*)(cursor + g.ntiles);
-  float* border = (float*)(list + (size_t)D * H * W);
+  const int nt = B * g.ntiles;
+  unsigned* amax = (unsigned*)ws;
+  unsigned* count = amax + 64;
+  unsigned* offsets = count + nt;
+  unsigned* cursor = offsets + nt;
+  int* list = (int*)(cursor + nt);
+  float* border = (float*)(list + (size_t)B * D * H * W);
   const int bx_n = (W + SX - 1) / SX, by_n = (H + SY - 1) / SY, bz_n = (D + SZ - 1) / SZ;
   if (phases & 1) {
-    hipMemsetAsync(count, 0, (size_t)g.ntiles * 4, s);
-    hipLaunchKernelGGL(bin_kernel<false>, dim3(bx_n * by_n * bz_n), dim3(256), 0, s, flow, count, list, g, bx_n, by_n);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)count, offsets, cursor, g.ntiles);
-    hipLaunchKernelGGL(bin_kernel<true>, dim3(bx_n * by_n * bz_n), dim3(256), 0, s, flow, cursor, list, g, bx_n, by_n);
+    hipLaunchKernelGGL(zero_kernel, dim3((64 + nt + 255) / 256), dim3(256), 0, s, amax, 64 + nt);
+    hipLaunchKernelGGL(bin_kernel<false>, dim3(bx_n * by_n * bz_n, B), dim3(256), 0, s, flow, count, list, g, bx_n, by_n);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)count, offsets, cursor, nt);
+    hipLaunchKernelGGL(bin_kernel<true>, dim3(bx_n * by_n * bz_n, B), dim3(256), 0, s, flow, cursor, list, g, bx_n, by_n);
   }
-  int e = 0;
-  float m = frexpf(amax > 0.f ? amax : 1.f, &e);          // amax = m 2^e, m in [0.5, 1): |d_out| * 2^(30 - e) < 2^30
-  (void)m;
-  const float scale = ldexpf(1.f, 30 - e), inv = ldexpf(1.f, e - 30);
-  if (phases & 2)
-    hipLaunchKernelGGL(accumulate_kernel, dim3(g.ntiles), dim3(256), 0, s, flow, dout, (const unsigned*)offsets, (const unsigned*)count,
-                       (const int*)list, dsrc, border, g, scale, inv, (phases >> 4) & 3);
-  if (phases & 4) {
-    hipLaunchKernelGGL(border_kernel, dim3(g.ntiles), dim3(256), 0, s, dsrc, (const float*)border, g);
+  if (phases & 2) {
+    const int64_t n = (int64_t)B * D * H * W * C;
+    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, s, dout, n, amax);
+    hipLaunchKernelGGL(accumulate_kernel, dim3(nt), dim3(256), 0, s, flow, dout, (const unsigned*)offsets, (const unsigned*)count,
+                       (const int*)list, dsrc, border, g, (const unsigned*)amax, (phases >> 4) & 3);
   }
+  if (phases & 4) hipLaunchKernelGGL(border_kernel, dim3(nt), dim3(256), 0, s, dsrc, (const float*)border, g);
   return (int)hipGetLastError();
 }
 }
