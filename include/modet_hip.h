@@ -418,6 +418,16 @@ size_t modet_warp_bwd_det_ws_bytes(int B, int D, int H, int W, int C);
 int modet_warp_bwd_det(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow,
                        const float* d_flow_add, void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, int add_flow,
                        modet_stream_t stream);
+/* d_src of the trilinear warp's backward WITHOUT global float atomics (round 5, csrc/warp_tile.hip): source voxels binned by the
+ * 8^3 destination tile of their base corner, one workgroup per tile accumulates its list in a 64-bit fixed-point LDS window (scale
+ * from max |d_out|, 2^-30 of it per contribution), a gather adds the tile borders.  Equal to modet_warp_bwd's d_src within fp32
+ * rounding of the sums (the float-atomic order is what differs there run to run; this one is bit-reproducible), every launch a
+ * kernel with fixed arguments (capturable).  d_src need NOT be zeroed.  C a multiple of 8, dimensions <= 1024; _ws_bytes returns
+ * 0 for anything else.  d_flow: call modet_warp_bwd / _acc with d_src = NULL.  The Python layer routes to it only when
+ * ops.WARP_TILE_DSRC is set (off by default: op-level parity only so far). */
+size_t modet_warp_bwd_dsrc_tiles_ws_bytes(int B, int D, int H, int W, int C);
+int modet_warp_bwd_dsrc_tiles(const float* flow, const float* d_out, float* d_src, void* ws, size_t ws_bytes,
+                              int B, int D, int H, int W, int C, modet_stream_t stream);
 /* d_src and/or d_flow; either may be NULL.  Trilinear only.
  * flow_bound = 0: arbitrary flow, d_src is zeroed here and scatter-added with float atomics (as ATen does).
  * flow_bound = 1: the CALLER guarantees |flow| <= 1 voxel everywhere (true for the attention output w of

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "libmodet_hip.so")
-SOURCES = ["api.hip", "na.hip", "qk_op.hip", "warp.hip", "norm_act.hip", "proj_ln.hip", "losses.hip", "conv3d.hip", "conv3d_bf16.hip", "conv3d_x3.hip", "conv3d_wtr.hip", "conv3d_q.hip", "corr3d.hip", "eval.hip"]
+SOURCES = ["api.hip", "na.hip", "qk_op.hip", "warp.hip", "warp_tile.hip", "norm_act.hip", "proj_ln.hip", "losses.hip", "conv3d.hip", "conv3d_bf16.hip", "conv3d_x3.hip", "conv3d_wtr.hip", "conv3d_q.hip", "corr3d.hip", "eval.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
          # NO packed-fp32 code from the SLP vectoriser (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 pairs formed out of scalar
          # source).  Round 5: with -O3 alone na_bwd_kernel's query role (27 x v_exp_f32 feeding v_pk_mul_f32 / v_pk_fma_f32

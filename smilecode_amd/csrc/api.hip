@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 433;
+int modet_hip_version(void) { return 434;
   /* 0.4.0: + modet_conv3d_kernel_family_v, conv kernel family 4 (conv_wgrad_tr_kernel); no environment reads in product builds
      0.4.1: + typed (fp32 | bf16) entry points modet_na_{fwd,bwd}_t, modet_proj_ln_*_t, modet_warp_*_t, modet_warp_fwd_o16,
               modet_avgpool2_fwd_x16, modet_instnorm_*_pool_bf16; modet_ncc_*_box (any window); conv kernel family 5 (conv_q_kernel)
@@ -17,7 +17,9 @@ int modet_hip_version(void) { return 433;
      0.4.3.2: + modet_leaf_reduce_many / modet_leaf_job_t, modet_na_bwd_partial_rows, modet_proj_ln_bwd_pair_partial_rows; d_rpb == NULL
               (modet_na_bwd[_t]) and d_Wt == d_bias == d_gamma == d_beta == NULL (modet_proj_ln_bwd_pair[_t]) leave the partial rows
               in the workspace: every leaf reduction of a backward pass in one launch
-     0.4.3.3: + modet_proj_ln_fwd_pair; the grouped paired-projection kernels (levels 3-5) run both uses in one launch (grid.y = 2) */ }
+     0.4.3.3: + modet_proj_ln_fwd_pair; the grouped paired-projection kernels (levels 3-5) run both uses in one launch (grid.y = 2)
+     0.4.3.4: + modet_warp_bwd_dsrc_tiles[_ws_bytes]: the warp backward's d_src without global float atomics (destination tiles,
+              64-bit fixed-point LDS window); not routed to by default */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {

@@ -1402,11 +1402,30 @@ def set_deterministic(on=True):
     return prev
 
 
+# Round 5 (end): d_src of the feature warps by destination tiles + a fixed-point LDS window instead of float atomics
+# (modet_warp_bwd_dsrc_tiles, csrc/warp_tile.hip; d_flow keeps the shipped kernel's d_flow-only form).  OFF: its op-level parity
+# tests are green and the prototype measurements are in profiles/r05z_*, but the full suite has not run with the step routed
+# through it.  Volumes below WARP_TILE_MIN_VOXELS keep the atomics either way (fixed costs of the binning passes).
+WARP_TILE_DSRC = False
+WARP_TILE_MIN_VOXELS = 1_500_000
+
+
 def _warp_backward(src, flow, dout, dsrc, dflow, galias, add_flow, flow_bound):
     """launch the warp backward: plain (float atomics; galias = a second flow gradient added on the way out) or deterministic"""
     B, D, H, W, C = src.shape
     L = _L()
     s16 = int(src.dtype == torch.bfloat16)
+    if (WARP_TILE_DSRC and dsrc is not None and not flow_bound and not add_flow and not DETERMINISTIC and dout.dtype == torch.float32
+            and B * D * H * W >= WARP_TILE_MIN_VOXELS):
+        nb = L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C)
+        if nb:
+            ws = _ws(nb, src)
+            _lib.check(L.modet_warp_bwd_dsrc_tiles(_p(flow), _p(dout), _p(dsrc), _p(ws), nb, B, D, H, W, C, _stream()),
+                       "modet_warp_bwd_dsrc_tiles")
+            if dflow is not None:
+                _lib.check(L.modet_warp_bwd_acc(_p(src), s16, _p(flow), _p(dout), None, _p(dflow), _p(galias), B, D, H, W, C, 0, 0,
+                                                _stream()), "modet_warp_bwd_acc")
+            return
     if DETERMINISTIC and dsrc is not None and not flow_bound:
         nb = L.modet_warp_bwd_det_ws_bytes(B, D, H, W, C)
         ws = torch.empty((nb + 7) // 8, dtype=torch.int64, device=src.device)

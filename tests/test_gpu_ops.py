@@ -271,6 +271,62 @@ def test_warp_tee_adds_the_second_flow_gradient_in_the_kernel(C, shape):
     assert torch.equal(f_.grad, f2.grad)
 
 
+@pytest.mark.parametrize("C,shape,amp", [(8, (2, 16, 24, 40), 2.0), (16, (1, 13, 21, 37), 6.0), (8, (1, 40, 48, 40), 12.0),
+                                         (32, (1, 9, 8, 17), 3.0), (8, (1, 8, 8, 8), 40.0)])
+def test_warp_backward_d_src_by_destination_tiles(C, shape, amp, monkeypatch):
+    """modet_warp_bwd_dsrc_tiles (round 5, csrc/warp_tile.hip): the scatter of SpatialTransformer's backward (reference
+    models.py:55-67 -> ATen grid_sampler_3d_backward) with destination-tile lists and a 64-bit fixed-point LDS window instead
+    of float atomics.  Against the shipped kernel (float atomics, itself pinned by the goldens): equal within fp32 rounding of the
+    sums; bit-identical run to run; ragged volumes (partial tiles), two samples, channel passes (C = 16, 32), flows that fold and
+    that leave the volume, an all-zero d_out and a d_src buffer full of NaN on entry (it is not read).  Then the routed form:
+    ops.warp_tee's backward with ops.WARP_TILE_DSRC gives the default path's d_src / d_flow (incl. the second flow gradient)."""
+    import ctypes
+    from smilecode_amd import _lib, ops
+    L = _lib.load()
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(C + D)
+    src = torch.randn(B, D, H, W, C, generator=g).cuda()
+    flow = (torch.randn(B, D, H, W, 3, generator=g) * amp).cuda()
+    dout = torch.randn(B, D, H, W, C, generator=g).cuda() * 3.7
+    dout[:, : D // 3] = 0.0                                       # zero contributions are skipped on both sides
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.empty_like(src)
+    _lib.check(L.modet_warp_bwd(src.data_ptr(), flow.data_ptr(), dout.data_ptr(), ref.data_ptr(), None, B, D, H, W, C, 0, 0, st), "warp_bwd")
+    nb = L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C)
+    assert nb > 0 and L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C + 4) == 0 and L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, 2000, H, W, C) == 0
+    ws = torch.empty(nb // 4 + 8, dtype=torch.float32, device="cuda")
+    outs = []
+    for rep in range(2):
+        out = torch.full_like(src, float("nan"))
+        ws.fill_(float("nan"))                                     # (the workspace needs no preparation either)
+        _lib.check(L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), dout.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, B, D, H, W, C, st), "tiles")
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0]).all())
+    assert torch.equal(outs[0], outs[1]), "integer sums: bit-reproducible"
+    scale = float(ref.abs().max())
+    err = float((outs[0] - ref).abs().max())
+    if scale > 0.0:                                               # (the last case: every sample point leaves the volume -> all zero)
+        _note(f"warp_tiles[C{C},{'x'.join(map(str, shape))}].dsrc_maxdiff_of_max", err / scale)
+    assert err <= 2e-6 * scale, (err, scale)
+    assert L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), dout.data_ptr(), outs[0].data_ptr(), ws.data_ptr(), nb - 4, B, D, H, W, C, st) != 0
+    z = torch.full_like(src, float("nan"))
+    _lib.check(L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), torch.zeros_like(dout).data_ptr(), z.data_ptr(), ws.data_ptr(), nb, B, D, H, W, C, st), "tiles")
+    assert float(z.abs().max()) == 0.0
+    # routed through the autograd node
+    r2 = torch.randn(B, D, H, W, 3, generator=g).cuda()
+    res = []
+    for routed in (False, True):
+        monkeypatch.setattr(ops, "WARP_TILE_DSRC", routed)
+        monkeypatch.setattr(ops, "WARP_TILE_MIN_VOXELS", 0)
+        s_, f_ = src.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+        o, fl = ops.warp_tee(s_, f_)
+        ((o * dout).sum() + (fl * fl * r2).sum()).backward()
+        res.append((s_.grad, f_.grad))
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * float(res[0][1].abs().max()) + 1e-30, "d_flow (the shipped kernel's d_flow-only form)"
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-6 * scale
+
+
 @pytest.mark.parametrize("C,shape,add_flow", [(8, (1, 40, 48, 40), False), (3, (2, 12, 16, 20), True), (16, (1, 8, 12, 16), False),
                                               (32, (1, 20, 24, 20), False)])
 def test_warp_backward_deterministic_mode(C, shape, add_flow):
