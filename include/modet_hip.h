@@ -428,6 +428,12 @@ int modet_warp_bwd_det(const void* src, int src_bf16, const float* flow, const f
 size_t modet_warp_bwd_dsrc_tiles_ws_bytes(int B, int D, int H, int W, int C);
 int modet_warp_bwd_dsrc_tiles(const float* flow, const float* d_out, float* d_src, void* ws, size_t ws_bytes,
                               int B, int D, int H, int W, int C, modet_stream_t stream);
+/* The same with d_flow (+ d_flow_add, NULL = none: a second gradient of the flow, as modet_warp_bwd_acc) from the SAME pass: the
+ * corners of an entry are cells of its tile's window, so the tile's src cells are staged in LDS once and d_flow needs no gather.
+ * C == 8 (the level-1 feature warp), fp32 src; same workspace. */
+int modet_warp_bwd_tiles(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow,
+                         const float* d_flow_add, void* ws, size_t ws_bytes, int B, int D, int H, int W, int C,
+                         modet_stream_t stream);
 /* d_src and/or d_flow; either may be NULL.  Trilinear only.
  * flow_bound = 0: arbitrary flow, d_src is zeroed here and scatter-added with float atomics (as ATen does).
  * flow_bound = 1: the CALLER guarantees |flow| <= 1 voxel everywhere (true for the attention output w of

@@ -39,7 +39,8 @@ __device__ __forceinline__ bool make_entry(const float* __restrict__ flow, int64
 // a segment per (workgroup, tile) and the voxel indices are written there
 template <bool FILL>
 __global__ __launch_bounds__(256) void bin_kernel(const float* __restrict__ flow, unsigned* __restrict__ counter, int* __restrict__ list,
-                                                  const Geo g, int bx_n, int by_n) {
+                                                  const Geo g, int bx_n, int by_n, float* __restrict__ dflow = nullptr,
+                                                  const float* __restrict__ dflow_add = nullptr) {
   __shared__ int keys[HASH];
   __shared__ unsigned cnt[HASH], off[HASH];
   const int tid = threadIdx.x;
@@ -61,7 +62,15 @@ __global__ __launch_bounds__(256) void bin_kernel(const float* __restrict__ flow
     if (x >= g.W || y >= g.H || z >= g.D) continue;
     const int64_t p = ((int64_t)z * g.H + y) * g.W + x;
     Entry e;
-    if (!make_entry(flow, p, z, y, x, g, e)) continue;
+    if (!make_entry(flow, p, z, y, x, g, e)) {
+      // no corner inside the volume: no entry; the fused form's d_flow of this voxel is just the second gradient (or 0)
+      if (FILL && dflow) {
+        const int64_t o = ((int64_t)b * g.D * g.H * g.W + p) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dflow[o + a] = dflow_add ? dflow_add[o + a] : 0.f;
+      }
+      continue;
+    }
     e.tile += b * g.ntiles;
     int s = (e.tile * 40503) & (HASH - 1);
     for (int probe = 0; probe < HASH; ++probe) {
@@ -142,11 +151,18 @@ __device__ __forceinline__ float fx_to_float(unsigned long long u, float inv_sca
   const float m = fmaf((float)(unsigned)(a >> 32), 4294967296.f, (float)(unsigned)a);
   return (x < 0 ? -m : m) * inv_scale;
 }
+// FLOW (C == 8 only): d_flow as well, from the SAME window -- the eight corners of an entry are cells of its tile's window, so the
+// tile's src cells are staged in LDS once (coalesced, every src value read from HBM once) and d_flow[p] = sum over the corners of
+// (+-) the other two weights x <src[corner], d_out[p]> needs no gather from memory; + dflow_add[p] (a second gradient of the flow).
+template <bool FLOW>
 __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict__ flow, const float* __restrict__ dout,
                                                          const unsigned* __restrict__ offsets, const unsigned* __restrict__ count,
                                                          const int* __restrict__ list, float* __restrict__ dsrc,
-                                                         float* __restrict__ border, const Geo g, const unsigned* __restrict__ amax) {
+                                                         float* __restrict__ border, const Geo g, const unsigned* __restrict__ amax,
+                                                         const float* __restrict__ src = nullptr, float* __restrict__ dflow = nullptr,
+                                                         const float* __restrict__ dflow_add = nullptr) {
   __shared__ __attribute__((aligned(16))) unsigned long long win[CELLS * 8];
+  __shared__ float swin[FLOW ? CELLS * 8 : 1];
   const int tid = threadIdx.x;
   float scale, inv_scale;
   fx_scales(amax, scale, inv_scale);
@@ -162,6 +178,21 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict
   dout += (int64_t)b * V * g.C;
   dsrc += (int64_t)b * V * g.C;
   const int C = g.C;
+  if constexpr (FLOW) {
+    src += (int64_t)b * V * 8; dflow += (int64_t)b * V * 3;
+    if (dflow_add) dflow_add += (int64_t)b * V * 3;
+    for (int cell = tid; cell < CELLS; cell += 256) {
+      const int lx = cell % WN, lr = cell / WN, ly = lr % WN, lz = lr / WN;
+      const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+      if (gz < g.D && gy < g.H && gx < g.W) {
+        const float* sp = src + (((int64_t)gz * g.H + gy) * g.W + gx) * 8;
+        a = *reinterpret_cast<const float4*>(sp); c = *reinterpret_cast<const float4*>(sp + 4);
+      }
+      swin[0 * CELLS + cell] = a.x; swin[1 * CELLS + cell] = a.y; swin[2 * CELLS + cell] = a.z; swin[3 * CELLS + cell] = a.w;
+      swin[4 * CELLS + cell] = c.x; swin[5 * CELLS + cell] = c.y; swin[6 * CELLS + cell] = c.z; swin[7 * CELLS + cell] = c.w;
+    }
+  }
   // C channels in passes of eight: the window is 46 KB whatever C is (three workgroups per CU); the list and the flow are re-read
   // per pass (L2), d_out once in total
   for (int c0 = 0; c0 < C; c0 += 8) {
@@ -194,7 +225,15 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict
       bool any = false;
 #pragma unroll
       for (int c = 0; c < 8; ++c) any = any || gvv[c] != 0.f;
-      if (!any) continue;
+      const int64_t vox = ((int64_t)(pk[u] >> 20) * g.H + ((pk[u] >> 10) & 1023)) * g.W + (pk[u] & 1023);
+      if (!any) {
+        if constexpr (FLOW) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) dflow[vox * 3 + a] = dflow_add ? dflow_add[vox * 3 + a] : 0.f;
+        }
+        continue;
+      }
+      float gfz = 0.f, gfy = 0.f, gfx = 0.f;
       const float pz = (float)(pk[u] >> 20) + f0[u], py = (float)((pk[u] >> 10) & 1023) + f1[u], px = (float)(pk[u] & 1023) + f2[u];
       const float flz = floorf(pz), fly = floorf(py), flx = floorf(px);
       const int bz = (int)flz, by = (int)fly, bx = (int)flx;
@@ -216,6 +255,20 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict
         unsigned long long* wp = win + (cell0 + (dz * WN + dy) * WN + dx);       // window = [channel][cell]: a wave's lanes (different entries) spread over the banks
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicAdd(wp + k * CELLS, (unsigned long long)(long long)__float2int_rn(vs[k] * w));
+        if constexpr (FLOW) {
+          const float* sp = swin + (cell0 + (dz * WN + dy) * WN + dx);
+          float dot = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dot = fmaf(sp[k * CELLS], gvv[k], dot);
+          const float wz = dz ? fz : 1.f - fz, wy = dy ? fy : 1.f - fy, wx = dx ? fx : 1.f - fx;
+          gfz += (dz ? 1.f : -1.f) * wy * wx * dot;
+          gfy += (dy ? 1.f : -1.f) * wz * wx * dot;
+          gfx += (dx ? 1.f : -1.f) * wz * wy * dot;
+        }
+      }
+      if constexpr (FLOW) {
+        if (dflow_add) { gfz += dflow_add[vox * 3]; gfy += dflow_add[vox * 3 + 1]; gfx += dflow_add[vox * 3 + 2]; }
+        dflow[vox * 3] = gfz; dflow[vox * 3 + 1] = gfy; dflow[vox * 3 + 2] = gfx;
       }
     }
   }
@@ -288,12 +341,12 @@ size_t modet_warp_bwd_dsrc_tiles_ws_bytes(int B, int D, int H, int W, int C) {
   return (64 + 3 * nt) * 4 + (size_t)B * D * H * W * 4 + nt * NBORDER * C * 4 + 256;
 }
 
-int modet_warp_bwd_dsrc_tiles(const float* flow, const float* d_out, float* d_src, void* ws, size_t ws_bytes, int B, int D, int H,
-                              int W, int C, modet_stream_t stream) {
+static int tiles_launch(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow, const float* d_flow_add,
+                        void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, modet_stream_t stream) {
   MODET_CHECK_PTR(flow); MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_src); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
   const size_t need = modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C);
-  if (need == 0) return MODET_ERR_UNSUPPORTED;
+  if (need == 0 || (d_flow && C != 8)) return MODET_ERR_UNSUPPORTED;
   if (ws_bytes < need) return MODET_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   Geo g{D, H, W, C, cdiv(D, 8), cdiv(H, 8), cdiv(W, 8), 0, B};
@@ -307,14 +360,31 @@ int modet_warp_bwd_dsrc_tiles(const float* flow, const float* d_out, float* d_sr
   float* border = (float*)(list + (size_t)B * D * H * W);
   const int bx_n = cdiv(W, SX), by_n = cdiv(H, SY), bz_n = cdiv(D, SZ);
   modet_zero_async(amax, (size_t)(64 + nt) * 4, s);
-  hipLaunchKernelGGL(bin_kernel<false>, dim3(bx_n * by_n * bz_n, B), dim3(256), 0, s, flow, count, list, g, bx_n, by_n);
+  hipLaunchKernelGGL(bin_kernel<false>, dim3(bx_n * by_n * bz_n, B), dim3(256), 0, s, flow, count, list, g, bx_n, by_n, (float*)nullptr,
+                     (const float*)nullptr);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)count, offsets, cursor, nt);
-  hipLaunchKernelGGL(bin_kernel<true>, dim3(bx_n * by_n * bz_n, B), dim3(256), 0, s, flow, cursor, list, g, bx_n, by_n);
+  hipLaunchKernelGGL(bin_kernel<true>, dim3(bx_n * by_n * bz_n, B), dim3(256), 0, s, flow, cursor, list, g, bx_n, by_n, d_flow, d_flow_add);
   hipLaunchKernelGGL(tile_absmax_kernel, dim3(1024), dim3(256), 0, s, d_out, (int64_t)B * D * H * W * C, amax);
-  hipLaunchKernelGGL(accumulate_kernel, dim3(nt), dim3(256), 0, s, flow, d_out, (const unsigned*)offsets, (const unsigned*)count,
-                     (const int*)list, d_src, border, g, (const unsigned*)amax);
+  if (d_flow)
+    hipLaunchKernelGGL(accumulate_kernel<true>, dim3(nt), dim3(256), 0, s, flow, d_out, (const unsigned*)offsets, (const unsigned*)count,
+                       (const int*)list, d_src, border, g, (const unsigned*)amax, src, d_flow, d_flow_add);
+  else
+    hipLaunchKernelGGL(accumulate_kernel<false>, dim3(nt), dim3(256), 0, s, flow, d_out, (const unsigned*)offsets, (const unsigned*)count,
+                       (const int*)list, d_src, border, g, (const unsigned*)amax, (const float*)nullptr, (float*)nullptr,
+                       (const float*)nullptr);
   hipLaunchKernelGGL(border_kernel, dim3(nt), dim3(256), 0, s, d_src, (const float*)border, g);
   return modet_launch_status();
+}
+
+int modet_warp_bwd_dsrc_tiles(const float* flow, const float* d_out, float* d_src, void* ws, size_t ws_bytes, int B, int D, int H,
+                              int W, int C, modet_stream_t stream) {
+  return tiles_launch(nullptr, flow, d_out, d_src, nullptr, nullptr, ws, ws_bytes, B, D, H, W, C, stream);
+}
+
+int modet_warp_bwd_tiles(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow, const float* d_flow_add,
+                         void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, modet_stream_t stream) {
+  MODET_CHECK_PTR(src); MODET_CHECK_PTR(d_flow);
+  return tiles_launch(src, flow, d_out, d_src, d_flow, d_flow_add, ws, ws_bytes, B, D, H, W, C, stream);
 }
 
 }  // extern "C"

@@ -1420,6 +1420,10 @@ def _warp_backward(src, flow, dout, dsrc, dflow, galias, add_flow, flow_bound):
         nb = L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C)
         if nb:
             ws = _ws(nb, src)
+            if dflow is not None and C == 8 and not s16:          # d_src and d_flow from one pass over the tile lists
+                _lib.check(L.modet_warp_bwd_tiles(_p(src), _p(flow), _p(dout), _p(dsrc), _p(dflow), _p(galias), _p(ws), nb, B, D, H, W, C,
+                                                  _stream()), "modet_warp_bwd_tiles")
+                return
             _lib.check(L.modet_warp_bwd_dsrc_tiles(_p(flow), _p(dout), _p(dsrc), _p(ws), nb, B, D, H, W, C, _stream()),
                        "modet_warp_bwd_dsrc_tiles")
             if dflow is not None:
