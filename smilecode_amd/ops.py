@@ -1396,7 +1396,8 @@ DETERMINISTIC = os.environ.get("MODET_DETERMINISTIC", "0") == "1"
 
 
 def set_deterministic(on=True):
-    """run-to-run bit-identical gradients (costs ~0.2 ms per 160x192x160 train step); returns the previous setting"""
+    """run-to-run bit-identical gradients (costs ~0.3 ms per 160x192x160 train step: profiles/r05z_deterministic_fullsize.txt);
+    returns the previous setting"""
     global DETERMINISTIC
     prev, DETERMINISTIC = DETERMINISTIC, bool(on)
     return prev
@@ -1408,6 +1409,7 @@ def set_deterministic(on=True):
 # through it.  Volumes below WARP_TILE_MIN_VOXELS keep the atomics either way (fixed costs of the binning passes).
 WARP_TILE_DSRC = False
 WARP_TILE_MIN_VOXELS = 1_500_000
+WARP_TILE_MIN_VOXELS_DET = 300_000          # deterministic mode: against 64-bit global atomics the tiles win from level 2 up
 
 
 def _warp_backward(src, flow, dout, dsrc, dflow, galias, add_flow, flow_bound):
@@ -1415,8 +1417,10 @@ def _warp_backward(src, flow, dout, dsrc, dflow, galias, add_flow, flow_bound):
     B, D, H, W, C = src.shape
     L = _L()
     s16 = int(src.dtype == torch.bfloat16)
-    if (WARP_TILE_DSRC and dsrc is not None and not flow_bound and not add_flow and not DETERMINISTIC and dout.dtype == torch.float32
-            and B * D * H * W >= WARP_TILE_MIN_VOXELS):
+    # (in deterministic mode the tile form IS the deterministic kernel for the large feature warps: integer sums in LDS instead of
+    # 64-bit fixed-point atomics on global memory)
+    if ((WARP_TILE_DSRC or DETERMINISTIC) and dsrc is not None and not flow_bound and not add_flow and dout.dtype == torch.float32
+            and B * D * H * W >= (WARP_TILE_MIN_VOXELS if WARP_TILE_DSRC else WARP_TILE_MIN_VOXELS_DET)):
         nb = L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C)
         if nb:
             ws = _ws(nb, src)
