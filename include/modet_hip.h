@@ -418,21 +418,23 @@ size_t modet_warp_bwd_det_ws_bytes(int B, int D, int H, int W, int C);
 int modet_warp_bwd_det(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow,
                        const float* d_flow_add, void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, int add_flow,
                        modet_stream_t stream);
-/* d_src of the trilinear warp's backward WITHOUT global float atomics (round 5, csrc/warp_tile.hip): source voxels binned by the
- * 8^3 destination tile of their base corner, one workgroup per tile accumulates its list in a 64-bit fixed-point LDS window (scale
- * from max |d_out|, 2^-30 of it per contribution), a gather adds the tile borders.  Equal to modet_warp_bwd's d_src within fp32
- * rounding of the sums (the float-atomic order is what differs there run to run; this one is bit-reproducible), every launch a
- * kernel with fixed arguments (capturable).  d_src need NOT be zeroed.  C a multiple of 8, dimensions <= 1024; _ws_bytes returns
- * 0 for anything else.  d_flow: call modet_warp_bwd / _acc with d_src = NULL.  The Python layer routes to it only when
- * ops.WARP_TILE_DSRC is set (off by default: op-level parity only so far). */
+/* The trilinear warp's backward WITHOUT global float atomics (csrc/warp_tile.hip; round 5 prototype, round 6 the DEFAULT path of
+ * the feature warps): COUNT source voxels per 8^3 destination tile of their base corner -> scan -> FILL per-tile lists of payload
+ * entries (voxel, flow, d_out; voxels whose d_out is all zero or whose corners all leave the volume are dropped; d_flow of every
+ * voxel is produced here, the src corners gathered) -> ACCUMULATE one workgroup per (tile, 8 channels) into a 64-bit fixed-point
+ * LDS window (2^-40 of the power of two above max |d_out| per unit, as modet_warp_bwd_det) -> BORDER gather of the tile faces.  Equal to modet_warp_bwd
+ * within fp32 rounding of the sums (the float-atomic ORDER is what differs there run to run; this one is bit-reproducible: integer
+ * sums), every launch a kernel with fixed arguments (capturable).  d_src need NOT be zeroed; the workspace needs no preparation.
+ * A non-finite d_out poisons d_src with NaN (as the float path would).  C a multiple of 8, or C == 3 (fp32 src; the flow
+ * compositions warp(src, flow) + flow with add_flow != 0: d_flow += d_out); dimensions <= 1024, B*D*H*W < 2^31; _ws_bytes returns
+ * 0 for anything else (then: modet_warp_bwd_acc / modet_warp_bwd_det).
+ * modet_warp_bwd_dsrc_tiles: d_src only.  modet_warp_bwd_tiles: d_src and d_flow (+ d_flow_add, NULL = none: a second gradient
+ * of the flow, as modet_warp_bwd_acc); src fp32 or (src_bf16 != 0) bf16.  Same workspace. */
 size_t modet_warp_bwd_dsrc_tiles_ws_bytes(int B, int D, int H, int W, int C);
 int modet_warp_bwd_dsrc_tiles(const float* flow, const float* d_out, float* d_src, void* ws, size_t ws_bytes,
                               int B, int D, int H, int W, int C, modet_stream_t stream);
-/* The same with d_flow (+ d_flow_add, NULL = none: a second gradient of the flow, as modet_warp_bwd_acc) from the SAME pass: the
- * corners of an entry are cells of its tile's window, so the tile's src cells are staged in LDS once and d_flow needs no gather.
- * C == 8 (the level-1 feature warp), fp32 src; same workspace. */
-int modet_warp_bwd_tiles(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow,
-                         const float* d_flow_add, void* ws, size_t ws_bytes, int B, int D, int H, int W, int C,
+int modet_warp_bwd_tiles(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow,
+                         const float* d_flow_add, void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, int add_flow,
                          modet_stream_t stream);
 /* d_src and/or d_flow; either may be NULL.  Trilinear only.
  * flow_bound = 0: arbitrary flow, d_src is zeroed here and scatter-added with float atomics (as ATen does).

@@ -101,7 +101,7 @@ SIGNATURES = {
     "modet_warp_bwd_det": (I, [P, I, P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
     "modet_warp_bwd_dsrc_tiles_ws_bytes": (SZ, [I, I, I, I, I]),
     "modet_warp_bwd_dsrc_tiles": (I, [P, P, P, P, SZ, I, I, I, I, I, P]),
-    "modet_warp_bwd_tiles": (I, [P, P, P, P, P, P, P, SZ, I, I, I, I, I, P]),
+    "modet_warp_bwd_tiles": (I, [P, I, P, P, P, P, P, P, SZ, I, I, I, I, I, I, P]),
     "modet_warp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "modet_upsample2_fwd": (I, [P, P, I, I, I, I, I, F, P]),
     "modet_upsample2_bwd": (I, [P, P, I, I, I, I, I, F, P]),

@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int modet_hip_version(void) { return 434;
+int modet_hip_version(void) { return 440;
   /* 0.4.0: + modet_conv3d_kernel_family_v, conv kernel family 4 (conv_wgrad_tr_kernel); no environment reads in product builds
      0.4.1: + typed (fp32 | bf16) entry points modet_na_{fwd,bwd}_t, modet_proj_ln_*_t, modet_warp_*_t, modet_warp_fwd_o16,
               modet_avgpool2_fwd_x16, modet_instnorm_*_pool_bf16; modet_ncc_*_box (any window); conv kernel family 5 (conv_q_kernel)
@@ -19,7 +19,10 @@ int modet_hip_version(void) { return 434;
               in the workspace: every leaf reduction of a backward pass in one launch
      0.4.3.3: + modet_proj_ln_fwd_pair; the grouped paired-projection kernels (levels 3-5) run both uses in one launch (grid.y = 2)
      0.4.3.4: + modet_warp_bwd_dsrc_tiles[_ws_bytes]: the warp backward's d_src without global float atomics (destination tiles,
-              64-bit fixed-point LDS window); not routed to by default */ }
+              64-bit fixed-point LDS window); not routed to by default
+     0.4.4.0: the destination-tile warp backward rebuilt (payload lists, zero-d_out entries dropped while binning, d_flow in the fill
+              pass, 2^-38 fixed point, NaN propagation, hash table that cannot overflow) and made the default of the feature warps;
+              modet_warp_bwd_tiles takes (src, src_bf16) and any C % 8 == 0 */ }
 
 const char* modet_hip_strerror(int code) {
   switch (code) {

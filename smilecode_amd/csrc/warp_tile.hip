@@ -1,30 +1,43 @@
-// d_src of the trilinear warp's backward WITHOUT global float atomics (SpatialTransformer backward, reference
-// ModeT/models.py:55-67 -> ATen grid_sampler_3d_backward scatters with atomicAdd): round 5's prototype
-// (tools/micro/warp_tile_proto.hip, profiles/r05y_*, r05z_*) as an entry point.  OFF by default in the Python layer
-// (ops.WARP_TILE_DSRC): it has its op-level parity tests, not yet a full-suite pass with the step routed through it.
-//   Why it exists: the shipped scatter is bound by the L2 float-atomic unit (18 G sector-atomics/s on the model's flow), and the
-//   LDS privatisations of rounds 1 / 4 lost because ds_add_f32 retires 0.33 lanes/clk/CU -- the INTEGER LDS atomics run 20-37 x
-//   faster (ds_add_u64 6.9-12.3 lanes/clk/CU, profiles/r05y_lds_atomic_microbench.txt).
-//   A  bin the source voxels by the 8^3 DESTINATION tile of their base corner: per source workgroup an LDS hash histogram
-//      (integer LDS atomics), one returning global atomic per (workgroup, tile); twice: count -> exclusive scan -> fill
-//   B  one workgroup per destination tile: its list -> a 9^3 x 8-channel window of 64-bit FIXED-POINT sums in LDS (scale from
-//      max |d_out|: 2^-30 of it per contribution, finer than fp32), laid out [channel][cell] (as [cell][channel] a wave's lanes
-//      pile onto two banks: 0.33 instead of 0.09 ms of atomics at level 1); the 8^3 owned cells leave as plain stores (no zero
-//      fill of d_src), the 217 high-face cells go to a side buffer; C > 8 in channel passes through the same window
-//   C  every owned cell on a low tile face adds the neighbours' side-buffer cells (gather)
-// Integer sums: the result does not depend on the order of the lists -> bit-reproducible.  Every launch is a kernel with fixed
-// arguments (no memset node, no host read of max |d_out|): capturable into a hipGraph.
+// The trilinear warp's backward WITHOUT global float atomics (SpatialTransformer backward, reference ModeT/models.py:55-67 ->
+// ATen grid_sampler_3d_backward scatters d_src with atomicAdd).  Round 5 built the destination-tile form as a prototype that broke
+// even in the step; round 6 rebuilt it around what the profile of that prototype said (every phase was waiting on a dependent
+// gather or on a half-empty workgroup, none on HBM or on the LDS atomics) and made it the default path of every feature warp.
+//   Why tiles at all: the float-atomic scatter is bound by the L2 atomic unit (18 G sector-atomics/s on the model's flow, 3.3 x
+//   write amplification) and ds_add_f32 retires 0.33 lanes/clk/CU -- the INTEGER LDS atomics run 20-37 x faster (ds_add_u64
+//   6.9-12.3 lanes/clk/CU, profiles/r05y_lds_atomic_microbench.txt).
+//   A  COUNT: source voxels binned by the 8^3 DESTINATION tile of their base corner; per source workgroup (4 x 8 x 32 voxels) an
+//      LDS hash histogram, one global atomic per (workgroup, tile).  Reads the flow only.  -> exclusive scan (upper bounds).
+//   B  FILL: the same walk, now reading d_out as well: a voxel whose d_out is all zero (the step's d_out is, on the background:
+//      ~60 % of the voxels) or whose corners all leave the volume is DROPPED; the others get their d_flow here (the eight src
+//      corners gathered through L2: this pass is a stream with 24 waves per CU, the place where a gather's latency hides) and a
+//      PAYLOAD entry -- (voxel, flow, d_out) -- in their tile's list segment, so pass C never chases an index.  max |d_out| of
+//      the kept entries falls out of the same read (one atomicMax per workgroup over 64 slots).
+//   C  ACCUMULATE: one 512-lane workgroup per (tile, group of 8 channels): the tile's payload, read as a contiguous stream, goes
+//      into a 9^3 x 8 window of 64-bit FIXED-POINT sums in LDS (2^-40 of the power of two above max |d_out| per unit: finer
+//      than the fp32 product it converts), laid out [channel][cell] so that a wave's lanes (different entries, same channel)
+//      spread over the banks.  46 KB: three workgroups per CU.  The 8^3 owned cells leave as plain stores (d_src needs no zero
+//      fill), the 217 high-face cells go to a side buffer.  A tile without entries stores zeros and touches nothing else.
+//   D  BORDER: every owned cell on a low tile face adds the high-face cells of the (non-empty) neighbours.
+// Integer sums: the result does not depend on the order of the lists -> bit-reproducible run to run.  Every launch is a kernel
+// with fixed arguments (no memset node, no host read): capturable into a hipGraph.  Non-finite d_out: max |d_out| is taken on
+// bit patterns (NaN orders above inf), and a non-finite maximum poisons d_src with NaN instead of converting garbage.
 #include "common.h"
 
 namespace {
 constexpr int TL = 8, WN = 9, CELLS = WN * WN * WN, NBORDER = CELLS - TL * TL * TL;      // 729 window cells, 217 on the high faces
-constexpr int SZ = 4, SY = 8, SX = 32, SVOX = SZ * SY * SX;                             // source block of pass A: 1024 voxels
-constexpr int HASH = 256;
+constexpr int SY = 8, SX = 32;                                // source block of passes A / B: SZ x 8 x 32 voxels, SZ per thread; SZ = 4, or
+                                                              // 1 for the small volumes (levels 2-5: 4 x more workgroups -- their passes are latency-, not bandwidth-bound)
+// a source block holds SZ x 256 voxels, so at most that many distinct tiles: with twice the slots (HASH = 512 SZ) linear probing
+// always ends on a free slot or on the key (round 5's 256 slots for 1024 voxels overflowed silently on flows rougher than ~12
+// voxels: ADVICE r5)
+constexpr int ACC = 512;                                      // lanes of an accumulate workgroup
+constexpr int FXBITS = 40;
 struct Geo { int D, H, W, C, tz, ty, tx, ntiles, B; };      // ntiles = tiles per sample
 
 struct Entry { int tile, bz, by, bx; float fz, fy, fx; };
-__device__ __forceinline__ bool make_entry(const float* __restrict__ flow, int64_t p, int z, int y, int x, const Geo g, Entry& e) {
-  const float pz = (float)z + flow[p * 3], py = (float)y + flow[p * 3 + 1], px = (float)x + flow[p * 3 + 2];
+// the ONE place that decides a voxel's base cell and tile: passes A, B and C must agree bit for bit
+__device__ __forceinline__ bool make_entry(float f0, float f1, float f2, int z, int y, int x, const Geo& g, Entry& e) {
+  const float pz = (float)z + f0, py = (float)y + f1, px = (float)x + f2;
   const float flz = floorf(pz), fly = floorf(py), flx = floorf(px);
   if (!(flz >= -1.f && flz <= (float)(g.D - 1) && fly >= -1.f && fly <= (float)(g.H - 1) && flx >= -1.f && flx <= (float)(g.W - 1)))
     return false;                                   // every corner outside the volume (or a non-finite flow)
@@ -35,61 +48,59 @@ __device__ __forceinline__ bool make_entry(const float* __restrict__ flow, int64
   return true;
 }
 
-// ---- A: FILL = false: tile_count[tile] += entries;  FILL = true: cursor[tile] (initialised to the tile's list offset) hands out
-// a segment per (workgroup, tile) and the voxel indices are written there
-template <bool FILL>
-__global__ __launch_bounds__(256) void bin_kernel(const float* __restrict__ flow, unsigned* __restrict__ counter, int* __restrict__ list,
-                                                  const Geo g, int bx_n, int by_n, float* __restrict__ dflow = nullptr,
-                                                  const float* __restrict__ dflow_add = nullptr) {
+template <int HASH>
+__device__ __forceinline__ int hash_insert(int* keys, unsigned* cnt, int tile, unsigned& rank) {
+  int s = (int)(((unsigned)tile * 40503u) & (unsigned)(HASH - 1));
+  for (;;) {                                        // (terminates: at most HASH / 2 keys)
+    const int k0 = atomicCAS(&keys[s], -1, tile);
+    if (k0 == -1 || k0 == tile) break;
+    s = (s + 1) & (HASH - 1);
+  }
+  rank = atomicAdd(&cnt[s], 1u);
+  return s;
+}
+
+template <int SZ>
+__device__ __forceinline__ void block_origin(int blk, int bx_n, int by_n, int& x0, int& y0, int& z0) {
+  x0 = (blk % bx_n) * SX; blk /= bx_n;
+  y0 = (blk % by_n) * SY;
+  z0 = (blk / by_n) * SZ;
+}
+
+// ---- A: tile_count[tile] += voxels whose base corner lies in the tile (an upper bound of what pass B keeps)
+template <int SZ>
+__global__ __launch_bounds__(256) void count_kernel(const float* __restrict__ flow, unsigned* __restrict__ counter, const Geo g,
+                                                    int bx_n, int by_n) {
+  constexpr int HASH = 512 * SZ;
   __shared__ int keys[HASH];
-  __shared__ unsigned cnt[HASH], off[HASH];
+  __shared__ unsigned cnt[HASH];
   const int tid = threadIdx.x;
-  keys[tid] = -1; cnt[tid] = 0;
+  for (int i = tid; i < HASH; i += 256) { keys[i] = -1; cnt[i] = 0; }
   __syncthreads();
-  int t = blockIdx.x;
-  const int x0 = (t % bx_n) * SX; t /= bx_n;
-  const int y0 = (t % by_n) * SY;
-  const int z0 = (t / by_n) * SZ;
+  int x0, y0, z0;
+  block_origin<SZ>(blockIdx.x, bx_n, by_n, x0, y0, z0);
   const int x = x0 + (tid & 31), y = y0 + (tid >> 5);
   const int b = blockIdx.y;                                   // sample: its tiles are [b * ntiles, (b + 1) * ntiles)
   flow += (int64_t)b * g.D * g.H * g.W * 3;
-  int slot[SZ];
-  unsigned rank[SZ];
+  float f[SZ][3];
+  bool in[SZ];
 #pragma unroll
   for (int k = 0; k < SZ; ++k) {
     const int z = z0 + k;
-    slot[k] = -1; rank[k] = 0;
-    if (x >= g.W || y >= g.H || z >= g.D) continue;
-    const int64_t p = ((int64_t)z * g.H + y) * g.W + x;
-    Entry e;
-    if (!make_entry(flow, p, z, y, x, g, e)) {
-      // no corner inside the volume: no entry; the fused form's d_flow of this voxel is just the second gradient (or 0)
-      if (FILL && dflow) {
-        const int64_t o = ((int64_t)b * g.D * g.H * g.W + p) * 3;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) dflow[o + a] = dflow_add ? dflow_add[o + a] : 0.f;
-      }
-      continue;
-    }
-    e.tile += b * g.ntiles;
-    int s = (e.tile * 40503) & (HASH - 1);
-    for (int probe = 0; probe < HASH; ++probe) {
-      const int k0 = atomicCAS(&keys[s], -1, e.tile);
-      if (k0 == -1 || k0 == e.tile) break;
-      s = (s + 1) & (HASH - 1);
-    }
-    slot[k] = s;
-    rank[k] = atomicAdd(&cnt[s], 1u);
+    in[k] = x < g.W && y < g.H && z < g.D;
+    const int64_t p = in[k] ? ((int64_t)z * g.H + y) * g.W + x : 0;
+    f[k][0] = flow[p * 3]; f[k][1] = flow[p * 3 + 1]; f[k][2] = flow[p * 3 + 2];
   }
-  __syncthreads();
-  if (keys[tid] >= 0) off[tid] = atomicAdd(&counter[keys[tid]], cnt[tid]);
-  if (!FILL) return;
-  __syncthreads();
 #pragma unroll
   for (int k = 0; k < SZ; ++k) {
-    if (slot[k] < 0) continue;
-    list[off[slot[k]] + rank[k]] = ((z0 + k) << 20) | (y << 10) | x;          // (dimensions <= 1024)
+    Entry e;
+    if (!in[k] || !make_entry(f[k][0], f[k][1], f[k][2], z0 + k, y, x, g, e)) continue;
+    unsigned rank;
+    hash_insert<HASH>(keys, cnt, e.tile + b * g.ntiles, rank);
   }
+  __syncthreads();
+  for (int i = tid; i < HASH; i += 256)
+    if (keys[i] >= 0) atomicAdd(&counter[keys[i]], cnt[i]);
 }
 
 // exclusive scan of the tile counts (one workgroup): offsets[t], cursor[t] = offsets[t]
@@ -112,28 +123,269 @@ __global__ __launch_bounds__(1024) void scan_kernel(const unsigned* __restrict__
     if (b + i < n) { offsets[b + i] = run; cursor[b + i] = run; run += count[b + i]; }
 }
 
-// amax[0] = bits of max |x| (non-negative floats order like their bit patterns); amax[0] must be zero on entry
-__global__ __launch_bounds__(256) void tile_absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ amax) {
-  float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i * 4 < n; i += (int64_t)gridDim.x * 256) {
-    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-  }
-  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  __shared__ float wm[4];
-  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {                                     // ONE atomic per workgroup (8 192 same-address atomics cost 0.1 ms)
-    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    if (m > 0.f) atomicMax(amax, __float_as_uint(m));
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// eight channels of src (fp32, or bf16 widened) at element offset `e`
+template <bool S16>
+__device__ __forceinline__ void load8(const void* __restrict__ src, int64_t e, float (&s)[8]) {
+  if constexpr (S16) {
+    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + e);
+    s[0] = bf16_lo(u.x); s[1] = bf16_hi(u.x); s[2] = bf16_lo(u.y); s[3] = bf16_hi(u.y);
+    s[4] = bf16_lo(u.z); s[5] = bf16_hi(u.z); s[6] = bf16_lo(u.w); s[7] = bf16_hi(u.w);
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + e);
+    const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + e + 4);
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = c.x; s[5] = c.y; s[6] = c.z; s[7] = c.w;
   }
 }
-// scale = 2^(30 - e) with max |d_out| = m 2^e, m in [0.5, 1): |d_out| * scale < 2^30 (an int32 per contribution, int64 sums)
-__device__ __forceinline__ void fx_scales(const unsigned* amax, float& scale, float& inv) {
-  const float a = __uint_as_float(amax[0]);
+
+// ---- B: cursor[tile] (initialised to the tile's list offset) hands out a segment per (workgroup, tile); kept voxels write their
+// payload entry [voxel id, flow x 3, d_out x C] there; d_flow of EVERY voxel of the block is written here (dropped: d_flow_add or 0)
+template <bool S16, int SZ>
+__global__ __launch_bounds__(256) void fill_kernel(const void* __restrict__ src, const float* __restrict__ flow,
+                                                   const float* __restrict__ dout, unsigned* __restrict__ cursor,
+                                                   unsigned* __restrict__ amax, float* __restrict__ list, float* __restrict__ dflow,
+                                                   const float* __restrict__ dflow_add, const Geo g, int bx_n, int by_n, int dbg_arg) {
+#ifdef MODET_TUNING
+  const int dbg = dbg_arg;
+#else
+  constexpr int dbg = 0; (void)dbg_arg;
+#endif
+  constexpr int HASH = 512 * SZ;
+  __shared__ int keys[HASH];
+  __shared__ unsigned cnt[HASH], off[HASH];
+  __shared__ unsigned wmax[4];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < HASH; i += 256) { keys[i] = -1; cnt[i] = 0; }
+  __syncthreads();
+  int x0, y0, z0;
+  block_origin<SZ>(blockIdx.x, bx_n, by_n, x0, y0, z0);
+  const int x = x0 + (tid & 31), y = y0 + (tid >> 5);
+  const int b = blockIdx.y;
+  const int64_t V = (int64_t)g.D * g.H * g.W;
+  const int C = g.C;
+  flow += b * V * 3;
+  dout += b * V * C;
+  if (dflow) dflow += b * V * 3;
+  if (dflow_add) dflow_add += b * V * 3;
+  const int64_t sbase = b * V * C;                            // element offset of the sample inside src
+  const int64_t sX = C, sY = (int64_t)g.W * C, sZ = (int64_t)g.H * g.W * C;
+  int slot[SZ];
+  unsigned rank[SZ];
+  float f[SZ][3];
+  unsigned mbits = 0;
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) {
+    const int z = z0 + k;
+    const bool in = x < g.W && y < g.H && z < g.D;
+    const int64_t p = in ? ((int64_t)z * g.H + y) * g.W + x : 0;
+    f[k][0] = flow[p * 3]; f[k][1] = flow[p * 3 + 1]; f[k][2] = flow[p * 3 + 2];
+    slot[k] = in ? -1 : -2;
+  }
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) {
+    if (slot[k] == -2) continue;
+    const int z = z0 + k;
+    const int64_t p = ((int64_t)z * g.H + y) * g.W + x;
+    Entry e;
+    const bool has = make_entry(f[k][0], f[k][1], f[k][2], z, y, x, g, e);
+    float gz = 0.f, gy = 0.f, gx = 0.f;
+    unsigned vb = 0;                                          // max of the bit patterns of |d_out[p, :]| (0 <=> all zero)
+    const float* dp = dout + p * C;
+    if (has) {
+      for (int c0 = 0; c0 < C; c0 += 8) {
+        const float4 ga = *reinterpret_cast<const float4*>(dp + c0), gb = *reinterpret_cast<const float4*>(dp + c0 + 4);
+        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const unsigned u = __float_as_uint(fabsf(gv[c])); vb = u > vb ? u : vb; }
+      }
+    }
+    if (has && vb && dflow && !(dbg & 2)) {                   // the eight src corners, gathered (only where something arrives)
+      // corner validity (the base cell may be -1, the upper corner may be the dimension)
+      const bool okz[2] = {e.bz >= 0, e.bz + 1 < g.D}, oky[2] = {e.by >= 0, e.by + 1 < g.H}, okx[2] = {e.bx >= 0, e.bx + 1 < g.W};
+      const int64_t o000 = sbase + (((int64_t)e.bz * g.H + e.by) * g.W + e.bx) * C;
+      float dot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int c0 = 0; c0 < C; c0 += 8) {
+        const float4 ga = *reinterpret_cast<const float4*>(dp + c0), gb = *reinterpret_cast<const float4*>(dp + c0 + 4);
+        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool ok = okz[q >> 2] && oky[(q >> 1) & 1] && okx[q & 1];
+          const int64_t o = o000 + ((q >> 2) ? sZ : 0) + (((q >> 1) & 1) ? sY : 0) + ((q & 1) ? sX : 0) + c0;
+          float s[8];
+          load8<S16>(src, ok ? o : sbase, s);                 // (unconditional load of a valid address; masked below)
+          float d = 0.f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) d = fmaf(s[c], gv[c], d);
+          dot[q] += ok ? d : 0.f;
+        }
+      }
+      const float wz[2] = {1.f - e.fz, e.fz}, wy[2] = {1.f - e.fy, e.fy}, wx[2] = {1.f - e.fx, e.fx};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+        gz += (dz ? 1.f : -1.f) * wy[dy] * wx[dx] * dot[q];
+        gy += (dy ? 1.f : -1.f) * wz[dz] * wx[dx] * dot[q];
+        gx += (dx ? 1.f : -1.f) * wz[dz] * wy[dy] * dot[q];
+      }
+    }
+    if (dflow && !(dbg & 4)) {
+      if (dflow_add) { gz += dflow_add[p * 3]; gy += dflow_add[p * 3 + 1]; gx += dflow_add[p * 3 + 2]; }
+      dflow[p * 3] = gz; dflow[p * 3 + 1] = gy; dflow[p * 3 + 2] = gx;
+    }
+    if (!has || vb == 0) continue;                            // dropped: contributes nothing to d_src
+    mbits = vb > mbits ? vb : mbits;
+    slot[k] = hash_insert<HASH>(keys, cnt, e.tile + b * g.ntiles, rank[k]);
+  }
+  __syncthreads();
+  for (int i = tid; i < HASH; i += 256)
+    if (keys[i] >= 0) off[i] = atomicAdd(&cursor[keys[i]], cnt[i]);
+  for (int o = 32; o; o >>= 1) { const unsigned v = __shfl_xor(mbits, o, 64); mbits = v > mbits ? v : mbits; }
+  if ((tid & 63) == 0) wmax[tid >> 6] = mbits;
+  __syncthreads();
+  if (tid == 0) {                                             // one atomic per workgroup, spread over 64 addresses
+    unsigned m = wmax[0];
+    for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+    if (m) atomicMax(&amax[(blockIdx.x + blockIdx.y) & 63], m);
+  }
+  const int S = 4 + C;                                        // words per payload entry (a multiple of 4)
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) {
+    if (slot[k] < 0 || (dbg & 1)) continue;
+    const int z = z0 + k;
+    const int64_t p = ((int64_t)z * g.H + y) * g.W + x;
+    float* dst = list + (size_t)(off[slot[k]] + rank[k]) * S;
+    *reinterpret_cast<float4*>(dst) = make_float4(__int_as_float((z << 20) | (y << 10) | x), f[k][0], f[k][1], f[k][2]);   // (dimensions <= 1024)
+    const float* dp = dout + p * C;                           // (read a moment ago: L1 / L2)
+    for (int c0 = 0; c0 < C; c0 += 4) *reinterpret_cast<float4*>(dst + 4 + c0) = *reinterpret_cast<const float4*>(dp + c0);
+  }
+}
+
+// ---- B for C == 3 (the flow compositions whose flow is NOT bounded by one voxel: warp(up(2 flow), w) + w with w a CWM output,
+// reference models.py:392-403; the bounded ones gather, warp.hip): three scalars per voxel, payload entry = [header][d_out x 3, 0]
+// (S = 8 words); add_flow: out = warp(src, flow) + flow, so d_flow += d_out for EVERY voxel.
+template <int SZ>
+__global__ __launch_bounds__(256) void fill_c3_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                      const float* __restrict__ dout, unsigned* __restrict__ cursor,
+                                                      unsigned* __restrict__ amax, float* __restrict__ list, float* __restrict__ dflow,
+                                                      const float* __restrict__ dflow_add, const Geo g, int bx_n, int by_n, int add_flow) {
+  constexpr int HASH = 512 * SZ;
+  __shared__ int keys[HASH];
+  __shared__ unsigned cnt[HASH], off[HASH];
+  __shared__ unsigned wmax[4];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < HASH; i += 256) { keys[i] = -1; cnt[i] = 0; }
+  __syncthreads();
+  int x0, y0, z0;
+  block_origin<SZ>(blockIdx.x, bx_n, by_n, x0, y0, z0);
+  const int x = x0 + (tid & 31), y = y0 + (tid >> 5);
+  const int b = blockIdx.y;
+  const int64_t V = (int64_t)g.D * g.H * g.W;
+  flow += b * V * 3;
+  dout += b * V * 3;
+  src += b * V * 3;
+  if (dflow) dflow += b * V * 3;
+  if (dflow_add) dflow_add += b * V * 3;
+  const int64_t sX = 3, sY = (int64_t)g.W * 3, sZ = (int64_t)g.H * g.W * 3;
+  int slot[SZ];
+  unsigned rank[SZ];
+  float f[SZ][3], gv[SZ][3];
+  unsigned mbits = 0;
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) {
+    const int z = z0 + k;
+    const bool in = x < g.W && y < g.H && z < g.D;
+    const int64_t p = in ? ((int64_t)z * g.H + y) * g.W + x : 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { f[k][a] = flow[p * 3 + a]; gv[k][a] = dout[p * 3 + a]; }
+    slot[k] = in ? -1 : -2;
+  }
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) {
+    if (slot[k] == -2) continue;
+    const int z = z0 + k;
+    const int64_t p = ((int64_t)z * g.H + y) * g.W + x;
+    Entry e;
+    const bool has = make_entry(f[k][0], f[k][1], f[k][2], z, y, x, g, e);
+    float gz = 0.f, gy = 0.f, gx = 0.f;
+    unsigned vb = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const unsigned u = __float_as_uint(fabsf(gv[k][a])); vb = u > vb ? u : vb; }
+    if (has && vb && dflow) {
+      const bool okz[2] = {e.bz >= 0, e.bz + 1 < g.D}, oky[2] = {e.by >= 0, e.by + 1 < g.H}, okx[2] = {e.bx >= 0, e.bx + 1 < g.W};
+      const int64_t o000 = (((int64_t)e.bz * g.H + e.by) * g.W + e.bx) * 3;
+      const float wz[2] = {1.f - e.fz, e.fz}, wy[2] = {1.f - e.fy, e.fy}, wx[2] = {1.f - e.fx, e.fx};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+        const bool ok = okz[dz] && oky[dy] && okx[dx];
+        const int64_t o = ok ? o000 + (dz ? sZ : 0) + (dy ? sY : 0) + (dx ? sX : 0) : 0;
+        float d = fmaf(src[o + 2], gv[k][2], fmaf(src[o + 1], gv[k][1], src[o] * gv[k][0]));
+        d = ok ? d : 0.f;
+        gz += (dz ? 1.f : -1.f) * wy[dy] * wx[dx] * d;
+        gy += (dy ? 1.f : -1.f) * wz[dz] * wx[dx] * d;
+        gx += (dx ? 1.f : -1.f) * wz[dz] * wy[dy] * d;
+      }
+    }
+    if (dflow) {
+      if (add_flow) { gz += gv[k][0]; gy += gv[k][1]; gx += gv[k][2]; }
+      if (dflow_add) { gz += dflow_add[p * 3]; gy += dflow_add[p * 3 + 1]; gx += dflow_add[p * 3 + 2]; }
+      dflow[p * 3] = gz; dflow[p * 3 + 1] = gy; dflow[p * 3 + 2] = gx;
+    }
+    if (!has || vb == 0) continue;
+    mbits = vb > mbits ? vb : mbits;
+    slot[k] = hash_insert<HASH>(keys, cnt, e.tile + b * g.ntiles, rank[k]);
+  }
+  __syncthreads();
+  for (int i = tid; i < HASH; i += 256)
+    if (keys[i] >= 0) off[i] = atomicAdd(&cursor[keys[i]], cnt[i]);
+  for (int o = 32; o; o >>= 1) { const unsigned v = __shfl_xor(mbits, o, 64); mbits = v > mbits ? v : mbits; }
+  if ((tid & 63) == 0) wmax[tid >> 6] = mbits;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned m = wmax[0];
+    for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+    if (m) atomicMax(&amax[(blockIdx.x + blockIdx.y) & 63], m);
+  }
+#pragma unroll
+  for (int k = 0; k < SZ; ++k) {
+    if (slot[k] < 0) continue;
+    const int z = z0 + k;
+    float* dst = list + (size_t)(off[slot[k]] + rank[k]) * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(__int_as_float((z << 20) | (y << 10) | x), f[k][0], f[k][1], f[k][2]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(gv[k][0], gv[k][1], gv[k][2], 0.f);
+  }
+}
+
+// The fixed point: unit u = 2^(E - FXBITS), E = the exponent of max |d_out| (max = m 2^E, m in [0.5, 1)); int64 sums hold 2^23
+// terms of the largest size.  A contribution v w is converted through the 32-bit converter with a scale PER ENTRY (the 64-bit
+// converter is a ~10-instruction sequence, and there are 64 conversions per entry: it made pass C VALU-bound):
+//   e = the exponent of the entry's own max |d_out[c]|, D = E - e >= 0
+//   D <= SHMAX - 1: x = rint(v w 2^(29 - e)) (|x| <= 2^29: 29 bits below the ENTRY's maximum, finer than fp32's 24), shifted left
+//                   by sh = SHMAX - D >= 1 as two 32-bit shifts (lo = x << sh, hi = x >> (32 - sh), arithmetic)
+//   D >= SHMAX:     the entry is small against the tensor: x = rint(v w 2^(FXBITS - 1 - E)) (< 2^28), sh = 1 -- 2^-39 of the
+//                   tensor's maximum per unit, where round 5's single scale stopped at 2^-30
+constexpr int SHMAX = FXBITS - 29;
+__device__ __forceinline__ bool fx_global(const unsigned* __restrict__ amax, int& E, float& inv) {
+  unsigned m = amax[threadIdx.x & 63];
+  for (int o = 32; o; o >>= 1) { const unsigned v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
+  const bool finite = m < 0x7f800000u;
+  E = 0;
+  (void)frexpf(m && finite ? __uint_as_float(m) : 1.f, &E);
+  inv = ldexpf(1.f, E - FXBITS);
+  return finite;
+}
+__device__ __forceinline__ void fx_entry(unsigned vb /* bits of the entry's max |d_out[c]|, != 0 */, int E, float& fs, int& sh) {
   int e = 0;
-  (void)frexpf(a > 0.f && a < 3.0e38f ? a : 1.f, &e);
-  scale = ldexpf(1.f, 30 - e); inv = ldexpf(1.f, e - 30);
+  (void)frexpf(__uint_as_float(vb), &e);
+  const int D = E - e;
+  const bool big = D <= SHMAX - 1;
+  sh = big ? SHMAX - D : 1;
+  fs = ldexpf(1.f, big ? 29 - e : FXBITS - 1 - E);
+}
+__device__ __forceinline__ unsigned long long fx_make(float x, int sh) {
+  const int xi = __float2int_rn(x);
+  return ((unsigned long long)(unsigned)(xi >> (32 - sh)) << 32) | (unsigned)(xi << sh);
 }
 
 __device__ __forceinline__ int border_index(int lz, int ly, int lx) {      // cells with max(l) == 8
@@ -142,169 +394,177 @@ __device__ __forceinline__ int border_index(int lz, int ly, int lx) {      // ce
   return 153 + lz * 8 + ly;                          // 64 (lx == 8, lz, ly < 8)
 }
 
-// ---- B: the tile's list -> fixed-point window -> owned cells (plain stores) + high-face cells (side buffer).  ONE lane per
-// entry, all eight channels (two float4 of d_out; C == 8): the corner / weight arithmetic of an entry is done once; an entry
-// whose d_out is all zero (the step's d_out is: background) costs its loads only; U entries per lane in flight.
-__device__ __forceinline__ float fx_to_float(unsigned long long u, float inv_scale) {
-  const long long x = (long long)u;
-  const unsigned long long a = x < 0 ? (unsigned long long)(-x) : (unsigned long long)x;      // sign-magnitude: no cancellation
-  const float m = fmaf((float)(unsigned)(a >> 32), 4294967296.f, (float)(unsigned)a);
-  return (x < 0 ? -m : m) * inv_scale;
+// ---- C: the tile's payload -> fixed-point window -> owned cells (plain stores) + high-face cells (side buffer).  Work item =
+// (tile, group of eight channels).  ONE lane per entry and all eight channels: the corner / weight arithmetic of an entry is done
+// once.  PERSISTENT workgroups (three per CU: 46 KB of LDS each) walk the work items with the NEXT item's first 2 x ACC payload
+// entries already in flight (and the counts of the one after): as one workgroup per item the kernel spent 42 % of its wave
+// cycles parked on the payload's round trip and the LDS unit was busy 40 % of the time (profiles/r06*_pmc_accumulate.txt).
+// Measured and NOT done: counting-sorting a chunk by base cell so that a wave's lanes walk consecutive banks -- the conflict
+// cycles did not fall (same-address duplicates replace the bank conflicts) and the sort's five barriers cost 90 us.
+struct AccEntry { float4 hd, ga, gb; };
+template <int NCH>
+__device__ __forceinline__ void acc_load(const float* __restrict__ lp, unsigned i, unsigned n, int S, int c0, AccEntry& a) {
+  const float* ep = lp + (size_t)(i < n ? i : 0u) * S;       // (n > 0 here: entry 0 exists; lanes past the end are masked at use)
+  a.hd = *reinterpret_cast<const float4*>(ep);
+  a.ga = *reinterpret_cast<const float4*>(ep + 4 + c0);
+  if constexpr (NCH == 8) a.gb = *reinterpret_cast<const float4*>(ep + 8 + c0);
+  else a.gb = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-// FLOW (C == 8 only): d_flow as well, from the SAME window -- the eight corners of an entry are cells of its tile's window, so the
-// tile's src cells are staged in LDS once (coalesced, every src value read from HBM once) and d_flow[p] = sum over the corners of
-// (+-) the other two weights x <src[corner], d_out[p]> needs no gather from memory; + dflow_add[p] (a second gradient of the flow).
-template <bool FLOW>
-__global__ __launch_bounds__(256) void accumulate_kernel(const float* __restrict__ flow, const float* __restrict__ dout,
-                                                         const unsigned* __restrict__ offsets, const unsigned* __restrict__ count,
-                                                         const int* __restrict__ list, float* __restrict__ dsrc,
-                                                         float* __restrict__ border, const Geo g, const unsigned* __restrict__ amax,
-                                                         const float* __restrict__ src = nullptr, float* __restrict__ dflow = nullptr,
-                                                         const float* __restrict__ dflow_add = nullptr) {
-  __shared__ __attribute__((aligned(16))) unsigned long long win[CELLS * 8];
-  __shared__ float swin[FLOW ? CELLS * 8 : 1];
-  const int tid = threadIdx.x;
-  float scale, inv_scale;
-  fx_scales(amax, scale, inv_scale);
-  const int tile = blockIdx.x;                                // over all samples
-  const int b = tile / g.ntiles;
-  int t = tile - b * g.ntiles;
-  const int ox = (t % g.tx) * TL; t /= g.tx;
-  const int oy = (t % g.ty) * TL;
-  const int oz = (t / g.ty) * TL;
-  const unsigned n = count[tile], base = offsets[tile];
-  const int64_t V = (int64_t)g.D * g.H * g.W;
-  flow += (int64_t)b * V * 3;
-  dout += (int64_t)b * V * g.C;
-  dsrc += (int64_t)b * V * g.C;
-  const int C = g.C;
-  if constexpr (FLOW) {
-    src += (int64_t)b * V * 8; dflow += (int64_t)b * V * 3;
-    if (dflow_add) dflow_add += (int64_t)b * V * 3;
-    for (int cell = tid; cell < CELLS; cell += 256) {
-      const int lx = cell % WN, lr = cell / WN, ly = lr % WN, lz = lr / WN;
-      const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-      if (gz < g.D && gy < g.H && gx < g.W) {
-        const float* sp = src + (((int64_t)gz * g.H + gy) * g.W + gx) * 8;
-        a = *reinterpret_cast<const float4*>(sp); c = *reinterpret_cast<const float4*>(sp + 4);
-      }
-      swin[0 * CELLS + cell] = a.x; swin[1 * CELLS + cell] = a.y; swin[2 * CELLS + cell] = a.z; swin[3 * CELLS + cell] = a.w;
-      swin[4 * CELLS + cell] = c.x; swin[5 * CELLS + cell] = c.y; swin[6 * CELLS + cell] = c.z; swin[7 * CELLS + cell] = c.w;
+template <int NCH>
+__device__ __forceinline__ void acc_entry(const AccEntry& a, unsigned long long* win, const Geo& g, int oz, int oy, int ox, int E, bool finite) {
+  const float gvv[8] = {a.ga.x, a.ga.y, a.ga.z, a.ga.w, a.gb.x, a.gb.y, a.gb.z, a.gb.w};
+  unsigned vb = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { const unsigned u = __float_as_uint(fabsf(gvv[c])); vb = u > vb ? u : vb; }
+  if (!vb) return;                                            // (C > 8: this group of the entry is all zero)
+  float fs;
+  int sh;
+  fx_entry(finite ? vb : 0x3f800000u, E, fs, sh);
+  const int pk = __float_as_int(a.hd.x);
+  Entry e;
+  (void)make_entry(a.hd.y, a.hd.z, a.hd.w, pk >> 20, (pk >> 10) & 1023, pk & 1023, g, e);
+  float vs[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) vs[c] = gvv[c] * fs;
+  const int cell0 = ((e.bz - oz) * WN + (e.by - oy)) * WN + (e.bx - ox);
+  // every corner inside the volume (all but the entries at the volume's faces): no per-corner tests
+  const bool inner = e.bz >= 0 && e.bz + 1 < g.D && e.by >= 0 && e.by + 1 < g.H && e.bx >= 0 && e.bx + 1 < g.W;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+    if (!inner) {
+      const int gz = e.bz + dz, gy = e.by + dy, gx = e.bx + dx;
+      if (gz < 0 || gz >= g.D || gy < 0 || gy >= g.H || gx < 0 || gx >= g.W) continue;
     }
+    const float w = (dz ? e.fz : 1.f - e.fz) * (dy ? e.fy : 1.f - e.fy) * (dx ? e.fx : 1.f - e.fx);
+    unsigned long long* wp = win + (cell0 + (dz * WN + dy) * WN + dx);       // window = [channel][cell]
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) atomicAdd(wp + k * CELLS, fx_make(vs[k] * w, sh));
   }
-  // C channels in passes of eight: the window is 46 KB whatever C is (three workgroups per CU); the list and the flow are re-read
-  // per pass (L2), d_out once in total
-  for (int c0 = 0; c0 < C; c0 += 8) {
-  if (c0) __syncthreads();                                    // the previous pass's flush has read the window
-  {
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    u64x2* w2 = reinterpret_cast<u64x2*>(win);
-    for (int i = tid; i < CELLS * 4; i += 256) w2[i] = (u64x2){0ull, 0ull};
-  }
-  __syncthreads();
-  constexpr int U = 4;
-  for (unsigned i0 = tid; i0 < n; i0 += 256 * U) {
-    int pk[U];
-    float f0[U], f1[U], f2[U];
-    float4 ga[U], gb[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { const unsigned i = i0 + 256 * u; pk[u] = i < n ? list[base + i] : -1; }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int q = pk[u] < 0 ? 0 : pk[u];
-      const int64_t v = ((int64_t)(q >> 20) * g.H + ((q >> 10) & 1023)) * g.W + (q & 1023);
-      f0[u] = flow[v * 3]; f1[u] = flow[v * 3 + 1]; f2[u] = flow[v * 3 + 2];
-      ga[u] = *reinterpret_cast<const float4*>(dout + v * C + c0);
-      gb[u] = *reinterpret_cast<const float4*>(dout + v * C + c0 + 4);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (pk[u] < 0) continue;
-      const float gvv[8] = {ga[u].x, ga[u].y, ga[u].z, ga[u].w, gb[u].x, gb[u].y, gb[u].z, gb[u].w};
-      bool any = false;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) any = any || gvv[c] != 0.f;
-      const int64_t vox = ((int64_t)(pk[u] >> 20) * g.H + ((pk[u] >> 10) & 1023)) * g.W + (pk[u] & 1023);
-      if (!any) {
-        if constexpr (FLOW) {
-#pragma unroll
-          for (int a = 0; a < 3; ++a) dflow[vox * 3 + a] = dflow_add ? dflow_add[vox * 3 + a] : 0.f;
-        }
-        continue;
-      }
-      float gfz = 0.f, gfy = 0.f, gfx = 0.f;
-      const float pz = (float)(pk[u] >> 20) + f0[u], py = (float)((pk[u] >> 10) & 1023) + f1[u], px = (float)(pk[u] & 1023) + f2[u];
-      const float flz = floorf(pz), fly = floorf(py), flx = floorf(px);
-      const int bz = (int)flz, by = (int)fly, bx = (int)flx;
-      const float fz = pz - flz, fy = py - fly, fx = px - flx;
-      float vs[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) vs[c] = gvv[c] * scale;
-      const int cell0 = ((bz - oz) * WN + (by - oy)) * WN + (bx - ox);
-      // every corner inside the volume (all but the entries at the volume's faces): no per-corner tests
-      const bool inner = bz >= 0 && bz + 1 < g.D && by >= 0 && by + 1 < g.H && bx >= 0 && bx + 1 < g.W;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int dz = c >> 2, dy = (c >> 1) & 1, dx = c & 1;
-        if (!inner) {
-          const int gz = bz + dz, gy = by + dy, gx = bx + dx;
-          if (gz < 0 || gz >= g.D || gy < 0 || gy >= g.H || gx < 0 || gx >= g.W) continue;
-        }
-        const float w = (dz ? fz : 1.f - fz) * (dy ? fy : 1.f - fy) * (dx ? fx : 1.f - fx);
-        unsigned long long* wp = win + (cell0 + (dz * WN + dy) * WN + dx);       // window = [channel][cell]: a wave's lanes (different entries) spread over the banks
-#pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(wp + k * CELLS, (unsigned long long)(long long)__float2int_rn(vs[k] * w));
-        if constexpr (FLOW) {
-          const float* sp = swin + (cell0 + (dz * WN + dy) * WN + dx);
-          float dot = 0.f;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) dot = fmaf(sp[k * CELLS], gvv[k], dot);
-          const float wz = dz ? fz : 1.f - fz, wy = dy ? fy : 1.f - fy, wx = dx ? fx : 1.f - fx;
-          gfz += (dz ? 1.f : -1.f) * wy * wx * dot;
-          gfy += (dy ? 1.f : -1.f) * wz * wx * dot;
-          gfx += (dx ? 1.f : -1.f) * wz * wy * dot;
-        }
-      }
-      if constexpr (FLOW) {
-        if (dflow_add) { gfz += dflow_add[vox * 3]; gfy += dflow_add[vox * 3 + 1]; gfx += dflow_add[vox * 3 + 2]; }
-        dflow[vox * 3] = gfz; dflow[vox * 3 + 1] = gfy; dflow[vox * 3 + 2] = gfx;
-      }
-    }
-  }
-  __syncthreads();
-  // flush: one cell (8 channels = 32 bytes of output) per thread and trip
-  for (int cell = tid; cell < CELLS; cell += 256) {
-    const int lx = cell % WN, lr = cell / WN, ly = lr % WN, lz = lr / WN;
-    float o[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = fx_to_float(win[k * CELLS + cell], inv_scale);
-    float* dst;
-    if (lz < TL && ly < TL && lx < TL) {
-      const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
-      if (gz >= g.D || gy >= g.H || gx >= g.W) continue;
-      dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C + c0;
-    } else {
-      dst = border + ((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * C + c0;
-    }
-    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-  }
-  }       // channel pass
 }
 
-// ---- C: owned cells on a low face of their tile (169 of 512) += the high-face cells of the up to seven neighbours; every
-// side-buffer cell is read exactly once
-__global__ __launch_bounds__(256) void border_kernel(float* __restrict__ dsrc, const float* __restrict__ border, const Geo g) {
+constexpr int ACC_U = 2;                                      // payload entries per lane in flight for the next work item
+template <int NCH>      // channels of a work item: 8, or 3 (C == 3: payload entries of 8 words, d_src / side-buffer cells of 3 / 4 floats)
+__global__ __launch_bounds__(ACC) __attribute__((amdgpu_waves_per_eu(6, 6))) void accumulate_kernel(const float* __restrict__ list, const unsigned* __restrict__ offsets,
+                                                         const unsigned* __restrict__ cursor, const unsigned* __restrict__ amax,
+                                                         float* __restrict__ dsrc_all, float* __restrict__ border, const Geo g, int nt) {
+  __shared__ __attribute__((aligned(16))) unsigned long long win[CELLS * NCH + 1];
+  const int tid = threadIdx.x;
+  const int C = g.C, S = NCH == 8 ? 4 + C : 8, ngrp = NCH == 8 ? C / 8 : 1, BC = NCH == 8 ? C : 4;
+  const int nitems = nt * ngrp, G = gridDim.x;
+  int E;
+  float inv_scale;
+  bool finite = true;
+  bool have_scale = false;
+  // item -> (tile, channel group): groups of a tile are neighbours in the walk (the payload they share stays in L2)
+  int it = blockIdx.x;
+  if (it >= nitems) return;
+  unsigned base = offsets[it / ngrp], n = cursor[it / ngrp] - base;
+  unsigned base1 = 0, n1 = 0;
+  if (it + G < nitems) { base1 = offsets[(it + G) / ngrp]; n1 = cursor[(it + G) / ngrp] - base1; }
+  AccEntry cur[ACC_U], nxt[ACC_U];
+  if (n) {
+#pragma unroll
+    for (int u = 0; u < ACC_U; ++u) acc_load<NCH>(list + (size_t)base * S, tid + u * ACC, n, S, (it % ngrp) * 8, cur[u]);
+  }
+  for (; it < nitems; it += G) {
+    const int tile = it / ngrp, c0 = (it % ngrp) * 8;         // tile: over all samples
+    // ---- the next item's payload, and the counts of the one after
+    const int itn = it + G;
+    if (itn < nitems && n1) {
+#pragma unroll
+      for (int u = 0; u < ACC_U; ++u) acc_load<NCH>(list + (size_t)base1 * S, tid + u * ACC, n1, S, (itn % ngrp) * 8, nxt[u]);
+    }
+    unsigned base2 = 0, n2 = 0;
+    if (itn + G < nitems) { base2 = offsets[(itn + G) / ngrp]; n2 = cursor[(itn + G) / ngrp] - base2; }
+    // ---- this item
+    const int b = tile / g.ntiles;
+    int t = tile - b * g.ntiles;
+    const int ox = (t % g.tx) * TL; t /= g.tx;
+    const int oy = (t % g.ty) * TL;
+    const int oz = (t / g.ty) * TL;
+    float* dsrc = dsrc_all + (int64_t)b * g.D * g.H * g.W * C + c0;
+    if (n == 0) {                                             // nothing lands here: zeros, and no side-buffer cells (pass D tests the count)
+      const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
+      const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
+      if (gz < g.D && gy < g.H && gx < g.W) {
+        float* dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C;
+        if constexpr (NCH == 8) {
+          *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f;
+        }
+      }
+    } else {
+      if (!have_scale) { finite = fx_global(amax, E, inv_scale); have_scale = true; }
+      {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2* w2 = reinterpret_cast<u64x2*>(win);
+        for (int i = tid; i < (CELLS * NCH + 1) / 2; i += ACC) w2[i] = (u64x2){0ull, 0ull};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < ACC_U; ++u)
+        if ((unsigned)(tid + u * ACC) < n) acc_entry<NCH>(cur[u], win, g, oz, oy, ox, E, finite);
+      for (unsigned i = ACC_U * ACC + tid; i < n; i += ACC) { // (a folded tile: more than 2 x ACC entries)
+        AccEntry a;
+        acc_load<NCH>(list + (size_t)base * S, i, n, S, c0, a);
+        acc_entry<NCH>(a, win, g, oz, oy, ox, E, finite);
+      }
+      __syncthreads();
+      // flush: one cell (8 channels = 32 bytes of output) per thread and trip
+      const float poison = finite ? 0.f : __uint_as_float(0x7fc00000u);
+      for (int cell = tid; cell < CELLS; cell += ACC) {
+        const int lx = cell % WN, lr = cell / WN, ly = lr % WN, lz = lr / WN;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) o[k] = (float)(long long)win[k * CELLS + cell] * inv_scale + poison;
+        const bool owned = lz < TL && ly < TL && lx < TL;
+        float* dst;
+        if (owned) {
+          const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
+          if (gz >= g.D || gy >= g.H || gx >= g.W) continue;
+          dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C;
+        } else {
+          dst = border + ((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * BC + c0;
+        }
+        if (NCH == 8 || !owned) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; }
+        if constexpr (NCH == 8) *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+      __syncthreads();                                        // (the next item zeroes the window)
+    }
+    base = base1; n = n1; base1 = base2; n1 = n2;
+#pragma unroll
+    for (int u = 0; u < ACC_U; ++u) cur[u] = nxt[u];
+  }
+}
+
+// ---- D: owned cells on a low face of their tile (169 of 512) += the high-face cells of the up to seven neighbours that have
+// entries; every side-buffer cell is read exactly once, in a fixed order
+template <bool C3>
+__global__ __launch_bounds__(256) void border_kernel(float* __restrict__ dsrc, const float* __restrict__ border,
+                                                     const unsigned* __restrict__ offsets, const unsigned* __restrict__ cursor, const Geo g) {
   const int tile = blockIdx.x;
   const int b = tile / g.ntiles;
   int t = tile - b * g.ntiles;
   const int tx = t % g.tx; t /= g.tx;
   const int ty = t % g.ty, tz = t / g.ty;
-  const int C = g.C, q4 = C / 4;                              // a thread = four channels of one face cell
+  const int C = g.C, q4 = C3 ? 1 : 2, cb = blockIdx.y * 8, BC = C3 ? 4 : C;      // a thread = four channels of one face cell (C == 3: the cell); blockIdx.y = eight channels
+  // which of the seven lower neighbours exist and have entries (uniform over the workgroup)
+  unsigned live = 0;
+#pragma unroll
+  for (int m = 1; m < 8; ++m) {
+    const int dz = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
+    if ((dz && tz == 0) || (dy && ty == 0) || (dx && tx == 0)) continue;
+    const int nt = b * g.ntiles + ((tz - dz) * g.ty + (ty - dy)) * g.tx + (tx - dx);
+    if (cursor[nt] != offsets[nt]) live |= 1u << m;
+  }
+  if (!live) return;
   dsrc += (int64_t)b * g.D * g.H * g.W * C;
   for (int j = threadIdx.x; j < 169 * q4; j += 256) {
-    const int ch = (j % q4) * 4, k = j / q4;
+    const int ch = cb + (j % q4) * 4, k = j / q4;
     int lz, ly, lx;
     if (k < 64) { lz = 0; ly = k >> 3; lx = k & 7; }
     else if (k < 120) { const int r = k - 64; ly = 0; lz = 1 + r / 8; lx = r & 7; }
@@ -316,75 +576,106 @@ __global__ __launch_bounds__(256) void border_kernel(float* __restrict__ dsrc, c
 #pragma unroll
     for (int m = 1; m < 8; ++m) {
       const int dz = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
-      if ((dz && (lz || tz == 0)) || (dy && (ly || ty == 0)) || (dx && (lx || tx == 0))) continue;
+      if (!(live & (1u << m)) || (dz && lz) || (dy && ly) || (dx && lx)) continue;
       const int nt = b * g.ntiles + ((tz - dz) * g.ty + (ty - dy)) * g.tx + (tx - dx);
-      const float4 v = *reinterpret_cast<const float4*>(border + ((int64_t)nt * NBORDER + border_index(dz ? 8 : lz, dy ? 8 : ly, dx ? 8 : lx)) * C + ch);
+      const float4 v = *reinterpret_cast<const float4*>(border + ((int64_t)nt * NBORDER + border_index(dz ? 8 : lz, dy ? 8 : ly, dx ? 8 : lx)) * BC + ch);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       any = true;
     }
     if (!any) continue;
-    float4* dp = reinterpret_cast<float4*>(dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C + ch);
-    float4 d = *dp;
-    d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
-    *dp = d;
+    float* dq = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C + ch;
+    if constexpr (C3) {
+      dq[0] += s.x; dq[1] += s.y; dq[2] += s.z;
+    } else {
+      float4* dp = reinterpret_cast<float4*>(dq);
+      float4 d = *dp;
+      d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+      *dp = d;
+    }
   }
+}
+
+struct Ws { unsigned *amax, *count, *offsets, *cursor; float *list, *border; size_t bytes; };
+// [amax 64][count nt][offsets nt][cursor nt] unsigned (padded to 16 bytes), [payload list B*D*H*W x (4 + C)] float,
+// [side buffer nt*217*C] float   (nt = tiles of all samples; C == 3: entries of 8 words, side-buffer cells of 4)
+__host__ bool ws_layout(void* ws, int B, int D, int H, int W, int C, Ws& w) {
+  if (B < 1 || D < 1 || H < 1 || W < 1 || (C != 3 && (C < 8 || C % 8 != 0)) || D > 1024 || H > 1024 || W > 1024) return false;
+  const size_t nt = (size_t)B * cdiv(D, 8) * cdiv(H, 8) * cdiv(W, 8);
+  const size_t vox = (size_t)B * D * H * W;
+  if (vox >= (1ull << 31) || nt >= (1u << 30)) return false;      // (32-bit entry indices)
+  const size_t hdr = (64 + 3 * nt + 3) / 4 * 4;
+  w.amax = (unsigned*)ws; w.count = w.amax + 64; w.offsets = w.count + nt; w.cursor = w.offsets + nt;
+  w.list = (float*)(w.amax + hdr);
+  const size_t S = C == 3 ? 8 : 4 + C, BC = C == 3 ? 4 : C;
+  w.border = w.list + vox * S;
+  w.bytes = (hdr + vox * S + nt * NBORDER * BC) * 4 + 256;
+  return true;
+}
+
+int tiles_launch(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow, const float* d_flow_add,
+                 void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, int add_flow, modet_stream_t stream) {
+  MODET_CHECK_PTR(flow); MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_src); MODET_CHECK_PTR(ws);
+  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
+  Ws w;
+  if (!ws_layout(ws, B, D, H, W, C, w) || (C == 3 && src_bf16) || (add_flow && C != 3)) return MODET_ERR_UNSUPPORTED;
+  if (ws_bytes < w.bytes) return MODET_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int dbg = 0;                 // tuning builds only: WT_DBG = bit mask of parts to leave out (timing experiments, wrong results)
+#ifdef MODET_TUNING
+  if (const char* e = getenv("WT_DBG")) dbg = atoi(e);
+#endif
+  Geo g{D, H, W, C, cdiv(D, 8), cdiv(H, 8), cdiv(W, 8), 0, B};
+  g.ntiles = g.tz * g.ty * g.tx;
+  const int nt = B * g.ntiles;
+  const bool small = (int64_t)B * D * H * W < 400000;      // (levels 3-5; level 2, 614 k voxels, is faster with SZ = 4)
+  const int bx_n = cdiv(W, SX), by_n = cdiv(H, SY), bz_n = cdiv(D, small ? 1 : 4);
+  const dim3 bgrid(bx_n * by_n * bz_n, B);
+  modet_zero_async(w.amax, (size_t)(64 + nt) * 4, s);
+  if (small) hipLaunchKernelGGL(count_kernel<1>, bgrid, dim3(256), 0, s, flow, w.count, g, bx_n, by_n);
+  else hipLaunchKernelGGL(count_kernel<4>, bgrid, dim3(256), 0, s, flow, w.count, g, bx_n, by_n);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)w.count, w.offsets, w.cursor, nt);
+  if (C == 3) {
+    if (small) hipLaunchKernelGGL(fill_c3_kernel<1>, bgrid, dim3(256), 0, s, (const float*)src, flow, d_out, w.cursor, w.amax, w.list, d_flow,
+                                  d_flow_add, g, bx_n, by_n, add_flow);
+    else hipLaunchKernelGGL(fill_c3_kernel<4>, bgrid, dim3(256), 0, s, (const float*)src, flow, d_out, w.cursor, w.amax, w.list, d_flow,
+                            d_flow_add, g, bx_n, by_n, add_flow);
+    hipLaunchKernelGGL(accumulate_kernel<3>, dim3(nt < 768 ? nt : 768), dim3(ACC), 0, s, (const float*)w.list, (const unsigned*)w.offsets,
+                       (const unsigned*)w.cursor, (const unsigned*)w.amax, d_src, w.border, g, nt);
+    hipLaunchKernelGGL(border_kernel<true>, dim3(nt, 1), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.offsets,
+                       (const unsigned*)w.cursor, g);
+    return modet_launch_status();
+  }
+#define WT_FILL(S16, SZ) hipLaunchKernelGGL((fill_kernel<S16, SZ>), bgrid, dim3(256), 0, s, src, flow, d_out, w.cursor, w.amax, w.list, d_flow, \
+                                            d_flow_add, g, bx_n, by_n, dbg)
+  if (src_bf16) { if (small) WT_FILL(true, 1); else WT_FILL(true, 4); }
+  else { if (small) WT_FILL(false, 1); else WT_FILL(false, 4); }
+#undef WT_FILL
+  const int items = nt * (C / 8);
+  hipLaunchKernelGGL(accumulate_kernel<8>, dim3(items < 768 ? items : 768), dim3(ACC), 0, s, (const float*)w.list, (const unsigned*)w.offsets,
+                     (const unsigned*)w.cursor, (const unsigned*)w.amax, d_src, w.border, g, nt);
+  hipLaunchKernelGGL(border_kernel<false>, dim3(nt, C / 8), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.offsets,
+                     (const unsigned*)w.cursor, g);
+  return modet_launch_status();
 }
 }  // namespace
 
 extern "C" {
 
-// [amax 1 + pad 63][count nt][offsets nt][cursor nt] unsigned, [list B*D*H*W] int, [side buffer nt*217*C] float  (nt = tiles of all samples)
 size_t modet_warp_bwd_dsrc_tiles_ws_bytes(int B, int D, int H, int W, int C) {
-  if (B < 1 || D < 1 || H < 1 || W < 1 || C < 8 || C % 8 != 0 || D > 1024 || H > 1024 || W > 1024) return 0;
-  const size_t nt = (size_t)B * cdiv(D, 8) * cdiv(H, 8) * cdiv(W, 8);
-  if ((int64_t)B * D * H * W >= (1ll << 31) || nt >= (1u << 30)) return 0;
-  return (64 + 3 * nt) * 4 + (size_t)B * D * H * W * 4 + nt * NBORDER * C * 4 + 256;
-}
-
-static int tiles_launch(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow, const float* d_flow_add,
-                        void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, modet_stream_t stream) {
-  MODET_CHECK_PTR(flow); MODET_CHECK_PTR(d_out); MODET_CHECK_PTR(d_src); MODET_CHECK_PTR(ws);
-  MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && C > 0);
-  const size_t need = modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C);
-  if (need == 0 || (d_flow && C != 8)) return MODET_ERR_UNSUPPORTED;
-  if (ws_bytes < need) return MODET_ERR_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
-  Geo g{D, H, W, C, cdiv(D, 8), cdiv(H, 8), cdiv(W, 8), 0, B};
-  g.ntiles = g.tz * g.ty * g.tx;
-  const int nt = B * g.ntiles;
-  unsigned* amax = (unsigned*)ws;
-  unsigned* count = amax + 64;
-  unsigned* offsets = count + nt;
-  unsigned* cursor = offsets + nt;
-  int* list = (int*)(cursor + nt);
-  float* border = (float*)(list + (size_t)B * D * H * W);
-  const int bx_n = cdiv(W, SX), by_n = cdiv(H, SY), bz_n = cdiv(D, SZ);
-  modet_zero_async(amax, (size_t)(64 + nt) * 4, s);
-  hipLaunchKernelGGL(bin_kernel<false>, dim3(bx_n * by_n * bz_n, B), dim3(256), 0, s, flow, count, list, g, bx_n, by_n, (float*)nullptr,
-                     (const float*)nullptr);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)count, offsets, cursor, nt);
-  hipLaunchKernelGGL(bin_kernel<true>, dim3(bx_n * by_n * bz_n, B), dim3(256), 0, s, flow, cursor, list, g, bx_n, by_n, d_flow, d_flow_add);
-  hipLaunchKernelGGL(tile_absmax_kernel, dim3(1024), dim3(256), 0, s, d_out, (int64_t)B * D * H * W * C, amax);
-  if (d_flow)
-    hipLaunchKernelGGL(accumulate_kernel<true>, dim3(nt), dim3(256), 0, s, flow, d_out, (const unsigned*)offsets, (const unsigned*)count,
-                       (const int*)list, d_src, border, g, (const unsigned*)amax, src, d_flow, d_flow_add);
-  else
-    hipLaunchKernelGGL(accumulate_kernel<false>, dim3(nt), dim3(256), 0, s, flow, d_out, (const unsigned*)offsets, (const unsigned*)count,
-                       (const int*)list, d_src, border, g, (const unsigned*)amax, (const float*)nullptr, (float*)nullptr,
-                       (const float*)nullptr);
-  hipLaunchKernelGGL(border_kernel, dim3(nt), dim3(256), 0, s, d_src, (const float*)border, g);
-  return modet_launch_status();
+  Ws w;
+  return ws_layout(nullptr, B, D, H, W, C, w) ? w.bytes : 0;
 }
 
 int modet_warp_bwd_dsrc_tiles(const float* flow, const float* d_out, float* d_src, void* ws, size_t ws_bytes, int B, int D, int H,
                               int W, int C, modet_stream_t stream) {
-  return tiles_launch(nullptr, flow, d_out, d_src, nullptr, nullptr, ws, ws_bytes, B, D, H, W, C, stream);
+  return tiles_launch(nullptr, 0, flow, d_out, d_src, nullptr, nullptr, ws, ws_bytes, B, D, H, W, C, 0, stream);
 }
 
-int modet_warp_bwd_tiles(const float* src, const float* flow, const float* d_out, float* d_src, float* d_flow, const float* d_flow_add,
-                         void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, modet_stream_t stream) {
+int modet_warp_bwd_tiles(const void* src, int src_bf16, const float* flow, const float* d_out, float* d_src, float* d_flow,
+                         const float* d_flow_add, void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, int add_flow,
+                         modet_stream_t stream) {
   MODET_CHECK_PTR(src); MODET_CHECK_PTR(d_flow);
-  return tiles_launch(src, flow, d_out, d_src, d_flow, d_flow_add, ws, ws_bytes, B, D, H, W, C, stream);
+  return tiles_launch(src, src_bf16, flow, d_out, d_src, d_flow, d_flow_add, ws, ws_bytes, B, D, H, W, C, add_flow, stream);
 }
 
 }  // extern "C"

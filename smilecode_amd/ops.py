@@ -1403,36 +1403,33 @@ def set_deterministic(on=True):
     return prev
 
 
-# Round 5 (end): d_src of the feature warps by destination tiles + a fixed-point LDS window instead of float atomics
-# (modet_warp_bwd_dsrc_tiles, csrc/warp_tile.hip; d_flow keeps the shipped kernel's d_flow-only form).  OFF: its op-level parity
-# tests are green and the prototype measurements are in profiles/r05z_*, but the full suite has not run with the step routed
-# through it.  Volumes below WARP_TILE_MIN_VOXELS keep the atomics either way (fixed costs of the binning passes).
-WARP_TILE_DSRC = False
-WARP_TILE_MIN_VOXELS = 1_500_000
-WARP_TILE_MIN_VOXELS_DET = 300_000          # deterministic mode: against 64-bit global atomics the tiles win from level 2 up
+# The feature warps' backward by destination tiles (csrc/warp_tile.hip): integer sums in an LDS window instead of float atomics on
+# global memory.  Round 5 built it (off: break-even in the step); round 6 rebuilt it (payload lists, zero-d_out entries dropped
+# while binning, d_flow in the fill pass) and made it the default: faster AND bit-reproducible, so the plain step has no float
+# atomics left and set_deterministic() costs nothing for these warps.  WARP_TILES = False brings the float-atomic kernel back
+# (tools/ A/B runs).  Volumes below WARP_TILE_MIN_VOXELS keep it either way.
+WARP_TILES = True
+WARP_TILE_MIN_VOXELS = 0
 
 
 def _warp_backward(src, flow, dout, dsrc, dflow, galias, add_flow, flow_bound):
-    """launch the warp backward: plain (float atomics; galias = a second flow gradient added on the way out) or deterministic"""
+    """launch the warp backward: destination tiles (feature warps: C % 8 == 0, d_src wanted), else the float-atomic / gather
+    kernel, else (deterministic mode, d_src of another channel count) 64-bit integer atomics on global memory.
+    galias = a second flow gradient added on the way out"""
     B, D, H, W, C = src.shape
     L = _L()
     s16 = int(src.dtype == torch.bfloat16)
-    # (in deterministic mode the tile form IS the deterministic kernel for the large feature warps: integer sums in LDS instead of
-    # 64-bit fixed-point atomics on global memory)
-    if ((WARP_TILE_DSRC or DETERMINISTIC) and dsrc is not None and not flow_bound and not add_flow and dout.dtype == torch.float32
-            and B * D * H * W >= (WARP_TILE_MIN_VOXELS if WARP_TILE_DSRC else WARP_TILE_MIN_VOXELS_DET)):
+    if (WARP_TILES and dsrc is not None and not flow_bound and (C == 3 or not add_flow) and not (C == 3 and s16)
+            and dout.dtype == torch.float32 and B * D * H * W >= WARP_TILE_MIN_VOXELS):
         nb = L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C)
         if nb:
             ws = _ws(nb, src)
-            if dflow is not None and C == 8 and not s16:          # d_src and d_flow from one pass over the tile lists
-                _lib.check(L.modet_warp_bwd_tiles(_p(src), _p(flow), _p(dout), _p(dsrc), _p(dflow), _p(galias), _p(ws), nb, B, D, H, W, C,
-                                                  _stream()), "modet_warp_bwd_tiles")
-                return
-            _lib.check(L.modet_warp_bwd_dsrc_tiles(_p(flow), _p(dout), _p(dsrc), _p(ws), nb, B, D, H, W, C, _stream()),
-                       "modet_warp_bwd_dsrc_tiles")
             if dflow is not None:
-                _lib.check(L.modet_warp_bwd_acc(_p(src), s16, _p(flow), _p(dout), None, _p(dflow), _p(galias), B, D, H, W, C, 0, 0,
-                                                _stream()), "modet_warp_bwd_acc")
+                _lib.check(L.modet_warp_bwd_tiles(_p(src), s16, _p(flow), _p(dout), _p(dsrc), _p(dflow), _p(galias), _p(ws), nb,
+                                                  B, D, H, W, C, int(add_flow), _stream()), "modet_warp_bwd_tiles")
+            else:
+                _lib.check(L.modet_warp_bwd_dsrc_tiles(_p(flow), _p(dout), _p(dsrc), _p(ws), nb, B, D, H, W, C, _stream()),
+                           "modet_warp_bwd_dsrc_tiles")
             return
     if DETERMINISTIC and dsrc is not None and not flow_bound:
         nb = L.modet_warp_bwd_det_ws_bytes(B, D, H, W, C)

@@ -477,15 +477,20 @@ def test_attention_backward_is_bit_stable_beside_another_process(tmp_path):
     assert nbad == 0, f"{nbad} of 6000 calls differ from the first"
 
 
-def test_deterministic_train_step_is_bit_reproducible():
-    """VERDICT r4 missing-4: with ops.set_deterministic the warp scatter (the step's only atomics) accumulates in fixed point, so
-    the whole train step is bit-reproducible: two eager steps, two trainers, and the captured hipGraph's replays all return
-    IDENTICAL gradients -- the comparison every graph-vs-eager check otherwise makes through a 1e-6 noise floor."""
+@pytest.mark.parametrize("mode", ["default", "set_deterministic"])
+def test_deterministic_train_step_is_bit_reproducible(mode, monkeypatch):
+    """The warp scatter holds the step's only atomics.  Round 6: the DEFAULT path of every feature warp is the
+    destination-tile kernel (integer sums in LDS, csrc/warp_tile.hip), so the plain train step is bit-reproducible: two eager
+    steps, two trainers, and the captured hipGraph's replays all return IDENTICAL gradients -- the comparison every
+    graph-vs-eager check otherwise makes through a 1e-6 noise floor.  ops.set_deterministic (round 5: 64-bit integer atomics on
+    global memory for whatever the tiles do not take) must stay so.  Against the float-atomic kernel (ops.WARP_TILES off): the
+    same gradients within its run-to-run noise."""
     from smilecode_amd import ops
     from smilecode_amd.engine import Trainer
     shape = (32, 48, 32)
     mov, fix = _pair(shape)
-    prev = ops.set_deterministic(True)
+    assert ops.WARP_TILES and not ops.DETERMINISTIC, "the product defaults"
+    prev = ops.set_deterministic(mode == "set_deterministic")
     try:
         a, b = Trainer(_model(shape, 1.0)), Trainer(_model(shape, 1.0))
         a._fwd_bwd(mov, fix)
@@ -502,10 +507,11 @@ def test_deterministic_train_step_is_bit_reproducible():
             assert torch.equal(b.fp.grad, g1), "a hipGraph replay differs from the eager step"
     finally:
         ops.set_deterministic(prev)
+    monkeypatch.setattr(ops, "WARP_TILES", False)
     c = Trainer(_model(shape, 1.0))
     c._fwd_bwd(mov, fix)
     gerr = float((c.fp.grad - g1).abs().max() / g1.abs().max())
-    _note("deterministic.grad_relerr_vs_float_atomics", gerr)
+    _note(f"deterministic[{mode}].grad_relerr_vs_float_atomics", gerr)
     assert gerr < 1e-5, gerr
 
 

@@ -272,15 +272,19 @@ def test_warp_tee_adds_the_second_flow_gradient_in_the_kernel(C, shape):
 
 
 @pytest.mark.parametrize("C,shape,amp", [(8, (2, 16, 24, 40), 2.0), (16, (1, 13, 21, 37), 6.0), (8, (1, 40, 48, 40), 12.0),
-                                         (32, (1, 9, 8, 17), 3.0), (8, (1, 8, 8, 8), 40.0)])
-def test_warp_backward_d_src_by_destination_tiles(C, shape, amp, monkeypatch):
-    """modet_warp_bwd_dsrc_tiles (round 5, csrc/warp_tile.hip): the scatter of SpatialTransformer's backward (reference
-    models.py:55-67 -> ATen grid_sampler_3d_backward) with destination-tile lists and a 64-bit fixed-point LDS window instead
-    of float atomics.  Against the shipped kernel (float atomics, itself pinned by the goldens): equal within fp32 rounding of the
-    sums; bit-identical run to run; ragged volumes (partial tiles), two samples, channel passes (C = 16, 32), flows that fold and
-    that leave the volume, an all-zero d_out and a d_src buffer full of NaN on entry (it is not read).  Then the routed form:
-    ops.warp_tee's backward with ops.WARP_TILE_DSRC gives the default path's d_src / d_flow (incl. the second flow gradient)."""
-    import ctypes
+                                         (32, (1, 9, 8, 17), 3.0), (8, (1, 8, 8, 8), 40.0), (64, (2, 10, 12, 10), 1.5),
+                                         (8, (1, 80, 96, 80), 25.0), (3, (2, 20, 24, 36), 2.5), (3, (1, 7, 9, 11), 1.0)])
+def test_warp_backward_by_destination_tiles(C, shape, amp, monkeypatch):
+    """csrc/warp_tile.hip, the DEFAULT backward of the feature warps since round 6: the scatter of SpatialTransformer's backward
+    (reference models.py:55-67 -> ATen grid_sampler_3d_backward) with destination-tile payload lists and a 64-bit fixed-point LDS
+    window instead of float atomics.  Against the float-atomic kernel (itself pinned by the goldens): d_src equal within fp32
+    rounding of the sums, d_flow within rounding of the 8-corner dot products; bit-identical run to run; ragged volumes (partial
+    tiles), two samples, channel groups (C = 16, 32, 64), flows that fold and that leave the volume, a block of all-zero d_out
+    (those voxels are dropped while binning), a d_src buffer and a workspace full of NaN on entry (neither is read), bf16 src.
+    The last case is ADVICE r5's: on 80x96x80 with sigma = 25 voxels a 1024-voxel source block reaches ~500 distinct destination
+    tiles -- round 5's 256-slot hash table overflowed silently there.  Then the routed form: ops.warp_tee's backward with
+    ops.WARP_TILES on / off gives the same d_src / d_flow (incl. the second flow gradient).  C == 3: the flow compositions
+    warp(src, flow) + flow whose flow is not bounded by a voxel (reference models.py:392-403 with a CWM output): add_flow."""
     from smilecode_amd import _lib, ops
     L = _lib.load()
     B, D, H, W = shape
@@ -289,42 +293,99 @@ def test_warp_backward_d_src_by_destination_tiles(C, shape, amp, monkeypatch):
     flow = (torch.randn(B, D, H, W, 3, generator=g) * amp).cuda()
     dout = torch.randn(B, D, H, W, C, generator=g).cuda() * 3.7
     dout[:, : D // 3] = 0.0                                       # zero contributions are skipped on both sides
+    add = torch.randn(B, D, H, W, 3, generator=g).cuda()
     st = torch.cuda.current_stream().cuda_stream
-    ref = torch.empty_like(src)
-    _lib.check(L.modet_warp_bwd(src.data_ptr(), flow.data_ptr(), dout.data_ptr(), ref.data_ptr(), None, B, D, H, W, C, 0, 0, st), "warp_bwd")
+    af = int(C == 3)
+    ref, ref_f = torch.empty_like(src), torch.empty_like(flow)
+    _lib.check(L.modet_warp_bwd_acc(src.data_ptr(), 0, flow.data_ptr(), dout.data_ptr(), ref.data_ptr(), ref_f.data_ptr(), add.data_ptr(),
+                                    B, D, H, W, C, af, 0, st), "warp_bwd_acc")
     nb = L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C)
     assert nb > 0 and L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C + 4) == 0 and L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, 2000, H, W, C) == 0
     ws = torch.empty(nb // 4 + 8, dtype=torch.float32, device="cuda")
     outs = []
     for rep in range(2):
-        out = torch.full_like(src, float("nan"))
+        out, out_f = torch.full_like(src, float("nan")), torch.full_like(flow, float("nan"))
         ws.fill_(float("nan"))                                     # (the workspace needs no preparation either)
-        _lib.check(L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), dout.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, B, D, H, W, C, st), "tiles")
-        outs.append(out)
+        _lib.check(L.modet_warp_bwd_tiles(src.data_ptr(), 0, flow.data_ptr(), dout.data_ptr(), out.data_ptr(), out_f.data_ptr(),
+                                          add.data_ptr(), ws.data_ptr(), nb, B, D, H, W, C, af, st), "tiles")
+        outs.append((out, out_f))
     torch.cuda.synchronize()
-    assert bool(torch.isfinite(outs[0]).all())
-    assert torch.equal(outs[0], outs[1]), "integer sums: bit-reproducible"
-    scale = float(ref.abs().max())
-    err = float((outs[0] - ref).abs().max())
-    if scale > 0.0:                                               # (the last case: every sample point leaves the volume -> all zero)
+    assert bool(torch.isfinite(outs[0][0]).all()) and bool(torch.isfinite(outs[0][1]).all())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "integer sums: bit-reproducible"
+    scale, scale_f = float(ref.abs().max()), float(ref_f.abs().max())
+    err, err_f = float((outs[0][0] - ref).abs().max()), float((outs[0][1] - ref_f).abs().max())
+    if scale > 0.0:                                               # (the 8^3 case: every sample point leaves the volume -> all zero)
         _note(f"warp_tiles[C{C},{'x'.join(map(str, shape))}].dsrc_maxdiff_of_max", err / scale)
+        _note(f"warp_tiles[C{C},{'x'.join(map(str, shape))}].dflow_maxdiff_of_max", err_f / scale_f)
     assert err <= 2e-6 * scale, (err, scale)
-    assert L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), dout.data_ptr(), outs[0].data_ptr(), ws.data_ptr(), nb - 4, B, D, H, W, C, st) != 0
-    z = torch.full_like(src, float("nan"))
-    _lib.check(L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), torch.zeros_like(dout).data_ptr(), z.data_ptr(), ws.data_ptr(), nb, B, D, H, W, C, st), "tiles")
-    assert float(z.abs().max()) == 0.0
+    assert err_f <= 4e-6 * scale_f, (err_f, scale_f)
+    # d_src only (no src, no d_flow): the same d_src bit for bit
+    only = torch.full_like(src, float("nan"))
+    _lib.check(L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), dout.data_ptr(), only.data_ptr(), ws.data_ptr(), nb, B, D, H, W, C, st), "tiles")
+    assert torch.equal(only, outs[0][0])
+    assert L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), dout.data_ptr(), only.data_ptr(), ws.data_ptr(), nb - 4, B, D, H, W, C, st) != 0
+    z, zf = torch.full_like(src, float("nan")), torch.full_like(flow, float("nan"))
+    _lib.check(L.modet_warp_bwd_tiles(src.data_ptr(), 0, flow.data_ptr(), torch.zeros_like(dout).data_ptr(), z.data_ptr(), zf.data_ptr(), None,
+                                      ws.data_ptr(), nb, B, D, H, W, C, af, st), "tiles")
+    assert float(z.abs().max()) == 0.0 and float(zf.abs().max()) == 0.0
+    if C == 3:
+        assert L.modet_warp_bwd_tiles(src.to(torch.bfloat16).data_ptr(), 1, flow.data_ptr(), dout.data_ptr(), z.data_ptr(), zf.data_ptr(), None,
+                                      ws.data_ptr(), nb, B, D, H, W, C, af, st) != 0, "C == 3 takes fp32 src only"
+    else:
+        assert L.modet_warp_bwd_tiles(src.data_ptr(), 0, flow.data_ptr(), dout.data_ptr(), z.data_ptr(), zf.data_ptr(), None,
+                                      ws.data_ptr(), nb, B, D, H, W, C, 1, st) != 0, "add_flow is the C == 3 composition's"
+        # bf16 src (cfg 5's feature warps): bit-identical to the fp32 entry fed with the widened values
+        s16 = src.to(torch.bfloat16)
+        a16, f16 = torch.empty_like(src), torch.empty_like(flow)
+        _lib.check(L.modet_warp_bwd_tiles(s16.data_ptr(), 1, flow.data_ptr(), dout.data_ptr(), a16.data_ptr(), f16.data_ptr(), add.data_ptr(),
+                                          ws.data_ptr(), nb, B, D, H, W, C, 0, st), "tiles bf16")
+        sw = s16.float()
+        a32, f32 = torch.empty_like(src), torch.empty_like(flow)
+        _lib.check(L.modet_warp_bwd_tiles(sw.data_ptr(), 0, flow.data_ptr(), dout.data_ptr(), a32.data_ptr(), f32.data_ptr(), add.data_ptr(),
+                                          ws.data_ptr(), nb, B, D, H, W, C, 0, st), "tiles")
+        assert torch.equal(a16, a32) and torch.equal(f16, f32)
     # routed through the autograd node
     r2 = torch.randn(B, D, H, W, 3, generator=g).cuda()
     res = []
     for routed in (False, True):
-        monkeypatch.setattr(ops, "WARP_TILE_DSRC", routed)
-        monkeypatch.setattr(ops, "WARP_TILE_MIN_VOXELS", 0)
+        monkeypatch.setattr(ops, "WARP_TILES", routed)
         s_, f_ = src.clone().requires_grad_(True), flow.clone().requires_grad_(True)
-        o, fl = ops.warp_tee(s_, f_)
+        if C == 3:
+            o, fl = ops.warp(s_, f_, 0, True), f_
+        else:
+            o, fl = ops.warp_tee(s_, f_)
         ((o * dout).sum() + (fl * fl * r2).sum()).backward()
         res.append((s_.grad, f_.grad))
-    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * float(res[0][1].abs().max()) + 1e-30, "d_flow (the shipped kernel's d_flow-only form)"
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 4e-6 * float(res[0][1].abs().max()) + 1e-30
     assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-6 * scale
+
+
+def test_warp_backward_tiles_range_and_non_finite():
+    """(1) contributions far below the tensor's maximum must survive the fixed point -- 2^-40 of the power of two
+    above max |d_out| per unit (modet_warp_bwd_det's), so a region 1e-7 of the maximum keeps 3-4 digits where round 5's 2^-30 left one bit;
+    (2) a NaN or inf in d_out must not be turned into finite numbers (the float path propagates it)."""
+    from smilecode_amd import _lib
+    L = _lib.load()
+    B, D, H, W, C = 1, 16, 16, 24, 8
+    g = torch.Generator().manual_seed(5)
+    flow = (torch.randn(B, D, H, W, 3, generator=g) * 0.3).cuda()
+    dout = torch.randn(B, D, H, W, C, generator=g).cuda()
+    dout[:, :, :, 12:] *= 1e-7
+    st = torch.cuda.current_stream().cuda_stream
+    nb = L.modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C)
+    ws = torch.empty(nb // 4 + 8, dtype=torch.float32, device="cuda")
+    ref, out = torch.empty_like(dout), torch.empty_like(dout)
+    _lib.check(L.modet_warp_bwd(dout.data_ptr(), flow.data_ptr(), dout.data_ptr(), ref.data_ptr(), None, B, D, H, W, C, 0, 0, st), "warp_bwd")
+    _lib.check(L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), dout.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, B, D, H, W, C, st), "tiles")
+    small = ref[:, :, :, 14:22]
+    rel = float((out[:, :, :, 14:22] - small).abs().max() / small.abs().max())
+    _note("warp_tiles.small_region_relerr", rel)
+    assert float(small.abs().max()) < 1e-5 and rel < 1e-3, rel
+    for bad in (float("nan"), float("inf")):
+        d2 = dout.clone()
+        d2[0, 3, 4, 5, 2] = bad
+        _lib.check(L.modet_warp_bwd_dsrc_tiles(flow.data_ptr(), d2.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, B, D, H, W, C, st), "tiles")
+        assert not bool(torch.isfinite(out[0, 2:6, 3:7, 4:8]).all()), "a non-finite d_out was laundered into finite d_src"
 
 
 @pytest.mark.parametrize("C,shape,add_flow", [(8, (1, 40, 48, 40), False), (3, (2, 12, 16, 20), True), (16, (1, 8, 12, 16), False),
