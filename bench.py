@@ -59,9 +59,63 @@ def family(tag):
         return "conv_x3_wgrad_kernel" if tag.endswith(("@x3", "@x3h")) else ("conv_wgrad_tr_kernel" if tag.endswith(("@tr", "@trh")) else "conv3d_wgrad_kernel")
     if base == "warp_bwd":
         return "warp_bwd_kernel"
+    if base == "warp_bwd_tiles":
+        return "warp_bwd_tiles"
     if base == "warp_bwd_gather3":
         return "warp_bwd_gather3_tiled_kernel"
     return base
+
+
+# kernel family -> the rocprof kernel SYMBOLS (template arguments stripped) its launches run: a family is what one launch tag of
+# ops.py enqueues, which may be several kernels (the destination-tile warp backward is six) or one of several variants of a
+# kernel (warp_bwd_kernel / warp_bwd2_kernel).  roofline.traffic sums the counter bytes of ALL of them (the
+# family name looked up as a symbol found the minor variant only).  Families not listed are their own symbol.
+FAMILY_SYMBOLS = {
+    "warp_bwd_kernel": ("warp_bwd_kernel", "warp_bwd2_kernel"),
+    "warp_bwd_tiles": ("count_kernel", "scan_kernel", "fill_kernel", "fill_c3_kernel", "accumulate_kernel", "border_kernel"),
+    "warp_fwd": ("warp_fwd_kernel",),
+    "instnorm_lrelu_bwd": ("in_bwd_apply_kernel", "in_partial_kernel", "in_rows_finalize_bwd_kernel"),
+    "instnorm_lrelu_fwd": ("in_apply_kernel", "in_apply_pool_kernel", "in_rows_finalize_kernel", "in_finalize_kernel"),
+    "proj_ln_bwd": ("proj_ln_bwd_g_kernel", "proj_ln_bwd_kernel"),
+    "proj_ln_fwd": ("proj_ln_fwd_g_kernel", "proj_ln_fwd_kernel"),
+    "na_bwd": ("na_bwd_march_kernel", "na_bwd_kernel"),
+    "na_fwd": ("na_fwd_kernel",),
+    "ncc_fwd_bwd": ("ncc_march_kernel",),
+    "grad3d_fwd_bwd": ("grad3d_kernel",),
+    "upsample2_bwd": ("upsample2_bwd_kernel", "upsample2_bwd_rows_kernel", "upsample2_bwd_axis_kernel"),
+    "upsample2_fwd": ("upsample2_fwd_kernel",),
+    "conv_c1_fwd_kernel": ("conv_c1_march_kernel",),
+    "conv_x3_kernel<NPC=1>": ("conv_x3_kernel",),
+    "conv_x3_wgrad_kernel<NPC=1>": ("conv_x3_wgrad_kernel",),
+}
+
+
+def family_traffic(pj, fam, launches_per_step):
+    """HBM bytes of one family from profiles/pmc_traffic.json: (bytes per step, bytes per launch of the family) or (None, None).
+    Per step = sum over the family's kernel symbols of (mean bytes per launch of the symbol) x (its launches per step)"""
+    fams = pj.get("families", {})
+    tot, found = 0.0, False
+    for sym in FAMILY_SYMBOLS.get(fam, (fam,)):
+        v = fams.get(sym)
+        if v and v.get("launches_per_step"):
+            tot += v["hbm_bytes_per_launch_corrected"] * v["launches_per_step"]
+            found = True
+    if not found:
+        return None, None
+    return tot, (tot / launches_per_step if launches_per_step else None)
+
+
+def add_traffic(r, pj, fam, launches_per_step, alg_bytes_per_step):
+    """traffic fields of a roofline object (r['traffic'] stays per launch, as 'achieved' is)"""
+    r["algorithmic_bytes_per_step"] = alg_bytes_per_step
+    per_step, per_launch = (None, None) if pj is None else family_traffic(pj, fam, launches_per_step)
+    r["traffic"], r["traffic_per_step"] = per_launch, per_step
+    r["traffic_over_algorithmic"] = (per_step / alg_bytes_per_step) if (per_step and alg_bytes_per_step) else None
+    if r["traffic_over_algorithmic"] is not None and r["traffic_over_algorithmic"] < 1.0:
+        # possible physically (the 256 MB Infinity Cache serves a tensor the previous kernel just wrote) -- but say so
+        r["traffic_note"] = ("counter traffic below the algorithmic bytes: part of this family's input was served by the 256 MB "
+                             "Infinity Cache (written by the kernel before it) or a symbol of the family is missing from the profile")
+        log(f"[bench] note: {fam}: counter traffic {per_step / 1e6:.1f} MB/step < algorithmic {alg_bytes_per_step / 1e6:.1f} MB/step")
 
 
 # fp32-accurate matrix work on the 16-bit pipe costs six bf16 MFMAs per fp32 product (three bf16 pieces per operand,
@@ -156,6 +210,21 @@ def cpu_baseline(shape, workload, budget_s=40.0):
         out = {"value": 1.0 / (8.0 * t_half), "unit": "volume-pairs/sec", "cores": nt, "kind": "port",
                "sample": "1 pair %dx%dx%d %s (1/8 of the voxels, %.2f s) scaled x8, oracle/modet_torch.py (ATen-CPU fp32)"
                          % (*half, workload, t_half)}
+    # the one-thread leg BASELINE.md section 4(2) asks for: the same oracle on ONE core, on the largest sample of the workload
+    # that one core finishes in about half a minute (the full pair would take minutes), scaled by voxels
+    try:
+        torch.set_num_threads(1)
+        tiny = (32, 48, 32)
+        t_tiny = run(tiny)
+        vox = lambda s: s[0] * s[1] * s[2]                               # noqa: E731
+        sample = half if t_tiny * vox(half) / vox(tiny) <= 45.0 else (64, 64, 64)
+        t1 = run(sample)
+        scale = vox(shape) / vox(sample)
+        out["value_1_thread"] = 1.0 / (t1 * scale)
+        out["sample_1_thread"] = ("1 pair %dx%dx%d %s on one thread (%.2f s) scaled x%.2f by voxels, oracle/modet_torch.py (ATen-CPU fp32)"
+                                  % (*sample, workload, t1, scale))
+    except Exception as e:                                                # noqa: BLE001
+        out["value_1_thread"], out["sample_1_thread"] = None, f"failed: {e!r}"
     torch.set_num_threads(cores)
     return out
 
@@ -597,7 +666,6 @@ def main():
                 pfl += v["flops"] * piece_products(k)
             sec = d["ms"] * 1e-3
             roof = roof_of(dominant, d["flops"], d["bytes"], sec, pfl)
-            roof["traffic"] = None
             roof.update({"kernel": dominant, "launches": d["calls"], "launches_per_step": d["calls"] / roof_steps,
                          "avg_launch_ms": d["ms"] / d["calls"], "share_of_step": d["ms"] / ((dt_eager or dt) * 1e3),
                          "measured_over": ("%d eager steps right after the timed region (the timed region replays a hipGraph, "
@@ -605,21 +673,24 @@ def main():
                          "note": "all launches of this kernel symbol in the K timed steps; algorithmic work summed per "
                                  "launch shape (DESIGN.md section 4)" + ("; warp_bwd_kernel is bound by the L2 float-atomic "
                                  "unit (its d_src scatter), not by HBM: DESIGN.md section 4" if dominant == "warp_bwd_kernel" else "")})
-            # per-launch HBM bytes from the rocprofv3 --pmc passes of tools/refresh_profiles.sh: quoted only while the profile
-            # was taken on THESE kernel sources (fingerprint of smilecode_amd/csrc), otherwise null + the reason
+            # HBM bytes from the rocprofv3 --pmc passes of tools/refresh_profiles.sh: quoted only while the profile was taken on
+            # THESE kernel sources (fingerprint of smilecode_amd/csrc), otherwise null + the reason
+            pj = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    pj = json.load(open(pmc))
-                    have, now = pj.get("csrc_sha16"), csrc_sha16()
+                    pj_ = json.load(open(pmc))
+                    have, now = pj_.get("csrc_sha16"), csrc_sha16()
                     if have == now:
-                        roof["traffic"] = pj.get(dominant, pj.get("families", {}).get(dominant, {}).get("hbm_bytes_per_launch_corrected"))
-                        roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE), csrc %s" % now
+                        pj = pj_
+                        roof["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, summed over the "
+                                                  "family's kernel symbols %s), csrc %s" % (list(FAMILY_SYMBOLS.get(dominant, (dominant,))), now))
                     else:
                         roof["traffic_source"] = ("profiles/pmc_traffic.json is stale: taken on csrc %s, this build is %s "
                                                   "(re-run tools/refresh_profiles.sh)" % (have, now))
                 except Exception:
                     pass
+            add_traffic(roof, pj, dominant, d["calls"] / roof_steps, d["bytes"] / roof_steps)
         # the same object for the six largest families of the profiled warm-up steps (median of those steps)
         tot_ms = sum(v["ms"] for v in fams.values()) or 1.0
         roof_top = []
@@ -627,6 +698,7 @@ def main():
             r = roof_of(k, v["flops"], v["bytes"], v["ms"] * 1e-3, v.get("pflops"))
             r.pop("peak_note", None)
             r.update({"kernel": k, "ms_per_step": v["ms"], "launches_per_step": v["calls"], "share_of_kernel_time": v["ms"] / tot_ms})
+            add_traffic(r, pj if dominant else None, k, v["calls"], v["bytes"])
             roof_top.append(r)
         out = {
             "metric": "volume-pairs/sec (%dx%dx%d) %s" % (*shape, "fwd+bwd" if args.workload == "train" else "fwd+warp"),

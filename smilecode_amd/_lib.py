@@ -43,9 +43,11 @@ SIGNATURES = {
     "modet_conv3d_kernel_family_v": (I, [I, I, I, I, I, I, I, I]),
     "modet_conv3d_ws_bytes": (SZ, [I, I]),
     "modet_conv3d_fwd": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P, P]),
+    "modet_conv3d_fwd_bounded": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P, P]),
     "modet_conv3d_stats_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_normin_stats_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_fwd_stats": (I, [P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
+    "modet_conv3d_fwd_stats_bounded": (I, [P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_fwd_normin": (I, [P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_bwd_data": (I, [P, P, P, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I, I]),

@@ -1766,7 +1766,7 @@ size_t modetx_x3_ws_bytes(int Cin, int Cout);
 size_t modetx_x3_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                    const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int act, int mode,
-                   hipStream_t s, const float* amax = nullptr);
+                   hipStream_t s, const float* amax = nullptr, bool x_free = false);
 size_t modetx_x3_bst_rows_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_dgrad_bst(modet_step_ctx* step, const float* dy, const float* w, float* dx, const float* xraw, const float* mean,
                         const float* rstd, float* rows, void* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t s,
@@ -1803,7 +1803,7 @@ size_t modetx_q_stats_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                   const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int mode,
                   hipStream_t s, const float* amax = nullptr, const float* xraw = nullptr, const float* bmean = nullptr,
-                  const float* brstd = nullptr, float* bst_rows = nullptr);
+                  const float* brstd = nullptr, float* bst_rows = nullptr, bool x_free = false);
 size_t modetx_q_bst_rows_bytes(int B, int D, int H, int W, int Cin, int Cout);
 static bool use_q(int B, int D, int H, int W, int Cin, int Cout) {
   static const bool on = modet_tuning_env("MODET_CONV_Q") != '0';
@@ -1938,8 +1938,9 @@ size_t modet_conv3d_ws_bytes(int Cin, int Cout) {
   return a > d ? a : d;
 }
 
-int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
-                     int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream, modet_step_ctx_t* step) {
+// x_free: nothing is known about the range of x -> the bf16x3 forms (fp32's range) in the families that have an f16 form
+static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
+                           int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream, modet_step_ctx_t* step, bool x_free) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
@@ -1962,17 +1963,26 @@ int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y
   }
   if (use_x3(B, D, H, W, Cin, Cout)) {
     if (ws_bytes < modetx_x3_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
-    return modetx_x3_conv(step, x, w, bias, y, ws, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
+    return modetx_x3_conv(step, x, w, bias, y, ws, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream, nullptr, x_free);
   }
   if (!act && use_q(B, D, H, W, Cin, Cout)) {
     if (ws_bytes < modetx_q_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
-    return modetx_q_conv(step, x, w, bias, y, ws, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
+    return modetx_q_conv(step, x, w, bias, y, ws, nullptr, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream, nullptr, nullptr, nullptr,
+                         nullptr, nullptr, x_free);
   }
   if (!act && use_split(Cin, Cout, (int64_t)B * D * H * W)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     return modetx_split_conv(step, x, w, bias, y, ws, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
   }
   return conv_launch(step, x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, act, 0, (hipStream_t)stream);
+}
+int modet_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
+                     int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream, modet_step_ctx_t* step) {
+  return conv3d_fwd_impl(x, w, bias, y, ws, ws_bytes, B, D, H, W, Cin, Cout, act, stream, step, true);
+}
+int modet_conv3d_fwd_bounded(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
+                             int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream, modet_step_ctx_t* step) {
+  return conv3d_fwd_impl(x, w, bias, y, ws, ws_bytes, B, D, H, W, Cin, Cout, act, stream, step, false);
 }
 
 // InstanceNorm statistics are fused into the conv epilogue (staged or direct-store) for every Cout the model
@@ -2002,9 +2012,9 @@ size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   return ((size_t)B * Cout + (size_t)B * conv_stats_rows(B, D, H, W, Cin, Cout) * Cout * 2) * sizeof(float);
 }
 
-int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
-                           float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                           modet_stream_t stream, modet_step_ctx_t* step) {
+static int conv3d_fwd_stats_impl(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                                 float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                                 modet_stream_t stream, modet_step_ctx_t* step, bool x_free) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws); MODET_CHECK_PTR(stats);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
@@ -2014,13 +2024,14 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
     if (ws_bytes < modetx_x3_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                        (const float*)nullptr, (const float*)nullptr, stats, B, D, H, W, Cin, Cout);
-    return modetx_x3_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream);
+    return modetx_x3_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, nullptr, x_free);
   }
   if (use_q(B, D, H, W, Cin, Cout)) {
     if (ws_bytes < modetx_q_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                        (const float*)nullptr, (const float*)nullptr, stats, B, D, H, W, Cin, Cout);
-    return modetx_q_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream);
+    return modetx_q_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, (hipStream_t)stream, nullptr, nullptr, nullptr,
+                         nullptr, nullptr, x_free);
   }
   if (use_split(Cin, Cout, (int64_t)B * D * H * W)) {
     if (ws_bytes < modetx_split_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
@@ -2028,6 +2039,16 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
   }
   return conv_launch(step, x, w, bias, y, (float*)ws, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, stats, nullptr,
                      ConvIn{nullptr, nullptr, conv_stats_rows(B, D, H, W, Cin, Cout), nullptr});
+}
+int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                           float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                           modet_stream_t stream, modet_step_ctx_t* step) {
+  return conv3d_fwd_stats_impl(x, w, bias, y, ws, ws_bytes, stats, stats_bytes, B, D, H, W, Cin, Cout, stream, step, true);
+}
+int modet_conv3d_fwd_stats_bounded(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                                   float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                                   modet_stream_t stream, modet_step_ctx_t* step) {
+  return conv3d_fwd_stats_impl(x, w, bias, y, ws, ws_bytes, stats, stats_bytes, B, D, H, W, Cin, Cout, stream, step, false);
 }
 
 int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* w,

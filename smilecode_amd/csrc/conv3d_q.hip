@@ -496,11 +496,12 @@ size_t modetx_q_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
 // stats != null: [B][Cout] shift header (filled by the caller's shift kernel) followed by the rows [B][tiles][Cout][2]
 int modetx_q_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                   const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int mode,
-                  hipStream_t s, const float* amax, const float* xraw, const float* bmean, const float* brstd, float* bst_rows) {
+                  hipStream_t s, const float* amax, const float* xraw, const float* bmean, const float* brstd, float* bst_rows, bool x_free) {
   const QPlan p = q_plan(B, D, H, W, Cin, Cout);
   unsigned short* wpk = (unsigned short*)ws;
-  // forward: two f16 pieces (the input is an activation); data gradient: the same when the caller knows max |d_y|, else bf16x3
-  const bool f16 = Q_F16 && (int64_t)D * H * W < (1ll << 24) && (mode == 0 || amax != nullptr);
+  // forward: two f16 pieces when the caller vouches for the input's range (an activation; the lazily normalised input is one by
+  // construction), else bf16x3 (fp32's range); data gradient: f16 when the caller knows max |d_y|, else bf16x3
+  const bool f16 = Q_F16 && (int64_t)D * H * W < (1ll << 24) && (mode == 0 ? (!x_free || in_mean != nullptr) : amax != nullptr);
   const int np = f16 ? 2 : 3;
   // CoutP = 16 ct makes the arena's size formula (nstage * ksteps * CoutP * 32 * npiece elements) this packing's size
   const PackBKey key{w, Cin, Cout, p.ct_total * 16, p.nq, p.nstage, p.ks, mode, np, 4};

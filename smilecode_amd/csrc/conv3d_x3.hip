@@ -767,11 +767,12 @@ inline const uint4* x3_weights(modet_step_ctx* step, const float* w, void* ws, i
 }
 
 template <bool NORM, bool STATS>
-int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s) {
+int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, int B, int mode, const X3Plan& p, hipStream_t s, bool x_free) {
   X3Args a = a0;
-  // forward: two f16 pieces, three products (see split2_h); data gradient: the same when the caller knows max |d_y| (a.amax),
-  // else three bf16 pieces.  (LeakyReLU(InstanceNorm(.)) is bounded by sqrt(V): beyond 2^24 voxels x 2^4 could overflow f16.)
-  const bool f16 = X3_F16_FWD && (int64_t)a.D * a.H * a.W < (1ll << 24) && (mode == 0 || a.amax != nullptr);
+  // forward: two f16 pieces, three products (see split2_h) when the caller vouches for the input's range (x_free == false: an
+  // activation), else three bf16 pieces, which have fp32's range; data gradient: f16 when the caller knows max |d_y| (a.amax),
+  // else bf16.  (LeakyReLU(InstanceNorm(.)) is bounded by sqrt(V): beyond 2^24 voxels x 2^4 could overflow f16.)
+  const bool f16 = X3_F16_FWD && (int64_t)a.D * a.H * a.W < (1ll << 24) && (mode == 0 ? !x_free : a.amax != nullptr);
   if (!f16) a.amax = nullptr;
   a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, f16 ? 2 : 3, p, s);
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.nchunk = p.nchunk; a.ZC = p.zc; a.nitems = p.nitems;
@@ -1233,15 +1234,15 @@ size_t modetx_x3_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
 // stats != null: stats = [B][Cout] shift header (filled by the caller's shift kernel) followed by the partial rows
 int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const float* bias, float* y, void* ws, float* stats,
                    const float* in_mean, const float* in_rstd, int B, int D, int H, int W, int Cin, int Cout, int act, int mode,
-                   hipStream_t s, const float* amax) {
+                   hipStream_t s, const float* amax, bool x_free) {
   const X3Plan p = x3_plan(B, D, H, W, Cin, Cout);
   X3Args a{};
   a.amax = mode == 1 ? amax : nullptr;
   a.x = x; a.bias = bias; a.y = y; a.in_mean = in_mean; a.in_rstd = in_rstd;
   a.shift = stats; a.stats_rows = stats ? stats + (size_t)B * Cout : nullptr;
   a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
-  if (in_mean) return stats ? x3_launch<true, true>(step, a, w, ws, B, mode, p, s) : x3_launch<true, false>(step, a, w, ws, B, mode, p, s);
-  return stats ? x3_launch<false, true>(step, a, w, ws, B, mode, p, s) : x3_launch<false, false>(step, a, w, ws, B, mode, p, s);
+  if (in_mean) return stats ? x3_launch<true, true>(step, a, w, ws, B, mode, p, s, false) : x3_launch<true, false>(step, a, w, ws, B, mode, p, s, false);
+  return stats ? x3_launch<false, true>(step, a, w, ws, B, mode, p, s, x_free) : x3_launch<false, false>(step, a, w, ws, B, mode, p, s, x_free);
 }
 // data gradient d_x = conv^T(d_y) (Cout channels in, Cin out) whose output is the gradient w.r.t. LeakyReLU(InstanceNorm(xraw)):
 // also writes rows [B][items][Cin][2] of (sum g, sum g*xhat) -- the first pass of the InstanceNorm backward, for free

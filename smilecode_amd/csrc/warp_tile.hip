@@ -32,7 +32,7 @@ constexpr int SY = 8, SX = 32;                                // source block of
 // voxels: ADVICE r5)
 constexpr int ACC = 512;                                      // lanes of an accumulate workgroup
 constexpr int FXBITS = 40;
-struct Geo { int D, H, W, C, tz, ty, tx, ntiles, B; };      // ntiles = tiles per sample
+struct Geo { int D, H, W, C, tz, ty, tx, ntiles, B, dbg; };      // ntiles = tiles per sample; dbg: tuning builds only
 
 struct Entry { int tile, bz, by, bx; float fz, fy, fx; };
 // the ONE place that decides a voxel's base cell and tile: passes A, B and C must agree bit for bit
@@ -394,13 +394,16 @@ __device__ __forceinline__ int border_index(int lz, int ly, int lx) {      // ce
   return 153 + lz * 8 + ly;                          // 64 (lx == 8, lz, ly < 8)
 }
 
-// ---- C: the tile's payload -> fixed-point window -> owned cells (plain stores) + high-face cells (side buffer).  Work item =
-// (tile, group of eight channels).  ONE lane per entry and all eight channels: the corner / weight arithmetic of an entry is done
-// once.  PERSISTENT workgroups (three per CU: 46 KB of LDS each) walk the work items with the NEXT item's first 2 x ACC payload
-// entries already in flight (and the counts of the one after): as one workgroup per item the kernel spent 42 % of its wave
-// cycles parked on the payload's round trip and the LDS unit was busy 40 % of the time (profiles/r06*_pmc_accumulate.txt).
-// Measured and NOT done: counting-sorting a chunk by base cell so that a wave's lanes walk consecutive banks -- the conflict
-// cycles did not fall (same-address duplicates replace the bank conflicts) and the sort's five barriers cost 90 us.
+// ---- C: the tile's payload -> fixed-point window -> owned cells (plain stores) + high-face cells (side buffer).  One workgroup
+// per (tile, group of eight channels); ONE lane per entry and all eight channels: the corner / weight arithmetic of an entry is
+// done once.  46 KB of LDS: three workgroups per CU.  What the counters say (level 1, 160x192x160, profiles/r06*_accumulate*):
+// the CU's VALU + LDS pipes are the bound, not latency -- 314 M ds_add_u64 at ~10 LDS cycles per wave instruction (a wave's 64
+// lanes hit the 32 64-bit banks ~3.5 deep: the lists are in source order, random in the tile's cells) = ~80 us, the 5 VALU
+// per contribution (multiply, round, convert, two shifts) ~60 us, and they overlap badly; one / two / three workgroups per CU
+// run 356 / 277 / 254 us.  Measured and NOT kept: (a) counting-sorting each chunk by base cell so that a wave walks consecutive
+// banks -- same-address duplicates replace the bank conflicts and the sort's barriers cost 90 us; (b) persistent workgroups with
+// the next item's payload prefetched -- no faster (the payload's round trip is hidden by the other workgroups already) and
+// the static striding unbalances (254 against 236 us).
 struct AccEntry { float4 hd, ga, gb; };
 template <int NCH>
 __device__ __forceinline__ void acc_load(const float* __restrict__ lp, unsigned i, unsigned n, int S, int c0, AccEntry& a) {
@@ -439,105 +442,81 @@ __device__ __forceinline__ void acc_entry(const AccEntry& a, unsigned long long*
     const float w = (dz ? e.fz : 1.f - e.fz) * (dy ? e.fy : 1.f - e.fy) * (dx ? e.fx : 1.f - e.fx);
     unsigned long long* wp = win + (cell0 + (dz * WN + dy) * WN + dx);       // window = [channel][cell]
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) atomicAdd(wp + k * CELLS, fx_make(vs[k] * w, sh));
+    for (int k = 0; k < NCH; ++k) {
+      const unsigned long long cv = fx_make(vs[k] * w, sh);
+#ifdef MODET_TUNING
+      if (g.dbg & 16) { wp[k * CELLS] = cv; continue; }                      // plain store instead of the atomic
+      if (g.dbg & 32) { if (cv == 0x123456789abcull) wp[k * CELLS] = cv; continue; }   // no LDS operation at all
+#endif
+      atomicAdd(wp + k * CELLS, cv);
+    }
   }
 }
 
-constexpr int ACC_U = 2;                                      // payload entries per lane in flight for the next work item
 template <int NCH>      // channels of a work item: 8, or 3 (C == 3: payload entries of 8 words, d_src / side-buffer cells of 3 / 4 floats)
-__global__ __launch_bounds__(ACC) __attribute__((amdgpu_waves_per_eu(6, 6))) void accumulate_kernel(const float* __restrict__ list, const unsigned* __restrict__ offsets,
+__global__ __launch_bounds__(ACC) void accumulate_kernel(const float* __restrict__ list, const unsigned* __restrict__ offsets,
                                                          const unsigned* __restrict__ cursor, const unsigned* __restrict__ amax,
-                                                         float* __restrict__ dsrc_all, float* __restrict__ border, const Geo g, int nt) {
+                                                         float* __restrict__ dsrc, float* __restrict__ border, const Geo g) {
   __shared__ __attribute__((aligned(16))) unsigned long long win[CELLS * NCH + 1];
   const int tid = threadIdx.x;
-  const int C = g.C, S = NCH == 8 ? 4 + C : 8, ngrp = NCH == 8 ? C / 8 : 1, BC = NCH == 8 ? C : 4;
-  const int nitems = nt * ngrp, G = gridDim.x;
+  const int C = g.C, S = NCH == 8 ? 4 + C : 8, BC = NCH == 8 ? C : 4;
+  const int tile = blockIdx.x, c0 = blockIdx.y * 8;           // tile: over all samples
+  const int b = tile / g.ntiles;
+  int t = tile - b * g.ntiles;
+  const int ox = (t % g.tx) * TL; t /= g.tx;
+  const int oy = (t % g.ty) * TL;
+  const int oz = (t / g.ty) * TL;
+  const unsigned base = offsets[tile], n = cursor[tile] - base;
+  dsrc += (int64_t)b * g.D * g.H * g.W * C + c0;
+  if (n == 0) {                                               // nothing lands here: zeros, and no side-buffer cells (pass D tests the count)
+    const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
+    const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
+    if (gz < g.D && gy < g.H && gx < g.W) {
+      float* dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C;
+      if constexpr (NCH == 8) {
+        *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f;
+      }
+    }
+    return;
+  }
   int E;
   float inv_scale;
-  bool finite = true;
-  bool have_scale = false;
-  // item -> (tile, channel group): groups of a tile are neighbours in the walk (the payload they share stays in L2)
-  int it = blockIdx.x;
-  if (it >= nitems) return;
-  unsigned base = offsets[it / ngrp], n = cursor[it / ngrp] - base;
-  unsigned base1 = 0, n1 = 0;
-  if (it + G < nitems) { base1 = offsets[(it + G) / ngrp]; n1 = cursor[(it + G) / ngrp] - base1; }
-  AccEntry cur[ACC_U], nxt[ACC_U];
-  if (n) {
-#pragma unroll
-    for (int u = 0; u < ACC_U; ++u) acc_load<NCH>(list + (size_t)base * S, tid + u * ACC, n, S, (it % ngrp) * 8, cur[u]);
+  const bool finite = fx_global(amax, E, inv_scale);
+  {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2* w2 = reinterpret_cast<u64x2*>(win);
+    for (int i = tid; i < (CELLS * NCH + 1) / 2; i += ACC) w2[i] = (u64x2){0ull, 0ull};
   }
-  for (; it < nitems; it += G) {
-    const int tile = it / ngrp, c0 = (it % ngrp) * 8;         // tile: over all samples
-    // ---- the next item's payload, and the counts of the one after
-    const int itn = it + G;
-    if (itn < nitems && n1) {
+  __syncthreads();
+  const float* lp = list + (size_t)base * S;
+  for (unsigned i = tid; i < n; i += ACC) {
+    AccEntry a;
+    acc_load<NCH>(lp, i, n, S, c0, a);
+    acc_entry<NCH>(a, win, g, oz, oy, ox, E, finite);
+  }
+  __syncthreads();
+  // flush: one cell (NCH channels) per thread and trip
+  const float poison = finite ? 0.f : __uint_as_float(0x7fc00000u);
+  for (int cell = tid; cell < CELLS; cell += ACC) {
+    const int lx = cell % WN, lr = cell / WN, ly = lr % WN, lz = lr / WN;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < ACC_U; ++u) acc_load<NCH>(list + (size_t)base1 * S, tid + u * ACC, n1, S, (itn % ngrp) * 8, nxt[u]);
-    }
-    unsigned base2 = 0, n2 = 0;
-    if (itn + G < nitems) { base2 = offsets[(itn + G) / ngrp]; n2 = cursor[(itn + G) / ngrp] - base2; }
-    // ---- this item
-    const int b = tile / g.ntiles;
-    int t = tile - b * g.ntiles;
-    const int ox = (t % g.tx) * TL; t /= g.tx;
-    const int oy = (t % g.ty) * TL;
-    const int oz = (t / g.ty) * TL;
-    float* dsrc = dsrc_all + (int64_t)b * g.D * g.H * g.W * C + c0;
-    if (n == 0) {                                             // nothing lands here: zeros, and no side-buffer cells (pass D tests the count)
-      const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
+    for (int k = 0; k < NCH; ++k) o[k] = (float)(long long)win[k * CELLS + cell] * inv_scale + poison;
+    const bool owned = lz < TL && ly < TL && lx < TL;
+    float* dst;
+    if (owned) {
       const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
-      if (gz < g.D && gy < g.H && gx < g.W) {
-        float* dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C;
-        if constexpr (NCH == 8) {
-          *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(dst + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-          dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f;
-        }
-      }
+      if (gz >= g.D || gy >= g.H || gx >= g.W) continue;
+      dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C;
     } else {
-      if (!have_scale) { finite = fx_global(amax, E, inv_scale); have_scale = true; }
-      {
-        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        u64x2* w2 = reinterpret_cast<u64x2*>(win);
-        for (int i = tid; i < (CELLS * NCH + 1) / 2; i += ACC) w2[i] = (u64x2){0ull, 0ull};
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < ACC_U; ++u)
-        if ((unsigned)(tid + u * ACC) < n) acc_entry<NCH>(cur[u], win, g, oz, oy, ox, E, finite);
-      for (unsigned i = ACC_U * ACC + tid; i < n; i += ACC) { // (a folded tile: more than 2 x ACC entries)
-        AccEntry a;
-        acc_load<NCH>(list + (size_t)base * S, i, n, S, c0, a);
-        acc_entry<NCH>(a, win, g, oz, oy, ox, E, finite);
-      }
-      __syncthreads();
-      // flush: one cell (8 channels = 32 bytes of output) per thread and trip
-      const float poison = finite ? 0.f : __uint_as_float(0x7fc00000u);
-      for (int cell = tid; cell < CELLS; cell += ACC) {
-        const int lx = cell % WN, lr = cell / WN, ly = lr % WN, lz = lr / WN;
-        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) o[k] = (float)(long long)win[k * CELLS + cell] * inv_scale + poison;
-        const bool owned = lz < TL && ly < TL && lx < TL;
-        float* dst;
-        if (owned) {
-          const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
-          if (gz >= g.D || gy >= g.H || gx >= g.W) continue;
-          dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C;
-        } else {
-          dst = border + ((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * BC + c0;
-        }
-        if (NCH == 8 || !owned) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-        else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; }
-        if constexpr (NCH == 8) *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-      }
-      __syncthreads();                                        // (the next item zeroes the window)
+      dst = border + ((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * BC + c0;
     }
-    base = base1; n = n1; base1 = base2; n1 = n2;
-#pragma unroll
-    for (int u = 0; u < ACC_U; ++u) cur[u] = nxt[u];
+    if (NCH == 8 || !owned) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; }
+    if constexpr (NCH == 8) *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
   }
 }
 
@@ -624,7 +603,7 @@ int tiles_launch(const void* src, int src_bf16, const float* flow, const float* 
 #ifdef MODET_TUNING
   if (const char* e = getenv("WT_DBG")) dbg = atoi(e);
 #endif
-  Geo g{D, H, W, C, cdiv(D, 8), cdiv(H, 8), cdiv(W, 8), 0, B};
+  Geo g{D, H, W, C, cdiv(D, 8), cdiv(H, 8), cdiv(W, 8), 0, B, dbg};
   g.ntiles = g.tz * g.ty * g.tx;
   const int nt = B * g.ntiles;
   const bool small = (int64_t)B * D * H * W < 400000;      // (levels 3-5; level 2, 614 k voxels, is faster with SZ = 4)
@@ -639,8 +618,8 @@ int tiles_launch(const void* src, int src_bf16, const float* flow, const float* 
                                   d_flow_add, g, bx_n, by_n, add_flow);
     else hipLaunchKernelGGL(fill_c3_kernel<4>, bgrid, dim3(256), 0, s, (const float*)src, flow, d_out, w.cursor, w.amax, w.list, d_flow,
                             d_flow_add, g, bx_n, by_n, add_flow);
-    hipLaunchKernelGGL(accumulate_kernel<3>, dim3(nt < 768 ? nt : 768), dim3(ACC), 0, s, (const float*)w.list, (const unsigned*)w.offsets,
-                       (const unsigned*)w.cursor, (const unsigned*)w.amax, d_src, w.border, g, nt);
+    hipLaunchKernelGGL(accumulate_kernel<3>, dim3(nt, 1), dim3(ACC), 0, s, (const float*)w.list, (const unsigned*)w.offsets,
+                       (const unsigned*)w.cursor, (const unsigned*)w.amax, d_src, w.border, g);
     hipLaunchKernelGGL(border_kernel<true>, dim3(nt, 1), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.offsets,
                        (const unsigned*)w.cursor, g);
     return modet_launch_status();
@@ -650,9 +629,8 @@ int tiles_launch(const void* src, int src_bf16, const float* flow, const float* 
   if (src_bf16) { if (small) WT_FILL(true, 1); else WT_FILL(true, 4); }
   else { if (small) WT_FILL(false, 1); else WT_FILL(false, 4); }
 #undef WT_FILL
-  const int items = nt * (C / 8);
-  hipLaunchKernelGGL(accumulate_kernel<8>, dim3(items < 768 ? items : 768), dim3(ACC), 0, s, (const float*)w.list, (const unsigned*)w.offsets,
-                     (const unsigned*)w.cursor, (const unsigned*)w.amax, d_src, w.border, g, nt);
+  hipLaunchKernelGGL(accumulate_kernel<8>, dim3(nt, C / 8), dim3(ACC), 0, s, (const float*)w.list, (const unsigned*)w.offsets,
+                     (const unsigned*)w.cursor, (const unsigned*)w.amax, d_src, w.border, g);
   hipLaunchKernelGGL(border_kernel<false>, dim3(nt, C / 8), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.offsets,
                      (const unsigned*)w.cursor, g);
   return modet_launch_status();

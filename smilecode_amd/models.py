@@ -114,21 +114,23 @@ class ConvInsBlock(nn.Module):
         return ops.conv3d_instnorm_lrelu(x, self.main.weight, self.main.bias)
 
 
-def _two_blocks_pool(inp, first, second, Bh):
+def _two_blocks_pool(inp, first, second, Bh, x_act=True):
     """_two_blocks followed by the pool tee of the [moving; fixed] batch, fp32 path: the second block's InstanceNorm apply pass
     also writes the pooled tensor of the next level (ops.instnorm_lrelu_pool_tee_split); returns (pooled, moving, fixed)"""
-    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias, x_act=True)   # (inp: a block's / a pool's output)
+    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias, x_act=x_act)
     raw2, st2 = ops.lazy_instnorm_conv3d(raw, st, second.main.weight, second.main.bias)
     return ops.instnorm_lrelu_pool_tee_split(raw2, st2, Bh)
 
 
-def _two_blocks(inp, first, second, bf16=False):
+def _two_blocks(inp, first, second, bf16=False, x_act=True):
     """ConvInsBlock -> ConvInsBlock: the first block's normalised output exists only inside the second conv's kernels
     (ops.lazy_instnorm_conv3d); the second block's InstanceNorm is applied for real (its output has several consumers).
     bf16: the chain's internal tensors are stored in bf16 and the convs run on the bf16 matrix pipe (cfg 5)."""
     if bf16:
         return ops.conv_ins_pair_bf16(inp, first.main.weight, first.main.bias, second.main.weight, second.main.bias)
-    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias, x_act=True)   # (inp: a block's / a pool's output)
+    # x_act: inp is a normalised block's output or a pooled copy of one (bounded).  Level 1's inp is the ConvBlock 1 -> 4 output --
+    # LeakyReLU(conv(image)), as large as the image is -- and goes in with x_act=False: no assumption about its range
+    raw, st = ops.conv3d_with_stats(inp, first.main.weight, first.main.bias, x_act=x_act)
     raw2, st2 = ops.lazy_instnorm_conv3d(raw, st, second.main.weight, second.main.bias)
     return ops._InstNormLReLU.apply(raw2, 1e-5, st2)
 
@@ -154,7 +156,7 @@ class Encoder(nn.Module):
     def forward(self, x):
         # each level's output goes to the next level (pooled) AND to the caller: pool_tee fuses the two gradient paths
         outs = []
-        cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2], self.bf16)
+        cur = _two_blocks(self.conv0[0](x), self.conv0[1], self.conv0[2], self.bf16, x_act=False)
         for blk in (self.conv1, self.conv2, self.conv3, self.conv4):
             pooled, keep = ops.pool_tee(cur)
             outs.append(keep)
@@ -182,7 +184,7 @@ class Encoder(nn.Module):
         pooled_in = []
         if not self.bf16:
             # fp32: the last InstanceNorm of a level writes the level's features and their pooled copy in one pass
-            pooled, m, f = _two_blocks_pool(self.conv0[0](x), self.conv0[1], self.conv0[2], B)
+            pooled, m, f = _two_blocks_pool(self.conv0[0](x), self.conv0[1], self.conv0[2], B, x_act=False)
             Ms.append(m)
             Fs.append(f)
             pooled_in.append(pooled)

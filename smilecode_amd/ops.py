@@ -192,7 +192,10 @@ def _conv16_tag(kind, x_shape, Cin, Cout, x_bf16):
 
 
 # ------------------------------------------------------------------------------------------------ raw calls
-def conv3d_forward(x, w, b, act, step=None):
+def conv3d_forward(x, w, b, act, step=None, x_act=False):
+    """x_act: the caller's word that x is an activation inside the f16 forms' range (include/modet_hip.h, "TWO f16 PIECES":
+    |x| < 4 094) -> the *_bounded entry point, half the matrix work; without it the launch makes no assumption about x (three
+    bf16 pieces: fp32's range), as nn.Conv3d makes none"""
     _chk(x, w, b)
     step = step if step is not None else current_step()
     B, D, H, W, Cin = x.shape
@@ -204,9 +207,9 @@ def conv3d_forward(x, w, b, act, step=None):
     nb = L.modet_conv3d_ws_bytes(Cin, Cout)
     ws = _ws(nb, x)
     n = float(B) * D * H * W
-    with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout, 1 if act else 0), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
-        _lib.check(L.modet_conv3d_fwd(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, B, D, H, W, Cin, Cout, int(act),
-                                      _stream(), _h(step)), "modet_conv3d_fwd")
+    with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout, 1 if act else 0, f16=bool(x_act)), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+        fn = L.modet_conv3d_fwd_bounded if x_act else L.modet_conv3d_fwd
+        _lib.check(fn(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, B, D, H, W, Cin, Cout, int(act), _stream(), _h(step)), "modet_conv3d_fwd")
     return y
 
 
@@ -596,9 +599,9 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
 # ------------------------------------------------------------------------------------------------ autograd ops
 class _Conv3d(Function):
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    def forward(ctx, x, w, b, act, x_act=False):
         ctx.step = current_step()
-        y = conv3d_forward(x, w, b, act, ctx.step)
+        y = conv3d_forward(x, w, b, act, ctx.step, x_act)
         ctx.act = bool(act)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act else None, b)
@@ -611,7 +614,7 @@ class _Conv3d(Function):
         if ctx.act and not ctx.needs_input_grad[0] and x.shape[-1] == 1 and w.shape[0] == 4:
             # first encoder block: no d_x, and the weight-gradient kernel folds LeakyReLU' into its d_y load
             dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, y_act=y, w=w, b=b, step=ctx.step)
-            return None, dw, db, None
+            return None, dw, db, None, None
         if ctx.act:
             g = torch.empty_like(dy)
             with _Guard(dy, "lrelu_bwd", dy.numel(), 12.0 * dy.numel()):
@@ -621,7 +624,7 @@ class _Conv3d(Function):
         amax = None if ctx.act else _amax_of(dy)                 # (x is whatever the caller convolved: no f16 weight gradient)
         dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step)
         dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step, amax) if ctx.needs_input_grad[0] else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _Conv3dStats(Function):
@@ -641,9 +644,10 @@ class _Conv3dStats(Function):
         sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)
         stats = torch.empty(sb // 4, dtype=torch.float32, device=x.device)
         n = float(B) * D * H * W
-        with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout, 3), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
-            _lib.check(L.modet_conv3d_fwd_stats(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
-                                                Cout, _stream(), _h(ctx.step)), "modet_conv3d_fwd_stats")
+        with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout, 3, f16=ctx.x_act), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+            fn = L.modet_conv3d_fwd_stats_bounded if ctx.x_act else L.modet_conv3d_fwd_stats
+            _lib.check(fn(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin, Cout, _stream(), _h(ctx.step)),
+                       "modet_conv3d_fwd_stats")
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(stats)
@@ -678,13 +682,13 @@ def _fuse_stats(x, w, needs_grad=None):
     return Cout in (4, 8, 16) or not needs_grad
 
 
-def conv3d_instnorm_lrelu(x, w, b, eps=1e-5):
+def conv3d_instnorm_lrelu(x, w, b, eps=1e-5, x_act=False):
     """ConvInsBlock = conv + InstanceNorm3d + LeakyReLU(0.1) (reference models.py:135-151); the norm statistics are
-    fused into the conv epilogue when the configuration supports it"""
+    fused into the conv epilogue when the configuration supports it.  x_act: see conv3d_forward"""
     if _fuse_stats(x, w):
-        y, stats = _Conv3dStats.apply(x, w, b)
+        y, stats = _Conv3dStats.apply(x, w, b, x_act)
         return _InstNormLReLU.apply(y, eps, stats)
-    return _InstNormLReLU.apply(_Conv3d.apply(x, w, b, False), eps, None)
+    return _InstNormLReLU.apply(_Conv3d.apply(x, w, b, False, x_act), eps, None)
 
 
 def lazy_instnorm_conv3d(x_raw, stats_in, w, b, eps=1e-5, want_stats=True):
@@ -761,12 +765,12 @@ class _InstNormConv(Function):
             sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)
             stats = torch.empty(sb // 4, dtype=torch.float32, device=y.device)
             n = float(B) * D * H * W
-            with _Guard(y, _conv_tag("fwd", y.shape, Cin, Cout, 3), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
-                _lib.check(L.modet_conv3d_fwd_stats(_p(y), _p(w), _p(b), _p(z), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
-                                                    Cout, _stream(), _h(ctx.step)), "modet_conv3d_fwd_stats")
+            with _Guard(y, _conv_tag("fwd", y.shape, Cin, Cout, 3, f16=True), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+                _lib.check(L.modet_conv3d_fwd_stats_bounded(_p(y), _p(w), _p(b), _p(z), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin,
+                                                            Cout, _stream(), _h(ctx.step)), "modet_conv3d_fwd_stats")    # (y: LeakyReLU(InstanceNorm(.)))
             ctx.mark_non_differentiable(stats)
         else:
-            z = conv3d_forward(y, w, b, False, ctx.step)
+            z = conv3d_forward(y, w, b, False, ctx.step, x_act=True)
         ctx.set_materialize_grads(False)        # no zeros_like(stats) fill launch for the statistics output's "gradient"
         ctx.has_bias = b is not None
         ctx.save_for_backward(x_raw, mean, rstd, y, w, b)
@@ -825,12 +829,13 @@ def conv3d_with_stats(x, w, b, x_act=False):
     one), which lets the weight gradient split it into f16 pieces with a fixed scale."""
     if _fuse_stats(x, w):
         return _Conv3dStats.apply(x, w, b, x_act)
-    return _Conv3d.apply(x, w, b, False), None
+    return _Conv3d.apply(x, w, b, False, x_act), None
 
 
-def conv3d(x, w, b=None, act=False):
-    """3x3x3 conv, zero pad 1 (+ fused LeakyReLU(0.1) if act).  reference: nn.Conv3d, models.py:127,:144,:254"""
-    return _Conv3d.apply(x, w, b, act)
+def conv3d(x, w, b=None, act=False, x_act=False):
+    """3x3x3 conv, zero pad 1 (+ fused LeakyReLU(0.1) if act).  reference: nn.Conv3d, models.py:127,:144,:254.  Any input range
+    (x_act=True: the caller's word that |x| < 4 094 -- half the matrix work, see conv3d_forward)"""
+    return _Conv3d.apply(x, w, b, act, x_act)
 
 
 class _InstNormLReLU(Function):
@@ -1300,7 +1305,7 @@ class _LevelAttnBF16(Function):
         dM = torch.empty(M.shape, dtype=torch.float32, device=M.device) if ctx.needs_input_grad[1] else None
         dflow = torch.empty_like(flow) if ctx.needs_input_grad[2] else None
         if dM is not None or dflow is not None:
-            with _Guard(M, f"warp_bwd[C{Cin}]", n * (60.0 * Cin + 40.0), 4.0 * n * (3 * Cin + 6)):
+            with _Guard(M, _warp_bwd_tag(M, dM, 0, 0), n * (60.0 * Cin + 40.0), 4.0 * n * (3 * Cin + 6)):
                 _warp_backward(M, flow, dMw, dM, dflow, galias, 0, 0)
         elif galias is not None:
             dflow = galias
@@ -1384,7 +1389,7 @@ class _Warp(Function):
         dsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
         dflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
         n = float(B) * D * H * W
-        tag = "warp_bwd_gather3[C3]" if (C == 3 and ctx.flow_bound) else f"warp_bwd[C{C}]"     # the kernel that runs
+        tag = _warp_bwd_tag(src, dsrc, ctx.add_flow, ctx.flow_bound if C == 3 else 0)     # the kernels that run
         with _Guard(src, tag, n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6)):
             _warp_backward(src, flow, dout, dsrc, dflow, None, ctx.add_flow, ctx.flow_bound if C == 3 else 0)
         return dsrc, dflow, None, None, None
@@ -1410,6 +1415,18 @@ def set_deterministic(on=True):
 # (tools/ A/B runs).  Volumes below WARP_TILE_MIN_VOXELS keep it either way.
 WARP_TILES = True
 WARP_TILE_MIN_VOXELS = 0
+
+
+def _warp_bwd_tag(src, dsrc, add_flow, flow_bound):
+    """launch tag of a warp backward = the kernels that run (bench.py maps tags to kernel families)"""
+    B, D, H, W, C = src.shape
+    if C == 3 and flow_bound:
+        return "warp_bwd_gather3[C3]"
+    s16 = src.dtype == torch.bfloat16
+    if (WARP_TILES and dsrc is not None and (C == 3 or not add_flow) and not (C == 3 and s16) and B * D * H * W >= WARP_TILE_MIN_VOXELS
+            and _L().modet_warp_bwd_dsrc_tiles_ws_bytes(B, D, H, W, C)):
+        return f"warp_bwd_tiles[C{C}]"
+    return f"warp_bwd[C{C}]"
 
 
 def _warp_backward(src, flow, dout, dsrc, dflow, galias, add_flow, flow_bound):
@@ -1472,7 +1489,7 @@ class _WarpTee(Function):
         dsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
         dflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
         n = float(B) * D * H * W
-        with _Guard(src, f"warp_bwd[C{C}]", n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6 + (3 if galias is not None else 0))):
+        with _Guard(src, _warp_bwd_tag(src, dsrc, 0, 0), n * (60.0 * C + 40.0), 4.0 * n * (3 * C + 6 + (3 if galias is not None else 0))):
             _warp_backward(src, flow, dout, dsrc, dflow, galias, 0, 0)
         return dsrc, dflow
 

@@ -617,6 +617,13 @@ def test_device_volume_cache_indexes_pairs_like_the_datasets(tmp_path):
     assert torch.equal(x[0], syn[4][0]) and torch.equal(y[0], syn[4][1])
 
 
+def test_data_pipeline_golden_from_the_reference(tmp_path):
+    """f2 pinned: pair order, volumes and Seg_norm labels equal what the reference's data/datasets.py + data/trans.py returned
+    (tests/golden/data_pipeline.npz, make_goldens_data.py); the cache on the CPU device here, on the GPU in test_gpu_e2e.py"""
+    from tests.util import check_data_pipeline_golden
+    assert check_data_pipeline_golden(tmp_path, "cpu") == 4
+
+
 def test_data_pipeline_pairs_and_label_remap(tmp_path):
     """all-ordered-pairs indexing and Seg_norm table of the reference (datasets.py:24-26, trans.py:27-39)"""
     import pickle

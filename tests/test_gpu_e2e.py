@@ -190,6 +190,40 @@ def test_forward_vs_oracle_64_batch2():
     _note("fwd[64^3,B=2].y_moved_maxerr", ey)
 
 
+@pytest.mark.parametrize("gain", [4000.0, 60000.0])
+def test_forward_and_grads_with_an_unnormalised_image(gain):
+    """The reference runs on whatever intensities it is given (nn.Conv3d has no range, reference models.py:119-133): a user who
+    forgot to min-max an MR volume (x 4 000) or feeds raw 16-bit intensities (x 60 000) must get the reference's answer, not
+    NaN (round 5's f16 forward forms overflowed in the first ConvInsBlock).  Forward and the gradients of one
+    loss against the fp64 oracle on the same scaled pair; the ConvBlock 1 -> 4 output reaches ~1e4 / ~2e5 here."""
+    from oracle import modet_torch as orc
+    from smilecode_amd import losses, synth
+    shape = (32, 48, 32)
+    w = synth.make_weights(24)
+    mov_np, fix_np = (a * np.float32(gain) for a in synth.make_pair(shape, 24))
+    p64 = {n: torch.from_numpy(v).double().requires_grad_(True) for n, v in w.items()}
+    loss64, _, _, y64, f64 = orc.train_loss(p64, torch.from_numpy(mov_np).double(), torch.from_numpy(fix_np).double(), (8, 4, 2, 1, 1), 6, 1.0)
+    g64 = torch.autograd.grad(loss64, list(p64.values()), allow_unused=True)
+    model = _model(shape, 1.0)
+    mov, fix = torch.from_numpy(mov_np).cuda(), torch.from_numpy(fix_np).cuda()
+    y, flow = model(mov, fix)
+    assert bool(torch.isfinite(flow).all()) and bool(torch.isfinite(y).all())
+    _note(f"unnormalised[x{gain:g}].flow_maxerr", assert_close(np64(flow), f64.detach().numpy(), atol=2e-3, rtol=0, what="flow (voxels)"))
+    assert_close(np64(y) / gain, y64.detach().numpy() / gain, atol=5e-4, rtol=0, what="y_moved / gain")
+    loss = losses.NCC_vxm()(fix, y) + losses.Grad3d(penalty="l2")(flow, fix)
+    assert abs(float(loss.detach()) - float(loss64.detach())) < 2e-4 * max(1.0, abs(float(loss64.detach())))
+    loss.backward()
+    worst = 0.0
+    for (n, p_), g in zip(model.named_parameters(), g64):
+        if g is None or float(g.abs().max()) < 1e-8 * max(1.0, float(max(x.abs().max() for x in g64 if x is not None))):
+            continue                                           # (analytically zero: conv biases under InstanceNorm)
+        assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n
+        e = float((p_.grad.double().cpu() - g).abs().max() / g.abs().max())
+        worst = max(worst, e)
+    _note(f"unnormalised[x{gain:g}].worst_grad_relerr", worst)
+    assert worst < 2e-2, worst
+
+
 @pytest.mark.parametrize("shape,batch", [((16, 32, 16), 1), ((32, 32, 48), 3), ((16, 48, 80), 2)])
 def test_forward_and_grads_vs_oracle_edge_shapes(shape, batch):
     """smallest volume the reference's pure path accepts (16x32x16: level 5 is 1x2x1, smaller than the 3^3 window, every
@@ -475,6 +509,14 @@ def test_attention_backward_is_bit_stable_beside_another_process(tmp_path):
     nbad = int((torch.stack(bad).sum(1) > 0).sum())
     _note("na_bwd.calls_not_bit_identical_beside_another_process_of_6000", nbad)
     assert nbad == 0, f"{nbad} of 6000 calls differ from the first"
+
+
+def test_device_volume_cache_on_the_gpu_equals_the_reference_pipeline(tmp_path):
+    """SURVEY 8(f) rank 2 on the GPU box: `.pkl` subjects -> DeviceVolumeCache(device="cuda") through the
+    pinned double-buffered H2D path -> device-resident pairs EQUAL to what the reference's datasets + transforms returned
+    (fixture generated from /root/reference/ModeT/data/{datasets,trans}.py by tests/golden/make_goldens_data.py)."""
+    from tests.util import check_data_pipeline_golden
+    assert check_data_pipeline_golden(tmp_path, "cuda") == 4
 
 
 @pytest.mark.parametrize("mode", ["default", "set_deterministic"])

@@ -46,18 +46,21 @@ def load(path, counter):
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+# steps profiled = launches of the optimizer kernel (one per train step); a forward-only run has none: per-step fields stay null
+steps = max(len(fetch.get("adam_kernel", [])), len(write.get("adam_kernel", [])))
 fams = {}
 for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * sum(fetch.get(k, [0])) + sum(write.get(k, [0])))):
     f, w = fetch.get(k, []), write.get(k, [])
     n = max(len(f), len(w))
     fm, wm = (sum(f) / len(f) if f else 0.0), (sum(w) / len(w) if w else 0.0)
-    fams[k] = {"launches_profiled": n, "fetch_bytes_raw": fm, "write_bytes": wm,
+    fams[k] = {"launches_profiled": n, "launches_per_step": (n / steps if steps else None), "fetch_bytes_raw": fm, "write_bytes": wm,
                "hbm_bytes_per_launch_corrected": 2 * fm + wm}
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes over `bench.py --steps 2 --warmup 2` (train "
                "step, 160x192x160, B=1); counters are KB; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per "
                "MI355X_MICROARCH.md (gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads); averaged over all launches of "
                "the kernel symbol in a step",
        "csrc_sha16": csrc_sha16(),
+       "steps_profiled": steps,
        "families": fams}
 for k in fams:                                   # bench.py reads the dominant family's per-launch bytes from the top level
     out[k] = fams[k]["hbm_bytes_per_launch_corrected"]
