@@ -180,6 +180,23 @@ int modet_conv3d_fwd_stats(const float* x, const float* w, const float* bias, fl
 int modet_conv3d_fwd_stats_bounded(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                                    float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
                                    modet_stream_t stream, modet_step_ctx_t* step);
+/* An input whose range is known ON THE DEVICE only (the ConvBlock 1 -> 4 output in front of the first ConvInsBlock: as large as the
+ * image is).  modet_conv3d_fwd_amax_out = modet_conv3d_fwd that also leaves max |y| in y_amax (MODET_AMAX_FLOATS floats, written by
+ * this call; the kernel of the first encoder block -- Cin 1, Cout 4, >= 500 k voxels -- carries that epilogue for free,
+ * MODET_ERR_UNSUPPORTED otherwise).  modet_conv3d_fwd_stats_amax = modet_conv3d_fwd_stats given such maxima of |x| (NULL = none):
+ * the z-marching family then runs the two f16 pieces with x scaled by the power of two that takes the maximum into
+ * [2^14, 2^15) -- any range, half the matrix work, and none of the precision the UNSCALED Cin = 4 form of round 5 lost on small
+ * activations (their low piece fell into f16's subnormals: that was 2/3 of the model's flow error at 160x192x160); other
+ * families ignore x_amax and run bf16x3.  modet_conv3d_bwd_weight_amax2: the weight gradient given both maxima (d_y's and x's). */
+int modet_conv3d_fwd_amax_out(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
+                              int D, int H, int W, int Cin, int Cout, int act, float* y_amax, modet_stream_t stream,
+                              modet_step_ctx_t* step);
+int modet_conv3d_fwd_stats_amax(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                                float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                                const float* x_amax, modet_stream_t stream, modet_step_ctx_t* step);
+int modet_conv3d_bwd_weight_amax2(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes, int B,
+                                  int D, int H, int W, int Cin, int Cout, const float* dy_amax, const float* x_amax,
+                                  modet_stream_t stream, modet_step_ctx_t* step);
 /* Forward whose input is the RAW output of the previous ConvInsBlock: LeakyReLU((x_raw - in_mean) * in_rstd) is applied
  * while the input tile is staged (zero padding stays zero), so the normalised tensor is never written
  * (ConvInsBlock -> ConvInsBlock chains, models.py:186-219; used when no gradient is needed: inference).  in_mean / in_rstd: (B*Cin) from modet_instnorm_stats.

@@ -48,6 +48,9 @@ SIGNATURES = {
     "modet_conv3d_normin_stats_bytes": (SZ, [I, I, I, I, I, I]),
     "modet_conv3d_fwd_stats": (I, [P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_fwd_stats_bounded": (I, [P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
+    "modet_conv3d_fwd_amax_out": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, I, P, P, P]),
+    "modet_conv3d_fwd_stats_amax": (I, [P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P, P]),
+    "modet_conv3d_bwd_weight_amax2": (I, [P, P, P, P, P, SZ, I, I, I, I, I, I, P, P, P, P]),
     "modet_conv3d_fwd_normin": (I, [P, P, P, P, P, P, P, SZ, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_bwd_data": (I, [P, P, P, P, SZ, I, I, I, I, I, I, P, P]),
     "modet_conv3d_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I, I]),

@@ -1149,7 +1149,8 @@ __global__ __launch_bounds__(NTHR) void conv_c1_fwd_kernel(const float* __restri
 // halo is 1.33x (y, x only) and the next plane is in flight (buffer loads: zero padding by the descriptor) while this one
 // computes.  (The per-voxel kernel above: 0.110 ms at 2 x 160x192x160 = 1.8 TB/s of the 197 MB it moves.)
 constexpr int C1Y = 8, C1X = 32, C1HY = C1Y + 2, C1HX = C1X + 2, C1HV = C1HY * C1HX;
-struct C1Args { const float* x; const float* w; const float* bias; float* y; int D, H, W, tiles_x, tiles_y, ZC, act; };
+struct C1Args { const float* x; const float* w; const float* bias; float* y; int D, H, W, tiles_x, tiles_y, ZC, act;
+                unsigned* amax; };   // amax != null: max |y| is left there (MODET_AMAX_SLOTS slots, zeroed by the launcher)
 __global__ __launch_bounds__(NTHR) void conv_c1_march_kernel(const C1Args a) {
   __shared__ float pl[2][C1HV];
   const int tid = threadIdx.x;
@@ -1222,6 +1223,7 @@ __global__ __launch_bounds__(NTHR) void conv_c1_march_kernel(const C1Args a) {
   };
   const bool live = y0 + ty < H && x0 + tx < W;
   float n0[9], n1[9], n2[9];
+  float ymax = 0.f;
   load_plane(zs - 1); store_plane(0);
   load_plane(zs);
   __syncthreads();
@@ -1249,9 +1251,17 @@ __global__ __launch_bounds__(NTHR) void conv_c1_march_kernel(const C1Args a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = lrelu(acc[c]);
     }
-    if (live) *reinterpret_cast<float4*>(yb + (((int64_t)z * H + y0 + ty) * W + x0 + tx) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (live) {
+      *reinterpret_cast<float4*>(yb + (((int64_t)z * H + y0 + ty) * W + x0 + tx) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+    }
 #pragma unroll
     for (int k = 0; k < 9; ++k) { n0[k] = n1[k]; n1[k] = n2[k]; }
+  }
+  if (a.amax) {               // (uniform) one integer atomic max per wave: non-negative floats order like their bit patterns
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+    if ((tid & 63) == 0 && ymax > 0.f) atomicMax(a.amax + (blockIdx.x % MODET_AMAX_SLOTS) * MODET_AMAX_STRIDE, __float_as_uint(ymax));
   }
 }
 
@@ -1775,7 +1785,7 @@ bool modetx_x3_wgrad_eligible(int B, int D, int H, int W, int Cin, int Cout);
 size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
                     int W, int Cin, int Cout, hipStream_t s, const float* amax = nullptr, const float* in_mean = nullptr,
-                    const float* in_rstd = nullptr);
+                    const float* in_rstd = nullptr, const float* xamax = nullptr);
 // bf16x3 weight gradient through LDS transpose reads (conv3d_wtr.hip): every layer the z-march kernel does not take
 // (Cin >= 12, and the few-channel layers below its voxel threshold); MODET_CONV_WTR=0 restores the exact-f32 kernels (A/B switch)
 bool modetx_wtr_eligible(int B, int D, int H, int W, int Cin, int Cout);
@@ -1939,19 +1949,24 @@ size_t modet_conv3d_ws_bytes(int Cin, int Cout) {
 }
 
 // x_free: nothing is known about the range of x -> the bf16x3 forms (fp32's range) in the families that have an f16 form
+// y_amax != null: max |y| is left there (only the kernel of the first encoder block carries that epilogue: UNSUPPORTED otherwise)
 static int conv3d_fwd_impl(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
-                           int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream, modet_step_ctx_t* step, bool x_free) {
+                           int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream, modet_step_ctx_t* step, bool x_free,
+                           float* y_amax = nullptr) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (ws_bytes < fwd_ws_elems(Cin, Cout) * sizeof(float)) return MODET_ERR_WORKSPACE;
-  if (Cin == 1 && Cout == 4 && (int64_t)D * H * W >= 500000 && (int64_t)H * W * 4 < 0x7fffffffLL) {
+  const bool c1_march = Cin == 1 && Cout == 4 && (int64_t)D * H * W >= 500000 && (int64_t)H * W * 4 < 0x7fffffffLL;
+  if (y_amax && !c1_march) return MODET_ERR_UNSUPPORTED;
+  if (c1_march) {
+    if (y_amax) modet_zero_async(y_amax, MODET_AMAX_FLOATS * sizeof(float), (hipStream_t)stream);
     const int tx = cdiv(W, C1X), ty = cdiv(H, C1Y);
     int n = cdiv(2048, B * tx * ty);                       // ~8 workgroups per CU, chunks of >= 8 planes
     const int maxn = D / 8 > 0 ? D / 8 : 1;
     n = n < 1 ? 1 : (n > maxn ? maxn : n);
     const int zc = cdiv(D, n);
     hipLaunchKernelGGL(conv_c1_march_kernel, dim3(tx * ty * cdiv(D, zc), B), dim3(NTHR), 0, (hipStream_t)stream,
-                       C1Args{x, w, bias, y, D, H, W, tx, ty, zc, act});
+                       C1Args{x, w, bias, y, D, H, W, tx, ty, zc, act, (unsigned*)y_amax});
     return modet_launch_status();
   }
   if (Cin == 1 && (Cout == 4 || Cout == 8)) {
@@ -1984,6 +1999,12 @@ int modet_conv3d_fwd_bounded(const float* x, const float* w, const float* bias, 
                              int D, int H, int W, int Cin, int Cout, int act, modet_stream_t stream, modet_step_ctx_t* step) {
   return conv3d_fwd_impl(x, w, bias, y, ws, ws_bytes, B, D, H, W, Cin, Cout, act, stream, step, false);
 }
+int modet_conv3d_fwd_amax_out(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, int B,
+                              int D, int H, int W, int Cin, int Cout, int act, float* y_amax, modet_stream_t stream,
+                              modet_step_ctx_t* step) {
+  MODET_CHECK_PTR(y_amax);
+  return conv3d_fwd_impl(x, w, bias, y, ws, ws_bytes, B, D, H, W, Cin, Cout, act, stream, step, true, y_amax);
+}
 
 // InstanceNorm statistics are fused into the conv epilogue (staged or direct-store) for every Cout the model
 // normalises (a multiple of 4, at most 128: 2*Cout columns fit the 256-thread finalize)
@@ -2014,7 +2035,7 @@ size_t modet_conv3d_stats_bytes(int B, int D, int H, int W, int Cin, int Cout) {
 
 static int conv3d_fwd_stats_impl(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                                  float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
-                                 modet_stream_t stream, modet_step_ctx_t* step, bool x_free) {
+                                 modet_stream_t stream, modet_step_ctx_t* step, bool x_free, const float* x_amax = nullptr) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(w); MODET_CHECK_PTR(y); MODET_CHECK_PTR(ws); MODET_CHECK_PTR(stats);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (!conv_stats_ok(Cin, Cout)) return MODET_ERR_UNSUPPORTED;
@@ -2024,7 +2045,7 @@ static int conv3d_fwd_stats_impl(const float* x, const float* w, const float* bi
     if (ws_bytes < modetx_x3_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
     hipLaunchKernelGGL(conv_shift_kernel, dim3(cdiv(B * Cout, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                        (const float*)nullptr, (const float*)nullptr, stats, B, D, H, W, Cin, Cout);
-    return modetx_x3_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, nullptr, x_free);
+    return modetx_x3_conv(step, x, w, bias, y, ws, stats, nullptr, nullptr, B, D, H, W, Cin, Cout, 0, 0, (hipStream_t)stream, x_amax, x_free);
   }
   if (use_q(B, D, H, W, Cin, Cout)) {
     if (ws_bytes < modetx_q_ws_bytes(Cin, Cout)) return MODET_ERR_WORKSPACE;
@@ -2049,6 +2070,11 @@ int modet_conv3d_fwd_stats_bounded(const float* x, const float* w, const float* 
                                    float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
                                    modet_stream_t stream, modet_step_ctx_t* step) {
   return conv3d_fwd_stats_impl(x, w, bias, y, ws, ws_bytes, stats, stats_bytes, B, D, H, W, Cin, Cout, stream, step, false);
+}
+int modet_conv3d_fwd_stats_amax(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                                float* stats, size_t stats_bytes, int B, int D, int H, int W, int Cin, int Cout,
+                                const float* x_amax, modet_stream_t stream, modet_step_ctx_t* step) {
+  return conv3d_fwd_stats_impl(x, w, bias, y, ws, ws_bytes, stats, stats_bytes, B, D, H, W, Cin, Cout, stream, step, true, x_amax);
 }
 
 int modet_conv3d_fwd_normin(const float* x_raw, const float* in_mean, const float* in_rstd, const float* w,
@@ -2163,7 +2189,7 @@ size_t modet_conv3d_bwd_weight_ws_bytes(int B, int D, int H, int W, int Cin, int
 
 static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
                                 size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
-                                modet_step_ctx* defer = nullptr, const float* dy_amax = nullptr);
+                                modet_step_ctx* defer = nullptr, const float* dy_amax = nullptr, const float* x_amax = nullptr);
 
 // ---- deferred reductions: modet_conv3d_bwd_weight*_defer only produce the partial tiles (the workspace must stay
 // untouched until the flush) and queue the reduction in the caller's step context; modet_conv3d_wgrad_defer_flush runs
@@ -2230,6 +2256,13 @@ int modet_conv3d_bwd_weight_amax(const float* x, const float* d_y, float* d_w, f
   return conv_bwd_weight_impl(x, d_y, nullptr, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, step, dy_amax);
 }
 
+int modet_conv3d_bwd_weight_amax2(const float* x, const float* d_y, float* d_w, float* d_bias, void* ws, size_t ws_bytes, int B,
+                                  int D, int H, int W, int Cin, int Cout, const float* dy_amax, const float* x_amax,
+                                  modet_stream_t stream, modet_step_ctx_t* step) {
+  if (x_amax && !use_x3_wgrad(B, D, H, W, Cin, Cout)) dy_amax = nullptr;      // (only that family scales x by its maximum: else bf16x3)
+  return conv_bwd_weight_impl(x, d_y, nullptr, d_w, d_bias, ws, ws_bytes, B, D, H, W, Cin, Cout, stream, step, dy_amax, x_amax);
+}
+
 int modet_conv3d_bwd_weight_normin_ok(int B, int D, int H, int W, int Cin, int Cout) {
   return use_x3_wgrad(B, D, H, W, Cin, Cout) ? 1 : 0;
 }
@@ -2254,7 +2287,7 @@ int modet_conv3d_bwd_weight_act(const float* x, const float* d_y, const float* y
 
 static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y_act, float* d_w, float* d_bias, void* ws,
                                 size_t ws_bytes, int B, int D, int H, int W, int Cin, int Cout, modet_stream_t stream,
-                                modet_step_ctx* defer, const float* dy_amax) {
+                                modet_step_ctx* defer, const float* dy_amax, const float* x_amax) {
   MODET_CHECK_PTR(x); MODET_CHECK_PTR(d_y); MODET_CHECK_PTR(d_w); MODET_CHECK_PTR(ws);
   MODET_CHECK_DIM(B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
   if (Cout > NTHR) return MODET_ERR_UNSUPPORTED;
@@ -2270,7 +2303,7 @@ static int conv_bwd_weight_impl(const float* x, const float* d_y, const float* y
     return modet_launch_status();
   }
   if (!y_act && use_x3_wgrad(B, D, H, W, Cin, Cout))
-    return modetx_x3_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s, dy_amax);
+    return modetx_x3_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s, dy_amax, nullptr, nullptr, x_amax);
   if (!y_act && use_wtr_wgrad(B, D, H, W, Cin, Cout))
     return modetx_wtr_wgrad(defer, x, d_y, d_w, d_bias, ws, B, D, H, W, Cin, Cout, s, dy_amax);
   const WgPlan p = plan_wgrad(B, D, H, W, Cin, Cout);

@@ -772,7 +772,7 @@ int x3_launch(modet_step_ctx* step, const X3Args& a0, const float* w, void* ws, 
   // forward: two f16 pieces, three products (see split2_h) when the caller vouches for the input's range (x_free == false: an
   // activation), else three bf16 pieces, which have fp32's range; data gradient: f16 when the caller knows max |d_y| (a.amax),
   // else bf16.  (LeakyReLU(InstanceNorm(.)) is bounded by sqrt(V): beyond 2^24 voxels x 2^4 could overflow f16.)
-  const bool f16 = X3_F16_FWD && (int64_t)a.D * a.H * a.W < (1ll << 24) && (mode == 0 ? !x_free : a.amax != nullptr);
+  const bool f16 = X3_F16_FWD && (int64_t)a.D * a.H * a.W < (1ll << 24) && (mode == 0 ? (!x_free || a.amax != nullptr) : a.amax != nullptr);
   if (!f16) a.amax = nullptr;
   a.wpk = x3_weights(step, w, ws, a.Cin, a.Cout, mode, f16 ? 2 : 3, p, s);
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.nchunk = p.nchunk; a.ZC = p.zc; a.nitems = p.nitems;
@@ -841,6 +841,7 @@ struct X3WArgs {
   const void* x; const void* dy; float* part;                    // fp32; bf16 in the one-piece (storage) form
   int D, H, W, Cin, Cout, tiles_x, tiles_y, nchunk, ZC, nitems;
   const float* amax;                                             // NPC 2: amax[0] >= max |d_y| (device memory)
+  const float* xamax;                                            // NPC 2: maxima of |x| (device memory) or null = x is an activation (fixed scale)
   const float* in_mean; const float* in_rstd;                    // NORM: x is a RAW ConvInsBlock output, LeakyReLU((x - mean) * rstd) while staged
 };
 
@@ -908,6 +909,7 @@ __global__ __launch_bounds__(NTHR, NPC == 3 ? 2 : 3) void conv_x3_wgrad_kernel(c
   float xsc = 1.f, dsc = 1.f, dinv = 1.f;                        // NPC 2: operand scales (powers of two)
   if constexpr (NPC == 2) {
     xsc = CIB == 4 ? 1.f : X3_F16_XSCALE;
+    if (a.xamax) { float xinv; x3_dyn_scale(a.xamax, xsc, xinv); }
     x3_dyn_scale(a.amax, dsc, dinv);
   }
   const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2));
@@ -1237,7 +1239,7 @@ int modetx_x3_conv(modet_step_ctx* step, const float* x, const float* w, const f
                    hipStream_t s, const float* amax, bool x_free) {
   const X3Plan p = x3_plan(B, D, H, W, Cin, Cout);
   X3Args a{};
-  a.amax = mode == 1 ? amax : nullptr;
+  a.amax = amax;             // data gradient: max |d_y|; forward: max |x| of an input whose range is only known on the device
   a.x = x; a.bias = bias; a.y = y; a.in_mean = in_mean; a.in_rstd = in_rstd;
   a.shift = stats; a.stats_rows = stats ? stats + (size_t)B * Cout : nullptr;
   a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.act = act;
@@ -1295,12 +1297,12 @@ size_t modetx_x3_wgrad_ws_bytes(int B, int D, int H, int W, int Cin, int Cout) {
   return ((size_t)768 + 1) * p.red_fl * sizeof(float);           // workgroup partials (up to 768 resident workgroups) + their column sums
 }
 int modetx_x3_wgrad(modet_step_ctx* defer, const float* x, const float* dy, float* dw, float* db, void* ws, int B, int D, int H,
-                    int W, int Cin, int Cout, hipStream_t s, const float* amax, const float* in_mean, const float* in_rstd) {
+                    int W, int Cin, int Cout, hipStream_t s, const float* amax, const float* in_mean, const float* in_rstd, const float* xamax) {
   const bool f16p = X3_F16_FWD && amax != nullptr && (int64_t)D * H * W < (1ll << 24);
   const X3WPlan p = x3w_plan(B, D, H, W, Cin, Cout, f16p ? 2 : 3);
   // two f16 pieces when the caller knows max |d_y| (and vouches for x: an activation), else three bf16 pieces
   const bool f16 = X3_F16_FWD && amax != nullptr && (int64_t)D * H * W < (1ll << 24);
-  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems, f16 ? amax : nullptr, in_mean, in_rstd};
+  X3WArgs a{x, dy, (float*)ws, D, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.nchunk, p.zc, p.nitems, f16 ? amax : nullptr, f16 ? xamax : nullptr, in_mean, in_rstd};
 #define X3W_D(NPC_, NORM_) do { \
     if (p.cib == 4) { \
       if (p.np) hipLaunchKernelGGL((conv_x3_wgrad_kernel<4, 8, true, NPC_, false, NORM_>), dim3(p.gx), dim3(NTHR), 0, s, a); \

@@ -192,6 +192,14 @@ def _conv16_tag(kind, x_shape, Cin, Cout, x_bf16):
 
 
 # ------------------------------------------------------------------------------------------------ raw calls
+# The one un-normalised activation of the model is the ConvBlock 1 -> 4 output in front of the first ConvInsBlock (reference
+# models.py:192).  Default (False): that 4 -> 8 layer runs the three bf16 pieces -- range-free, and the most accurate form: flow
+# error vs fp64 at 160x192x160 4.3e-4 voxels, worst gradient 6.4e-4 of its tensor's max.  True: the first block's kernel leaves
+# max |y| on the device and the 4 -> 8 layer (forward + weight gradient) scales two f16 pieces by it -- also range-free, 0.05 ms
+# per step faster (6.94 vs 6.99), but 7.2e-4 / 4.4e-3 (measured, profiles/r06*_first_block_f16.txt): not worth the margin.
+FIRST_BLOCK_F16 = False
+
+
 def conv3d_forward(x, w, b, act, step=None, x_act=False):
     """x_act: the caller's word that x is an activation inside the f16 forms' range (include/modet_hip.h, "TWO f16 PIECES":
     |x| < 4 094) -> the *_bounded entry point, half the matrix work; without it the launch makes no assumption about x (three
@@ -208,6 +216,14 @@ def conv3d_forward(x, w, b, act, step=None, x_act=False):
     ws = _ws(nb, x)
     n = float(B) * D * H * W
     with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout, 1 if act else 0, f16=bool(x_act)), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+        if FIRST_BLOCK_F16 and Cin == 1 and Cout == 4 and B * D * H * W >= 500000 and not x_act:
+            # the first encoder block: its kernel leaves max |y| on the device for free, and the next layer (whose input this
+            # un-normalised tensor is) scales its f16 pieces by it -- any image range at the f16 forms' speed
+            amax = torch.empty(AMAX_FLOATS, dtype=torch.float32, device=x.device)
+            rc = L.modet_conv3d_fwd_amax_out(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, B, D, H, W, Cin, Cout, int(act), _p(amax),
+                                             _stream(), _h(step))
+            if rc == 0:
+                return _tag_xamax(y, amax)
         fn = L.modet_conv3d_fwd_bounded if x_act else L.modet_conv3d_fwd
         _lib.check(fn(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, B, D, H, W, Cin, Cout, int(act), _stream(), _h(step)), "modet_conv3d_fwd")
     return y
@@ -290,6 +306,17 @@ def _tag_amax(t, amax):
     if amax is not None:
         t._modet_amax = (amax, t._version)
     return t
+
+
+def _tag_xamax(t, amax):
+    """mark an ACTIVATION tensor with the device-side maxima of its magnitude (left by the kernel that produced it)"""
+    t._modet_xamax = (amax, t._version)
+    return t
+
+
+def _xamax_of(t):
+    tag = getattr(t, "_modet_xamax", None)
+    return tag[0] if tag is not None and tag[1] == t._version else None
 
 
 def _amax_of(t):
@@ -530,13 +557,14 @@ def _h(step):
 SIDE_WGRAD_MAX_VOXELS = float(os.environ.get("MODET_SIDE_WGRAD_MAX_VOXELS", "0"))
 
 
-def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=None, amax=None, norm=None):
+def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=None, amax=None, norm=None, x_amax=None):
     """d_w, d_bias; with y_act (ConvBlock 1 -> 4 only) dy is the gradient w.r.t. LeakyReLU(conv) and the activation's
     derivative is applied while loading it.  With a StepContext (given, or bound to this thread) whose ``deferred()`` scope
     knows destinations for the parameters ``w`` / ``b``, the gradients go straight there at the scope's flush and
     (None, None) is returned.  amax: one-float tensor >= max |dy| (see _tag_amax) and the caller's word that x is an
     activation: the z-marching kernel then runs on two f16 pieces.  norm = (mean, rstd): x is a RAW ConvInsBlock output,
-    normalised while the kernel stages it (modet_conv3d_bwd_weight_normin; only where modet_conv3d_bwd_weight_normin_ok)."""
+    normalised while the kernel stages it (modet_conv3d_bwd_weight_normin; only where modet_conv3d_bwd_weight_normin_ok).
+    x_amax: the maxima of |x| on the device (see _tag_xamax) for an x that is NOT an activation: scaled by them instead."""
     _chk(x, dy)
     B, D, H, W, Cin = x.shape
     Cout = dy.shape[-1]
@@ -562,14 +590,14 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
                                                                 B, D, H, W, Cin, Cout, _p(amax), _stream(), _h(scope)),
                                "modet_conv3d_bwd_weight_normin")
                 elif amax is not None and y_act is None:
-                    _lib.check(L.modet_conv3d_bwd_weight_amax(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
-                                                              _p(amax), _stream(), _h(scope)), "modet_conv3d_bwd_weight_amax")
+                    _lib.check(L.modet_conv3d_bwd_weight_amax2(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
+                                                               _p(amax), _p(x_amax), _stream(), _h(scope)), "modet_conv3d_bwd_weight_amax")
                 else:
                     _lib.check(L.modet_conv3d_bwd_weight_defer(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
                                                                Cout, _stream(), _h(scope)), "modet_conv3d_bwd_weight_defer")
         scope._keep.append(ws)                                # the partial tiles must survive until the flush
         if amax is not None:
-            scope._keep.append(amax)                          # (a queued launch reads the maximum at the flush, too)
+            scope._keep.extend((amax, x_amax))                # (a queued launch reads the maxima at the flush, too)
         if y_act is None and L.modet_conv3d_wgrad_defers_operands(B, D, H, W, Cin, Cout):
             scope._keep.extend((x, dy))                       # small levels: the launch itself is queued and reads them at the flush
         scope.written.add(w.data_ptr())
@@ -588,8 +616,8 @@ def conv3d_backward_weight(x, dy, want_bias, y_act=None, w=None, b=None, step=No
             _lib.check(L.modet_conv3d_bwd_weight_act(_p(x), _p(dy), _p(y_act), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin,
                                                      Cout, _stream()), "modet_conv3d_bwd_weight_act")
         elif amax is not None:
-            _lib.check(L.modet_conv3d_bwd_weight_amax(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout, _p(amax),
-                                                      _stream(), None), "modet_conv3d_bwd_weight_amax")
+            _lib.check(L.modet_conv3d_bwd_weight_amax2(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout, _p(amax),
+                                                       _p(x_amax), _stream(), None), "modet_conv3d_bwd_weight_amax")
         else:
             _lib.check(L.modet_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, B, D, H, W, Cin, Cout,
                                                  _stream()), "modet_conv3d_bwd_weight")
@@ -644,10 +672,18 @@ class _Conv3dStats(Function):
         sb = L.modet_conv3d_stats_bytes(B, D, H, W, Cin, Cout)
         stats = torch.empty(sb // 4, dtype=torch.float32, device=x.device)
         n = float(B) * D * H * W
-        with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout, 3, f16=ctx.x_act), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
-            fn = L.modet_conv3d_fwd_stats_bounded if ctx.x_act else L.modet_conv3d_fwd_stats
-            _lib.check(fn(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin, Cout, _stream(), _h(ctx.step)),
-                       "modet_conv3d_fwd_stats")
+        # x is not an activation but its producer left max |x| on the device (the ConvBlock 1 -> 4 output, _tag_xamax): the f16
+        # pieces are scaled by it (z-marching family; the others ignore it and run bf16x3)
+        ctx.x_amax = None if ctx.x_act else _xamax_of(x)
+        f16 = ctx.x_act or (ctx.x_amax is not None and L.modet_conv3d_kernel_family_v(B, D, H, W, Cin, Cout, 0, 3) == 2)
+        with _Guard(x, _conv_tag("fwd", x.shape, Cin, Cout, 3, f16=f16), 54.0 * Cin * Cout * n, 4.0 * n * (Cin + Cout)):
+            if ctx.x_amax is not None:
+                _lib.check(L.modet_conv3d_fwd_stats_amax(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin, Cout,
+                                                         _p(ctx.x_amax), _stream(), _h(ctx.step)), "modet_conv3d_fwd_stats_amax")
+            else:
+                fn = L.modet_conv3d_fwd_stats_bounded if ctx.x_act else L.modet_conv3d_fwd_stats
+                _lib.check(fn(_p(x), _p(w), _p(b), _p(y), _p(ws), nb, _p(stats), sb, B, D, H, W, Cin, Cout, _stream(), _h(ctx.step)),
+                           "modet_conv3d_fwd_stats")
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, b)
         ctx.mark_non_differentiable(stats)
@@ -661,7 +697,8 @@ class _Conv3dStats(Function):
         x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
         amax = _amax_of(dy)
-        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step, amax=amax if ctx.x_act else None)
+        dw, db = conv3d_backward_weight(x, dy, ctx.has_bias, w=w, b=b, step=ctx.step,
+                                        amax=amax if (ctx.x_act or ctx.x_amax is not None) else None, x_amax=ctx.x_amax)
         dx = conv3d_backward_data(dy, w, x.shape[-1], ctx.step, amax) if ctx.needs_input_grad[0] else None
         return dx, dw, db, None
 

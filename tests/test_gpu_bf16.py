@@ -310,7 +310,7 @@ def _loss_and_grads(m, mov, fix):
 def test_cfg5_shape_fp32_parity_vs_fp64_oracle(cfg5_oracle):
     """VERDICT r2 next-1a, fp32 half: at 160x192x224 with 2 pairs per GPU the HIP path holds the tolerances stated for every
     other size -- flow <= 2e-3 voxels against the fp64 oracle on BOTH samples, loss terms to 2e-5 / 2e-6 and every
-    parameter gradient <= 2e-2 of its tensor's max on sample 0 (the oracle's autograd ran there) -- and the batch-2
+    parameter gradient <= 5e-3 of its tensor's max on sample 0 (the oracle's autograd ran there) -- and the batch-2
     gradient is the mean of the two single-sample gradients (the loss is a mean over the batch; that linearity pins the
     batch-2 step the bench times without a second fp64 tape)."""
     from tests.util import note
@@ -329,13 +329,13 @@ def test_cfg5_shape_fp32_parity_vs_fp64_oracle(cfg5_oracle):
         if err / gmax > worst:
             worst, worst_name = err / gmax, n
     note("cfg5_f32[160x192x224].grad_worst_rel_to_max", worst)
-    assert worst <= 2e-2, f"worst gradient error {worst:.3e} of max|g| in {worst_name}"
+    assert worst <= 5e-3, f"worst gradient error {worst:.3e} of max|g| in {worst_name}"        # (measured 6.3e-4)
     s1, r1, fl1, g1 = _loss_and_grads(m, mov[1:], fix[1:])
     sb, rb, flb, gb = _loss_and_grads(m, mov, fix)
     e = float((flb.double().cpu() - o["flow"]).abs().max())
     note("cfg5_f32[160x192x224,B=2].flow_maxerr_voxels_vs_fp64", e)
     note("cfg5_f32[160x192x224,B=2].flow_absmax", float(o["flow"].abs().max()))
-    assert e <= 2e-3, e
+    assert e <= 1.3e-3, e         # (measured 7.4e-4 since round 6; round 5: 1.85e-3 against 2e-3.  VERDICT r5 item 2's bar: >= 35 % headroom)
     # a sample's flow does not depend on its batch (the fused statistics are summed in another grouping: fp32 noise only)
     indep = max(float((flb[:1] - fl0).abs().max()), float((flb[1:] - fl1).abs().max()))
     note("cfg5_f32[160x192x224,B=2].flow_maxdiff_batch2_vs_single", indep)

@@ -80,7 +80,7 @@ def test_modet_cu_through_the_operator_boundary(shape, B):
         if gmax < 1e-8:
             continue
         worst = max(worst, float((res[False][2][n].double().cpu() - ref).abs().max()) / gmax)
-    assert worst <= 2e-2, worst
+    assert worst <= 5e-3, worst                      # (measured 2.6e-4 / 1.8e-3; round 5's bound was 2e-2: VERDICT r5 item 2)
     _note(f"modet_cu_operator[{'x'.join(map(str, shape))},B={B}].flow_maxerr_vs_fp64", eo)
     _note(f"modet_cu_operator[{'x'.join(map(str, shape))},B={B}].flow_maxdiff_vs_fused", ef)
     _note(f"modet_cu_operator[{'x'.join(map(str, shape))},B={B}].grad_worst_rel_to_max", worst)
@@ -149,7 +149,7 @@ def test_train_step_golden():
             continue
         err = float(np.abs(got - ref.reshape(-1)).max())
         worst = max(worst, err / gmax)
-        assert err <= 2e-2 * gmax + 1e-7, f"grad {name}: max err {err:.3e} vs max|g| {gmax:.3e}"
+        assert err <= 5e-3 * gmax + 1e-7, f"grad {name}: max err {err:.3e} vs max|g| {gmax:.3e}"
     _note("train.grad_worst_rel_to_max", worst)
     # two optimizer steps (train.py:131-133)
     model2 = _model(shape, 1.0)
@@ -221,7 +221,7 @@ def test_forward_and_grads_with_an_unnormalised_image(gain):
         e = float((p_.grad.double().cpu() - g).abs().max() / g.abs().max())
         worst = max(worst, e)
     _note(f"unnormalised[x{gain:g}].worst_grad_relerr", worst)
-    assert worst < 2e-2, worst
+    assert worst < 5e-3, worst
 
 
 @pytest.mark.parametrize("shape,batch", [((16, 32, 16), 1), ((32, 32, 48), 3), ((16, 48, 80), 2)])
@@ -253,7 +253,7 @@ def test_forward_and_grads_vs_oracle_edge_shapes(shape, batch):
         scale = max(float(gref.abs().max()), 1e-7)
         worst = max(worst, float((g - gref).abs().max()) / scale if float(gref.abs().max()) > 1e-6 else 0.0)
     _note(f"edge_{tag}_grad_relerr", worst)
-    assert worst < 2e-2, worst
+    assert worst < 5e-3, worst
 
 
 def test_full_size_properties():
@@ -332,8 +332,11 @@ def test_full_size_dice_parity_vs_oracle(oracle_job):
     _note("fwd[160x192x160].flow_maxerr_voxels_hip_vs_fp64", e_hip)
     _note("fwd[160x192x160].flow_maxerr_voxels_cpu_fp32_vs_fp64", e_cpu32)
     _note("fwd[160x192x160].flow_rmserr_voxels_hip_vs_fp64", float((flow.double().cpu() - f64).pow(2).mean().sqrt()))
-    # the stated end-to-end tolerance: max |flow error| <= 2e-3 voxels, at the full size too
-    assert e_hip <= 2e-3, f"HIP flow deviates {e_hip:.2e} voxels from the fp64 oracle (fp32 CPU path: {e_cpu32:.2e})"
+    # the stated end-to-end tolerance is max |flow error| <= 2e-3 voxels.  Asserted here since round 6
+    # (VERDICT r5 item 2): 8e-4 -- measured 4.3e-4, >= 45 % headroom (round 5: 1.20e-3; the un-scaled f16 pieces of the 4 -> 8
+    # layer were the noise) -- and not noisier than twice the reference's own fp32 arithmetic on the same pair (4.7e-4)
+    assert e_hip <= 8e-4, f"HIP flow deviates {e_hip:.2e} voxels from the fp64 oracle (fp32 CPU path: {e_cpu32:.2e})"
+    assert e_hip <= 2.0 * e_cpu32, f"HIP flow error {e_hip:.2e} > 2 x the ATen-CPU fp32 path's {e_cpu32:.2e}"
     _note("dice[160x192x160].hip", dice_gpu)
     _note("dice[160x192x160].oracle", d_ref)
     _note("dice[160x192x160].flow_maxerr_voxels_fp32_vs_fp32", float((flow.cpu() - f_ref).abs().max()))
@@ -343,7 +346,7 @@ def test_full_size_dice_parity_vs_oracle(oracle_job):
 def test_full_size_gradient_parity_vs_oracle(oracle_job):
     """BASELINE size 160x192x160: loss and EVERY parameter gradient of one train step against the fp64 CPU oracle's
     autograd (ModeT/train.py:122-131 on ModeT/models.py:377-412), same tolerance as the small shapes: worst error per
-    tensor <= 2e-2 of that tensor's max |g| (biases in front of an InstanceNorm have an analytically zero gradient and
+    tensor <= 5e-3 of that tensor's max |g| (biases in front of an InstanceNorm have an analytically zero gradient and
     are compared absolutely)."""
     from smilecode_amd import losses, synth
     shape = (160, 192, 160)
@@ -370,7 +373,7 @@ def test_full_size_gradient_parity_vs_oracle(oracle_job):
             worst, worst_name = err / gmax, n
     _note("train[160x192x160].grad_worst_rel_to_max", worst)
     _note("train[160x192x160].loss_abs_err", abs(float(loss.detach()) - float(loss64)))
-    assert worst <= 2e-2, f"worst gradient error {worst:.3e} of max|g| in {worst_name}"
+    assert worst <= 5e-3, f"worst gradient error {worst:.3e} of max|g| in {worst_name}"        # (measured 6.4e-4)
 
 
 @pytest.mark.parametrize("overlap,graph", [("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")])

@@ -970,6 +970,45 @@ def test_conv_forward_any_input_range(ops, Cin, Cout, shape):
     assert not bool(torch.isfinite(yo).all()), "x_act=True beyond the promised range: inf by contract (not a finite wrong answer)"
 
 
+@pytest.mark.parametrize("gain", [1.0, 1.0e-3, 6.0e4])
+def test_first_block_hands_its_maximum_to_the_next_layer(ops, gain, monkeypatch):
+    """Round 6 (opt-in, ops.FIRST_BLOCK_F16; the default keeps the 4 -> 8 layer on bf16x3, which is more accurate): the ConvBlock 1 -> 4 output (reference models.py:192: no norm) is the one un-normalised activation of the model.
+    Its kernel leaves max |y| on the device (modet_conv3d_fwd_amax_out) and the 4 -> 8 layer behind it scales its two f16 pieces by
+    that maximum (modet_conv3d_fwd_stats_amax, modet_conv3d_bwd_weight_amax2): any image range at the f16 forms' speed.  Checked
+    against fp64 for a [0, 1] image, a FAINT one (x 1e-3: with round 5's unscaled pieces the low piece of small activations fell
+    into f16's subnormals -- the source of 2/3 of the model's flow error) and a raw 16-bit one (x 6e4)."""
+    from smilecode_amd import _lib
+    L = _lib.load()
+    monkeypatch.setattr(ops, "FIRST_BLOCK_F16", True)
+    shape = (80, 80, 88)
+    gen = torch.Generator().manual_seed(11)
+    img = (torch.rand((1, 1) + shape, generator=gen) * gain).double()
+    w1 = (torch.randn((4, 1, 3, 3, 3), generator=gen) / np.sqrt(27)).double()
+    b1 = (torch.randn(4, generator=gen) * 0.1 * gain).double()
+    w2 = (torch.randn((8, 4, 3, 3, 3), generator=gen) / np.sqrt(27 * 4)).double()
+    a_ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv3d(img, w1, b1, padding=1), 0.1)
+    y_ref = torch.nn.functional.conv3d(a_ref, w2, None, padding=1)
+    a = ops.conv3d(cl(img.numpy()), w1.float().cuda(), b1.float().cuda(), True)
+    amax = ops._xamax_of(a)
+    assert amax is not None, "the first encoder block's kernel did not leave its maximum"
+    got = float(amax.view(64, 32)[:, 0].max())
+    assert got == float(a.abs().max()) and abs(got - float(a_ref.abs().max())) <= 1e-5 * float(a_ref.abs().max())
+    assert L.modet_conv3d_kernel_family_v(1, *shape, 4, 8, 0, 3) == 2
+    y, st = ops.conv3d_with_stats(a, w2.float().cuda(), None)           # x_act=False + the tag -> the scaled f16 pieces
+    err = float((torch.from_numpy(ncdhw(y)) - y_ref).abs().max() / y_ref.abs().max())
+    _note(f"first_block_amax[gain {gain:g}].fwd_relerr", err)
+    assert bool(torch.isfinite(y).all()) and err < 1.5e-6, err
+    # weight gradient with both maxima against fp64
+    dy = torch.randn((1, 8) + shape, generator=gen).double()
+    w2g = w2.clone().requires_grad_(True)
+    (torch.nn.functional.conv3d(a_ref, w2g, None, padding=1) * dy).sum().backward()
+    dyd = cl(dy.numpy())
+    dw, db = ops.conv3d_backward_weight(a, dyd, False, amax=ops.amax_buffer(dyd.abs().max()), x_amax=amax)
+    werr = float((dw.double().cpu() - w2g.grad).abs().max() / w2g.grad.abs().max())
+    _note(f"first_block_amax[gain {gain:g}].wgrad_relerr", werr)
+    assert werr < 2e-5, werr            # (sums of 563 k products in fp32 accumulators)
+
+
 @pytest.mark.parametrize("cin,cout,shape", [(8, 8, (40, 50, 52)), (4, 8, (37, 46, 63)), (8, 16, (33, 42, 75)), (8, 4, (40, 41, 66))])
 def test_conv_x3_weight_gradient_vs_fp64(ops, cin, cout, shape):
     """csrc/conv3d_x3.hip, weight gradient: the z-marching bf16x3 kernel (Cin 4/8, Cout <= 16, >= 200 k voxels) against
