@@ -103,7 +103,9 @@ __global__ __launch_bounds__(256) void count_kernel(const float* __restrict__ fl
     if (keys[i] >= 0) atomicAdd(&counter[keys[i]], cnt[i]);
 }
 
-// exclusive scan of the tile counts (one workgroup): offsets[t], cursor[t] = offsets[t]
+// exclusive scan of the tile counts (one workgroup): offsets[t], cursor[t] = offsets[t].  (Folding it into pass A -- the last
+// workgroup to take a ticket scans -- was measured: the device-scope fence every workgroup needs in front of its ticket writes
+// back its XCD's L2, and the level-1 launch went from 0.61 to 1.03 ms.  Kernel boundaries are the cheap cross-XCD fence.)
 __global__ __launch_bounds__(1024) void scan_kernel(const unsigned* __restrict__ count, unsigned* __restrict__ offsets,
                                                     unsigned* __restrict__ cursor, int n) {
   __shared__ unsigned part[1024];
@@ -384,7 +386,8 @@ __device__ __forceinline__ void fx_entry(unsigned vb /* bits of the entry's max 
   fs = ldexpf(1.f, big ? 29 - e : FXBITS - 1 - E);
 }
 __device__ __forceinline__ unsigned long long fx_make(float x, int sh) {
-  const int xi = __float2int_rn(x);
+  int xi;                                                     // floor(x + 0.5) in ONE instruction (round-to-nearest-even is two: v_rndne + v_cvt)
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(xi) : "v"(x));
   return ((unsigned long long)(unsigned)(xi >> (32 - sh)) << 32) | (unsigned)(xi << sh);
 }
 
