@@ -41,6 +41,29 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+# kernels whose correctness beside another process depends on -fno-slp-vectorize (see FLAGS): source -> kernel name fragments.  After
+# every recompile of these sources the device assembly is scanned: a packed-fp32 instruction inside them fails the build (ADVICE r5:
+# the cure must not silently depend on a compiler heuristic -- a new compiler that forms v_pk_*_f32 by another pass would show here).
+NO_PACKED_FP32 = {"na.hip": ("na_bwd_kernel", "na_bwd_march_kernel"), "warp.hip": ("cwm_tail_bwd_kernel",)}
+
+
+def _check_no_packed_fp32(hipcc: str, src: str, kernels) -> None:
+    import re
+    asm = os.path.join(OBJ_DIR, os.path.basename(src).replace(".hip", ".s"))
+    r = subprocess.run([hipcc] + FLAGS + ["--cuda-device-only", "-S", src, "-o", asm], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc -S failed: %s\n%s" % (src, r.stderr))
+    cur, bad = None, {}
+    for line in open(asm):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+        elif cur and any(k in cur for k in kernels) and re.search(r"\bv_pk_(fma|mul|add)_f32\b", line):
+            bad[cur] = bad.get(cur, 0) + 1
+    if bad:
+        raise RuntimeError("packed-fp32 instructions in kernels that must be scalar (build.py FLAGS, DESIGN.md section 6): %s" % bad)
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -73,6 +96,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
             for done in ex.map(run, jobs):
                 if verbose:
                     print("[build] compiled", os.path.basename(done), flush=True)
+            rebuilt = {os.path.basename(j[-3]) for j in jobs}
+            checks = [(os.path.join(CSRC, k), v) for k, v in NO_PACKED_FP32.items() if k in rebuilt]
+            for _ in ex.map(lambda kv: _check_no_packed_fp32(hipcc, *kv), checks):
+                pass
+            if checks and verbose:
+                print("[build] no packed-fp32 code in", ", ".join(n for _, v in checks for n in v), flush=True)
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
         if verbose:
