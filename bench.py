@@ -72,7 +72,7 @@ def family(tag):
 # family name looked up as a symbol found the minor variant only).  Families not listed are their own symbol.
 FAMILY_SYMBOLS = {
     "warp_bwd_kernel": ("warp_bwd_kernel", "warp_bwd2_kernel"),
-    "warp_bwd_tiles": ("count_kernel", "scan_kernel", "fill_kernel", "fill_c3_kernel", "accumulate_kernel", "border_kernel"),
+    "warp_bwd_tiles": ("fill_kernel", "fill_c3_kernel", "accumulate_kernel", "border_kernel"),
     "warp_fwd": ("warp_fwd_kernel",),
     "instnorm_lrelu_bwd": ("in_bwd_apply_kernel", "in_partial_kernel", "in_rows_finalize_bwd_kernel"),
     "instnorm_lrelu_fwd": ("in_apply_kernel", "in_apply_pool_kernel", "in_rows_finalize_kernel", "in_finalize_kernel"),

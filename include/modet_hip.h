@@ -446,9 +446,10 @@ int modet_warp_bwd_det(const void* src, int src_bf16, const float* flow, const f
                        const float* d_flow_add, void* ws, size_t ws_bytes, int B, int D, int H, int W, int C, int add_flow,
                        modet_stream_t stream);
 /* The trilinear warp's backward WITHOUT global float atomics (csrc/warp_tile.hip; round 5 prototype, round 6 the DEFAULT path of
- * the feature warps): COUNT source voxels per 8^3 destination tile of their base corner -> scan -> FILL per-tile lists of payload
- * entries (voxel, flow, d_out; voxels whose d_out is all zero or whose corners all leave the volume are dropped; d_flow of every
- * voxel is produced here, the src corners gathered) -> ACCUMULATE one workgroup per (tile, 8 channels) into a 64-bit fixed-point
+ * the feature warps): FILL per-tile lists (a fixed segment of 1 536 entries per 8^3 destination tile of the base corner + one
+ * overflow list) of payload entries (voxel, flow, d_out; voxels whose d_out is all zero or whose corners all leave the volume are
+ * dropped; d_flow of every voxel is produced here, the src corners gathered) -> ACCUMULATE one workgroup per (tile, 8 channels)
+ * into a 64-bit fixed-point
  * LDS window (2^-40 of the power of two above max |d_out| per unit, as modet_warp_bwd_det) -> BORDER gather of the tile faces.  Equal to modet_warp_bwd
  * within fp32 rounding of the sums (the float-atomic ORDER is what differs there run to run; this one is bit-reproducible: integer
  * sums), every launch a kernel with fixed arguments (capturable).  d_src need NOT be zeroed; the workspace needs no preparation.

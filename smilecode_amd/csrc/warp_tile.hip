@@ -5,9 +5,11 @@
 //   Why tiles at all: the float-atomic scatter is bound by the L2 atomic unit (18 G sector-atomics/s on the model's flow, 3.3 x
 //   write amplification) and ds_add_f32 retires 0.33 lanes/clk/CU -- the INTEGER LDS atomics run 20-37 x faster (ds_add_u64
 //   6.9-12.3 lanes/clk/CU, profiles/r05y_lds_atomic_microbench.txt).
-//   A  COUNT: source voxels binned by the 8^3 DESTINATION tile of their base corner; per source workgroup (4 x 8 x 32 voxels) an
-//      LDS hash histogram, one global atomic per (workgroup, tile).  Reads the flow only.  -> exclusive scan (upper bounds).
-//   B  FILL: the same walk, now reading d_out as well: a voxel whose d_out is all zero (the step's d_out is, on the background:
+//   (A  COUNT + scan, rounds 5 - early 6: a first walk over the flow sized every tile's list exactly.  Gone: every tile now owns a
+//      FIXED segment of CAP = 1 536 entries (three times the 512 a tile receives from a non-folding flow) and the rare entries
+//      beyond it go to one overflow list that pass C filters by tile -- two launches and a 59 MB read less per call, six calls a step.)
+//   B  FILL: source voxels binned by the 8^3 DESTINATION tile of their base corner -- per source workgroup (4 x 8 x 32 voxels) an LDS
+//      hash histogram, one returning global atomic per (workgroup, tile) reserves the segment positions.  A voxel whose d_out is all zero (the step's d_out is, on the background:
 //      ~60 % of the voxels) or whose corners all leave the volume is DROPPED; the others get their d_flow here (the eight src
 //      corners gathered through L2: this pass is a stream with 24 waves per CU, the place where a gather's latency hides) and a
 //      PAYLOAD entry -- (voxel, flow, d_out) -- in their tile's list segment, so pass C never chases an index.  max |d_out| of
@@ -17,6 +19,7 @@
 //      than the fp32 product it converts), laid out [channel][cell] so that a wave's lanes (different entries, same channel)
 //      spread over the banks.  46 KB: three workgroups per CU.  The 8^3 owned cells leave as plain stores (d_src needs no zero
 //      fill), the 217 high-face cells go to a side buffer.  A tile without entries stores zeros and touches nothing else.
+//      Entries of the overflow list (usually none) are filtered by tile id and added the same way.
 //   D  BORDER: every owned cell on a low tile face adds the high-face cells of the (non-empty) neighbours.
 // Integer sums: the result does not depend on the order of the lists -> bit-reproducible run to run.  Every launch is a kernel
 // with fixed arguments (no memset node, no host read): capturable into a hipGraph.  Non-finite d_out: max |d_out| is taken on
@@ -67,62 +70,15 @@ __device__ __forceinline__ void block_origin(int blk, int bx_n, int by_n, int& x
   z0 = (blk / by_n) * SZ;
 }
 
-// ---- A: tile_count[tile] += voxels whose base corner lies in the tile (an upper bound of what pass B keeps)
-template <int SZ>
-__global__ __launch_bounds__(256) void count_kernel(const float* __restrict__ flow, unsigned* __restrict__ counter, const Geo g,
-                                                    int bx_n, int by_n) {
-  constexpr int HASH = 512 * SZ;
-  __shared__ int keys[HASH];
-  __shared__ unsigned cnt[HASH];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < HASH; i += 256) { keys[i] = -1; cnt[i] = 0; }
-  __syncthreads();
-  int x0, y0, z0;
-  block_origin<SZ>(blockIdx.x, bx_n, by_n, x0, y0, z0);
-  const int x = x0 + (tid & 31), y = y0 + (tid >> 5);
-  const int b = blockIdx.y;                                   // sample: its tiles are [b * ntiles, (b + 1) * ntiles)
-  flow += (int64_t)b * g.D * g.H * g.W * 3;
-  float f[SZ][3];
-  bool in[SZ];
-#pragma unroll
-  for (int k = 0; k < SZ; ++k) {
-    const int z = z0 + k;
-    in[k] = x < g.W && y < g.H && z < g.D;
-    const int64_t p = in[k] ? ((int64_t)z * g.H + y) * g.W + x : 0;
-    f[k][0] = flow[p * 3]; f[k][1] = flow[p * 3 + 1]; f[k][2] = flow[p * 3 + 2];
-  }
-#pragma unroll
-  for (int k = 0; k < SZ; ++k) {
-    Entry e;
-    if (!in[k] || !make_entry(f[k][0], f[k][1], f[k][2], z0 + k, y, x, g, e)) continue;
-    unsigned rank;
-    hash_insert<HASH>(keys, cnt, e.tile + b * g.ntiles, rank);
-  }
-  __syncthreads();
-  for (int i = tid; i < HASH; i += 256)
-    if (keys[i] >= 0) atomicAdd(&counter[keys[i]], cnt[i]);
-}
-
-// exclusive scan of the tile counts (one workgroup): offsets[t], cursor[t] = offsets[t].  (Folding it into pass A -- the last
-// workgroup to take a ticket scans -- was measured: the device-scope fence every workgroup needs in front of its ticket writes
-// back its XCD's L2, and the level-1 launch went from 0.61 to 1.03 ms.  Kernel boundaries are the cheap cross-XCD fence.)
-__global__ __launch_bounds__(1024) void scan_kernel(const unsigned* __restrict__ count, unsigned* __restrict__ offsets,
-                                                    unsigned* __restrict__ cursor, int n) {
-  __shared__ unsigned part[1024];
-  const int per = (n + 1023) / 1024, b = threadIdx.x * per;
-  unsigned s = 0;
-  for (int i = 0; i < per; ++i) if (b + i < n) s += count[b + i];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const unsigned v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
-  for (int i = 0; i < per; ++i)
-    if (b + i < n) { offsets[b + i] = run; cursor[b + i] = run; run += count[b + i]; }
+constexpr unsigned CAP = 1536;                                // entries of a tile's own list segment
+// where the entries go: tile t owns list[t * CAP ... ) (cursor[t] = entries handed out so far, may exceed CAP), the rest goes to
+// ovf_list[ovf_count++] with its tile id beside it
+struct Lists { float* list; unsigned* cursor; unsigned* ovf_count; unsigned* ovf_tile; float* ovf_list; };
+__device__ __forceinline__ float* entry_slot(const Lists& L, int tile, unsigned pos, int S) {
+  if (pos < CAP) return L.list + ((size_t)tile * CAP + pos) * S;
+  const unsigned oi = atomicAdd(L.ovf_count, 1u);
+  L.ovf_tile[oi] = (unsigned)tile;
+  return L.ovf_list + (size_t)oi * S;
 }
 
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
@@ -141,12 +97,12 @@ __device__ __forceinline__ void load8(const void* __restrict__ src, int64_t e, f
   }
 }
 
-// ---- B: cursor[tile] (initialised to the tile's list offset) hands out a segment per (workgroup, tile); kept voxels write their
+// ---- B: cursor[tile] (zero on entry) hands out positions per (workgroup, tile); kept voxels write their
 // payload entry [voxel id, flow x 3, d_out x C] there; d_flow of EVERY voxel of the block is written here (dropped: d_flow_add or 0)
 template <bool S16, int SZ>
 __global__ __launch_bounds__(256) void fill_kernel(const void* __restrict__ src, const float* __restrict__ flow,
-                                                   const float* __restrict__ dout, unsigned* __restrict__ cursor,
-                                                   unsigned* __restrict__ amax, float* __restrict__ list, float* __restrict__ dflow,
+                                                   const float* __restrict__ dout, const Lists L,
+                                                   unsigned* __restrict__ amax, float* __restrict__ dflow,
                                                    const float* __restrict__ dflow_add, const Geo g, int bx_n, int by_n, int dbg_arg) {
 #ifdef MODET_TUNING
   const int dbg = dbg_arg;
@@ -241,7 +197,7 @@ __global__ __launch_bounds__(256) void fill_kernel(const void* __restrict__ src,
   }
   __syncthreads();
   for (int i = tid; i < HASH; i += 256)
-    if (keys[i] >= 0) off[i] = atomicAdd(&cursor[keys[i]], cnt[i]);
+    if (keys[i] >= 0) off[i] = atomicAdd(&L.cursor[keys[i]], cnt[i]);
   for (int o = 32; o; o >>= 1) { const unsigned v = __shfl_xor(mbits, o, 64); mbits = v > mbits ? v : mbits; }
   if ((tid & 63) == 0) wmax[tid >> 6] = mbits;
   __syncthreads();
@@ -256,7 +212,7 @@ __global__ __launch_bounds__(256) void fill_kernel(const void* __restrict__ src,
     if (slot[k] < 0 || (dbg & 1)) continue;
     const int z = z0 + k;
     const int64_t p = ((int64_t)z * g.H + y) * g.W + x;
-    float* dst = list + (size_t)(off[slot[k]] + rank[k]) * S;
+    float* dst = entry_slot(L, keys[slot[k]], off[slot[k]] + rank[k], S);
     *reinterpret_cast<float4*>(dst) = make_float4(__int_as_float((z << 20) | (y << 10) | x), f[k][0], f[k][1], f[k][2]);   // (dimensions <= 1024)
     const float* dp = dout + p * C;                           // (read a moment ago: L1 / L2)
     for (int c0 = 0; c0 < C; c0 += 4) *reinterpret_cast<float4*>(dst + 4 + c0) = *reinterpret_cast<const float4*>(dp + c0);
@@ -268,8 +224,8 @@ __global__ __launch_bounds__(256) void fill_kernel(const void* __restrict__ src,
 // (S = 8 words); add_flow: out = warp(src, flow) + flow, so d_flow += d_out for EVERY voxel.
 template <int SZ>
 __global__ __launch_bounds__(256) void fill_c3_kernel(const float* __restrict__ src, const float* __restrict__ flow,
-                                                      const float* __restrict__ dout, unsigned* __restrict__ cursor,
-                                                      unsigned* __restrict__ amax, float* __restrict__ list, float* __restrict__ dflow,
+                                                      const float* __restrict__ dout, const Lists L,
+                                                      unsigned* __restrict__ amax, float* __restrict__ dflow,
                                                       const float* __restrict__ dflow_add, const Geo g, int bx_n, int by_n, int add_flow) {
   constexpr int HASH = 512 * SZ;
   __shared__ int keys[HASH];
@@ -340,7 +296,7 @@ __global__ __launch_bounds__(256) void fill_c3_kernel(const float* __restrict__ 
   }
   __syncthreads();
   for (int i = tid; i < HASH; i += 256)
-    if (keys[i] >= 0) off[i] = atomicAdd(&cursor[keys[i]], cnt[i]);
+    if (keys[i] >= 0) off[i] = atomicAdd(&L.cursor[keys[i]], cnt[i]);
   for (int o = 32; o; o >>= 1) { const unsigned v = __shfl_xor(mbits, o, 64); mbits = v > mbits ? v : mbits; }
   if ((tid & 63) == 0) wmax[tid >> 6] = mbits;
   __syncthreads();
@@ -353,7 +309,7 @@ __global__ __launch_bounds__(256) void fill_c3_kernel(const float* __restrict__ 
   for (int k = 0; k < SZ; ++k) {
     if (slot[k] < 0) continue;
     const int z = z0 + k;
-    float* dst = list + (size_t)(off[slot[k]] + rank[k]) * 8;
+    float* dst = entry_slot(L, keys[slot[k]], off[slot[k]] + rank[k], 8);
     *reinterpret_cast<float4*>(dst) = make_float4(__int_as_float((z << 20) | (y << 10) | x), f[k][0], f[k][1], f[k][2]);
     *reinterpret_cast<float4*>(dst + 4) = make_float4(gv[k][0], gv[k][1], gv[k][2], 0.f);
   }
@@ -457,8 +413,7 @@ __device__ __forceinline__ void acc_entry(const AccEntry& a, unsigned long long*
 }
 
 template <int NCH>      // channels of a work item: 8, or 3 (C == 3: payload entries of 8 words, d_src / side-buffer cells of 3 / 4 floats)
-__global__ __launch_bounds__(ACC) void accumulate_kernel(const float* __restrict__ list, const unsigned* __restrict__ offsets,
-                                                         const unsigned* __restrict__ cursor, const unsigned* __restrict__ amax,
+__global__ __launch_bounds__(ACC) void accumulate_kernel(const Lists L, const unsigned* __restrict__ amax,
                                                          float* __restrict__ dsrc, float* __restrict__ border, const Geo g) {
   __shared__ __attribute__((aligned(16))) unsigned long long win[CELLS * NCH + 1];
   const int tid = threadIdx.x;
@@ -469,7 +424,7 @@ __global__ __launch_bounds__(ACC) void accumulate_kernel(const float* __restrict
   const int ox = (t % g.tx) * TL; t /= g.tx;
   const int oy = (t % g.ty) * TL;
   const int oz = (t / g.ty) * TL;
-  const unsigned base = offsets[tile], n = cursor[tile] - base;
+  const unsigned handed = L.cursor[tile], n = handed < CAP ? handed : CAP;
   dsrc += (int64_t)b * g.D * g.H * g.W * C + c0;
   if (n == 0) {                                               // nothing lands here: zeros, and no side-buffer cells (pass D tests the count)
     const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
@@ -494,11 +449,20 @@ __global__ __launch_bounds__(ACC) void accumulate_kernel(const float* __restrict
     for (int i = tid; i < (CELLS * NCH + 1) / 2; i += ACC) w2[i] = (u64x2){0ull, 0ull};
   }
   __syncthreads();
-  const float* lp = list + (size_t)base * S;
+  const float* lp = L.list + (size_t)tile * CAP * S;
   for (unsigned i = tid; i < n; i += ACC) {
     AccEntry a;
     acc_load<NCH>(lp, i, n, S, c0, a);
     acc_entry<NCH>(a, win, g, oz, oy, ox, E, finite);
+  }
+  if (handed > CAP) {                                         // (uniform, rare: a folded tile) its entries beyond CAP are in the overflow list
+    const unsigned novf = *L.ovf_count;
+    for (unsigned i = tid; i < novf; i += ACC) {
+      if (L.ovf_tile[i] != (unsigned)tile) continue;
+      AccEntry a;
+      acc_load<NCH>(L.ovf_list, i, novf, S, c0, a);
+      acc_entry<NCH>(a, win, g, oz, oy, ox, E, finite);
+    }
   }
   __syncthreads();
   // flush: one cell (NCH channels) per thread and trip
@@ -527,7 +491,7 @@ __global__ __launch_bounds__(ACC) void accumulate_kernel(const float* __restrict
 // entries; every side-buffer cell is read exactly once, in a fixed order
 template <bool C3>
 __global__ __launch_bounds__(256) void border_kernel(float* __restrict__ dsrc, const float* __restrict__ border,
-                                                     const unsigned* __restrict__ offsets, const unsigned* __restrict__ cursor, const Geo g) {
+                                                     const unsigned* __restrict__ cursor, const Geo g) {
   const int tile = blockIdx.x;
   const int b = tile / g.ntiles;
   int t = tile - b * g.ntiles;
@@ -541,7 +505,7 @@ __global__ __launch_bounds__(256) void border_kernel(float* __restrict__ dsrc, c
     const int dz = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
     if ((dz && tz == 0) || (dy && ty == 0) || (dx && tx == 0)) continue;
     const int nt = b * g.ntiles + ((tz - dz) * g.ty + (ty - dy)) * g.tx + (tx - dx);
-    if (cursor[nt] != offsets[nt]) live |= 1u << m;
+    if (cursor[nt] != 0u) live |= 1u << m;
   }
   if (!live) return;
   dsrc += (int64_t)b * g.D * g.H * g.W * C;
@@ -577,20 +541,22 @@ __global__ __launch_bounds__(256) void border_kernel(float* __restrict__ dsrc, c
   }
 }
 
-struct Ws { unsigned *amax, *count, *offsets, *cursor; float *list, *border; size_t bytes; };
-// [amax 64][count nt][offsets nt][cursor nt] unsigned (padded to 16 bytes), [payload list B*D*H*W x (4 + C)] float,
-// [side buffer nt*217*C] float   (nt = tiles of all samples; C == 3: entries of 8 words, side-buffer cells of 4)
+struct Ws { unsigned *amax, *ovf_count, *cursor, *ovf_tile; float *list, *ovf_list, *border; size_t bytes; };
+// [amax 64][overflow count 4][cursor nt] unsigned -- zeroed by the launcher -- [overflow tile ids B*D*H*W] unsigned (padded to 16 bytes),
+// [tile lists nt x CAP x S] float, [overflow list B*D*H*W x S] float, [side buffer nt x 217 x BC] float
+// (nt = tiles of all samples; S = 4 + C words per entry, C == 3: S = 8 and side-buffer cells of BC = 4)
 __host__ bool ws_layout(void* ws, int B, int D, int H, int W, int C, Ws& w) {
   if (B < 1 || D < 1 || H < 1 || W < 1 || (C != 3 && (C < 8 || C % 8 != 0)) || D > 1024 || H > 1024 || W > 1024) return false;
   const size_t nt = (size_t)B * cdiv(D, 8) * cdiv(H, 8) * cdiv(W, 8);
   const size_t vox = (size_t)B * D * H * W;
   if (vox >= (1ull << 31) || nt >= (1u << 30)) return false;      // (32-bit entry indices)
-  const size_t hdr = (64 + 3 * nt + 3) / 4 * 4;
-  w.amax = (unsigned*)ws; w.count = w.amax + 64; w.offsets = w.count + nt; w.cursor = w.offsets + nt;
-  w.list = (float*)(w.amax + hdr);
+  const size_t hdr = (68 + nt + vox + 3) / 4 * 4;
   const size_t S = C == 3 ? 8 : 4 + C, BC = C == 3 ? 4 : C;
-  w.border = w.list + vox * S;
-  w.bytes = (hdr + vox * S + nt * NBORDER * BC) * 4 + 256;
+  w.amax = (unsigned*)ws; w.ovf_count = w.amax + 64; w.cursor = w.ovf_count + 4; w.ovf_tile = w.cursor + nt;
+  w.list = (float*)(w.amax + hdr);
+  w.ovf_list = w.list + nt * CAP * S;
+  w.border = w.ovf_list + vox * S;
+  w.bytes = (hdr + nt * CAP * S + vox * S + nt * NBORDER * BC) * 4 + 256;
   return true;
 }
 
@@ -612,30 +578,24 @@ int tiles_launch(const void* src, int src_bf16, const float* flow, const float* 
   const bool small = (int64_t)B * D * H * W < 400000;      // (levels 3-5; level 2, 614 k voxels, is faster with SZ = 4)
   const int bx_n = cdiv(W, SX), by_n = cdiv(H, SY), bz_n = cdiv(D, small ? 1 : 4);
   const dim3 bgrid(bx_n * by_n * bz_n, B);
-  modet_zero_async(w.amax, (size_t)(64 + nt) * 4, s);
-  if (small) hipLaunchKernelGGL(count_kernel<1>, bgrid, dim3(256), 0, s, flow, w.count, g, bx_n, by_n);
-  else hipLaunchKernelGGL(count_kernel<4>, bgrid, dim3(256), 0, s, flow, w.count, g, bx_n, by_n);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)w.count, w.offsets, w.cursor, nt);
+  const Lists L{w.list, w.cursor, w.ovf_count, w.ovf_tile, w.ovf_list};
+  modet_zero_async(w.amax, (size_t)(68 + nt) * 4, s);
   if (C == 3) {
-    if (small) hipLaunchKernelGGL(fill_c3_kernel<1>, bgrid, dim3(256), 0, s, (const float*)src, flow, d_out, w.cursor, w.amax, w.list, d_flow,
+    if (small) hipLaunchKernelGGL(fill_c3_kernel<1>, bgrid, dim3(256), 0, s, (const float*)src, flow, d_out, L, w.amax, d_flow,
                                   d_flow_add, g, bx_n, by_n, add_flow);
-    else hipLaunchKernelGGL(fill_c3_kernel<4>, bgrid, dim3(256), 0, s, (const float*)src, flow, d_out, w.cursor, w.amax, w.list, d_flow,
+    else hipLaunchKernelGGL(fill_c3_kernel<4>, bgrid, dim3(256), 0, s, (const float*)src, flow, d_out, L, w.amax, d_flow,
                             d_flow_add, g, bx_n, by_n, add_flow);
-    hipLaunchKernelGGL(accumulate_kernel<3>, dim3(nt, 1), dim3(ACC), 0, s, (const float*)w.list, (const unsigned*)w.offsets,
-                       (const unsigned*)w.cursor, (const unsigned*)w.amax, d_src, w.border, g);
-    hipLaunchKernelGGL(border_kernel<true>, dim3(nt, 1), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.offsets,
-                       (const unsigned*)w.cursor, g);
+    hipLaunchKernelGGL(accumulate_kernel<3>, dim3(nt, 1), dim3(ACC), 0, s, L, (const unsigned*)w.amax, d_src, w.border, g);
+    hipLaunchKernelGGL(border_kernel<true>, dim3(nt, 1), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.cursor, g);
     return modet_launch_status();
   }
-#define WT_FILL(S16, SZ) hipLaunchKernelGGL((fill_kernel<S16, SZ>), bgrid, dim3(256), 0, s, src, flow, d_out, w.cursor, w.amax, w.list, d_flow, \
+#define WT_FILL(S16, SZ) hipLaunchKernelGGL((fill_kernel<S16, SZ>), bgrid, dim3(256), 0, s, src, flow, d_out, L, w.amax, d_flow, \
                                             d_flow_add, g, bx_n, by_n, dbg)
   if (src_bf16) { if (small) WT_FILL(true, 1); else WT_FILL(true, 4); }
   else { if (small) WT_FILL(false, 1); else WT_FILL(false, 4); }
 #undef WT_FILL
-  hipLaunchKernelGGL(accumulate_kernel<8>, dim3(nt, C / 8), dim3(ACC), 0, s, (const float*)w.list, (const unsigned*)w.offsets,
-                     (const unsigned*)w.cursor, (const unsigned*)w.amax, d_src, w.border, g);
-  hipLaunchKernelGGL(border_kernel<false>, dim3(nt, C / 8), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.offsets,
-                     (const unsigned*)w.cursor, g);
+  hipLaunchKernelGGL(accumulate_kernel<8>, dim3(nt, C / 8), dim3(ACC), 0, s, L, (const unsigned*)w.amax, d_src, w.border, g);
+  hipLaunchKernelGGL(border_kernel<false>, dim3(nt, C / 8), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.cursor, g);
   return modet_launch_status();
 }
 }  // namespace
