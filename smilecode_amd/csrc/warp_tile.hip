@@ -1,26 +1,23 @@
 // The trilinear warp's backward WITHOUT global float atomics (SpatialTransformer backward, reference ModeT/models.py:55-67 ->
-// ATen grid_sampler_3d_backward scatters d_src with atomicAdd).  Round 5 built the destination-tile form as a prototype that broke
-// even in the step; round 6 rebuilt it around what the profile of that prototype said (every phase was waiting on a dependent
-// gather or on a half-empty workgroup, none on HBM or on the LDS atomics) and made it the default path of every feature warp.
-//   Why tiles at all: the float-atomic scatter is bound by the L2 atomic unit (18 G sector-atomics/s on the model's flow, 3.3 x
-//   write amplification) and ds_add_f32 retires 0.33 lanes/clk/CU -- the INTEGER LDS atomics run 20-37 x faster (ds_add_u64
-//   6.9-12.3 lanes/clk/CU, profiles/r05y_lds_atomic_microbench.txt).
-//   (A  COUNT + scan, rounds 5 - early 6: a first walk over the flow sized every tile's list exactly.  Gone: every tile now owns a
-//      FIXED segment of CAP = 1 536 entries (three times the 512 a tile receives from a non-folding flow) and the rare entries
-//      beyond it go to one overflow list that pass C filters by tile -- two launches and a 59 MB read less per call, six calls a step.)
-//   B  FILL: source voxels binned by the 8^3 DESTINATION tile of their base corner -- per source workgroup (4 x 8 x 32 voxels) an LDS
-//      hash histogram, one returning global atomic per (workgroup, tile) reserves the segment positions.  A voxel whose d_out is all zero (the step's d_out is, on the background:
-//      ~60 % of the voxels) or whose corners all leave the volume is DROPPED; the others get their d_flow here (the eight src
-//      corners gathered through L2: this pass is a stream with 24 waves per CU, the place where a gather's latency hides) and a
-//      PAYLOAD entry -- (voxel, flow, d_out) -- in their tile's list segment, so pass C never chases an index.  max |d_out| of
-//      the kept entries falls out of the same read (one atomicMax per workgroup over 64 slots).
-//   C  ACCUMULATE: one 512-lane workgroup per (tile, group of 8 channels): the tile's payload, read as a contiguous stream, goes
-//      into a 9^3 x 8 window of 64-bit FIXED-POINT sums in LDS (2^-40 of the power of two above max |d_out| per unit: finer
-//      than the fp32 product it converts), laid out [channel][cell] so that a wave's lanes (different entries, same channel)
-//      spread over the banks.  46 KB: three workgroups per CU.  The 8^3 owned cells leave as plain stores (d_src needs no zero
-//      fill), the 217 high-face cells go to a side buffer.  A tile without entries stores zeros and touches nothing else.
-//      Entries of the overflow list (usually none) are filtered by tile id and added the same way.
-//   D  BORDER: every owned cell on a low tile face adds the high-face cells of the (non-empty) neighbours.
+// ATen grid_sampler_3d_backward scatters d_src with atomicAdd).  Default path of every warp of the model whose backward scatters
+// (feature warps: C % 8 == 0, fp32 or bf16 src; the unbounded flow compositions: C == 3 with add_flow) since round 6; design,
+// measurements and the rejected variants: DESIGN.md section 4.2, profiles/r06b_warp_tile_experiments.txt.
+//   Why tiles: the float-atomic scatter is bound by the L2 atomic unit (18 G sector-atomics/s on the model's flow, 3.3 x write
+//   amplification) and is not reproducible; ds_add_f32 retires 0.33 lanes/clk/CU, but the INTEGER LDS atomics run 20-37 x faster
+//   (profiles/r05y_lds_atomic_microbench.txt).
+//   FILL        source voxels are binned by the 8^3 DESTINATION tile of their base corner: per source workgroup (SZ x 8 x 32 voxels)
+//               an LDS hash histogram, one returning global atomic per (workgroup, tile) reserves positions in the tile's list.
+//               Every tile owns a FIXED segment of CAP entries (three times what a non-folding flow sends it); entries beyond it
+//               go to one overflow list.  A voxel whose d_out is all zero or whose corners all leave the volume is dropped; the
+//               others get a PAYLOAD entry -- (voxel, flow, d_out) -- so the next pass chases no index, and their d_flow (the eight
+//               src corners gathered through L2: this pass is a stream with >= 20 waves per CU, where a gather's latency hides).
+//               max |d_out| of the kept entries falls out of the same read (one atomicMax per workgroup over 64 slots).
+//   ACCUMULATE  one 512-lane workgroup per (tile, group of 8 channels): the tile's payload, a contiguous stream, goes into a
+//               9^3 x 8 window of 64-bit FIXED-POINT sums in LDS (2^-40 of the power of two above max |d_out| per unit, scaled
+//               per entry), laid out [channel][cell].  46 KB: three workgroups per CU.  The 8^3 owned cells leave as plain stores
+//               (d_src needs no zero fill), the 217 high-face cells go to a side buffer.  A tile without entries stores zeros.
+//               Entries of the overflow list (usually none) are filtered by tile id and added the same way.
+//   BORDER      every owned cell on a low tile face adds the high-face cells of the (non-empty) neighbours, in a fixed order.
 // Integer sums: the result does not depend on the order of the lists -> bit-reproducible run to run.  Every launch is a kernel
 // with fixed arguments (no memset node, no host read): capturable into a hipGraph.  Non-finite d_out: max |d_out| is taken on
 // bit patterns (NaN orders above inf), and a non-finite maximum poisons d_src with NaN instead of converting garbage.
@@ -28,8 +25,8 @@
 
 namespace {
 constexpr int TL = 8, WN = 9, CELLS = WN * WN * WN, NBORDER = CELLS - TL * TL * TL;      // 729 window cells, 217 on the high faces
-constexpr int SY = 8, SX = 32;                                // source block of passes A / B: SZ x 8 x 32 voxels, SZ per thread; SZ = 4, or
-                                                              // 1 for the small volumes (levels 2-5: 4 x more workgroups -- their passes are latency-, not bandwidth-bound)
+constexpr int SY = 8, SX = 32;                                // source block of the fill pass: SZ x 8 x 32 voxels, SZ per thread; SZ = 4, or
+                                                              // 1 below 400 k voxels (levels 3-5: 4 x more workgroups -- latency-, not bandwidth-bound there)
 // a source block holds SZ x 256 voxels, so at most that many distinct tiles: with twice the slots (HASH = 512 SZ) linear probing
 // always ends on a free slot or on the key (round 5's 256 slots for 1024 voxels overflowed silently on flows rougher than ~12
 // voxels: ADVICE r5)
@@ -38,7 +35,7 @@ constexpr int FXBITS = 40;
 struct Geo { int D, H, W, C, tz, ty, tx, ntiles, B, dbg; };      // ntiles = tiles per sample; dbg: tuning builds only
 
 struct Entry { int tile, bz, by, bx; float fz, fy, fx; };
-// the ONE place that decides a voxel's base cell and tile: passes A, B and C must agree bit for bit
+// the ONE place that decides a voxel's base cell and tile: the fill and the accumulate pass must agree bit for bit
 __device__ __forceinline__ bool make_entry(float f0, float f1, float f2, int z, int y, int x, const Geo& g, Entry& e) {
   const float pz = (float)z + f0, py = (float)y + f1, px = (float)x + f2;
   const float flz = floorf(pz), fly = floorf(py), flx = floorf(px);
@@ -370,7 +367,7 @@ __device__ __forceinline__ void acc_load(const float* __restrict__ lp, unsigned 
   a.hd = *reinterpret_cast<const float4*>(ep);
   a.ga = *reinterpret_cast<const float4*>(ep + 4 + c0);
   if constexpr (NCH == 8) a.gb = *reinterpret_cast<const float4*>(ep + 8 + c0);
-  else a.gb = make_float4(0.f, 0.f, 0.f, 0.f);
+  else a.gb = make_float4(0.f, 0.f, 0.f, 0.f);              // (NCH 4: a half group; NCH 3: three channels + a zero)
 }
 template <int NCH>
 __device__ __forceinline__ void acc_entry(const AccEntry& a, unsigned long long* win, const Geo& g, int oz, int oy, int ox, int E, bool finite) {
@@ -412,13 +409,15 @@ __device__ __forceinline__ void acc_entry(const AccEntry& a, unsigned long long*
   }
 }
 
-template <int NCH>      // channels of a work item: 8, or 3 (C == 3: payload entries of 8 words, d_src / side-buffer cells of 3 / 4 floats)
-__global__ __launch_bounds__(ACC) void accumulate_kernel(const Lists L, const unsigned* __restrict__ amax,
-                                                         float* __restrict__ dsrc, float* __restrict__ border, const Geo g) {
+// NCH = channels of a work item: 8, 4 (a half group: 23 KB of LDS, six 256-lane workgroups per CU) or 3 (C == 3: payload entries of
+// 8 words, d_src / side-buffer cells of 3 / 4 floats); NT = lanes of the workgroup
+template <int NCH, int NT>
+__global__ __launch_bounds__(NT) void accumulate_kernel(const Lists L, const unsigned* __restrict__ amax,
+                                                        float* __restrict__ dsrc, float* __restrict__ border, const Geo g) {
   __shared__ __attribute__((aligned(16))) unsigned long long win[CELLS * NCH + 1];
   const int tid = threadIdx.x;
-  const int C = g.C, S = NCH == 8 ? 4 + C : 8, BC = NCH == 8 ? C : 4;
-  const int tile = blockIdx.x, c0 = blockIdx.y * 8;           // tile: over all samples
+  const int C = g.C, S = NCH == 3 ? 8 : 4 + C, BC = NCH == 3 ? 4 : C;
+  const int tile = blockIdx.x, c0 = blockIdx.y * (NCH == 3 ? 8 : NCH);           // tile: over all samples
   const int b = tile / g.ntiles;
   int t = tile - b * g.ntiles;
   const int ox = (t % g.tx) * TL; t /= g.tx;
@@ -426,16 +425,17 @@ __global__ __launch_bounds__(ACC) void accumulate_kernel(const Lists L, const un
   const int oz = (t / g.ty) * TL;
   const unsigned handed = L.cursor[tile], n = handed < CAP ? handed : CAP;
   dsrc += (int64_t)b * g.D * g.H * g.W * C + c0;
-  if (n == 0) {                                               // nothing lands here: zeros, and no side-buffer cells (pass D tests the count)
-    const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
-    const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
-    if (gz < g.D && gy < g.H && gx < g.W) {
-      float* dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C;
-      if constexpr (NCH == 8) {
-        *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f;
+  if (n == 0) {                                               // nothing lands here: zeros, and no side-buffer cells (the border pass tests the count)
+    for (int cell = tid; cell < TL * TL * TL; cell += NT) {
+      const int lx = cell & 7, ly = (cell >> 3) & 7, lz = cell >> 6;
+      const int gz = oz + lz, gy = oy + ly, gx = ox + lx;
+      if (gz < g.D && gy < g.H && gx < g.W) {
+        float* dst = dsrc + (((int64_t)gz * g.H + gy) * g.W + gx) * C;
+        if constexpr (NCH == 3) { dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; }
+        else {
+          *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+          if constexpr (NCH == 8) *reinterpret_cast<float4*>(dst + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
     }
     return;
@@ -446,18 +446,18 @@ __global__ __launch_bounds__(ACC) void accumulate_kernel(const Lists L, const un
   {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     u64x2* w2 = reinterpret_cast<u64x2*>(win);
-    for (int i = tid; i < (CELLS * NCH + 1) / 2; i += ACC) w2[i] = (u64x2){0ull, 0ull};
+    for (int i = tid; i < (CELLS * NCH + 1) / 2; i += NT) w2[i] = (u64x2){0ull, 0ull};
   }
   __syncthreads();
   const float* lp = L.list + (size_t)tile * CAP * S;
-  for (unsigned i = tid; i < n; i += ACC) {
+  for (unsigned i = tid; i < n; i += NT) {
     AccEntry a;
     acc_load<NCH>(lp, i, n, S, c0, a);
     acc_entry<NCH>(a, win, g, oz, oy, ox, E, finite);
   }
   if (handed > CAP) {                                         // (uniform, rare: a folded tile) its entries beyond CAP are in the overflow list
     const unsigned novf = *L.ovf_count;
-    for (unsigned i = tid; i < novf; i += ACC) {
+    for (unsigned i = tid; i < novf; i += NT) {
       if (L.ovf_tile[i] != (unsigned)tile) continue;
       AccEntry a;
       acc_load<NCH>(L.ovf_list, i, novf, S, c0, a);
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(ACC) void accumulate_kernel(const Lists L, const un
   __syncthreads();
   // flush: one cell (NCH channels) per thread and trip
   const float poison = finite ? 0.f : __uint_as_float(0x7fc00000u);
-  for (int cell = tid; cell < CELLS; cell += ACC) {
+  for (int cell = tid; cell < CELLS; cell += NT) {
     const int lx = cell % WN, lr = cell / WN, ly = lr % WN, lz = lr / WN;
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(ACC) void accumulate_kernel(const Lists L, const un
     } else {
       dst = border + ((int64_t)tile * NBORDER + border_index(lz, ly, lx)) * BC + c0;
     }
-    if (NCH == 8 || !owned) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    if (NCH != 3 || !owned) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
     else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; }
     if constexpr (NCH == 8) *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
   }
@@ -585,7 +585,7 @@ int tiles_launch(const void* src, int src_bf16, const float* flow, const float* 
                                   d_flow_add, g, bx_n, by_n, add_flow);
     else hipLaunchKernelGGL(fill_c3_kernel<4>, bgrid, dim3(256), 0, s, (const float*)src, flow, d_out, L, w.amax, d_flow,
                             d_flow_add, g, bx_n, by_n, add_flow);
-    hipLaunchKernelGGL(accumulate_kernel<3>, dim3(nt, 1), dim3(ACC), 0, s, L, (const unsigned*)w.amax, d_src, w.border, g);
+    hipLaunchKernelGGL((accumulate_kernel<3, ACC>), dim3(nt, 1), dim3(ACC), 0, s, L, (const unsigned*)w.amax, d_src, w.border, g);
     hipLaunchKernelGGL(border_kernel<true>, dim3(nt, 1), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.cursor, g);
     return modet_launch_status();
   }
@@ -594,7 +594,14 @@ int tiles_launch(const void* src, int src_bf16, const float* flow, const float* 
   if (src_bf16) { if (small) WT_FILL(true, 1); else WT_FILL(true, 4); }
   else { if (small) WT_FILL(false, 1); else WT_FILL(false, 4); }
 #undef WT_FILL
-  hipLaunchKernelGGL(accumulate_kernel<8>, dim3(nt, C / 8), dim3(ACC), 0, s, L, (const unsigned*)w.amax, d_src, w.border, g);
+  int half = 0;
+#ifdef MODET_TUNING
+  if (const char* e = getenv("WT_NCH4")) half = atoi(e);
+#endif
+  if (half == 1) hipLaunchKernelGGL((accumulate_kernel<4, 256>), dim3(nt, C / 4), dim3(256), 0, s, L, (const unsigned*)w.amax, d_src, w.border, g);
+  else if (half == 2) hipLaunchKernelGGL((accumulate_kernel<4, 512>), dim3(nt, C / 4), dim3(512), 0, s, L, (const unsigned*)w.amax, d_src, w.border, g);
+  else if (half == 3) hipLaunchKernelGGL((accumulate_kernel<8, 256>), dim3(nt, C / 8), dim3(256), 0, s, L, (const unsigned*)w.amax, d_src, w.border, g);
+  else hipLaunchKernelGGL((accumulate_kernel<8, ACC>), dim3(nt, C / 8), dim3(ACC), 0, s, L, (const unsigned*)w.amax, d_src, w.border, g);
   hipLaunchKernelGGL(border_kernel<false>, dim3(nt, C / 8), dim3(256), 0, s, d_src, (const float*)w.border, (const unsigned*)w.cursor, g);
   return modet_launch_status();
 }

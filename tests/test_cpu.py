@@ -428,6 +428,34 @@ def test_staged_backward_with_bucket_allreduce_gloo_world2():
     assert np.array_equal(res[0][2], res[1][2]), "ranks must end with identical averaged gradients"
 
 
+def test_bench_roofline_traffic_sums_the_family_symbols():
+    """roofline.traffic looked the FAMILY name up as a kernel symbol and quoted the minor variant's bytes (119 MB
+    against 400 MB per launch of the real kernel, below the algorithmic bytes).  bench.family_traffic sums (bytes per launch x launches
+    per step) over every symbol a family runs; add_traffic emits per-launch / per-step / ratio fields and flags a ratio below one."""
+    sys.path.insert(0, ROOT)
+    import bench
+    pj = {"families": {"warp_bwd2_kernel": {"hbm_bytes_per_launch_corrected": 400e6, "launches_per_step": 4.0},
+                       "warp_bwd_kernel": {"hbm_bytes_per_launch_corrected": 120e6, "launches_per_step": 3.0},
+                       "fill_kernel": {"hbm_bytes_per_launch_corrected": 300e6, "launches_per_step": 4.0},
+                       "accumulate_kernel": {"hbm_bytes_per_launch_corrected": 100e6, "launches_per_step": 6.0},
+                       "adam_kernel": {"hbm_bytes_per_launch_corrected": 1e6, "launches_per_step": None}}}
+    per_step, per_launch = bench.family_traffic(pj, "warp_bwd_kernel", 7.0)
+    assert per_step == 4 * 400e6 + 3 * 120e6 and abs(per_launch - per_step / 7.0) < 1.0
+    assert bench.family_traffic(pj, "warp_bwd_tiles", 6.0)[0] == 4 * 300e6 + 6 * 100e6           # (symbols absent from the profile add nothing)
+    assert bench.family_traffic(pj, "no_such_family", 1.0) == (None, None)
+    assert bench.family_traffic(pj, "adam_kernel", 1.0) == (None, None)                          # no per-step count in the profile
+    r = {}
+    bench.add_traffic(r, pj, "warp_bwd_kernel", 7.0, 1.1e9)
+    assert r["traffic_per_step"] == 1.96e9 and abs(r["traffic_over_algorithmic"] - 1.96 / 1.1) < 1e-9 and "traffic_note" not in r
+    r = {}
+    bench.add_traffic(r, pj, "warp_bwd_kernel", 7.0, 5e9)
+    assert r["traffic_over_algorithmic"] < 1.0 and "traffic_note" in r
+    r = {}
+    bench.add_traffic(r, None, "warp_bwd_kernel", 7.0, 1.1e9)
+    assert r["traffic"] is None and r["traffic_per_step"] is None and r["algorithmic_bytes_per_step"] == 1.1e9
+    assert bench.family("warp_bwd_tiles[C8]") == "warp_bwd_tiles" and bench.family("warp_bwd[C1]") == "warp_bwd_kernel"
+
+
 def test_bench_self_launches_n_ranks_and_refuses_missing_gpus():
     """`python bench.py --gpus N` (no torchrun env) must itself start N ranks and prove it in the JSON line; with fewer
     than N GPUs it must fail loudly instead of silently running world=1.  Exercised on gloo with the
