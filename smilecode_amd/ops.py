@@ -1455,7 +1455,10 @@ WARP_TILE_MIN_VOXELS = 0
 
 
 def _warp_bwd_tag(src, dsrc, add_flow, flow_bound):
-    """launch tag of a warp backward = the kernels that run (bench.py maps tags to kernel families)"""
+    """launch tag of a warp backward = the kernels that run (bench.py maps tags to kernel families); like _conv_tag only
+    evaluated while a timer is installed"""
+    if _TIMER is None:
+        return None
     B, D, H, W, C = src.shape
     if C == 3 and flow_bound:
         return "warp_bwd_gather3[C3]"
